@@ -1,0 +1,226 @@
+"""Parameter inventory + seeded synthetic weights for the DeeR-VLA hot path.
+
+Keys are the *reference's* state-dict names (SURVEY §8b "Weight/ckpt format"), so the same dict
+layout is what a real OpenFlamingo ``.pt`` + DeeR ``.pth`` pair provides:
+
+* ``vision_encoder.visual.*``  - open_clip ``VisionTransformer`` (EXTERNAL)
+* ``perceiver.*``              - ``PerceiverResampler`` (open_flamingo/src/helpers.py:68-105)
+* ``lang_encoder.transformer.wte.weight`` and
+  ``lang_encoder.transformer.blocks.N.decoder_layer.*``            - MPT ``GPTBlock`` (EXTERNAL, App. B.1)
+  ``lang_encoder.transformer.blocks.N.gated_cross_attn_layer.*``   - helpers.py:236-258
+* ``extra_exit.*`` - ``DeterministicDecoder`` (robot_flamingo/models/action_head.py:408-497)
+
+There is no network and no checkpoint in the build container, so benchmarks and parity tests use
+``make_synthetic_state`` (seeded N(0, 0.02^2) weights, LN gamma 1, gates 0.5,
+Perceiver latents N(0,1)).
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import torch
+
+from .config import DeerConfig
+
+# kinds: how a tensor is initialised and whether the engine stores it as bf16
+LINEAR, EMBED, LN_W, LN_B, BIAS, GATE, LATENT, POS = "linear", "embed", "ln_w", "ln_b", "bias", "gate", "latent", "pos"
+BF16_KINDS = (LINEAR, EMBED)     # GEMM/GEMV operands live in HBM as bf16; everything else stays fp32
+
+
+def mlp_layer_indices(n_hidden: int) -> Tuple[list, list, int]:
+    """Indices of Linear / LayerNorm modules inside ``MLPTanhHead.mlp`` for dropout_mode='layerwise'
+    (action_head.py:86-116): [Drop, (Lin, LN|Id, ReLU, Drop) * n_hidden, Lin, Tanh]."""
+    lin = [1 + 4 * i for i in range(n_hidden)]
+    ln = [2 + 4 * i for i in range(n_hidden)]
+    out = 1 + 4 * n_hidden
+    return lin, ln, out
+
+
+def param_shapes(cfg: DeerConfig) -> "OrderedDict[str, Tuple[tuple, str]]":
+    """name -> (shape, kind) for every tensor the hot path reads."""
+    P: "OrderedDict[str, Tuple[tuple, str]]" = OrderedDict()
+    W = cfg.vit_width
+    v = "vision_encoder.visual."
+    P[v + "conv1.weight"] = ((W, 3, cfg.patch_size, cfg.patch_size), LINEAR)
+    P[v + "class_embedding"] = ((W,), POS)
+    P[v + "positional_embedding"] = ((cfg.vit_tokens, W), POS)
+    P[v + "ln_pre.weight"] = ((W,), LN_W)
+    P[v + "ln_pre.bias"] = ((W,), LN_B)
+    for l in range(cfg.vit_layers):
+        b = f"{v}transformer.resblocks.{l}."
+        P[b + "ln_1.weight"] = ((W,), LN_W)
+        P[b + "ln_1.bias"] = ((W,), LN_B)
+        P[b + "attn.in_proj_weight"] = ((3 * W, W), LINEAR)
+        P[b + "attn.in_proj_bias"] = ((3 * W,), BIAS)
+        P[b + "attn.out_proj.weight"] = ((W, W), LINEAR)
+        P[b + "attn.out_proj.bias"] = ((W,), BIAS)
+        P[b + "ln_2.weight"] = ((W,), LN_W)
+        P[b + "ln_2.bias"] = ((W,), LN_B)
+        P[b + "mlp.c_fc.weight"] = ((cfg.vit_mlp, W), LINEAR)
+        P[b + "mlp.c_fc.bias"] = ((cfg.vit_mlp,), BIAS)
+        P[b + "mlp.c_proj.weight"] = ((W, cfg.vit_mlp), LINEAR)
+        P[b + "mlp.c_proj.bias"] = ((W,), BIAS)
+
+    inner = cfg.perc_heads * cfg.perc_dim_head
+    P["perceiver.latents"] = ((cfg.perc_latents, W), LATENT)
+    for l in range(cfg.perc_depth):
+        a = f"perceiver.layers.{l}.0."
+        P[a + "norm_media.weight"] = ((W,), LN_W)
+        P[a + "norm_media.bias"] = ((W,), LN_B)
+        P[a + "norm_latents.weight"] = ((W,), LN_W)
+        P[a + "norm_latents.bias"] = ((W,), LN_B)
+        P[a + "to_q.weight"] = ((inner, W), LINEAR)
+        P[a + "to_kv.weight"] = ((2 * inner, W), LINEAR)
+        P[a + "to_out.weight"] = ((W, inner), LINEAR)
+        f = f"perceiver.layers.{l}.1."
+        P[f + "0.weight"] = ((W,), LN_W)
+        P[f + "0.bias"] = ((W,), LN_B)
+        P[f + "1.weight"] = ((cfg.perc_ff_mult * W, W), LINEAR)
+        P[f + "3.weight"] = ((W, cfg.perc_ff_mult * W), LINEAR)
+    P["perceiver.norm.weight"] = ((W,), LN_W)
+    P["perceiver.norm.bias"] = ((W,), LN_B)
+
+    d = cfg.d_model
+    xin = cfg.xattn_heads * cfg.xattn_dim_head
+    P["lang_encoder.transformer.wte.weight"] = ((cfg.vocab_size, d), EMBED)
+    for n in range(cfg.n_layers):
+        blk = f"lang_encoder.transformer.blocks.{n}."
+        if cfg.has_xattn(n):
+            x = blk + "gated_cross_attn_layer."
+            P[x + "attn.norm.weight"] = ((d,), LN_W)
+            P[x + "attn.norm.bias"] = ((d,), LN_B)
+            P[x + "attn.to_q.weight"] = ((xin, d), LINEAR)
+            P[x + "attn.to_kv.weight"] = ((2 * xin, W), LINEAR)
+            P[x + "attn.to_out.weight"] = ((d, xin), LINEAR)
+            P[x + "attn_gate"] = ((1,), GATE)
+            P[x + "ff.0.weight"] = ((d,), LN_W)
+            P[x + "ff.0.bias"] = ((d,), LN_B)
+            P[x + "ff.1.weight"] = ((cfg.xattn_ff_mult * d, d), LINEAR)
+            P[x + "ff.3.weight"] = ((d, cfg.xattn_ff_mult * d), LINEAR)
+            P[x + "ff_gate"] = ((1,), GATE)
+        m = blk + "decoder_layer."
+        if cfg.llm_name == "mpt_9b":
+            # MPT-7B names: norm_1 / ffn.up_proj / ffn.down_proj, no qk-LN
+            P[m + "norm_1.weight"] = ((d,), LN_W)
+            P[m + "attn.Wqkv.weight"] = ((3 * d, d), LINEAR)
+            P[m + "attn.out_proj.weight"] = ((d, d), LINEAR)
+            P[m + "norm_2.weight"] = ((d,), LN_W)
+            P[m + "ffn.up_proj.weight"] = ((cfg.mlp_ratio * d, d), LINEAR)
+            P[m + "ffn.down_proj.weight"] = ((d, cfg.mlp_ratio * d), LINEAR)
+        else:
+            P[m + "ln_1.weight"] = ((d,), LN_W)
+            P[m + "attn.Wqkv.weight"] = ((3 * d, d), LINEAR)
+            if cfg.attn_qk_ln:
+                P[m + "attn.q_ln.weight"] = ((d,), LN_W)
+                P[m + "attn.k_ln.weight"] = ((d,), LN_W)
+            P[m + "attn.out_proj.weight"] = ((d, d), LINEAR)
+            P[m + "ln_2.weight"] = ((d,), LN_W)
+            P[m + "mlp.mlp_up.weight"] = ((cfg.mlp_ratio * d, d), LINEAR)
+            P[m + "mlp.mlp_down.weight"] = ((d, cfg.mlp_ratio * d), LINEAR)
+
+    P.update(head_param_shapes(cfg, "extra_exit."))
+    return P
+
+
+def head_param_shapes(cfg: DeerConfig, prefix: str) -> "OrderedDict[str, Tuple[tuple, str]]":
+    """``DeterministicDecoder`` parameters (action_head.py:15-64,72-79,86-116,467-473)."""
+    P: "OrderedDict[str, Tuple[tuple, str]]" = OrderedDict()
+    H = cfg.head_hidden
+    in_f = cfg.d_model
+    for l in range(cfg.lstm_num_layers):
+        if cfg.lstm_layernorm:
+            r = f"{prefix}rnn.layers.{3 * l}."            # LSTM at 0,3,6,9; LN at 1,4,7,10
+            sfx = "_l0"
+        else:
+            r = f"{prefix}rnn."
+            sfx = f"_l{l}"
+        P[r + "weight_ih" + sfx] = ((4 * H, in_f), LINEAR)
+        P[r + "weight_hh" + sfx] = ((4 * H, H), LINEAR)
+        P[r + "bias_ih" + sfx] = ((4 * H,), BIAS)
+        P[r + "bias_hh" + sfx] = ((4 * H,), BIAS)
+        if cfg.lstm_layernorm:
+            P[f"{prefix}rnn.layers.{3 * l + 1}.weight"] = ((H,), LN_W)
+            P[f"{prefix}rnn.layers.{3 * l + 1}.bias"] = ((H,), LN_B)
+        in_f = H
+    lin, ln, out = mlp_layer_indices(cfg.mlp_num_hidden_layers)
+    for head, n_out in (("actions", 6), ("gripper", 1)):
+        cur = H
+        for li, ni, dim in zip(lin, ln, cfg.mlp_hidden_dims):
+            P[f"{prefix}{head}.mlp.{li}.weight"] = ((dim, cur), LINEAR)
+            P[f"{prefix}{head}.mlp.{li}.bias"] = ((dim,), BIAS)
+            if cfg.mlp_layernorm:
+                P[f"{prefix}{head}.mlp.{ni}.weight"] = ((dim,), LN_W)
+                P[f"{prefix}{head}.mlp.{ni}.bias"] = ((dim,), LN_B)
+            cur = dim
+        P[f"{prefix}{head}.mlp.{out}.weight"] = ((n_out, cur), LINEAR)
+        P[f"{prefix}{head}.mlp.{out}.bias"] = ((n_out,), BIAS)
+    return P
+
+
+def _fan_in(shape) -> int:
+    n = 1
+    for s in shape[1:]:
+        n *= s
+    return max(n, 1)
+
+
+def make_synthetic_state(cfg: DeerConfig, seed: int = 0, std: str = "fanin", device="cpu",
+                         bf16_round: bool = False) -> Dict[str, torch.Tensor]:
+    """Seeded random fp32 state dict.  Every tensor has its own generator seeded with
+    crc32(name) + seed, so values do not depend on enumeration order or on which subset is built.
+
+    std="fanin": Linear ~ N(0, 1/fan_in)   (keeps activations O(1) at every width; tiny configs)
+    std="0.02" : Linear ~ N(0, 0.02^2)     (BASELINE.md §3 protocol; ~ same thing at d=2048)
+    bf16_round : round the tensors the engine stores as bf16 (so an fp32 oracle fed with this dict
+                 sees exactly the weights the HIP path sees)."""
+    out: Dict[str, torch.Tensor] = {}
+    for name, (shape, kind) in param_shapes(cfg).items():
+        g = torch.Generator(device="cpu")
+        g.manual_seed((zlib.crc32(name.encode()) + 1000003 * seed) & 0x7FFFFFFF)
+        if kind == LINEAR:
+            s = 0.02 if std == "0.02" else _fan_in(shape) ** -0.5
+            t = torch.randn(shape, generator=g) * s
+        elif kind == EMBED:
+            t = torch.randn(shape, generator=g) * (0.02 if std == "0.02" else 0.5)
+        elif kind == LN_W:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif kind in (LN_B, BIAS):
+            t = 0.05 * torch.randn(shape, generator=g)
+        elif kind == GATE:
+            t = torch.full(shape, 0.5)
+        elif kind == LATENT:
+            t = torch.randn(shape, generator=g)
+        elif kind == POS:
+            t = 0.1 * torch.randn(shape, generator=g)
+        else:  # pragma: no cover
+            raise ValueError(kind)
+        if bf16_round and kind in BF16_KINDS:
+            t = t.to(torch.bfloat16).to(torch.float32)
+        out[name] = t.to(device)
+    return out
+
+
+def round_state_to_bf16(cfg: DeerConfig, sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """fp32 copy of ``sd`` whose GEMM operands are rounded to bf16 (what the engine keeps in HBM)."""
+    kinds = {k: v[1] for k, v in param_shapes(cfg).items()}
+    return {k: (t.to(torch.bfloat16).to(torch.float32) if kinds.get(k) in BF16_KINDS else t.clone())
+            for k, t in sd.items()}
+
+
+def synthetic_step_inputs(cfg: DeerConfig, step: int, rank: int = 0, text_len: int = 14,
+                          text_seed: int = 7):
+    """SURVEY §8(d) synthetic inputs: rgb, gripper ~ N(0,1) (1,1,1,3,S,S) with seed
+    1234+1000*rank+step; text = [<image>] + (text_len-3) fixed random ids + [<|endofchunk|>, eos]."""
+    g = torch.Generator().manual_seed(1234 + 1000 * rank + step)
+    S = cfg.image_size
+    rgb = torch.randn(1, 1, 1, 3, S, S, generator=g)
+    grip = torch.randn(1, 1, 1, 3, S, S, generator=g)
+    gt = torch.Generator().manual_seed(text_seed)
+    hi = min(cfg.vocab_size, cfg.eoc_token_id)      # ordinary ids live below the special tokens
+    body = torch.randint(0, hi, (text_len - 3,), generator=gt)
+    ids = torch.cat([torch.tensor([cfg.media_token_id]), body,
+                     torch.tensor([cfg.eoc_token_id, 0])]).view(1, -1).long()
+    mask = torch.ones_like(ids, dtype=torch.bool)
+    return rgb, grip, ids, mask

@@ -1,0 +1,526 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own modules (imported
+from /root/reference where they lie; see ref_import.py) on seeded inputs.  Run in the build
+container only:  ``python tests/golden/make_golden.py``.
+
+A fixture is data: inputs + expected outputs (+ the config/seed that regenerates the weights with
+``deer_vla_amd.synthetic``).  Weights are NOT stored: every reference module is loaded with
+``make_synthetic_state``-style tensors through ``load_state_dict`` - which at the same time pins this
+repo's parameter inventory (names + shapes) against the reference's state-dict keys.
+
+Cases (SURVEY.md §8c golden-vector plan):
+  perceiver.npz        PerceiverResampler                      helpers.py:68-132
+  xattn.npz            GatedCrossAttentionBlock (3 mask cases) helpers.py:136-279
+  flamingo_layer.npz   FlamingoLayer ordering                  flamingo_lm.py:46-83
+  head_ln.npz/head_plain.npz  DeterministicDecoder step sequence with update_hidden_state
+                       interleaving + a 12-long window call    action_head.py:408-611
+  controller_*.npz     ActionValueNet + ExitController traces  value_net.py:72-297
+  thresholds.npz       ExitController.set_threshold solver     value_net.py:185-272
+  mosaic_loop.npz      MosaicGPT.forward multi-exit loop       mosaic_gpt_3b.py:274-449 (blocks = stand-ins)
+  deer_forward.npz     MPTFlamingo.forward, static exit_id and dynamic exit over several steps
+                       flamingo_mpt.py:308-461 (config[0] of BASELINE.json: fixed exit, B=1, CPU)
+  hf_mpt_block.npz     transformers MptBlock cross-check of the un-vendored block arithmetic
+  hf_clip_vit.npz      transformers CLIPVisionModel cross-check of the un-vendored ViT arithmetic
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_import  # noqa: E402
+
+ref_import.install_stubs()
+
+from deer_vla_amd.config import DeerConfig  # noqa: E402
+from deer_vla_amd import synthetic as syn  # noqa: E402
+from oracle import deer_oracle as orc  # noqa: E402  (only to host the ViT inside the reference's MPTFlamingo)
+
+from open_flamingo.src.helpers import PerceiverResampler, GatedCrossAttentionBlock  # noqa: E402
+from open_flamingo.src.flamingo_lm import FlamingoLayer, FlamingoLMMixin  # noqa: E402
+from open_flamingo.src.utils import extend_instance  # noqa: E402
+from robot_flamingo.models.action_head import DeterministicDecoder  # noqa: E402
+from robot_flamingo.models.value_net import ActionValueNet, ExitController  # noqa: E402
+from robot_flamingo.models.flamingo_mpt import MPTFlamingo  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def seeded(name: str, shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + 7919 * seed) & 0x7FFFFFFF)
+    return torch.randn(shape, generator=g) * scale
+
+
+def sub_state(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def load_strict(module: nn.Module, sd):
+    """strict load: the reference module's keys/shapes must equal this repo's inventory."""
+    ref_keys = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    my_keys = {k: tuple(v.shape) for k, v in sd.items()}
+    assert ref_keys == my_keys, (sorted(set(ref_keys) ^ set(my_keys)),
+                                 [(k, ref_keys[k], my_keys[k]) for k in ref_keys if k in my_keys and ref_keys[k] != my_keys[k]])
+    module.load_state_dict(sd, strict=True)
+
+
+def save(name, cfg: DeerConfig, seed: int, **arrays):
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    out["cfg_json"] = np.frombuffer(json.dumps(cfg.to_dict()).encode(), dtype=np.uint8)
+    out["seed"] = np.asarray(seed)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB  keys={sorted(arrays)}")
+
+
+# ------------------------------------------------------------------------------------------------
+def small_cfg(**kw):
+    base = dict(image_size=28, patch_size=14, vit_width=32, vit_layers=1, vit_heads=2, vit_mlp=64,
+                perc_depth=2, perc_heads=2, perc_dim_head=16, perc_latents=8,
+                d_model=32, n_heads=2, n_layers_total=6, vocab_size=100, media_token_id=98, eoc_token_id=97,
+                xattn_heads=2, xattn_dim_head=16, early_exit_layer=5, head_hidden=16)
+    base.update(kw)
+    return DeerConfig(**base)
+
+
+def gen_perceiver():
+    cfg, seed = small_cfg(), 1
+    sd = syn.make_synthetic_state(cfg, seed)
+    m = PerceiverResampler(dim=cfg.vit_width, depth=cfg.perc_depth, dim_head=cfg.perc_dim_head,
+                           heads=cfg.perc_heads, num_latents=cfg.perc_latents).eval()
+    load_strict(m, sub_state(sd, "perceiver."))
+    x = seeded("perc.x", (2, 1, 1, 10, cfg.vit_width))
+    save("perceiver.npz", cfg, seed, x=x, out=m(x))
+
+
+def gen_xattn():
+    cfg, seed = small_cfg(), 2
+    sd = syn.make_synthetic_state(cfg, seed)
+    pfx = "lang_encoder.transformer.blocks.0.gated_cross_attn_layer."
+    m = GatedCrossAttentionBlock(dim=cfg.d_model, dim_visual=cfg.vit_width, dim_head=cfg.xattn_dim_head,
+                                 heads=cfg.xattn_heads).eval()
+    s = sub_state(sd, pfx)
+    s["attn_gate"] = torch.tensor([0.5])
+    s["ff_gate"] = torch.tensor([-0.3])
+    load_strict(m, s)
+    x = seeded("xattn.x", (2, 6, cfg.d_model))
+    media1 = seeded("xattn.media1", (2, 1, 8, cfg.vit_width))
+    media2 = seeded("xattn.media2", (2, 2, 4, cfg.vit_width))
+    loc_a = torch.zeros(2, 6, dtype=torch.bool)
+    loc_a[:, 0] = True                                   # DeeR step mode: <image> is token 0
+    loc_b = torch.zeros(2, 6, dtype=torch.bool)
+    loc_b[0, 0] = True
+    loc_b[1, 2] = True                                   # tokens 0,1 of row 1 precede any media -> zeroed rows
+    loc_c = torch.zeros(2, 6, dtype=torch.bool)
+    loc_c[:, 0] = True
+    loc_c[:, 3] = True                                   # two media, only_attend_immediate_media
+    save("xattn.npz", cfg, seed, x=x, media1=media1, media2=media2,
+         loc_a=loc_a, loc_b=loc_b, loc_c=loc_c, attn_gate=0.5, ff_gate=-0.3,
+         out_a=m(x, media1, media_locations=loc_a), out_b=m(x, media1, media_locations=loc_b),
+         out_c=m(x, media2, media_locations=loc_c),
+         out_cached=m(x, media1, media_locations=loc_a, use_cached_media=True))
+
+
+class _ToyDecoder(nn.Module):
+    """A decoder_layer stand-in for the ordering test: x -> tanh(x W^T) (returns a tuple like GPTBlock)."""
+
+    def __init__(self, w):
+        super().__init__()
+        self.w = nn.Parameter(w)
+
+    def forward(self, x, attention_mask=None, **kw):
+        return torch.tanh(x @ self.w.t()), None
+
+
+def gen_flamingo_layer():
+    cfg, seed = small_cfg(), 3
+    sd = syn.make_synthetic_state(cfg, seed)
+    pfx = "lang_encoder.transformer.blocks.0.gated_cross_attn_layer."
+    xa = GatedCrossAttentionBlock(dim=cfg.d_model, dim_visual=cfg.vit_width, dim_head=cfg.xattn_dim_head,
+                                  heads=cfg.xattn_heads).eval()
+    load_strict(xa, sub_state(sd, pfx))
+    w = seeded("toy.w", (cfg.d_model, cfg.d_model), scale=cfg.d_model ** -0.5)
+    layer = FlamingoLayer(xa, _ToyDecoder(w)).eval()
+    x = seeded("fl.x", (1, 5, cfg.d_model))
+    media = seeded("fl.media", (1, 1, 8, cfg.vit_width))
+    loc = torch.zeros(1, 5, dtype=torch.bool)
+    loc[:, 0] = True
+    layer.condition_vis_x(media)
+    layer.condition_media_locations(loc)
+    layer.condition_use_cached_media(False)
+    out = layer(x, attention_mask=None)[0]
+    save("flamingo_layer.npz", cfg, seed, x=x, media=media, loc=loc, toy_w=w, out=out)
+
+
+def build_ref_head(cfg, sd, prefix="extra_exit."):
+    m = DeterministicDecoder(cfg.d_model, cfg.window_size, 0.0, 0.0, "layerwise", cfg.mlp_layernorm,
+                             cfg.lstm_layernorm, cfg.mlp_num_hidden_layers, hidden_size=cfg.head_hidden,
+                             lstm_num_layers=cfg.lstm_num_layers, pooling=cfg.pooling).eval()
+    load_strict(m, sub_state(sd, prefix))
+    return m
+
+
+def gen_head(name, **kw):
+    cfg, seed = small_cfg(**kw), 4
+    sd = syn.make_synthetic_state(cfg, seed)
+    m = build_ref_head(cfg, sd)
+    m.window_size = 1                                   # ModelWrapper.step: set_all_exit_window_size(1)
+    T = 7
+    feats = seeded("head.feats", (6, 1, T, cfg.d_model))
+    upd = [False, False, True, False, True, True]       # controller evals (False) vs committing eval (True)
+    poses, grips, hs, cs = [], [], [], []
+    for t in range(6):
+        a, g = m(feats[t], update_hidden_state=upd[t])
+        poses.append(a)
+        grips.append(g)
+        if m.hidden_state is None:
+            hs.append(torch.zeros(cfg.lstm_num_layers, 1, cfg.head_hidden))
+            cs.append(torch.zeros(cfg.lstm_num_layers, 1, cfg.head_hidden))
+        else:
+            hs.append(m.hidden_state[0].clone())
+            cs.append(m.hidden_state[1].clone())
+    # window mode: (bs*12, T, d) -> 12-step LSTM from h_0=None (action_head.py:588-595)
+    m2 = build_ref_head(cfg, sd)
+    m2.window_size = cfg.window_size
+    wfeat = seeded("head.wfeat", (2 * cfg.window_size, T, cfg.d_model))
+    wa, wg = m2(wfeat)
+    m2.last_action = True
+    wa_last, wg_last = m2(wfeat)
+    _, (wgp, wgl) = m2(wfeat, with_gripper_logits=True)
+    save(name, cfg, seed, feats=feats, upd=np.asarray(upd), pose=torch.stack(poses), grip=torch.stack(grips),
+         h=torch.stack(hs), c=torch.stack(cs), wfeat=wfeat, wpose=wa, wgrip=wg, wpose_last=wa_last,
+         wgrip_last=wg_last, wgrip_logits=wgl)
+
+
+def _dist_init():
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+
+
+class _RecVN(ActionValueNet):
+    """ActionValueNet that remembers every (exit id, delta) it produced (fixture generation only)."""
+
+    def forward(self, feats, i=None, mode="infer", rand_layer_feat=None):
+        v = super().forward(feats, i, mode, rand_layer_feat)
+        if not hasattr(self, "rec"):
+            self.rec = []
+        self.rec.append((i, float(v)))
+        return v
+
+
+def gen_controller(name, n_layers, max_layer, steps_per_stage, threshold_type="L2", n_steps=9, **kw):
+    """Drive the reference ActionValueNet/ExitController exactly like the LLM loop does
+    (mosaic_gpt_3b.py:397-443) + the committing head call (flamingo_mpt.py:459) on random features."""
+    _dist_init()
+    cfg, seed = small_cfg(early_exit_layer=n_layers - 1, **kw), 5
+    sd = syn.make_synthetic_state(cfg, seed)
+    head = build_ref_head(cfg, sd)
+    head.window_size = 1
+    exit_ids = cfg.exit_ids()
+    vn = _RecVN(exit_list=exit_ids, exit_head=head, interval=cfg.exit_interval, window_size=1,
+                threshold_type=threshold_type)
+    ctl = ExitController(vn, exit_id_list=exit_ids, steps_per_stage=1, leq=True, exit_dist="exp",
+                         max_layer=max_layer)
+    T = 5
+    feats = seeded("ctl.feats", (n_steps, n_layers, 1, T, cfg.d_model))
+    # make later layers converge (smaller change between consecutive exits) like a trained model does
+    for l in range(1, n_layers):
+        feats[:, l] = feats[:, l - 1] + feats[:, l] * (0.6 ** l)
+    real = len([x for x in exit_ids if x <= ctl.max_layer])
+    # pass 1 (not recorded): thresholds=-1 => only the forced exit fires; collect every delta of the stateful run
+    ctl._set_threshold_value([-1.0] * real)
+    for s_ in range(n_steps):
+        ctl.set_timestep(0)
+        hidden = ()
+        for b_ in range(n_layers):
+            hidden = hidden + (feats[s_, b_],)
+            if ctl(hidden, b_):
+                break
+        head(hidden[b_], update_hidden_state=True)
+    deltas = [[v for (i, v) in vn.rec if i == e] for e in exit_ids[:real]]
+    thresholds = [float(np.quantile(d, q)) for d, q in zip(deltas, [0.3, 0.4, 0.5, 0.5, 0.6, 0.6])]
+    thresholds[-1] = 1e5                                 # README.md:142 style: last threshold is "always exit"
+    # the run that is recorded
+    head2 = build_ref_head(cfg, sd)
+    head2.window_size = 1
+    vn = _RecVN(exit_list=exit_ids, exit_head=head2, interval=cfg.exit_interval, window_size=1,
+                threshold_type=threshold_type)
+    ctl = ExitController(vn, exit_id_list=exit_ids, steps_per_stage=steps_per_stage, leq=True, exit_dist="exp",
+                         max_layer=max_layer)
+    ctl._set_threshold_value(thresholds)
+    exit_layers, poses, grips, n_evals = [], [], [], []
+    for s in range(n_steps):
+        ctl.set_timestep(s)
+        hidden = ()
+        n0 = len(vn.action_list)
+        for b in range(n_layers):
+            hidden = hidden + (feats[s, b],)
+            if ctl(hidden, b):
+                break
+        exit_layers.append(b)
+        n_evals.append(len(vn.action_list) - n0)
+        a, g = head2(hidden[b], update_hidden_state=True)   # flamingo_mpt.py:459
+        poses.append(a)
+        grips.append(g)
+    print(f"  {name}: exits={exit_layers} thresholds={np.round(thresholds, 5).tolist()}")
+    save(name, cfg, seed, feats=feats, thresholds=np.asarray(thresholds), exit_layers=np.asarray(exit_layers),
+         pose=torch.stack(poses), grip=torch.stack(grips), n_evals=np.asarray(n_evals),
+         rec_layer=np.asarray([i for i, _ in vn.rec]), rec_delta=np.asarray([v for _, v in vn.rec]),
+         max_layer=max_layer, steps_per_stage=steps_per_stage,
+         threshold_type=np.frombuffer(threshold_type.encode(), dtype=np.uint8), ctl_max_layer=ctl.max_layer)
+
+
+def gen_thresholds():
+    _dist_init()
+    cfg = small_cfg(early_exit_layer=11)
+    args = types.SimpleNamespace(rank=1)
+    g = torch.Generator().manual_seed(11)
+    values = torch.rand(6, 400, generator=g) * torch.tensor([0.05, 0.02, 0.02, 0.01, 0.01, 0.01]).view(6, 1)
+    values[2, 10:20] = values[2, 5]                      # ties
+    out = {"values": values}
+    for model_name in ("mpt_dolly_3b", "mpt_9b"):
+        for ratio in (0.8, 1.0, 1.5):
+            for max_layer in (12, 8):
+                ctl = ExitController(None, exit_id_list=cfg.exit_ids(), steps_per_stage=1, leq=True, exit_dist="exp",
+                                     max_layer=max_layer)
+                real = len([x for x in ctl.exit_id_list if x <= ctl.max_layer])
+                ctl.set_threshold(args, None, None, ratio, model_name, values=values[:real].clone())
+                T = torch.stack([torch.as_tensor(ctl.thresholds[i]) for i in ctl.exit_id_list[:real]])
+                out[f"T_{model_name}_{ratio}_{max_layer}"] = T
+    save("thresholds.npz", cfg, 0, **out)
+
+
+def llm_cfg(**kw):
+    base = dict(image_size=28, patch_size=14, vit_width=64, vit_layers=1, vit_heads=2, vit_mlp=128,
+                d_model=64, n_heads=2, n_layers_total=6, vocab_size=100, media_token_id=98, eoc_token_id=97,
+                early_exit_layer=4, head_hidden=1024)     # perceiver / x-attn / head dims = reference ctor defaults
+    base.update(kw)
+    return DeerConfig(**base)
+
+
+def build_ref_lang_encoder(cfg, sd):
+    mod = ref_import.load_mosaic_gpt()
+    st = sys.modules["deer_mpt1b_pkg._standins"]
+    hf = st.MosaicGPTConfig(d_model=cfg.d_model, n_heads=cfg.n_heads, n_layers=cfg.n_layers_total, max_seq_len=32,
+                            vocab_size=cfg.vocab_size, attn_qk_ln=cfg.attn_qk_ln, alibi_bias_max=cfg.alibi_bias_max)
+    lm = mod.MosaicGPT(hf).eval()
+    return lm, mod
+
+
+def gen_mosaic_loop():
+    """The reference's own MosaicGPT.forward loop (exit_id / exit_controller / hidden_states semantics,
+    ALiBi + key-padding bias plumbing) on stand-in blocks; no x-attn here."""
+    cfg, seed = llm_cfg(cross_attn_every_n_layers=10 ** 6, early_exit_layer=5), 6
+    sd = syn.make_synthetic_state(cfg, seed)
+    lm, mod = build_ref_lang_encoder(cfg, sd)
+    s = {k[len("lang_encoder."):].replace(".decoder_layer.", "."): v for k, v in sd.items()
+         if k.startswith("lang_encoder.transformer.")}
+    missing, unexpected = lm.load_state_dict(s, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("transformer.ln_f") for k in missing), missing
+    ids = torch.randint(0, 90, (2, 9), generator=torch.Generator().manual_seed(3))
+    mask = torch.ones(2, 9, dtype=torch.bool)
+    mask[1, 6:] = False                                  # right padding (data.py:914 padding="longest")
+    o_full = lm(ids, attention_mask=mask, output_hidden_states=True, return_dict=True)
+    o_e2 = lm(ids, attention_mask=mask, output_hidden_states=True, return_dict=True, exit_id=2)
+    o_neg = lm(ids, attention_mask=mask, output_hidden_states=True, return_dict=True, exit_id=-2)
+    calls = []
+
+    def ctl(hidden, b):
+        calls.append((len(hidden), b))
+        return b == 3
+    o_ctl = lm(ids, attention_mask=mask, output_hidden_states=True, return_dict=True, exit_controller=ctl)
+    save("mosaic_loop.npz", cfg, seed, ids=ids, mask=mask,
+         full=torch.stack(o_full.hidden_states), full_exit=o_full.exit_layer,
+         e2=torch.stack(o_e2.hidden_states), e2_exit=o_e2.exit_layer,
+         neg=torch.stack(o_neg.hidden_states), neg_exit=o_neg.exit_layer,
+         ctl=torch.stack(o_ctl.hidden_states), ctl_exit=o_ctl.exit_layer, ctl_calls=np.asarray(calls))
+
+
+class _OracleVisual(nn.Module):
+    """Hosts the (un-vendored) ViT inside the reference's MPTFlamingo: ``visual(x) -> (pooled, tokens)``."""
+
+    def __init__(self, cfg, sd):
+        super().__init__()
+        self.cfg, self.sd = cfg, sd
+        self.output_tokens = True
+
+    def forward(self, x):
+        t = orc.vit_visual_tokens(self.sd, self.cfg, x.float())
+        return t[:, 0], t
+
+
+def gen_deer_forward():
+    """The reference's own MPTFlamingo.forward (+FlamingoLMMixin +MosaicGPT loop +Perceiver +x-attn
+    +DeterministicDecoder +ExitController) end to end on CPU."""
+    _dist_init()
+    cfg, seed = llm_cfg(), 7
+    sd = syn.make_synthetic_state(cfg, seed)
+    lm, mod = build_ref_lang_encoder(cfg, sd)
+    extend_instance(lm, FlamingoLMMixin)
+    lm.set_decoder_layers_attr_name("transformer.blocks")
+    venc = types.SimpleNamespace(visual=_OracleVisual(cfg, sd))
+    venc_mod = nn.Module()
+    venc_mod.visual = venc.visual
+    model = MPTFlamingo(venc_mod, lm, cfg.eoc_token_id, cfg.media_token_id, vis_dim=cfg.vit_width,
+                        cross_attn_every_n_layers=cfg.cross_attn_every_n_layers, window_size=cfg.window_size,
+                        use_gripper=True, fusion_mode="post", llm="mpt_dolly_3b", pooling="max",
+                        early_exit_layer=cfg.early_exit_layer, multi_exit=False, exit_interval=cfg.exit_interval,
+                        mlp_layernorm=True, lstm_layernorm=True, mlp_num_hidden_layers=2, lstm_num_layers=4).eval()
+    assert model.get_all_exit_idx() == cfg.exit_ids(), (model.get_all_exit_idx(), cfg.exit_ids())
+    ref_keys = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd_model = {k: v for k, v in sd.items() if not k.startswith("vision_encoder.")}   # ViT hosted by the oracle
+    for k, v in sd_model.items():
+        assert k in ref_keys and ref_keys[k] == tuple(v.shape), (k, tuple(v.shape), ref_keys.get(k))
+    missing, unexpected = model.load_state_dict(sd_model, strict=False)
+    assert not unexpected, unexpected
+    # every tensor we did not provide must be an alias of one we did, an unused head, or the never-applied ln_f
+    provided = {id(p) for k, p in model.state_dict(keep_vars=True).items() if k in sd}
+    for k in missing:
+        p = model.state_dict(keep_vars=True)[k]
+        assert id(p) in provided or k.startswith("lm_head.") or "ln_f" in k, k
+
+    T = 8
+    ids = torch.tensor([[cfg.media_token_id, 5, 17, 3, 42, 8, cfg.eoc_token_id, 0]])
+    mask = torch.ones(1, T, dtype=torch.bool)
+    S = cfg.image_size
+    n_steps = 6
+    rgb = seeded("deer.rgb", (n_steps, 1, 1, 1, 3, S, S))
+    grip = seeded("deer.grip", (n_steps, 1, 1, 1, 3, S, S))
+    state = torch.zeros(1, 1, 1, 15)
+    model.set_all_exit_window_size(1)
+
+    # --- static exit (BASELINE config[0]) -------------------------------------------------------
+    outs = {}
+    for eid in (3, 4, -1):
+        model.clear_all_exit_memory()
+        o = model(vision_x=rgb[0], lang_x=ids, attention_mask=mask, vision_gripper=grip[0], state_tensor=state,
+                  return_feature=True, deterministic=True, exit_id=eid, dynamic_early_exit=False, exit_controller=None)
+        tag = f"static{eid}"
+        outs[tag + "_pose"], outs[tag + "_grip"] = o.logits[0], o.logits[1]
+        outs[tag + "_hidden"] = torch.stack(o.hidden_states)
+        outs[tag + "_exit"] = o.exit_layer
+    outs["vis_x"] = lm._get_decoder_layers()[0].vis_x
+
+    # --- dynamic exit over n_steps control steps with LSTM carry (ModelWrapper.step protocol) ----
+    exit_ids = model.get_all_exit_idx()
+    for tag, max_layer in (("dyn", 12), ("dynS", 4)):
+        model.clear_all_exit_memory()
+        vn = _RecVN(exit_list=exit_ids, exit_head=model.extra_exit, interval=cfg.exit_interval,
+                    window_size=cfg.window_size, threshold_type="L2")
+        ctl = ExitController(vn, exit_id_list=exit_ids, steps_per_stage=1, leq=True, exit_dist="exp", max_layer=max_layer)
+        real = len([x for x in exit_ids if x <= ctl.max_layer])
+        ctl._set_threshold_value([-1.0] * real)          # never-exit pass (not recorded) to see the delta scale
+        for s in range(n_steps):
+            ctl.set_timestep(s)
+            model(vision_x=rgb[s], lang_x=ids, attention_mask=mask, vision_gripper=grip[s], state_tensor=state,
+                  return_feature=True, deterministic=True, exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
+        thr = [float(np.median([v for (i, v) in vn.rec if i == e])) for e in exit_ids[:real]]
+        thr[-1] = 1e5
+        model.clear_all_exit_memory()
+        vn.reset_actions()
+        vn.rec = []
+        ctl._set_threshold_value(thr)
+        ex, ps, gs, hid = [], [], [], []
+        for s in range(n_steps):
+            ctl.set_timestep(s)
+            o = model(vision_x=rgb[s], lang_x=ids, attention_mask=mask, vision_gripper=grip[s], state_tensor=state,
+                      return_feature=True, deterministic=True, exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
+            ex.append(o.exit_layer)
+            ps.append(o.logits[0])
+            gs.append(o.logits[1])
+            hid.append(o.hidden_states[o.exit_layer])
+        print(f"  deer_forward {tag}: exits={ex}")
+        outs[tag + "_thr"] = np.asarray(thr)
+        outs[tag + "_exit"] = np.asarray(ex)
+        outs[tag + "_pose"] = torch.stack(ps)
+        outs[tag + "_grip"] = torch.stack(gs)
+        outs[tag + "_hidden"] = torch.stack(hid)
+        outs[tag + "_max_layer"] = max_layer
+        outs[tag + "_rec_layer"] = np.asarray([i for i, _ in vn.rec])
+        outs[tag + "_rec_delta"] = np.asarray([v for _, v in vn.rec])
+    save("deer_forward.npz", cfg, seed, ids=ids, mask=mask, rgb=rgb, grip=grip, **outs)
+
+
+def gen_hf_mpt_block():
+    from transformers import MptConfig
+    from transformers.models.mpt import modeling_mpt as mm
+    cfg, seed = llm_cfg(llm_name="mpt_9b", attn_qk_ln=False, cross_attn_every_n_layers=10 ** 6, n_heads=4), 8
+    sd = syn.make_synthetic_state(cfg, seed)
+    hf = MptConfig(d_model=cfg.d_model, n_heads=cfg.n_heads, n_layers=1, expansion_ratio=cfg.mlp_ratio, max_seq_len=32,
+                   vocab_size=cfg.vocab_size)
+    blk = mm.MptBlock(hf).eval()
+    load_strict(blk, sub_state(sd, "lang_encoder.transformer.blocks.0.decoder_layer."))
+    S = 9
+    x = seeded("hf.x", (2, S, cfg.d_model))
+    alibi = mm.build_mpt_alibi_tensor(cfg.n_heads, 32)                       # (H,1,32)
+    causal = torch.ones(S, S, dtype=torch.bool).triu(1).view(1, 1, S, S)
+    out, _ = blk(x, position_bias=alibi, attention_mask=causal)
+    save("hf_mpt_block.npz", cfg, seed, x=x, out=out)
+
+
+def gen_hf_clip():
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    cfg, seed = small_cfg(image_size=42, vit_width=64, vit_layers=2, vit_heads=2, vit_mlp=128), 9
+    sd = syn.make_synthetic_state(cfg, seed)
+    hf = CLIPVisionConfig(hidden_size=cfg.vit_width, intermediate_size=cfg.vit_mlp, num_hidden_layers=cfg.vit_layers,
+                          num_attention_heads=cfg.vit_heads, image_size=cfg.image_size, patch_size=cfg.patch_size,
+                          hidden_act="quick_gelu", layer_norm_eps=1e-5)
+    m = CLIPVisionModel(hf).eval()
+    v = "vision_encoder.visual."
+    W = cfg.vit_width
+    t = {"embeddings.class_embedding": sd[v + "class_embedding"],
+         "embeddings.patch_embedding.weight": sd[v + "conv1.weight"],
+         "embeddings.position_embedding.weight": sd[v + "positional_embedding"],
+         "pre_layrnorm.weight": sd[v + "ln_pre.weight"],
+         "pre_layrnorm.bias": sd[v + "ln_pre.bias"]}
+    for l in range(cfg.vit_layers):
+        p, q = f"{v}transformer.resblocks.{l}.", f"encoder.layers.{l}."
+        wq, wk, wv = sd[p + "attn.in_proj_weight"].chunk(3, dim=0)
+        bq, bk, bv = sd[p + "attn.in_proj_bias"].chunk(3, dim=0)
+        t.update({q + "self_attn.q_proj.weight": wq, q + "self_attn.k_proj.weight": wk, q + "self_attn.v_proj.weight": wv,
+                  q + "self_attn.q_proj.bias": bq, q + "self_attn.k_proj.bias": bk, q + "self_attn.v_proj.bias": bv,
+                  q + "self_attn.out_proj.weight": sd[p + "attn.out_proj.weight"],
+                  q + "self_attn.out_proj.bias": sd[p + "attn.out_proj.bias"],
+                  q + "layer_norm1.weight": sd[p + "ln_1.weight"], q + "layer_norm1.bias": sd[p + "ln_1.bias"],
+                  q + "layer_norm2.weight": sd[p + "ln_2.weight"], q + "layer_norm2.bias": sd[p + "ln_2.bias"],
+                  q + "mlp.fc1.weight": sd[p + "mlp.c_fc.weight"], q + "mlp.fc1.bias": sd[p + "mlp.c_fc.bias"],
+                  q + "mlp.fc2.weight": sd[p + "mlp.c_proj.weight"], q + "mlp.fc2.bias": sd[p + "mlp.c_proj.bias"]})
+    missing, unexpected = m.load_state_dict(t, strict=False)
+    assert not unexpected, unexpected
+    assert all("post_layernorm" in k or "position_ids" in k for k in missing), missing
+    img = seeded("clip.img", (2, 3, cfg.image_size, cfg.image_size))
+    out = m(pixel_values=img).last_hidden_state[:, 1:]                        # pre-post_layernorm patch tokens
+    save("hf_clip_vit.npz", cfg, seed, img=img, out=out)
+
+
+if __name__ == "__main__":
+    gen_perceiver()
+    gen_xattn()
+    gen_flamingo_layer()
+    gen_head("head_ln.npz")
+    gen_head("head_plain.npz", lstm_layernorm=False, mlp_layernorm=False)
+    gen_head("head_avg3.npz", pooling="avg", mlp_num_hidden_layers=3)
+    gen_controller("controller_b12.npz", n_layers=12, max_layer=12, steps_per_stage=1)
+    gen_controller("controller_s4.npz", n_layers=5, max_layer=4, steps_per_stage=1)
+    gen_controller("controller_sps3.npz", n_layers=12, max_layer=12, steps_per_stage=3)
+    gen_controller("controller_max.npz", n_layers=12, max_layer=8, steps_per_stage=1, threshold_type="max")
+    gen_thresholds()
+    gen_mosaic_loop()
+    gen_deer_forward()
+    gen_hf_mpt_block()
+    gen_hf_clip()

@@ -1,0 +1,214 @@
+"""Pins the CPU oracle (oracle/deer_oracle.py) against golden vectors produced by the REFERENCE's own
+modules (tests/golden/make_golden.py).  CPU only; runs in the `-m "not gpu"` suite."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load, state, s2str
+from oracle import deer_oracle as orc
+
+TOL = dict(rtol=1e-5, atol=2e-6)
+
+
+def close(a, b, **kw):
+    tol = dict(TOL)
+    tol.update(kw)
+    torch.testing.assert_close(a.float(), b.float(), **tol)
+
+
+def test_perceiver_matches_reference():
+    cfg, seed, g = load("perceiver.npz")
+    out = orc.perceiver_resampler(state(cfg, seed), cfg, g["x"])
+    close(out, g["out"])
+
+
+def test_gated_xattn_matches_reference():
+    cfg, seed, g = load("xattn.npz")
+    sd = state(cfg, seed)
+    p = "lang_encoder.transformer.blocks.0.gated_cross_attn_layer."
+    sd[p + "attn_gate"] = torch.tensor([float(g["attn_gate"])])
+    sd[p + "ff_gate"] = torch.tensor([float(g["ff_gate"])])
+    kw = dict(heads=cfg.xattn_heads, dim_head=cfg.xattn_dim_head)
+    close(orc.gated_cross_attention_block(sd, p, g["x"], g["media1"], g["loc_a"].bool(), **kw), g["out_a"])
+    close(orc.gated_cross_attention_block(sd, p, g["x"], g["media1"], g["loc_b"].bool(), **kw), g["out_b"])
+    close(orc.gated_cross_attention_block(sd, p, g["x"], g["media2"], g["loc_c"].bool(), **kw), g["out_c"])
+    close(orc.gated_cross_attention_block(sd, p, g["x"], g["media1"], g["loc_a"].bool(), True, **kw), g["out_cached"])
+    # rows of batch 1 that precede any media get NO attention contribution (helpers.py:223-229)
+    x = g["x"]
+    ff_only = orc.feed_forward(sd, p + "ff.", x) * sd[p + "ff_gate"].tanh() + x
+    close(g["out_b"][1, :2], ff_only[1, :2])
+
+
+def test_flamingo_layer_order_matches_reference():
+    cfg, seed, g = load("flamingo_layer.npz")
+    sd = state(cfg, seed)
+    p = "lang_encoder.transformer.blocks.0.gated_cross_attn_layer."
+    x = orc.gated_cross_attention_block(sd, p, g["x"], g["media"], g["loc"].bool(), False,
+                                        cfg.xattn_heads, cfg.xattn_dim_head)
+    close(torch.tanh(x @ g["toy_w"].t()), g["out"])       # x-attn FIRST, decoder layer second
+
+
+@pytest.mark.parametrize("name", ["head_ln.npz", "head_plain.npz", "head_avg3.npz"])
+def test_action_head_matches_reference(name):
+    cfg, seed, g = load(name)
+    sd = state(cfg, seed)
+    head = orc.OracleHead(sd, cfg)
+    head.window_size = 1
+    for t in range(g["feats"].shape[0]):
+        a, gr = head(g["feats"][t], update_hidden_state=bool(g["upd"][t]))
+        close(a, g["pose"][t])
+        close(gr, g["grip"][t])
+        if head.hidden_state is None:
+            assert float(g["h"][t].abs().max()) == 0.0
+        else:
+            close(head.hidden_state[0], g["h"][t])
+            close(head.hidden_state[1], g["c"][t])
+    # window mode (calibration path)
+    h2 = orc.OracleHead(sd, cfg)
+    h2.window_size = cfg.window_size
+    a, gr = h2(g["wfeat"])
+    close(a, g["wpose"])
+    close(gr, g["wgrip"])
+    h2.last_action = True
+    a, gr = h2(g["wfeat"])
+    close(a, g["wpose_last"])
+    close(gr, g["wgrip_last"])
+    _, (_, logits) = h2(g["wfeat"], with_gripper_logits=True)
+    close(logits, g["wgrip_logits"], atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["controller_b12.npz", "controller_s4.npz", "controller_sps3.npz",
+                                  "controller_max.npz"])
+def test_exit_controller_trace_matches_reference(name):
+    cfg, seed, g = load(name)
+    sd = state(cfg, seed)
+    head = orc.OracleHead(sd, cfg)
+    head.window_size = 1
+    exit_ids = cfg.exit_ids()
+    ttype = s2str(g["threshold_type"])
+    vn = orc.OracleValueNet(exit_ids, head, cfg.exit_interval, 1, ttype)
+    ctl = orc.OracleExitController(vn, exit_ids, steps_per_stage=int(g["steps_per_stage"]),
+                                   max_layer=int(g["max_layer"]))
+    assert ctl.max_layer == int(g["ctl_max_layer"])
+    ctl._set_threshold_value([float(t) for t in g["thresholds"]])
+    feats = g["feats"]
+    n_steps, n_layers = feats.shape[:2]
+    rec = []
+    for s in range(n_steps):
+        ctl.set_timestep(s)
+        hidden = ()
+        n0 = len(vn.action_list)
+        for b in range(n_layers):
+            hidden = hidden + (feats[s, b],)
+            if ctl(hidden, b):
+                break
+        assert b == int(g["exit_layers"][s]), (s, b, g["exit_layers"])
+        assert len(vn.action_list) - n0 == int(g["n_evals"][s])
+        a, gr = head(hidden[b], update_hidden_state=True)
+        close(a, g["pose"][s])
+        close(gr, g["grip"][s])
+    # exit decisions are not knife-edge: recorded deltas keep a margin to their thresholds
+    thr = {e: float(t) for e, t in zip(exit_ids, g["thresholds"])}
+    margins = [abs(float(d) - thr[int(l)]) / max(thr[int(l)], 1e-9) for l, d in zip(g["rec_layer"], g["rec_delta"])
+               if thr[int(l)] < 1e4]
+    assert min(margins) > 1e-3
+
+
+def test_threshold_solver_matches_reference():
+    cfg, seed, g = load("thresholds.npz")
+    values = g["values"]
+    for key in [k for k in g if k.startswith("T_")]:
+        _, rest = key.split("T_", 1)
+        model_name, ratio, max_layer = rest.rsplit("_", 2)
+        ctl = orc.OracleExitController(None, cfg.exit_ids(), max_layer=int(max_layer))
+        T = orc.solve_thresholds(values[: ctl.real_num_exit].clone(), ctl.real_num_exit, float(ratio), "exp", True,
+                                 model_name)
+        close(T, g[key], rtol=0, atol=0)
+        assert float(T[-1]) == 1e8
+    # mpt_9b disables the first exit (value_net.py:235-236): its threshold stays at -1e8
+    assert float(g["T_mpt_9b_0.8_12"][0]) == -1e8
+
+
+def test_multi_exit_loop_matches_reference_mosaic_gpt():
+    cfg, seed, g = load("mosaic_loop.npz")
+    sd = state(cfg, seed)
+    ids, mask = g["ids"].long(), g["mask"].bool()
+    hid, ex = orc.llm_forward(sd, cfg, ids, mask, None)
+    assert ex == int(g["full_exit"]) == cfg.n_layers - 1
+    close(torch.stack(hid), g["full"], atol=1e-5)
+    hid, ex = orc.llm_forward(sd, cfg, ids, mask, None, exit_id=2)
+    assert ex == int(g["e2_exit"]) == 2 and len(hid) == 3
+    close(torch.stack(hid), g["e2"], atol=1e-5)
+    hid, ex = orc.llm_forward(sd, cfg, ids, mask, None, exit_id=-2)
+    assert ex == int(g["neg_exit"]) == cfg.n_layers - 2
+    close(torch.stack(hid), g["neg"], atol=1e-5)
+    calls = []
+
+    def ctl(hidden, b):
+        calls.append((len(hidden), b))
+        return b == 3
+    hid, ex = orc.llm_forward(sd, cfg, ids, mask, None, exit_controller=ctl)
+    assert ex == int(g["ctl_exit"]) == 3
+    assert calls == [tuple(c) for c in g["ctl_calls"].tolist()]
+    close(torch.stack(hid), g["ctl"], atol=1e-5)
+    with pytest.raises(AssertionError):
+        orc.llm_forward(sd, cfg, ids, mask, None, exit_controller=ctl, exit_id=1)
+
+
+def test_full_forward_matches_reference_mptflamingo():
+    """BASELINE config[0] (fixed exit, B=1, CPU) and the dynamic-exit step protocol, against the
+    reference's own MPTFlamingo.forward."""
+    cfg, seed, g = load("deer_forward.npz")
+    sd = state(cfg, seed)
+    model = orc.OracleDeer(sd, cfg)
+    model.set_all_exit_window_size(1)
+    ids, mask = g["ids"].long(), g["mask"].bool()
+    rgb, grip = g["rgb"], g["grip"]
+    vis = model.encode_vision(rgb[0], grip[0])
+    close(vis, g["vis_x"], atol=1e-5)
+    for eid in (3, 4, -1):
+        model.clear_all_exit_memory()
+        o = model.forward(rgb[0], ids, mask, grip[0], exit_id=eid)
+        tag = f"static{eid}"
+        assert o["exit_layer"] == int(g[tag + "_exit"])
+        close(torch.stack(o["hidden_states"]), g[tag + "_hidden"], atol=2e-5)
+        close(o["logits"][0], g[tag + "_pose"], atol=1e-5)
+        close(o["logits"][1], g[tag + "_grip"], atol=1e-5)
+    for tag in ("dyn", "dynS"):
+        model.clear_all_exit_memory()
+        exit_ids = cfg.exit_ids()
+        vn = orc.OracleValueNet(exit_ids, model.extra_exit, cfg.exit_interval, cfg.window_size, "L2")
+        ctl = orc.OracleExitController(vn, exit_ids, steps_per_stage=1, max_layer=int(g[tag + "_max_layer"]))
+        ctl._set_threshold_value([float(t) for t in g[tag + "_thr"]])
+        for s in range(rgb.shape[0]):
+            ctl.set_timestep(s)
+            o = model.forward(rgb[s], ids, mask, grip[s], dynamic_early_exit=True, exit_controller=ctl)
+            assert o["exit_layer"] == int(g[tag + "_exit"][s]), (tag, s)
+            close(o["hidden_states"][o["exit_layer"]], g[tag + "_hidden"][s], atol=2e-5)
+            close(o["logits"][0], g[tag + "_pose"][s], atol=1e-5)
+            close(o["logits"][1], g[tag + "_grip"][s], atol=1e-5)
+
+
+def test_mpt_block_matches_hf_port():
+    """Un-vendored MPT block arithmetic: cross-check against transformers' independent MptBlock."""
+    cfg, seed, g = load("hf_mpt_block.npz")
+    sd = state(cfg, seed)
+    bias = orc.mpt_attn_bias(cfg, g["x"].shape[1], None)
+    out = orc.mpt_block(sd, "lang_encoder.transformer.blocks.0.decoder_layer.", cfg, g["x"], bias)
+    close(out, g["out"], atol=1e-5)
+
+
+def test_vit_matches_hf_clip_port():
+    """Un-vendored CLIP ViT arithmetic: cross-check against transformers' CLIPVisionModel (quick_gelu,
+    patch tokens before post_layernorm)."""
+    cfg, seed, g = load("hf_clip_vit.npz")
+    out = orc.vit_visual_tokens(state(cfg, seed), cfg, g["img"])
+    close(out, g["out"], atol=2e-5)
+
+
+def test_postprocess_action():
+    pose = torch.tensor([[[0.1, -0.2, 0.3, 0.0, 0.5, -0.9]]])
+    a = orc.postprocess_action(pose, torch.tensor([[[0.7]]]))
+    assert a.shape == (7,) and float(a[-1]) == 1.0
+    a = orc.postprocess_action(pose, torch.tensor([[[0.2]]]))
+    assert float(a[-1]) == -1.0
