@@ -1,0 +1,105 @@
+"""ctypes binding of libdeer_hip.so (C ABI declared in include/deer_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or fails to load, ``lib()`` raises.
+``build()`` (re)compiles it in-tree with hipcc for gfx950 (works without a GPU; used by
+``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdeer_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+P, I, L, F = c_void_p, c_int, c_long, c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/deer_hip.h one to one
+SIGNATURES = {
+    "deer_gemm_bf16_nt": [P, I, L, P, I, P, P, I, L, I, I, I, I, I, P, I, P, P],
+    "deer_gemm_skinny": [P, I, P, I, L, I, P, P, I, I, I, I, P, P],
+    "deer_skinny_splitk": [I, I, I],
+    "deer_pack_weight_mfma16": [P, P, I, I, P],
+    "deer_attn_mfma_hd64": [P, P, P, P, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
+    "deer_xattn_small": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, F, P, P],
+    "deer_mpt_attn_small": [P, I, L, I, I, P, P, F, P, F, P, I, I, P, P],
+    "deer_layernorm_rows": [P, L, L, I, I, P, P, P, P, L, L, I, F, P],
+    "deer_resadd_ln": [P, P, I, L, P, P, P, P, P, I, I, F, P, P],
+    "deer_vit_im2col": [P, I, I, I, I, P, I, P],
+    "deer_vit_embed_lnpre": [P, P, P, P, P, P, I, I, I, F, P],
+    "deer_embed_tokens": [P, P, P, P, I, I, I, I, P],
+    "deer_broadcast_rows": [P, P, L, I, P],
+    "deer_head_lstm_layer": [P, I, I, I, P, P, P, P, P, P, P, P, P, P, I, F, P, I, I, P],
+    "deer_head_fc": [P, I, I, P, P, P, P, P, P, P, P, I, P, F, P, I, I, P],
+    "deer_head_final": [P, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, P, F, P],
+    "deer_ctl_begin_step": [P, P, P],
+    "deer_hip_arch": [],
+    "deer_hip_abi_version": [],
+}
+_RESTYPE = {"deer_hip_arch": c_char_p}
+
+# constants of include/deer_hip.h
+CTL_EXIT_FLAG, CTL_EXIT_LAYER, CTL_CUR_EXIT_ID, CTL_HOLD, CTL_N_EVALS = 0, 1, 2, 3, 4
+CTL_PREV_ACTION, CTL_OUT_ACTION, CTL_DELTAS, CTL_WORDS = 8, 16, 24, 64
+EPI_BF16, EPI_F32, EPI_QGELU_BF16, EPI_GELU_BF16, EPI_RESADD_F32 = 0, 1, 2, 3, 4
+A_BF16, A_SLABS_GELU, A_SLABS = 0, 1, 2
+X_RAW, X_POOL_MAX, X_POOL_AVG, X_LN = 0, 1, 2, 3
+PRO_RAW, PRO_LN, PRO_GROUP_LN_RELU, PRO_GROUP_RELU = 0, 1, 2, 3
+KIND_PSEUDO, KIND_CHECK, KIND_COMMIT = 0, 1, 2
+THR_TYPES = {"L2": 0, "mean": 1, "max": 2, "cosine": 3}
+
+_lib = None
+
+
+class DeerHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into deer_vla_amd/lib/libdeer_hip.so (hipcc; no GPU needed)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise DeerHipError("hipcc build of libdeer_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if not os.path.isfile(LIB_PATH):
+        raise DeerHipError("build finished but %s is missing" % LIB_PATH)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load libdeer_hip.so (once).  Raises if it is not there: the engine has no other compute path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise DeerHipError(
+            f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc, gfx950).  deer_vla_amd has no CPU fallback.")
+    try:
+        l = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise DeerHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(l, name, None)
+        if fn is None:
+            raise DeerHipError(f"{LIB_PATH} does not export {name} (stale build?)")
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, c_int)
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise DeerHipError(f"{what} failed with code {rc} ({ {1: 'invalid shape/argument', 2: 'kernel launch error'}.get(rc, '?')})")
+
+
+def ptr(t, byte_offset: int = 0):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr() + byte_offset)

@@ -1,0 +1,354 @@
+// Attention kernels of the DeeR-VLA step.
+//
+//  (1) attn_mfma_kernel      - ViT-L/14 self-attention (257x257, 16 heads x 64) and Perceiver cross-attention
+//                              (64 latents x 320 keys, 8 heads x 64): MFMA, whole K/V of one head in LDS.
+//  (2) xattn_small_kernel    - gated cross-attention inside the LLM (T<=32 text tokens x 128 media tokens,
+//                              8 heads x 64): fp32 VALU, one workgroup per head.
+//  (3) mpt_attn_small_kernel - MPT causal self-attention with ALiBi, optional q/k LayerNorm over d_model and
+//                              key-padding mask (T<=32, head_dim 128): fp32 VALU, one workgroup per head.
+//
+// (2) and (3) read their q / qkv input as split-K partial slabs of the skinny GEMM and reduce them while
+// loading (launch-boundary reduce), and write a bf16 activation that is the A operand of the next GEMM.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// (1) MFMA attention, head_dim 64, kv_len <= 320.
+// Swapped QK^T (S^T = K * Q^T): after the MFMA each lane holds, for ONE query row (lane&15), four
+// consecutive keys per 16-key tile -> the softmax row reductions are in-lane + two xor-shuffles, and the
+// un-normalised P values are already in the register layout the P*V MFMA wants as its "B" operand (the
+// k-slot permutation is applied identically to the V^T operand), so P never goes through LDS.
+// ------------------------------------------------------------------------------------------------
+#define AM_HD 64
+#define AM_KPITCH 72          // K rows: 64 + 8 bf16
+#define AM_MAXT 20            // max 16-key tiles (kv_len <= 320)
+
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
+                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
+                                                        int q_len, int kv_len, int ldq, int ldk, int ldv, int ldo,
+                                                        long q_bstride, long k_bstride, long v_bstride, long o_bstride,
+                                                        float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int kvpad = (kv_len + 31) & ~31;
+  const int vpitch = kvpad + 8;
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);                 // [kvpad][72]
+  bf16_t* Vt = Ks + kvpad * AM_KPITCH;                               // [64][kvpad + 8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* Qb = Q + b * q_bstride + h * AM_HD;
+  const bf16_t* Kb = Kp + b * k_bstride + h * AM_HD;
+  const bf16_t* Vb = V + b * v_bstride + h * AM_HD;
+
+  // ---- stage K (row-major) and V (transposed) for this head; rows >= kv_len are zero ----
+  for (int idx = tid; idx < kvpad * 8; idx += 256) {
+    const int row = idx >> 3, seg = idx & 7;
+    uint4 kv = uint4{0, 0, 0, 0}, vv = uint4{0, 0, 0, 0};
+    if (row < kv_len) {
+      kv = *reinterpret_cast<const uint4*>(Kb + (long)row * ldk + seg * 8);
+      vv = *reinterpret_cast<const uint4*>(Vb + (long)row * ldv + seg * 8);
+    }
+    *reinterpret_cast<uint4*>(Ks + row * AM_KPITCH + seg * 8) = kv;
+    const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Vt[(seg * 8 + e) * vpitch + row] = ve[e];
+  }
+  __syncthreads();
+
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  if (q0 >= q_len) return;
+  const int nt = kvpad >> 4;
+
+  // Q fragments (MFMA "B" operand: B[k = d][n = query]); rows >= q_len are zero
+  bf16x8 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint4 v = uint4{0, 0, 0, 0};
+    if (q0 + c < q_len) v = *reinterpret_cast<const uint4*>(Qb + (long)(q0 + c) * ldq + ks * 32 + g * 8);
+    qf[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+
+  // ---- S^T tiles: s[t][r] = S[q = c][key = t*16 + g*4 + r] ----
+  f32x4 s[AM_MAXT];
+#pragma unroll
+  for (int t = 0; t < AM_MAXT; ++t) {
+    s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t < nt) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c) * AM_KPITCH + ks * 32 + g * 8);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+      }
+    }
+  }
+  // ---- softmax over keys (fp32) ----
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < AM_MAXT; ++t) {
+    if (t < nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 16 + g * 4 + r;
+        const float v = (key < kv_len) ? s[t][r] * scale : -INFINITY;
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < AM_MAXT; ++t) {
+    if (t < nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[t][r] - mx);
+        s[t][r] = p;
+        sum += p;
+      }
+    }
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+
+  // ---- O^T = V^T * P^T : k-slot (g, j<4) <-> key 32*ch + g*4 + j ; (g, j>=4) <-> key 32*ch + 16 + g*4 + (j-4) ----
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ch = 0; ch < AM_MAXT / 2; ++ch) {
+    if (ch * 2 < nt) {
+      uint4 pw;
+      pw.x = pack2bf(s[2 * ch][0], s[2 * ch][1]);
+      pw.y = pack2bf(s[2 * ch][2], s[2 * ch][3]);
+      pw.z = pack2bf(s[2 * ch + 1][0], s[2 * ch + 1][1]);
+      pw.w = pack2bf(s[2 * ch + 1][2], s[2 * ch + 1][3]);
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16_t* vp = Vt + (dt * 16 + c) * vpitch + ch * 32 + g * 4;
+        uint4 vw;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
+        vw.x = lo.x; vw.y = lo.y; vw.z = hi.x; vw.w = hi.y;
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[dt], 0, 0, 0);
+      }
+    }
+  }
+  // lane holds O[q = q0 + c][d = dt*16 + g*4 .. +3]
+  if (q0 + c < q_len) {
+    bf16_t* op = O + b * o_bstride + (long)(q0 + c) * ldo + h * AM_HD + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<uint2*>(op + dt * 16) =
+          uint2{pack2bf(o[dt][0] * inv, o[dt][1] * inv), pack2bf(o[dt][2] * inv, o[dt][3] * inv)};
+  }
+}
+
+extern "C" int deer_attn_mfma_hd64(const void* Q, const void* K, const void* V, void* O, int batch, int heads,
+                                   int q_len, int kv_len, int ldq, int ldk, int ldv, int ldo, long q_bstride,
+                                   long k_bstride, long v_bstride, long o_bstride, float scale, void* stream) {
+  if (q_len <= 0 || kv_len <= 0 || kv_len > AM_MAXT * 16 || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3))
+    return DEER_ERR_SHAPE;
+  const int kvpad = (kv_len + 31) & ~31;
+  const int smem = (kvpad * AM_KPITCH + AM_HD * (kvpad + 8)) * (int)sizeof(bf16_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (AM_MAXT * 16 * AM_KPITCH + AM_HD * (AM_MAXT * 16 + 8)) * 2) != hipSuccess)
+      return DEER_ERR_LAUNCH;
+    attr_set = true;
+  }
+  dim3 grid((q_len + 63) / 64, heads, batch);
+  hipLaunchKernelGGL(attn_mfma_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const bf16_t*>(Q), reinterpret_cast<const bf16_t*>(K),
+                     reinterpret_cast<const bf16_t*>(V), reinterpret_cast<bf16_t*>(O), q_len, kv_len, ldq, ldk, ldv, ldo,
+                     q_bstride, k_bstride, v_bstride, o_bstride, scale);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// (2) gated cross-attention core (open_flamingo/src/helpers.py:184-233): per head
+//     q = sum_s qslab[s][t][h*64..] * 64^-0.5 ; sim = q k^T ; mask: text_time[t] == media_time[j]
+//     (only_attend_immediate_media) ; softmax ; rows with text_time == 0 zeroed ; out = attn v.
+// kv: bf16 [n_kv][ldkv] with k at column h*64 and v at column inner + h*64.
+// ------------------------------------------------------------------------------------------------
+#define XA_MAXT 32
+#define XA_MAXKV 128
+__global__ __launch_bounds__(256) void xattn_small_kernel(const float* __restrict__ qslab, int s_in, long slab_stride,
+                                                          int ldqs, const bf16_t* __restrict__ kv, int ldkv, int inner,
+                                                          const int* __restrict__ text_time, int n_per_media,
+                                                          bf16_t* __restrict__ out, int ldo, int T, int n_kv,
+                                                          float scale, const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
+  __shared__ float qs[XA_MAXT][64 + 1];
+  __shared__ float sim[XA_MAXT][XA_MAXKV + 1];
+  __shared__ bf16_t ks[XA_MAXKV][64 + 2];
+  __shared__ bf16_t vs[XA_MAXKV][64 + 2];
+  const int h = blockIdx.x, tid = threadIdx.x;
+  for (int idx = tid; idx < T * 64; idx += 256) {
+    const int t = idx >> 6, d = idx & 63;
+    float a = 0.f;
+    for (int s = 0; s < s_in; ++s) a += qslab[(long)s * slab_stride + (long)t * ldqs + h * 64 + d];
+    qs[t][d] = a * scale;
+  }
+  for (int idx = tid; idx < n_kv * 64; idx += 256) {
+    const int j = idx >> 6, d = idx & 63;
+    ks[j][d] = kv[(long)j * ldkv + h * 64 + d];
+    vs[j][d] = kv[(long)j * ldkv + inner + h * 64 + d];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < T * n_kv; idx += 256) {
+    const int t = idx / n_kv, j = idx - t * n_kv;
+    float a = 0.f;
+#pragma unroll 16
+    for (int d = 0; d < 64; ++d) a += qs[t][d] * bf2f(ks[j][d]);
+    const int media_time = j / n_per_media + 1;
+    if (text_time[t] != media_time) a = -3.4028234663852886e38f;      // -finfo.max (helpers.py:218)
+    sim[t][j] = a;
+  }
+  __syncthreads();
+  // softmax per row: one wave per row
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int t = wave; t < T; t += 4) {
+    float mx = -INFINITY;
+    for (int j = lane; j < n_kv; j += 64) mx = fmaxf(mx, sim[t][j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < n_kv; j += 64) {
+      const float p = expf(sim[t][j] - mx);
+      sim[t][j] = p;
+      sum += p;
+    }
+    sum = wave_sum(sum);
+    const float inv = (text_time[t] == 0) ? 0.f : 1.f / sum;           // helpers.py:223-229
+    for (int j = lane; j < n_kv; j += 64) sim[t][j] *= inv;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < T * 64; idx += 256) {
+    const int t = idx >> 6, d = idx & 63;
+    float a = 0.f;
+    for (int j = 0; j < n_kv; ++j) a += sim[t][j] * bf2f(vs[j][d]);
+    out[(long)t * ldo + h * 64 + d] = f2bf(a);
+  }
+}
+
+extern "C" int deer_xattn_small(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv,
+                                int inner, const int* text_time, int n_per_media, void* out, int ldo, int T, int n_kv,
+                                int heads, float scale, const int* ctl, void* stream) {
+  if (T <= 0 || T > XA_MAXT || n_kv <= 0 || n_kv > XA_MAXKV || s_in <= 0 || n_per_media <= 0) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(xattn_small_kernel, dim3(heads), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qslab, s_in,
+                     slab_stride, ldqs, reinterpret_cast<const bf16_t*>(kv), ldkv, inner, text_time, n_per_media,
+                     reinterpret_cast<bf16_t*>(out), ldo, T, n_kv, scale, ctl);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// (3) MPT self-attention: qkv = sum_s slab[s][t][0..3d); optional LayerNorm over the
+// FULL d_model of q and of k (attn_qk_ln, weight only); per head h: softmax(q k^T / sqrt(hd) + alibi +
+// key-pad + causal) v.  alibi[h][j] = -(T-1-j) * 2^(-bias_max*(h+1)/H).  HD = head_dim <= 128.
+// ------------------------------------------------------------------------------------------------
+#define MA_MAXT 32
+__global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __restrict__ qkvslab, int s_in,
+                                                             long slab_stride, int d_model, int hd,
+                                                             const float* __restrict__ q_ln_w,
+                                                             const float* __restrict__ k_ln_w, float eps,
+                                                             const unsigned char* __restrict__ key_mask,
+                                                             float alibi_slope_base, int n_heads,
+                                                             bf16_t* __restrict__ out, int ldo, int T, const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
+  __shared__ float qs[MA_MAXT][128 + 1];
+  __shared__ float ks[MA_MAXT][128 + 1];
+  __shared__ float vs[MA_MAXT][128 + 1];
+  __shared__ float sim[MA_MAXT][MA_MAXT + 1];
+  __shared__ float stat[MA_MAXT][4];       // q mean, q rstd, k mean, k rstd
+  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ld = 3 * d_model;
+  const bool qk_ln = (q_ln_w != nullptr);
+  if (qk_ln) {
+    // full-row statistics of q and k (two-pass, like torch), one wave per (row, q|k)
+    for (int job = wave; job < 2 * T; job += 4) {
+      const int t = job >> 1, which = job & 1;
+      const long base = (long)t * ld + which * d_model;
+      float sum = 0.f;
+      for (int i = lane; i < d_model; i += 64) {
+        float a = 0.f;
+        for (int s = 0; s < s_in; ++s) a += qkvslab[(long)s * slab_stride + base + i];
+        sum += a;
+      }
+      const float mean = wave_sum(sum) / d_model;
+      float var = 0.f;
+      for (int i = lane; i < d_model; i += 64) {
+        float a = 0.f;
+        for (int s = 0; s < s_in; ++s) a += qkvslab[(long)s * slab_stride + base + i];
+        var += (a - mean) * (a - mean);
+      }
+      var = wave_sum(var) / d_model;
+      if (lane == 0) {
+        stat[t][which * 2] = mean;
+        stat[t][which * 2 + 1] = rsqrtf(var + eps);
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < T * hd; idx += 256) {
+    const int t = idx / hd, d = idx - t * hd;
+    const long base = (long)t * ld + h * hd + d;
+    float q = 0.f, k = 0.f, v = 0.f;
+    for (int s = 0; s < s_in; ++s) {
+      const float* p = qkvslab + (long)s * slab_stride + base;
+      q += p[0];
+      k += p[d_model];
+      v += p[2 * d_model];
+    }
+    if (qk_ln) {
+      q = (q - stat[t][0]) * stat[t][1] * q_ln_w[h * hd + d];
+      k = (k - stat[t][2]) * stat[t][3] * k_ln_w[h * hd + d];
+    }
+    qs[t][d] = q;
+    ks[t][d] = k;
+    vs[t][d] = v;
+  }
+  __syncthreads();
+  const float sc = rsqrtf((float)hd);
+  const float slope = exp2f(-alibi_slope_base * (float)(h + 1) / (float)n_heads);
+  for (int idx = tid; idx < T * T; idx += 256) {
+    const int i = idx / T, j = idx - i * T;
+    float a = 0.f;
+    for (int d = 0; d < hd; ++d) a += qs[i][d] * ks[j][d];
+    a = a * sc - (float)(T - 1 - j) * slope;
+    if (j > i || (key_mask != nullptr && key_mask[j] == 0)) a = -INFINITY;
+    sim[i][j] = a;
+  }
+  __syncthreads();
+  for (int i = wave; i < T; i += 4) {
+    float v = (lane < T) ? sim[i][lane] : -INFINITY;
+    const float mx = wave_max(v);
+    const float p = (lane < T) ? expf(v - mx) : 0.f;
+    const float sum = wave_sum(p);
+    if (lane < T) sim[i][lane] = p / sum;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < T * hd; idx += 256) {
+    const int t = idx / hd, d = idx - t * hd;
+    float a = 0.f;
+    for (int j = 0; j <= t; ++j) a += sim[t][j] * vs[j][d];
+    out[(long)t * ldo + h * hd + d] = f2bf(a);
+  }
+}
+
+extern "C" int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads,
+                                   const float* q_ln_w, const float* k_ln_w, float eps, const unsigned char* key_mask,
+                                   float alibi_bias_max, void* out, int ldo, int T, const int* ctl, void* stream) {
+  const int hd = d_model / n_heads;
+  if (T <= 0 || T > MA_MAXT || hd > 128 || hd * n_heads != d_model || s_in <= 0) return DEER_ERR_SHAPE;
+  if ((q_ln_w == nullptr) != (k_ln_w == nullptr)) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(mpt_attn_small_kernel, dim3(n_heads), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qkvslab,
+                     s_in, slab_stride, d_model, hd, q_ln_w, k_ln_w, eps, key_mask, alibi_bias_max, n_heads,
+                     reinterpret_cast<bf16_t*>(out), ldo, T, ctl);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}

@@ -1,0 +1,91 @@
+// Shared device helpers for the DeeR-VLA gfx950 kernels (CDNA4: wave64, MFMA 16x16x32 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // bf16 storage type in HBM / LDS
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define DEER_WAVE 64
+
+// Error codes returned by every extern "C" entry point (0 = ok).
+#define DEER_OK 0
+#define DEER_ERR_SHAPE 1
+#define DEER_ERR_LAUNCH 2
+
+// Device-side control block shared by the LLM-layer kernels and the action-head kernels
+// (int32 words; see include/deer_hip.h for the ABI view).
+#define CTL_EXIT_FLAG 0     // 1 once the exit criterion fired in this step -> later kernels return at entry
+#define CTL_EXIT_LAYER 1    // layer index the step exited at
+#define CTL_CUR_EXIT_ID 2   // ExitController.cur_exit_id (value_net.py:285-286,294)
+#define CTL_HOLD 3          // 1 when cur_step % steps_per_stage != 0 (reuse cur_exit_id)
+#define CTL_N_EVALS 4       // number of head evaluations executed this step (diagnostics)
+#define CTL_PREV_ACTION 8   // float[8]: action_list[-1] (pose6, gripper, pad)
+#define CTL_OUT_ACTION 16   // float[8]: committed action (pose6, gripper prob, gripper logit)
+#define CTL_DELTAS 24       // float[16]: delta per exit slot of this step (NaN = not evaluated)
+#define CTL_WORDS 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved (same as torch .to(bfloat16))
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (red must hold >= 16 floats of LDS).
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = -INFINITY;
+  for (int i = 0; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// Kernels on the early-exit path return at entry once the exit flag is set (device-side
+// termination: no host round trip per layer).
+#define DEER_RETURN_IF_EXITED(ctl) \
+  do {                             \
+    if ((ctl) != nullptr && ((const volatile int*)(ctl))[CTL_EXIT_FLAG] != 0) return; \
+  } while (0)
+
+#define DEER_LAUNCH_CHECK()                                   \
+  do {                                                        \
+    hipError_t e_ = hipGetLastError();                        \
+    if (e_ != hipSuccess) return DEER_ERR_LAUNCH;             \
+  } while (0)

@@ -1,0 +1,167 @@
+// Skinny (M <= 32 rows) bf16 MFMA GEMM for the weight-bandwidth-bound part of the step: the MPT blocks
+// and gated x-attn layers at T ~ 14 text tokens (174 MB of weights per layer for 2.7 GFLOP).
+//
+//   part[ks][m][n] = sum_{k in K-slice ks} A[m,k] * W[n,k]          (f32 partial slabs, split-K)
+//
+// gfx950 design notes
+//  * HBM-bound: the only thing that matters is streaming W once at full bandwidth.  W is PRE-PACKED at
+//    load time into MFMA-fragment order  Wp[N/16][K/32][64 lanes][8 bf16]  (deer_pack_weight_mfma16) so
+//    every wave-level load is one fully coalesced, contiguous 1 KiB read (no 64-byte row striding),
+//    issued non-temporal (each byte is used exactly once per step).
+//  * One wave = one 16-column tile over the block's K-slice; 8 fragment loads are kept in flight per
+//    wave (deep unroll, late wait) and the weights go straight to VGPRs - an LDS round trip would be pure
+//    overhead for an operand that is not shared between waves.
+//  * The tiny activation slice A[<=32][KS] is staged once per block in LDS (bf16, padded rows) and read
+//    back as MFMA fragments with ds_read_b128; operands are swapped (W fragment = MFMA "A") so each lane
+//    ends up with 4 consecutive output columns -> 16-byte stores.
+//  * Split-K partials are written as slabs and summed by the CONSUMER kernel's prologue (residual+LN,
+//    attention, or the next GEMM's A-staging which also applies the exact GELU).  No atomics, no
+//    in-kernel cross-workgroup hand-off: deterministic, and a kernel boundary (~1.5 us) is cheaper than
+//    a grid barrier on this chip (MI355X_MICROARCH price list).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define GS_UNROLL 8
+
+enum { A_BF16 = 0, A_SLABS_GELU = 1, A_SLABS = 2 };
+
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ A, int lda,
+                                                          const float* __restrict__ Aslab, int s_in, long slab_stride_in,
+                                                          int a_mode, const bf16_t* __restrict__ Wp,
+                                                          float* __restrict__ part, int M, int N, int K, int KS,
+                                                          const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
+  constexpr int MPAD = MT * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);      // [MPAD][KS + 8]
+  const int pitch = KS + 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int ks = blockIdx.y, k0 = ks * KS;
+  const int klen = min(KS, K - k0);                       // multiple of 32
+
+  // ---- stage the activation slice (rows >= M are zero) ----
+  if (a_mode == A_BF16) {
+    const int segs = klen >> 3;
+    for (int idx = tid; idx < MPAD * segs; idx += 256) {
+      const int row = idx / segs, seg = idx - row * segs;
+      uint4 v = uint4{0, 0, 0, 0};
+      if (row < M) v = *reinterpret_cast<const uint4*>(A + (long)row * lda + k0 + seg * 8);
+      *reinterpret_cast<uint4*>(As + row * pitch + seg * 8) = v;
+    }
+  } else {
+    const int segs = klen >> 2;
+    for (int idx = tid; idx < MPAD * segs; idx += 256) {
+      const int row = idx / segs, seg = idx - row * segs;
+      float4 s = float4{0.f, 0.f, 0.f, 0.f};
+      if (row < M) {
+        const float* p = Aslab + (long)row * K + k0 + seg * 4;
+        for (int i = 0; i < s_in; ++i) {
+          const float4 v = *reinterpret_cast<const float4*>(p + (long)i * slab_stride_in);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (a_mode == A_SLABS_GELU) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
+      }
+      *reinterpret_cast<uint2*>(As + row * pitch + seg * 4) = uint2{pack2bf(s.x, s.y), pack2bf(s.z, s.w)};
+    }
+  }
+  __syncthreads();
+
+  const int tile = blockIdx.x * 4 + wave;                 // 16-column tile of this wave
+  if (tile * 16 >= N) return;
+  const int ktiles = K >> 5;
+  const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + ((long)tile * ktiles + (k0 >> 5)) * 64 + lane;
+  const bf16_t* as = As + c * pitch + g * 8;
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = klen >> 5;
+  int kt = 0;
+  for (; kt + GS_UNROLL <= nkt; kt += GS_UNROLL) {
+    u32x4 w[GS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < GS_UNROLL; ++u) w[u] = __builtin_nontemporal_load(wp + (long)(kt + u) * 64);
+    __builtin_amdgcn_sched_barrier(0);   // keep all GS_UNROLL weight loads in flight before the first MFMA
+#pragma unroll
+    for (int u = 0; u < GS_UNROLL; ++u) {
+      const bf16x8 wf = __builtin_bit_cast(bf16x8, w[u]);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(as + j * 16 * pitch + (kt + u) * 32);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  for (; kt < nkt; ++kt) {
+    const bf16x8 wf = __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(wp + (long)kt * 64));
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(as + j * 16 * pitch + kt * 32);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[j], 0, 0, 0);
+    }
+  }
+  // lane holds part[m = j*16 + c][n = tile*16 + g*4 .. +3]
+  float* dst = part + ((long)ks * MPAD) * N + tile * 16 + g * 4;
+#pragma unroll
+  for (int j = 0; j < MT; ++j)
+    *reinterpret_cast<float4*>(dst + (long)(j * 16 + c) * N) = float4{acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+}
+
+// ---- weight packing: row-major W[N,K] bf16 -> Wp[N/16][K/32][64][8] (done once at load time) ----
+__global__ void pack_weight_kernel(const bf16_t* __restrict__ W, bf16_t* __restrict__ Wp, int N, int K) {
+  const long total = (long)(N >> 4) * (K >> 5) * 64;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    const long tk = idx >> 6;
+    const int kt = (int)(tk % (K >> 5));
+    const int tile = (int)(tk / (K >> 5));
+    const int n = tile * 16 + (lane & 15), k = kt * 32 + (lane >> 4) * 8;
+    *reinterpret_cast<uint4*>(Wp + idx * 8) = *reinterpret_cast<const uint4*>(W + (long)n * K + k);
+  }
+}
+
+extern "C" int deer_pack_weight_mfma16(const void* W, void* Wp, int N, int K, void* stream) {
+  if (N <= 0 || K <= 0 || (N & 15) || (K & 31)) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(1024), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const bf16_t*>(W), reinterpret_cast<bf16_t*>(Wp), N, K);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// Suggested split-K for a skinny GEMM: enough workgroups to cover the chip (~2 per CU) while each wave
+// still streams >= 8 KiB, and an LDS slice <= 32 KiB.  Deterministic function of the shape.
+extern "C" int deer_skinny_splitk(int M, int N, int K) {
+  const int mt = (M > 16) ? 2 : 1;
+  const int max_ks = 1024 / mt;
+  const int groups = (N + 63) / 64;
+  int s = 1;
+  while ((K / s) > max_ks) s *= 2;
+  while (groups * s < 512 && (K / (s * 2)) >= 256 && (K % (s * 2 * 32)) == 0) s *= 2;
+  return s;
+}
+
+extern "C" int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int s_in, long slab_stride_in, int a_mode,
+                                const void* Wp, float* part, int M, int N, int K, int splitk, const int* ctl,
+                                void* stream) {
+  if (M <= 0 || M > 32 || N <= 0 || (N & 15) || K <= 0 || (K & 31) || splitk <= 0 || (K % (splitk * 32)) != 0)
+    return DEER_ERR_SHAPE;
+  if (a_mode == A_BF16 ? (A == nullptr || (lda & 7)) : (Aslab == nullptr || s_in <= 0)) return DEER_ERR_SHAPE;
+  const int KS = K / splitk;
+  const int mt = (M > 16) ? 2 : 1;
+  const int smem = mt * 16 * (KS + 8) * (int)sizeof(bf16_t);
+  if (smem > 64 * 1024) return DEER_ERR_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((N + 63) / 64, splitk);
+  if (mt == 1)
+    hipLaunchKernelGGL((gemm_skinny_kernel<1>), grid, dim3(256), smem, st, reinterpret_cast<const bf16_t*>(A), lda,
+                       Aslab, s_in, slab_stride_in, a_mode, reinterpret_cast<const bf16_t*>(Wp), part, M, N, K, KS, ctl);
+  else
+    hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, dim3(256), smem, st, reinterpret_cast<const bf16_t*>(A), lda,
+                       Aslab, s_in, slab_stride_in, a_mode, reinterpret_cast<const bf16_t*>(Wp), part, M, N, K, KS, ctl);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}

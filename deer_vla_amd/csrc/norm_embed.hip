@@ -1,0 +1,201 @@
+// Row-wise kernels of the DeeR-VLA step: LayerNorm, fused "split-K reduce + gated residual + LayerNorm",
+// ViT patch im2col and cls/pos/ln_pre embedding, token embedding, media-time bookkeeping.
+// All statistics are fp32 two-pass (mean, then biased variance), eps 1e-5, like torch.nn.LayerNorm.
+#include "common.h"
+
+// ---- LayerNorm over rows: f32 in -> bf16 out (GEMM A operand) and/or f32 out -------------------------
+// Row r of batch b is read at  x + b*in_bstride + r*in_rstride  and written at  out + b*out_bstride + r*out_rstride
+// (lets the Perceiver write LN_media(x) and LN_latents(latents) into one [x; latents] buffer, helpers.py:51).
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, long in_rstride, long in_bstride,
+                                                      int rows_per_batch, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16_t* __restrict__ out_bf,
+                                                      float* __restrict__ out_f32, long out_rstride, long out_bstride,
+                                                      int C, float eps) {
+  __shared__ float red[16];
+  const int b = blockIdx.x / rows_per_batch, r = blockIdx.x - b * rows_per_batch;
+  const float* xr = x + b * in_bstride + r * in_rstride;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < C; i += 256) s += xr[i];
+  const float mean = block_sum(s, red) / C;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < C; i += 256) {
+    const float d = xr[i] - mean;
+    v += d * d;
+  }
+  const float rstd = rsqrtf(block_sum(v, red) / C + eps);
+  const long o = b * out_bstride + r * out_rstride;
+  for (int i = threadIdx.x; i < C; i += 256) {
+    float y = (xr[i] - mean) * rstd * gamma[i];
+    if (beta != nullptr) y += beta[i];
+    if (out_bf != nullptr) out_bf[o + i] = f2bf(y);
+    if (out_f32 != nullptr) out_f32[o + i] = y;
+  }
+}
+
+extern "C" int deer_layernorm_rows(const float* x, long in_rstride, long in_bstride, int rows_per_batch, int batch,
+                                   const float* gamma, const float* beta, void* out_bf16, float* out_f32,
+                                   long out_rstride, long out_bstride, int C, float eps, void* stream) {
+  if (rows_per_batch <= 0 || batch <= 0 || C <= 0 || gamma == nullptr || (out_bf16 == nullptr && out_f32 == nullptr))
+    return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(ln_rows_kernel, dim3(rows_per_batch * batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     x, in_rstride, in_bstride, rows_per_batch, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16),
+                     out_f32, out_rstride, out_bstride, C, eps);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// ---- LLM row op: x += scale * sum_s slab[s] ; [copy x] ; [LN(x) -> bf16] ------------------------------
+// The consumer-side half of the skinny GEMM's split-K (launch-boundary reduce) fused with the gated
+// residual update (helpers.py:267-279: x + tanh(gate) * y; MPT block: x + y) and the following LayerNorm.
+__global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, const float* __restrict__ slab, int s_in,
+                                                        long slab_stride, const float* __restrict__ gate,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        bf16_t* __restrict__ out_bf, float* __restrict__ x_copy, int d,
+                                                        float eps, const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  float* xr = x + (long)r * d;
+  if (slab != nullptr) {
+    const float sc = (gate != nullptr) ? tanhf(*gate) : 1.f;
+    for (int i = threadIdx.x; i < d; i += 256) {
+      float a = 0.f;
+      for (int s = 0; s < s_in; ++s) a += slab[(long)s * slab_stride + (long)r * d + i];
+      xr[i] += sc * a;
+    }
+  }
+  if (x_copy != nullptr)
+    for (int i = threadIdx.x; i < d; i += 256) x_copy[(long)r * d + i] = xr[i];
+  if (gamma == nullptr) return;
+  // each thread re-reads only the elements it wrote itself -> no barrier needed before the statistics
+  float s = 0.f;
+  for (int i = threadIdx.x; i < d; i += 256) s += xr[i];
+  const float mean = block_sum(s, red) / d;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    const float dd = xr[i] - mean;
+    v += dd * dd;
+  }
+  const float rstd = rsqrtf(block_sum(v, red) / d + eps);
+  for (int i = threadIdx.x; i < d; i += 256) {
+    float y = (xr[i] - mean) * rstd * gamma[i];
+    if (beta != nullptr) y += beta[i];
+    out_bf[(long)r * d + i] = f2bf(y);
+  }
+}
+
+extern "C" int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_stride, const float* gate,
+                              const float* gamma, const float* beta, void* out_bf16, float* x_copy, int T, int d,
+                              float eps, const int* ctl, void* stream) {
+  if (T <= 0 || d <= 0 || (slab != nullptr && s_in <= 0) || (gamma != nullptr && out_bf16 == nullptr)) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(resadd_ln_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in,
+                     slab_stride, gate, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), x_copy, d, eps, ctl);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// ---- ViT patch embedding, step 1: im2col of 14x14/14 patches -> bf16 [N*P, Kpad] -----------------------
+// k = ch*p*p + py*p + px matches conv1.weight[W,3,p,p].reshape(W, 3*p*p); columns >= 3*p*p are zero.
+__global__ void im2col_kernel(const void* __restrict__ img, int img_is_bf16, int N, int S, int p, int gw,
+                              bf16_t* __restrict__ out, int Kpad) {
+  const long total = (long)N * gw * gw * Kpad;
+  const int kk = 3 * p * p;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % Kpad);
+    const long row = idx / Kpad;
+    bf16_t v = 0;
+    if (k < kk) {
+      const int P = gw * gw;
+      const int n = (int)(row / P), pi = (int)(row - (long)n * P);
+      const int gy = pi / gw, gx = pi - gy * gw;
+      const int ch = k / (p * p), rem = k - ch * p * p, py = rem / p, px = rem - py * p;
+      const long src = (((long)n * 3 + ch) * S + (gy * p + py)) * S + gx * p + px;
+      v = img_is_bf16 ? reinterpret_cast<const bf16_t*>(img)[src] : f2bf(reinterpret_cast<const float*>(img)[src]);
+    }
+    out[idx] = v;
+  }
+}
+
+extern "C" int deer_vit_im2col(const void* img, int img_is_bf16, int N, int S, int patch, void* out, int Kpad,
+                               void* stream) {
+  if (N <= 0 || S <= 0 || patch <= 0 || S % patch != 0 || Kpad < 3 * patch * patch) return DEER_ERR_SHAPE;
+  const int gw = S / patch;
+  const long total = (long)N * gw * gw * Kpad;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), img, img_is_bf16,
+                     N, S, patch, gw, reinterpret_cast<bf16_t*>(out), Kpad);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// ---- ViT patch embedding, step 2: [cls ; patches] + positional embedding, then ln_pre ----
+__global__ __launch_bounds__(256) void vit_embed_lnpre_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
+                                                              const float* __restrict__ pos, const float* __restrict__ g,
+                                                              const float* __restrict__ bta, float* __restrict__ x, int P,
+                                                              int W, float eps) {
+  __shared__ float red[16];
+  const int row = blockIdx.x, n = row / (P + 1), t = row - n * (P + 1);
+  const float* src = (t == 0) ? cls : patch + ((long)n * P + (t - 1)) * W;
+  const float* pp = pos + (long)t * W;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < W; i += 256) s += src[i] + pp[i];
+  const float mean = block_sum(s, red) / W;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < W; i += 256) {
+    const float d = src[i] + pp[i] - mean;
+    v += d * d;
+  }
+  const float rstd = rsqrtf(block_sum(v, red) / W + eps);
+  for (int i = threadIdx.x; i < W; i += 256) x[(long)row * W + i] = (src[i] + pp[i] - mean) * rstd * g[i] + bta[i];
+}
+
+extern "C" int deer_vit_embed_lnpre(const float* patch, const float* cls, const float* pos, const float* ln_w,
+                                    const float* ln_b, float* x, int N, int P, int W, float eps, void* stream) {
+  if (N <= 0 || P <= 0 || W <= 0) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(vit_embed_lnpre_kernel, dim3(N * (P + 1)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), patch,
+                     cls, pos, ln_w, ln_b, x, P, W, eps);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// ---- token embedding (mosaic_gpt_3b.py:341) + media bookkeeping (flamingo_lm.py:211, helpers.py:208) ----
+// x[t] = wte[ids[t]] (bf16 table -> f32 residual stream); text_time[t] = cumsum(ids == media_token_id).
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* __restrict__ ids, const bf16_t* __restrict__ wte,
+                                                           float* __restrict__ x, int* __restrict__ text_time, int T, int d,
+                                                           int vocab, int media_id) {
+  const int t = blockIdx.x;
+  long long id = ids[t];
+  if (id < 0) id = 0;
+  if (id >= vocab) id = vocab - 1;
+  for (int i = threadIdx.x; i < d; i += 256) x[(long)t * d + i] = bf2f(wte[id * d + i]);
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int j = 0; j <= t; ++j) c += (ids[j] == media_id) ? 1 : 0;
+    text_time[t] = c;
+  }
+}
+
+extern "C" int deer_embed_tokens(const long long* ids, const void* wte, float* x, int* text_time, int T, int d, int vocab,
+                                 int media_id, void* stream) {
+  if (T <= 0 || d <= 0 || vocab <= 0) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ids,
+                     reinterpret_cast<const bf16_t*>(wte), x, text_time, T, d, vocab, media_id);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// ---- broadcast a [rows, C] f32 parameter to `batch` copies (Perceiver latents, helpers.py:128) -------------
+__global__ void broadcast_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long n, int batch) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n * batch; i += (long)gridDim.x * blockDim.x)
+    dst[i] = src[i % n];
+}
+
+extern "C" int deer_broadcast_rows(const float* src, float* dst, long n, int batch, void* stream) {
+  if (n <= 0 || batch <= 0) return DEER_ERR_SHAPE;
+  const long total = n * batch;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, n,
+                     batch);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}

@@ -1,0 +1,528 @@
+"""MI355X execution engine for one DeeR-VLA control step.
+
+Owns the device-resident weights (bf16, the LLM ones pre-packed into MFMA-fragment order), the static
+workspace, the device-side exit control block, and the order in which the HIP kernels of
+``libdeer_hip.so`` are enqueued.  A whole control step (2x ViT-L/14 -> 2x Perceiver -> MPT layers with gated
+x-attn -> action-head evaluations at the exit layers) is enqueued WITHOUT any host synchronisation: the exit
+criterion is evaluated on the device and later kernels return at entry once it fired, so the step can be
+captured once into a HIP graph and replayed (``DeerEngine.step``); the host reads {exit_layer, action} once.
+
+Reference path being replaced: ``ModelWrapper.step`` -> ``MPTFlamingo.forward``
+(robot_flamingo/eval/eval_utils.py:279-480, robot_flamingo/models/flamingo_mpt.py:308-461).
+
+PyTorch is plumbing here (device allocations, streams, graph capture, H2D/D2H copies); every FLOP of the step
+runs in this repo's hand-written gfx950 kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _abi as abi
+from .config import DeerConfig
+from .synthetic import mlp_layer_indices
+
+EPS = 1e-5
+
+
+def _cur_stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class DeerEngine:
+    def __init__(self, cfg: DeerConfig, state_dict: Dict[str, torch.Tensor], device="cuda", max_text_len: int = 32,
+                 n_cams: int = 2, threshold_type: str = "L2", leq: bool = True):
+        if not torch.cuda.is_available():
+            raise abi.DeerHipError("DeerEngine needs a HIP device (no CPU fallback exists in deer_vla_amd)")
+        self.lib = abi.lib()
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        self.n_cams = n_cams
+        self.max_T = max_text_len
+        self.thr_type = abi.THR_TYPES[threshold_type]
+        self.leq = 1 if leq else 0
+        assert cfg.vit_head_dim == 64 and cfg.perc_dim_head == 64 and cfg.xattn_dim_head == 64, "head_dim 64 kernels"
+        assert cfg.head_dim <= 128 and cfg.d_model % 32 == 0
+        assert cfg.n_media <= 128, "xattn_small kernel holds <=128 media tokens"
+        self._keep: List[torch.Tensor] = []
+        self._load_weights(state_dict)
+        self._alloc_workspace()
+        self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
+        # controller configuration (set by configure_exit)
+        self.exit_ids = cfg.exit_ids()
+        self.ctl_max_layer = self.exit_ids[-1]
+        self.steps_per_stage = 1
+        self.reset()
+
+    # ------------------------------------------------------------------------------------------ weights
+    def _dev(self, t: torch.Tensor, dtype) -> torch.Tensor:
+        return t.detach().to(device=self.dev, dtype=dtype).contiguous()
+
+    def _bf(self, t):
+        return self._dev(t, torch.bfloat16)
+
+    def _f32(self, t):
+        return self._dev(t, torch.float32)
+
+    def _packed(self, t: torch.Tensor) -> torch.Tensor:
+        """row-major [N,K] -> MFMA-fragment order for the skinny GEMM (deer_pack_weight_mfma16)."""
+        w = self._bf(t)
+        N, K = w.shape
+        out = torch.empty_like(w)
+        abi.check(self.lib.deer_pack_weight_mfma16(abi.ptr(w), abi.ptr(out), N, K, _cur_stream()), "pack_weight")
+        torch.cuda.current_stream().synchronize()
+        return out
+
+    def _load_weights(self, sd: Dict[str, torch.Tensor]):
+        cfg = self.cfg
+        W = cfg.vit_width
+        g = lambda k: sd[k]
+        self.vit = {}
+        v = "vision_encoder.visual."
+        kk = 3 * cfg.patch_size ** 2
+        self.patch_kpad = (kk + 63) // 64 * 64
+        conv = g(v + "conv1.weight").reshape(W, kk)
+        convp = torch.zeros(W, self.patch_kpad, dtype=conv.dtype, device=conv.device)
+        convp[:, :kk] = conv
+        self.vit["conv"] = self._bf(convp)
+        self.vit["cls"] = self._f32(g(v + "class_embedding"))
+        self.vit["pos"] = self._f32(g(v + "positional_embedding"))
+        self.vit["ln_pre_w"], self.vit["ln_pre_b"] = self._f32(g(v + "ln_pre.weight")), self._f32(g(v + "ln_pre.bias"))
+        self.vit_layers = []
+        for l in range(cfg.vit_layers):
+            p = f"{v}transformer.resblocks.{l}."
+            self.vit_layers.append(dict(
+                ln1w=self._f32(g(p + "ln_1.weight")), ln1b=self._f32(g(p + "ln_1.bias")),
+                wqkv=self._bf(g(p + "attn.in_proj_weight")), bqkv=self._f32(g(p + "attn.in_proj_bias")),
+                wo=self._bf(g(p + "attn.out_proj.weight")), bo=self._f32(g(p + "attn.out_proj.bias")),
+                ln2w=self._f32(g(p + "ln_2.weight")), ln2b=self._f32(g(p + "ln_2.bias")),
+                wfc=self._bf(g(p + "mlp.c_fc.weight")), bfc=self._f32(g(p + "mlp.c_fc.bias")),
+                wpr=self._bf(g(p + "mlp.c_proj.weight")), bpr=self._f32(g(p + "mlp.c_proj.bias"))))
+        self.perc = dict(latents=self._f32(g("perceiver.latents")), normw=self._f32(g("perceiver.norm.weight")),
+                         normb=self._f32(g("perceiver.norm.bias")))
+        self.perc_layers = []
+        for l in range(cfg.perc_depth):
+            a, f = f"perceiver.layers.{l}.0.", f"perceiver.layers.{l}.1."
+            self.perc_layers.append(dict(
+                nmw=self._f32(g(a + "norm_media.weight")), nmb=self._f32(g(a + "norm_media.bias")),
+                nlw=self._f32(g(a + "norm_latents.weight")), nlb=self._f32(g(a + "norm_latents.bias")),
+                wq=self._bf(g(a + "to_q.weight")), wkv=self._bf(g(a + "to_kv.weight")), wo=self._bf(g(a + "to_out.weight")),
+                fnw=self._f32(g(f + "0.weight")), fnb=self._f32(g(f + "0.bias")),
+                w1=self._bf(g(f + "1.weight")), w2=self._bf(g(f + "3.weight"))))
+        # ---- LLM ----
+        self.wte = self._bf(g("lang_encoder.transformer.wte.weight"))
+        nine_b = cfg.llm_name == "mpt_9b"
+        ln1, ln2 = ("norm_1", "norm_2") if nine_b else ("ln_1", "ln_2")
+        up, down = ("ffn.up_proj", "ffn.down_proj") if nine_b else ("mlp.mlp_up", "mlp.mlp_down")
+        self.llm_layers = []
+        kv_rows = []
+        for n in range(cfg.n_layers):
+            blk = f"lang_encoder.transformer.blocks.{n}."
+            L = {}
+            if cfg.has_xattn(n):
+                x = blk + "gated_cross_attn_layer."
+                L["xa"] = dict(nw=self._f32(g(x + "attn.norm.weight")), nb=self._f32(g(x + "attn.norm.bias")),
+                               wq=self._packed(g(x + "attn.to_q.weight")), wo=self._packed(g(x + "attn.to_out.weight")),
+                               ag=self._f32(g(x + "attn_gate")), fg=self._f32(g(x + "ff_gate")),
+                               fnw=self._f32(g(x + "ff.0.weight")), fnb=self._f32(g(x + "ff.0.bias")),
+                               w1=self._packed(g(x + "ff.1.weight")), w2=self._packed(g(x + "ff.3.weight")),
+                               kv_index=len(kv_rows))
+                kv_rows.append(g(x + "attn.to_kv.weight"))
+            m = blk + "decoder_layer."
+            L["ln1w"] = self._f32(g(m + ln1 + ".weight"))
+            L["ln1b"] = self._f32(sd[m + ln1 + ".bias"]) if (m + ln1 + ".bias") in sd else None
+            L["wqkv"] = self._packed(g(m + "attn.Wqkv.weight"))
+            L["qlnw"] = self._f32(g(m + "attn.q_ln.weight")) if cfg.attn_qk_ln else None
+            L["klnw"] = self._f32(g(m + "attn.k_ln.weight")) if cfg.attn_qk_ln else None
+            L["wo"] = self._packed(g(m + "attn.out_proj.weight"))
+            L["ln2w"] = self._f32(g(m + ln2 + ".weight"))
+            L["ln2b"] = self._f32(sd[m + ln2 + ".bias"]) if (m + ln2 + ".bias") in sd else None
+            L["wup"] = self._packed(g(m + up + ".weight"))
+            L["wdown"] = self._packed(g(m + down + ".weight"))
+            self.llm_layers.append(L)
+        # K/V projections of the media tokens for ALL x-attn layers in one GEMM (media is layer-invariant)
+        self.n_xattn = len(kv_rows)
+        self.xinner = cfg.xattn_heads * cfg.xattn_dim_head
+        self.wkv_all = self._bf(torch.cat(kv_rows, dim=0)) if kv_rows else None
+        # ---- head ----
+        self.head = self._load_head(sd, "extra_exit.")
+
+    def _load_head(self, sd, p):
+        cfg = self.cfg
+        H = {"lstm": [], "fc": []}
+        for l in range(cfg.lstm_num_layers):
+            if cfg.lstm_layernorm:
+                r, sfx = f"{p}rnn.layers.{3 * l}.", "_l0"
+            else:
+                r, sfx = f"{p}rnn.", f"_l{l}"
+            d = dict(wih=self._bf(sd[r + "weight_ih" + sfx]), whh=self._bf(sd[r + "weight_hh" + sfx]),
+                     bih=self._f32(sd[r + "bias_ih" + sfx]), bhh=self._f32(sd[r + "bias_hh" + sfx]))
+            if cfg.lstm_layernorm:
+                d["lnw"] = self._f32(sd[f"{p}rnn.layers.{3 * l + 1}.weight"])
+                d["lnb"] = self._f32(sd[f"{p}rnn.layers.{3 * l + 1}.bias"])
+            H["lstm"].append(d)
+        lin, ln, out = mlp_layer_indices(cfg.mlp_num_hidden_layers)
+        for li, ni in zip(lin, ln):
+            d = {}
+            for gi, hname in enumerate(("actions", "gripper")):
+                d[f"w{gi}"] = self._bf(sd[f"{p}{hname}.mlp.{li}.weight"])
+                d[f"b{gi}"] = self._f32(sd[f"{p}{hname}.mlp.{li}.bias"])
+                if cfg.mlp_layernorm:
+                    d[f"lnw{gi}"] = self._f32(sd[f"{p}{hname}.mlp.{ni}.weight"])
+                    d[f"lnb{gi}"] = self._f32(sd[f"{p}{hname}.mlp.{ni}.bias"])
+            H["fc"].append(d)
+        H["wa"], H["ba"] = self._bf(sd[f"{p}actions.mlp.{out}.weight"]), self._f32(sd[f"{p}actions.mlp.{out}.bias"])
+        H["wg"], H["bg"] = self._bf(sd[f"{p}gripper.mlp.{out}.weight"]), self._f32(sd[f"{p}gripper.mlp.{out}.bias"])
+        return H
+
+    # ---------------------------------------------------------------------------------------- workspace
+    def _alloc_workspace(self):
+        cfg, dev = self.cfg, self.dev
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        bf = torch.bfloat16
+        N, P, W, S = self.n_cams, cfg.n_patches, cfg.vit_width, cfg.image_size
+        R = N * (P + 1)
+        self.img = z(N, 3, S, S, dt=bf)                      # static input buffer (both cameras batched)
+        self.im2col = z(N * P, self.patch_kpad, dt=bf)
+        self.patch_out = z(N * P, W)
+        self.vx = z(N, P + 1, W)                             # ViT residual stream (fp32)
+        self.v_ln = z(R, W, dt=bf)
+        self.v_qkv = z(R, 3 * W, dt=bf)
+        self.v_ao = z(R, W, dt=bf)
+        self.v_h = z(R, cfg.vit_mlp, dt=bf)
+        nl, inner = cfg.perc_latents, cfg.perc_heads * cfg.perc_dim_head
+        self.p_lat = z(N, nl, W)
+        self.p_kvin = z(N, P + nl, W, dt=bf)
+        self.p_q = z(N * nl, inner, dt=bf)
+        self.p_kv = z(N * (P + nl), 2 * inner, dt=bf)
+        self.p_ao = z(N * nl, inner, dt=bf)
+        self.p_ln = z(N * nl, W, dt=bf)
+        self.p_h = z(N * nl, cfg.perc_ff_mult * W, dt=bf)
+        self.vis_x = z(N * nl, W, dt=bf)                     # media tokens [rgb latents ; gripper latents]
+        self.vis_x_f32 = z(N * nl, W)
+        self.kv_all = z(N * nl, max(self.n_xattn, 1) * 2 * self.xinner, dt=bf)
+        d, T = cfg.d_model, self.max_T
+        self.ids = torch.zeros(T, dtype=torch.int64, device=dev)
+        self.key_mask = torch.ones(T, dtype=torch.uint8, device=dev)
+        self.text_time = torch.zeros(T, dtype=torch.int32, device=dev)
+        self.x = z(T, d)
+        self.xn = z(T, d, dt=bf)
+        self.ao = z(T, max(d, self.xinner), dt=bf)
+        max_n = max(cfg.mlp_ratio * d, cfg.xattn_ff_mult * d, 3 * d)
+        self.max_split = 32
+        self.slab_a = z(self.max_split * 32 * d)             # outputs of width d (residual branches)
+        self.slab_b = z(16 * 32 * max_n)                     # outputs of width 3d / 4d / inner
+        self.hidden = z(cfg.n_layers, T, d)                  # hidden_states[i] = output of layer i
+        Lh, H = cfg.lstm_num_layers, cfg.head_hidden
+        self.h_state, self.c_state = z(Lh, H), z(Lh, H)
+        self.h_tmp, self.c_tmp = z(Lh, H), z(Lh, H)
+        dims = cfg.mlp_hidden_dims
+        self.z_fc = [z(2 * dm) for dm in dims]
+        self.ctl = torch.zeros(abi.CTL_WORDS, dtype=torch.int32, device=dev)
+        self.ctl_host = torch.zeros(abi.CTL_WORDS, dtype=torch.int32).pin_memory()
+        self.hold_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.thresholds = torch.full((16,), 1e8, dtype=torch.float32, device=dev)
+        self.action_dbg = z(8)
+
+    # ------------------------------------------------------------------------------------- small helpers
+    def _gemm(self, A, W, C, M, N, K, epi, bias=None, gate=None, lda=None, ldc=None, batch=1, strideA=0, strideC=0,
+              tile=0, a_off=0, c_off=0):
+        lda = K if lda is None else lda
+        ldc = N if ldc is None else ldc
+        abi.check(self.lib.deer_gemm_bf16_nt(abi.ptr(A, a_off), lda, strideA, abi.ptr(W), K, abi.ptr(bias), abi.ptr(C, c_off),
+                                             ldc, strideC, M, N, K, batch, epi, abi.ptr(gate), tile, None, _cur_stream()),
+                  "deer_gemm_bf16_nt")
+
+    def _ln(self, x, gamma, beta, out_bf, rows, C, in_rstride=None, in_bstride=0, batch=1, out_rstride=None, out_bstride=0,
+            x_off=0, out_off=0, out_f32=None):
+        in_rstride = C if in_rstride is None else in_rstride
+        out_rstride = C if out_rstride is None else out_rstride
+        abi.check(self.lib.deer_layernorm_rows(abi.ptr(x, x_off), in_rstride, in_bstride, rows, batch, abi.ptr(gamma), abi.ptr(beta),
+                                               abi.ptr(out_bf, out_off), abi.ptr(out_f32), out_rstride, out_bstride, C, EPS,
+                                               _cur_stream()), "deer_layernorm_rows")
+
+    # ------------------------------------------------------------------------------------------ vision
+    def enqueue_vision(self):
+        """ViT-L/14 on both camera frames (batched, the reference runs them separately: flamingo_mpt.py:626,633),
+        Perceiver on each, concat -> vis_x, then K/V of every x-attn layer."""
+        cfg, lib, st = self.cfg, self.lib, _cur_stream()
+        N, P, W = self.n_cams, cfg.n_patches, cfg.vit_width
+        R = N * (P + 1)
+        abi.check(lib.deer_vit_im2col(abi.ptr(self.img), 1, N, cfg.image_size, cfg.patch_size, abi.ptr(self.im2col),
+                                      self.patch_kpad, st), "im2col")
+        self._gemm(self.im2col, self.vit["conv"], self.patch_out, N * P, W, self.patch_kpad, abi.EPI_F32)
+        abi.check(lib.deer_vit_embed_lnpre(abi.ptr(self.patch_out), abi.ptr(self.vit["cls"]), abi.ptr(self.vit["pos"]),
+                                           abi.ptr(self.vit["ln_pre_w"]), abi.ptr(self.vit["ln_pre_b"]), abi.ptr(self.vx), N, P, W,
+                                           EPS, st), "vit_embed")
+        H = cfg.vit_heads
+        tok = P + 1
+        for L in self.vit_layers:
+            self._ln(self.vx, L["ln1w"], L["ln1b"], self.v_ln, R, W)
+            self._gemm(self.v_ln, L["wqkv"], self.v_qkv, R, 3 * W, W, abi.EPI_BF16, bias=L["bqkv"])
+            abi.check(lib.deer_attn_mfma_hd64(abi.ptr(self.v_qkv), abi.ptr(self.v_qkv, 2 * W), abi.ptr(self.v_qkv, 4 * W),
+                                              abi.ptr(self.v_ao), N, H, tok, tok, 3 * W, 3 * W, 3 * W, W, tok * 3 * W, tok * 3 * W,
+                                              tok * 3 * W, tok * W, 64 ** -0.5, st), "vit attn")
+            self._gemm(self.v_ao, L["wo"], self.vx, R, W, W, abi.EPI_RESADD_F32, bias=L["bo"])
+            self._ln(self.vx, L["ln2w"], L["ln2b"], self.v_ln, R, W)
+            self._gemm(self.v_ln, L["wfc"], self.v_h, R, cfg.vit_mlp, W, abi.EPI_QGELU_BF16, bias=L["bfc"])
+            self._gemm(self.v_h, L["wpr"], self.vx, R, W, cfg.vit_mlp, abi.EPI_RESADD_F32, bias=L["bpr"])
+        # ---- Perceiver (helpers.py:107-132) on the patch tokens x[:, 1:] of each camera ----
+        nl, inner = cfg.perc_latents, cfg.perc_heads * cfg.perc_dim_head
+        kvr = P + nl
+        abi.check(lib.deer_broadcast_rows(abi.ptr(self.perc["latents"]), abi.ptr(self.p_lat), nl * W, N, st), "latents")
+        for L in self.perc_layers:
+            # kv_in = [LN_media(x) ; LN_latents(latents)]  (helpers.py:47-51)
+            self._ln(self.vx, L["nmw"], L["nmb"], self.p_kvin, P, W, in_bstride=tok * W, batch=N, out_bstride=kvr * W, x_off=W * 4)
+            self._ln(self.p_lat, L["nlw"], L["nlb"], self.p_kvin, nl, W, in_bstride=nl * W, batch=N, out_bstride=kvr * W,
+                     out_off=P * W * 2)
+            self._gemm(self.p_kvin, L["wkv"], self.p_kv, N * kvr, 2 * inner, W, abi.EPI_BF16)
+            self._gemm(self.p_kvin, L["wq"], self.p_q, nl, inner, W, abi.EPI_BF16, batch=N, strideA=kvr * W, strideC=nl * inner,
+                       a_off=P * W * 2)
+            abi.check(lib.deer_attn_mfma_hd64(abi.ptr(self.p_q), abi.ptr(self.p_kv), abi.ptr(self.p_kv, inner * 2), abi.ptr(self.p_ao),
+                                              N, cfg.perc_heads, nl, kvr, inner, 2 * inner, 2 * inner, inner, nl * inner,
+                                              kvr * 2 * inner, kvr * 2 * inner, nl * inner, cfg.perc_dim_head ** -0.5, st), "perc attn")
+            self._gemm(self.p_ao, L["wo"], self.p_lat, N * nl, W, inner, abi.EPI_RESADD_F32)
+            self._ln(self.p_lat, L["fnw"], L["fnb"], self.p_ln, N * nl, W)
+            self._gemm(self.p_ln, L["w1"], self.p_h, N * nl, cfg.perc_ff_mult * W, W, abi.EPI_GELU_BF16)
+            self._gemm(self.p_h, L["w2"], self.p_lat, N * nl, W, cfg.perc_ff_mult * W, abi.EPI_RESADD_F32)
+        self._ln(self.p_lat, self.perc["normw"], self.perc["normb"], self.vis_x, N * nl, W, out_f32=self.vis_x_f32)
+        if self.n_xattn:
+            self._gemm(self.vis_x, self.wkv_all, self.kv_all, N * nl, self.n_xattn * 2 * self.xinner, W, abi.EPI_BF16)
+
+    # --------------------------------------------------------------------------------------------- LLM
+    def _skinny(self, Wp, N, K, T, out_slab, A=None, a_slab=None, s_in=0, a_mode=abi.A_BF16, lda=None, ctl=True):
+        S = self.lib.deer_skinny_splitk(T, N, K)
+        mpad = 16 if T <= 16 else 32
+        assert S * mpad * N <= out_slab.numel(), (S, mpad, N, out_slab.numel())
+        abi.check(self.lib.deer_gemm_skinny(abi.ptr(A), (K if lda is None else lda), abi.ptr(a_slab), s_in,
+                                            (32 if T > 16 else 16) * K, a_mode, abi.ptr(Wp), abi.ptr(out_slab), T, N, K, S,
+                                            abi.ptr(self.ctl) if ctl else None, _cur_stream()), "deer_gemm_skinny")
+        return S, mpad * N
+
+    def _resadd(self, T, pending, gamma=None, beta=None, x_copy=None, ctl=True):
+        slab, S, stride, gate = pending if pending is not None else (None, 0, 0, None)
+        abi.check(self.lib.deer_resadd_ln(abi.ptr(self.x), abi.ptr(slab), S, stride, abi.ptr(gate), abi.ptr(gamma), abi.ptr(beta),
+                                          abi.ptr(self.xn) if gamma is not None else None, abi.ptr(x_copy), T, self.cfg.d_model, EPS,
+                                          abi.ptr(self.ctl) if ctl else None, _cur_stream()), "deer_resadd_ln")
+
+    def enqueue_embed(self, T):
+        cfg = self.cfg
+        abi.check(self.lib.deer_embed_tokens(abi.ptr(self.ids), abi.ptr(self.wte), abi.ptr(self.x), abi.ptr(self.text_time), T,
+                                             cfg.d_model, cfg.vocab_size, cfg.media_token_id, _cur_stream()), "embed_tokens")
+
+    def enqueue_llm_layer(self, i, T, pending, use_mask: bool, finalize: bool, ctl=True):
+        """FlamingoLayer.forward (flamingo_lm.py:46-83): gated x-attn (helpers.py:260-279) then the MPT block
+        (SURVEY App. B.1).  ``pending`` = not-yet-applied residual branch of the previous op (split-K slabs + gate)."""
+        cfg, L, st = self.cfg, self.llm_layers[i], _cur_stream()
+        d = cfg.d_model
+        c = abi.ptr(self.ctl) if ctl else None
+        if "xa" in L:
+            X = L["xa"]
+            self._resadd(T, pending, X["nw"], X["nb"], ctl=ctl)
+            S, stride = self._skinny(X["wq"], self.xinner, d, T, self.slab_b, A=self.xn, ctl=ctl)
+            kv_off = X["kv_index"] * 2 * self.xinner * 2          # bytes into a kv_all row
+            abi.check(self.lib.deer_xattn_small(abi.ptr(self.slab_b), S, stride, self.xinner, abi.ptr(self.kv_all, kv_off),
+                                                self.n_xattn * 2 * self.xinner, self.xinner, abi.ptr(self.text_time),
+                                                cfg.perc_latents * self.n_cams, abi.ptr(self.ao), self.xinner, T, cfg.n_media,
+                                                cfg.xattn_heads, cfg.xattn_dim_head ** -0.5, c, st), "deer_xattn_small")
+            S, stride = self._skinny(X["wo"], d, self.xinner, T, self.slab_a, A=self.ao, lda=self.xinner, ctl=ctl)
+            self._resadd(T, (self.slab_a, S, stride, X["ag"]), X["fnw"], X["fnb"], ctl=ctl)
+            S, stride = self._skinny(X["w1"], cfg.xattn_ff_mult * d, d, T, self.slab_b, A=self.xn, ctl=ctl)
+            S, stride = self._skinny(X["w2"], d, cfg.xattn_ff_mult * d, T, self.slab_a, a_slab=self.slab_b, s_in=S,
+                                     a_mode=abi.A_SLABS_GELU, ctl=ctl)
+            pending = (self.slab_a, S, stride, X["fg"])
+        self._resadd(T, pending, L["ln1w"], L["ln1b"], ctl=ctl)
+        S, stride = self._skinny(L["wqkv"], 3 * d, d, T, self.slab_b, A=self.xn, ctl=ctl)
+        abi.check(self.lib.deer_mpt_attn_small(abi.ptr(self.slab_b), S, stride, d, cfg.n_heads, abi.ptr(L["qlnw"]), abi.ptr(L["klnw"]),
+                                               EPS, abi.ptr(self.key_mask) if use_mask else None, float(cfg.alibi_bias_max),
+                                               abi.ptr(self.ao), d, T, c, st), "deer_mpt_attn_small")
+        S, stride = self._skinny(L["wo"], d, d, T, self.slab_a, A=self.ao, lda=d, ctl=ctl)
+        self._resadd(T, (self.slab_a, S, stride, None), L["ln2w"], L["ln2b"], ctl=ctl)
+        S, stride = self._skinny(L["wup"], cfg.mlp_ratio * d, d, T, self.slab_b, A=self.xn, ctl=ctl)
+        S, stride = self._skinny(L["wdown"], d, cfg.mlp_ratio * d, T, self.slab_a, a_slab=self.slab_b, s_in=S,
+                                 a_mode=abi.A_SLABS_GELU, ctl=ctl)
+        pending = (self.slab_a, S, stride, None)
+        if finalize:                                            # hidden_states[i] = output of layer i (mosaic_gpt_3b.py:424-427)
+            self._resadd(T, pending, None, None, x_copy=self.hidden[i], ctl=ctl)
+            pending = None
+        return pending
+
+    # -------------------------------------------------------------------------------------------- head
+    def enqueue_head(self, layer: int, T: int, kind: int, slot: int = -1, force: bool = False, use_ctl: bool = True,
+                     feats: Optional[torch.Tensor] = None, h_prev=None, c_prev=None):
+        """One DeterministicDecoder evaluation on hidden_states[layer] (action_head.py:499-611) followed by the
+        exit gate (value_net.py:120-133,277-297).  kind: PSEUDO (prev action from layer i-1, value_net.py:122-125),
+        CHECK (delta <= threshold -> exit + commit LSTM state), COMMIT (static exit_id / committing call)."""
+        cfg, Hd, lib, st = self.cfg, self.head, self.lib, _cur_stream()
+        c = abi.ptr(self.ctl) if use_ctl else None
+        H, d = cfg.head_hidden, cfg.d_model
+        feats = self.hidden[layer] if feats is None else feats
+        h_prev = self.h_state if h_prev is None else h_prev
+        c_prev = self.c_state if c_prev is None else c_prev
+        pool = abi.X_POOL_MAX if cfg.pooling == "max" else abi.X_POOL_AVG
+        for l, Lw in enumerate(Hd["lstm"]):
+            if l == 0:
+                src, mode, in_dim, lnw, lnb = feats, pool, d, None, None
+            else:
+                prev = Hd["lstm"][l - 1]
+                src, in_dim = self.h_tmp[l - 1], H
+                mode, lnw, lnb = (abi.X_LN, prev["lnw"], prev["lnb"]) if cfg.lstm_layernorm else (abi.X_RAW, None, None)
+            abi.check(lib.deer_head_lstm_layer(abi.ptr(src), mode, T, in_dim, abi.ptr(lnw), abi.ptr(lnb), abi.ptr(Lw["wih"]),
+                                               abi.ptr(Lw["whh"]), abi.ptr(Lw["bih"]), abi.ptr(Lw["bhh"]), abi.ptr(h_prev[l]),
+                                               abi.ptr(c_prev[l]), abi.ptr(self.h_tmp[l]), abi.ptr(self.c_tmp[l]), H, EPS, c, kind,
+                                               layer, st), "deer_head_lstm_layer")
+        src, in_dim = self.h_tmp[cfg.lstm_num_layers - 1], H
+        last = Hd["lstm"][-1]
+        pro, ln = (abi.PRO_LN, (last["lnw"], last["lnb"], None, None)) if cfg.lstm_layernorm else (abi.PRO_RAW, (None,) * 4)
+        for fi, (Fw, dim) in enumerate(zip(Hd["fc"], cfg.mlp_hidden_dims)):
+            abi.check(lib.deer_head_fc(abi.ptr(src), in_dim, pro, abi.ptr(ln[0]), abi.ptr(ln[1]), abi.ptr(ln[2]), abi.ptr(ln[3]),
+                                       abi.ptr(Fw["w0"]), abi.ptr(Fw["b0"]), abi.ptr(Fw["w1"]), abi.ptr(Fw["b1"]), dim,
+                                       abi.ptr(self.z_fc[fi]), EPS, c, kind, layer, st), "deer_head_fc")
+            src, in_dim = self.z_fc[fi], dim
+            if cfg.mlp_layernorm:
+                pro, ln = abi.PRO_GROUP_LN_RELU, (Fw["lnw0"], Fw["lnb0"], Fw["lnw1"], Fw["lnb1"])
+            else:
+                pro, ln = abi.PRO_GROUP_RELU, (None,) * 4
+        LH = cfg.lstm_num_layers * H
+        abi.check(lib.deer_head_final(abi.ptr(src), in_dim, pro, abi.ptr(ln[0]), abi.ptr(ln[1]), abi.ptr(ln[2]), abi.ptr(ln[3]),
+                                      abi.ptr(Hd["wa"]), abi.ptr(Hd["ba"]), abi.ptr(Hd["wg"]), abi.ptr(Hd["bg"]),
+                                      abi.ptr(self.ctl), kind, layer, slot, abi.ptr(self.thresholds), 1 if force else 0,
+                                      self.thr_type, self.leq, abi.ptr(self.h_tmp), abi.ptr(self.c_tmp), abi.ptr(self.h_state),
+                                      abi.ptr(self.c_state), LH, abi.ptr(self.action_dbg), EPS, st), "deer_head_final")
+
+    # ------------------------------------------------------------------------------------- step assembly
+    def configure_exit(self, exit_ids: Sequence[int], max_layer: int, steps_per_stage: int = 1):
+        """``ExitController.__init__`` (value_net.py:164-173): max_layer = min(max_layer-1, last exit)."""
+        self.exit_ids = list(exit_ids)
+        self.ctl_max_layer = min(max_layer - 1, self.exit_ids[-1])
+        self.steps_per_stage = steps_per_stage
+        self._graphs.clear()
+
+    @property
+    def real_num_exit(self) -> int:
+        return len([x for x in self.exit_ids if x <= self.ctl_max_layer])
+
+    def set_thresholds(self, thresholds: Sequence[float]):
+        """``ExitController._set_threshold_value`` (value_net.py:178-183)."""
+        assert len(thresholds) == self.real_num_exit, (len(thresholds), self.real_num_exit)
+        t = torch.full((16,), 1e8, dtype=torch.float32)
+        t[: len(thresholds)] = torch.tensor([float(v) for v in thresholds], dtype=torch.float32)
+        self.thresholds.copy_(t)
+
+    def reset(self):
+        """Episode start: ``clear_all_exit_memory`` + controller state (eval_utils.py:252-277)."""
+        self.h_state.zero_()
+        self.c_state.zero_()
+        self.ctl.zero_()
+        self.cur_step = 0
+
+    def enqueue_llm_dynamic(self, T, use_mask):
+        """MosaicGPT.forward loop with an exit controller (mosaic_gpt_3b.py:397-443), device-predicated."""
+        cfg = self.cfg
+        interval = cfg.exit_interval
+        self.enqueue_embed(T)
+        pending = None
+        for i in range(cfg.n_layers):
+            need_pseudo = ((i + 1) in self.exit_ids) and ((i + 1) - interval < 0) and (i + 1) <= self.ctl_max_layer
+            is_exit = (i in self.exit_ids) and i <= self.ctl_max_layer
+            pending = self.enqueue_llm_layer(i, T, pending, use_mask, finalize=(need_pseudo or is_exit))
+            if need_pseudo:
+                self.enqueue_head(i, T, abi.KIND_PSEUDO)
+            if is_exit:
+                self.enqueue_head(i, T, abi.KIND_CHECK, slot=self.exit_ids.index(i), force=(i >= self.ctl_max_layer))
+            if i >= self.ctl_max_layer:
+                break
+
+    def enqueue_llm_static(self, T, use_mask, exit_id):
+        """exit_id given (flamingo_mpt.py:402-411,446-461): run layers 0..exit_id, committing head call."""
+        self.enqueue_embed(T)
+        pending = None
+        for i in range(exit_id + 1):
+            pending = self.enqueue_llm_layer(i, T, pending, use_mask, finalize=True, ctl=False)
+        self.enqueue_head(exit_id, T, abi.KIND_COMMIT, use_ctl=False)
+
+    def _enqueue_step(self, T, use_mask, exit_id):
+        abi.check(self.lib.deer_ctl_begin_step(abi.ptr(self.ctl), abi.ptr(self.hold_dev), _cur_stream()), "ctl_begin_step")
+        self.enqueue_vision()
+        if exit_id is None:
+            self.enqueue_llm_dynamic(T, use_mask)
+        else:
+            self.enqueue_llm_static(T, use_mask, exit_id)
+
+    # ---------------------------------------------------------------------------------------- host API
+    def load_inputs(self, rgb: torch.Tensor, gripper: torch.Tensor, ids: torch.Tensor, mask: Optional[torch.Tensor] = None):
+        """rgb / gripper: (..., 3, S, S) one frame each; ids (1,T) or (T,) int64; mask (1,T) bool."""
+        S = self.cfg.image_size
+        self.img[0].copy_(rgb.reshape(3, S, S), non_blocking=True)
+        self.img[1].copy_(gripper.reshape(3, S, S), non_blocking=True)
+        ids = ids.reshape(-1)
+        T = ids.numel()
+        assert 0 < T <= self.max_T
+        self.ids[:T].copy_(ids, non_blocking=True)
+        use_mask = False
+        if mask is not None:
+            m = mask.reshape(-1).to(torch.uint8)
+            use_mask = bool((m == 0).any())
+            self.key_mask[:T].copy_(m, non_blocking=True)
+        return T, use_mask
+
+    def step(self, rgb, gripper, ids, mask=None, exit_id: Optional[int] = None, use_graph: bool = True, sync: bool = True):
+        """One control step.  Returns dict(pose (6,), gripper prob, gripper_logit, exit_layer, deltas) when sync."""
+        T, use_mask = self.load_inputs(rgb, gripper, ids, mask)
+        if exit_id is not None and exit_id < 0:
+            exit_id += self.cfg.n_layers
+        hold = 1 if (exit_id is None and self.cur_step % self.steps_per_stage != 0) else 0
+        self.hold_dev.fill_(hold)
+        key = (T, use_mask, exit_id)
+        if use_graph:
+            g = self._graphs.get(key)
+            if g is None:
+                self._enqueue_step(T, use_mask, exit_id)          # eager warm-up (sets kernel attributes) - a real step
+                torch.cuda.current_stream().synchronize()
+                g = torch.cuda.CUDAGraph()
+                self._graph_pending = (T, use_mask, exit_id)
+                # state was advanced by the warm-up run; capture does not execute kernels
+                with torch.cuda.graph(g):
+                    self._enqueue_step(T, use_mask, exit_id)
+                self._graphs[key] = g
+                self._warm_result = True
+            else:
+                g.replay()
+        else:
+            self._enqueue_step(T, use_mask, exit_id)
+        self.ctl_host.copy_(self.ctl, non_blocking=True)
+        self.cur_step += 1
+        if not sync:
+            return None
+        torch.cuda.current_stream().synchronize()
+        return self.read_result()
+
+    def read_result(self):
+        c = self.ctl_host
+        f = c.view(torch.float32)
+        return dict(exit_layer=int(c[abi.CTL_EXIT_LAYER]), n_evals=int(c[abi.CTL_N_EVALS]),
+                    pose=f[abi.CTL_OUT_ACTION: abi.CTL_OUT_ACTION + 6].clone(),
+                    gripper=float(f[abi.CTL_OUT_ACTION + 6]), gripper_logit=float(f[abi.CTL_OUT_ACTION + 7]),
+                    deltas=f[abi.CTL_DELTAS: abi.CTL_DELTAS + 16].clone())
+
+    def weight_bytes(self) -> int:
+        tot = 0
+        seen = set()
+
+        def walk(o):
+            nonlocal tot
+            if torch.is_tensor(o):
+                if o.data_ptr() not in seen:
+                    seen.add(o.data_ptr())
+                    tot += o.numel() * o.element_size()
+            elif isinstance(o, dict):
+                for v in o.values():
+                    walk(v)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    walk(v)
+        for o in (self.vit, self.vit_layers, self.perc, self.perc_layers, self.wte, self.llm_layers, self.wkv_all, self.head):
+            walk(o)
+        return tot

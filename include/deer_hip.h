@@ -1,0 +1,147 @@
+/* deer_hip.h - C ABI of libdeer_hip.so: the MI355X (gfx950) kernels behind DeeR-VLA's early-exit forward path.
+ *
+ * The reference (yueyang130/DeeR-VLA) has no C ABI: its "plugin interface" for this path is a Python object
+ * protocol whose compute is implicit vendor kernels reached through torch ops.  Each entry
+ * point below replaces one such implicit op and cites the reference call site it stands for (paths relative
+ * to the reference repo).  The Python host in deer_vla_amd/ binds these with ctypes (deer_vla_amd/_abi.py)
+ * and keeps the reference's Python surface (create_model_and_transforms / MPTFlamingo.forward / the
+ * mosaic_gpt multi-exit lang_encoder.forward / ExitController) on top - see INTEGRATION.md.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless noted; `stream` is a hipStream_t passed as void*
+ *   - bf16 data is passed as `const void*` (uint16 storage); f32 as float*
+ *   - every function only ENQUEUES work on `stream` (graph-capturable, no allocation, no sync) and
+ *     returns 0 on success, DEER_ERR_SHAPE (1) for an invalid argument, DEER_ERR_LAUNCH (2) if the launch failed
+ *   - `ctl` is the device control block (int32[DEER_CTL_WORDS]); kernels on the early-exit path return at
+ *     entry once ctl[DEER_CTL_EXIT_FLAG] != 0  (device-side termination, no host round trip per layer)
+ */
+#ifndef DEER_HIP_H
+#define DEER_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEER_OK 0
+#define DEER_ERR_SHAPE 1
+#define DEER_ERR_LAUNCH 2
+
+/* control block layout (32-bit words) */
+#define DEER_CTL_EXIT_FLAG 0
+#define DEER_CTL_EXIT_LAYER 1
+#define DEER_CTL_CUR_EXIT_ID 2
+#define DEER_CTL_HOLD 3
+#define DEER_CTL_N_EVALS 4
+#define DEER_CTL_PREV_ACTION 8   /* float[8] */
+#define DEER_CTL_OUT_ACTION 16   /* float[8]: pose[6], gripper prob, gripper logit */
+#define DEER_CTL_DELTAS 24       /* float[16] */
+#define DEER_CTL_WORDS 64
+
+/* GEMM epilogues (deer_gemm_bf16_nt) */
+#define DEER_EPI_BF16 0
+#define DEER_EPI_F32 1
+#define DEER_EPI_QGELU_BF16 2
+#define DEER_EPI_GELU_BF16 3
+#define DEER_EPI_RESADD_F32 4
+/* skinny-GEMM A operand sources */
+#define DEER_A_BF16 0
+#define DEER_A_SLABS_GELU 1
+#define DEER_A_SLABS 2
+/* head input modes / prologues / evaluation kinds / delta types */
+#define DEER_X_RAW 0
+#define DEER_X_POOL_MAX 1
+#define DEER_X_POOL_AVG 2
+#define DEER_X_LN 3
+#define DEER_PRO_RAW 0
+#define DEER_PRO_LN 1
+#define DEER_PRO_GROUP_LN_RELU 2
+#define DEER_PRO_GROUP_RELU 3
+#define DEER_KIND_PSEUDO 0
+#define DEER_KIND_CHECK 1
+#define DEER_KIND_COMMIT 2
+#define DEER_THR_L2 0
+#define DEER_THR_MEAN 1
+#define DEER_THR_MAX 2
+#define DEER_THR_COSINE 3
+
+/* ---- MFMA GEMM, large M:  C = epi(A[M,K] * W[N,K]^T + bias) -----------------------------------------------
+ * Replaces the nn.Linear / nn.Conv2d(patch embed) calls inside open_clip's ViT-L/14 (called at
+ * robot_flamingo/models/flamingo_mpt.py:580), PerceiverAttention/FeedForward (open_flamingo/src/helpers.py:47-52,
+ * 15-22) and MaskedCrossAttention.to_kv (helpers.py:190).  A, W bf16; bias f32 or NULL; C bf16 or f32 per `epi`;
+ * DEER_EPI_RESADD_F32: C(f32) += tanh(*gate or 1) * (A W^T + bias).  batch: A += z*strideA, C += z*strideC.
+ * tile: 0 auto, 1 64x64, 2 64x128, 3 128x128.  Needs K%8==0, N%16==0. */
+int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const void* W, int ldw, const float* bias, void* C, int ldc,
+                      long strideC, int M, int N, int K, int batch, int epi, const float* gate, int tile, const int* ctl,
+                      void* stream);
+
+/* ---- MFMA GEMM, M <= 32 (weight-streaming): part[ks][Mpad][N] = A[:, Kslice ks] * W[:, Kslice ks]^T -------
+ * Replaces the bias-free nn.Linear calls of the MPT GPTBlock (EXTERNAL; constructed mosaic_gpt_3b.py:104-106,
+ * called :413-417) and of GatedCrossAttentionBlock (helpers.py:188,231,15-22) at T<=32 text tokens.
+ * Wp = deer_pack_weight_mfma16(W).  Mpad = 16 (M<=16) or 32.  a_mode: DEER_A_BF16 reads A (bf16 [M,lda]);
+ * DEER_A_SLABS(_GELU) reads sum_s Aslab[s*slab_stride_in + m*K + k] (optionally through exact GELU).
+ * Partials are reduced by the consumer (deer_resadd_ln / deer_*_attn_small / next deer_gemm_skinny). */
+int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int s_in, long slab_stride_in, int a_mode, const void* Wp,
+                     float* part, int M, int N, int K, int splitk, const int* ctl, void* stream);
+int deer_skinny_splitk(int M, int N, int K);                       /* host helper: suggested split-K */
+int deer_pack_weight_mfma16(const void* W, void* Wp, int N, int K, void* stream);  /* [N,K] -> [N/16][K/32][64][8] */
+
+/* ---- attention ----------------------------------------------------------------------------------------------
+ * deer_attn_mfma_hd64: softmax(scale * Q K^T) V per (batch, head), head_dim 64, kv_len <= 320.  Replaces
+ * nn.MultiheadAttention inside the open_clip ViT blocks and the einsum/softmax of PerceiverAttention
+ * (helpers.py:53-63).  Q,K,V,O bf16 with row strides ld* and batch strides *_bstride (elements); head h lives at
+ * column h*64. */
+int deer_attn_mfma_hd64(const void* Q, const void* K, const void* V, void* O, int batch, int heads, int q_len, int kv_len,
+                        int ldq, int ldk, int ldv, int ldo, long q_bstride, long k_bstride, long v_bstride, long o_bstride,
+                        float scale, void* stream);
+/* deer_xattn_small: MaskedCrossAttention core (helpers.py:192-232): q from split-K slabs (x scale), kv bf16
+ * [n_kv, ldkv] (k at col h*64, v at col inner+h*64), mask text_time[t] == j/n_per_media + 1, rows with
+ * text_time == 0 zeroed; out bf16 [T, ldo]. */
+int deer_xattn_small(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv, int inner,
+                     const int* text_time, int n_per_media, void* out, int ldo, int T, int n_kv, int heads, float scale,
+                     const int* ctl, void* stream);
+/* deer_mpt_attn_small: MPT attention core (attn bias built at mosaic_gpt_3b.py:158-219): qkv from
+ * split-K slabs [T,3d]; optional q/k LayerNorm over d_model (weights f32 or NULL); ALiBi slope
+ * 2^(-alibi_bias_max*(h+1)/H); causal; key_mask (uint8[T], 0 = padded) or NULL; out bf16 [T, ldo]. */
+int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w,
+                        const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, void* out,
+                        int ldo, int T, const int* ctl, void* stream);
+
+/* ---- row ops ------------------------------------------------------------------------------------------------
+ * deer_layernorm_rows: nn.LayerNorm (ViT ln_1/ln_2, helpers.py:32-33,17,132), f32 in, bf16 and/or f32 out. */
+int deer_layernorm_rows(const float* x, long in_rstride, long in_bstride, int rows_per_batch, int batch, const float* gamma,
+                        const float* beta, void* out_bf16, float* out_f32, long out_rstride, long out_bstride, int C,
+                        float eps, void* stream);
+/* deer_resadd_ln: x += tanh(*gate or 1) * sum_s slab[s]; optional copy of x (hidden_states[i], mosaic_gpt_3b.py:424-427);
+ * optional LayerNorm -> bf16 (helpers.py:267-279 gated residuals; MPT block residuals + ln_1/ln_2). */
+int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* gamma,
+                   const float* beta, void* out_bf16, float* x_copy, int T, int d, float eps, const int* ctl, void* stream);
+/* ViT patch embedding (open_clip conv1 + class/positional embedding + ln_pre) */
+int deer_vit_im2col(const void* img, int img_is_bf16, int N, int S, int patch, void* out_bf16, int Kpad, void* stream);
+int deer_vit_embed_lnpre(const float* patch, const float* cls, const float* pos, const float* ln_w, const float* ln_b,
+                         float* x, int N, int P, int W, float eps, void* stream);
+/* wte lookup (mosaic_gpt_3b.py:341) + text_time = cumsum(ids == media_token_id) (flamingo_lm.py:211, helpers.py:208) */
+int deer_embed_tokens(const long long* ids, const void* wte_bf16, float* x, int* text_time, int T, int d, int vocab,
+                      int media_id, void* stream);
+int deer_broadcast_rows(const float* src, float* dst, long n, int batch, void* stream);   /* helpers.py:128 */
+
+/* ---- action head + exit gate (robot_flamingo/models/action_head.py:499-611, value_net.py:105-133,277-297) ----- */
+int deer_head_lstm_layer(const float* x_src, int x_mode, int T, int in_dim, const float* ln_w, const float* ln_b,
+                         const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh, const float* h_prev,
+                         const float* c_prev, float* h_out, float* c_out, int H, float eps, const int* ctl, int kind,
+                         int layer, void* stream);
+int deer_head_fc(const float* src, int in_dim, int pro, const float* lnw0, const float* lnb0, const float* lnw1,
+                 const float* lnb1, const void* W0, const float* b0, const void* W1, const float* b1, int out_dim, float* dst,
+                 float eps, const int* ctl, int kind, int layer, void* stream);
+int deer_head_final(const float* src, int in_dim, int pro, const float* lnw0, const float* lnb0, const float* lnw1,
+                    const float* lnb1, const void* Wa, const float* ba, const void* Wg, const float* bg, int* ctl, int kind,
+                    int layer, int slot, const float* thresholds, int force, int thr_type, int leq, const float* h_tmp,
+                    const float* c_tmp, float* h_state, float* c_state, int LH, float* action_dbg, float eps, void* stream);
+int deer_ctl_begin_step(int* ctl, const int* hold_src, void* stream);   /* ExitController.set_timestep, eval_utils.py:662-663 */
+
+/* library identification: returns the gfx arch string the kernels were compiled for ("gfx950") */
+const char* deer_hip_arch(void);
+int deer_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEER_HIP_H */

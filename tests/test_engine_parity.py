@@ -1,0 +1,216 @@
+"""End-to-end parity of the HIP engine (through libdeer_hip.so's C ABI) against
+  (a) golden vectors produced by the REFERENCE's own MPTFlamingo.forward (tests/golden/deer_forward.npz), and
+  (b) the CPU oracle on the same seeded inputs (tiny config: every step of an episode; full MPT-1B/ViT-L
+      config: a few steps).
+Tolerances (BASELINE.json north_star): action outputs within 1e-2 for the bf16 path, exit-layer indices EXACT.
+The oracle / golden weights are the bf16-representable weights the engine holds, so the two arms differ only by
+bf16 rounding of activations and summation order."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import load  # noqa: E402
+from deer_vla_amd import synthetic as syn  # noqa: E402
+from deer_vla_amd.config import deer_tiny, deer_3b  # noqa: E402
+from deer_vla_amd.engine import DeerEngine  # noqa: E402
+from oracle import deer_oracle as orc  # noqa: E402
+
+ACTION_TOL = 1e-2
+
+
+def gap_threshold(vals, lo=0.2, hi=0.8):
+    v = np.sort(np.asarray(vals, dtype=np.float64))
+    a = int(len(v) * lo)
+    b = min(max(int(len(v) * hi), a + 2), len(v))
+    gaps = v[a + 1:b] - v[a:b - 1]
+    i = int(np.argmax(gaps)) + a
+    return float(0.5 * (v[i] + v[i + 1])), float(gaps.max())
+
+
+class RecVN(orc.OracleValueNet):
+    def __call__(self, feats, i=None, mode="infer", rand_layer_feat=None):
+        v = super().__call__(feats, i, mode, rand_layer_feat)
+        self.rec = getattr(self, "rec", [])
+        self.rec.append((i, float(v)))
+        return v
+
+
+def oracle_episode(cfg, sd, inputs, thresholds, max_layer, steps_per_stage=1):
+    model = orc.OracleDeer(sd, cfg)
+    model.set_all_exit_window_size(1)
+    vn = RecVN(cfg.exit_ids(), model.extra_exit, cfg.exit_interval, 1, "L2")
+    ctl = orc.OracleExitController(vn, cfg.exit_ids(), steps_per_stage=steps_per_stage, max_layer=max_layer)
+    ctl._set_threshold_value(thresholds)
+    outs = []
+    for s, (rgb, grip, ids, mask) in enumerate(inputs):
+        ctl.set_timestep(s)
+        o = model.forward(rgb, ids, mask, grip, dynamic_early_exit=True, exit_controller=ctl)
+        outs.append((o["exit_layer"], o["logits"][0].reshape(-1), float(o["logits"][1])))
+    return outs, vn.rec, ctl
+
+
+def probe_thresholds(cfg, sd, inputs, max_layer):
+    """thresholds in the widest gap of the oracle's own deltas (never-exit pass) -> robust exit decisions"""
+    ctl0 = orc.OracleExitController(None, cfg.exit_ids(), max_layer=max_layer)
+    real = ctl0.real_num_exit
+    _, rec, _ = oracle_episode(cfg, sd, inputs, [-1.0] * real, max_layer)
+    thr = []
+    for e in cfg.exit_ids()[:real]:
+        t, _ = gap_threshold([v for (i, v) in rec if i == e])
+        thr.append(t)
+    thr[-1] = 1e5
+    return thr
+
+
+def make_inputs(cfg, n_steps, text_len=14):
+    return [syn.synthetic_step_inputs(cfg, s, text_len=text_len) for s in range(n_steps)]
+
+
+# ----------------------------------------------------------------------------------------------------
+def test_engine_matches_reference_golden_forward():
+    """HIP engine vs the reference's own MPTFlamingo.forward outputs (static exit ids = BASELINE config[0],
+    and the dynamic-exit step protocol with LSTM carry)."""
+    cfg, seed, g = load("deer_forward.npz")
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
+    eng = DeerEngine(cfg, sd)
+    ids, mask = g["ids"].long(), g["mask"].bool()
+    rgb, grip = g["rgb"], g["grip"]
+    for eid in (3, 4, -1):
+        eng.reset()
+        r = eng.step(rgb[0], grip[0], ids, mask, exit_id=eid, use_graph=False)
+        tag = f"static{eid}"
+        assert r["exit_layer"] == int(g[tag + "_exit"])
+        torch.cuda.synchronize()
+        if eid == 3:
+            vis = eng.vis_x_f32.cpu().view(1, 1, cfg.n_media, cfg.vit_width)
+            assert float((vis - g["vis_x"]).abs().max()) < 5e-2
+        hid = eng.hidden[: r["exit_layer"] + 1, : ids.shape[1]].cpu()
+        ref_h = g[tag + "_hidden"][:, 0]
+        assert float((hid - ref_h).abs().max() / ref_h.abs().max()) < 2e-2
+        assert float((r["pose"] - g[tag + "_pose"].reshape(-1)).abs().max()) < ACTION_TOL
+        assert abs(r["gripper"] - float(g[tag + "_grip"])) < ACTION_TOL
+    for tag in ("dyn", "dynS"):
+        eng.reset()
+        eng.configure_exit(cfg.exit_ids(), int(g[tag + "_max_layer"]), 1)
+        eng.set_thresholds([float(t) for t in g[tag + "_thr"]])
+        for s in range(rgb.shape[0]):
+            r = eng.step(rgb[s], grip[s], ids, mask, use_graph=(s > 1))
+            assert r["exit_layer"] == int(g[tag + "_exit"][s]), (tag, s, r["exit_layer"], g[tag + "_exit"])
+            assert float((r["pose"] - g[tag + "_pose"][s].reshape(-1)).abs().max()) < ACTION_TOL, (tag, s)
+            assert abs(r["gripper"] - float(g[tag + "_grip"][s])) < ACTION_TOL
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
+    eng = DeerEngine(cfg, sd)
+    return cfg, sd, eng
+
+
+def test_tiny_vision_and_hidden_states_vs_oracle(tiny):
+    cfg, sd, eng = tiny
+    rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, 0)
+    model = orc.OracleDeer(sd, cfg)
+    model.set_all_exit_window_size(1)
+    o = model.forward(rgb, ids, mask, grip, exit_id=cfg.n_layers - 1)
+    eng.reset()
+    r = eng.step(rgb, grip, ids, mask, exit_id=cfg.n_layers - 1, use_graph=False)
+    vis = eng.vis_x_f32.cpu()
+    ref_vis = o["vis_x"].reshape(cfg.n_media, cfg.vit_width)
+    assert float((vis - ref_vis).abs().max()) < 6e-2 and float((vis - ref_vis).norm() / ref_vis.norm()) < 1e-2
+    T = ids.shape[1]
+    for i in range(cfg.n_layers):
+        a, b = eng.hidden[i, :T].cpu(), o["hidden_states"][i][0]
+        assert float((a - b).norm() / b.norm()) < 1e-2, i
+    assert r["exit_layer"] == cfg.n_layers - 1
+    assert float((r["pose"] - o["logits"][0].reshape(-1)).abs().max()) < ACTION_TOL
+    assert abs(r["gripper"] - float(o["logits"][1])) < ACTION_TOL
+
+
+@pytest.mark.parametrize("max_layer,sps", [(12, 1), (4, 1), (12, 3)])
+def test_tiny_dynamic_exit_episode_vs_oracle(tiny, max_layer, sps):
+    """A 24-step episode with LSTM carry: exit layers identical, actions within 1e-2, per-exit deltas close."""
+    cfg, sd, eng = tiny
+    inputs = make_inputs(cfg, 24, text_len=11)
+    thr = probe_thresholds(cfg, sd, inputs, max_layer)
+    ref, rec, ctl = oracle_episode(cfg, sd, inputs, thr, max_layer, sps)
+    eng.configure_exit(cfg.exit_ids(), max_layer, sps)
+    eng.set_thresholds(thr)
+    eng.reset()
+    exits = []
+    for s, (rgb, grip, ids, mask) in enumerate(inputs):
+        r = eng.step(rgb, grip, ids, mask, use_graph=(s >= 2))
+        exits.append(r["exit_layer"])
+        assert r["exit_layer"] == ref[s][0], (s, exits, [x[0] for x in ref])
+        assert float((r["pose"] - ref[s][1]).abs().max()) < ACTION_TOL, s
+        assert abs(r["gripper"] - ref[s][2]) < ACTION_TOL
+    assert len(set(exits)) > 1, exits                     # the schedule really is dynamic
+    assert exits == [x[0] for x in ref]
+
+
+def test_graph_replay_is_bit_identical_to_eager(tiny):
+    cfg, sd, eng = tiny
+    inputs = make_inputs(cfg, 6)
+    eng.configure_exit(cfg.exit_ids(), 12, 1)
+    eng.set_thresholds([0.05] * (eng.real_num_exit - 1) + [1e5])
+    res = []
+    for use_graph in (False, True):
+        eng.reset()
+        out = []
+        for s, (rgb, grip, ids, mask) in enumerate(inputs):
+            r = eng.step(rgb, grip, ids, mask, use_graph=use_graph)
+            out.append((r["exit_layer"], r["pose"].clone(), r["gripper"]))
+        res.append(out)
+    for a, b in zip(*res):
+        assert a[0] == b[0] and torch.equal(a[1], b[1]) and a[2] == b[2]
+
+
+def test_padding_mask_and_text_lengths(tiny):
+    cfg, sd, eng = tiny
+    for T, pad in ((5, 0), (16, 3), (17, 0), (32, 5)):
+        rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, 1, text_len=T)
+        if pad:
+            mask[0, T - pad:] = False
+        o = orc.OracleDeer(sd, cfg)
+        o.set_all_exit_window_size(1)
+        ref = o.forward(rgb, ids, mask, grip, exit_id=2)
+        eng.reset()
+        r = eng.step(rgb, grip, ids, mask, exit_id=2, use_graph=False)
+        a, b = eng.hidden[2, :T].cpu(), ref["hidden_states"][2][0]
+        assert float((a - b).norm() / b.norm()) < 1e-2, (T, pad)
+        assert float((r["pose"] - ref["logits"][0].reshape(-1)).abs().max()) < ACTION_TOL
+
+
+def test_full_size_mpt1b_vitl14_steps_vs_oracle():
+    """BASELINE config sizes (ViT-L/14 x2, Perceiver, MPT-1B d=2048 x12 layers, 4x1024 LSTM head): static exit
+    and a short dynamic episode against the fp32 CPU oracle."""
+    cfg = deer_3b(max_layer=12)
+    sd = syn.make_synthetic_state(cfg, 0, std="0.02", bf16_round=True)
+    eng = DeerEngine(cfg, sd)
+    inputs = make_inputs(cfg, 3)
+    model = orc.OracleDeer(sd, cfg)
+    model.set_all_exit_window_size(1)
+    rgb, grip, ids, mask = inputs[0]
+    o = model.forward(rgb, ids, mask, grip, exit_id=11)
+    eng.reset()
+    r = eng.step(rgb, grip, ids, mask, exit_id=11, use_graph=False)
+    vis, ref_vis = eng.vis_x_f32.cpu(), o["vis_x"].reshape(cfg.n_media, cfg.vit_width)
+    assert float((vis - ref_vis).norm() / ref_vis.norm()) < 2e-2
+    for i in (0, 5, 11):
+        a, b = eng.hidden[i, :14].cpu(), o["hidden_states"][i][0]
+        assert float((a - b).norm() / b.norm()) < 2e-2, i
+    assert float((r["pose"] - o["logits"][0].reshape(-1)).abs().max()) < ACTION_TOL
+    assert abs(r["gripper"] - float(o["logits"][1])) < ACTION_TOL
+    # dynamic: thresholds in the widest gaps of the oracle's deltas
+    thr = probe_thresholds(cfg, sd, inputs, 12)
+    ref, rec, _ = oracle_episode(cfg, sd, inputs, thr, 12)
+    eng.configure_exit(cfg.exit_ids(), 12, 1)
+    eng.set_thresholds(thr)
+    eng.reset()
+    for s, (rgb, grip, ids, mask) in enumerate(inputs):
+        rr = eng.step(rgb, grip, ids, mask, use_graph=False)
+        assert rr["exit_layer"] == ref[s][0], (s, rr["exit_layer"], ref[s][0], rr["deltas"][:6], thr)
+        assert float((rr["pose"] - ref[s][1]).abs().max()) < ACTION_TOL

@@ -1,0 +1,299 @@
+"""Per-kernel parity tests on a real MI355X, calling libdeer_hip.so THROUGH ITS C ABI (ctypes, raw device
+pointers) and comparing with plain fp32 torch math on the same inputs.  Tolerances are written in each test:
+integer/index results exact; fp32-accumulated bf16 GEMMs ~1e-5 relative (inputs are bf16-exact in both arms);
+kernels that round an intermediate to bf16 (softmax probabilities, bf16 outputs) ~1e-2."""
+import ctypes
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from deer_vla_amd import _abi as abi  # noqa: E402
+
+
+def st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(t, dt=None):
+    return t.to("cuda", dtype=dt).contiguous() if dt is not None else t.to("cuda").contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def rel_err(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    l = abi.lib()
+    assert l.deer_hip_arch() == b"gfx950"
+    return l
+
+
+# ------------------------------------------------------------------------------------------ skinny GEMM
+@pytest.mark.parametrize("M", [1, 14, 16, 17, 32])
+@pytest.mark.parametrize("N,K", [(512, 2048), (2048, 512), (6144, 2048), (2048, 8192), (64, 32), (48, 96)])
+def test_gemm_skinny_packed(lib, M, N, K):
+    A = dev(rnd(M, K, seed=1), torch.bfloat16)
+    W = dev(rnd(N, K, seed=2, scale=K ** -0.5), torch.bfloat16)
+    Wp = torch.empty_like(W)
+    abi.check(lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), N, K, st()), "pack")
+    S = lib.deer_skinny_splitk(M, N, K)
+    assert S >= 1 and K % (S * 32) == 0
+    mpad = 16 if M <= 16 else 32
+    part = torch.full((S, mpad, N), float("nan"), device="cuda")
+    abi.check(lib.deer_gemm_skinny(abi.ptr(A), K, None, 0, 0, abi.A_BF16, abi.ptr(Wp), abi.ptr(part), M, N, K, S, None, st()), "skinny")
+    torch.cuda.synchronize()
+    out = part.sum(0)[:M]
+    ref = A.float() @ W.float().t()
+    assert rel_err(out, ref) < 2e-5
+    assert torch.isfinite(part).all()                      # padded rows are written as zeros, never NaN
+    if mpad > M:
+        assert float(part[:, M:].abs().max()) == 0.0
+
+
+def test_gemm_skinny_slab_gelu_input_and_determinism(lib):
+    M, K, N = 14, 8192, 2048
+    s_in = 4
+    slab = dev(rnd(s_in, 16, K, seed=3))
+    W = dev(rnd(N, K, seed=4, scale=K ** -0.5), torch.bfloat16)
+    Wp = torch.empty_like(W)
+    abi.check(lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), N, K, st()), "pack")
+    S = lib.deer_skinny_splitk(M, N, K)
+    outs = []
+    for _ in range(2):
+        part = torch.zeros(S, 16, N, device="cuda")
+        abi.check(lib.deer_gemm_skinny(None, 0, abi.ptr(slab), s_in, 16 * K, abi.A_SLABS_GELU, abi.ptr(Wp), abi.ptr(part), M, N, K, S,
+                                       None, st()), "skinny")
+        torch.cuda.synchronize()
+        outs.append(part.sum(0)[:M].clone())
+    a = torch.nn.functional.gelu(slab.sum(0)[:M]).to(torch.bfloat16).float()
+    ref = a @ W.float().t()
+    assert rel_err(outs[0], ref) < 1e-3                      # bf16 rounding of gelu(sum) may differ by 1 ulp on ties
+    assert torch.equal(outs[0], outs[1])                     # bit-reproducible (no atomics)
+
+
+def test_skinny_respects_exit_flag(lib):
+    ctl = torch.zeros(abi.CTL_WORDS, dtype=torch.int32, device="cuda")
+    ctl[abi.CTL_EXIT_FLAG] = 1
+    A = dev(rnd(4, 64), torch.bfloat16)
+    W = dev(rnd(32, 64), torch.bfloat16)
+    Wp = torch.empty_like(W)
+    abi.check(lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), 32, 64, st()), "pack")
+    part = torch.full((1, 16, 32), 7.0, device="cuda")
+    abi.check(lib.deer_gemm_skinny(abi.ptr(A), 64, None, 0, 0, abi.A_BF16, abi.ptr(Wp), abi.ptr(part), 4, 32, 64, 1, abi.ptr(ctl), st()), "skinny")
+    torch.cuda.synchronize()
+    assert float(part.min()) == 7.0                          # kernel returned at entry
+
+
+def test_abi_rejects_bad_shapes(lib):
+    assert lib.deer_gemm_skinny(None, 0, None, 0, 0, 0, None, None, 40, 64, 64, 1, None, st()) == 1      # M > 32
+    assert lib.deer_gemm_skinny(None, 0, None, 0, 0, 0, None, None, 4, 60, 64, 1, None, st()) == 1       # N % 16
+    assert lib.deer_gemm_bf16_nt(None, 8, 0, None, 8, None, None, 8, 0, 4, 16, 12, 1, 0, None, 0, None, st()) == 1   # K % 8
+    assert lib.deer_attn_mfma_hd64(None, None, None, None, 1, 1, 4, 400, 64, 64, 64, 64, 0, 0, 0, 0, 1.0, st()) == 1  # kv_len
+
+
+# ------------------------------------------------------------------------------------------- tiled GEMM
+@pytest.mark.parametrize("tile", [1, 2, 3, 0])
+@pytest.mark.parametrize("M,N,K", [(514, 3072, 1024), (514, 1024, 4096), (128, 1024, 512), (37, 128, 640), (640, 1024, 1024)])
+def test_gemm_tiled_epilogues(lib, tile, M, N, K):
+    A = dev(rnd(M, K, seed=5), torch.bfloat16)
+    W = dev(rnd(N, K, seed=6, scale=K ** -0.5), torch.bfloat16)
+    bias = dev(rnd(N, seed=7, scale=0.1))
+    ref = A.float() @ W.float().t() + bias
+
+    def run(epi, C, gate=None, b=bias):
+        abi.check(lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(W), K, abi.ptr(b), abi.ptr(C), N, 0, M, N, K, 1, epi, abi.ptr(gate),
+                                        tile, None, st()), "gemm")
+        torch.cuda.synchronize()
+
+    C = torch.zeros(M, N, device="cuda")
+    run(abi.EPI_F32, C)
+    assert rel_err(C, ref) < 2e-5
+    Cb = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    run(abi.EPI_BF16, Cb)
+    assert rel_err(Cb.float(), ref) < 4e-3                   # one bf16 rounding of the output
+    run(abi.EPI_QGELU_BF16, Cb)
+    assert rel_err(Cb.float(), ref * torch.sigmoid(1.702 * ref)) < 4e-3
+    run(abi.EPI_GELU_BF16, Cb)
+    assert rel_err(Cb.float(), torch.nn.functional.gelu(ref)) < 4e-3
+    R0 = dev(rnd(M, N, seed=8))
+    R = R0.clone()
+    gate = torch.tensor([0.5], device="cuda")
+    run(abi.EPI_RESADD_F32, R, gate)
+    assert rel_err(R, R0 + math.tanh(0.5) * ref) < 2e-5
+    R = R0.clone()
+    run(abi.EPI_RESADD_F32, R, None, None)
+    assert rel_err(R, R0 + (ref - bias)) < 2e-5
+
+
+def test_gemm_tiled_batched_strided(lib):
+    B, M, N, K, rows = 2, 64, 512, 128, 80
+    A = dev(rnd(B, rows, K, seed=9), torch.bfloat16)         # use rows 16..79 of each batch
+    W = dev(rnd(N, K, seed=10, scale=K ** -0.5), torch.bfloat16)
+    C = torch.zeros(B, M, N, device="cuda", dtype=torch.bfloat16)
+    abi.check(lib.deer_gemm_bf16_nt(abi.ptr(A, 16 * K * 2), K, rows * K, abi.ptr(W), K, None, abi.ptr(C), N, M * N, M, N, K, B, abi.EPI_BF16,
+                                    None, 0, None, st()), "gemm")
+    torch.cuda.synchronize()
+    ref = A[:, 16:].float() @ W.float().t()
+    assert rel_err(C.float(), ref) < 4e-3
+
+
+# -------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,H,q_len,kv_len", [(2, 16, 257, 257), (2, 8, 64, 320), (2, 2, 17, 17), (1, 1, 5, 68), (1, 3, 100, 33)])
+def test_attn_mfma(lib, B, H, q_len, kv_len):
+    hd = 64
+    q = dev(rnd(B, q_len, H * hd, seed=11), torch.bfloat16)
+    k = dev(rnd(B, kv_len, H * hd, seed=12), torch.bfloat16)
+    v = dev(rnd(B, kv_len, H * hd, seed=13), torch.bfloat16)
+    o = torch.zeros(B, q_len, H * hd, device="cuda", dtype=torch.bfloat16)
+    scale = hd ** -0.5
+    abi.check(lib.deer_attn_mfma_hd64(abi.ptr(q), abi.ptr(k), abi.ptr(v), abi.ptr(o), B, H, q_len, kv_len, H * hd, H * hd, H * hd, H * hd,
+                                      q_len * H * hd, kv_len * H * hd, kv_len * H * hd, q_len * H * hd, scale, st()), "attn")
+    torch.cuda.synchronize()
+    qf = q.float().view(B, q_len, H, hd).transpose(1, 2)
+    kf = k.float().view(B, kv_len, H, hd).transpose(1, 2)
+    vf = v.float().view(B, kv_len, H, hd).transpose(1, 2)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * scale, -1) @ vf).transpose(1, 2).reshape(B, q_len, H * hd)
+    assert rel_err(o.float(), ref) < 8e-3                    # P and O are rounded to bf16
+    assert float((o.float() - ref).abs().max()) < 3e-2
+
+
+def test_xattn_small(lib):
+    T, n_kv, heads, inner, ldkv = 14, 128, 8, 512, 3 * 1024
+    s_in = 3
+    qs = dev(rnd(s_in, 16, inner, seed=14))
+    kv = dev(rnd(n_kv, ldkv, seed=15), torch.bfloat16)
+    tt = torch.tensor([1] * T, dtype=torch.int32, device="cuda")
+    tt[3] = 0                                                # a token without preceding media -> zero row
+    out = torch.zeros(T, inner, device="cuda", dtype=torch.bfloat16)
+    off = 1024                                               # second layer's slice
+    abi.check(lib.deer_xattn_small(abi.ptr(qs), s_in, 16 * inner, inner, abi.ptr(kv, off * 2), ldkv, inner, abi.ptr(tt), 128, abi.ptr(out),
+                                   inner, T, n_kv, heads, 64 ** -0.5, None, st()), "xattn")
+    torch.cuda.synchronize()
+    q = qs.sum(0)[:T].view(T, heads, 64).transpose(0, 1) * 64 ** -0.5
+    k = kv[:, off:off + inner].float().view(n_kv, heads, 64).transpose(0, 1)
+    v = kv[:, off + inner:off + 2 * inner].float().view(n_kv, heads, 64).transpose(0, 1)
+    a = torch.softmax(q @ k.transpose(-1, -2), -1)
+    a[:, 3] = 0
+    ref = (a @ v).transpose(0, 1).reshape(T, inner)
+    assert rel_err(out.float(), ref) < 4e-3
+    assert float(out[3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("qk_ln", [True, False])
+@pytest.mark.parametrize("T,d,H", [(14, 2048, 16), (9, 256, 2), (32, 64, 2)])
+def test_mpt_attn_small(lib, qk_ln, T, d, H):
+    s_in = 2
+    mpad = 16 if T <= 16 else 32
+    slab = dev(rnd(s_in, mpad, 3 * d, seed=16))
+    qw, kw = dev(1 + 0.1 * rnd(d, seed=17)), dev(1 + 0.1 * rnd(d, seed=18))
+    mask = torch.ones(T, dtype=torch.uint8, device="cuda")
+    mask[T - 2:] = 0                                         # right padding
+    out = torch.zeros(T, d, device="cuda", dtype=torch.bfloat16)
+    abi.check(lib.deer_mpt_attn_small(abi.ptr(slab), s_in, mpad * 3 * d, d, H, abi.ptr(qw) if qk_ln else None, abi.ptr(kw) if qk_ln else None,
+                                      1e-5, abi.ptr(mask), 8.0, abi.ptr(out), d, T, None, st()), "mpt attn")
+    torch.cuda.synchronize()
+    qkv = slab.sum(0)[:T]
+    q, k, v = qkv.chunk(3, -1)
+    if qk_ln:
+        q = torch.nn.functional.layer_norm(q, (d,), qw)
+        k = torch.nn.functional.layer_norm(k, (d,), kw)
+    hd = d // H
+    q, k, v = (t.view(T, H, hd).transpose(0, 1) for t in (q, k, v))
+    slopes = 2.0 ** (-8.0 * torch.arange(1, H + 1, device="cuda") / H)
+    bias = -(T - 1 - torch.arange(T, device="cuda")).float().view(1, 1, T) * slopes.view(H, 1, 1)
+    w = q @ k.transpose(-1, -2) * hd ** -0.5 + bias
+    w = w.masked_fill(~mask.bool().view(1, 1, T), float("-inf"))
+    w = w.masked_fill(torch.ones(T, T, device="cuda").triu(1).bool(), float("-inf"))
+    ref = (torch.softmax(w, -1) @ v).transpose(0, 1).reshape(T, d)
+    assert rel_err(out.float(), ref) < 4e-3                  # output rounded to bf16
+
+
+# ---------------------------------------------------------------------------------------------- row ops
+def test_layernorm_rows_and_strides(lib):
+    B, R, C = 2, 5, 1024
+    x = dev(rnd(B, R + 1, C, seed=19))
+    g, b = dev(1 + 0.1 * rnd(C, seed=20)), dev(0.1 * rnd(C, seed=21))
+    out = torch.zeros(B, R + 3, C, device="cuda", dtype=torch.bfloat16)
+    outf = torch.zeros(B, R + 3, C, device="cuda")
+    # read rows 1..R of each batch, write them at rows 2..R+1
+    abi.check(lib.deer_layernorm_rows(abi.ptr(x, C * 4), C, (R + 1) * C, R, B, abi.ptr(g), abi.ptr(b), abi.ptr(out, 2 * C * 2),
+                                      abi.ptr(outf, 2 * C * 4), C, (R + 3) * C, C, 1e-5, st()), "ln")
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x[:, 1:], (C,), g, b)
+    assert float((outf[:, 2:R + 2] - ref).abs().max()) < 2e-5
+    assert rel_err(out[:, 2:R + 2].float(), ref) < 4e-3
+    assert float(out[:, :2].abs().max()) == 0 and float(out[:, R + 2:].abs().max()) == 0
+
+
+def test_resadd_ln(lib):
+    T, d, s_in = 14, 2048, 5
+    x0 = dev(rnd(T, d, seed=22))
+    slab = dev(rnd(s_in, 16, d, seed=23))
+    gate = torch.tensor([-0.3], device="cuda")
+    g = dev(1 + 0.1 * rnd(d, seed=24))
+    x = x0.clone()
+    out = torch.zeros(T, d, device="cuda", dtype=torch.bfloat16)
+    cp = torch.zeros(T, d, device="cuda")
+    abi.check(lib.deer_resadd_ln(abi.ptr(x), abi.ptr(slab), s_in, 16 * d, abi.ptr(gate), abi.ptr(g), None, abi.ptr(out), abi.ptr(cp), T, d, 1e-5,
+                                 None, st()), "resadd")
+    torch.cuda.synchronize()
+    xr = x0 + math.tanh(-0.3) * slab.sum(0)[:T]
+    assert float((x - xr).abs().max()) < 1e-5 and torch.equal(x, cp)
+    assert rel_err(out.float(), torch.nn.functional.layer_norm(xr, (d,), g)) < 4e-3
+    # no slab, no LN: pure copy
+    x2 = x0.clone()
+    abi.check(lib.deer_resadd_ln(abi.ptr(x2), None, 0, 0, None, None, None, None, abi.ptr(cp), T, d, 1e-5, None, st()), "resadd")
+    torch.cuda.synchronize()
+    assert torch.equal(cp, x0)
+
+
+def test_vit_patch_embed(lib):
+    N, S, p, W = 2, 56, 14, 128
+    gw, P, kk, Kpad = 4, 16, 588, 640
+    img = dev(rnd(N, 3, S, S, seed=25))
+    conv = dev(rnd(W, 3, p, p, seed=26, scale=kk ** -0.5))
+    col = torch.full((N * P, Kpad), 9.0, device="cuda", dtype=torch.bfloat16)
+    abi.check(lib.deer_vit_im2col(abi.ptr(img), 0, N, S, p, abi.ptr(col), Kpad, st()), "im2col")
+    torch.cuda.synchronize()
+    ref_col = torch.nn.functional.unfold(img, p, stride=p).transpose(1, 2).reshape(N * P, kk)
+    assert torch.equal(col[:, :kk].float(), ref_col.to(torch.bfloat16).float())
+    assert float(col[:, kk:].abs().max()) == 0.0
+    imgb = img.to(torch.bfloat16)
+    abi.check(lib.deer_vit_im2col(abi.ptr(imgb), 1, N, S, p, abi.ptr(col), Kpad, st()), "im2col")
+    torch.cuda.synchronize()
+    assert torch.equal(col[:, :kk].float(), ref_col.to(torch.bfloat16).float())
+    patch = dev(rnd(N * P, W, seed=27))
+    cls, pos = dev(rnd(W, seed=28)), dev(rnd(P + 1, W, seed=29))
+    g, b = dev(1 + 0.1 * rnd(W, seed=30)), dev(0.1 * rnd(W, seed=31))
+    x = torch.zeros(N, P + 1, W, device="cuda")
+    abi.check(lib.deer_vit_embed_lnpre(abi.ptr(patch), abi.ptr(cls), abi.ptr(pos), abi.ptr(g), abi.ptr(b), abi.ptr(x), N, P, W, 1e-5, st()), "embed")
+    torch.cuda.synchronize()
+    ref = torch.cat([cls.view(1, 1, W).expand(N, 1, W), patch.view(N, P, W)], 1) + pos
+    ref = torch.nn.functional.layer_norm(ref, (W,), g, b)
+    assert float((x - ref).abs().max()) < 2e-5
+
+
+def test_embed_tokens_and_text_time(lib):
+    T, d, V = 9, 256, 515
+    wte = dev(rnd(V, d, seed=32), torch.bfloat16)
+    ids = torch.tensor([513, 4, 77, 513, 5, 6, 512, 0, 514], device="cuda")
+    x = torch.zeros(T, d, device="cuda")
+    tt = torch.zeros(T, dtype=torch.int32, device="cuda")
+    abi.check(lib.deer_embed_tokens(abi.ptr(ids), abi.ptr(wte), abi.ptr(x), abi.ptr(tt), T, d, V, 513, st()), "embed")
+    torch.cuda.synchronize()
+    assert torch.equal(x, wte[ids].float())
+    assert tt.tolist() == [1, 1, 1, 2, 2, 2, 2, 2, 2]
+    lat = dev(rnd(64, d, seed=33))
+    dst = torch.zeros(3, 64, d, device="cuda")
+    abi.check(lib.deer_broadcast_rows(abi.ptr(lat), abi.ptr(dst), 64 * d, 3, st()), "bcast")
+    torch.cuda.synchronize()
+    assert torch.equal(dst, lat.expand(3, 64, d))

@@ -159,7 +159,8 @@ def test_full_forward_matches_reference_mptflamingo():
     """BASELINE config[0] (fixed exit, B=1, CPU) and the dynamic-exit step protocol, against the
     reference's own MPTFlamingo.forward."""
     cfg, seed, g = load("deer_forward.npz")
-    sd = state(cfg, seed)
+    from deer_vla_amd import synthetic as syn
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=bool(int(g["bf16_round"])))
     model = orc.OracleDeer(sd, cfg)
     model.set_all_exit_window_size(1)
     ids, mask = g["ids"].long(), g["mask"].bool()
