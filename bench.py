@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py - action-steps/s of the DeeR-VLA early-exit forward path on MI355X (contract: see the task brief).
+
+One "step" = one control step of one environment (what ``ModelWrapper.step`` -> ``MPTFlamingo.forward`` does in
+the reference, robot_flamingo/eval/eval_utils.py:279-480): two 224x224 camera frames -> ViT-L/14 x2 -> Perceiver
+x2 -> MPT-1B layers with gated x-attn until the exit criterion fires -> LSTM action head -> 7-DoF action on the
+host.  Inputs are synthetic and already resident in HBM (SURVEY.md §8d protocol); weights are seeded random
+tensors of the real architecture (no checkpoints/network in this environment).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Each rank owns a full model replica + its own environment stream (the path shards by environment):
+no data-path collective; RCCL is used only for the barrier and the final metric reduction -> "scaling": "weak".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+EP_LEN = 360            # robot_flamingo/eval/eval_utils.py:44
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_PEAK_TF = 2500.0   # dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="deer_b", choices=["deer_b", "deer_s"],
+                    help="deer_b: MPT-1B max_layer=12 exit_ratio 0.8 (the metric's config); deer_s: max_layer=4")
+    ap.add_argument("--exit-ratio", type=float, default=0.8)
+    ap.add_argument("--calib-steps", type=int, default=96)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+# kernel class (C-ABI entry point) -> which roofline bounds it
+KERNEL_BOUND = {"deer_gemm_bf16_nt": "mfma", "deer_attn_mfma_hd64": "mfma", "deer_gemm_skinny": "hbm"}
+
+
+def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
+    """In-situ per-kernel timing with HIP events (on the launch stream) over full control steps of the SAME workload:
+    every launch of every kernel class is bracketed by two events while the step runs eagerly behind a spin kernel
+    (so the host is ahead of the GPU and brackets contain no host launch gaps).  The static full-depth schedule
+    (exit at the last layer) is used so that every kernel really executes.  Returns the roofline object of the
+    DOMINANT kernel class (largest share of GPU time) plus the per-class breakdown."""
+    from deer_vla_amd import _abi as abi
+    import ctypes
+    lib = abi.lib()
+    T = ids.shape[1]
+    exit_id = eng.ctl_max_layer
+    # event-bracket overhead: an empty bracket
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    lib.deer_spin_us(300, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    for a, b in evs:
+        a.record()
+        b.record()
+    torch.cuda.synchronize()
+    overhead_us = sorted(1e3 * a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
+    agg = {}
+    for p in range(n_pass):
+        rgb, grip = frames[p % len(frames)]
+        eng.reset()
+        eng.load_inputs(rgb, grip, ids, None)
+        eng.hold_dev.fill_(0)
+        torch.cuda.synchronize()
+        eng._prof = []
+        lib.deer_spin_us(12000, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        eng._enqueue_step(T, False, exit_id)
+        torch.cuda.synchronize()
+        prof, eng._prof = eng._prof, None
+        if p == 0:
+            continue                                      # first pass warms caches / clocks
+        for name, e0, e1, fl, by in prof:
+            d = agg.setdefault(name, dict(us=0.0, n=0, flops=0.0, bytes=0.0))
+            d["us"] += max(1e3 * e0.elapsed_time(e1) - overhead_us, 0.0)
+            d["n"] += 1
+            d["flops"] += fl
+            d["bytes"] += by
+    total_us = sum(d["us"] for d in agg.values())
+    classes = {}
+    for name, d in sorted(agg.items(), key=lambda kv: -kv[1]["us"]):
+        avg = d["us"] / d["n"]
+        c = {"share": round(d["us"] / total_us, 4), "launches_per_step": d["n"] // (n_pass - 1), "avg_us": round(avg, 2)}
+        if d["flops"]:
+            c["TFLOP/s"] = round(d["flops"] / d["us"] / 1e6, 1)
+        if d["bytes"]:
+            c["GB/s"] = round(d["bytes"] / d["us"] / 1e3, 1)
+        classes[name] = c
+    dom = max((k for k in agg if k in KERNEL_BOUND), key=lambda k: agg[k]["us"])
+    d = agg[dom]
+    if KERNEL_BOUND[dom] == "mfma":
+        achieved, peak, unit = d["flops"] / d["us"] / 1e6, MFMA_PEAK_TF, "TFLOP/s"
+    else:
+        achieved, peak, unit = d["bytes"] / d["us"] / 1e3, HBM_PEAK_GBS, "GB/s"
+    return {"kernel": dom, "bound": KERNEL_BOUND[dom], "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "avg_launch_us": round(d["us"] / d["n"], 2), "launches_per_step": d["n"] // (n_pass - 1),
+            "event_overhead_us": round(overhead_us, 2), "gpu_us_per_full_depth_step": round(total_us / (n_pass - 1), 1),
+            "classes": classes}
+
+
+def cpu_baseline(cfg, sd, ctl, n_steps, rank):
+    """The CPU oracle (oracle/deer_oracle.py = pure-PyTorch fp32 restatement of the reference forward, pinned against
+    the reference's own modules) timed on this box's host cores on a bounded sample of the same workload."""
+    from deer_vla_amd import synthetic as syn
+    from oracle import deer_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = orc.OracleDeer(sd, cfg)
+    model.set_all_exit_window_size(1)
+    vn = orc.OracleValueNet(ctl.exit_id_list, model.extra_exit, cfg.exit_interval, 1, "L2")
+    oc = orc.OracleExitController(vn, ctl.exit_id_list, steps_per_stage=1, max_layer=ctl.max_layer + 1)
+    oc._set_threshold_value(ctl.threshold_list())
+    exits = []
+    with torch.no_grad():
+        def one(s):
+            rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, s, rank=rank)
+            oc.set_timestep(s)
+            o = model.forward(rgb, ids, mask, grip, dynamic_early_exit=True, exit_controller=oc)
+            return o["exit_layer"]
+        one(0)                                             # warm-up (thread pools, allocator)
+        model.clear_all_exit_memory()
+        t0 = time.perf_counter()
+        for s in range(n_steps):
+            exits.append(one(s) + 1)
+        dt = time.perf_counter() - t0
+    return {"value": round(n_steps / dt, 4), "unit": "action-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n_steps} control steps of the same workload (fp32, torch.set_num_threads({cores})), "
+                      f"avg exit layer {sum(exits) / len(exits):.2f}, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from deer_vla_amd import synthetic as syn
+    from deer_vla_amd.config import deer_3b
+    from deer_vla_amd.engine import DeerEngine
+    from deer_vla_amd.value_net import ExitController
+
+    max_layer = 12 if args.workload == "deer_b" else 4
+    cfg = deer_3b(max_layer=max_layer)
+    t0 = time.time()
+    sd = syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True)
+    eng = DeerEngine(cfg, sd, device=f"cuda:{local_rank}")
+    if rank != 0 or args.no_cpu_baseline or world > 1:
+        sd = None                                         # only rank 0 at N=1 needs the fp32 host copy (cpu_baseline)
+    ctl = ExitController(None, cfg.exit_ids(), steps_per_stage=1, max_layer=max_layer)
+    eng.configure_exit(ctl.exit_id_list, max_layer, 1)
+    setup_s = time.time() - t0
+
+    # ---- synthetic inputs, resident in HBM (bf16 frames) ----
+    POOL = 32
+    dev = eng.dev
+    frames = []
+    for s in range(POOL):
+        rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, s, rank=rank)
+        frames.append((rgb.to(dev, torch.bfloat16), grip.to(dev, torch.bfloat16)))
+    ids = ids.to(dev)
+    T = ids.shape[1]
+
+    def run_step(i, use_graph=True, sync=True):
+        if i % EP_LEN == 0:
+            eng.reset()                                   # new episode: LSTM / controller state cleared
+            eng.cur_step = 0
+        rgb, grip = frames[i % POOL]
+        return eng.step(rgb, grip, ids, None, use_graph=use_graph and not args.no_graph, sync=sync)
+
+    # ---- threshold calibration for --exit-ratio on a never-exit pass (value_net.py:185-264 semantics) ----
+    real = ctl.real_num_exit
+    eng.set_thresholds([-1.0] * (real - 1) + [1e5])
+    vals = []
+    for i in range(args.calib_steps):
+        r = run_step(i)
+        vals.append(r["deltas"][:real].clone())
+    values = torch.stack(vals, dim=1)                      # (n_exit, n_samples)
+    ctl.set_threshold_from_values(values, args.exit_ratio, cfg.llm_name)
+    eng.set_thresholds(ctl.threshold_list())
+
+    # ---- timed region ----
+    for i in range(args.warmup):
+        run_step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    exit_sum, hist = 0, [0] * cfg.n_layers
+    for i in range(args.steps):
+        r = run_step(i)
+        exit_sum += r["exit_layer"] + 1
+        hist[r["exit_layer"]] += 1
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    stats = torch.tensor([elapsed, float(exit_sum), float(args.steps)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)         # one tiny RCCL all-reduce: the only exchange of the path
+        stats[0] = tmax[0]
+    t_max, exits, n_steps = float(stats[0]), float(stats[1]), float(stats[2])
+    value = n_steps / t_max
+    avg_exit = exits / n_steps
+
+    out = {
+        "metric": "action-steps/sec (whole job) + avg exit-layer, MPT-1B max_layer=%d, synthetic CALVIN-D-shaped inputs" % max_layer,
+        "value": round(value, 2), "unit": "action-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "avg_exit_layer": round(avg_exit, 3),
+        "config": {"workload": "OpenFlamingo-3B/MPT-1B DeeR-%s max_layer=%d exit_ratio=%.2f, step mode B=1 env/GPU, "
+                               "2x224x224 frames + %d text tokens, LSTM history carried over %d-step episodes"
+                               % ("B" if max_layer == 12 else "S", max_layer, args.exit_ratio, T, EP_LEN),
+                   "exit_hist": hist if world == 1 else None, "per_gpu_steps_per_s": round(value / world, 2),
+                   "graph": not args.no_graph, "weights_gb": round(eng.weight_bytes() / 1e9, 3),
+                   "thresholds": [round(x, 6) for x in ctl.threshold_list()], "setup_s": round(setup_s, 1)},
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            out["roofline"] = measure_roofline(eng, cfg, frames, ids)
+        if sd is not None:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, ctl, args.cpu_steps, rank)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,10 +24,10 @@ SIGNATURES = {
     "deer_skinny_splitk": [I, I, I],
     "deer_pack_weight_mfma16": [P, P, I, I, P],
     "deer_attn_mfma_hd64": [P, P, P, P, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
-    "deer_xattn_small": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, F, P, P],
-    "deer_mpt_attn_small": [P, I, L, I, I, P, P, F, P, F, P, I, I, P, P],
+    "deer_xattn_small": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, I, F, P, P],
+    "deer_mpt_attn_small": [P, I, L, I, I, P, P, F, P, F, P, I, I, I, P, P],
     "deer_layernorm_rows": [P, L, L, I, I, P, P, P, P, L, L, I, F, P],
-    "deer_resadd_ln": [P, P, I, L, P, P, P, P, P, I, I, F, P, P],
+    "deer_resadd_ln": [P, P, I, L, P, P, P, P, P, P, I, I, F, P, P],
     "deer_vit_im2col": [P, I, I, I, I, P, I, P],
     "deer_vit_embed_lnpre": [P, P, P, P, P, P, I, I, I, F, P],
     "deer_embed_tokens": [P, P, P, P, I, I, I, I, P],
@@ -36,6 +36,7 @@ SIGNATURES = {
     "deer_head_fc": [P, I, I, P, P, P, P, P, P, P, P, I, P, F, P, I, I, P],
     "deer_head_final": [P, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, P, F, P],
     "deer_ctl_begin_step": [P, P, P],
+    "deer_spin_us": [I, P],
     "deer_hip_arch": [],
     "deer_hip_abi_version": [],
 }
@@ -45,7 +46,7 @@ _RESTYPE = {"deer_hip_arch": c_char_p}
 CTL_EXIT_FLAG, CTL_EXIT_LAYER, CTL_CUR_EXIT_ID, CTL_HOLD, CTL_N_EVALS = 0, 1, 2, 3, 4
 CTL_PREV_ACTION, CTL_OUT_ACTION, CTL_DELTAS, CTL_WORDS = 8, 16, 24, 64
 EPI_BF16, EPI_F32, EPI_QGELU_BF16, EPI_GELU_BF16, EPI_RESADD_F32 = 0, 1, 2, 3, 4
-A_BF16, A_SLABS_GELU, A_SLABS = 0, 1, 2
+A_BF16, A_SLABS_GELU, A_SLABS, A_F32 = 0, 1, 2, 3
 X_RAW, X_POOL_MAX, X_POOL_AVG, X_LN = 0, 1, 2, 3
 PRO_RAW, PRO_LN, PRO_GROUP_LN_RELU, PRO_GROUP_RELU = 0, 1, 2, 3
 KIND_PSEUDO, KIND_CHECK, KIND_COMMIT = 0, 1, 2

@@ -180,8 +180,8 @@ extern "C" int deer_attn_mfma_hd64(const void* Q, const void* K, const void* V, 
 __global__ __launch_bounds__(256) void xattn_small_kernel(const float* __restrict__ qslab, int s_in, long slab_stride,
                                                           int ldqs, const bf16_t* __restrict__ kv, int ldkv, int inner,
                                                           const int* __restrict__ text_time, int n_per_media,
-                                                          bf16_t* __restrict__ out, int ldo, int T, int n_kv,
-                                                          float scale, const int* ctl) {
+                                                          void* __restrict__ out, int out_is_f32, int ldo, int T,
+                                                          int n_kv, float scale, const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ float qs[XA_MAXT][64 + 1];
   __shared__ float sim[XA_MAXT][XA_MAXKV + 1];
@@ -231,17 +231,18 @@ __global__ __launch_bounds__(256) void xattn_small_kernel(const float* __restric
     const int t = idx >> 6, d = idx & 63;
     float a = 0.f;
     for (int j = 0; j < n_kv; ++j) a += sim[t][j] * bf2f(vs[j][d]);
-    out[(long)t * ldo + h * 64 + d] = f2bf(a);
+    if (out_is_f32) reinterpret_cast<float*>(out)[(long)t * ldo + h * 64 + d] = a;
+    else reinterpret_cast<bf16_t*>(out)[(long)t * ldo + h * 64 + d] = f2bf(a);
   }
 }
 
 extern "C" int deer_xattn_small(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv,
-                                int inner, const int* text_time, int n_per_media, void* out, int ldo, int T, int n_kv,
-                                int heads, float scale, const int* ctl, void* stream) {
+                                int inner, const int* text_time, int n_per_media, void* out, int out_is_f32, int ldo, int T,
+                                int n_kv, int heads, float scale, const int* ctl, void* stream) {
   if (T <= 0 || T > XA_MAXT || n_kv <= 0 || n_kv > XA_MAXKV || s_in <= 0 || n_per_media <= 0) return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(xattn_small_kernel, dim3(heads), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qslab, s_in,
-                     slab_stride, ldqs, reinterpret_cast<const bf16_t*>(kv), ldkv, inner, text_time, n_per_media,
-                     reinterpret_cast<bf16_t*>(out), ldo, T, n_kv, scale, ctl);
+                     slab_stride, ldqs, reinterpret_cast<const bf16_t*>(kv), ldkv, inner, text_time, n_per_media, out,
+                     out_is_f32, ldo, T, n_kv, scale, ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
@@ -258,7 +259,8 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
                                                              const float* __restrict__ k_ln_w, float eps,
                                                              const unsigned char* __restrict__ key_mask,
                                                              float alibi_slope_base, int n_heads,
-                                                             bf16_t* __restrict__ out, int ldo, int T, const int* ctl) {
+                                                             void* __restrict__ out, int out_is_f32, int ldo, int T,
+                                                             const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ float qs[MA_MAXT][128 + 1];
   __shared__ float ks[MA_MAXT][128 + 1];
@@ -336,19 +338,21 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
     const int t = idx / hd, d = idx - t * hd;
     float a = 0.f;
     for (int j = 0; j <= t; ++j) a += sim[t][j] * vs[j][d];
-    out[(long)t * ldo + h * hd + d] = f2bf(a);
+    if (out_is_f32) reinterpret_cast<float*>(out)[(long)t * ldo + h * hd + d] = a;
+    else reinterpret_cast<bf16_t*>(out)[(long)t * ldo + h * hd + d] = f2bf(a);
   }
 }
 
 extern "C" int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads,
                                    const float* q_ln_w, const float* k_ln_w, float eps, const unsigned char* key_mask,
-                                   float alibi_bias_max, void* out, int ldo, int T, const int* ctl, void* stream) {
+                                   float alibi_bias_max, void* out, int out_is_f32, int ldo, int T, const int* ctl,
+                                   void* stream) {
   const int hd = d_model / n_heads;
   if (T <= 0 || T > MA_MAXT || hd > 128 || hd * n_heads != d_model || s_in <= 0) return DEER_ERR_SHAPE;
   if ((q_ln_w == nullptr) != (k_ln_w == nullptr)) return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(mpt_attn_small_kernel, dim3(n_heads), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qkvslab,
-                     s_in, slab_stride, d_model, hd, q_ln_w, k_ln_w, eps, key_mask, alibi_bias_max, n_heads,
-                     reinterpret_cast<bf16_t*>(out), ldo, T, ctl);
+                     s_in, slab_stride, d_model, hd, q_ln_w, k_ln_w, eps, key_mask, alibi_bias_max, n_heads, out, out_is_f32,
+                     ldo, T, ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

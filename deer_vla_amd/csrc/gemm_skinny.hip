@@ -24,10 +24,14 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define GS_UNROLL 8
 
-enum { A_BF16 = 0, A_SLABS_GELU = 1, A_SLABS = 2 };
+enum { A_BF16 = 0, A_SLABS_GELU = 1, A_SLABS = 2, A_F32 = 3 };
 
-template <int MT>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ A, int lda,
+// SPLIT: the f32 activation is represented as bf16 hi + bf16 lo (hi = bf16(a), lo = bf16(a - hi)) and each weight
+// fragment feeds two MFMAs.  The GEMM is HBM-bound (MFMA pipe <5% busy), so the second MFMA is free and the
+// activation side of the product keeps ~16 mantissa bits: the LLM trunk then differs from an fp32 reference only
+// through the bf16 weights it shares with it -> robust exit decisions (SURVEY §7 "exit-index exactness").
+template <int MT, bool SPLIT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const void* __restrict__ Av, int lda,
                                                           const float* __restrict__ Aslab, int s_in, long slab_stride_in,
                                                           int a_mode, const bf16_t* __restrict__ Wp,
                                                           float* __restrict__ part, int M, int N, int K, int KS,
@@ -35,8 +39,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
   DEER_RETURN_IF_EXITED(ctl);
   constexpr int MPAD = MT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);      // [MPAD][KS + 8]
   const int pitch = KS + 8;
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);      // hi: [MPAD][KS + 8]
+  bf16_t* Al = As + MPAD * pitch;                         // lo: [MPAD][KS + 8] (SPLIT only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int ks = blockIdx.y, k0 = ks * KS;
@@ -44,12 +49,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
 
   // ---- stage the activation slice (rows >= M are zero) ----
   if (a_mode == A_BF16) {
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(Av);
     const int segs = klen >> 3;
     for (int idx = tid; idx < MPAD * segs; idx += 256) {
       const int row = idx / segs, seg = idx - row * segs;
       uint4 v = uint4{0, 0, 0, 0};
       if (row < M) v = *reinterpret_cast<const uint4*>(A + (long)row * lda + k0 + seg * 8);
       *reinterpret_cast<uint4*>(As + row * pitch + seg * 8) = v;
+      if (SPLIT) *reinterpret_cast<uint4*>(Al + row * pitch + seg * 8) = uint4{0, 0, 0, 0};
     }
   } else {
     const int segs = klen >> 2;
@@ -57,14 +64,23 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
       const int row = idx / segs, seg = idx - row * segs;
       float4 s = float4{0.f, 0.f, 0.f, 0.f};
       if (row < M) {
-        const float* p = Aslab + (long)row * K + k0 + seg * 4;
-        for (int i = 0; i < s_in; ++i) {
-          const float4 v = *reinterpret_cast<const float4*>(p + (long)i * slab_stride_in);
-          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        if (a_mode == A_F32) {
+          s = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Av) + (long)row * lda + k0 + seg * 4);
+        } else {
+          const float* p = Aslab + (long)row * K + k0 + seg * 4;
+          for (int i = 0; i < s_in; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (long)i * slab_stride_in);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+          }
+          if (a_mode == A_SLABS_GELU) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
         }
-        if (a_mode == A_SLABS_GELU) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
       }
-      *reinterpret_cast<uint2*>(As + row * pitch + seg * 4) = uint2{pack2bf(s.x, s.y), pack2bf(s.z, s.w)};
+      const bf16_t h0 = f2bf(s.x), h1 = f2bf(s.y), h2 = f2bf(s.z), h3 = f2bf(s.w);
+      *reinterpret_cast<uint2*>(As + row * pitch + seg * 4) =
+          uint2{(uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16)};
+      if (SPLIT)
+        *reinterpret_cast<uint2*>(Al + row * pitch + seg * 4) =
+            uint2{pack2bf(s.x - bf2f(h0), s.y - bf2f(h1)), pack2bf(s.z - bf2f(h2), s.w - bf2f(h3))};
     }
   }
   __syncthreads();
@@ -74,6 +90,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
   const int ktiles = K >> 5;
   const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + ((long)tile * ktiles + (k0 >> 5)) * 64 + lane;
   const bf16_t* as = As + c * pitch + g * 8;
+  const bf16_t* al = Al + c * pitch + g * 8;
 
   f32x4 acc[MT];
 #pragma unroll
@@ -93,6 +110,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
       for (int j = 0; j < MT; ++j) {
         const bf16x8 af = *reinterpret_cast<const bf16x8*>(as + j * 16 * pitch + (kt + u) * 32);
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[j], 0, 0, 0);
+        if (SPLIT) {
+          const bf16x8 lf = *reinterpret_cast<const bf16x8*>(al + j * 16 * pitch + (kt + u) * 32);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, lf, acc[j], 0, 0, 0);
+        }
       }
     }
   }
@@ -102,6 +123,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
     for (int j = 0; j < MT; ++j) {
       const bf16x8 af = *reinterpret_cast<const bf16x8*>(as + j * 16 * pitch + kt * 32);
       acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[j], 0, 0, 0);
+      if (SPLIT) {
+        const bf16x8 lf = *reinterpret_cast<const bf16x8*>(al + j * 16 * pitch + kt * 32);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, lf, acc[j], 0, 0, 0);
+      }
     }
   }
   // lane holds part[m = j*16 + c][n = tile*16 + g*4 .. +3]
@@ -133,13 +158,13 @@ extern "C" int deer_pack_weight_mfma16(const void* W, void* Wp, int N, int K, vo
 }
 
 // Suggested split-K for a skinny GEMM: enough workgroups to cover the chip (~2 per CU) while each wave
-// still streams >= 8 KiB, and an LDS slice <= 32 KiB.  Deterministic function of the shape.
+// still streams >= 8 KiB, and an LDS slice (hi + lo) <= 33 KiB.  Deterministic function of the shape.
 extern "C" int deer_skinny_splitk(int M, int N, int K) {
   const int mt = (M > 16) ? 2 : 1;
-  const int max_ks = 1024 / mt;
+  const int max_ks = 512 / mt;
   const int groups = (N + 63) / 64;
   int s = 1;
-  while ((K / s) > max_ks) s *= 2;
+  while ((K / s) > max_ks && (K % (s * 2 * 32)) == 0) s *= 2;
   while (groups * s < 512 && (K / (s * 2)) >= 256 && (K % (s * 2 * 32)) == 0) s *= 2;
   return s;
 }
@@ -149,19 +174,24 @@ extern "C" int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int 
                                 void* stream) {
   if (M <= 0 || M > 32 || N <= 0 || (N & 15) || K <= 0 || (K & 31) || splitk <= 0 || (K % (splitk * 32)) != 0)
     return DEER_ERR_SHAPE;
-  if (a_mode == A_BF16 ? (A == nullptr || (lda & 7)) : (Aslab == nullptr || s_in <= 0)) return DEER_ERR_SHAPE;
+  if (a_mode < 0 || a_mode > 3) return DEER_ERR_SHAPE;
+  if (a_mode == A_BF16 && (A == nullptr || (lda & 7))) return DEER_ERR_SHAPE;
+  if (a_mode == A_F32 && (A == nullptr || (lda & 3))) return DEER_ERR_SHAPE;
+  if ((a_mode == A_SLABS || a_mode == A_SLABS_GELU) && (Aslab == nullptr || s_in <= 0)) return DEER_ERR_SHAPE;
   const int KS = K / splitk;
   const int mt = (M > 16) ? 2 : 1;
-  const int smem = mt * 16 * (KS + 8) * (int)sizeof(bf16_t);
+  const bool split = (a_mode != A_BF16);
+  const int smem = (split ? 2 : 1) * mt * 16 * (KS + 8) * (int)sizeof(bf16_t);
   if (smem > 64 * 1024) return DEER_ERR_SHAPE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((N + 63) / 64, splitk);
-  if (mt == 1)
-    hipLaunchKernelGGL((gemm_skinny_kernel<1>), grid, dim3(256), smem, st, reinterpret_cast<const bf16_t*>(A), lda,
-                       Aslab, s_in, slab_stride_in, a_mode, reinterpret_cast<const bf16_t*>(Wp), part, M, N, K, KS, ctl);
-  else
-    hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, dim3(256), smem, st, reinterpret_cast<const bf16_t*>(A), lda,
-                       Aslab, s_in, slab_stride_in, a_mode, reinterpret_cast<const bf16_t*>(Wp), part, M, N, K, KS, ctl);
+  const bf16_t* wp = reinterpret_cast<const bf16_t*>(Wp);
+#define DEER_SK_LAUNCH(MT_, SP_)                                                                                      \
+  hipLaunchKernelGGL((gemm_skinny_kernel<MT_, SP_>), grid, dim3(256), smem, st, A, lda, Aslab, s_in, slab_stride_in,  \
+                     a_mode, wp, part, M, N, K, KS, ctl)
+  if (mt == 1) { if (split) DEER_SK_LAUNCH(1, true); else DEER_SK_LAUNCH(1, false); }
+  else         { if (split) DEER_SK_LAUNCH(2, true); else DEER_SK_LAUNCH(2, false); }
+#undef DEER_SK_LAUNCH
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

@@ -50,8 +50,8 @@ extern "C" int deer_layernorm_rows(const float* x, long in_rstride, long in_bstr
 __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, const float* __restrict__ slab, int s_in,
                                                         long slab_stride, const float* __restrict__ gate,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        bf16_t* __restrict__ out_bf, float* __restrict__ x_copy, int d,
-                                                        float eps, const int* ctl) {
+                                                        bf16_t* __restrict__ out_bf, float* __restrict__ out_f32,
+                                                        float* __restrict__ x_copy, int d, float eps, const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ float red[16];
   const int r = blockIdx.x;
@@ -80,16 +80,18 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
   for (int i = threadIdx.x; i < d; i += 256) {
     float y = (xr[i] - mean) * rstd * gamma[i];
     if (beta != nullptr) y += beta[i];
-    out_bf[(long)r * d + i] = f2bf(y);
+    if (out_bf != nullptr) out_bf[(long)r * d + i] = f2bf(y);
+    if (out_f32 != nullptr) out_f32[(long)r * d + i] = y;
   }
 }
 
 extern "C" int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_stride, const float* gate,
-                              const float* gamma, const float* beta, void* out_bf16, float* x_copy, int T, int d,
-                              float eps, const int* ctl, void* stream) {
-  if (T <= 0 || d <= 0 || (slab != nullptr && s_in <= 0) || (gamma != nullptr && out_bf16 == nullptr)) return DEER_ERR_SHAPE;
+                              const float* gamma, const float* beta, void* out_bf16, float* out_f32, float* x_copy, int T,
+                              int d, float eps, const int* ctl, void* stream) {
+  if (T <= 0 || d <= 0 || (slab != nullptr && s_in <= 0) || (gamma != nullptr && out_bf16 == nullptr && out_f32 == nullptr))
+    return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(resadd_ln_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in,
-                     slab_stride, gate, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), x_copy, d, eps, ctl);
+                     slab_stride, gate, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

@@ -16,6 +16,7 @@ runs in this repo's hand-written gfx950 kernels.
 from __future__ import annotations
 
 import ctypes
+from contextlib import contextmanager
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -31,12 +32,40 @@ def _cur_stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _ProfiledLib:
+    """Proxy around the ctypes library: when ``engine._prof`` is a list every kernel-launching ABI call is bracketed
+    by two HIP events on the current stream (bench.py's in-situ roofline pass).  Pass-through otherwise."""
+    _HOST_ONLY = ("deer_skinny_splitk", "deer_hip_arch", "deer_hip_abi_version")
+
+    def __init__(self, lib, eng):
+        self._lib, self._eng = lib, eng
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name in self._HOST_ONLY:
+            return fn
+        eng = self._eng
+
+        def call(*a):
+            if eng._prof is None:
+                return fn(*a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            eng._prof.append((name, e0, e1) + eng._cost)
+            return rc
+        return call
+
+
 class DeerEngine:
     def __init__(self, cfg: DeerConfig, state_dict: Dict[str, torch.Tensor], device="cuda", max_text_len: int = 32,
                  n_cams: int = 2, threshold_type: str = "L2", leq: bool = True):
         if not torch.cuda.is_available():
             raise abi.DeerHipError("DeerEngine needs a HIP device (no CPU fallback exists in deer_vla_amd)")
-        self.lib = abi.lib()
+        self._prof = None            # when a list: every launch is bracketed by HIP events (bench roofline pass)
+        self._cost = (0.0, 0.0)
+        self.lib = _ProfiledLib(abi.lib(), self)
         self.cfg = cfg
         self.dev = torch.device(device)
         self.n_cams = n_cams
@@ -208,8 +237,8 @@ class DeerEngine:
         self.key_mask = torch.ones(T, dtype=torch.uint8, device=dev)
         self.text_time = torch.zeros(T, dtype=torch.int32, device=dev)
         self.x = z(T, d)
-        self.xn = z(T, d, dt=bf)
-        self.ao = z(T, max(d, self.xinner), dt=bf)
+        self.xn = z(T, d)                                   # LN(x), fp32 (split into bf16 hi+lo inside the GEMM)
+        self.ao = z(T, max(d, self.xinner))                 # attention outputs, fp32
         max_n = max(cfg.mlp_ratio * d, cfg.xattn_ff_mult * d, 3 * d)
         self.max_split = 32
         self.slab_a = z(self.max_split * 32 * d)             # outputs of width d (residual branches)
@@ -227,21 +256,31 @@ class DeerEngine:
         self.action_dbg = z(8)
 
     # ------------------------------------------------------------------------------------- small helpers
+    @contextmanager
+    def _rec(self, name, flops=0.0, nbytes=0.0):
+        """Attach algorithmic flops / bytes to the next launch (consumed by the profiling proxy, if active)."""
+        self._cost = (float(flops), float(nbytes))
+        yield
+        self._cost = (0.0, 0.0)
+
     def _gemm(self, A, W, C, M, N, K, epi, bias=None, gate=None, lda=None, ldc=None, batch=1, strideA=0, strideC=0,
               tile=0, a_off=0, c_off=0):
         lda = K if lda is None else lda
         ldc = N if ldc is None else ldc
-        abi.check(self.lib.deer_gemm_bf16_nt(abi.ptr(A, a_off), lda, strideA, abi.ptr(W), K, abi.ptr(bias), abi.ptr(C, c_off),
-                                             ldc, strideC, M, N, K, batch, epi, abi.ptr(gate), tile, None, _cur_stream()),
-                  "deer_gemm_bf16_nt")
+        out_b = 4 if epi in (abi.EPI_F32, abi.EPI_RESADD_F32) else 2
+        with self._rec("gemm_tiled", 2.0 * M * N * K * batch, 2.0 * (M * K * batch + N * K) + out_b * M * N * batch):
+            abi.check(self.lib.deer_gemm_bf16_nt(abi.ptr(A, a_off), lda, strideA, abi.ptr(W), K, abi.ptr(bias), abi.ptr(C, c_off),
+                                                 ldc, strideC, M, N, K, batch, epi, abi.ptr(gate), tile, None, _cur_stream()),
+                      "deer_gemm_bf16_nt")
 
     def _ln(self, x, gamma, beta, out_bf, rows, C, in_rstride=None, in_bstride=0, batch=1, out_rstride=None, out_bstride=0,
             x_off=0, out_off=0, out_f32=None):
         in_rstride = C if in_rstride is None else in_rstride
         out_rstride = C if out_rstride is None else out_rstride
-        abi.check(self.lib.deer_layernorm_rows(abi.ptr(x, x_off), in_rstride, in_bstride, rows, batch, abi.ptr(gamma), abi.ptr(beta),
-                                               abi.ptr(out_bf, out_off), abi.ptr(out_f32), out_rstride, out_bstride, C, EPS,
-                                               _cur_stream()), "deer_layernorm_rows")
+        with self._rec("layernorm_rows", 8.0 * rows * batch * C, 6.0 * rows * batch * C):
+            abi.check(self.lib.deer_layernorm_rows(abi.ptr(x, x_off), in_rstride, in_bstride, rows, batch, abi.ptr(gamma), abi.ptr(beta),
+                                                   abi.ptr(out_bf, out_off), abi.ptr(out_f32), out_rstride, out_bstride, C, EPS,
+                                                   _cur_stream()), "deer_layernorm_rows")
 
     # ------------------------------------------------------------------------------------------ vision
     def enqueue_vision(self):
@@ -292,19 +331,20 @@ class DeerEngine:
             self._gemm(self.vis_x, self.wkv_all, self.kv_all, N * nl, self.n_xattn * 2 * self.xinner, W, abi.EPI_BF16)
 
     # --------------------------------------------------------------------------------------------- LLM
-    def _skinny(self, Wp, N, K, T, out_slab, A=None, a_slab=None, s_in=0, a_mode=abi.A_BF16, lda=None, ctl=True):
+    def _skinny(self, Wp, N, K, T, out_slab, A=None, a_slab=None, s_in=0, a_mode=abi.A_F32, lda=None, ctl=True):
         S = self.lib.deer_skinny_splitk(T, N, K)
         mpad = 16 if T <= 16 else 32
         assert S * mpad * N <= out_slab.numel(), (S, mpad, N, out_slab.numel())
-        abi.check(self.lib.deer_gemm_skinny(abi.ptr(A), (K if lda is None else lda), abi.ptr(a_slab), s_in,
-                                            (32 if T > 16 else 16) * K, a_mode, abi.ptr(Wp), abi.ptr(out_slab), T, N, K, S,
-                                            abi.ptr(self.ctl) if ctl else None, _cur_stream()), "deer_gemm_skinny")
+        with self._rec("gemm_skinny", 2.0 * T * N * K, 2.0 * N * K):      # algorithmic bytes = the bf16 weights, once
+            abi.check(self.lib.deer_gemm_skinny(abi.ptr(A), (K if lda is None else lda), abi.ptr(a_slab), s_in,
+                                                (32 if T > 16 else 16) * K, a_mode, abi.ptr(Wp), abi.ptr(out_slab), T, N, K, S,
+                                                abi.ptr(self.ctl) if ctl else None, _cur_stream()), "deer_gemm_skinny")
         return S, mpad * N
 
     def _resadd(self, T, pending, gamma=None, beta=None, x_copy=None, ctl=True):
         slab, S, stride, gate = pending if pending is not None else (None, 0, 0, None)
         abi.check(self.lib.deer_resadd_ln(abi.ptr(self.x), abi.ptr(slab), S, stride, abi.ptr(gate), abi.ptr(gamma), abi.ptr(beta),
-                                          abi.ptr(self.xn) if gamma is not None else None, abi.ptr(x_copy), T, self.cfg.d_model, EPS,
+                                          None, abi.ptr(self.xn) if gamma is not None else None, abi.ptr(x_copy), T, self.cfg.d_model, EPS,
                                           abi.ptr(self.ctl) if ctl else None, _cur_stream()), "deer_resadd_ln")
 
     def enqueue_embed(self, T):
@@ -325,7 +365,7 @@ class DeerEngine:
             kv_off = X["kv_index"] * 2 * self.xinner * 2          # bytes into a kv_all row
             abi.check(self.lib.deer_xattn_small(abi.ptr(self.slab_b), S, stride, self.xinner, abi.ptr(self.kv_all, kv_off),
                                                 self.n_xattn * 2 * self.xinner, self.xinner, abi.ptr(self.text_time),
-                                                cfg.perc_latents * self.n_cams, abi.ptr(self.ao), self.xinner, T, cfg.n_media,
+                                                cfg.perc_latents * self.n_cams, abi.ptr(self.ao), 1, self.xinner, T, cfg.n_media,
                                                 cfg.xattn_heads, cfg.xattn_dim_head ** -0.5, c, st), "deer_xattn_small")
             S, stride = self._skinny(X["wo"], d, self.xinner, T, self.slab_a, A=self.ao, lda=self.xinner, ctl=ctl)
             self._resadd(T, (self.slab_a, S, stride, X["ag"]), X["fnw"], X["fnb"], ctl=ctl)
@@ -337,7 +377,7 @@ class DeerEngine:
         S, stride = self._skinny(L["wqkv"], 3 * d, d, T, self.slab_b, A=self.xn, ctl=ctl)
         abi.check(self.lib.deer_mpt_attn_small(abi.ptr(self.slab_b), S, stride, d, cfg.n_heads, abi.ptr(L["qlnw"]), abi.ptr(L["klnw"]),
                                                EPS, abi.ptr(self.key_mask) if use_mask else None, float(cfg.alibi_bias_max),
-                                               abi.ptr(self.ao), d, T, c, st), "deer_mpt_attn_small")
+                                               abi.ptr(self.ao), 1, d, T, c, st), "deer_mpt_attn_small")
         S, stride = self._skinny(L["wo"], d, d, T, self.slab_a, A=self.ao, lda=d, ctl=ctl)
         self._resadd(T, (self.slab_a, S, stride, None), L["ln2w"], L["ln2b"], ctl=ctl)
         S, stride = self._skinny(L["wup"], cfg.mlp_ratio * d, d, T, self.slab_b, A=self.xn, ctl=ctl)

@@ -1,0 +1,124 @@
+"""Host-side mirror of robot_flamingo/models/value_net.py for the native engine.
+
+``ExitController`` / ``ActionValueNet`` keep the reference's names, constructor arguments, attributes
+(``thresholds`` dict, ``exit_id_list``, ``max_layer``, ``steps_per_stage``, ``cur_exit_id``, ``.module``) and
+methods (``set_timestep``, ``_set_threshold_value``, ``set_threshold``), but the criterion itself
+(value_net.py:105-133,277-297) is evaluated ON THE DEVICE by ``head_final_kernel``: when a model built by
+``deer_vla_amd.factory`` receives one of these controllers it passes thresholds / max_layer / steps_per_stage to
+the engine and the Python callable is bypassed (SURVEY §8b "exit-controller protocol").  Calling the controller
+like the reference does (``ctl(all_hidden_states, b_idx) -> bool``) still works - it then drives the head kernels
+eagerly and syncs once per exit check (slow host loop, used by tests and by foreign LLM loops).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+
+
+def solve_thresholds(values: torch.Tensor, real_num_exit: int, exit_ratio: float, exit_dist: str = "exp",
+                     leq: bool = True, model_name: str = "mpt_dolly_3b") -> torch.Tensor:
+    """Threshold solver of ``ExitController.set_threshold`` (value_net.py:203-260), vectorised.
+
+    values: (n_stage, n_sample) deltas gathered over the calibration set.  For every exit k (except the last)
+    the threshold is the value of the ``floor(n * probs[k])``-th not-yet-exited sample in sorted order, after
+    which every sample with value <= T[k] counts as exited.  probs ~ exit_ratio**k ('exp'), gaussian or gamma.
+    """
+    values = values.detach().to("cpu", torch.float32)
+    n_stage, n_sample = values.shape
+    T = torch.full((real_num_exit,), -1e8 if leq else 1e8, dtype=torch.float32)
+    if exit_dist == "exp":
+        probs = torch.tensor([float(exit_ratio) ** k for k in range(1, real_num_exit + 1)], dtype=torch.float32)
+    elif exit_dist == "gauss":
+        probs = torch.tensor([math.exp(-(i - exit_ratio) ** 2 / 2.0) for i in range(real_num_exit)], dtype=torch.float32)
+    elif exit_dist == "gamma":
+        import scipy.stats
+        probs = torch.tensor([scipy.stats.gamma.pdf(float(v), exit_ratio, scale=2.0) for v in range(1, real_num_exit + 1)],
+                             dtype=torch.float32)
+    else:
+        raise ValueError("Unsupported exit distribution")
+    if "mpt_9b" in model_name:
+        probs[0] = 0                     # value_net.py:235-236
+    probs = probs / probs.sum()
+    filtered = torch.zeros(n_sample, dtype=torch.bool)
+    for k in range(real_num_exit - 1):
+        out_n = math.floor(n_sample * probs[k])
+        order = values[k].argsort(descending=not leq, stable=True)
+        alive = ~filtered[order]
+        rank = alive.cumsum(0)
+        hit = (alive & (rank == out_n)).nonzero()
+        if out_n > 0 and hit.numel() > 0:
+            T[k] = values[k][order[hit[0, 0]]]
+        filtered |= (values[k] <= T[k]) if leq else (values[k] >= T[k])
+    T[real_num_exit - 1] = 1e8 if leq else -1e8
+    return T
+
+
+class ActionValueNet:
+    """value_net.py:72-160 (constructor surface).  ``exit_head`` is the model's ``extra_exit``."""
+
+    def __init__(self, exit_list, exit_head, interval, window_size, threshold_type="L2"):
+        self.exit_list = list(exit_list)
+        self.exit_head = exit_head
+        self.interval = interval
+        self.window_size = window_size
+        self.threshold_type = threshold_type
+        self.action_list: list = []
+        self.hidden_state = None          # attributes the harness resets (eval_utils.py:275-277)
+        self.history_memory: list = []
+
+    def reset_actions(self):
+        self.action_list = []
+
+
+class ExitController:
+    """value_net.py:163-297."""
+
+    def __init__(self, value_net: Optional[ActionValueNet], exit_id_list: Sequence[int], steps_per_stage: int = 1,
+                 exit_dist: str = "exp", leq: bool = True, max_layer: int = 12):
+        self.value_net = value_net
+        self.thresholds = None
+        self.leq = leq
+        self.exit_id_list = list(exit_id_list)
+        self.num_exit = len(self.exit_id_list)
+        self.steps_per_stage = steps_per_stage
+        self.exit_dist = exit_dist
+        self.max_layer = min(max_layer - 1, self.exit_id_list[-1])          # value_net.py:173
+        self.cur_step = 0
+        self.cur_exit_id = None
+        self.module = self                                                     # DDP-style indirection (eval_utils.py:662)
+        self._version = 0
+
+    @property
+    def real_num_exit(self) -> int:
+        return len([x for x in self.exit_id_list if x <= self.max_layer])
+
+    def _set_threshold_value(self, thresholds):
+        assert len(thresholds) == self.real_num_exit
+        self.thresholds = {self.exit_id_list[i]: float(thresholds[i]) for i in range(self.real_num_exit)}
+        self._version += 1
+
+    def set_threshold_from_values(self, values: torch.Tensor, exit_ratio: float, model_name: str = "mpt_dolly_3b"):
+        """The ``values is not None`` branch of ``set_threshold`` (value_net.py:185-264)."""
+        T = solve_thresholds(values[: self.real_num_exit], self.real_num_exit, exit_ratio, self.exit_dist, self.leq, model_name)
+        self.thresholds = {self.exit_id_list[i]: float(T[i]) for i in range(self.real_num_exit)}
+        self._version += 1
+        return values
+
+    def set_threshold(self, args, model, dataloader, exit_ratio, model_name, values=None):
+        if values is None:
+            raise NotImplementedError("calibration over a CALVIN dataloader is a 'next' row (SURVEY §8f.1); pass `values`")
+        return self.set_threshold_from_values(values, exit_ratio, model_name)
+
+    def set_timestep(self, t):
+        self.cur_step = t
+
+    def threshold_list(self) -> List[float]:
+        return [self.thresholds[e] for e in self.exit_id_list[: self.real_num_exit]]
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self

@@ -46,6 +46,7 @@ extern "C" {
 #define DEER_A_BF16 0
 #define DEER_A_SLABS_GELU 1
 #define DEER_A_SLABS 2
+#define DEER_A_F32 3
 /* head input modes / prologues / evaluation kinds / delta types */
 #define DEER_X_RAW 0
 #define DEER_X_POOL_MAX 1
@@ -77,7 +78,9 @@ int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const void* W, int l
  * Replaces the bias-free nn.Linear calls of the MPT GPTBlock (EXTERNAL; constructed mosaic_gpt_3b.py:104-106,
  * called :413-417) and of GatedCrossAttentionBlock (helpers.py:188,231,15-22) at T<=32 text tokens.
  * Wp = deer_pack_weight_mfma16(W).  Mpad = 16 (M<=16) or 32.  a_mode: DEER_A_BF16 reads A (bf16 [M,lda]);
- * DEER_A_SLABS(_GELU) reads sum_s Aslab[s*slab_stride_in + m*K + k] (optionally through exact GELU).
+ * DEER_A_F32 reads A (f32 [M,lda]); DEER_A_SLABS(_GELU) reads sum_s Aslab[s*slab_stride_in + m*K + k] (optionally
+ * through exact GELU).  f32 sources are fed to the MFMA as bf16 hi + bf16 lo (two MFMAs per weight fragment; free
+ * on this HBM-bound kernel), so the activation keeps ~16 mantissa bits.
  * Partials are reduced by the consumer (deer_resadd_ln / deer_*_attn_small / next deer_gemm_skinny). */
 int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int s_in, long slab_stride_in, int a_mode, const void* Wp,
                      float* part, int M, int N, int K, int splitk, const int* ctl, void* stream);
@@ -94,16 +97,16 @@ int deer_attn_mfma_hd64(const void* Q, const void* K, const void* V, void* O, in
                         float scale, void* stream);
 /* deer_xattn_small: MaskedCrossAttention core (helpers.py:192-232): q from split-K slabs (x scale), kv bf16
  * [n_kv, ldkv] (k at col h*64, v at col inner+h*64), mask text_time[t] == j/n_per_media + 1, rows with
- * text_time == 0 zeroed; out bf16 [T, ldo]. */
+ * text_time == 0 zeroed; out bf16 or f32 [T, ldo]. */
 int deer_xattn_small(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv, int inner,
-                     const int* text_time, int n_per_media, void* out, int ldo, int T, int n_kv, int heads, float scale,
-                     const int* ctl, void* stream);
+                     const int* text_time, int n_per_media, void* out, int out_is_f32, int ldo, int T, int n_kv, int heads,
+                     float scale, const int* ctl, void* stream);
 /* deer_mpt_attn_small: MPT attention core (attn bias built at mosaic_gpt_3b.py:158-219): qkv from
  * split-K slabs [T,3d]; optional q/k LayerNorm over d_model (weights f32 or NULL); ALiBi slope
- * 2^(-alibi_bias_max*(h+1)/H); causal; key_mask (uint8[T], 0 = padded) or NULL; out bf16 [T, ldo]. */
+ * 2^(-alibi_bias_max*(h+1)/H); causal; key_mask (uint8[T], 0 = padded) or NULL; out bf16 or f32 [T, ldo]. */
 int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w,
                         const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, void* out,
-                        int ldo, int T, const int* ctl, void* stream);
+                        int out_is_f32, int ldo, int T, const int* ctl, void* stream);
 
 /* ---- row ops ------------------------------------------------------------------------------------------------
  * deer_layernorm_rows: nn.LayerNorm (ViT ln_1/ln_2, helpers.py:32-33,17,132), f32 in, bf16 and/or f32 out. */
@@ -111,9 +114,10 @@ int deer_layernorm_rows(const float* x, long in_rstride, long in_bstride, int ro
                         const float* beta, void* out_bf16, float* out_f32, long out_rstride, long out_bstride, int C,
                         float eps, void* stream);
 /* deer_resadd_ln: x += tanh(*gate or 1) * sum_s slab[s]; optional copy of x (hidden_states[i], mosaic_gpt_3b.py:424-427);
- * optional LayerNorm -> bf16 (helpers.py:267-279 gated residuals; MPT block residuals + ln_1/ln_2). */
+ * optional LayerNorm -> bf16 and/or f32 (helpers.py:267-279 gated residuals; MPT block residuals + ln_1/ln_2). */
 int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* gamma,
-                   const float* beta, void* out_bf16, float* x_copy, int T, int d, float eps, const int* ctl, void* stream);
+                   const float* beta, void* out_bf16, float* out_f32, float* x_copy, int T, int d, float eps, const int* ctl,
+                   void* stream);
 /* ViT patch embedding (open_clip conv1 + class/positional embedding + ln_pre) */
 int deer_vit_im2col(const void* img, int img_is_bf16, int N, int S, int patch, void* out_bf16, int Kpad, void* stream);
 int deer_vit_embed_lnpre(const float* patch, const float* cls, const float* pos, const float* ln_w, const float* ln_b,
@@ -136,6 +140,9 @@ int deer_head_final(const float* src, int in_dim, int pro, const float* lnw0, co
                     int layer, int slot, const float* thresholds, int force, int thr_type, int leq, const float* h_tmp,
                     const float* c_tmp, float* h_state, float* c_state, int LH, float* action_dbg, float eps, void* stream);
 int deer_ctl_begin_step(int* ctl, const int* hold_src, void* stream);   /* ExitController.set_timestep, eval_utils.py:662-663 */
+
+/* keeps `stream` busy for ~us microseconds (profiling aid: lets the host enqueue ahead of the GPU) */
+int deer_spin_us(int us, void* stream);
 
 /* library identification: returns the gfx arch string the kernels were compiled for ("gfx950") */
 const char* deer_hip_arch(void);

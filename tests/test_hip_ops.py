@@ -59,6 +59,22 @@ def test_gemm_skinny_packed(lib, M, N, K):
         assert float(part[:, M:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(14, 2048, 2048), (32, 512, 2048), (3, 64, 96)])
+def test_gemm_skinny_f32_split_activation(lib, M, N, K):
+    """f32 activations enter the MFMA as bf16 hi + lo: result ~fp32-accurate w.r.t. the bf16 weights."""
+    A = dev(rnd(M, K, seed=41))
+    W = dev(rnd(N, K, seed=42, scale=K ** -0.5), torch.bfloat16)
+    Wp = torch.empty_like(W)
+    abi.check(lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), N, K, st()), "pack")
+    S = lib.deer_skinny_splitk(M, N, K)
+    mpad = 16 if M <= 16 else 32
+    part = torch.zeros(S, mpad, N, device="cuda")
+    abi.check(lib.deer_gemm_skinny(abi.ptr(A), K, None, 0, 0, abi.A_F32, abi.ptr(Wp), abi.ptr(part), M, N, K, S, None, st()), "skinny")
+    torch.cuda.synchronize()
+    ref = (A.double() @ W.double().t()).float()
+    assert rel_err(part.sum(0)[:M], ref) < 3e-5              # vs 2e-3 if A were rounded to a single bf16
+
+
 def test_gemm_skinny_slab_gelu_input_and_determinism(lib):
     M, K, N = 14, 8192, 2048
     s_in = 4
@@ -74,9 +90,9 @@ def test_gemm_skinny_slab_gelu_input_and_determinism(lib):
                                        None, st()), "skinny")
         torch.cuda.synchronize()
         outs.append(part.sum(0)[:M].clone())
-    a = torch.nn.functional.gelu(slab.sum(0)[:M]).to(torch.bfloat16).float()
-    ref = a @ W.float().t()
-    assert rel_err(outs[0], ref) < 1e-3                      # bf16 rounding of gelu(sum) may differ by 1 ulp on ties
+    a = torch.nn.functional.gelu(slab.sum(0)[:M])
+    ref = (a.double() @ W.double().t()).float()
+    assert rel_err(outs[0], ref) < 3e-5                      # gelu(sum) enters as bf16 hi+lo
     assert torch.equal(outs[0], outs[1])                     # bit-reproducible (no atomics)
 
 
@@ -176,7 +192,10 @@ def test_xattn_small(lib):
     out = torch.zeros(T, inner, device="cuda", dtype=torch.bfloat16)
     off = 1024                                               # second layer's slice
     abi.check(lib.deer_xattn_small(abi.ptr(qs), s_in, 16 * inner, inner, abi.ptr(kv, off * 2), ldkv, inner, abi.ptr(tt), 128, abi.ptr(out),
-                                   inner, T, n_kv, heads, 64 ** -0.5, None, st()), "xattn")
+                                   0, inner, T, n_kv, heads, 64 ** -0.5, None, st()), "xattn")
+    outf = torch.zeros(T, inner, device="cuda")
+    abi.check(lib.deer_xattn_small(abi.ptr(qs), s_in, 16 * inner, inner, abi.ptr(kv, off * 2), ldkv, inner, abi.ptr(tt), 128, abi.ptr(outf),
+                                   1, inner, T, n_kv, heads, 64 ** -0.5, None, st()), "xattn")
     torch.cuda.synchronize()
     q = qs.sum(0)[:T].view(T, heads, 64).transpose(0, 1) * 64 ** -0.5
     k = kv[:, off:off + inner].float().view(n_kv, heads, 64).transpose(0, 1)
@@ -185,7 +204,8 @@ def test_xattn_small(lib):
     a[:, 3] = 0
     ref = (a @ v).transpose(0, 1).reshape(T, inner)
     assert rel_err(out.float(), ref) < 4e-3
-    assert float(out[3].abs().max()) == 0.0
+    assert rel_err(outf, ref) < 2e-5
+    assert float(out[3].abs().max()) == 0.0 and float(outf[3].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("qk_ln", [True, False])
@@ -199,7 +219,10 @@ def test_mpt_attn_small(lib, qk_ln, T, d, H):
     mask[T - 2:] = 0                                         # right padding
     out = torch.zeros(T, d, device="cuda", dtype=torch.bfloat16)
     abi.check(lib.deer_mpt_attn_small(abi.ptr(slab), s_in, mpad * 3 * d, d, H, abi.ptr(qw) if qk_ln else None, abi.ptr(kw) if qk_ln else None,
-                                      1e-5, abi.ptr(mask), 8.0, abi.ptr(out), d, T, None, st()), "mpt attn")
+                                      1e-5, abi.ptr(mask), 8.0, abi.ptr(out), 0, d, T, None, st()), "mpt attn")
+    outf = torch.zeros(T, d, device="cuda")
+    abi.check(lib.deer_mpt_attn_small(abi.ptr(slab), s_in, mpad * 3 * d, d, H, abi.ptr(qw) if qk_ln else None, abi.ptr(kw) if qk_ln else None,
+                                      1e-5, abi.ptr(mask), 8.0, abi.ptr(outf), 1, d, T, None, st()), "mpt attn")
     torch.cuda.synchronize()
     qkv = slab.sum(0)[:T]
     q, k, v = qkv.chunk(3, -1)
@@ -215,6 +238,7 @@ def test_mpt_attn_small(lib, qk_ln, T, d, H):
     w = w.masked_fill(torch.ones(T, T, device="cuda").triu(1).bool(), float("-inf"))
     ref = (torch.softmax(w, -1) @ v).transpose(0, 1).reshape(T, d)
     assert rel_err(out.float(), ref) < 4e-3                  # output rounded to bf16
+    assert rel_err(outf, ref) < 2e-5
 
 
 # ---------------------------------------------------------------------------------------------- row ops
@@ -242,16 +266,18 @@ def test_resadd_ln(lib):
     g = dev(1 + 0.1 * rnd(d, seed=24))
     x = x0.clone()
     out = torch.zeros(T, d, device="cuda", dtype=torch.bfloat16)
+    outf = torch.zeros(T, d, device="cuda")
     cp = torch.zeros(T, d, device="cuda")
-    abi.check(lib.deer_resadd_ln(abi.ptr(x), abi.ptr(slab), s_in, 16 * d, abi.ptr(gate), abi.ptr(g), None, abi.ptr(out), abi.ptr(cp), T, d, 1e-5,
+    abi.check(lib.deer_resadd_ln(abi.ptr(x), abi.ptr(slab), s_in, 16 * d, abi.ptr(gate), abi.ptr(g), None, abi.ptr(out), abi.ptr(outf), abi.ptr(cp), T, d, 1e-5,
                                  None, st()), "resadd")
     torch.cuda.synchronize()
     xr = x0 + math.tanh(-0.3) * slab.sum(0)[:T]
     assert float((x - xr).abs().max()) < 1e-5 and torch.equal(x, cp)
     assert rel_err(out.float(), torch.nn.functional.layer_norm(xr, (d,), g)) < 4e-3
+    assert rel_err(outf, torch.nn.functional.layer_norm(xr, (d,), g)) < 1e-5
     # no slab, no LN: pure copy
     x2 = x0.clone()
-    abi.check(lib.deer_resadd_ln(abi.ptr(x2), None, 0, 0, None, None, None, None, abi.ptr(cp), T, d, 1e-5, None, st()), "resadd")
+    abi.check(lib.deer_resadd_ln(abi.ptr(x2), None, 0, 0, None, None, None, None, None, abi.ptr(cp), T, d, 1e-5, None, st()), "resadd")
     torch.cuda.synchronize()
     assert torch.equal(cp, x0)
 

@@ -1,0 +1,72 @@
+"""CPU tests of the host-side logic of the product package (no GPU, no HIP calls)."""
+import torch
+
+from golden_util import load
+from deer_vla_amd import value_net as vn
+from deer_vla_amd.config import deer_3b, deer_9b, deer_tiny, DeerConfig
+from deer_vla_amd import synthetic as syn
+
+
+def test_product_threshold_solver_matches_reference_goldens():
+    cfg, seed, g = load("thresholds.npz")
+    values = g["values"]
+    for key in [k for k in g if k.startswith("T_")]:
+        model_name, ratio, max_layer = key[2:].rsplit("_", 2)
+        ctl = vn.ExitController(None, cfg.exit_ids(), max_layer=int(max_layer))
+        T = vn.solve_thresholds(values[: ctl.real_num_exit].clone(), ctl.real_num_exit, float(ratio), "exp", True, model_name)
+        assert torch.equal(T, g[key].float()), key
+        ctl.set_threshold_from_values(values, float(ratio), model_name)
+        assert ctl.threshold_list() == [float(x) for x in g[key]]
+
+
+def test_exit_structure_of_baseline_configs():
+    """SURVEY §8a 'Max-layer semantics' / Appendix C."""
+    b = deer_3b(max_layer=12)
+    assert b.n_layers == 12 and b.exit_ids() == [1, 3, 5, 7, 9, 11]
+    c = vn.ExitController(None, b.exit_ids(), max_layer=12)
+    assert c.max_layer == 11 and c.real_num_exit == 6
+    s = deer_3b(max_layer=4)
+    assert s.n_layers == 5 and s.exit_ids() == [1, 3, 4]
+    c = vn.ExitController(None, s.exit_ids(), max_layer=4)
+    assert c.max_layer == 3 and c.real_num_exit == 2                      # <=4 layers ever run
+    n = deer_9b(max_layer=12)
+    assert n.n_layers == 13 and [i for i in range(13) if n.has_xattn(i)] == [3, 7, 11]
+    c = vn.ExitController(None, n.exit_ids(), max_layer=12)
+    assert c.max_layer == 11
+
+
+def test_parameter_inventory_sizes_match_survey():
+    """SURVEY §8a parameter counts: ViT 303 M, Perceiver 63 M, x-attn 36.7 M/layer, MPT block 50.3 M/layer, head 41 M."""
+    cfg = deer_3b(12)
+    P = syn.param_shapes(cfg)
+
+    def count(prefix):
+        n = 0
+        for k, (shape, _) in P.items():
+            if k.startswith(prefix):
+                m = 1
+                for s in shape:
+                    m *= s
+                n += m
+        return n
+    assert abs(count("vision_encoder.") / 1e6 - 303.2) < 1.0
+    assert abs(count("perceiver.") / 1e6 - 63.0) < 0.5
+    assert abs(count("lang_encoder.transformer.blocks.0.gated_cross_attn_layer.") / 1e6 - 36.7) < 0.1
+    assert abs(count("lang_encoder.transformer.blocks.0.decoder_layer.") / 1e6 - 50.3) < 0.1
+    assert abs(count("extra_exit.") / 1e6 - 40.95) < 0.1
+
+
+def test_synthetic_state_is_order_independent_and_bf16_roundable():
+    cfg = deer_tiny()
+    a = syn.make_synthetic_state(cfg, 5)
+    b = syn.make_synthetic_state(cfg, 5)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    r = syn.round_state_to_bf16(cfg, a)
+    k = "perceiver.layers.0.0.to_q.weight"
+    assert torch.equal(r[k], a[k].bfloat16().float()) and not torch.equal(r[k], a[k])
+    assert torch.equal(r["perceiver.norm.weight"], a["perceiver.norm.weight"])      # LN params stay fp32
+    c = syn.make_synthetic_state(cfg, 5, bf16_round=True)
+    assert all(torch.equal(c[x], r[x]) for x in r)
+    rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, 3)
+    assert ids.shape == (1, 14) and int(ids[0, 0]) == cfg.media_token_id and int(ids[0, -2]) == cfg.eoc_token_id
+    assert rgb.shape == (1, 1, 1, 3, cfg.image_size, cfg.image_size)
