@@ -39,9 +39,11 @@ def parse():
     ap.add_argument("--workload", default="deer_b", choices=["deer_b", "deer_s"],
                     help="deer_b: MPT-1B max_layer=12 exit_ratio 0.8 (the metric's config); deer_s: max_layer=4")
     ap.add_argument("--exit-ratio", type=float, default=0.8)
-    ap.add_argument("--calib-steps", type=int, default=96)
+    ap.add_argument("--calib-steps", type=int, default=128)
+    ap.add_argument("--calib-iters", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -114,12 +116,12 @@ def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
             "classes": classes}
 
 
-def cpu_baseline(cfg, sd, ctl, n_steps, rank):
+def cpu_baseline(cfg, sd, ctl, budget_s, threads, rank):
     """The CPU oracle (oracle/deer_oracle.py = pure-PyTorch fp32 restatement of the reference forward, pinned against
     the reference's own modules) timed on this box's host cores on a bounded sample of the same workload."""
     from deer_vla_amd import synthetic as syn
     from oracle import deer_oracle as orc
-    cores = os.cpu_count() or 1
+    cores = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(cores)
     model = orc.OracleDeer(sd, cfg)
     model.set_all_exit_window_size(1)
@@ -133,15 +135,18 @@ def cpu_baseline(cfg, sd, ctl, n_steps, rank):
             oc.set_timestep(s)
             o = model.forward(rgb, ids, mask, grip, dynamic_early_exit=True, exit_controller=oc)
             return o["exit_layer"]
-        one(0)                                             # warm-up (thread pools, allocator)
+        t0 = time.perf_counter()
+        one(0)                                             # warm-up (thread pools, allocator); also sizes the sample
+        warm = time.perf_counter() - t0
         model.clear_all_exit_memory()
+        n_steps = int(max(2, min(40, budget_s / max(warm, 1e-3))))
         t0 = time.perf_counter()
         for s in range(n_steps):
             exits.append(one(s) + 1)
         dt = time.perf_counter() - t0
     return {"value": round(n_steps / dt, 4), "unit": "action-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n_steps} control steps of the same workload (fp32, torch.set_num_threads({cores})), "
-                      f"avg exit layer {sum(exits) / len(exits):.2f}, {dt:.1f} s"}
+            "sample": f"{n_steps} control steps of the same workload (fp32 oracle, torch.set_num_threads({cores}) on a "
+                      f"{os.cpu_count()}-logical-core host), avg exit layer {sum(exits) / len(exits):.2f}, {dt:.1f} s"}
 
 
 def main():
@@ -183,23 +188,29 @@ def main():
     ids = ids.to(dev)
     T = ids.shape[1]
 
-    def run_step(i, use_graph=True, sync=True):
+    def run_step(i, use_graph=True, sync=True, shadow=False):
         if i % EP_LEN == 0:
             eng.reset()                                   # new episode: LSTM / controller state cleared
             eng.cur_step = 0
         rgb, grip = frames[i % POOL]
-        return eng.step(rgb, grip, ids, None, use_graph=use_graph and not args.no_graph, sync=sync)
+        return eng.step(rgb, grip, ids, None, use_graph=use_graph and not args.no_graph, sync=sync, shadow=shadow)
 
-    # ---- threshold calibration for --exit-ratio on a never-exit pass (value_net.py:185-264 semantics) ----
+    # ---- threshold calibration for --exit-ratio (value_net.py:185-264 solver) -------------------------------
+    # Fixed-point on-policy calibration: in shadow mode every exit's delta is recorded at every step while the LSTM
+    # state follows the CURRENT exit policy; thresholds are re-solved for the target exit distribution
+    # p_k ~ exit_ratio^k until the policy's own delta distribution is the one the thresholds were solved on.
     real = ctl.real_num_exit
-    eng.set_thresholds([-1.0] * (real - 1) + [1e5])
-    vals = []
-    for i in range(args.calib_steps):
-        r = run_step(i)
-        vals.append(r["deltas"][:real].clone())
-    values = torch.stack(vals, dim=1)                      # (n_exit, n_samples)
-    ctl.set_threshold_from_values(values, args.exit_ratio, cfg.llm_name)
-    eng.set_thresholds(ctl.threshold_list())
+    thr = [-1.0] * (real - 1) + [1e5]
+    for it in range(args.calib_iters):
+        eng.set_thresholds(thr)
+        vals = []
+        for i in range(args.calib_steps):
+            r = run_step(i, shadow=True)
+            vals.append(r["deltas"][:real].clone())
+        values = torch.stack(vals, dim=1)                  # (n_exit, n_samples)
+        ctl.set_threshold_from_values(values, args.exit_ratio, cfg.llm_name)
+        thr = ctl.threshold_list()
+    eng.set_thresholds(thr)
 
     # ---- timed region ----
     for i in range(args.warmup):
@@ -247,7 +258,7 @@ def main():
         if not args.no_roofline:
             out["roofline"] = measure_roofline(eng, cfg, frames, ids)
         if sd is not None:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, ctl, args.cpu_steps, rank)
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, ctl, args.cpu_budget_s, args.cpu_threads, rank)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

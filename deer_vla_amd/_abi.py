@@ -25,7 +25,7 @@ SIGNATURES = {
     "deer_pack_weight_mfma16": [P, P, I, I, P],
     "deer_attn_mfma_hd64": [P, P, P, P, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
     "deer_xattn_small": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, I, F, P, P],
-    "deer_mpt_attn_small": [P, I, L, I, I, P, P, F, P, F, P, I, I, I, P, P],
+    "deer_mpt_attn_small": [P, I, L, I, I, P, P, F, P, F, P, P, I, I, I, P, P],
     "deer_layernorm_rows": [P, L, L, I, I, P, P, P, P, L, L, I, F, P],
     "deer_resadd_ln": [P, P, I, L, P, P, P, P, P, P, I, I, F, P, P],
     "deer_vit_im2col": [P, I, I, I, I, P, I, P],
@@ -43,7 +43,7 @@ SIGNATURES = {
 _RESTYPE = {"deer_hip_arch": c_char_p}
 
 # constants of include/deer_hip.h
-CTL_EXIT_FLAG, CTL_EXIT_LAYER, CTL_CUR_EXIT_ID, CTL_HOLD, CTL_N_EVALS = 0, 1, 2, 3, 4
+CTL_EXIT_FLAG, CTL_EXIT_LAYER, CTL_CUR_EXIT_ID, CTL_HOLD, CTL_N_EVALS, CTL_SHADOW, CTL_COMMITTED = 0, 1, 2, 3, 4, 5, 6
 CTL_PREV_ACTION, CTL_OUT_ACTION, CTL_DELTAS, CTL_WORDS = 8, 16, 24, 64
 EPI_BF16, EPI_F32, EPI_QGELU_BF16, EPI_GELU_BF16, EPI_RESADD_F32 = 0, 1, 2, 3, 4
 A_BF16, A_SLABS_GELU, A_SLABS, A_F32 = 0, 1, 2, 3

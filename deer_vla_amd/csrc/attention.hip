@@ -248,15 +248,68 @@ extern "C" int deer_xattn_small(const float* qslab, int s_in, long slab_stride, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// (3) MPT self-attention: qkv = sum_s slab[s][t][0..3d); optional LayerNorm over the
-// FULL d_model of q and of k (attn_qk_ln, weight only); per head h: softmax(q k^T / sqrt(hd) + alibi +
-// key-pad + causal) v.  alibi[h][j] = -(T-1-j) * 2^(-bias_max*(h+1)/H).  HD = head_dim <= 128.
+// (3) MPT self-attention, two launches:
+//   qkv_reduce_ln_kernel : qkv[t] = sum_s slab[s][t][0..3d); optional LayerNorm over the FULL d_model of q and
+//                          of k (attn_qk_ln, weight only).  grid (T, 3) - one workgroup per (row, q|k|v).
+//   mpt_attn_small_kernel: per head h: softmax(q k^T / sqrt(hd) + alibi + key-pad + causal) v, head_dim <= 128,
+//                          alibi[h][j] = -(T-1-j) * 2^(-bias_max*(h+1)/H).
 // ------------------------------------------------------------------------------------------------
 #define MA_MAXT 32
-__global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __restrict__ qkvslab, int s_in,
-                                                             long slab_stride, int d_model, int hd,
-                                                             const float* __restrict__ q_ln_w,
-                                                             const float* __restrict__ k_ln_w, float eps,
+__global__ __launch_bounds__(256) void qkv_reduce_ln_kernel(const float* __restrict__ slab, int s_in, long slab_stride,
+                                                            int d, const float* __restrict__ q_ln_w,
+                                                            const float* __restrict__ k_ln_w, float eps,
+                                                            float* __restrict__ qkv, const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
+  __shared__ float red[16];
+  const int t = blockIdx.x, part = blockIdx.y;
+  const long base = (long)t * 3 * d + (long)part * d;
+  const int n4 = d >> 2;
+  float4 v[4];                                           // d <= 4096
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = float4{0.f, 0.f, 0.f, 0.f};
+    const int i4 = threadIdx.x + j * 256;
+    if (i4 < n4) {
+      const float* p = slab + base + (long)i4 * 4;
+#pragma unroll 4
+      for (int s = 0; s < s_in; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(p + (long)s * slab_stride);
+        v[j].x += a.x; v[j].y += a.y; v[j].z += a.z; v[j].w += a.w;
+      }
+    }
+  }
+  const float* w = (part == 0) ? q_ln_w : (part == 1 ? k_ln_w : nullptr);
+  if (w != nullptr) {
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += v[j].x + v[j].y + v[j].z + v[j].w;      // lanes beyond n4 hold zeros
+    const float mean = block_sum(sum, red) / d;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (threadIdx.x + j * 256 < n4) {
+        const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, e = v[j].w - mean;
+        var += a * a + b * b + c * c + e * e;
+      }
+    const float rstd = rsqrtf(block_sum(var, red) / d + eps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i4 = threadIdx.x + j * 256;
+      if (i4 < n4) {
+        const float4 g = *reinterpret_cast<const float4*>(w + (long)i4 * 4);
+        v[j].x = (v[j].x - mean) * rstd * g.x; v[j].y = (v[j].y - mean) * rstd * g.y;
+        v[j].z = (v[j].z - mean) * rstd * g.z; v[j].w = (v[j].w - mean) * rstd * g.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i4 = threadIdx.x + j * 256;
+    if (i4 < n4) *reinterpret_cast<float4*>(qkv + base + (long)i4 * 4) = v[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __restrict__ qkv, int d_model, int hd,
                                                              const unsigned char* __restrict__ key_mask,
                                                              float alibi_slope_base, int n_heads,
                                                              void* __restrict__ out, int out_is_f32, int ldo, int T,
@@ -266,53 +319,14 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
   __shared__ float ks[MA_MAXT][128 + 1];
   __shared__ float vs[MA_MAXT][128 + 1];
   __shared__ float sim[MA_MAXT][MA_MAXT + 1];
-  __shared__ float stat[MA_MAXT][4];       // q mean, q rstd, k mean, k rstd
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * d_model;
-  const bool qk_ln = (q_ln_w != nullptr);
-  if (qk_ln) {
-    // full-row statistics of q and k (two-pass, like torch), one wave per (row, q|k)
-    for (int job = wave; job < 2 * T; job += 4) {
-      const int t = job >> 1, which = job & 1;
-      const long base = (long)t * ld + which * d_model;
-      float sum = 0.f;
-      for (int i = lane; i < d_model; i += 64) {
-        float a = 0.f;
-        for (int s = 0; s < s_in; ++s) a += qkvslab[(long)s * slab_stride + base + i];
-        sum += a;
-      }
-      const float mean = wave_sum(sum) / d_model;
-      float var = 0.f;
-      for (int i = lane; i < d_model; i += 64) {
-        float a = 0.f;
-        for (int s = 0; s < s_in; ++s) a += qkvslab[(long)s * slab_stride + base + i];
-        var += (a - mean) * (a - mean);
-      }
-      var = wave_sum(var) / d_model;
-      if (lane == 0) {
-        stat[t][which * 2] = mean;
-        stat[t][which * 2 + 1] = rsqrtf(var + eps);
-      }
-    }
-  }
-  __syncthreads();
   for (int idx = tid; idx < T * hd; idx += 256) {
     const int t = idx / hd, d = idx - t * hd;
-    const long base = (long)t * ld + h * hd + d;
-    float q = 0.f, k = 0.f, v = 0.f;
-    for (int s = 0; s < s_in; ++s) {
-      const float* p = qkvslab + (long)s * slab_stride + base;
-      q += p[0];
-      k += p[d_model];
-      v += p[2 * d_model];
-    }
-    if (qk_ln) {
-      q = (q - stat[t][0]) * stat[t][1] * q_ln_w[h * hd + d];
-      k = (k - stat[t][2]) * stat[t][3] * k_ln_w[h * hd + d];
-    }
-    qs[t][d] = q;
-    ks[t][d] = k;
-    vs[t][d] = v;
+    const float* p = qkv + (long)t * ld + h * hd + d;
+    qs[t][d] = p[0];
+    ks[t][d] = p[d_model];
+    vs[t][d] = p[2 * d_model];
   }
   __syncthreads();
   const float sc = rsqrtf((float)hd);
@@ -343,16 +357,21 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
   }
 }
 
+// qkv_ws: f32 [T, 3*d_model] workspace holding the reduced (and q/k-normalised) qkv.
 extern "C" int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads,
                                    const float* q_ln_w, const float* k_ln_w, float eps, const unsigned char* key_mask,
-                                   float alibi_bias_max, void* out, int out_is_f32, int ldo, int T, const int* ctl,
-                                   void* stream) {
+                                   float alibi_bias_max, float* qkv_ws, void* out, int out_is_f32, int ldo, int T,
+                                   const int* ctl, void* stream) {
   const int hd = d_model / n_heads;
-  if (T <= 0 || T > MA_MAXT || hd > 128 || hd * n_heads != d_model || s_in <= 0) return DEER_ERR_SHAPE;
+  if (T <= 0 || T > MA_MAXT || hd > 128 || hd * n_heads != d_model || s_in <= 0 || (d_model & 3) || d_model > 4096 ||
+      qkv_ws == nullptr)
+    return DEER_ERR_SHAPE;
   if ((q_ln_w == nullptr) != (k_ln_w == nullptr)) return DEER_ERR_SHAPE;
-  hipLaunchKernelGGL(mpt_attn_small_kernel, dim3(n_heads), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qkvslab,
-                     s_in, slab_stride, d_model, hd, q_ln_w, k_ln_w, eps, key_mask, alibi_bias_max, n_heads, out, out_is_f32,
-                     ldo, T, ctl);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(qkv_reduce_ln_kernel, dim3(T, 3), dim3(256), 0, st, qkvslab, s_in, slab_stride, d_model, q_ln_w, k_ln_w,
+                     eps, qkv_ws, ctl);
+  hipLaunchKernelGGL(mpt_attn_small_kernel, dim3(n_heads), dim3(256), 0, st, qkv_ws, d_model, hd, key_mask, alibi_bias_max,
+                     n_heads, out, out_is_f32, ldo, T, ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

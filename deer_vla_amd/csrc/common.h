@@ -21,6 +21,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CTL_CUR_EXIT_ID 2   // ExitController.cur_exit_id (value_net.py:285-286,294)
 #define CTL_HOLD 3          // 1 when cur_step % steps_per_stage != 0 (reuse cur_exit_id)
 #define CTL_N_EVALS 4       // number of head evaluations executed this step (diagnostics)
+#define CTL_SHADOW 5        // calibration mode: evaluate EVERY exit, commit at the first that fires, never stop
+#define CTL_COMMITTED 6     // shadow mode: a commit already happened in this step
 #define CTL_PREV_ACTION 8   // float[8]: action_list[-1] (pose6, gripper, pad)
 #define CTL_OUT_ACTION 16   // float[8]: committed action (pose6, gripper prob, gripper logit)
 #define CTL_DELTAS 24       // float[16]: delta per exit slot of this step (NaN = not evaluated)

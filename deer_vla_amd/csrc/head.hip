@@ -289,14 +289,20 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
       } else {                                          // KIND_COMMIT, or CHECK while holding a stage
         commit = true;
       }
-      if (commit) {
+      ctl[CTL_N_EVALS] += 1;
+      if (commit && ctl[CTL_SHADOW] != 0) {
+        // calibration: remember the FIRST exit that fires, keep evaluating the deeper exits (no EXIT_FLAG)
+        if (ctl[CTL_COMMITTED] != 0) commit = false;
+        else ctl[CTL_COMMITTED] = 1;
+        if (commit) {
+          for (int i = 0; i < 8; ++i) outa[i] = cur[i];
+          ctl[CTL_EXIT_LAYER] = layer;
+        }
+      } else if (commit) {
         for (int i = 0; i < 8; ++i) outa[i] = cur[i];
         ctl[CTL_EXIT_LAYER] = layer;
-        ctl[CTL_N_EVALS] += 1;
         __threadfence();
         ctl[CTL_EXIT_FLAG] = 1;
-      } else {
-        ctl[CTL_N_EVALS] += 1;
       }
     }
     *flag = commit ? 1 : 0;
@@ -333,6 +339,7 @@ __global__ void ctl_begin_step_kernel(int* ctl, const int* hold_src) {
     ctl[CTL_EXIT_LAYER] = -1;
     ctl[CTL_HOLD] = (hold_src != nullptr) ? *hold_src : 0;
     ctl[CTL_N_EVALS] = 0;
+    ctl[CTL_COMMITTED] = 0;
   }
   if (threadIdx.x < 16) reinterpret_cast<float*>(ctl + CTL_DELTAS)[threadIdx.x] = __int_as_float(0x7fc00000);
 }

@@ -55,40 +55,68 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ float red[16];
   const int r = blockIdx.x;
+  const int n4 = d >> 2;
   float* xr = x + (long)r * d;
-  if (slab != nullptr) {
-    const float sc = (gate != nullptr) ? tanhf(*gate) : 1.f;
-    for (int i = threadIdx.x; i < d; i += 256) {
-      float a = 0.f;
-      for (int s = 0; s < s_in; ++s) a += slab[(long)s * slab_stride + (long)r * d + i];
-      xr[i] += sc * a;
+  float4 v[4];                                            // d <= 4096: the row stays in registers
+  const float sc = (slab != nullptr && gate != nullptr) ? tanhf(*gate) : 1.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i4 = threadIdx.x + j * 256;
+    v[j] = float4{0.f, 0.f, 0.f, 0.f};
+    if (i4 < n4) {
+      float4 a = float4{0.f, 0.f, 0.f, 0.f};
+      if (slab != nullptr) {
+        const float* p = slab + (long)r * d + (long)i4 * 4;
+#pragma unroll 4
+        for (int s = 0; s < s_in; ++s) {
+          const float4 t = *reinterpret_cast<const float4*>(p + (long)s * slab_stride);
+          a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+      }
+      float4 xv = *reinterpret_cast<const float4*>(xr + (long)i4 * 4);
+      xv.x += sc * a.x; xv.y += sc * a.y; xv.z += sc * a.z; xv.w += sc * a.w;
+      v[j] = xv;
+      if (slab != nullptr) *reinterpret_cast<float4*>(xr + (long)i4 * 4) = xv;
+      if (x_copy != nullptr) *reinterpret_cast<float4*>(x_copy + (long)r * d + (long)i4 * 4) = xv;
     }
   }
-  if (x_copy != nullptr)
-    for (int i = threadIdx.x; i < d; i += 256) x_copy[(long)r * d + i] = xr[i];
   if (gamma == nullptr) return;
-  // each thread re-reads only the elements it wrote itself -> no barrier needed before the statistics
   float s = 0.f;
-  for (int i = threadIdx.x; i < d; i += 256) s += xr[i];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s += v[j].x + v[j].y + v[j].z + v[j].w;
   const float mean = block_sum(s, red) / d;
-  float v = 0.f;
-  for (int i = threadIdx.x; i < d; i += 256) {
-    const float dd = xr[i] - mean;
-    v += dd * dd;
-  }
-  const float rstd = rsqrtf(block_sum(v, red) / d + eps);
-  for (int i = threadIdx.x; i < d; i += 256) {
-    float y = (xr[i] - mean) * rstd * gamma[i];
-    if (beta != nullptr) y += beta[i];
-    if (out_bf != nullptr) out_bf[(long)r * d + i] = f2bf(y);
-    if (out_f32 != nullptr) out_f32[(long)r * d + i] = y;
+  float var = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (threadIdx.x + j * 256 < n4) {
+      const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, e = v[j].w - mean;
+      var += a * a + b * b + c * c + e * e;
+    }
+  const float rstd = rsqrtf(block_sum(var, red) / d + eps);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i4 = threadIdx.x + j * 256;
+    if (i4 < n4) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + (long)i4 * 4);
+      float4 y;
+      y.x = (v[j].x - mean) * rstd * g.x; y.y = (v[j].y - mean) * rstd * g.y;
+      y.z = (v[j].z - mean) * rstd * g.z; y.w = (v[j].w - mean) * rstd * g.w;
+      if (beta != nullptr) {
+        const float4 bb = *reinterpret_cast<const float4*>(beta + (long)i4 * 4);
+        y.x += bb.x; y.y += bb.y; y.z += bb.z; y.w += bb.w;
+      }
+      if (out_bf != nullptr)
+        *reinterpret_cast<uint2*>(out_bf + (long)r * d + (long)i4 * 4) = uint2{pack2bf(y.x, y.y), pack2bf(y.z, y.w)};
+      if (out_f32 != nullptr) *reinterpret_cast<float4*>(out_f32 + (long)r * d + (long)i4 * 4) = y;
+    }
   }
 }
 
 extern "C" int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_stride, const float* gate,
                               const float* gamma, const float* beta, void* out_bf16, float* out_f32, float* x_copy, int T,
                               int d, float eps, const int* ctl, void* stream) {
-  if (T <= 0 || d <= 0 || (slab != nullptr && s_in <= 0) || (gamma != nullptr && out_bf16 == nullptr && out_f32 == nullptr))
+  if (T <= 0 || d <= 0 || (d & 3) || d > 4096 || (slab != nullptr && s_in <= 0) ||
+      (gamma != nullptr && out_bf16 == nullptr && out_f32 == nullptr))
     return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(resadd_ln_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in,
                      slab_stride, gate, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl);

@@ -243,10 +243,12 @@ class DeerEngine:
         self.max_split = 32
         self.slab_a = z(self.max_split * 32 * d)             # outputs of width d (residual branches)
         self.slab_b = z(16 * 32 * max_n)                     # outputs of width 3d / 4d / inner
+        self.qkv_ws = z(T, 3 * d)                            # reduced (+ q/k-normalised) qkv of the MPT attention
         self.hidden = z(cfg.n_layers, T, d)                  # hidden_states[i] = output of layer i
         Lh, H = cfg.lstm_num_layers, cfg.head_hidden
         self.h_state, self.c_state = z(Lh, H), z(Lh, H)
         self.h_tmp, self.c_tmp = z(Lh, H), z(Lh, H)
+        self.h_shadow, self.c_shadow = z(Lh, H), z(Lh, H)    # commit target in shadow (calibration) mode
         dims = cfg.mlp_hidden_dims
         self.z_fc = [z(2 * dm) for dm in dims]
         self.ctl = torch.zeros(abi.CTL_WORDS, dtype=torch.int32, device=dev)
@@ -377,7 +379,7 @@ class DeerEngine:
         S, stride = self._skinny(L["wqkv"], 3 * d, d, T, self.slab_b, A=self.xn, ctl=ctl)
         abi.check(self.lib.deer_mpt_attn_small(abi.ptr(self.slab_b), S, stride, d, cfg.n_heads, abi.ptr(L["qlnw"]), abi.ptr(L["klnw"]),
                                                EPS, abi.ptr(self.key_mask) if use_mask else None, float(cfg.alibi_bias_max),
-                                               abi.ptr(self.ao), 1, d, T, c, st), "deer_mpt_attn_small")
+                                               abi.ptr(self.qkv_ws), abi.ptr(self.ao), 1, d, T, c, st), "deer_mpt_attn_small")
         S, stride = self._skinny(L["wo"], d, d, T, self.slab_a, A=self.ao, lda=d, ctl=ctl)
         self._resadd(T, (self.slab_a, S, stride, None), L["ln2w"], L["ln2b"], ctl=ctl)
         S, stride = self._skinny(L["wup"], cfg.mlp_ratio * d, d, T, self.slab_b, A=self.xn, ctl=ctl)
@@ -391,7 +393,7 @@ class DeerEngine:
 
     # -------------------------------------------------------------------------------------------- head
     def enqueue_head(self, layer: int, T: int, kind: int, slot: int = -1, force: bool = False, use_ctl: bool = True,
-                     feats: Optional[torch.Tensor] = None, h_prev=None, c_prev=None):
+                     feats: Optional[torch.Tensor] = None, h_prev=None, c_prev=None, shadow: bool = False):
         """One DeterministicDecoder evaluation on hidden_states[layer] (action_head.py:499-611) followed by the
         exit gate (value_net.py:120-133,277-297).  kind: PSEUDO (prev action from layer i-1, value_net.py:122-125),
         CHECK (delta <= threshold -> exit + commit LSTM state), COMMIT (static exit_id / committing call)."""
@@ -429,8 +431,10 @@ class DeerEngine:
         abi.check(lib.deer_head_final(abi.ptr(src), in_dim, pro, abi.ptr(ln[0]), abi.ptr(ln[1]), abi.ptr(ln[2]), abi.ptr(ln[3]),
                                       abi.ptr(Hd["wa"]), abi.ptr(Hd["ba"]), abi.ptr(Hd["wg"]), abi.ptr(Hd["bg"]),
                                       abi.ptr(self.ctl), kind, layer, slot, abi.ptr(self.thresholds), 1 if force else 0,
-                                      self.thr_type, self.leq, abi.ptr(self.h_tmp), abi.ptr(self.c_tmp), abi.ptr(self.h_state),
-                                      abi.ptr(self.c_state), LH, abi.ptr(self.action_dbg), EPS, st), "deer_head_final")
+                                      self.thr_type, self.leq, abi.ptr(self.h_tmp), abi.ptr(self.c_tmp),
+                                      abi.ptr(self.h_shadow if shadow else self.h_state),
+                                      abi.ptr(self.c_shadow if shadow else self.c_state), LH, abi.ptr(self.action_dbg), EPS, st),
+                  "deer_head_final")
 
     # ------------------------------------------------------------------------------------- step assembly
     def configure_exit(self, exit_ids: Sequence[int], max_layer: int, steps_per_stage: int = 1):
@@ -456,9 +460,10 @@ class DeerEngine:
         self.h_state.zero_()
         self.c_state.zero_()
         self.ctl.zero_()
+        self._shadow_on = False
         self.cur_step = 0
 
-    def enqueue_llm_dynamic(self, T, use_mask):
+    def enqueue_llm_dynamic(self, T, use_mask, shadow: bool = False):
         """MosaicGPT.forward loop with an exit controller (mosaic_gpt_3b.py:397-443), device-predicated."""
         cfg = self.cfg
         interval = cfg.exit_interval
@@ -471,7 +476,8 @@ class DeerEngine:
             if need_pseudo:
                 self.enqueue_head(i, T, abi.KIND_PSEUDO)
             if is_exit:
-                self.enqueue_head(i, T, abi.KIND_CHECK, slot=self.exit_ids.index(i), force=(i >= self.ctl_max_layer))
+                self.enqueue_head(i, T, abi.KIND_CHECK, slot=self.exit_ids.index(i), force=(i >= self.ctl_max_layer),
+                                  shadow=shadow)
             if i >= self.ctl_max_layer:
                 break
 
@@ -483,11 +489,11 @@ class DeerEngine:
             pending = self.enqueue_llm_layer(i, T, pending, use_mask, finalize=True, ctl=False)
         self.enqueue_head(exit_id, T, abi.KIND_COMMIT, use_ctl=False)
 
-    def _enqueue_step(self, T, use_mask, exit_id):
+    def _enqueue_step(self, T, use_mask, exit_id, shadow: bool = False):
         abi.check(self.lib.deer_ctl_begin_step(abi.ptr(self.ctl), abi.ptr(self.hold_dev), _cur_stream()), "ctl_begin_step")
         self.enqueue_vision()
         if exit_id is None:
-            self.enqueue_llm_dynamic(T, use_mask)
+            self.enqueue_llm_dynamic(T, use_mask, shadow)
         else:
             self.enqueue_llm_static(T, use_mask, exit_id)
 
@@ -508,30 +514,39 @@ class DeerEngine:
             self.key_mask[:T].copy_(m, non_blocking=True)
         return T, use_mask
 
-    def step(self, rgb, gripper, ids, mask=None, exit_id: Optional[int] = None, use_graph: bool = True, sync: bool = True):
-        """One control step.  Returns dict(pose (6,), gripper prob, gripper_logit, exit_layer, deltas) when sync."""
+    def step(self, rgb, gripper, ids, mask=None, exit_id: Optional[int] = None, use_graph: bool = True, sync: bool = True,
+             shadow: bool = False):
+        """One control step.  Returns dict(pose (6,), gripper prob, gripper_logit, exit_layer, deltas) when sync.
+        shadow=True (calibration): every exit is evaluated and its delta recorded, the LSTM state / action are
+        committed at the first exit whose criterion fires, but the step never terminates early."""
         T, use_mask = self.load_inputs(rgb, gripper, ids, mask)
+        if bool(shadow) != getattr(self, "_shadow_on", False):
+            self.ctl[abi.CTL_SHADOW] = 1 if shadow else 0
+            self._shadow_on = bool(shadow)
         if exit_id is not None and exit_id < 0:
             exit_id += self.cfg.n_layers
         hold = 1 if (exit_id is None and self.cur_step % self.steps_per_stage != 0) else 0
         self.hold_dev.fill_(hold)
-        key = (T, use_mask, exit_id)
+        key = (T, use_mask, exit_id, bool(shadow))
         if use_graph:
             g = self._graphs.get(key)
             if g is None:
-                self._enqueue_step(T, use_mask, exit_id)          # eager warm-up (sets kernel attributes) - a real step
+                self._enqueue_step(T, use_mask, exit_id, shadow)  # eager warm-up (sets kernel attributes) - a real step
                 torch.cuda.current_stream().synchronize()
                 g = torch.cuda.CUDAGraph()
                 self._graph_pending = (T, use_mask, exit_id)
                 # state was advanced by the warm-up run; capture does not execute kernels
                 with torch.cuda.graph(g):
-                    self._enqueue_step(T, use_mask, exit_id)
+                    self._enqueue_step(T, use_mask, exit_id, shadow)
                 self._graphs[key] = g
                 self._warm_result = True
             else:
                 g.replay()
         else:
-            self._enqueue_step(T, use_mask, exit_id)
+            self._enqueue_step(T, use_mask, exit_id, shadow)
+        if shadow:
+            self.h_state.copy_(self.h_shadow)
+            self.c_state.copy_(self.c_shadow)
         self.ctl_host.copy_(self.ctl, non_blocking=True)
         self.cur_step += 1
         if not sync:

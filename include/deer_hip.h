@@ -31,6 +31,8 @@ extern "C" {
 #define DEER_CTL_CUR_EXIT_ID 2
 #define DEER_CTL_HOLD 3
 #define DEER_CTL_N_EVALS 4
+#define DEER_CTL_SHADOW 5      /* calibration: evaluate every exit, commit at the first that fires, never stop */
+#define DEER_CTL_COMMITTED 6
 #define DEER_CTL_PREV_ACTION 8   /* float[8] */
 #define DEER_CTL_OUT_ACTION 16   /* float[8]: pose[6], gripper prob, gripper logit */
 #define DEER_CTL_DELTAS 24       /* float[16] */
@@ -103,10 +105,12 @@ int deer_xattn_small(const float* qslab, int s_in, long slab_stride, int ldqs, c
                      float scale, const int* ctl, void* stream);
 /* deer_mpt_attn_small: MPT attention core (attn bias built at mosaic_gpt_3b.py:158-219): qkv from
  * split-K slabs [T,3d]; optional q/k LayerNorm over d_model (weights f32 or NULL); ALiBi slope
- * 2^(-alibi_bias_max*(h+1)/H); causal; key_mask (uint8[T], 0 = padded) or NULL; out bf16 or f32 [T, ldo]. */
+ * 2^(-alibi_bias_max*(h+1)/H); causal; key_mask (uint8[T], 0 = padded) or NULL; qkv_ws = f32 [T,3d] workspace;
+ * out bf16 or f32 [T, ldo].  Two launches: slab reduce + q/k LayerNorm (one workgroup per row and q|k|v), then one
+ * workgroup per head. */
 int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w,
-                        const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, void* out,
-                        int out_is_f32, int ldo, int T, const int* ctl, void* stream);
+                        const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws,
+                        void* out, int out_is_f32, int ldo, int T, const int* ctl, void* stream);
 
 /* ---- row ops ------------------------------------------------------------------------------------------------
  * deer_layernorm_rows: nn.LayerNorm (ViT ln_1/ln_2, helpers.py:32-33,17,132), f32 in, bf16 and/or f32 out. */

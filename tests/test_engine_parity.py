@@ -51,17 +51,39 @@ def oracle_episode(cfg, sd, inputs, thresholds, max_layer, steps_per_stage=1):
     return outs, vn.rec, ctl
 
 
-def probe_thresholds(cfg, sd, inputs, max_layer):
-    """thresholds in the widest gap of the oracle's own deltas (never-exit pass) -> robust exit decisions"""
-    ctl0 = orc.OracleExitController(None, cfg.exit_ids(), max_layer=max_layer)
+def min_margin(rec, thr_by_exit):
+    m = [abs(v - thr_by_exit[i]) / thr_by_exit[i] for (i, v) in rec if thr_by_exit[i] < 1e4]
+    return min(m) if m else 1.0
+
+
+def probe_thresholds(cfg, sd, inputs, max_layer, sps=1, iters=5):
+    """Thresholds with a wide safety margin: start in the widest gap of the oracle's never-exit deltas, then re-pick
+    each threshold in the widest gap of the deltas the oracle's OWN policy visits (on-policy, a few rounds) and keep
+    the set with the largest minimum relative margin.  Exit decisions are then far from knife-edge, which is what
+    makes "exit-layer indices match exactly" a meaningful requirement for a bf16 device path."""
+    exit_ids = cfg.exit_ids()
+    ctl0 = orc.OracleExitController(None, exit_ids, max_layer=max_layer)
     real = ctl0.real_num_exit
     _, rec, _ = oracle_episode(cfg, sd, inputs, [-1.0] * real, max_layer)
-    thr = []
-    for e in cfg.exit_ids()[:real]:
-        t, _ = gap_threshold([v for (i, v) in rec if i == e])
-        thr.append(t)
+    thr = [gap_threshold([v for (i, v) in rec if i == e])[0] for e in exit_ids[:real]]
     thr[-1] = 1e5
-    return thr
+    best, best_m = list(thr), -1.0
+    for _ in range(iters):
+        _, rec, _ = oracle_episode(cfg, sd, inputs, thr, max_layer, sps)
+        m = min_margin(rec, dict(zip(exit_ids, thr)))
+        if m > best_m:
+            best, best_m = list(thr), m
+        if m > 0.08:
+            break
+        new = list(thr)
+        for k, e in enumerate(exit_ids[:real - 1]):
+            vals = [v for (i, v) in rec if i == e]
+            if len(vals) >= 4:
+                new[k] = gap_threshold(vals, 0.15, 0.85)[0]
+        if new == thr:
+            break
+        thr = new
+    return best, best_m
 
 
 def make_inputs(cfg, n_steps, text_len=14):
@@ -135,7 +157,8 @@ def test_tiny_dynamic_exit_episode_vs_oracle(tiny, max_layer, sps):
     """A 24-step episode with LSTM carry: exit layers identical, actions within 1e-2, per-exit deltas close."""
     cfg, sd, eng = tiny
     inputs = make_inputs(cfg, 24, text_len=11)
-    thr = probe_thresholds(cfg, sd, inputs, max_layer)
+    thr, margin = probe_thresholds(cfg, sd, inputs, max_layer, sps)
+    assert margin > 0.01, margin
     ref, rec, ctl = oracle_episode(cfg, sd, inputs, thr, max_layer, sps)
     eng.configure_exit(cfg.exit_ids(), max_layer, sps)
     eng.set_thresholds(thr)
@@ -144,11 +167,46 @@ def test_tiny_dynamic_exit_episode_vs_oracle(tiny, max_layer, sps):
     for s, (rgb, grip, ids, mask) in enumerate(inputs):
         r = eng.step(rgb, grip, ids, mask, use_graph=(s >= 2))
         exits.append(r["exit_layer"])
-        assert r["exit_layer"] == ref[s][0], (s, exits, [x[0] for x in ref])
+        assert r["exit_layer"] == ref[s][0], (s, exits, [x[0] for x in ref], r["deltas"][:6].tolist(), thr, margin)
         assert float((r["pose"] - ref[s][1]).abs().max()) < ACTION_TOL, s
         assert abs(r["gripper"] - ref[s][2]) < ACTION_TOL
     assert len(set(exits)) > 1, exits                     # the schedule really is dynamic
     assert exits == [x[0] for x in ref]
+
+
+def test_shadow_calibration_mode_records_every_exit_on_policy(tiny):
+    """Shadow mode (bench.py calibration): all exits are evaluated every step, the state is committed at the first
+    exit that fires.  Reference semantics restated with the oracle head/controller pieces."""
+    cfg, sd, eng = tiny
+    inputs = make_inputs(cfg, 10, text_len=9)
+    thr, margin = probe_thresholds(cfg, sd, inputs, 12)
+    exit_ids = cfg.exit_ids()
+    model = orc.OracleDeer(sd, cfg)
+    model.set_all_exit_window_size(1)
+    head = model.extra_exit
+    eng.configure_exit(exit_ids, 12, 1)
+    eng.set_thresholds(thr)
+    eng.reset()
+    for s, (rgb, grip, ids, mask) in enumerate(inputs):
+        hidden, _ = orc.llm_forward(sd, cfg, ids, mask, model.encode_vision(rgb, grip), exit_id=exit_ids[-1])
+        prev = head(hidden[0], update_hidden_state=False)
+        deltas, first = [], None
+        for k, e in enumerate(exit_ids):
+            act = head(hidden[e], update_hidden_state=False)
+            d = float(orc.get_delta(act[0], prev[0], "L2"))
+            deltas.append(d)
+            prev = act
+            if first is None and (d <= thr[k] or e >= exit_ids[-1]):
+                first = e
+        ref_act = head(hidden[first], update_hidden_state=True)
+        r = eng.step(rgb, grip, ids, mask, use_graph=(s >= 2), shadow=True)
+        assert r["exit_layer"] == first, (s, r["exit_layer"], first)
+        got = r["deltas"][: len(exit_ids)]
+        assert float((got - torch.tensor(deltas)).abs().max()) < 5e-3, (s, got, deltas)
+        assert float((r["pose"] - ref_act[0].reshape(-1)).abs().max()) < ACTION_TOL
+    # leaving shadow mode restores normal early termination
+    r = eng.step(*inputs[0][:3], inputs[0][3], use_graph=False)
+    assert r["n_evals"] <= len(exit_ids) + 1
 
 
 def test_graph_replay_is_bit_identical_to_eager(tiny):
@@ -205,7 +263,7 @@ def test_full_size_mpt1b_vitl14_steps_vs_oracle():
     assert float((r["pose"] - o["logits"][0].reshape(-1)).abs().max()) < ACTION_TOL
     assert abs(r["gripper"] - float(o["logits"][1])) < ACTION_TOL
     # dynamic: thresholds in the widest gaps of the oracle's deltas
-    thr = probe_thresholds(cfg, sd, inputs, 12)
+    thr, margin = probe_thresholds(cfg, sd, inputs, 12, iters=1)
     ref, rec, _ = oracle_episode(cfg, sd, inputs, thr, 12)
     eng.configure_exit(cfg.exit_ids(), 12, 1)
     eng.set_thresholds(thr)

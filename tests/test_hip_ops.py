@@ -218,11 +218,12 @@ def test_mpt_attn_small(lib, qk_ln, T, d, H):
     mask = torch.ones(T, dtype=torch.uint8, device="cuda")
     mask[T - 2:] = 0                                         # right padding
     out = torch.zeros(T, d, device="cuda", dtype=torch.bfloat16)
+    ws = torch.zeros(T, 3 * d, device="cuda")
     abi.check(lib.deer_mpt_attn_small(abi.ptr(slab), s_in, mpad * 3 * d, d, H, abi.ptr(qw) if qk_ln else None, abi.ptr(kw) if qk_ln else None,
-                                      1e-5, abi.ptr(mask), 8.0, abi.ptr(out), 0, d, T, None, st()), "mpt attn")
+                                      1e-5, abi.ptr(mask), 8.0, abi.ptr(ws), abi.ptr(out), 0, d, T, None, st()), "mpt attn")
     outf = torch.zeros(T, d, device="cuda")
     abi.check(lib.deer_mpt_attn_small(abi.ptr(slab), s_in, mpad * 3 * d, d, H, abi.ptr(qw) if qk_ln else None, abi.ptr(kw) if qk_ln else None,
-                                      1e-5, abi.ptr(mask), 8.0, abi.ptr(outf), 1, d, T, None, st()), "mpt attn")
+                                      1e-5, abi.ptr(mask), 8.0, abi.ptr(ws), abi.ptr(outf), 1, d, T, None, st()), "mpt attn")
     torch.cuda.synchronize()
     qkv = slab.sum(0)[:T]
     q, k, v = qkv.chunk(3, -1)
