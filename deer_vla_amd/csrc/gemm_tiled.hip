@@ -135,39 +135,73 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Pipelined variant: register ring of THREE K-tiles in flight.  At M ~ 514 (two camera frames) every GEMM of the
-// ViT is latency-bound: few workgroups per CU, 16-64 K-steps each, and with a 1-deep prefetch every K-step pays a
-// full L2/HBM round trip (~1 us measured).  Here the loads of tile kt+3 are issued while tile kt is computed, tile
-// kt+1 (loaded two steps ago) is written to the other LDS buffer, and the counted vmcnt the compiler derives from
-// the static issue order never drains the younger loads.  Loads past the last K-tile are clamped (not branched
-// around) so that the outstanding-load count stays compile-time known.
+// LDS-ring variant (the one the engine uses).  At M ~ 514 rows (two camera frames) every GEMM of the ViT is
+// LATENCY-bound: 1-2 workgroups per CU, 16-64 K-steps each, and a K-step is only ~100 ns of MFMA work, so a
+// shallow prefetch pays a full L2/HBM round trip per K-step (measured ~1 us/step, 4 % of the MFMA roof).
+// Here tiles are streamed with the CDNA4 LDS-DMA path (global_load_lds_dwordx4: no VGPR round trip) into a ring of
+// D stages; D-1 tiles (~100 KiB per CU) are always in flight and the only per-step synchronisation is ONE counted
+// `s_waitcnt vmcnt((D-2)*loads_per_stage)` + ONE raw s_barrier (a __syncthreads() would drain vmcnt to 0).
+//  * LDS image of a stage is lane-linear (DMA writes wave-base + lane*16): rows of 128 B (BK = 64 bf16), A rows
+//    then W rows.  Bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of the 16-byte
+//    slot with (row & 7), applied on the SOURCE address of the DMA and again on the read (same involution).
+//  * rows beyond M / N are clamped (they only feed never-stored accumulators); K % 64 == 0 is required.
+//  * loads past the last K-tile are clamped, not branched around, so the outstanding-load count stays static.
 // ------------------------------------------------------------------------------------------------------------
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_tiled_pipe_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
-                                                              const bf16_t* __restrict__ W, int ldw,
-                                                              const float* __restrict__ bias, void* __restrict__ Cv,
-                                                              int ldc, long strideC, int M, int N, int K, int epi,
-                                                              const float* __restrict__ gate, const int* ctl) {
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+// WM x WN waves per workgroup (64*WM*WN threads); each wave owns a (BM/WM) x (BN/WN) sub-tile.
+// Measured on MI355X (tools/fill_bench.hip): the rate at which a CU can pull L2-resident data is set by the number
+// of WAVES issuing loads on it (~8-9 GB/s per wave: 4 waves 8 TB/s chip-wide, 8 waves 16 TB/s, 16 waves 20 TB/s),
+// not by how many loads each wave keeps in flight - so these kernels run 8-16 waves per workgroup and are sized so
+// that two workgroups fit on a CU.
+template <int BM, int BN, int WM, int WN, int D>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
+                                                                        const bf16_t* __restrict__ W, int ldw,
+                                                                        const float* __restrict__ bias,
+                                                                        void* __restrict__ Cv, int ldc, long strideC,
+                                                                        int M, int N, int K, int epi,
+                                                                        const float* __restrict__ gate, const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
-  constexpr int TM = BM / 32, TN = BN / 32;
-  constexpr int A_CH = BM * 8 / 256, W_CH = BN * 8 / 256;
-  struct Regs { uint4 a[A_CH]; uint4 w[W_CH]; };
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);                 // [2][BM][PITCH]
-  bf16_t* Ws = As + 2 * BM * GT_PITCH;                              // [2][BN][PITCH]
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;               // 16x16 MFMA tiles per wave
+  constexpr int CH = (BM + BN) / 8;                                 // 1 KiB DMA chunks (8 rows x 128 B) per stage
+  constexpr int CPW = CH / NW;                                      // chunks per wave per stage
+  static_assert(CH % NW == 0, "every wave must issue the same number of DMA loads (static vmcnt)");
+  static_assert((BM / WM) % 16 == 0 && (BN / WN) % 16 == 0, "wave tile");
+  static_assert((D - 2) * CPW <= 63, "vmcnt field");
+  constexpr int STAGE = (BM + BN) * 128;                            // bytes per ring stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int c = lane & 15, g = lane >> 4;
-  // XCD-aware mapping: consecutive workgroup ids round-robin over the 8 XCDs; give each XCD a contiguous band of
-  // N-tiles so that a W panel is fetched from HBM into ONE L2 instead of eight (A is small and shared by all).
-  int bx = blockIdx.x;
-  {
-    const int nbx = gridDim.x;
-    if ((nbx & 7) == 0) bx = (blockIdx.x & 7) * (nbx >> 3) + (blockIdx.x >> 3);
-  }
+  int bx = blockIdx.x;                                              // XCD-aware: contiguous band of N-tiles per XCD
+  if ((gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int m0 = blockIdx.y * BM, n0 = bx * BN;
   A += (long)blockIdx.z * strideA;
+
+  // DMA chunk q = wave + i*NW: rows 8q..8q+7 of [A tile ; W tile]; lane: row 8q + (lane>>3), slot (lane&7) ^ (row&7)
+  const int lr = lane >> 3, ls = ((lane & 7) ^ lr) * 8;
+  const bf16_t* sp[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int row = (wave + i * NW) * 8 + lr;                       // uniform per wave: A chunk or W chunk
+    sp[i] = (row < BM) ? A + (long)min(m0 + row, M - 1) * lda + ls : W + (long)min(n0 + row - BM, N - 1) * ldw + ls;
+  }
+  const int nk = K / GT_BK;
+  auto issue = [&](int tile) {
+    const int k0 = min(tile, nk - 1) * GT_BK;
+    unsigned char* st = smem + (tile % D) * STAGE;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(sp[i] + k0), (lptr_t*)(st + (wave + i * NW) * 1024), 16, 0, 0);
+  };
 
   f32x4 acc[TN][TM];
 #pragma unroll
@@ -175,88 +209,37 @@ __global__ __launch_bounds__(256) void gemm_tiled_pipe_kernel(const bf16_t* __re
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (K + GT_BK - 1) / GT_BK;
-  const int k_last = (nk - 1) * GT_BK;
-  // per-thread source pointers, hoisted out of the K loop.  Rows beyond M / N are CLAMPED to the last valid row
-  // instead of predicated: they only feed accumulator rows/columns that are never stored, and unconditional loads
-  // keep hipcc from branching around every load with a vmcnt(0) behind it (which would serialise the pipeline).
-  // K must be a multiple of GT_BK here (checked on the host), so there is no K tail either.
-  const bf16_t* ap[A_CH];
-  const bf16_t* wp[W_CH];
+  // fragment read offsets inside a stage (bytes): row*128 + ((slot ^ (row&7)) << 4), slot = kk*4 + g, row&7 == c&7
+  const int a_row = (wm * (BM / WM) + c) * 128, w_row = (BM + wn * (BN / WN) + c) * 128;
+  const int sw0 = ((0 * 4 + g) ^ (c & 7)) << 4, sw1 = ((1 * 4 + g) ^ (c & 7)) << 4;
+
 #pragma unroll
-  for (int i = 0; i < A_CH; ++i) {
-    const int id = tid + i * 256, row = id >> 3;
-    ap[i] = A + (long)min(m0 + row, M - 1) * lda + (id & 7) * 8;
-  }
+  for (int t = 0; t < D - 1; ++t) issue(t);
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<(D - 2) * CPW>();                // this wave's part of tile kt has landed
+    __builtin_amdgcn_s_barrier();               // ... everybody's part; and everybody finished reading tile kt-1
+    issue(kt + D - 1);                          // refill the slot of tile kt-1
+    const unsigned char* st = smem + (kt % D) * STAGE;
 #pragma unroll
-  for (int i = 0; i < W_CH; ++i) {
-    const int id = tid + i * 256, row = id >> 3;
-    wp[i] = W + (long)min(n0 + row, N - 1) * ldw + (id & 7) * 8;
-  }
-  auto gload = [&](Regs& r, int k0) {
-    k0 = min(k0, k_last);                                           // clamp: keeps the load count static
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) r.a[i] = *reinterpret_cast<const uint4*>(ap[i] + k0);
-#pragma unroll
-    for (int i = 0; i < W_CH; ++i) r.w[i] = *reinterpret_cast<const uint4*>(wp[i] + k0);
-  };
-  auto swrite = [&](const Regs& r, int buf) {
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      const int id = tid + i * 256, row = id >> 3, seg = id & 7;
-      *reinterpret_cast<uint4*>(As + (buf * BM + row) * GT_PITCH + seg * 8) = r.a[i];
-    }
-#pragma unroll
-    for (int i = 0; i < W_CH; ++i) {
-      const int id = tid + i * 256, row = id >> 3, seg = id & 7;
-      *reinterpret_cast<uint4*>(Ws + (buf * BN + row) * GT_PITCH + seg * 8) = r.w[i];
-    }
-  };
-  auto compute = [&](int buf) {
-    const bf16_t* as = As + (buf * BM + wm * (BM / 2) + c) * GT_PITCH + g * 8;
-    const bf16_t* ws = Ws + (buf * BN + wn * (BN / 2) + c) * GT_PITCH + g * 8;
-#pragma unroll
-    for (int kk = 0; kk < GT_BK / 32; ++kk) {
+    for (int kk = 0; kk < 2; ++kk) {
+      const int sw = kk ? sw1 : sw0;
       bf16x8 af[TM], wf[TN];
 #pragma unroll
-      for (int j = 0; j < TM; ++j) af[j] = *reinterpret_cast<const bf16x8*>(as + j * 16 * GT_PITCH + kk * 32);
+      for (int j = 0; j < TM; ++j) af[j] = *reinterpret_cast<const bf16x8*>(st + a_row + j * 16 * 128 + sw);
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(ws + i * 16 * GT_PITCH + kk * 32);
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + w_row + i * 16 * 128 + sw);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
     }
-  };
-
-  Regs r0, r1, r2;
-  gload(r0, 0);
-  gload(r1, GT_BK);
-  gload(r2, 2 * GT_BK);
-  swrite(r0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt += 3) {
-    gload(r0, (kt + 3) * GT_BK);                 // tile kt in LDS[kt&1]; r1 = kt+1, r2 = kt+2 in flight
-    compute(kt & 1);
-    swrite(r1, (kt + 1) & 1);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    gload(r1, (kt + 4) * GT_BK);                 // tile kt+1; r2 = kt+2, r0 = kt+3 in flight
-    compute((kt + 1) & 1);
-    swrite(r2, kt & 1);
-    __syncthreads();
-    if (kt + 2 >= nk) break;
-    gload(r2, (kt + 5) * GT_BK);                 // tile kt+2; r0 = kt+3, r1 = kt+4 in flight
-    compute(kt & 1);
-    swrite(r0, (kt + 1) & 1);
-    __syncthreads();
   }
 
   const float gs = (epi == EPI_RESADD_F32 && gate != nullptr) ? tanhf(*gate) : 1.f;
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
-    const int n = n0 + wn * (BN / 2) + i * 16 + g * 4;
+    const int n = n0 + wn * (BN / WN) + i * 16 + g * 4;
     if (n >= N) continue;
     float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
     if (bias != nullptr) {
@@ -265,7 +248,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_pipe_kernel(const bf16_t* __re
     }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-      const int m = m0 + wm * (BM / 2) + j * 16 + c;
+      const int m = m0 + wm * (BM / WM) + j * 16 + c;
       if (m >= M) continue;
       float v0 = acc[i][j][0] + b0, v1 = acc[i][j][1] + b1, v2 = acc[i][j][2] + b2, v3 = acc[i][j][3] + b3;
       const long off = (long)blockIdx.z * strideC + (long)m * ldc + n;
@@ -288,13 +271,33 @@ __global__ __launch_bounds__(256) void gemm_tiled_pipe_kernel(const bf16_t* __re
   }
 }
 
-template <int BM, int BN, bool PIPE>
+template <int BM, int BN, int WM, int WN, int D>
+static int launch_ring(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, const float* bias, void* C,
+                       int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate,
+                       const int* ctl, hipStream_t st) {
+  constexpr int smem = D * (BM + BN) * 128;
+  static_assert(smem <= 160 * 1024, "LDS");
+  static bool attr_set = false;
+  auto kern = &gemm_tiled_ring_kernel<BM, BN, WM, WN, D>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return DEER_ERR_LAUNCH;
+    attr_set = true;
+  }
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, st, A, lda, strideA, W, ldw, bias, C, ldc, strideC, M, N, K, epi, gate,
+                     ctl);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+template <int BM, int BN>
 static int launch_tiled(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, const float* bias, void* C,
                         int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate,
                         const int* ctl, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * GT_PITCH * (int)sizeof(bf16_t);
   static bool attr_set = false;
-  auto kern = PIPE ? &gemm_tiled_pipe_kernel<BM, BN> : &gemm_tiled_kernel<BM, BN>;
+  auto kern = &gemm_tiled_kernel<BM, BN>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return DEER_ERR_LAUNCH;
@@ -306,37 +309,42 @@ static int launch_tiled(const bf16_t* A, int lda, long strideA, const bf16_t* W,
   return DEER_OK;
 }
 
-// tile: 0 = auto; simple 1-deep-prefetch kernels: 1 = 64x64, 2 = 64x128, 3 = 128x128;
-//       3-deep pipelined kernels: 4 = 64x64, 5 = 128x64, 6 = 64x128, 7 = 128x128
+// tile: 0 = auto; simple register-staged kernels (any K % 8 == 0): 1 = 64x64, 2 = 64x128, 3 = 128x128;
+//       LDS-ring DMA kernels (K % 64 == 0): 4 = 64x64 / 8 waves / 4 stages, 5 = 128x64 / 8 waves / 3 stages,
+//       6 = 64x64 / 16 waves / 6 stages, 7 = 128x128 / 16 waves / 3 stages, 8 = 64x128 / 8 waves / 3 stages,
+//       9 = 32x64 / 4 waves... (see switch)
 extern "C" int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const void* W, int ldw, const float* bias,
                                  void* C, int ldc, long strideC, int M, int N, int K, int batch, int epi,
                                  const float* gate, int tile, const int* ctl, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 15) || (lda & 7) || (ldw & 7) || (ldc & 3) || epi < 0 || epi > 4)
     return DEER_ERR_SHAPE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if ((K % GT_BK) != 0 && tile >= 4) tile -= 3;         // pipelined kernels need K % 64 == 0 (5 -> 2 is a different
-  if ((K % GT_BK) != 0 && tile == 0) tile = 1;          // shape but always valid)
+  const bool ring_ok = (K % GT_BK) == 0;
+  if (!ring_ok && tile >= 4) return DEER_ERR_SHAPE;
+  if (tile < 0 || tile > 10) return DEER_ERR_SHAPE;
   if (tile == 0) {
     // fill the 256 CUs first, then grow the tile (less L2->LDS traffic per flop)
     auto nblk = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
-    if (nblk(128, 128) >= 256) tile = 7;
-    else if (nblk(128, 64) >= 224) tile = 5;
-    else if (nblk(64, 128) >= 224) tile = 6;
-    else tile = 4;
+    if (!ring_ok) tile = (nblk(64, 128) >= 256) ? 2 : 1;
+    else if (nblk(128, 128) >= 512) tile = 7;          // large M (window / calibration mode): MFMA-bound regime
+    else if (nblk(64, 64) > 512) tile = 8;             // measured on MI355X at M = 514 (tools/bench_gemm.py):
+    else tile = 4;                                     //   64x64 / 8 waves wins whenever it gives <= 2 workgroups per CU
   }
   const bf16_t* a = reinterpret_cast<const bf16_t*>(A);
   const bf16_t* w = reinterpret_cast<const bf16_t*>(W);
-#define DEER_GT(BM_, BN_, P_) \
-  return launch_tiled<BM_, BN_, P_>(a, lda, strideA, w, ldw, bias, C, ldc, strideC, M, N, K, batch, epi, gate, ctl, st)
+#define DEER_ARGS a, lda, strideA, w, ldw, bias, C, ldc, strideC, M, N, K, batch, epi, gate, ctl, st
   switch (tile) {
-    case 1: DEER_GT(64, 64, false);
-    case 2: DEER_GT(64, 128, false);
-    case 3: DEER_GT(128, 128, false);
-    case 4: DEER_GT(64, 64, true);
-    case 5: DEER_GT(128, 64, true);
-    case 6: DEER_GT(64, 128, true);
-    case 7: DEER_GT(128, 128, true);
+    case 1: return launch_tiled<64, 64>(DEER_ARGS);
+    case 2: return launch_tiled<64, 128>(DEER_ARGS);
+    case 3: return launch_tiled<128, 128>(DEER_ARGS);
+    case 4: return launch_ring<64, 64, 2, 4, 4>(DEER_ARGS);
+    case 5: return launch_ring<128, 64, 4, 2, 3>(DEER_ARGS);
+    case 6: return launch_ring<64, 64, 4, 4, 6>(DEER_ARGS);
+    case 7: return launch_ring<128, 128, 4, 4, 3>(DEER_ARGS);
+    case 8: return launch_ring<64, 128, 2, 4, 3>(DEER_ARGS);
+    case 9: return launch_ring<32, 64, 2, 2, 6>(DEER_ARGS);
+    case 10: return launch_ring<128, 128, 2, 4, 3>(DEER_ARGS);
     default: return DEER_ERR_SHAPE;
   }
-#undef DEER_GT
+#undef DEER_ARGS
 }

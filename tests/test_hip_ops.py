@@ -117,7 +117,7 @@ def test_abi_rejects_bad_shapes(lib):
 
 
 # ------------------------------------------------------------------------------------------- tiled GEMM
-@pytest.mark.parametrize("tile", [1, 2, 3, 0])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 0])
 @pytest.mark.parametrize("M,N,K", [(514, 3072, 1024), (514, 1024, 4096), (128, 1024, 512), (37, 128, 640), (640, 1024, 1024)])
 def test_gemm_tiled_epilogues(lib, tile, M, N, K):
     A = dev(rnd(M, K, seed=5), torch.bfloat16)

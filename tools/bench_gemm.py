@@ -1,0 +1,38 @@
+"""GPU microbenchmark of deer_gemm_bf16_nt over the ViT / Perceiver shapes of one control step (cold weights:
+each repetition uses a different weight copy so that W comes from HBM like in the real step)."""
+import ctypes, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from deer_vla_amd import _abi as abi
+
+lib = abi.lib()
+st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+SHAPES = [("vit qkv", 514, 3072, 1024), ("vit out", 514, 1024, 1024), ("vit fc1", 514, 4096, 1024), ("vit fc2", 514, 1024, 4096),
+          ("patch", 512, 1024, 640), ("perc kv", 640, 1024, 1024), ("perc q", 128, 512, 1024), ("perc ff1", 128, 4096, 1024),
+          ("perc ff2", 128, 1024, 4096), ("media kv", 128, 12288, 1024)]
+NCOPY = 24
+for name, M, N, K in SHAPES:
+    A = torch.randn(M, K, device="cuda").bfloat16()
+    Ws = [torch.randn(N, K, device="cuda").bfloat16() * K ** -0.5 for _ in range(NCOPY)]
+    C = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    ref = (A.float() @ Ws[0].float().t())
+    line = f"{name:9s} M={M:4d} N={N:5d} K={K:4d} |"
+    for tile in (1, 4, 5, 6, 7, 8, 9, 10, 0):
+        rc = lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(Ws[0]), K, None, abi.ptr(C), N, 0, M, N, K, 1, abi.EPI_BF16, None, tile, None, st())
+        if rc != 0:
+            line += f" t{tile}:  n/a "
+            continue
+        torch.cuda.synchronize()
+        err = float((C.float() - ref).norm() / ref.norm())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2):
+            for w in Ws:
+                lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(w), K, None, abi.ptr(C), N, 0, M, N, K, 1, abi.EPI_BF16, None, tile, None, st())
+        e0.record()
+        for w in Ws:
+            lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(w), K, None, abi.ptr(C), N, 0, M, N, K, 1, abi.EPI_BF16, None, tile, None, st())
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / NCOPY
+        line += f" t{tile}:{us:6.1f}us{'' if err < 5e-3 else ' ERR%.1e' % err}"
+    print(line + f" | {2.0 * M * N * K / 1e6:8.0f} MF", flush=True)
