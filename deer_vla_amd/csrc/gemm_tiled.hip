@@ -160,7 +160,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // of WAVES issuing loads on it (~8-9 GB/s per wave: 4 waves 8 TB/s chip-wide, 8 waves 16 TB/s, 16 waves 20 TB/s),
 // not by how many loads each wave keeps in flight - so these kernels run 8-16 waves per workgroup and are sized so
 // that two workgroups fit on a CU.
-template <int BM, int BN, int WM, int WN, int D>
+template <int BM, int BN, int WM, int WN, int D, int DBG = 0>   // DBG (ablation only): 1 = no MFMA/ds_read, 2 = no DMA in the loop
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
                                                                         const bf16_t* __restrict__ W, int ldw,
                                                                         const float* __restrict__ bias,
@@ -218,10 +218,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
   for (int kt = 0; kt < nk; ++kt) {
     wait_vmcnt<(D - 2) * CPW>();                // this wave's part of tile kt has landed
     __builtin_amdgcn_s_barrier();               // ... everybody's part; and everybody finished reading tile kt-1
-    issue(kt + D - 1);                          // refill the slot of tile kt-1
+    if (DBG != 2) issue(kt + D - 1);            // refill the slot of tile kt-1
     const unsigned char* st = smem + (kt % D) * STAGE;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < (DBG == 1 ? 0 : 2); ++kk) {
       const int sw = kk ? sw1 : sw0;
       bf16x8 af[TM], wf[TN];
 #pragma unroll
@@ -271,14 +271,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
   }
 }
 
-template <int BM, int BN, int WM, int WN, int D>
+template <int BM, int BN, int WM, int WN, int D, int DBG = 0>
 static int launch_ring(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, const float* bias, void* C,
                        int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate,
                        const int* ctl, hipStream_t st) {
   constexpr int smem = D * (BM + BN) * 128;
   static_assert(smem <= 160 * 1024, "LDS");
   static bool attr_set = false;
-  auto kern = &gemm_tiled_ring_kernel<BM, BN, WM, WN, D>;
+  auto kern = &gemm_tiled_ring_kernel<BM, BN, WM, WN, D, DBG>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return DEER_ERR_LAUNCH;
@@ -321,7 +321,7 @@ extern "C" int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const voi
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool ring_ok = (K % GT_BK) == 0;
   if (!ring_ok && tile >= 4) return DEER_ERR_SHAPE;
-  if (tile < 0 || tile > 10) return DEER_ERR_SHAPE;
+  if (tile < 0 || tile > 44) return DEER_ERR_SHAPE;
   if (tile == 0) {
     // fill the 256 CUs first, then grow the tile (less L2->LDS traffic per flop)
     auto nblk = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
@@ -344,6 +344,9 @@ extern "C" int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const voi
     case 8: return launch_ring<64, 128, 2, 4, 3>(DEER_ARGS);
     case 9: return launch_ring<32, 64, 2, 2, 6>(DEER_ARGS);
     case 10: return launch_ring<128, 128, 2, 4, 3>(DEER_ARGS);
+    case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)
+    case 34: return launch_ring<64, 64, 2, 4, 4, 2>(DEER_ARGS);
+    case 44: return launch_ring<64, 64, 2, 4, 8>(DEER_ARGS);      // deeper ring
     default: return DEER_ERR_SHAPE;
   }
 #undef DEER_ARGS
