@@ -393,7 +393,8 @@ class DeerEngine:
 
     # -------------------------------------------------------------------------------------------- head
     def enqueue_head(self, layer: int, T: int, kind: int, slot: int = -1, force: bool = False, use_ctl: bool = True,
-                     feats: Optional[torch.Tensor] = None, h_prev=None, c_prev=None, shadow: bool = False):
+                     feats: Optional[torch.Tensor] = None, h_prev=None, c_prev=None, shadow: bool = False,
+                     no_ctl_final: bool = False):
         """One DeterministicDecoder evaluation on hidden_states[layer] (action_head.py:499-611) followed by the
         exit gate (value_net.py:120-133,277-297).  kind: PSEUDO (prev action from layer i-1, value_net.py:122-125),
         CHECK (delta <= threshold -> exit + commit LSTM state), COMMIT (static exit_id / committing call)."""
@@ -430,7 +431,7 @@ class DeerEngine:
         LH = cfg.lstm_num_layers * H
         abi.check(lib.deer_head_final(abi.ptr(src), in_dim, pro, abi.ptr(ln[0]), abi.ptr(ln[1]), abi.ptr(ln[2]), abi.ptr(ln[3]),
                                       abi.ptr(Hd["wa"]), abi.ptr(Hd["ba"]), abi.ptr(Hd["wg"]), abi.ptr(Hd["bg"]),
-                                      abi.ptr(self.ctl), kind, layer, slot, abi.ptr(self.thresholds), 1 if force else 0,
+                                      None if no_ctl_final else abi.ptr(self.ctl), kind, layer, slot, abi.ptr(self.thresholds), 1 if force else 0,
                                       self.thr_type, self.leq, abi.ptr(self.h_tmp), abi.ptr(self.c_tmp),
                                       abi.ptr(self.h_shadow if shadow else self.h_state),
                                       abi.ptr(self.c_shadow if shadow else self.c_state), LH, abi.ptr(self.action_dbg), EPS, st),

@@ -1,0 +1,154 @@
+"""Host-side mirror of robot_flamingo/models/factory.py: ``create_model_and_transforms`` with the reference's
+signature (factory.py:53-91) returning ``(model, image_processor, text_tokenizer)``.
+
+What differs, and why: the reference pulls the ViT from open_clip, the LLM from a HF remote-code repo and the
+tokenizer from HF, all by local path (``mpt_dict``, factory.py:13-26).  None of those exist in this environment (no
+network, no checkpoints), so
+ * weights are taken from a state dict in the reference's key names (``state_dict=`` kwarg, or later through
+   ``model.load_state_dict(torch.load(ckpt), strict=False)`` exactly like eval_calvin.py:541-543,572-578); when no
+   state dict is given, seeded synthetic weights of the real architecture are used (and flagged);
+ * ``image_processor`` is this repo's restatement of the open_clip ViT-L-14 transform (Resize 224 bicubic ->
+   CenterCrop -> ToTensor -> Normalize with the CLIP mean/std; data.py:898-902 stacks its outputs);
+ * ``text_tokenizer`` is ``transformers.AutoTokenizer`` when ``tokenizer_path`` exists locally, otherwise a
+   deterministic stand-in with the same call surface (flagged ``is_synthetic``).
+"""
+from __future__ import annotations
+
+import os
+import zlib
+from typing import Optional
+
+import torch
+
+from .config import DeerConfig, deer_3b, deer_9b
+from .flamingo_mpt import MPTFlamingo
+from . import synthetic as syn
+
+mpt_dict = {          # factory.py:13-26 (paths are deployment-specific; only cross_attn_every_n_layers matters here)
+    "mpt_dolly_3b": {"lang_encoder_path": "mpt-1b-redpajama-200b-dolly", "tokenizer_path": "mpt-1b-redpajama-200b-dolly",
+                     "cross_attn_every_n_layers": 1, "openflamingo_checkpoint": "OpenFlamingo-3B-vitl-mpt1b-langinstruct.pt"},
+    "mpt_9b": {"lang_encoder_path": "mpt-7b", "tokenizer_path": "mpt-7b", "cross_attn_every_n_layers": 4,
+               "openflamingo_checkpoint": "OpenFlamingo-9B-vitl-mpt7b.pt"},
+}
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+class ClipImageProcessor:
+    """open_clip ``image_transform(224, is_train=False)`` for ViT-L-14/openai, on PIL images or uint8 arrays."""
+
+    def __init__(self, size: int = 224):
+        self.size = size
+
+    def __call__(self, img) -> torch.Tensor:
+        import numpy as np
+        from PIL import Image
+        if not isinstance(img, Image.Image):
+            img = Image.fromarray(np.asarray(img))
+        img = img.convert("RGB")
+        w, h = img.size
+        s = self.size / min(w, h)
+        nw, nh = max(self.size, round(w * s)), max(self.size, round(h * s))
+        img = img.resize((nw, nh), Image.BICUBIC)
+        l, t = (nw - self.size) // 2, (nh - self.size) // 2
+        img = img.crop((l, t, l + self.size, t + self.size))
+        x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
+        mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
+        std = torch.tensor(CLIP_STD).view(3, 1, 1)
+        return (x - mean) / std
+
+
+class SyntheticTokenizer:
+    """Deterministic stand-in for the gpt-neox-20b tokenizer (no tokenizer files in this environment): words are hashed
+    into the ordinary-id range; ``<image>``, ``<|endofchunk|>``, ``<PAD>`` and eos map to the special ids."""
+    is_synthetic = True
+
+    def __init__(self, cfg: DeerConfig):
+        self.cfg = cfg
+        self.eos_token, self.pad_token = "<|endoftext|>", "<PAD>"
+        self.eos_token_id, self.pad_token_id = 0, cfg.eoc_token_id + 2
+        self.padding_side = "right"
+
+    def __len__(self):
+        return self.cfg.vocab_size
+
+    def _tok(self, text: str):
+        out = []
+        for piece in text.replace("<image>", " <image> ").replace("<|endofchunk|>", " <|endofchunk|> ") \
+                         .replace(self.eos_token, f" {self.eos_token} ").split():
+            if piece == "<image>":
+                out.append(self.cfg.media_token_id)
+            elif piece == "<|endofchunk|>":
+                out.append(self.cfg.eoc_token_id)
+            elif piece == self.eos_token:
+                out.append(self.eos_token_id)
+            else:
+                out.append(1 + zlib.crc32(piece.encode()) % (self.cfg.eoc_token_id - 1))
+        return out
+
+    def encode(self, text: str):
+        return self._tok(text)
+
+    def __call__(self, texts, max_length=32, padding="longest", truncation="only_first", return_tensors="pt"):
+        rows = [self._tok(t)[:max_length] for t in texts]
+        L = max(len(r) for r in rows)
+        ids = torch.full((len(rows), L), self.pad_token_id, dtype=torch.long)
+        mask = torch.zeros((len(rows), L), dtype=torch.long)
+        for i, r in enumerate(rows):
+            ids[i, :len(r)] = torch.tensor(r)
+            mask[i, :len(r)] = 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+def create_model_and_transforms(clip_vision_encoder_path: str = "ViT-L-14", clip_vision_encoder_pretrained: str = "openai",
+                                lang_encoder_path: str = "", tokenizer_path: str = "", cross_attn_every_n_layers: int = 1,
+                                use_local_files: bool = False, decoder_layers_attr_name: str = None, window_size: int = 32,
+                                freeze_embed: bool = False, train_params=-1, use_gripper=False, use_state=False,
+                                last_action=False, fusion_mode="", pad_length=-1, debug=False, sep_resampler=False,
+                                sep_lm_head=False, unfreeze_vit=False, return_feature=False, multi_step_action=1,
+                                llm_name="mpt_dolly_3b", pooling="max", residual=False, tcp_rel=False, replan=-1,
+                                decoder_type="lstm", hidden_size=None, freeze_sampler=False, fwd_pred=False,
+                                fwd_pred_hand=False, no_image_patch=False, global_latent=1, refresh=-1,
+                                head_type="deterministic", state_dict=None, cfg: Optional[DeerConfig] = None, device="cuda",
+                                **flamingo_kwargs):
+    if clip_vision_encoder_path != "ViT-L-14":
+        raise NotImplementedError("only the CLIP ViT-L/14 tower of the released checkpoints is implemented")
+    if "mpt" not in llm_name:
+        raise NotImplementedError("LLaMA-based BCFlamingo is out of scope (SURVEY §2 row 12)")
+    if decoder_type != "lstm" or head_type != "deterministic":
+        raise NotImplementedError("only the LSTM DeterministicDecoder head is used by DeeR checkpoints (SURVEY §2 row 5)")
+    early_exit_layer = flamingo_kwargs.get("early_exit_layer", -1)
+    if cfg is None:
+        base = deer_9b if llm_name == "mpt_9b" else deer_3b
+        cfg = base(max_layer=10 ** 6)
+        n_total = cfg.n_layers_total
+        if early_exit_layer < 0:
+            early_exit_layer += n_total
+        cfg.early_exit_layer = early_exit_layer
+        cfg.cross_attn_every_n_layers = mpt_dict[llm_name]["cross_attn_every_n_layers"]   # eval_calvin.py:427
+        cfg.exit_interval = flamingo_kwargs.get("exit_interval", 1)
+        cfg.mlp_layernorm = bool(flamingo_kwargs.get("mlp_layernorm", False))
+        cfg.lstm_layernorm = bool(flamingo_kwargs.get("lstm_layernorm", False))
+        cfg.mlp_num_hidden_layers = flamingo_kwargs.get("mlp_num_hidden_layers", 3)
+        cfg.lstm_num_layers = flamingo_kwargs.get("lstm_num_layers", 4)
+        cfg.pooling = pooling
+        cfg.window_size = window_size
+    synthetic = state_dict is None
+    if synthetic:
+        state_dict = syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True)
+    model = MPTFlamingo(cfg, state_dict, window_size=window_size, use_gripper=use_gripper, fusion_mode=fusion_mode, device=device)
+    model.synthetic_weights = synthetic
+    image_processor = ClipImageProcessor(cfg.image_size)
+    tok = None
+    if tokenizer_path and os.path.isdir(tokenizer_path):
+        from transformers import AutoTokenizer
+        tok = AutoTokenizer.from_pretrained(tokenizer_path, local_files_only=True)
+        tok.add_special_tokens({"additional_special_tokens": ["<|endofchunk|>", "<image>"]})     # factory.py:120-122
+        if tok.pad_token is None:
+            tok.add_special_tokens({"pad_token": "<PAD>"})
+        model.eoc_token_id = cfg.eoc_token_id = tok.encode("<|endofchunk|>")[-1]
+        model.media_token_id = cfg.media_token_id = tok.encode("<image>")[-1]
+    else:
+        tok = SyntheticTokenizer(cfg)
+    return model, image_processor, tok

@@ -1,0 +1,312 @@
+"""Host-side mirror of ``MPTFlamingo`` (robot_flamingo/models/flamingo_mpt.py:17-778) and of the multi-exit
+``lang_encoder`` surface (mosaic_gpt_3b.py:274-449 + open_flamingo/src/flamingo_lm.py:131-247) over the HIP engine.
+
+Drop-in contract: same constructor keywords that matter for inference, same ``forward`` signature,
+same returned object (``.logits=(pose (1,1,6), gripper (1,1,1))``, ``.exit_layer``, ``.hidden_states`` tuple with
+``len == exit_layer + 1``), same attributes the CALVIN harness reads through ``.module`` (eval_utils.py:192-480),
+same state-dict key names (``load_state_dict(..., strict=False)`` accepts the OpenFlamingo ``.pt`` and the DeeR
+``.pth`` ``model_state_dict`` with its ``module.`` prefix).
+
+Two execution paths:
+ * native controller (``deer_vla_amd.value_net.ExitController``) or static ``exit_id``: the whole control step is one
+   HIP-graph replay; the exit criterion runs on the device (no host round trip per layer).
+ * foreign controller (any callable ``ctl(all_hidden_states, b_idx) -> bool``, e.g. the reference's own class): the
+   reference's host loop - one layer at a time, one sync per exit check - on the same kernels.
+There is no CPU path: constructing the engine without a HIP device raises.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _abi as abi
+from .action_head import DeterministicDecoder
+from .config import DeerConfig
+from .engine import DeerEngine
+from .synthetic import param_shapes
+from .value_net import ExitController
+
+
+@dataclass
+class CausalLMOutputWithPast:
+    """mosaic_gpt_3b.py:27-61 (fields used on this path)."""
+    loss: Optional[torch.Tensor] = None
+    logits: Any = None
+    past_key_values: Any = None
+    hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
+    attentions: Any = None
+    exit_layer: Optional[int] = None
+
+
+class _Cfg:
+    def __init__(self, n_layers, d_model):
+        self.n_layers, self.d_model = n_layers, d_model
+
+
+class _Layer:
+    """Stand-in for ``FlamingoLayer`` (flamingo_lm.py:6-44): conditioning state only."""
+
+    def __init__(self, has_xattn):
+        self.gated_cross_attn_layer = object() if has_xattn else None
+        self.vis_x = None
+        self.media_locations = None
+        self.use_cached_media = False
+
+    def is_conditioned(self):
+        return self.vis_x is not None and self.media_locations is not None
+
+    def condition_vis_x(self, v):
+        self.vis_x = v
+
+    def condition_media_locations(self, m):
+        self.media_locations = m
+
+    def condition_use_cached_media(self, u):
+        self.use_cached_media = u
+
+
+class LangEncoder:
+    """The ``lang_encoder`` object of the reference (MosaicGPT + FlamingoLMMixin) as seen from outside."""
+
+    def __init__(self, model: "MPTFlamingo"):
+        self._m = model
+        cfg = model.cfg
+        self.config = _Cfg(cfg.n_layers, cfg.d_model)
+        self.media_token_id = cfg.media_token_id
+        self.initialized_flamingo = True
+        self._layers = [_Layer(cfg.has_xattn(i)) for i in range(cfg.n_layers)]
+        self.gated_cross_attn_layers = [l.gated_cross_attn_layer for l in self._layers]
+        self.old_decoder_blocks = list(range(cfg.n_layers))
+        self.lm_head = nn.Identity()                            # flamingo_mpt.py:188
+
+    def _get_decoder_layers(self):
+        return self._layers
+
+    def is_conditioned(self) -> bool:
+        return all(l.is_conditioned() for l in self._layers)
+
+    def clear_conditioned_layers(self):
+        for l in self._layers:
+            l.condition_vis_x(None)
+            l.condition_media_locations(None)
+            l.condition_use_cached_media(None)
+
+    def get_input_embeddings(self):
+        return self._m.engine.wte
+
+    def forward(self, input_ids, attention_mask=None, past_key_values=None, prefix_mask=None, sequence_id=None,
+                return_dict=None, output_attentions=None, output_hidden_states=None, use_cache=None,
+                exit_controller=None, exit_id=None, all_hidden_states=None, eval_flop=False, eval_time=False):
+        """mosaic_gpt_3b.py:274-449 on the already-encoded media (``MPTFlamingo.forward`` conditions the layers)."""
+        assert exit_controller is None or exit_id is None, "Only one exit indicator can be sepcified!"
+        if output_attentions:
+            raise NotImplementedError("output_attentions is not implemented yet for MosaicGPT")
+        return self._m._run_llm(input_ids, attention_mask, exit_controller, exit_id)
+
+    __call__ = forward
+
+
+class MPTFlamingo(nn.Module):
+    def __init__(self, cfg: DeerConfig, state_dict: Optional[Dict[str, torch.Tensor]] = None, window_size: int = 12,
+                 use_gripper: bool = True, fusion_mode: str = "post", device="cuda", **unused):
+        super().__init__()
+        if not use_gripper or fusion_mode != "post":
+            raise NotImplementedError("released DeeR checkpoints use use_gripper=True, fusion_mode='post' (flamingo_mpt.py:380-381)")
+        self.cfg = cfg
+        self._device = device
+        self._sd: Dict[str, torch.Tensor] = dict(state_dict) if state_dict is not None else {}
+        self._engine: Optional[DeerEngine] = None
+        # attributes read by the CALVIN harness through `.module` (eval_utils.py:192-247,300-331,456,480)
+        self.module = self
+        self.window_size = window_size
+        self.use_gripper, self.fusion_mode = use_gripper, fusion_mode
+        self.use_state, self.sep_lm_head, self.tcp_rel = False, True, False
+        self.replan, self.refresh, self.pad_length, self.act_step = -1, -1, -1, 1
+        self.decoder_type, self.head_type = "lstm", "deterministic"
+        self.use_diff, self.use_hist, self.sep_resampler = False, False, False
+        self.eoc_token_id, self.media_token_id = cfg.eoc_token_id, cfg.media_token_id
+        self.vis_dim, self.lang_dim = cfg.vit_width, cfg.d_model
+        self.early_exit_layer = cfg.early_exit_layer
+        self.layerwise_exit_eval = False
+        self.llm_inference_time = -1.0
+        self.lm_exits = {i: None for i in range(cfg.exit_interval - 1, cfg.early_exit_layer, cfg.exit_interval)}
+        self.lang_encoder = LangEncoder(self)
+        self.extra_exit: Optional[DeterministicDecoder] = None
+        self.lm_head = None
+        self._ctl_sig = None
+
+    # ---- engine / weights ------------------------------------------------------------------------------------
+    @property
+    def engine(self) -> DeerEngine:
+        if self._engine is None:
+            missing = [k for k in param_shapes(self.cfg) if k not in self._sd]
+            if missing:
+                raise RuntimeError(f"{len(missing)} parameters missing before the first forward, e.g. {missing[:3]}")
+            self._engine = DeerEngine(self.cfg, self._sd, device=self._device)
+            self.extra_exit = DeterministicDecoder(self._engine, self.window_size)
+            self.lm_head = self.extra_exit
+        return self._engine
+
+    def state_dict(self, *a, **k):
+        return dict(self._sd)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts reference key names, with or without the DDP ``module.`` prefix, plus the
+        ``lang_encoder.gated_cross_attn_layers.N.*`` alias of the x-attn weights."""
+        want = param_shapes(self.cfg)
+        unexpected, loaded = [], set()
+        for k, v in state_dict.items():
+            k2 = k[len("module."):] if k.startswith("module.") else k
+            if k2.startswith("lang_encoder.gated_cross_attn_layers."):
+                rest = k2[len("lang_encoder.gated_cross_attn_layers."):]
+                n, tail = rest.split(".", 1)
+                k2 = f"lang_encoder.transformer.blocks.{n}.gated_cross_attn_layer.{tail}"
+            if k2.startswith("lang_encoder.old_decoder_blocks."):
+                rest = k2[len("lang_encoder.old_decoder_blocks."):]
+                n, tail = rest.split(".", 1)
+                k2 = f"lang_encoder.transformer.blocks.{n}.decoder_layer.{tail}"
+            if k2 in want:
+                if tuple(v.shape) != tuple(want[k2][0]):
+                    if k2 == "lang_encoder.transformer.wte.weight" and v.shape[1] == want[k2][0][1]:
+                        pass                                      # vocab may be larger (resize_token_embeddings)
+                    else:
+                        raise RuntimeError(f"size mismatch for {k2}: {tuple(v.shape)} vs {want[k2][0]}")
+                self._sd[k2] = v.detach()
+                loaded.add(k2)
+            else:
+                unexpected.append(k)
+        missing = [k for k in want if k not in self._sd]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"missing keys {missing[:5]}..., unexpected keys {unexpected[:5]}...")
+        self._engine = None                                       # weights changed: rebuild on next use
+        return missing, unexpected
+
+    def to(self, *a, **k):
+        return self
+
+    def half(self):
+        return self
+
+    def bfloat16(self):
+        return self
+
+    # ---- exits bookkeeping (flamingo_mpt.py:268-306) ----------------------------------------------------------
+    def get_all_exit_idx(self):
+        return list(self.lm_exits.keys()) + [self.lang_encoder.config.n_layers - 1]
+
+    def get_exit_num(self):
+        return len(self.get_all_exit_idx())
+
+    def set_all_exit_window_size(self, new_window_size):
+        old = self.extra_exit.window_size if self.extra_exit is not None else self.window_size
+        if self.extra_exit is not None:
+            self.extra_exit.window_size = new_window_size
+        return old
+
+    def clear_all_exit_memory(self):
+        self.engine.reset()
+        self.extra_exit.history_memory = []
+
+    # ---- forward ---------------------------------------------------------------------------------------------------
+    def _sync_controller(self, ctl: ExitController):
+        e = self.engine
+        sig = (tuple(ctl.exit_id_list), ctl.max_layer, ctl.steps_per_stage, ctl._version, ctl.leq)
+        if sig != self._ctl_sig:
+            e.configure_exit(ctl.exit_id_list, ctl.max_layer + 1, ctl.steps_per_stage)
+            assert e.ctl_max_layer == ctl.max_layer
+            assert ctl.thresholds is not None, "Please set thresholds before calling forward"
+            e.set_thresholds(ctl.threshold_list())
+            e.leq = 1 if ctl.leq else 0
+            if ctl.value_net is not None:
+                e.thr_type = abi.THR_TYPES[ctl.value_net.threshold_type]
+            self._ctl_sig = sig
+        e.cur_step = ctl.cur_step
+
+    def _run_llm(self, input_ids, attention_mask, exit_controller, exit_id):
+        """Slow host loop (foreign controllers, or a direct ``lang_encoder(...)`` call): vision must already be encoded."""
+        e, cfg = self.engine, self.cfg
+        ids = input_ids.reshape(-1)
+        T = ids.numel()
+        e.ids[:T].copy_(ids)
+        use_mask = False
+        if attention_mask is not None:
+            m = attention_mask.reshape(-1).to(torch.uint8)
+            use_mask = bool((m == 0).any())
+            e.key_mask[:T].copy_(m)
+        if exit_id is not None and exit_id < 0:
+            exit_id += cfg.n_layers
+        e.ctl.zero_()
+        e.enqueue_embed(T)
+        hidden = ()
+        pending = None
+        b = -1
+        for b in range(cfg.n_layers):
+            pending = e.enqueue_llm_layer(b, T, pending, use_mask, finalize=True, ctl=False)
+            hidden = hidden + (e.hidden[b, :T].unsqueeze(0),)
+            if exit_id is not None and exit_id == b:
+                break
+            if exit_controller is not None:
+                torch.cuda.current_stream().synchronize()
+                if exit_controller(hidden, b):
+                    break
+        return CausalLMOutputWithPast(logits=[1.0], hidden_states=hidden, exit_layer=b)
+
+    def forward(self, vision_x: torch.Tensor, lang_x: torch.Tensor, attention_mask: torch.Tensor = None, labels=None,
+                use_cached_vision_x: bool = False, clear_conditioned_layers: bool = True, past_key_values=None,
+                use_cache: bool = False, vision_gripper=None, state_tensor=None, return_feature=False, policy_mask=None,
+                act=None, deterministic=False, with_gripper_logits=False, exit_id=None, dynamic_early_exit=False,
+                exit_controller=None, return_in_feat=False, return_aggregate_feature=False, only_extra_exit=False,
+                eval_time=False, no_backbone_grad=False):
+        assert (vision_x is not None) or use_cached_vision_x, "Must provide either vision_x or use_cached_vision_x to True."
+        if use_cached_vision_x:
+            raise NotImplementedError("use_cached_vision_x is not used on the DeeR robot path")
+        if vision_gripper is None:
+            raise ValueError("vision_gripper is required (flamingo_mpt.py:355 clones it unconditionally)")
+        if vision_x.ndim != 6 or vision_x.shape[0] != 1 or vision_x.shape[1] != 1:
+            raise NotImplementedError("native engine: step mode (B=1, T_img=1); window mode is a 'next' row (SURVEY §8f.1)")
+        assert vision_x.shape[2] == 1, "Only single frame supported"
+        if exit_id is None and not (dynamic_early_exit and exit_controller is not None):
+            raise NotImplementedError("training branch (all exits, flamingo_mpt.py:463-517) is out of scope; pass exit_id "
+                                      "or dynamic_early_exit=True with an exit_controller")
+        e, cfg = self.engine, self.cfg
+        ctl = getattr(exit_controller, "module", exit_controller)
+        native = isinstance(ctl, ExitController)
+        t0 = None
+        if eval_time:
+            torch.cuda.synchronize()
+            import time
+            t0 = time.time()
+        if exit_id is not None or native:
+            if native and exit_id is None:
+                self._sync_controller(ctl)
+            r = e.step(vision_x, vision_gripper, lang_x, attention_mask, exit_id=exit_id)
+            exit_layer = r["exit_layer"]
+            if native and exit_id is None:
+                ctl.cur_exit_id = int(e.ctl_host[abi.CTL_CUR_EXIT_ID])
+        else:
+            # foreign controller: the reference's host loop on our kernels
+            T, use_mask = e.load_inputs(vision_x, vision_gripper, lang_x, attention_mask)
+            e.enqueue_vision()
+            out = self._run_llm(lang_x, attention_mask, exit_controller, None)
+            exit_layer = out.exit_layer
+            self.extra_exit(out.hidden_states[exit_layer], update_hidden_state=True)      # flamingo_mpt.py:459
+            e.ctl_host.copy_(e.ctl)
+        if eval_time:
+            torch.cuda.synchronize()
+            self.llm_inference_time = time.time() - t0
+        T = lang_x.reshape(-1).numel()
+        if exit_id is not None or native:
+            a = e.ctl.view(torch.float32)[abi.CTL_OUT_ACTION: abi.CTL_OUT_ACTION + 8].clone()
+        else:
+            a = e.action_dbg.clone()
+        hidden = tuple(e.hidden[i, :T].unsqueeze(0) for i in range(exit_layer + 1))
+        assert len(hidden) == exit_layer + 1                                                # flamingo_mpt.py:458
+        pose, grip = a[:6].view(1, 1, 6), a[6:7].view(1, 1, 1)
+        logits = (pose, (grip, a[7:8].view(1, 1, 1))) if with_gripper_logits else (pose, grip)
+        vis = e.vis_x_f32.view(1, 1, cfg.n_media, cfg.vit_width)
+        for l in self.lang_encoder._get_decoder_layers():
+            l.condition_vis_x(vis)                                                          # flamingo_mpt.py:665-666
+        return CausalLMOutputWithPast(logits=logits, hidden_states=hidden, exit_layer=exit_layer)

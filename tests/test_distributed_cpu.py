@@ -1,0 +1,74 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the rank sharding, the single metric all-reduce and the
+calibration all_gather of deer_vla_amd.distributed (the GPU path uses the same calls over RCCL)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from deer_vla_amd import distributed as dd
+from deer_vla_amd.value_net import ExitController
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seqs = list(range(8))
+    mine = dd.shard_sequences(seqs, rank, world)
+    # fake per-chain results: chain i succeeds i % 6 subtasks; each chain takes 3 steps exiting at layer (i % 4) * 2 + 1
+    results = [i % 6 for i in mine]
+    exits = [(i % 4) * 2 + 1 for i in mine for _ in range(3)]
+    m = dd.reduce_metrics(dd.pack_metrics(results, exits, 12, llm_time=0.5))
+    vals = torch.arange(6 * 5, dtype=torch.float32).view(6, 5) + 100 * rank
+    gathered = dd.all_gather_values(vals)
+    ctl = ExitController(None, [1, 3, 5, 7, 9, 11], max_layer=12)
+    ctl.set_threshold_from_values(gathered, 0.8)
+    dist.barrier()
+    q.put((rank, mine, m, tuple(gathered.shape), ctl.threshold_list()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding_and_metric_reduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, mine0, m0, shp0, thr0), (r1, mine1, m1, shp1, thr1) = out
+    assert mine0 == [0, 1, 2, 3] and mine1 == [4, 5, 6, 7]               # contiguous rank blocks (eval_utils.py:523-527)
+    assert m0 == m1                                                       # every rank sees the global metrics
+    results = [i % 6 for i in range(8)]
+    assert m0["n_chains"] == 8 and abs(m0["avg_seq_len"] - sum(results) / 8) < 1e-12
+    assert m0["chain_sr"][0] == sum(1 for r in results if r >= 1) / 8
+    assert m0["n_steps"] == 24 and abs(m0["avg_exit"] - sum((i % 4) * 2 + 2 for i in range(8)) / 8) < 1e-12
+    assert sum(m0["exit_hist"]) == 24 and m0["exit_hist"][1] == 6
+    assert abs(m0["llm_time"] - 1.0) < 1e-12
+    assert shp0 == shp1 == (6, 10) and thr0 == thr1
+
+
+def test_single_process_fallbacks():
+    assert dd.world_info() == (0, 1)
+    m = dd.reduce_metrics(dd.pack_metrics([5, 0], [1, 11], 12))
+    assert m["avg_seq_len"] == 2.5 and m["avg_exit"] == 7.0
+    v = torch.ones(2, 3)
+    assert dd.all_gather_values(v) is v
+    try:
+        dd.shard_sequences(list(range(7)), 0, 2)
+        assert False
+    except AssertionError:
+        pass

@@ -1,0 +1,96 @@
+"""The reference's Python surface on top of the HIP engine: factory -> MPTFlamingo.forward with (a) a static exit_id,
+(b) the native ExitController (device-side exit, one graph replay per step) and (c) a FOREIGN controller written
+against the reference protocol `ctl(all_hidden_states, b_idx) -> bool` that calls `exit_head(feats[i],
+update_hidden_state=False)` (here: the oracle's restatement of ActionValueNet/ExitController, pinned to the
+reference) - all three against the golden outputs of the reference's own MPTFlamingo.forward."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import load  # noqa: E402
+from deer_vla_amd import factory, synthetic as syn  # noqa: E402
+from deer_vla_amd.value_net import ActionValueNet, ExitController  # noqa: E402
+from oracle import deer_oracle as orc  # noqa: E402
+
+TOL = 1e-2
+
+
+@pytest.fixture(scope="module")
+def setup():
+    cfg, seed, g = load("deer_forward.npz")
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
+    model, image_processor, tok = factory.create_model_and_transforms(
+        "ViT-L-14", "openai", "", "", cross_attn_every_n_layers=1, window_size=12, use_gripper=True, fusion_mode="post",
+        llm_name="mpt_dolly_3b", state_dict=sd, cfg=cfg)
+    return cfg, g, model
+
+
+def test_static_exit_matches_reference_forward(setup):
+    cfg, g, model = setup
+    ids, mask = g["ids"].long().cuda(), g["mask"].cuda()
+    for eid in (3, 4, -1):
+        model.clear_all_exit_memory()
+        o = model(vision_x=g["rgb"][0].cuda(), lang_x=ids, attention_mask=mask, vision_gripper=g["grip"][0].cuda(),
+                  state_tensor=torch.zeros(1, 1, 1, 15).cuda(), return_feature=True, deterministic=True, exit_id=eid)
+        tag = f"static{eid}"
+        assert o.exit_layer == int(g[tag + "_exit"]) and len(o.hidden_states) == o.exit_layer + 1
+        assert o.logits[0].shape == (1, 1, 6) and o.logits[1].shape == (1, 1, 1)
+        assert float((o.logits[0].cpu() - g[tag + "_pose"]).abs().max()) < TOL
+        assert float((o.logits[1].cpu() - g[tag + "_grip"]).abs().max()) < TOL
+        ref_h = g[tag + "_hidden"][-1]
+        assert float((o.hidden_states[-1].cpu() - ref_h).abs().max() / ref_h.abs().max()) < 2e-2
+    assert model.lang_encoder.is_conditioned()
+
+
+@pytest.mark.parametrize("tag", ["dyn", "dynS"])
+def test_native_controller_matches_reference_dynamic_exit(setup, tag):
+    cfg, g, model = setup
+    ids, mask = g["ids"].long().cuda(), g["mask"].cuda()
+    model.clear_all_exit_memory()
+    vn = ActionValueNet(model.get_all_exit_idx(), model.extra_exit, cfg.exit_interval, cfg.window_size, "L2")
+    ctl = ExitController(vn, model.get_all_exit_idx(), steps_per_stage=1, leq=True, exit_dist="exp", max_layer=int(g[tag + "_max_layer"]))
+    ctl._set_threshold_value([float(t) for t in g[tag + "_thr"]])
+    for s in range(g["rgb"].shape[0]):
+        ctl.module.set_timestep(s)                      # eval_utils.py:662-663
+        o = model(vision_x=g["rgb"][s].cuda(), lang_x=ids, attention_mask=mask, vision_gripper=g["grip"][s].cuda(),
+                  return_feature=True, deterministic=True, exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
+        assert o.exit_layer == int(g[tag + "_exit"][s]), (tag, s)
+        assert float((o.logits[0].cpu() - g[tag + "_pose"][s]).abs().max()) < TOL
+        assert float((o.logits[1].cpu() - g[tag + "_grip"][s]).abs().max()) < TOL
+        assert ctl.cur_exit_id == o.exit_layer
+
+
+def test_foreign_controller_protocol(setup):
+    """A controller that is NOT ours: the oracle's ExitController/ValueNet drive our `extra_exit` head object through
+    the reference protocol (slow host loop, one sync per exit check)."""
+    cfg, g, model = setup
+    ids, mask = g["ids"].long().cuda(), g["mask"].cuda()
+    tag = "dyn"
+    model.clear_all_exit_memory()
+    head = model.extra_exit
+
+    class HeadAdapter:                                   # the oracle value net calls head(feats, update_hidden_state=...)
+        def __call__(self, feats, update_hidden_state=True, **kw):
+            a, gr = head(feats, update_hidden_state=update_hidden_state)
+            return a.cpu(), gr.cpu()
+    vn = orc.OracleValueNet(model.get_all_exit_idx(), HeadAdapter(), cfg.exit_interval, cfg.window_size, "L2")
+    ctl = orc.OracleExitController(vn, model.get_all_exit_idx(), steps_per_stage=1, max_layer=int(g[tag + "_max_layer"]))
+    ctl._set_threshold_value([float(t) for t in g[tag + "_thr"]])
+    for s in range(g["rgb"].shape[0]):
+        ctl.set_timestep(s)
+        o = model(vision_x=g["rgb"][s].cuda(), lang_x=ids, attention_mask=mask, vision_gripper=g["grip"][s].cuda(),
+                  return_feature=True, deterministic=True, exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
+        assert o.exit_layer == int(g[tag + "_exit"][s]), s
+        assert float((o.logits[0].cpu() - g[tag + "_pose"][s]).abs().max()) < TOL
+
+
+def test_forward_argument_errors(setup):
+    cfg, g, model = setup
+    ids, mask = g["ids"].long().cuda(), g["mask"].cuda()
+    with pytest.raises(ValueError):
+        model(vision_x=g["rgb"][0].cuda(), lang_x=ids, attention_mask=mask, vision_gripper=None, exit_id=1)
+    with pytest.raises(NotImplementedError):                       # training branch is out of scope
+        model(vision_x=g["rgb"][0].cuda(), lang_x=ids, attention_mask=mask, vision_gripper=g["grip"][0].cuda())
+    with pytest.raises(AssertionError):                            # mosaic_gpt_3b.py:300
+        model.lang_encoder(ids, mask, exit_controller=lambda h, b: True, exit_id=1)

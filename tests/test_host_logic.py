@@ -70,3 +70,44 @@ def test_synthetic_state_is_order_independent_and_bf16_roundable():
     rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, 3)
     assert ids.shape == (1, 14) and int(ids[0, 0]) == cfg.media_token_id and int(ids[0, -2]) == cfg.eoc_token_id
     assert rgb.shape == (1, 1, 1, 3, cfg.image_size, cfg.image_size)
+
+
+def test_factory_surface_and_state_dict_contract_on_cpu():
+    """create_model_and_transforms keeps the reference signature/return triple; load_state_dict understands the DDP
+    `module.` prefix and the gated_cross_attn_layers alias; forward without a GPU fails loudly."""
+    import inspect
+    import numpy as np
+    import pytest
+    from deer_vla_amd import factory, _abi
+    from deer_vla_amd.flamingo_mpt import MPTFlamingo
+    sig = inspect.signature(factory.create_model_and_transforms)
+    for name in ("clip_vision_encoder_path", "clip_vision_encoder_pretrained", "lang_encoder_path", "tokenizer_path",
+                 "cross_attn_every_n_layers", "use_local_files", "decoder_layers_attr_name", "window_size", "use_gripper",
+                 "fusion_mode", "llm_name", "pooling", "decoder_type", "head_type"):
+        assert name in sig.parameters, name
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 2)
+    model, image_processor, tok = factory.create_model_and_transforms(
+        "ViT-L-14", "openai", "", "", window_size=12, use_gripper=True, fusion_mode="post", llm_name="mpt_dolly_3b",
+        state_dict=sd, cfg=cfg)
+    assert model.module is model and model.get_all_exit_idx() == cfg.exit_ids()
+    assert model.lang_encoder.config.n_layers == cfg.n_layers and model.lang_encoder.config.d_model == cfg.d_model
+    # DeeR ckpt style keys
+    k = "lang_encoder.transformer.blocks.1.gated_cross_attn_layer.attn.to_q.weight"
+    new = torch.full_like(sd[k], 0.25)
+    missing, unexpected = model.load_state_dict({"module.lang_encoder.gated_cross_attn_layers.1.attn.to_q.weight": new,
+                                                 "module.something.else": torch.zeros(1)}, strict=False)
+    assert not missing and unexpected == ["module.something.else"]
+    assert torch.equal(model.state_dict()[k], new)
+    with pytest.raises(RuntimeError):
+        model.load_state_dict({k: torch.zeros(3, 3)}, strict=False)
+    # preprocessing (data.py:898-919): image -> (3,224,224) CLIP-normalised; text -> "<image>{instr}<|endofchunk|>{eos}"
+    x = image_processor(np.full((200, 200, 3), 128, dtype=np.uint8))
+    assert x.shape == (3, cfg.image_size, cfg.image_size) or x.shape == (3, 224, 224)
+    t = tok([f"<image>push the block<|endofchunk|>{tok.eos_token}"], max_length=32, padding="longest", truncation="only_first",
+            return_tensors="pt")
+    ids = t["input_ids"]
+    assert int(ids[0, 0]) == cfg.media_token_id and int(ids[0, -2]) == cfg.eoc_token_id and int(t["attention_mask"].sum()) == ids.shape[1]
+    if not torch.cuda.is_available():
+        with pytest.raises(_abi.DeerHipError):
+            model(torch.zeros(1, 1, 1, 3, 56, 56), ids, t["attention_mask"], vision_gripper=torch.zeros(1, 1, 1, 3, 56, 56), exit_id=1)
