@@ -120,7 +120,6 @@ class MPTFlamingo(nn.Module):
         self._sd: Dict[str, torch.Tensor] = dict(state_dict) if state_dict is not None else {}
         self._engine: Optional[DeerEngine] = None
         # attributes read by the CALVIN harness through `.module` (eval_utils.py:192-247,300-331,456,480)
-        self.module = self
         self.window_size = window_size
         self.use_gripper, self.fusion_mode = use_gripper, fusion_mode
         self.use_state, self.sep_lm_head, self.tcp_rel = False, True, False
@@ -137,6 +136,12 @@ class MPTFlamingo(nn.Module):
         self.extra_exit: Optional[DeterministicDecoder] = None
         self.lm_head = None
         self._ctl_sig = None
+
+    @property
+    def module(self):
+        """DDP-style indirection expected by the harness (eval_utils.py:192-247); a property so that nn.Module does not
+        register the model as its own child."""
+        return self
 
     # ---- engine / weights ------------------------------------------------------------------------------------
     @property
@@ -307,6 +312,8 @@ class MPTFlamingo(nn.Module):
         pose, grip = a[:6].view(1, 1, 6), a[6:7].view(1, 1, 1)
         logits = (pose, (grip, a[7:8].view(1, 1, 1))) if with_gripper_logits else (pose, grip)
         vis = e.vis_x_f32.view(1, 1, cfg.n_media, cfg.vit_width)
+        media_locations = lang_x.reshape(1, -1) == self.media_token_id                      # flamingo_lm.py:211
         for l in self.lang_encoder._get_decoder_layers():
             l.condition_vis_x(vis)                                                          # flamingo_mpt.py:665-666
+            l.condition_media_locations(media_locations)
         return CausalLMOutputWithPast(logits=logits, hidden_states=hidden, exit_layer=exit_layer)
