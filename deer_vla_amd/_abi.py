@@ -24,18 +24,18 @@ SIGNATURES = {
     "deer_skinny_splitk": [I, I, I],
     "deer_pack_weight_mfma16": [P, P, I, I, P],
     "deer_attn_mfma_hd64": [P, P, P, P, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
-    "deer_xattn_small": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, I, F, P, P],
-    "deer_mpt_attn_small": [P, I, L, I, I, P, P, F, P, F, P, P, I, I, I, P, P],
+    "deer_xattn_small": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, I, I, F, P, P],
+    "deer_mpt_attn_small": [P, I, L, I, I, P, P, F, P, F, P, P, I, I, I, I, P, P],
     "deer_layernorm_rows": [P, L, L, I, I, P, P, P, P, L, L, I, F, P],
     "deer_resadd_ln": [P, P, I, L, P, P, P, P, P, P, I, I, F, P, P],
     "deer_vit_im2col": [P, I, I, I, I, P, I, P],
     "deer_vit_embed_lnpre": [P, P, P, P, P, P, I, I, I, F, P],
-    "deer_embed_tokens": [P, P, P, P, I, I, I, I, P],
+    "deer_embed_tokens": [P, P, P, P, I, I, I, I, I, P],
     "deer_broadcast_rows": [P, P, L, I, P],
-    "deer_head_lstm_layer": [P, I, I, I, P, P, P, P, P, P, P, P, P, P, I, F, P, I, I, P],
-    "deer_head_fc": [P, I, I, P, P, P, P, P, P, P, P, I, P, F, P, I, I, P],
-    "deer_head_final": [P, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, P, F, P],
-    "deer_ctl_begin_step": [P, P, P],
+    "deer_head_lstm_layer": [P, L, I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, P, I, I, P],
+    "deer_head_fc": [P, I, I, I, P, P, P, P, P, P, P, P, I, P, I, F, P, I, I, P],
+    "deer_head_final": [P, I, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, I, I, P, F, P],
+    "deer_ctl_begin_step": [P, P, I, P],
     "deer_spin_us": [I, P],
     "deer_hip_arch": [],
     "deer_hip_abi_version": [],
@@ -43,7 +43,7 @@ SIGNATURES = {
 _RESTYPE = {"deer_hip_arch": c_char_p}
 
 # constants of include/deer_hip.h
-CTL_EXIT_FLAG, CTL_EXIT_LAYER, CTL_CUR_EXIT_ID, CTL_HOLD, CTL_N_EVALS, CTL_SHADOW, CTL_COMMITTED = 0, 1, 2, 3, 4, 5, 6
+CTL_EXIT_FLAG, CTL_EXIT_LAYER, CTL_CUR_EXIT_ID, CTL_HOLD, CTL_N_EVALS, CTL_SHADOW, CTL_COMMITTED, CTL_ALL_EXITED = 0, 1, 2, 3, 4, 5, 6, 7
 CTL_PREV_ACTION, CTL_OUT_ACTION, CTL_DELTAS, CTL_WORDS = 8, 16, 24, 64
 EPI_BF16, EPI_F32, EPI_QGELU_BF16, EPI_GELU_BF16, EPI_RESADD_F32 = 0, 1, 2, 3, 4
 A_BF16, A_SLABS_GELU, A_SLABS, A_F32 = 0, 1, 2, 3
@@ -80,6 +80,9 @@ def lib() -> ctypes.CDLL:
         raise DeerHipError(
             f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc, gfx950).  deer_vla_amd has no CPU fallback.")
+    # torch bundles its own libamdhip64; it must be loaded FIRST so that this library binds to the same HIP runtime
+    # (two runtimes in one process = streams/pointers of one are invalid in the other -> launch errors)
+    import torch  # noqa: F401
     try:
         l = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # missing libamdhip64 etc.

@@ -34,7 +34,7 @@ class DeterministicDecoder:
         e = self.engine
         if not bool(e.h_state.any()) and not bool(e.c_state.any()):
             return None
-        return (e.h_state.unsqueeze(1).clone(), e.c_state.unsqueeze(1).clone())
+        return (e.h_state.clone(), e.c_state.clone())           # (L, 1, H) like the reference (action_head.py:61-63)
 
     @hidden_state.setter
     def hidden_state(self, value):
@@ -68,7 +68,7 @@ class DeterministicDecoder:
         self.history_memory.append(None)                      # the reference appends the pooled feature (unbounded leak)
         e.enqueue_head(0, T, abi.KIND_COMMIT, use_ctl=False, feats=feats, no_ctl_final=True)
         torch.cuda.current_stream().synchronize()
-        a = e.action_dbg.clone()
+        a = e.action_dbg[0].clone()
         if update_hidden_state:
             e.h_state.copy_(e.h_tmp)
             e.c_state.copy_(e.c_tmp)

@@ -188,6 +188,12 @@ __global__ __launch_bounds__(256) void xattn_small_kernel(const float* __restric
   __shared__ bf16_t ks[XA_MAXKV][64 + 2];
   __shared__ bf16_t vs[XA_MAXKV][64 + 2];
   const int h = blockIdx.x, tid = threadIdx.x;
+  // environment blockIdx.y: its T query rows, its n_kv media rows, its text_time entries
+  qslab += (long)blockIdx.y * T * ldqs;
+  kv += (long)blockIdx.y * n_kv * ldkv;
+  text_time += blockIdx.y * T;
+  out = out_is_f32 ? (void*)(reinterpret_cast<float*>(out) + (long)blockIdx.y * T * ldo)
+                   : (void*)(reinterpret_cast<bf16_t*>(out) + (long)blockIdx.y * T * ldo);
   for (int idx = tid; idx < T * 64; idx += 256) {
     const int t = idx >> 6, d = idx & 63;
     float a = 0.f;
@@ -238,9 +244,9 @@ __global__ __launch_bounds__(256) void xattn_small_kernel(const float* __restric
 
 extern "C" int deer_xattn_small(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv,
                                 int inner, const int* text_time, int n_per_media, void* out, int out_is_f32, int ldo, int T,
-                                int n_kv, int heads, float scale, const int* ctl, void* stream) {
-  if (T <= 0 || T > XA_MAXT || n_kv <= 0 || n_kv > XA_MAXKV || s_in <= 0 || n_per_media <= 0) return DEER_ERR_SHAPE;
-  hipLaunchKernelGGL(xattn_small_kernel, dim3(heads), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qslab, s_in,
+                                int n_kv, int heads, int batch, float scale, const int* ctl, void* stream) {
+  if (T <= 0 || T > XA_MAXT || n_kv <= 0 || n_kv > XA_MAXKV || s_in <= 0 || n_per_media <= 0 || batch <= 0) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(xattn_small_kernel, dim3(heads, batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qslab, s_in,
                      slab_stride, ldqs, reinterpret_cast<const bf16_t*>(kv), ldkv, inner, text_time, n_per_media, out,
                      out_is_f32, ldo, T, n_kv, scale, ctl);
   DEER_LAUNCH_CHECK();
@@ -321,6 +327,10 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
   __shared__ float sim[MA_MAXT][MA_MAXT + 1];
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * d_model;
+  qkv += (long)blockIdx.y * T * ld;                        // environment blockIdx.y
+  if (key_mask != nullptr) key_mask += blockIdx.y * T;
+  out = out_is_f32 ? (void*)(reinterpret_cast<float*>(out) + (long)blockIdx.y * T * ldo)
+                   : (void*)(reinterpret_cast<bf16_t*>(out) + (long)blockIdx.y * T * ldo);
   for (int idx = tid; idx < T * hd; idx += 256) {
     const int t = idx / hd, d = idx - t * hd;
     const float* p = qkv + (long)t * ld + h * hd + d;
@@ -360,17 +370,17 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
 // qkv_ws: f32 [T, 3*d_model] workspace holding the reduced (and q/k-normalised) qkv.
 extern "C" int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads,
                                    const float* q_ln_w, const float* k_ln_w, float eps, const unsigned char* key_mask,
-                                   float alibi_bias_max, float* qkv_ws, void* out, int out_is_f32, int ldo, int T,
+                                   float alibi_bias_max, float* qkv_ws, void* out, int out_is_f32, int ldo, int T, int batch,
                                    const int* ctl, void* stream) {
   const int hd = d_model / n_heads;
   if (T <= 0 || T > MA_MAXT || hd > 128 || hd * n_heads != d_model || s_in <= 0 || (d_model & 3) || d_model > 4096 ||
-      qkv_ws == nullptr)
+      qkv_ws == nullptr || batch <= 0)
     return DEER_ERR_SHAPE;
   if ((q_ln_w == nullptr) != (k_ln_w == nullptr)) return DEER_ERR_SHAPE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(qkv_reduce_ln_kernel, dim3(T, 3), dim3(256), 0, st, qkvslab, s_in, slab_stride, d_model, q_ln_w, k_ln_w,
+  hipLaunchKernelGGL(qkv_reduce_ln_kernel, dim3(T * batch, 3), dim3(256), 0, st, qkvslab, s_in, slab_stride, d_model, q_ln_w, k_ln_w,
                      eps, qkv_ws, ctl);
-  hipLaunchKernelGGL(mpt_attn_small_kernel, dim3(n_heads), dim3(256), 0, st, qkv_ws, d_model, hd, key_mask, alibi_bias_max,
+  hipLaunchKernelGGL(mpt_attn_small_kernel, dim3(n_heads, batch), dim3(256), 0, st, qkv_ws, d_model, hd, key_mask, alibi_bias_max,
                      n_heads, out, out_is_f32, ldo, T, ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;

@@ -14,8 +14,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define DEER_ERR_SHAPE 1
 #define DEER_ERR_LAUNCH 2
 
-// Device-side control block shared by the LLM-layer kernels and the action-head kernels
-// (int32 words; see include/deer_hip.h for the ABI view).
+// Device-side control blocks shared by the LLM-layer kernels and the action-head kernels (int32 words; see
+// include/deer_hip.h for the ABI view).  One block of CTL_WORDS per environment of the batch, env b at ctl + b*CTL_WORDS;
+// HOLD, SHADOW and ALL_EXITED are batch-global and live in block 0.
 #define CTL_EXIT_FLAG 0     // 1 once the exit criterion fired in this step -> later kernels return at entry
 #define CTL_EXIT_LAYER 1    // layer index the step exited at
 #define CTL_CUR_EXIT_ID 2   // ExitController.cur_exit_id (value_net.py:285-286,294)
@@ -23,6 +24,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CTL_N_EVALS 4       // number of head evaluations executed this step (diagnostics)
 #define CTL_SHADOW 5        // calibration mode: evaluate EVERY exit, commit at the first that fires, never stop
 #define CTL_COMMITTED 6     // shadow mode: a commit already happened in this step
+#define CTL_ALL_EXITED 7    // (block 0 only) 1 once EVERY environment of the batch has exited -> later kernels return at entry
 #define CTL_PREV_ACTION 8   // float[8]: action_list[-1] (pose6, gripper, pad)
 #define CTL_OUT_ACTION 16   // float[8]: committed action (pose6, gripper prob, gripper logit)
 #define CTL_DELTAS 24       // float[16]: delta per exit slot of this step (NaN = not evaluated)
@@ -83,7 +85,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // termination: no host round trip per layer).
 #define DEER_RETURN_IF_EXITED(ctl) \
   do {                             \
-    if ((ctl) != nullptr && ((const volatile int*)(ctl))[CTL_EXIT_FLAG] != 0) return; \
+    if ((ctl) != nullptr && ((const volatile int*)(ctl))[CTL_ALL_EXITED] != 0) return; \
   } while (0)
 
 #define DEER_LAUNCH_CHECK()                                   \

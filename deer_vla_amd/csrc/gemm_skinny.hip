@@ -1,4 +1,4 @@
-// Skinny (M <= 32 rows) bf16 MFMA GEMM for the weight-bandwidth-bound part of the step: the MPT blocks
+// Skinny (M <= 64 rows) bf16 MFMA GEMM for the weight-bandwidth-bound part of the step: the MPT blocks
 // and gated x-attn layers at T ~ 14 text tokens (174 MB of weights per layer for 2.7 GFLOP).
 //
 //   part[ks][m][n] = sum_{k in K-slice ks} A[m,k] * W[n,k]          (f32 partial slabs, split-K)
@@ -160,8 +160,8 @@ extern "C" int deer_pack_weight_mfma16(const void* W, void* Wp, int N, int K, vo
 // Suggested split-K for a skinny GEMM: enough workgroups to cover the chip (~2 per CU) while each wave
 // still streams >= 8 KiB, and an LDS slice (hi + lo) <= 33 KiB.  Deterministic function of the shape.
 extern "C" int deer_skinny_splitk(int M, int N, int K) {
-  const int mt = (M > 16) ? 2 : 1;
-  const int max_ks = 512 / mt;
+  const int mt = (M > 32) ? 4 : ((M > 16) ? 2 : 1);
+  const int max_ks = (mt == 4) ? 256 : 512 / mt;
   const int groups = (N + 63) / 64;
   int s = 1;
   while ((K / s) > max_ks && (K % (s * 2 * 32)) == 0) s *= 2;
@@ -172,25 +172,32 @@ extern "C" int deer_skinny_splitk(int M, int N, int K) {
 extern "C" int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int s_in, long slab_stride_in, int a_mode,
                                 const void* Wp, float* part, int M, int N, int K, int splitk, const int* ctl,
                                 void* stream) {
-  if (M <= 0 || M > 32 || N <= 0 || (N & 15) || K <= 0 || (K & 31) || splitk <= 0 || (K % (splitk * 32)) != 0)
+  if (M <= 0 || M > 64 || N <= 0 || (N & 15) || K <= 0 || (K & 31) || splitk <= 0 || (K % (splitk * 32)) != 0)
     return DEER_ERR_SHAPE;
   if (a_mode < 0 || a_mode > 3) return DEER_ERR_SHAPE;
   if (a_mode == A_BF16 && (A == nullptr || (lda & 7))) return DEER_ERR_SHAPE;
   if (a_mode == A_F32 && (A == nullptr || (lda & 3))) return DEER_ERR_SHAPE;
   if ((a_mode == A_SLABS || a_mode == A_SLABS_GELU) && (Aslab == nullptr || s_in <= 0)) return DEER_ERR_SHAPE;
   const int KS = K / splitk;
-  const int mt = (M > 16) ? 2 : 1;
+  const int mt = (M > 32) ? 4 : ((M > 16) ? 2 : 1);
   const bool split = (a_mode != A_BF16);
   const int smem = (split ? 2 : 1) * mt * 16 * (KS + 8) * (int)sizeof(bf16_t);
-  if (smem > 64 * 1024) return DEER_ERR_SHAPE;
+  if (smem > 72 * 1024) return DEER_ERR_SHAPE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    attr_set = true;
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((N + 63) / 64, splitk);
   const bf16_t* wp = reinterpret_cast<const bf16_t*>(Wp);
 #define DEER_SK_LAUNCH(MT_, SP_)                                                                                      \
   hipLaunchKernelGGL((gemm_skinny_kernel<MT_, SP_>), grid, dim3(256), smem, st, A, lda, Aslab, s_in, slab_stride_in,  \
                      a_mode, wp, part, M, N, K, KS, ctl)
-  if (mt == 1) { if (split) DEER_SK_LAUNCH(1, true); else DEER_SK_LAUNCH(1, false); }
-  else         { if (split) DEER_SK_LAUNCH(2, true); else DEER_SK_LAUNCH(2, false); }
+  if (mt == 1)      { if (split) DEER_SK_LAUNCH(1, true); else DEER_SK_LAUNCH(1, false); }
+  else if (mt == 2) { if (split) DEER_SK_LAUNCH(2, true); else DEER_SK_LAUNCH(2, false); }
+  else              { if (split) DEER_SK_LAUNCH(4, true); else DEER_SK_LAUNCH(4, false); }
 #undef DEER_SK_LAUNCH
   DEER_LAUNCH_CHECK();
   return DEER_OK;

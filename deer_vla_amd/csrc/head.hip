@@ -1,30 +1,42 @@
 // Action head + exit gate of DeeR-VLA as device-side kernels (robot_flamingo/models/action_head.py:408-611,
-// robot_flamingo/models/value_net.py:105-133,277-297).
+// robot_flamingo/models/value_net.py:105-133,277-297), for a BATCH of B independent environments per launch.
 //
 // One head evaluation = max-pool over tokens -> 4 x (LSTM cell [-> LayerNorm]) -> 2 MLP heads -> (pose6 tanh,
 // gripper sigmoid) -> delta vs. the previous exit's action -> compare with the exit threshold.  The decision
-// is taken ON THE DEVICE: head_final_kernel sets ctl[EXIT_FLAG]/ctl[EXIT_LAYER] and commits the LSTM state;
-// every later kernel of the step (LLM layers and head evaluations) returns at entry.  The host reads
-// {exit_layer, action} once per step - there is no host round trip per exit check (the reference syncs on
-// `bool(value <= thr)` at every exit, value_net.py:293).
+// is taken ON THE DEVICE, per environment: head_final_kernel sets that environment's ctl[EXIT_FLAG]/ctl[EXIT_LAYER]
+// and commits its LSTM state; once every environment of the batch has exited it sets ctl[ALL_EXITED] and every
+// later kernel of the step (LLM layers and head evaluations) returns at entry.  The host reads {exit_layer, action}
+// once per step - there is no host round trip per exit check (the reference syncs on `bool(value <= thr)` at every
+// exit, value_net.py:293).
+//
+// Batching: the B environments share every weight read (an M=B GEMV instead of B M=1 GEMVs): each wave loads its weight
+// rows once and keeps B accumulators.  Environments that already exited are still carried through the arithmetic (the
+// weight stream is what costs) but their control block, committed action and LSTM state are left untouched.
 //
 // Numerics: weights bf16 (streamed from HBM / Infinity Cache), activations, LSTM state, LayerNorm statistics
 // and the delta in fp32, so the exit decision differs from an fp32 reference only by summation order.
-// GEMVs are M=1: one wave per output row-group, 16-byte coalesced weight loads, wave shuffle reduction.
 #include "common.h"
+
+#define HB_MAX 8   // max environments per batch
 
 enum { X_RAW = 0, X_POOL_MAX = 1, X_POOL_AVG = 2, X_LN = 3 };
 enum { PRO_RAW = 0, PRO_LN = 1, PRO_GROUP_LN_RELU = 2, PRO_GROUP_RELU = 3 };
 enum { KIND_PSEUDO = 0, KIND_CHECK = 1, KIND_COMMIT = 2 };
 enum { THR_L2 = 0, THR_MEAN = 1, THR_MAX = 2, THR_COSINE = 3 };
 
-__device__ __forceinline__ bool head_skip(const int* ctl, int kind, int layer) {
+// Whole-launch skip: every environment exited, or (stage hold, value_net.py:285-286) nobody needs this evaluation.
+__device__ __forceinline__ bool head_skip(const int* ctl, int kind, int layer, int B) {
   if (ctl == nullptr) return false;
   const volatile int* c = ctl;
-  if (c[CTL_EXIT_FLAG] != 0) return true;
-  if (c[CTL_HOLD] != 0) {                         // value_net.py:285-286: reuse cur_exit_id, no value_net call
+  if (c[CTL_ALL_EXITED] != 0) return true;
+  if (c[CTL_HOLD] != 0) {
     if (kind == KIND_PSEUDO) return true;
-    if (kind == KIND_CHECK && layer < c[CTL_CUR_EXIT_ID]) return true;
+    if (kind == KIND_CHECK) {
+      bool any = false;
+      for (int b = 0; b < B; ++b)
+        any = any || (c[b * CTL_WORDS + CTL_EXIT_FLAG] == 0 && layer >= c[b * CTL_WORDS + CTL_CUR_EXIT_ID]);
+      if (!any) return true;
+    }
   }
   return false;
 }
@@ -58,111 +70,143 @@ __device__ __forceinline__ void block_ln(const float* __restrict__ src, float* d
   }
 }
 
-// ---- one LSTM layer, single time step (torch.nn.LSTM gate order i,f,g,o) -------------------------------
+// ---- one LSTM layer, single time step (torch.nn.LSTM gate order i,f,g,o), B environments -------------------------
 // wave -> hidden unit j: rows j, H+j, 2H+j, 3H+j of [W_ih | W_hh]; c' = s(f) c + s(i) tanh(g); h' = s(o) tanh(c').
-__global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __restrict__ x_src, int x_mode, int T, int in_dim,
-                                                              const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                                              const bf16_t* __restrict__ w_ih, const bf16_t* __restrict__ w_hh,
-                                                              const float* __restrict__ b_ih, const float* __restrict__ b_hh,
-                                                              const float* __restrict__ h_prev, const float* __restrict__ c_prev,
-                                                              float* __restrict__ h_out, float* __restrict__ c_out, int H,
-                                                              float eps, const int* ctl, int kind, int layer) {
-  if (head_skip(ctl, kind, layer)) return;
+// x_src: X_POOL_*: feats [B][T_stride rows][in_dim] (env b at x_src + b*x_bstride), pooled over the first T rows;
+//        X_LN / X_RAW: [B][in_dim] (previous layer's h of each env, x_bstride = in_dim).  State tensors are [B][H].
+__global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __restrict__ x_src, long x_bstride, int x_mode, int T,
+                                                              int in_dim, const float* __restrict__ ln_w,
+                                                              const float* __restrict__ ln_b, const bf16_t* __restrict__ w_ih,
+                                                              const bf16_t* __restrict__ w_hh, const float* __restrict__ b_ih,
+                                                              const float* __restrict__ b_hh, const float* __restrict__ h_prev,
+                                                              const float* __restrict__ c_prev, float* __restrict__ h_out,
+                                                              float* __restrict__ c_out, int H, int B, float eps, const int* ctl,
+                                                              int kind, int layer) {
+  if (head_skip(ctl, kind, layer, B)) return;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xs = lds;               // [in_dim]
-  float* hs = lds + in_dim;      // [H]
-  float* red = hs + H;           // [16]
-  if (x_mode == X_LN) {
-    block_ln(x_src, xs, in_dim, ln_w, ln_b, eps, false, red);
-  } else if (x_mode == X_RAW) {
-    for (int i = threadIdx.x; i < in_dim; i += 256) xs[i] = x_src[i];
-  } else {
-    for (int i = threadIdx.x; i < in_dim; i += 256) {
-      float a = x_src[i];
-      if (x_mode == X_POOL_MAX) {
-        for (int t = 1; t < T; ++t) a = fmaxf(a, x_src[(long)t * in_dim + i]);
-      } else {
-        for (int t = 1; t < T; ++t) a += x_src[(long)t * in_dim + i];
-        a /= (float)T;
+  float* xs = lds;                    // [B][in_dim]
+  float* hs = lds + B * in_dim;       // [B][H]
+  float* red = hs + B * H;            // [16]
+  for (int b = 0; b < B; ++b) {
+    const float* xb = x_src + b * x_bstride;
+    float* xd = xs + b * in_dim;
+    if (x_mode == X_LN) {
+      block_ln(xb, xd, in_dim, ln_w, ln_b, eps, false, red);
+    } else if (x_mode == X_RAW) {
+      for (int i = threadIdx.x; i < in_dim; i += 256) xd[i] = xb[i];
+    } else {
+      for (int i = threadIdx.x; i < in_dim; i += 256) {
+        float a = xb[i];
+        if (x_mode == X_POOL_MAX) {
+          for (int t = 1; t < T; ++t) a = fmaxf(a, xb[(long)t * in_dim + i]);
+        } else {
+          for (int t = 1; t < T; ++t) a += xb[(long)t * in_dim + i];
+          a /= (float)T;
+        }
+        xd[i] = a;
       }
-      xs[i] = a;
     }
   }
-  for (int i = threadIdx.x; i < H; i += 256) hs[i] = h_prev[i];
+  for (int i = threadIdx.x; i < B * H; i += 256) hs[i] = h_prev[i];
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 4 + wave;
   if (j >= H) return;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float acc[4][HB_MAX];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b = 0; b < HB_MAX; ++b) acc[q][b] = 0.f;
   for (int k = lane * 8; k < in_dim; k += 512) {
     uint4 w[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const uint4*>(w_ih + ((long)q * H + j) * in_dim + k);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] += dot8(w[q], xs + k);
+    for (int b = 0; b < HB_MAX; ++b)
+      if (b < B) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q][b] += dot8(w[q], xs + b * in_dim + k);
+      }
   }
   for (int k = lane * 8; k < H; k += 512) {
     uint4 w[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const uint4*>(w_hh + ((long)q * H + j) * H + k);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] += dot8(w[q], hs + k);
+    for (int b = 0; b < HB_MAX; ++b)
+      if (b < B) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q][b] += dot8(w[q], hs + b * H + k);
+      }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = wave_sum(acc[q]);
-  if (lane == 0) {
-    const float gi = acc[0] + b_ih[j] + b_hh[j];
-    const float gf = acc[1] + b_ih[H + j] + b_hh[H + j];
-    const float gg = acc[2] + b_ih[2 * H + j] + b_hh[2 * H + j];
-    const float go = acc[3] + b_ih[3 * H + j] + b_hh[3 * H + j];
-    const float c2 = sigmoidf_(gf) * c_prev[j] + sigmoidf_(gi) * tanhf(gg);
-    c_out[j] = c2;
-    h_out[j] = sigmoidf_(go) * tanhf(c2);
-  }
+  for (int b = 0; b < HB_MAX; ++b)
+    if (b < B) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q][b] = wave_sum(acc[q][b]);
+      if (lane == 0) {
+        const float gi = acc[0][b] + b_ih[j] + b_hh[j];
+        const float gf = acc[1][b] + b_ih[H + j] + b_hh[H + j];
+        const float gg = acc[2][b] + b_ih[2 * H + j] + b_hh[2 * H + j];
+        const float go = acc[3][b] + b_ih[3 * H + j] + b_hh[3 * H + j];
+        const float c2 = sigmoidf_(gf) * c_prev[b * H + j] + sigmoidf_(gi) * tanhf(gg);
+        c_out[b * H + j] = c2;
+        h_out[b * H + j] = sigmoidf_(go) * tanhf(c2);
+      }
+    }
 }
 
-extern "C" int deer_head_lstm_layer(const float* x_src, int x_mode, int T, int in_dim, const float* ln_w, const float* ln_b,
-                                    const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh,
-                                    const float* h_prev, const float* c_prev, float* h_out, float* c_out, int H, float eps,
+extern "C" int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w,
+                                    const float* ln_b, const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh,
+                                    const float* h_prev, const float* c_prev, float* h_out, float* c_out, int H, int B, float eps,
                                     const int* ctl, int kind, int layer, void* stream) {
   if (in_dim <= 0 || (in_dim & 7) || H <= 0 || (H & 7) || x_mode < 0 || x_mode > 3 || (x_mode == X_LN && ln_w == nullptr) ||
-      ((x_mode == X_POOL_MAX || x_mode == X_POOL_AVG) && T <= 0))
+      ((x_mode == X_POOL_MAX || x_mode == X_POOL_AVG) && T <= 0) || B <= 0 || B > HB_MAX)
     return DEER_ERR_SHAPE;
-  const int smem = (in_dim + H + 16) * (int)sizeof(float);
-  if (smem > 64 * 1024) return DEER_ERR_SHAPE;
+  const int smem = (B * (in_dim + H) + 16) * (int)sizeof(float);
+  if (smem > 150 * 1024) return DEER_ERR_SHAPE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&head_lstm_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            150 * 1024) != hipSuccess)
+      return DEER_ERR_LAUNCH;
+    attr_set = true;
+  }
   hipLaunchKernelGGL(head_lstm_layer_kernel, dim3((H + 3) / 4), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), x_src,
-                     x_mode, T, in_dim, ln_w, ln_b, reinterpret_cast<const bf16_t*>(w_ih),
-                     reinterpret_cast<const bf16_t*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, eps, ctl, kind, layer);
+                     x_bstride, x_mode, T, in_dim, ln_w, ln_b, reinterpret_cast<const bf16_t*>(w_ih),
+                     reinterpret_cast<const bf16_t*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, eps, ctl, kind, layer);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
 
-// ---- hidden Linear of both MLP heads: dst[g*out_dim + n] = W_g[n,:] . pro(src)_g + b_g[n] --------------
-// pro: PRO_LN           x = LN(src[0..in))          (shared: LSTM output LayerNorm, action_head.py:55-56)
-//      PRO_RAW          x = src[0..in)              (plain nn.LSTM)
-//      PRO_GROUP_LN_RELU x_g = relu(LN_g(src[g*in..]))   (Linear -> LN -> ReLU, action_head.py:97-103)
-//      PRO_GROUP_RELU   x_g = relu(src[g*in..])
-__global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ src, int in_dim, int pro,
+// ---- hidden Linear of both MLP heads: dst[b][g*out_dim + n] = W_g[n,:] . pro(src_b)_g + b_g[n] -------------------
+// src: [B][src_stride]; pro: PRO_LN   x = LN(src_b[0..in))  (shared: LSTM output LayerNorm, action_head.py:55-56)
+//      PRO_RAW x = src_b[0..in) (plain nn.LSTM); PRO_GROUP_LN_RELU x_g = relu(LN_g(src_b[g*in..])) (Linear -> LN -> ReLU,
+//      action_head.py:97-103); PRO_GROUP_RELU x_g = relu(src_b[g*in..]).   dst: [B][2*out_dim].
+__global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ src, int src_stride, int in_dim, int pro,
                                                       const float* __restrict__ lnw0, const float* __restrict__ lnb0,
                                                       const float* __restrict__ lnw1, const float* __restrict__ lnb1,
                                                       const bf16_t* __restrict__ W0, const float* __restrict__ b0,
-                                                      const bf16_t* __restrict__ W1, const float* __restrict__ b1,
-                                                      int out_dim, float* __restrict__ dst, float eps, const int* ctl,
-                                                      int kind, int layer) {
-  if (head_skip(ctl, kind, layer)) return;
+                                                      const bf16_t* __restrict__ W1, const float* __restrict__ b1, int out_dim,
+                                                      float* __restrict__ dst, int B, float eps, const int* ctl, int kind,
+                                                      int layer) {
+  if (head_skip(ctl, kind, layer, B)) return;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xs = lds;
-  float* red = lds + in_dim;
+  float* xs = lds;                     // [B][in_dim]
+  float* red = lds + B * in_dim;
   const int grp = blockIdx.y;
   const bool grouped = (pro == PRO_GROUP_LN_RELU || pro == PRO_GROUP_RELU);
-  const float* s = src + (grouped ? (long)grp * in_dim : 0);
-  if (pro == PRO_LN) {
-    block_ln(s, xs, in_dim, lnw0, lnb0, eps, false, red);
-  } else if (pro == PRO_GROUP_LN_RELU) {
-    block_ln(s, xs, in_dim, grp ? lnw1 : lnw0, grp ? lnb1 : lnb0, eps, true, red);
-  } else {
-    for (int i = threadIdx.x; i < in_dim; i += 256) xs[i] = (pro == PRO_GROUP_RELU) ? fmaxf(s[i], 0.f) : s[i];
+  for (int b = 0; b < B; ++b) {
+    const float* s = src + (long)b * src_stride + (grouped ? (long)grp * in_dim : 0);
+    float* xd = xs + b * in_dim;
+    if (pro == PRO_LN) {
+      block_ln(s, xd, in_dim, lnw0, lnb0, eps, false, red);
+    } else if (pro == PRO_GROUP_LN_RELU) {
+      block_ln(s, xd, in_dim, grp ? lnw1 : lnw0, grp ? lnb1 : lnb0, eps, true, red);
+    } else {
+      for (int i = threadIdx.x; i < in_dim; i += 256) xd[i] = (pro == PRO_GROUP_RELU) ? fmaxf(s[i], 0.f) : s[i];
+    }
   }
   __syncthreads();
   const bf16_t* W = grp ? W1 : W0;
@@ -171,46 +215,65 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
   const int n0 = (blockIdx.x * 4 + wave) * 2;
   if (n0 >= out_dim) return;
   const bool two = (n0 + 1 < out_dim);
-  float a0 = 0.f, a1 = 0.f;
+  float a0[HB_MAX], a1[HB_MAX];
+#pragma unroll
+  for (int b = 0; b < HB_MAX; ++b) a0[b] = a1[b] = 0.f;
   for (int k = lane * 8; k < in_dim; k += 512) {
     const uint4 w0 = *reinterpret_cast<const uint4*>(W + (long)n0 * in_dim + k);
     const uint4 w1 = two ? *reinterpret_cast<const uint4*>(W + (long)(n0 + 1) * in_dim + k) : uint4{0, 0, 0, 0};
-    a0 += dot8(w0, xs + k);
-    a1 += dot8(w1, xs + k);
+#pragma unroll
+    for (int b = 0; b < HB_MAX; ++b)
+      if (b < B) {
+        a0[b] += dot8(w0, xs + b * in_dim + k);
+        a1[b] += dot8(w1, xs + b * in_dim + k);
+      }
   }
-  a0 = wave_sum(a0);
-  a1 = wave_sum(a1);
-  if (lane == 0) {
-    dst[(long)grp * out_dim + n0] = a0 + bb[n0];
-    if (two) dst[(long)grp * out_dim + n0 + 1] = a1 + bb[n0 + 1];
-  }
+#pragma unroll
+  for (int b = 0; b < HB_MAX; ++b)
+    if (b < B) {
+      const float s0 = wave_sum(a0[b]), s1 = wave_sum(a1[b]);
+      if (lane == 0) {
+        dst[(long)b * 2 * out_dim + (long)grp * out_dim + n0] = s0 + bb[n0];
+        if (two) dst[(long)b * 2 * out_dim + (long)grp * out_dim + n0 + 1] = s1 + bb[n0 + 1];
+      }
+    }
 }
 
-extern "C" int deer_head_fc(const float* src, int in_dim, int pro, const float* lnw0, const float* lnb0, const float* lnw1,
-                            const float* lnb1, const void* W0, const float* b0, const void* W1, const float* b1, int out_dim,
-                            float* dst, float eps, const int* ctl, int kind, int layer, void* stream) {
-  if (in_dim <= 0 || (in_dim & 7) || out_dim <= 0 || pro < 0 || pro > 3) return DEER_ERR_SHAPE;
-  const int smem = (in_dim + 16) * (int)sizeof(float);
+extern "C" int deer_head_fc(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0,
+                            const float* lnw1, const float* lnb1, const void* W0, const float* b0, const void* W1, const float* b1,
+                            int out_dim, float* dst, int B, float eps, const int* ctl, int kind, int layer, void* stream) {
+  if (in_dim <= 0 || (in_dim & 7) || out_dim <= 0 || pro < 0 || pro > 3 || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
+  const int smem = (B * in_dim + 16) * (int)sizeof(float);
+  if (smem > 64 * 1024) return DEER_ERR_SHAPE;
   dim3 grid((out_dim + 7) / 8, 2);
-  hipLaunchKernelGGL(head_fc_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), src, in_dim, pro, lnw0, lnb0,
-                     lnw1, lnb1, reinterpret_cast<const bf16_t*>(W0), b0, reinterpret_cast<const bf16_t*>(W1), b1, out_dim, dst,
-                     eps, ctl, kind, layer);
+  hipLaunchKernelGGL(head_fc_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), src, src_stride, in_dim, pro, lnw0,
+                     lnb0, lnw1, lnb1, reinterpret_cast<const bf16_t*>(W0), b0, reinterpret_cast<const bf16_t*>(W1), b1, out_dim, dst,
+                     B, eps, ctl, kind, layer);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
 
-// ---- output Linear (6 tanh + 1 sigmoid) + exit gate ------------------------------------------------------
-__global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict__ src, int in_dim, int pro,
+// ---- output Linear (6 tanh + 1 sigmoid) + exit gate, per environment ----------------------------------------------
+// One workgroup per environment.  src: [B][src_stride] (the last hidden Linear's output, [2][in_dim] per env).
+// ctl: env b at ctl + b*CTL_WORDS.  State tensors h/c: [L][B][H] (LH = L, sH = H).  action_dbg: [B][8] or NULL.
+__global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict__ src, int src_stride, int in_dim, int pro,
                                                          const float* __restrict__ lnw0, const float* __restrict__ lnb0,
                                                          const float* __restrict__ lnw1, const float* __restrict__ lnb1,
                                                          const bf16_t* __restrict__ Wa, const float* __restrict__ ba,
-                                                         const bf16_t* __restrict__ Wg, const float* __restrict__ bg, int* ctl,
+                                                         const bf16_t* __restrict__ Wg, const float* __restrict__ bg, int* ctl0,
                                                          int kind, int layer, int slot, const float* __restrict__ thresholds,
                                                          int force, int thr_type, int leq, const float* __restrict__ h_tmp,
                                                          const float* __restrict__ c_tmp, float* __restrict__ h_state,
-                                                         float* __restrict__ c_state, int LH, float* __restrict__ action_dbg,
-                                                         float eps) {
-  if (head_skip(ctl, kind, layer)) return;
+                                                         float* __restrict__ c_state, int L, int H, int B,
+                                                         float* __restrict__ action_dbg, float eps) {
+  if (head_skip(ctl0, kind, layer, B)) return;
+  const int b = blockIdx.x;
+  int* ctl = (ctl0 != nullptr) ? ctl0 + b * CTL_WORDS : nullptr;
+  if (ctl != nullptr) {
+    // this environment already exited in this step, or (stage hold) does not need this evaluation
+    if (ctl[CTL_EXIT_FLAG] != 0) return;
+    if (ctl0[CTL_HOLD] != 0 && (kind == KIND_PSEUDO || (kind == KIND_CHECK && layer < ctl[CTL_CUR_EXIT_ID]))) return;
+  }
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xa = lds;                    // actions-head input [in_dim]
   float* xg = lds + in_dim;           // gripper-head input [in_dim]
@@ -218,14 +281,13 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
   float* outv = red + 16;             // [8]
   int* flag = reinterpret_cast<int*>(outv + 8);
   const bool grouped = (pro == PRO_GROUP_LN_RELU || pro == PRO_GROUP_RELU);
-  const float* s0 = src;
-  const float* s1 = src + (grouped ? in_dim : 0);
+  const float* s0 = src + (long)b * src_stride;
+  const float* s1 = s0 + (grouped ? in_dim : 0);
   if (pro == PRO_GROUP_LN_RELU) {
     block_ln(s0, xa, in_dim, lnw0, lnb0, eps, true, red);
     block_ln(s1, xg, in_dim, lnw1, lnb1, eps, true, red);
   } else if (pro == PRO_LN) {
     block_ln(s0, xa, in_dim, lnw0, lnb0, eps, false, red);
-    for (int i = threadIdx.x; i < in_dim; i += blockDim.x) xg[i] = 0.f;
     __syncthreads();
     for (int i = threadIdx.x; i < in_dim; i += blockDim.x) xg[i] = xa[i];
   } else {
@@ -252,13 +314,13 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
     cur[6] = sigmoidf_(outv[6]);
     cur[7] = outv[6];                                  // gripper logit (MLPSigmoidHead with_logits)
     if (action_dbg != nullptr)
-      for (int i = 0; i < 8; ++i) action_dbg[i] = cur[i];
+      for (int i = 0; i < 8; ++i) action_dbg[b * 8 + i] = cur[i];
     bool commit = false;
     if (ctl != nullptr) {
       float* prev = reinterpret_cast<float*>(ctl + CTL_PREV_ACTION);
       float* outa = reinterpret_cast<float*>(ctl + CTL_OUT_ACTION);
       float* deltas = reinterpret_cast<float*>(ctl + CTL_DELTAS);
-      const bool hold = ctl[CTL_HOLD] != 0;
+      const bool hold = ctl0[CTL_HOLD] != 0;
       if (kind == KIND_PSEUDO) {
         for (int i = 0; i < 8; ++i) prev[i] = cur[i];
       } else if (kind == KIND_CHECK && !hold) {
@@ -290,7 +352,7 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
         commit = true;
       }
       ctl[CTL_N_EVALS] += 1;
-      if (commit && ctl[CTL_SHADOW] != 0) {
+      if (commit && ctl0[CTL_SHADOW] != 0) {
         // calibration: remember the FIRST exit that fires, keep evaluating the deeper exits (no EXIT_FLAG)
         if (ctl[CTL_COMMITTED] != 0) commit = false;
         else ctl[CTL_COMMITTED] = 1;
@@ -301,7 +363,6 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
       } else if (commit) {
         for (int i = 0; i < 8; ++i) outa[i] = cur[i];
         ctl[CTL_EXIT_LAYER] = layer;
-        __threadfence();
         ctl[CTL_EXIT_FLAG] = 1;
       }
     }
@@ -309,44 +370,64 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
   }
   __syncthreads();
   if (*flag && h_state != nullptr) {                    // DeterministicDecoder.hidden_state = h_n (action_head.py:555-556)
-    for (int i = threadIdx.x; i < LH; i += blockDim.x) {
-      h_state[i] = h_tmp[i];
-      c_state[i] = c_tmp[i];
+    for (int i = threadIdx.x; i < L * H; i += blockDim.x) {
+      const int l = i / H, u = i - l * H;
+      const long o = ((long)l * B + b) * H + u;
+      h_state[o] = h_tmp[o];
+      c_state[o] = c_tmp[o];
     }
   }
 }
 
-extern "C" int deer_head_final(const float* src, int in_dim, int pro, const float* lnw0, const float* lnb0, const float* lnw1,
-                               const float* lnb1, const void* Wa, const float* ba, const void* Wg, const float* bg, int* ctl,
-                               int kind, int layer, int slot, const float* thresholds, int force, int thr_type, int leq,
-                               const float* h_tmp, const float* c_tmp, float* h_state, float* c_state, int LH,
+// after the per-environment gates: ALL_EXITED = every environment of the batch has its EXIT_FLAG set
+__global__ void head_all_exited_kernel(int* ctl0, int B) {
+  if (threadIdx.x == 0) {
+    if (ctl0[CTL_ALL_EXITED] != 0) return;
+    int all = 1;
+    for (int b = 0; b < B; ++b) all &= (ctl0[b * CTL_WORDS + CTL_EXIT_FLAG] != 0);
+    ctl0[CTL_ALL_EXITED] = all;
+  }
+}
+
+extern "C" int deer_head_final(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0,
+                               const float* lnw1, const float* lnb1, const void* Wa, const float* ba, const void* Wg, const float* bg,
+                               int* ctl, int kind, int layer, int slot, const float* thresholds, int force, int thr_type, int leq,
+                               const float* h_tmp, const float* c_tmp, float* h_state, float* c_state, int L, int H, int B,
                                float* action_dbg, float eps, void* stream) {
-  if (in_dim <= 0 || (in_dim & 7) || pro < 0 || pro > 3 || kind < 0 || kind > 2) return DEER_ERR_SHAPE;
+  if (in_dim <= 0 || (in_dim & 7) || pro < 0 || pro > 3 || kind < 0 || kind > 2 || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
   if (kind == KIND_CHECK && (thresholds == nullptr || slot < 0 || ctl == nullptr)) return DEER_ERR_SHAPE;
   const int smem = (2 * in_dim + 16 + 8 + 4) * (int)sizeof(float);
-  hipLaunchKernelGGL(head_final_kernel, dim3(1), dim3(512), smem, reinterpret_cast<hipStream_t>(stream), src, in_dim, pro, lnw0,
-                     lnb0, lnw1, lnb1, reinterpret_cast<const bf16_t*>(Wa), ba, reinterpret_cast<const bf16_t*>(Wg), bg, ctl, kind,
-                     layer, slot, thresholds, force, thr_type, leq, h_tmp, c_tmp, h_state, c_state, LH, action_dbg, eps);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(head_final_kernel, dim3(B), dim3(512), smem, st, src, src_stride, in_dim, pro, lnw0, lnb0, lnw1, lnb1,
+                     reinterpret_cast<const bf16_t*>(Wa), ba, reinterpret_cast<const bf16_t*>(Wg), bg, ctl, kind, layer, slot,
+                     thresholds, force, thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps);
+  if (ctl != nullptr && kind != KIND_PSEUDO)
+    hipLaunchKernelGGL(head_all_exited_kernel, dim3(1), dim3(64), 0, st, ctl, B);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
 
 // ---- per-step control-block reset (start of every control step) ----------------------------------------
 // hold_src: device int written by the host before the step: 1 iff cur_step % steps_per_stage != 0.
-__global__ void ctl_begin_step_kernel(int* ctl, const int* hold_src) {
+__global__ void ctl_begin_step_kernel(int* ctl0, const int* hold_src, int B) {
+  const int b = blockIdx.x;
+  int* ctl = ctl0 + b * CTL_WORDS;
   if (threadIdx.x == 0) {
     ctl[CTL_EXIT_FLAG] = 0;
     ctl[CTL_EXIT_LAYER] = -1;
-    ctl[CTL_HOLD] = (hold_src != nullptr) ? *hold_src : 0;
     ctl[CTL_N_EVALS] = 0;
     ctl[CTL_COMMITTED] = 0;
+    if (b == 0) {
+      ctl[CTL_HOLD] = (hold_src != nullptr) ? *hold_src : 0;
+      ctl[CTL_ALL_EXITED] = 0;
+    }
   }
   if (threadIdx.x < 16) reinterpret_cast<float*>(ctl + CTL_DELTAS)[threadIdx.x] = __int_as_float(0x7fc00000);
 }
 
-extern "C" int deer_ctl_begin_step(int* ctl, const int* hold_src, void* stream) {
-  if (ctl == nullptr) return DEER_ERR_SHAPE;
-  hipLaunchKernelGGL(ctl_begin_step_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ctl, hold_src);
+extern "C" int deer_ctl_begin_step(int* ctl, const int* hold_src, int B, void* stream) {
+  if (ctl == nullptr || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(ctl_begin_step_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ctl, hold_src, B);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

@@ -193,22 +193,22 @@ extern "C" int deer_vit_embed_lnpre(const float* patch, const float* cls, const 
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* __restrict__ ids, const bf16_t* __restrict__ wte,
                                                            float* __restrict__ x, int* __restrict__ text_time, int T, int d,
                                                            int vocab, int media_id) {
-  const int t = blockIdx.x;
-  long long id = ids[t];
+  const int row = blockIdx.x, t = row % T, e0 = row - t;   // rows are [env][T]; the media count restarts per environment
+  long long id = ids[row];
   if (id < 0) id = 0;
   if (id >= vocab) id = vocab - 1;
-  for (int i = threadIdx.x; i < d; i += 256) x[(long)t * d + i] = bf2f(wte[id * d + i]);
+  for (int i = threadIdx.x; i < d; i += 256) x[(long)row * d + i] = bf2f(wte[id * d + i]);
   if (threadIdx.x == 0) {
     int c = 0;
-    for (int j = 0; j <= t; ++j) c += (ids[j] == media_id) ? 1 : 0;
-    text_time[t] = c;
+    for (int j = 0; j <= t; ++j) c += (ids[e0 + j] == media_id) ? 1 : 0;
+    text_time[row] = c;
   }
 }
 
-extern "C" int deer_embed_tokens(const long long* ids, const void* wte, float* x, int* text_time, int T, int d, int vocab,
-                                 int media_id, void* stream) {
-  if (T <= 0 || d <= 0 || vocab <= 0) return DEER_ERR_SHAPE;
-  hipLaunchKernelGGL(embed_tokens_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ids,
+extern "C" int deer_embed_tokens(const long long* ids, const void* wte, float* x, int* text_time, int T, int batch, int d,
+                                 int vocab, int media_id, void* stream) {
+  if (T <= 0 || batch <= 0 || d <= 0 || vocab <= 0) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(T * batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ids,
                      reinterpret_cast<const bf16_t*>(wte), x, text_time, T, d, vocab, media_id);
   DEER_LAUNCH_CHECK();
   return DEER_OK;

@@ -60,7 +60,10 @@ class _ProfiledLib:
 
 class DeerEngine:
     def __init__(self, cfg: DeerConfig, state_dict: Dict[str, torch.Tensor], device="cuda", max_text_len: int = 32,
-                 n_cams: int = 2, threshold_type: str = "L2", leq: bool = True):
+                 n_envs: int = 1, threshold_type: str = "L2", leq: bool = True):
+        """n_envs: independent environments evaluated per control step (one "env batch" per rank).  They share every
+        weight read: the ViT sees M = 514*n_envs rows, the LLM n_envs*T rows, each environment keeps its own LSTM state,
+        thresholds are shared and every environment exits at its own layer (device side)."""
         if not torch.cuda.is_available():
             raise abi.DeerHipError("DeerEngine needs a HIP device (no CPU fallback exists in deer_vla_amd)")
         self._prof = None            # when a list: every launch is bracketed by HIP events (bench roofline pass)
@@ -68,8 +71,11 @@ class DeerEngine:
         self.lib = _ProfiledLib(abi.lib(), self)
         self.cfg = cfg
         self.dev = torch.device(device)
-        self.n_cams = n_cams
+        assert 1 <= n_envs <= 8
+        self.B = n_envs
+        self.n_cams = 2 * n_envs                       # images per step: (rgb, gripper) of every environment
         self.max_T = max_text_len
+        assert n_envs * 14 <= 64, "skinny GEMM handles <= 64 rows"
         self.thr_type = abi.THR_TYPES[threshold_type]
         self.leq = 1 if leq else 0
         assert cfg.vit_head_dim == 64 and cfg.perc_dim_head == 64 and cfg.xattn_dim_head == 64, "head_dim 64 kernels"
@@ -232,7 +238,9 @@ class DeerEngine:
         self.vis_x = z(N * nl, W, dt=bf)                     # media tokens [rgb latents ; gripper latents]
         self.vis_x_f32 = z(N * nl, W)
         self.kv_all = z(N * nl, max(self.n_xattn, 1) * 2 * self.xinner, dt=bf)
-        d, T = cfg.d_model, self.max_T
+        d = cfg.d_model
+        T = min(self.B * self.max_T, 64)                     # LLM rows = n_envs * text length
+        self.max_rows = T
         self.ids = torch.zeros(T, dtype=torch.int64, device=dev)
         self.key_mask = torch.ones(T, dtype=torch.uint8, device=dev)
         self.text_time = torch.zeros(T, dtype=torch.int32, device=dev)
@@ -241,21 +249,21 @@ class DeerEngine:
         self.ao = z(T, max(d, self.xinner))                 # attention outputs, fp32
         max_n = max(cfg.mlp_ratio * d, cfg.xattn_ff_mult * d, 3 * d)
         self.max_split = 32
-        self.slab_a = z(self.max_split * 32 * d)             # outputs of width d (residual branches)
-        self.slab_b = z(16 * 32 * max_n)                     # outputs of width 3d / 4d / inner
+        self.slab_a = z(self.max_split * 64 * d)             # outputs of width d (residual branches)
+        self.slab_b = z(16 * 64 * max_n)                     # outputs of width 3d / 4d / inner
         self.qkv_ws = z(T, 3 * d)                            # reduced (+ q/k-normalised) qkv of the MPT attention
         self.hidden = z(cfg.n_layers, T, d)                  # hidden_states[i] = output of layer i
-        Lh, H = cfg.lstm_num_layers, cfg.head_hidden
-        self.h_state, self.c_state = z(Lh, H), z(Lh, H)
-        self.h_tmp, self.c_tmp = z(Lh, H), z(Lh, H)
-        self.h_shadow, self.c_shadow = z(Lh, H), z(Lh, H)    # commit target in shadow (calibration) mode
+        Lh, H, B = cfg.lstm_num_layers, cfg.head_hidden, self.B
+        self.h_state, self.c_state = z(Lh, B, H), z(Lh, B, H)     # LSTM state of every environment: [layer][env][H]
+        self.h_tmp, self.c_tmp = z(Lh, B, H), z(Lh, B, H)
+        self.h_shadow, self.c_shadow = z(Lh, B, H), z(Lh, B, H)   # commit target in shadow (calibration) mode
         dims = cfg.mlp_hidden_dims
-        self.z_fc = [z(2 * dm) for dm in dims]
-        self.ctl = torch.zeros(abi.CTL_WORDS, dtype=torch.int32, device=dev)
-        self.ctl_host = torch.zeros(abi.CTL_WORDS, dtype=torch.int32).pin_memory()
+        self.z_fc = [z(B, 2 * dm) for dm in dims]
+        self.ctl = torch.zeros(B * abi.CTL_WORDS, dtype=torch.int32, device=dev)   # one control block per environment
+        self.ctl_host = torch.zeros(B * abi.CTL_WORDS, dtype=torch.int32).pin_memory()
         self.hold_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.thresholds = torch.full((16,), 1e8, dtype=torch.float32, device=dev)
-        self.action_dbg = z(8)
+        self.action_dbg = z(B, 8)
 
     # ------------------------------------------------------------------------------------- small helpers
     @contextmanager
@@ -335,11 +343,11 @@ class DeerEngine:
     # --------------------------------------------------------------------------------------------- LLM
     def _skinny(self, Wp, N, K, T, out_slab, A=None, a_slab=None, s_in=0, a_mode=abi.A_F32, lda=None, ctl=True):
         S = self.lib.deer_skinny_splitk(T, N, K)
-        mpad = 16 if T <= 16 else 32
+        mpad = 16 if T <= 16 else (32 if T <= 32 else 64)
         assert S * mpad * N <= out_slab.numel(), (S, mpad, N, out_slab.numel())
         with self._rec("gemm_skinny", 2.0 * T * N * K, 2.0 * N * K):      # algorithmic bytes = the bf16 weights, once
             abi.check(self.lib.deer_gemm_skinny(abi.ptr(A), (K if lda is None else lda), abi.ptr(a_slab), s_in,
-                                                (32 if T > 16 else 16) * K, a_mode, abi.ptr(Wp), abi.ptr(out_slab), T, N, K, S,
+                                                mpad * K, a_mode, abi.ptr(Wp), abi.ptr(out_slab), T, N, K, S,
                                                 abi.ptr(self.ctl) if ctl else None, _cur_stream()), "deer_gemm_skinny")
         return S, mpad * N
 
@@ -352,42 +360,44 @@ class DeerEngine:
     def enqueue_embed(self, T):
         cfg = self.cfg
         abi.check(self.lib.deer_embed_tokens(abi.ptr(self.ids), abi.ptr(self.wte), abi.ptr(self.x), abi.ptr(self.text_time), T,
-                                             cfg.d_model, cfg.vocab_size, cfg.media_token_id, _cur_stream()), "embed_tokens")
+                                             self.B, cfg.d_model, cfg.vocab_size, cfg.media_token_id, _cur_stream()), "embed_tokens")
 
     def enqueue_llm_layer(self, i, T, pending, use_mask: bool, finalize: bool, ctl=True):
         """FlamingoLayer.forward (flamingo_lm.py:46-83): gated x-attn (helpers.py:260-279) then the MPT block
-        (SURVEY App. B.1).  ``pending`` = not-yet-applied residual branch of the previous op (split-K slabs + gate)."""
+         on R = n_envs*T rows.  ``pending`` = not-yet-applied residual branch of the previous op
+        (split-K slabs + gate)."""
         cfg, L, st = self.cfg, self.llm_layers[i], _cur_stream()
-        d = cfg.d_model
+        d, B = cfg.d_model, self.B
+        R = B * T
         c = abi.ptr(self.ctl) if ctl else None
         if "xa" in L:
             X = L["xa"]
-            self._resadd(T, pending, X["nw"], X["nb"], ctl=ctl)
-            S, stride = self._skinny(X["wq"], self.xinner, d, T, self.slab_b, A=self.xn, ctl=ctl)
+            self._resadd(R, pending, X["nw"], X["nb"], ctl=ctl)
+            S, stride = self._skinny(X["wq"], self.xinner, d, R, self.slab_b, A=self.xn, ctl=ctl)
             kv_off = X["kv_index"] * 2 * self.xinner * 2          # bytes into a kv_all row
             abi.check(self.lib.deer_xattn_small(abi.ptr(self.slab_b), S, stride, self.xinner, abi.ptr(self.kv_all, kv_off),
                                                 self.n_xattn * 2 * self.xinner, self.xinner, abi.ptr(self.text_time),
-                                                cfg.perc_latents * self.n_cams, abi.ptr(self.ao), 1, self.xinner, T, cfg.n_media,
-                                                cfg.xattn_heads, cfg.xattn_dim_head ** -0.5, c, st), "deer_xattn_small")
-            S, stride = self._skinny(X["wo"], d, self.xinner, T, self.slab_a, A=self.ao, lda=self.xinner, ctl=ctl)
-            self._resadd(T, (self.slab_a, S, stride, X["ag"]), X["fnw"], X["fnb"], ctl=ctl)
-            S, stride = self._skinny(X["w1"], cfg.xattn_ff_mult * d, d, T, self.slab_b, A=self.xn, ctl=ctl)
-            S, stride = self._skinny(X["w2"], d, cfg.xattn_ff_mult * d, T, self.slab_a, a_slab=self.slab_b, s_in=S,
+                                                cfg.n_media, abi.ptr(self.ao), 1, self.xinner, T, cfg.n_media,
+                                                cfg.xattn_heads, B, cfg.xattn_dim_head ** -0.5, c, st), "deer_xattn_small")
+            S, stride = self._skinny(X["wo"], d, self.xinner, R, self.slab_a, A=self.ao, lda=self.xinner, ctl=ctl)
+            self._resadd(R, (self.slab_a, S, stride, X["ag"]), X["fnw"], X["fnb"], ctl=ctl)
+            S, stride = self._skinny(X["w1"], cfg.xattn_ff_mult * d, d, R, self.slab_b, A=self.xn, ctl=ctl)
+            S, stride = self._skinny(X["w2"], d, cfg.xattn_ff_mult * d, R, self.slab_a, a_slab=self.slab_b, s_in=S,
                                      a_mode=abi.A_SLABS_GELU, ctl=ctl)
             pending = (self.slab_a, S, stride, X["fg"])
-        self._resadd(T, pending, L["ln1w"], L["ln1b"], ctl=ctl)
-        S, stride = self._skinny(L["wqkv"], 3 * d, d, T, self.slab_b, A=self.xn, ctl=ctl)
+        self._resadd(R, pending, L["ln1w"], L["ln1b"], ctl=ctl)
+        S, stride = self._skinny(L["wqkv"], 3 * d, d, R, self.slab_b, A=self.xn, ctl=ctl)
         abi.check(self.lib.deer_mpt_attn_small(abi.ptr(self.slab_b), S, stride, d, cfg.n_heads, abi.ptr(L["qlnw"]), abi.ptr(L["klnw"]),
                                                EPS, abi.ptr(self.key_mask) if use_mask else None, float(cfg.alibi_bias_max),
-                                               abi.ptr(self.qkv_ws), abi.ptr(self.ao), 1, d, T, c, st), "deer_mpt_attn_small")
-        S, stride = self._skinny(L["wo"], d, d, T, self.slab_a, A=self.ao, lda=d, ctl=ctl)
-        self._resadd(T, (self.slab_a, S, stride, None), L["ln2w"], L["ln2b"], ctl=ctl)
-        S, stride = self._skinny(L["wup"], cfg.mlp_ratio * d, d, T, self.slab_b, A=self.xn, ctl=ctl)
-        S, stride = self._skinny(L["wdown"], d, cfg.mlp_ratio * d, T, self.slab_a, a_slab=self.slab_b, s_in=S,
+                                               abi.ptr(self.qkv_ws), abi.ptr(self.ao), 1, d, T, B, c, st), "deer_mpt_attn_small")
+        S, stride = self._skinny(L["wo"], d, d, R, self.slab_a, A=self.ao, lda=d, ctl=ctl)
+        self._resadd(R, (self.slab_a, S, stride, None), L["ln2w"], L["ln2b"], ctl=ctl)
+        S, stride = self._skinny(L["wup"], cfg.mlp_ratio * d, d, R, self.slab_b, A=self.xn, ctl=ctl)
+        S, stride = self._skinny(L["wdown"], d, cfg.mlp_ratio * d, R, self.slab_a, a_slab=self.slab_b, s_in=S,
                                  a_mode=abi.A_SLABS_GELU, ctl=ctl)
         pending = (self.slab_a, S, stride, None)
         if finalize:                                            # hidden_states[i] = output of layer i (mosaic_gpt_3b.py:424-427)
-            self._resadd(T, pending, None, None, x_copy=self.hidden[i], ctl=ctl)
+            self._resadd(R, pending, None, None, x_copy=self.hidden[i], ctl=ctl)
             pending = None
         return pending
 
@@ -400,41 +410,41 @@ class DeerEngine:
         CHECK (delta <= threshold -> exit + commit LSTM state), COMMIT (static exit_id / committing call)."""
         cfg, Hd, lib, st = self.cfg, self.head, self.lib, _cur_stream()
         c = abi.ptr(self.ctl) if use_ctl else None
-        H, d = cfg.head_hidden, cfg.d_model
-        feats = self.hidden[layer] if feats is None else feats
+        H, d, B = cfg.head_hidden, cfg.d_model, self.B
+        feats = self.hidden[layer] if feats is None else feats      # [B*T, d]: environment b owns rows b*T .. b*T+T-1
         h_prev = self.h_state if h_prev is None else h_prev
         c_prev = self.c_state if c_prev is None else c_prev
         pool = abi.X_POOL_MAX if cfg.pooling == "max" else abi.X_POOL_AVG
         for l, Lw in enumerate(Hd["lstm"]):
             if l == 0:
-                src, mode, in_dim, lnw, lnb = feats, pool, d, None, None
+                src, bstride, mode, in_dim, lnw, lnb = feats, T * d, pool, d, None, None
             else:
                 prev = Hd["lstm"][l - 1]
-                src, in_dim = self.h_tmp[l - 1], H
+                src, bstride, in_dim = self.h_tmp[l - 1], H, H
                 mode, lnw, lnb = (abi.X_LN, prev["lnw"], prev["lnb"]) if cfg.lstm_layernorm else (abi.X_RAW, None, None)
-            abi.check(lib.deer_head_lstm_layer(abi.ptr(src), mode, T, in_dim, abi.ptr(lnw), abi.ptr(lnb), abi.ptr(Lw["wih"]),
+            abi.check(lib.deer_head_lstm_layer(abi.ptr(src), bstride, mode, T, in_dim, abi.ptr(lnw), abi.ptr(lnb), abi.ptr(Lw["wih"]),
                                                abi.ptr(Lw["whh"]), abi.ptr(Lw["bih"]), abi.ptr(Lw["bhh"]), abi.ptr(h_prev[l]),
-                                               abi.ptr(c_prev[l]), abi.ptr(self.h_tmp[l]), abi.ptr(self.c_tmp[l]), H, EPS, c, kind,
+                                               abi.ptr(c_prev[l]), abi.ptr(self.h_tmp[l]), abi.ptr(self.c_tmp[l]), H, B, EPS, c, kind,
                                                layer, st), "deer_head_lstm_layer")
-        src, in_dim = self.h_tmp[cfg.lstm_num_layers - 1], H
+        src, in_dim, sstride = self.h_tmp[cfg.lstm_num_layers - 1], H, H
         last = Hd["lstm"][-1]
         pro, ln = (abi.PRO_LN, (last["lnw"], last["lnb"], None, None)) if cfg.lstm_layernorm else (abi.PRO_RAW, (None,) * 4)
         for fi, (Fw, dim) in enumerate(zip(Hd["fc"], cfg.mlp_hidden_dims)):
-            abi.check(lib.deer_head_fc(abi.ptr(src), in_dim, pro, abi.ptr(ln[0]), abi.ptr(ln[1]), abi.ptr(ln[2]), abi.ptr(ln[3]),
+            abi.check(lib.deer_head_fc(abi.ptr(src), sstride, in_dim, pro, abi.ptr(ln[0]), abi.ptr(ln[1]), abi.ptr(ln[2]), abi.ptr(ln[3]),
                                        abi.ptr(Fw["w0"]), abi.ptr(Fw["b0"]), abi.ptr(Fw["w1"]), abi.ptr(Fw["b1"]), dim,
-                                       abi.ptr(self.z_fc[fi]), EPS, c, kind, layer, st), "deer_head_fc")
-            src, in_dim = self.z_fc[fi], dim
+                                       abi.ptr(self.z_fc[fi]), B, EPS, c, kind, layer, st), "deer_head_fc")
+            src, in_dim, sstride = self.z_fc[fi], dim, 2 * dim
             if cfg.mlp_layernorm:
                 pro, ln = abi.PRO_GROUP_LN_RELU, (Fw["lnw0"], Fw["lnb0"], Fw["lnw1"], Fw["lnb1"])
             else:
                 pro, ln = abi.PRO_GROUP_RELU, (None,) * 4
-        LH = cfg.lstm_num_layers * H
-        abi.check(lib.deer_head_final(abi.ptr(src), in_dim, pro, abi.ptr(ln[0]), abi.ptr(ln[1]), abi.ptr(ln[2]), abi.ptr(ln[3]),
+        abi.check(lib.deer_head_final(abi.ptr(src), sstride, in_dim, pro, abi.ptr(ln[0]), abi.ptr(ln[1]), abi.ptr(ln[2]), abi.ptr(ln[3]),
                                       abi.ptr(Hd["wa"]), abi.ptr(Hd["ba"]), abi.ptr(Hd["wg"]), abi.ptr(Hd["bg"]),
-                                      None if no_ctl_final else abi.ptr(self.ctl), kind, layer, slot, abi.ptr(self.thresholds), 1 if force else 0,
-                                      self.thr_type, self.leq, abi.ptr(self.h_tmp), abi.ptr(self.c_tmp),
+                                      None if no_ctl_final else abi.ptr(self.ctl), kind, layer, slot, abi.ptr(self.thresholds),
+                                      1 if force else 0, self.thr_type, self.leq, abi.ptr(self.h_tmp), abi.ptr(self.c_tmp),
                                       abi.ptr(self.h_shadow if shadow else self.h_state),
-                                      abi.ptr(self.c_shadow if shadow else self.c_state), LH, abi.ptr(self.action_dbg), EPS, st),
+                                      abi.ptr(self.c_shadow if shadow else self.c_state), cfg.lstm_num_layers, H, B,
+                                      abi.ptr(self.action_dbg), EPS, st),
                   "deer_head_final")
 
     # ------------------------------------------------------------------------------------- step assembly
@@ -491,7 +501,7 @@ class DeerEngine:
         self.enqueue_head(exit_id, T, abi.KIND_COMMIT, use_ctl=False)
 
     def _enqueue_step(self, T, use_mask, exit_id, shadow: bool = False):
-        abi.check(self.lib.deer_ctl_begin_step(abi.ptr(self.ctl), abi.ptr(self.hold_dev), _cur_stream()), "ctl_begin_step")
+        abi.check(self.lib.deer_ctl_begin_step(abi.ptr(self.ctl), abi.ptr(self.hold_dev), self.B, _cur_stream()), "ctl_begin_step")
         self.enqueue_vision()
         if exit_id is None:
             self.enqueue_llm_dynamic(T, use_mask, shadow)
@@ -500,24 +510,27 @@ class DeerEngine:
 
     # ---------------------------------------------------------------------------------------- host API
     def load_inputs(self, rgb: torch.Tensor, gripper: torch.Tensor, ids: torch.Tensor, mask: Optional[torch.Tensor] = None):
-        """rgb / gripper: (..., 3, S, S) one frame each; ids (1,T) or (T,) int64; mask (1,T) bool."""
-        S = self.cfg.image_size
-        self.img[0].copy_(rgb.reshape(3, S, S), non_blocking=True)
-        self.img[1].copy_(gripper.reshape(3, S, S), non_blocking=True)
-        ids = ids.reshape(-1)
-        T = ids.numel()
-        assert 0 < T <= self.max_T
-        self.ids[:T].copy_(ids, non_blocking=True)
+        """rgb / gripper: (B, ..., 3, S, S) one frame per environment (any singleton dims in between; B may be omitted
+        when n_envs == 1); ids (B, T) int64 (right-padded to a common T); mask (B, T) bool."""
+        S, B = self.cfg.image_size, self.B
+        img = self.img.view(B, 2, 3, S, S)
+        img[:, 0].copy_(rgb.reshape(B, 3, S, S), non_blocking=True)
+        img[:, 1].copy_(gripper.reshape(B, 3, S, S), non_blocking=True)
+        ids = ids.reshape(B, -1)
+        T = ids.shape[1]
+        assert 0 < T <= self.max_T and B * T <= self.max_rows
+        self.ids[:B * T].copy_(ids.reshape(-1), non_blocking=True)
         use_mask = False
         if mask is not None:
-            m = mask.reshape(-1).to(torch.uint8)
+            m = mask.reshape(B, T).to(torch.uint8)
             use_mask = bool((m == 0).any())
-            self.key_mask[:T].copy_(m, non_blocking=True)
+            self.key_mask[:B * T].copy_(m.reshape(-1), non_blocking=True)
         return T, use_mask
 
     def step(self, rgb, gripper, ids, mask=None, exit_id: Optional[int] = None, use_graph: bool = True, sync: bool = True,
              shadow: bool = False):
-        """One control step.  Returns dict(pose (6,), gripper prob, gripper_logit, exit_layer, deltas) when sync.
+        """One control step of all n_envs environments.  Returns (when sync) dict(pose (6,), gripper prob, gripper_logit,
+        exit_layer, deltas) for n_envs == 1, else a list of such dicts (one per environment).
         shadow=True (calibration): every exit is evaluated and its delta recorded, the LSTM state / action are
         committed at the first exit whose criterion fires, but the step never terminates early."""
         T, use_mask = self.load_inputs(rgb, gripper, ids, mask)
@@ -535,12 +548,9 @@ class DeerEngine:
                 self._enqueue_step(T, use_mask, exit_id, shadow)  # eager warm-up (sets kernel attributes) - a real step
                 torch.cuda.current_stream().synchronize()
                 g = torch.cuda.CUDAGraph()
-                self._graph_pending = (T, use_mask, exit_id)
-                # state was advanced by the warm-up run; capture does not execute kernels
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g):                         # capture does not execute kernels
                     self._enqueue_step(T, use_mask, exit_id, shadow)
                 self._graphs[key] = g
-                self._warm_result = True
             else:
                 g.replay()
         else:
@@ -556,12 +566,17 @@ class DeerEngine:
         return self.read_result()
 
     def read_result(self):
-        c = self.ctl_host
-        f = c.view(torch.float32)
-        return dict(exit_layer=int(c[abi.CTL_EXIT_LAYER]), n_evals=int(c[abi.CTL_N_EVALS]),
-                    pose=f[abi.CTL_OUT_ACTION: abi.CTL_OUT_ACTION + 6].clone(),
-                    gripper=float(f[abi.CTL_OUT_ACTION + 6]), gripper_logit=float(f[abi.CTL_OUT_ACTION + 7]),
-                    deltas=f[abi.CTL_DELTAS: abi.CTL_DELTAS + 16].clone())
+        W = abi.CTL_WORDS
+        ci = self.ctl_host.view(self.B, W)
+        cf = self.ctl_host.view(torch.float32).view(self.B, W)
+        out = []
+        for b in range(self.B):
+            c, f = ci[b], cf[b]
+            out.append(dict(exit_layer=int(c[abi.CTL_EXIT_LAYER]), n_evals=int(c[abi.CTL_N_EVALS]),
+                            pose=f[abi.CTL_OUT_ACTION: abi.CTL_OUT_ACTION + 6].clone(),
+                            gripper=float(f[abi.CTL_OUT_ACTION + 6]), gripper_logit=float(f[abi.CTL_OUT_ACTION + 7]),
+                            deltas=f[abi.CTL_DELTAS: abi.CTL_DELTAS + 16].clone()))
+        return out[0] if self.B == 1 else out
 
     def weight_bytes(self) -> int:
         tot = 0

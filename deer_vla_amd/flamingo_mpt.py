@@ -306,7 +306,7 @@ class MPTFlamingo(nn.Module):
         if exit_id is not None or native:
             a = e.ctl.view(torch.float32)[abi.CTL_OUT_ACTION: abi.CTL_OUT_ACTION + 8].clone()
         else:
-            a = e.action_dbg.clone()
+            a = e.action_dbg[0].clone()
         hidden = tuple(e.hidden[i, :T].unsqueeze(0) for i in range(exit_layer + 1))
         assert len(hidden) == exit_layer + 1                                                # flamingo_mpt.py:458
         pose, grip = a[:6].view(1, 1, 6), a[6:7].view(1, 1, 1)

@@ -25,7 +25,8 @@ extern "C" {
 #define DEER_ERR_SHAPE 1
 #define DEER_ERR_LAUNCH 2
 
-/* control block layout (32-bit words) */
+/* control block layout (32-bit words); one block per environment of the batch (env b at ctl + b*DEER_CTL_WORDS);
+ * HOLD, SHADOW and ALL_EXITED are batch-global (block 0) */
 #define DEER_CTL_EXIT_FLAG 0
 #define DEER_CTL_EXIT_LAYER 1
 #define DEER_CTL_CUR_EXIT_ID 2
@@ -33,6 +34,7 @@ extern "C" {
 #define DEER_CTL_N_EVALS 4
 #define DEER_CTL_SHADOW 5      /* calibration: evaluate every exit, commit at the first that fires, never stop */
 #define DEER_CTL_COMMITTED 6
+#define DEER_CTL_ALL_EXITED 7  /* block 0: every environment of the batch has exited */
 #define DEER_CTL_PREV_ACTION 8   /* float[8] */
 #define DEER_CTL_OUT_ACTION 16   /* float[8]: pose[6], gripper prob, gripper logit */
 #define DEER_CTL_DELTAS 24       /* float[16] */
@@ -102,7 +104,7 @@ int deer_attn_mfma_hd64(const void* Q, const void* K, const void* V, void* O, in
  * text_time == 0 zeroed; out bf16 or f32 [T, ldo]. */
 int deer_xattn_small(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv, int inner,
                      const int* text_time, int n_per_media, void* out, int out_is_f32, int ldo, int T, int n_kv, int heads,
-                     float scale, const int* ctl, void* stream);
+                     int batch, float scale, const int* ctl, void* stream);
 /* deer_mpt_attn_small: MPT attention core (attn bias built at mosaic_gpt_3b.py:158-219): qkv from
  * split-K slabs [T,3d]; optional q/k LayerNorm over d_model (weights f32 or NULL); ALiBi slope
  * 2^(-alibi_bias_max*(h+1)/H); causal; key_mask (uint8[T], 0 = padded) or NULL; qkv_ws = f32 [T,3d] workspace;
@@ -110,7 +112,7 @@ int deer_xattn_small(const float* qslab, int s_in, long slab_stride, int ldqs, c
  * workgroup per head. */
 int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w,
                         const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws,
-                        void* out, int out_is_f32, int ldo, int T, const int* ctl, void* stream);
+                        void* out, int out_is_f32, int ldo, int T, int batch, const int* ctl, void* stream);
 
 /* ---- row ops ------------------------------------------------------------------------------------------------
  * deer_layernorm_rows: nn.LayerNorm (ViT ln_1/ln_2, helpers.py:32-33,17,132), f32 in, bf16 and/or f32 out. */
@@ -127,23 +129,26 @@ int deer_vit_im2col(const void* img, int img_is_bf16, int N, int S, int patch, v
 int deer_vit_embed_lnpre(const float* patch, const float* cls, const float* pos, const float* ln_w, const float* ln_b,
                          float* x, int N, int P, int W, float eps, void* stream);
 /* wte lookup (mosaic_gpt_3b.py:341) + text_time = cumsum(ids == media_token_id) (flamingo_lm.py:211, helpers.py:208) */
-int deer_embed_tokens(const long long* ids, const void* wte_bf16, float* x, int* text_time, int T, int d, int vocab,
+int deer_embed_tokens(const long long* ids, const void* wte_bf16, float* x, int* text_time, int T, int batch, int d, int vocab,
                       int media_id, void* stream);
 int deer_broadcast_rows(const float* src, float* dst, long n, int batch, void* stream);   /* helpers.py:128 */
 
-/* ---- action head + exit gate (robot_flamingo/models/action_head.py:499-611, value_net.py:105-133,277-297) ----- */
-int deer_head_lstm_layer(const float* x_src, int x_mode, int T, int in_dim, const float* ln_w, const float* ln_b,
+/* ---- action head + exit gate (robot_flamingo/models/action_head.py:499-611, value_net.py:105-133,277-297) -----
+ * All three evaluate a BATCH of B <= 8 independent environments per launch (weights read once): features [B][T][d],
+ * LSTM state tensors [L][B][H], control blocks ctl + b*DEER_CTL_WORDS, exit decision per environment. */
+int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w, const float* ln_b,
                          const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh, const float* h_prev,
-                         const float* c_prev, float* h_out, float* c_out, int H, float eps, const int* ctl, int kind,
+                         const float* c_prev, float* h_out, float* c_out, int H, int B, float eps, const int* ctl, int kind,
                          int layer, void* stream);
-int deer_head_fc(const float* src, int in_dim, int pro, const float* lnw0, const float* lnb0, const float* lnw1,
+int deer_head_fc(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0, const float* lnw1,
                  const float* lnb1, const void* W0, const float* b0, const void* W1, const float* b1, int out_dim, float* dst,
-                 float eps, const int* ctl, int kind, int layer, void* stream);
-int deer_head_final(const float* src, int in_dim, int pro, const float* lnw0, const float* lnb0, const float* lnw1,
+                 int B, float eps, const int* ctl, int kind, int layer, void* stream);
+int deer_head_final(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0, const float* lnw1,
                     const float* lnb1, const void* Wa, const float* ba, const void* Wg, const float* bg, int* ctl, int kind,
                     int layer, int slot, const float* thresholds, int force, int thr_type, int leq, const float* h_tmp,
-                    const float* c_tmp, float* h_state, float* c_state, int LH, float* action_dbg, float eps, void* stream);
-int deer_ctl_begin_step(int* ctl, const int* hold_src, void* stream);   /* ExitController.set_timestep, eval_utils.py:662-663 */
+                    const float* c_tmp, float* h_state, float* c_state, int L, int H, int B, float* action_dbg, float eps,
+                    void* stream);
+int deer_ctl_begin_step(int* ctl, const int* hold_src, int B, void* stream);   /* ExitController.set_timestep, eval_utils.py:662-663 */
 
 /* keeps `stream` busy for ~us microseconds (profiling aid: lets the host enqueue ahead of the GPU) */
 int deer_spin_us(int us, void* stream);

@@ -242,6 +242,43 @@ def test_padding_mask_and_text_lengths(tiny):
         assert float((r["pose"] - ref["logits"][0].reshape(-1)).abs().max()) < ACTION_TOL
 
 
+@pytest.mark.parametrize("B,sps", [(2, 1), (4, 1), (3, 2)])
+def test_batched_environments_match_independent_oracle_runs(B, sps):
+    """n_envs environments per step (one env batch per rank): every environment must behave exactly like an
+    independent single-environment run - its own exit layer (exact), action (1e-2), LSTM carry - while sharing the
+    weight stream.  B=2 -> 22 LLM rows (2 MFMA row tiles), B=4 -> 44 rows (4 row tiles)."""
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
+    eng = DeerEngine(cfg, sd, n_envs=B)
+    n_steps, T = 12, 11
+    env_inputs = [[syn.synthetic_step_inputs(cfg, s, rank=e, text_len=T, text_seed=7 + e) for s in range(n_steps)] for e in range(B)]
+    thr, _ = probe_thresholds(cfg, sd, env_inputs[0], 12, sps)
+    refs, margins = [], []
+    for e in range(B):
+        ref, rec, _ = oracle_episode(cfg, sd, env_inputs[e], thr, 12, sps)
+        refs.append(ref)
+        margins.append(min_margin(rec, dict(zip(cfg.exit_ids(), thr))))
+    eng.configure_exit(cfg.exit_ids(), 12, sps)
+    eng.set_thresholds(thr)
+    eng.reset()
+    seen = set()
+    for s in range(n_steps):
+        rgb = torch.stack([env_inputs[e][s][0] for e in range(B)])
+        grip = torch.stack([env_inputs[e][s][1] for e in range(B)])
+        ids = torch.cat([env_inputs[e][s][2] for e in range(B)])
+        mask = torch.cat([env_inputs[e][s][3] for e in range(B)])
+        out = eng.step(rgb, grip, ids, mask, use_graph=(s >= 2))
+        assert len(out) == B
+        for e in range(B):
+            if margins[e] > 0.01:                           # knife-edge thresholds for this env's data are not a parity statement
+                assert out[e]["exit_layer"] == refs[e][s][0], (e, s, out[e]["exit_layer"], refs[e][s][0], margins)
+                assert float((out[e]["pose"] - refs[e][s][1]).abs().max()) < ACTION_TOL, (e, s)
+                assert abs(out[e]["gripper"] - refs[e][s][2]) < ACTION_TOL
+            seen.add(out[e]["exit_layer"])
+    assert sum(m > 0.01 for m in margins) >= max(1, B - 1), margins
+    assert len(seen) > 1
+
+
 def test_full_size_mpt1b_vitl14_steps_vs_oracle():
     """BASELINE config sizes (ViT-L/14 x2, Perceiver, MPT-1B d=2048 x12 layers, 4x1024 LSTM head): static exit
     and a short dynamic episode against the fp32 CPU oracle."""

@@ -38,7 +38,7 @@ def lib():
 
 
 # ------------------------------------------------------------------------------------------ skinny GEMM
-@pytest.mark.parametrize("M", [1, 14, 16, 17, 32])
+@pytest.mark.parametrize("M", [1, 14, 16, 17, 32, 33, 56, 64])
 @pytest.mark.parametrize("N,K", [(512, 2048), (2048, 512), (6144, 2048), (2048, 8192), (64, 32), (48, 96)])
 def test_gemm_skinny_packed(lib, M, N, K):
     A = dev(rnd(M, K, seed=1), torch.bfloat16)
@@ -47,7 +47,7 @@ def test_gemm_skinny_packed(lib, M, N, K):
     abi.check(lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), N, K, st()), "pack")
     S = lib.deer_skinny_splitk(M, N, K)
     assert S >= 1 and K % (S * 32) == 0
-    mpad = 16 if M <= 16 else 32
+    mpad = 16 if M <= 16 else (32 if M <= 32 else 64)
     part = torch.full((S, mpad, N), float("nan"), device="cuda")
     abi.check(lib.deer_gemm_skinny(abi.ptr(A), K, None, 0, 0, abi.A_BF16, abi.ptr(Wp), abi.ptr(part), M, N, K, S, None, st()), "skinny")
     torch.cuda.synchronize()
@@ -59,7 +59,7 @@ def test_gemm_skinny_packed(lib, M, N, K):
         assert float(part[:, M:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,N,K", [(14, 2048, 2048), (32, 512, 2048), (3, 64, 96)])
+@pytest.mark.parametrize("M,N,K", [(14, 2048, 2048), (32, 512, 2048), (3, 64, 96), (56, 2048, 2048), (42, 8192, 2048)])
 def test_gemm_skinny_f32_split_activation(lib, M, N, K):
     """f32 activations enter the MFMA as bf16 hi + lo: result ~fp32-accurate w.r.t. the bf16 weights."""
     A = dev(rnd(M, K, seed=41))
@@ -67,7 +67,7 @@ def test_gemm_skinny_f32_split_activation(lib, M, N, K):
     Wp = torch.empty_like(W)
     abi.check(lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), N, K, st()), "pack")
     S = lib.deer_skinny_splitk(M, N, K)
-    mpad = 16 if M <= 16 else 32
+    mpad = 16 if M <= 16 else (32 if M <= 32 else 64)
     part = torch.zeros(S, mpad, N, device="cuda")
     abi.check(lib.deer_gemm_skinny(abi.ptr(A), K, None, 0, 0, abi.A_F32, abi.ptr(Wp), abi.ptr(part), M, N, K, S, None, st()), "skinny")
     torch.cuda.synchronize()
@@ -110,7 +110,7 @@ def test_skinny_respects_exit_flag(lib):
 
 
 def test_abi_rejects_bad_shapes(lib):
-    assert lib.deer_gemm_skinny(None, 0, None, 0, 0, 0, None, None, 40, 64, 64, 1, None, st()) == 1      # M > 32
+    assert lib.deer_gemm_skinny(None, 0, None, 0, 0, 0, None, None, 70, 64, 64, 1, None, st()) == 1      # M > 64
     assert lib.deer_gemm_skinny(None, 0, None, 0, 0, 0, None, None, 4, 60, 64, 1, None, st()) == 1       # N % 16
     assert lib.deer_gemm_bf16_nt(None, 8, 0, None, 8, None, None, 8, 0, 4, 16, 12, 1, 0, None, 0, None, st()) == 1   # K % 8
     assert lib.deer_attn_mfma_hd64(None, None, None, None, 1, 1, 4, 400, 64, 64, 64, 64, 0, 0, 0, 0, 1.0, st()) == 1  # kv_len
@@ -192,10 +192,10 @@ def test_xattn_small(lib):
     out = torch.zeros(T, inner, device="cuda", dtype=torch.bfloat16)
     off = 1024                                               # second layer's slice
     abi.check(lib.deer_xattn_small(abi.ptr(qs), s_in, 16 * inner, inner, abi.ptr(kv, off * 2), ldkv, inner, abi.ptr(tt), 128, abi.ptr(out),
-                                   0, inner, T, n_kv, heads, 64 ** -0.5, None, st()), "xattn")
+                                   0, inner, T, n_kv, heads, 1, 64 ** -0.5, None, st()), "xattn")
     outf = torch.zeros(T, inner, device="cuda")
     abi.check(lib.deer_xattn_small(abi.ptr(qs), s_in, 16 * inner, inner, abi.ptr(kv, off * 2), ldkv, inner, abi.ptr(tt), 128, abi.ptr(outf),
-                                   1, inner, T, n_kv, heads, 64 ** -0.5, None, st()), "xattn")
+                                   1, inner, T, n_kv, heads, 1, 64 ** -0.5, None, st()), "xattn")
     torch.cuda.synchronize()
     q = qs.sum(0)[:T].view(T, heads, 64).transpose(0, 1) * 64 ** -0.5
     k = kv[:, off:off + inner].float().view(n_kv, heads, 64).transpose(0, 1)
@@ -220,10 +220,10 @@ def test_mpt_attn_small(lib, qk_ln, T, d, H):
     out = torch.zeros(T, d, device="cuda", dtype=torch.bfloat16)
     ws = torch.zeros(T, 3 * d, device="cuda")
     abi.check(lib.deer_mpt_attn_small(abi.ptr(slab), s_in, mpad * 3 * d, d, H, abi.ptr(qw) if qk_ln else None, abi.ptr(kw) if qk_ln else None,
-                                      1e-5, abi.ptr(mask), 8.0, abi.ptr(ws), abi.ptr(out), 0, d, T, None, st()), "mpt attn")
+                                      1e-5, abi.ptr(mask), 8.0, abi.ptr(ws), abi.ptr(out), 0, d, T, 1, None, st()), "mpt attn")
     outf = torch.zeros(T, d, device="cuda")
     abi.check(lib.deer_mpt_attn_small(abi.ptr(slab), s_in, mpad * 3 * d, d, H, abi.ptr(qw) if qk_ln else None, abi.ptr(kw) if qk_ln else None,
-                                      1e-5, abi.ptr(mask), 8.0, abi.ptr(ws), abi.ptr(outf), 1, d, T, None, st()), "mpt attn")
+                                      1e-5, abi.ptr(mask), 8.0, abi.ptr(ws), abi.ptr(outf), 1, d, T, 1, None, st()), "mpt attn")
     torch.cuda.synchronize()
     qkv = slab.sum(0)[:T]
     q, k, v = qkv.chunk(3, -1)
@@ -315,7 +315,7 @@ def test_embed_tokens_and_text_time(lib):
     ids = torch.tensor([513, 4, 77, 513, 5, 6, 512, 0, 514], device="cuda")
     x = torch.zeros(T, d, device="cuda")
     tt = torch.zeros(T, dtype=torch.int32, device="cuda")
-    abi.check(lib.deer_embed_tokens(abi.ptr(ids), abi.ptr(wte), abi.ptr(x), abi.ptr(tt), T, d, V, 513, st()), "embed")
+    abi.check(lib.deer_embed_tokens(abi.ptr(ids), abi.ptr(wte), abi.ptr(x), abi.ptr(tt), T, 1, d, V, 513, st()), "embed")
     torch.cuda.synchronize()
     assert torch.equal(x, wte[ids].float())
     assert tt.tolist() == [1, 1, 1, 2, 2, 2, 2, 2, 2]
@@ -324,3 +324,58 @@ def test_embed_tokens_and_text_time(lib):
     abi.check(lib.deer_broadcast_rows(abi.ptr(lat), abi.ptr(dst), 64 * d, 3, st()), "bcast")
     torch.cuda.synchronize()
     assert torch.equal(dst, lat.expand(3, 64, d))
+
+
+def test_batched_small_attention_and_embedding(lib):
+    """batch = several environments per launch: rows [env][T]; each env has its own media rows / key mask / media count."""
+    B, T, d, H = 3, 9, 256, 2
+    s_in, mpad = 2, 32
+    slab = dev(rnd(s_in, mpad, 3 * d, seed=51))
+    qw, kw = dev(1 + 0.1 * rnd(d, seed=52)), dev(1 + 0.1 * rnd(d, seed=53))
+    mask = torch.ones(B, T, dtype=torch.uint8, device="cuda")
+    mask[1, T - 3:] = 0
+    ws = torch.zeros(B * T, 3 * d, device="cuda")
+    out = torch.zeros(B * T, d, device="cuda")
+    abi.check(lib.deer_mpt_attn_small(abi.ptr(slab), s_in, mpad * 3 * d, d, H, abi.ptr(qw), abi.ptr(kw), 1e-5, abi.ptr(mask), 8.0, abi.ptr(ws),
+                                      abi.ptr(out), 1, d, T, B, None, st()), "mpt attn")
+    torch.cuda.synchronize()
+    qkv = slab.sum(0)[:B * T].view(B, T, 3 * d)
+    hd = d // H
+    slopes = 2.0 ** (-8.0 * torch.arange(1, H + 1, device="cuda") / H)
+    bias = -(T - 1 - torch.arange(T, device="cuda")).float().view(1, 1, T) * slopes.view(H, 1, 1)
+    for b in range(B):
+        q, k, v = qkv[b].chunk(3, -1)
+        q = torch.nn.functional.layer_norm(q, (d,), qw)
+        k = torch.nn.functional.layer_norm(k, (d,), kw)
+        q, k, v = (t.view(T, H, hd).transpose(0, 1) for t in (q, k, v))
+        w = q @ k.transpose(-1, -2) * hd ** -0.5 + bias
+        w = w.masked_fill(~mask[b].bool().view(1, 1, T), float("-inf"))
+        w = w.masked_fill(torch.ones(T, T, device="cuda").triu(1).bool(), float("-inf"))
+        ref = (torch.softmax(w, -1) @ v).transpose(0, 1).reshape(T, d)
+        assert rel_err(out[b * T:(b + 1) * T], ref) < 2e-5, b
+    # x-attn: env b attends only to ITS media rows
+    n_kv, heads, inner = 128, 8, 512
+    qs = dev(rnd(1, 32, inner, seed=54))
+    kv = dev(rnd(B * n_kv, 2 * inner, seed=55), torch.bfloat16)
+    tt = torch.ones(B * T, dtype=torch.int32, device="cuda")
+    xo = torch.zeros(B * T, inner, device="cuda")
+    abi.check(lib.deer_xattn_small(abi.ptr(qs), 1, 32 * inner, inner, abi.ptr(kv), 2 * inner, inner, abi.ptr(tt), 128, abi.ptr(xo), 1, inner, T,
+                                   n_kv, heads, B, 64 ** -0.5, None, st()), "xattn")
+    torch.cuda.synchronize()
+    for b in range(B):
+        q = qs[0, b * T:(b + 1) * T].view(T, heads, 64).transpose(0, 1) * 64 ** -0.5
+        kb = kv[b * n_kv:(b + 1) * n_kv]
+        k = kb[:, :inner].float().view(n_kv, heads, 64).transpose(0, 1)
+        v = kb[:, inner:].float().view(n_kv, heads, 64).transpose(0, 1)
+        ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(0, 1).reshape(T, inner)
+        assert rel_err(xo[b * T:(b + 1) * T], ref) < 2e-5, b
+    # embedding: media count restarts per environment
+    V = 515
+    wte = dev(rnd(V, d, seed=56), torch.bfloat16)
+    ids = torch.tensor([[513, 4, 5, 513, 6, 7, 8, 9, 0], [1, 2, 513, 3, 4, 5, 6, 7, 8], [513, 1, 1, 1, 1, 1, 1, 1, 1]], device="cuda")
+    x = torch.zeros(B * T, d, device="cuda")
+    t2 = torch.zeros(B * T, dtype=torch.int32, device="cuda")
+    abi.check(lib.deer_embed_tokens(abi.ptr(ids), abi.ptr(wte), abi.ptr(x), abi.ptr(t2), T, B, d, V, 513, st()), "embed")
+    torch.cuda.synchronize()
+    assert torch.equal(x, wte[ids.reshape(-1)].float())
+    assert t2.view(B, T).tolist() == [[1, 1, 1, 2, 2, 2, 2, 2, 2], [0, 0, 1, 1, 1, 1, 1, 1, 1], [1] * 9]

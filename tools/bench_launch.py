@@ -17,7 +17,7 @@ def timeit(fn, n=200, label=""):
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     print(f"{label:50s} {1e3*e0.elapsed_time(e1)/n:7.2f} us/launch")
 
-timeit(lambda: lib.deer_ctl_begin_step(abi.ptr(ctl), None, st()), label="trivial kernel (1 block x 64 threads)")
+timeit(lambda: lib.deer_ctl_begin_step(abi.ptr(ctl), None, 1, st()), label="trivial kernel (1 block x 64 threads)")
 x = torch.zeros(14, 2048, device="cuda"); o = torch.zeros(14, 2048, device="cuda")
 g_ = torch.ones(2048, device="cuda")
 timeit(lambda: lib.deer_resadd_ln(abi.ptr(x), None, 0, 0, None, abi.ptr(g_), None, None, abi.ptr(o), None, 14, 2048, 1e-5, None, st()), label="resadd_ln 14x2048 (no slabs)")
