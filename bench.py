@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--workload", default="deer_b", choices=["deer_b", "deer_s"],
                     help="deer_b: MPT-1B max_layer=12 exit_ratio 0.8 (the metric's config); deer_s: max_layer=4")
     ap.add_argument("--exit-ratio", type=float, default=0.8)
+    ap.add_argument("--envs-per-gpu", type=int, default=1,
+                    help="independent environments evaluated per control step on each GPU (one env batch per rank); "
+                         "1 = the reference's one-environment-per-process latency mode")
     ap.add_argument("--calib-steps", type=int, default=128)
     ap.add_argument("--calib-iters", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -63,6 +66,7 @@ def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
     import ctypes
     lib = abi.lib()
     T = ids.shape[1]
+    T = ids.reshape(eng.B, -1).shape[1]
     exit_id = eng.ctl_max_layer
     # event-bracket overhead: an empty bracket
     torch.cuda.synchronize()
@@ -171,7 +175,8 @@ def main():
     cfg = deer_3b(max_layer=max_layer)
     t0 = time.time()
     sd = syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True)
-    eng = DeerEngine(cfg, sd, device=f"cuda:{local_rank}")
+    B = args.envs_per_gpu
+    eng = DeerEngine(cfg, sd, device=f"cuda:{local_rank}", n_envs=B)
     if rank != 0 or args.no_cpu_baseline or world > 1:
         sd = None                                         # only rank 0 at N=1 needs the fp32 host copy (cpu_baseline)
     ctl = ExitController(None, cfg.exit_ids(), steps_per_stage=1, max_layer=max_layer)
@@ -183,9 +188,10 @@ def main():
     dev = eng.dev
     frames = []
     for s in range(POOL):
-        rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, s, rank=rank)
-        frames.append((rgb.to(dev, torch.bfloat16), grip.to(dev, torch.bfloat16)))
-    ids = ids.to(dev)
+        per_env = [syn.synthetic_step_inputs(cfg, s, rank=rank * B + e, text_seed=7 + e) for e in range(B)]
+        frames.append((torch.stack([p[0] for p in per_env]).to(dev, torch.bfloat16),
+                       torch.stack([p[1] for p in per_env]).to(dev, torch.bfloat16)))
+    ids = torch.cat([p[2] for p in per_env]).to(dev)          # (B, T): one instruction per environment
     T = ids.shape[1]
 
     def run_step(i, use_graph=True, sync=True, shadow=False):
@@ -206,7 +212,8 @@ def main():
         vals = []
         for i in range(args.calib_steps):
             r = run_step(i, shadow=True)
-            vals.append(r["deltas"][:real].clone())
+            for re in (r if B > 1 else [r]):
+                vals.append(re["deltas"][:real].clone())
         values = torch.stack(vals, dim=1)                  # (n_exit, n_samples)
         ctl.set_threshold_from_values(values, args.exit_ratio, cfg.llm_name)
         thr = ctl.threshold_list()
@@ -223,15 +230,16 @@ def main():
     exit_sum, hist = 0, [0] * cfg.n_layers
     for i in range(args.steps):
         r = run_step(i)
-        exit_sum += r["exit_layer"] + 1
-        hist[r["exit_layer"]] += 1
+        for re in (r if B > 1 else [r]):
+            exit_sum += re["exit_layer"] + 1
+            hist[re["exit_layer"]] += 1
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    stats = torch.tensor([elapsed, float(exit_sum), float(args.steps)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, float(exit_sum), float(args.steps * B)], dtype=torch.float64, device=dev)
     if dist is not None:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -247,9 +255,10 @@ def main():
         "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "avg_exit_layer": round(avg_exit, 3),
-        "config": {"workload": "OpenFlamingo-3B/MPT-1B DeeR-%s max_layer=%d exit_ratio=%.2f, step mode B=1 env/GPU, "
-                               "2x224x224 frames + %d text tokens, LSTM history carried over %d-step episodes"
-                               % ("B" if max_layer == 12 else "S", max_layer, args.exit_ratio, T, EP_LEN),
+        "config": {"workload": "OpenFlamingo-3B/MPT-1B DeeR-%s max_layer=%d exit_ratio=%.2f, step mode, %d env(s)/GPU per control "
+                               "step, 2x224x224 frames + %d text tokens per env, LSTM history carried over %d-step episodes"
+                               % ("B" if max_layer == 12 else "S", max_layer, args.exit_ratio, B, T, EP_LEN),
+                   "envs_per_gpu": B, "ms_per_env_step": round(1e3 * t_max / (args.steps * B), 4),
                    "exit_hist": hist if world == 1 else None, "per_gpu_steps_per_s": round(value / world, 2),
                    "graph": not args.no_graph, "weights_gb": round(eng.weight_bytes() / 1e9, 3),
                    "thresholds": [round(x, 6) for x in ctl.threshold_list()], "setup_s": round(setup_s, 1)},

@@ -98,7 +98,7 @@ def test_gemm_skinny_slab_gelu_input_and_determinism(lib):
 
 def test_skinny_respects_exit_flag(lib):
     ctl = torch.zeros(abi.CTL_WORDS, dtype=torch.int32, device="cuda")
-    ctl[abi.CTL_EXIT_FLAG] = 1
+    ctl[abi.CTL_ALL_EXITED] = 1                               # every environment of the batch has exited
     A = dev(rnd(4, 64), torch.bfloat16)
     W = dev(rnd(32, 64), torch.bfloat16)
     Wp = torch.empty_like(W)

@@ -25,7 +25,7 @@ A = torch.randn(14, 2048, device="cuda"); W = torch.randn(512, 2048, device="cud
 lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), 512, 2048, st())
 part = torch.zeros(8, 16, 512, device="cuda")
 timeit(lambda: lib.deer_gemm_skinny(abi.ptr(A), 2048, None, 0, 0, 3, abi.ptr(Wp), abi.ptr(part), 14, 512, 2048, 8, None, st()), label="skinny 512x2048 (2 MB, L2-warm, same W)")
-ctl[0] = 1
+ctl[7] = 1
 timeit(lambda: lib.deer_gemm_skinny(abi.ptr(A), 2048, None, 0, 0, 3, abi.ptr(Wp), abi.ptr(part), 14, 512, 2048, 8, abi.ptr(ctl), st()), label="skinny 512x2048 skipped by exit flag (64 blocks)")
 W2 = torch.randn(8192, 2048, device="cuda").bfloat16(); part2 = torch.zeros(4, 16, 8192, device="cuda")
 timeit(lambda: lib.deer_gemm_skinny(abi.ptr(A), 2048, None, 0, 0, 3, abi.ptr(W2), abi.ptr(part2), 14, 8192, 2048, 4, abi.ptr(ctl), st()), label="skinny 8192x2048 skipped by exit flag (512 blocks)")
