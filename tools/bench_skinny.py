@@ -8,7 +8,10 @@ lib = abi.lib()
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 SHAPES = [("xa q", 512, 2048), ("xa out", 2048, 512), ("xa ff1", 8192, 2048), ("xa ff2", 2048, 8192), ("qkv", 6144, 2048),
           ("out", 2048, 2048), ("up", 8192, 2048), ("down", 2048, 8192)]
-T = 14
+import sys as _s
+T = int(_s.argv[1]) if len(_s.argv) > 1 else 14
+MP = 16 if T <= 16 else (32 if T <= 32 else 64)
+print('rows', T)
 for name, N, K in SHAPES:
     ncopy = max(4, int(600e6 / (N * K * 2)))
     ncopy = min(ncopy, 64)
@@ -23,9 +26,9 @@ for name, N, K in SHAPES:
     line = f"{name:7s} N={N:5d} K={K:5d} {N*K*2/1e6:5.1f}MB |"
     S0 = lib.deer_skinny_splitk(T, N, K)
     for S in sorted(set([1, 2, 4, 8, 16, S0])):
-        if K % (S * 32) or (K // S) > 512:
+        if K % (S * 32) or (K // S) > (512 if MP == 16 else 256):
             continue
-        part = torch.zeros(S, 16, N, device="cuda")
+        part = torch.zeros(S, MP, N, device="cuda")
         def run(w):
             return lib.deer_gemm_skinny(abi.ptr(A), K, None, 0, 0, abi.A_F32, abi.ptr(w), abi.ptr(part), T, N, K, S, None, st())
         if run(Ws[0]) != 0:
