@@ -30,8 +30,11 @@ enum { A_BF16 = 0, A_SLABS_GELU = 1, A_SLABS = 2, A_F32 = 3 };
 // fragment feeds two MFMAs.  The GEMM is HBM-bound (MFMA pipe <5% busy), so the second MFMA is free and the
 // activation side of the product keeps ~16 mantissa bits: the LLM trunk then differs from an fp32 reference only
 // through the bf16 weights it shares with it -> robust exit decisions (SURVEY §7 "exit-index exactness").
-template <int MT, bool SPLIT>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const void* __restrict__ Av, int lda,
+// NW waves per workgroup = NW 16-column tiles sharing one staged activation slice.  With more than 16 activation rows
+// the slice (rows x KS x 4 B) outweighs the weights a 4-wave workgroup streams, so wide (16-wave) workgroups are used
+// to amortise it (measured: 56 rows, 33 MB of weights: 28 us with 4 waves).
+template <int MT, bool SPLIT, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __restrict__ Av, int lda,
                                                           const float* __restrict__ Aslab, int s_in, long slab_stride_in,
                                                           int a_mode, const bf16_t* __restrict__ Wp,
                                                           float* __restrict__ part, int M, int N, int K, int KS,
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const void* __restrict
   if (a_mode == A_BF16) {
     const bf16_t* A = reinterpret_cast<const bf16_t*>(Av);
     const int segs = klen >> 3;
-    for (int idx = tid; idx < MPAD * segs; idx += 256) {
+    for (int idx = tid; idx < MPAD * segs; idx += 64 * NW) {
       const int row = idx / segs, seg = idx - row * segs;
       uint4 v = uint4{0, 0, 0, 0};
       if (row < M) v = *reinterpret_cast<const uint4*>(A + (long)row * lda + k0 + seg * 8);
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const void* __restrict
     }
   } else {
     const int segs = klen >> 2;
-    for (int idx = tid; idx < MPAD * segs; idx += 256) {
+    for (int idx = tid; idx < MPAD * segs; idx += 64 * NW) {
       const int row = idx / segs, seg = idx - row * segs;
       float4 s = float4{0.f, 0.f, 0.f, 0.f};
       if (row < M) {
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const void* __restrict
   }
   __syncthreads();
 
-  const int tile = blockIdx.x * 4 + wave;                 // 16-column tile of this wave
+  const int tile = blockIdx.x * NW + wave;                // 16-column tile of this wave
   if (tile * 16 >= N) return;
   const int ktiles = K >> 5;
   const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + ((long)tile * ktiles + (k0 >> 5)) * 64 + lane;
@@ -162,10 +165,11 @@ extern "C" int deer_pack_weight_mfma16(const void* W, void* Wp, int N, int K, vo
 extern "C" int deer_skinny_splitk(int M, int N, int K) {
   const int mt = (M > 32) ? 4 : ((M > 16) ? 2 : 1);
   const int max_ks = (mt == 4) ? 256 : 512 / mt;
-  const int groups = (N + 63) / 64;
+  const int cols = (mt == 1) ? 64 : 256;                   // 4-wave workgroups up to 16 rows, 16-wave beyond
+  const int groups = (N + cols - 1) / cols;
   int s = 1;
   while ((K / s) > max_ks && (K % (s * 2 * 32)) == 0) s *= 2;
-  while (groups * s < 512 && (K / (s * 2)) >= 256 && (K % (s * 2 * 32)) == 0) s *= 2;
+  while (groups * s < (mt == 1 ? 512 : 256) && (K / (s * 2)) >= (mt == 1 ? 256 : 128) && (K % (s * 2 * 32)) == 0) s *= 2;
   return s;
 }
 
@@ -185,19 +189,20 @@ extern "C" int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int 
   if (smem > 72 * 1024) return DEER_ERR_SHAPE;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<4, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<4, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
     attr_set = true;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid((N + 63) / 64, splitk);
+  const int nw = (mt == 1) ? 4 : 16;
+  dim3 grid((N + 16 * nw - 1) / (16 * nw), splitk);
   const bf16_t* wp = reinterpret_cast<const bf16_t*>(Wp);
-#define DEER_SK_LAUNCH(MT_, SP_)                                                                                      \
-  hipLaunchKernelGGL((gemm_skinny_kernel<MT_, SP_>), grid, dim3(256), smem, st, A, lda, Aslab, s_in, slab_stride_in,  \
+#define DEER_SK_LAUNCH(MT_, SP_, NW_)                                                                                         \
+  hipLaunchKernelGGL((gemm_skinny_kernel<MT_, SP_, NW_>), grid, dim3(64 * NW_), smem, st, A, lda, Aslab, s_in, slab_stride_in, \
                      a_mode, wp, part, M, N, K, KS, ctl)
-  if (mt == 1)      { if (split) DEER_SK_LAUNCH(1, true); else DEER_SK_LAUNCH(1, false); }
-  else if (mt == 2) { if (split) DEER_SK_LAUNCH(2, true); else DEER_SK_LAUNCH(2, false); }
-  else              { if (split) DEER_SK_LAUNCH(4, true); else DEER_SK_LAUNCH(4, false); }
+  if (mt == 1)      { if (split) DEER_SK_LAUNCH(1, true, 4); else DEER_SK_LAUNCH(1, false, 4); }
+  else if (mt == 2) { if (split) DEER_SK_LAUNCH(2, true, 16); else DEER_SK_LAUNCH(2, false, 16); }
+  else              { if (split) DEER_SK_LAUNCH(4, true, 16); else DEER_SK_LAUNCH(4, false, 16); }
 #undef DEER_SK_LAUNCH
   DEER_LAUNCH_CHECK();
   return DEER_OK;
