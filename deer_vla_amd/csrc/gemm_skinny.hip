@@ -169,7 +169,7 @@ extern "C" int deer_skinny_splitk(int M, int N, int K) {
   const int groups = (N + cols - 1) / cols;
   int s = 1;
   while ((K / s) > max_ks && (K % (s * 2 * 32)) == 0) s *= 2;
-  while (groups * s < (mt == 1 ? 512 : 256) && (K / (s * 2)) >= (mt == 1 ? 256 : 128) && (K % (s * 2 * 32)) == 0) s *= 2;
+  while (groups * s < (mt == 1 ? 512 : 192) && (K / (s * 2)) >= (mt == 1 ? 256 : 128) && (K % (s * 2 * 32)) == 0) s *= 2;
   return s;
 }
 

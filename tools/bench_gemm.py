@@ -7,17 +7,20 @@ from deer_vla_amd import _abi as abi
 
 lib = abi.lib()
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+import sys as _s
+MB = int(_s.argv[1]) if len(_s.argv) > 1 else 1
 SHAPES = [("vit qkv", 514, 3072, 1024), ("vit out", 514, 1024, 1024), ("vit fc1", 514, 4096, 1024), ("vit fc2", 514, 1024, 4096),
           ("patch", 512, 1024, 640), ("perc kv", 640, 1024, 1024), ("perc q", 128, 512, 1024), ("perc ff1", 128, 4096, 1024),
           ("perc ff2", 128, 1024, 4096), ("media kv", 128, 12288, 1024)]
 NCOPY = 24
 for name, M, N, K in SHAPES:
+    M = M * MB
     A = torch.randn(M, K, device="cuda").bfloat16()
     Ws = [torch.randn(N, K, device="cuda").bfloat16() * K ** -0.5 for _ in range(NCOPY)]
     C = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
     ref = (A.float() @ Ws[0].float().t())
     line = f"{name:9s} M={M:4d} N={N:5d} K={K:4d} |"
-    for tile in (4, 24, 34, 44, 9):
+    for tile in (4, 5, 7, 8, 10, 0):
         rc = lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(Ws[0]), K, None, abi.ptr(C), N, 0, M, N, K, 1, abi.EPI_BF16, None, tile, None, st())
         if rc != 0:
             line += f" t{tile}:  n/a "
