@@ -32,6 +32,7 @@ SIGNATURES = {
     "deer_vit_embed_lnpre": [P, P, P, P, P, P, I, I, I, F, P],
     "deer_embed_tokens": [P, P, P, P, I, I, I, I, I, P],
     "deer_broadcast_rows": [P, P, L, I, P],
+    "deer_head_pool": [P, P, I, I, I, I, P, I, I, P],
     "deer_head_lstm_layer": [P, L, I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, P, I, I, P],
     "deer_head_fc": [P, I, I, I, P, P, P, P, P, P, P, P, I, P, I, F, P, I, I, P],
     "deer_head_final": [P, I, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, I, I, P, F, P],

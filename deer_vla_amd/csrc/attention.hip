@@ -194,16 +194,26 @@ __global__ __launch_bounds__(256) void xattn_small_kernel(const float* __restric
   text_time += blockIdx.y * T;
   out = out_is_f32 ? (void*)(reinterpret_cast<float*>(out) + (long)blockIdx.y * T * ldo)
                    : (void*)(reinterpret_cast<bf16_t*>(out) + (long)blockIdx.y * T * ldo);
-  for (int idx = tid; idx < T * 64; idx += 256) {
-    const int t = idx >> 6, d = idx & 63;
-    float a = 0.f;
-    for (int s = 0; s < s_in; ++s) a += qslab[(long)s * slab_stride + (long)t * ldqs + h * 64 + d];
-    qs[t][d] = a * scale;
+  // q: split-K reduce, 4 floats per thread
+  for (int idx = tid; idx < T * 16; idx += 256) {
+    const int t = idx >> 4, d4 = (idx & 15) * 4;
+    const float* p = qslab + (long)t * ldqs + h * 64 + d4;
+    float4 a = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = 0; s < s_in; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (long)s * slab_stride);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    qs[t][d4] = a.x * scale; qs[t][d4 + 1] = a.y * scale; qs[t][d4 + 2] = a.z * scale; qs[t][d4 + 3] = a.w * scale;
   }
-  for (int idx = tid; idx < n_kv * 64; idx += 256) {
-    const int j = idx >> 6, d = idx & 63;
-    ks[j][d] = kv[(long)j * ldkv + h * 64 + d];
-    vs[j][d] = kv[(long)j * ldkv + inner + h * 64 + d];
+  // k, v of this head: 16-byte loads (8 bf16), 8 per media row
+  for (int idx = tid; idx < n_kv * 16; idx += 256) {
+    const int j = idx >> 4, part = idx & 15, isv = part >> 3, seg = (part & 7) * 8;
+    const uint4 v = *reinterpret_cast<const uint4*>(kv + (long)j * ldkv + (isv ? inner : 0) + h * 64 + seg);
+    bf16_t* dst = (isv ? &vs[j][seg] : &ks[j][seg]);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) reinterpret_cast<uint32_t*>(dst)[e] = u[e];
   }
   __syncthreads();
   for (int idx = tid; idx < T * n_kv; idx += 256) {

@@ -28,6 +28,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CTL_PREV_ACTION 8   // float[8]: action_list[-1] (pose6, gripper, pad)
 #define CTL_OUT_ACTION 16   // float[8]: committed action (pose6, gripper prob, gripper logit)
 #define CTL_DELTAS 24       // float[16]: delta per exit slot of this step (NaN = not evaluated)
+#define CTL_N_EXITED 40     // (block 0 only) number of environments that exited in this step
 #define CTL_WORDS 64
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }

@@ -70,6 +70,34 @@ __device__ __forceinline__ void block_ln(const float* __restrict__ src, float* d
   }
 }
 
+// ---- token pooling (AdaptiveMaxPool1d / AvgPool over the T text tokens, action_head.py:480-483,519-520) --------------
+// feats: [B][T][d] (env b at feats + b*T*d) -> pooled [B][d].  One launch per head evaluation, so that the 256
+// workgroups of the first LSTM layer do not each re-read B*T*d features.
+__global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict__ feats, float* __restrict__ pooled, int T, int d,
+                                                        int avg, int B, const int* ctl, int kind, int layer) {
+  if (head_skip(ctl, kind, layer, B)) return;
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= d) return;
+  const float* x = feats + ((long)b * T) * d + i;
+  float a = x[0];
+  if (avg) {
+    for (int t = 1; t < T; ++t) a += x[(long)t * d];
+    a /= (float)T;
+  } else {
+    for (int t = 1; t < T; ++t) a = fmaxf(a, x[(long)t * d]);
+  }
+  pooled[(long)b * d + i] = a;
+}
+
+extern "C" int deer_head_pool(const float* feats, float* pooled, int T, int d, int avg, int B, const int* ctl, int kind, int layer,
+                              void* stream) {
+  if (T <= 0 || d <= 0 || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(head_pool_kernel, dim3((d + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), feats, pooled, T, d,
+                     avg, B, ctl, kind, layer);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
 // ---- one LSTM layer, single time step (torch.nn.LSTM gate order i,f,g,o), B environments -------------------------
 // wave -> hidden unit j: rows j, H+j, 2H+j, 3H+j of [W_ih | W_hh]; c' = s(f) c + s(i) tanh(g); h' = s(o) tanh(c').
 // x_src: X_POOL_*: feats [B][T_stride rows][in_dim] (env b at x_src + b*x_bstride), pooled over the first T rows;
@@ -364,6 +392,9 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
         for (int i = 0; i < 8; ++i) outa[i] = cur[i];
         ctl[CTL_EXIT_LAYER] = layer;
         ctl[CTL_EXIT_FLAG] = 1;
+        // last environment of the batch to exit raises the batch-global flag (one workgroup per environment runs
+        // concurrently, hence the device-scope atomic)
+        if (atomicAdd(&ctl0[CTL_N_EXITED], 1) + 1 == B) ctl0[CTL_ALL_EXITED] = 1;
       }
     }
     *flag = commit ? 1 : 0;
@@ -379,16 +410,6 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
   }
 }
 
-// after the per-environment gates: ALL_EXITED = every environment of the batch has its EXIT_FLAG set
-__global__ void head_all_exited_kernel(int* ctl0, int B) {
-  if (threadIdx.x == 0) {
-    if (ctl0[CTL_ALL_EXITED] != 0) return;
-    int all = 1;
-    for (int b = 0; b < B; ++b) all &= (ctl0[b * CTL_WORDS + CTL_EXIT_FLAG] != 0);
-    ctl0[CTL_ALL_EXITED] = all;
-  }
-}
-
 extern "C" int deer_head_final(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0,
                                const float* lnw1, const float* lnb1, const void* Wa, const float* ba, const void* Wg, const float* bg,
                                int* ctl, int kind, int layer, int slot, const float* thresholds, int force, int thr_type, int leq,
@@ -401,8 +422,6 @@ extern "C" int deer_head_final(const float* src, int src_stride, int in_dim, int
   hipLaunchKernelGGL(head_final_kernel, dim3(B), dim3(512), smem, st, src, src_stride, in_dim, pro, lnw0, lnb0, lnw1, lnb1,
                      reinterpret_cast<const bf16_t*>(Wa), ba, reinterpret_cast<const bf16_t*>(Wg), bg, ctl, kind, layer, slot,
                      thresholds, force, thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps);
-  if (ctl != nullptr && kind != KIND_PSEUDO)
-    hipLaunchKernelGGL(head_all_exited_kernel, dim3(1), dim3(64), 0, st, ctl, B);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
@@ -420,6 +439,7 @@ __global__ void ctl_begin_step_kernel(int* ctl0, const int* hold_src, int B) {
     if (b == 0) {
       ctl[CTL_HOLD] = (hold_src != nullptr) ? *hold_src : 0;
       ctl[CTL_ALL_EXITED] = 0;
+      ctl[CTL_N_EXITED] = 0;
     }
   }
   if (threadIdx.x < 16) reinterpret_cast<float*>(ctl + CTL_DELTAS)[threadIdx.x] = __int_as_float(0x7fc00000);

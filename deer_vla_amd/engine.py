@@ -259,6 +259,7 @@ class DeerEngine:
         self.h_shadow, self.c_shadow = z(Lh, B, H), z(Lh, B, H)   # commit target in shadow (calibration) mode
         dims = cfg.mlp_hidden_dims
         self.z_fc = [z(B, 2 * dm) for dm in dims]
+        self.pooled = z(B, d)                                     # max/avg-pooled features of the current head evaluation
         self.ctl = torch.zeros(B * abi.CTL_WORDS, dtype=torch.int32, device=dev)   # one control block per environment
         self.ctl_host = torch.zeros(B * abi.CTL_WORDS, dtype=torch.int32).pin_memory()
         self.hold_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -414,10 +415,11 @@ class DeerEngine:
         feats = self.hidden[layer] if feats is None else feats      # [B*T, d]: environment b owns rows b*T .. b*T+T-1
         h_prev = self.h_state if h_prev is None else h_prev
         c_prev = self.c_state if c_prev is None else c_prev
-        pool = abi.X_POOL_MAX if cfg.pooling == "max" else abi.X_POOL_AVG
+        abi.check(lib.deer_head_pool(abi.ptr(feats), abi.ptr(self.pooled), T, d, 0 if cfg.pooling == "max" else 1, B, c, kind, layer, st),
+                  "deer_head_pool")
         for l, Lw in enumerate(Hd["lstm"]):
             if l == 0:
-                src, bstride, mode, in_dim, lnw, lnb = feats, T * d, pool, d, None, None
+                src, bstride, mode, in_dim, lnw, lnb = self.pooled, d, abi.X_RAW, d, None, None
             else:
                 prev = Hd["lstm"][l - 1]
                 src, bstride, in_dim = self.h_tmp[l - 1], H, H

@@ -38,6 +38,7 @@ extern "C" {
 #define DEER_CTL_PREV_ACTION 8   /* float[8] */
 #define DEER_CTL_OUT_ACTION 16   /* float[8]: pose[6], gripper prob, gripper logit */
 #define DEER_CTL_DELTAS 24       /* float[16] */
+#define DEER_CTL_N_EXITED 40   /* block 0: environments exited so far in this step */
 #define DEER_CTL_WORDS 64
 
 /* GEMM epilogues (deer_gemm_bf16_nt) */
@@ -136,6 +137,8 @@ int deer_broadcast_rows(const float* src, float* dst, long n, int batch, void* s
 /* ---- action head + exit gate (robot_flamingo/models/action_head.py:499-611, value_net.py:105-133,277-297) -----
  * All three evaluate a BATCH of B <= 8 independent environments per launch (weights read once): features [B][T][d],
  * LSTM state tensors [L][B][H], control blocks ctl + b*DEER_CTL_WORDS, exit decision per environment. */
+int deer_head_pool(const float* feats, float* pooled, int T, int d, int avg, int B, const int* ctl, int kind, int layer,
+                   void* stream);   /* AdaptiveMax/AvgPool1d over the text tokens (action_head.py:480-483,519-520) */
 int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w, const float* ln_b,
                          const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh, const float* h_prev,
                          const float* c_prev, float* h_out, float* c_out, int H, int B, float eps, const int* ctl, int kind,
