@@ -22,11 +22,17 @@
 #define AM_KPITCH 72          // K rows: 64 + 8 bf16
 #define AM_MAXT 20            // max 16-key tiles (kv_len <= 320)
 
-__global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
-                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
+// Optional extras (gated x-attn inside the LLM, helpers.py:192-232): Q given as f32 split-K partial slabs
+// (q_slabs > 0: Q points to f32, reduced while loading), keys masked by media time (text_time[q] == key/n_per_media + 1,
+// rows with text_time == 0 zeroed), f32 output, early-exit control block.
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const void* __restrict__ Qv, const bf16_t* __restrict__ Kp,
+                                                        const bf16_t* __restrict__ V, void* __restrict__ Ov,
                                                         int q_len, int kv_len, int ldq, int ldk, int ldv, int ldo,
                                                         long q_bstride, long k_bstride, long v_bstride, long o_bstride,
-                                                        float scale) {
+                                                        float scale, int q_slabs, long q_slab_stride,
+                                                        const int* __restrict__ text_time, int n_per_media, int out_is_f32,
+                                                        const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int kvpad = (kv_len + 31) & ~31;
   const int vpitch = kvpad + 8;
@@ -35,7 +41,6 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z;
-  const bf16_t* Qb = Q + b * q_bstride + h * AM_HD;
   const bf16_t* Kb = Kp + b * k_bstride + h * AM_HD;
   const bf16_t* Vb = V + b * v_bstride + h * AM_HD;
 
@@ -63,9 +68,25 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     uint4 v = uint4{0, 0, 0, 0};
-    if (q0 + c < q_len) v = *reinterpret_cast<const uint4*>(Qb + (long)(q0 + c) * ldq + ks * 32 + g * 8);
+    if (q0 + c < q_len) {
+      if (q_slabs > 0) {                                     // f32 split-K partials -> sum -> bf16
+        const float* qp = reinterpret_cast<const float*>(Qv) + b * q_bstride + h * AM_HD + (long)(q0 + c) * ldq + ks * 32 + g * 8;
+        float4 a0 = float4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        for (int si = 0; si < q_slabs; ++si) {
+          const float4 x0 = *reinterpret_cast<const float4*>(qp + (long)si * q_slab_stride);
+          const float4 x1 = *reinterpret_cast<const float4*>(qp + (long)si * q_slab_stride + 4);
+          a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+          a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+        }
+        v = uint4{pack2bf(a0.x, a0.y), pack2bf(a0.z, a0.w), pack2bf(a1.x, a1.y), pack2bf(a1.z, a1.w)};
+      } else {
+        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(Qv) + b * q_bstride + h * AM_HD +
+                                            (long)(q0 + c) * ldq + ks * 32 + g * 8);
+      }
+    }
     qf[ks] = __builtin_bit_cast(bf16x8, v);
   }
+  const int tt_q = (text_time != nullptr && q0 + c < q_len) ? text_time[b * q_len + q0 + c] : -1;
 
   // ---- S^T tiles: s[t][r] = S[q = c][key = t*16 + g*4 + r] ----
   f32x4 s[AM_MAXT];
@@ -88,7 +109,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = t * 16 + g * 4 + r;
-        const float v = (key < kv_len) ? s[t][r] * scale : -INFINITY;
+        float v = (key < kv_len) ? s[t][r] * scale : -INFINITY;
+        if (tt_q >= 0 && key < kv_len && tt_q != key / n_per_media + 1) v = -3.4028234663852886e38f;   // helpers.py:218
         s[t][r] = v;
         mx = fmaxf(mx, v);
       }
@@ -110,7 +132,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
   }
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.f / sum;
+  const float inv = (tt_q == 0) ? 0.f : 1.f / sum;         // helpers.py:223-229: no preceding media -> zero row
 
   // ---- O^T = V^T * P^T : k-slot (g, j<4) <-> key 32*ch + g*4 + j ; (g, j>=4) <-> key 32*ch + 16 + g*4 + (j-4) ----
   f32x4 o[4];
@@ -138,17 +160,23 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
   }
   // lane holds O[q = q0 + c][d = dt*16 + g*4 .. +3]
   if (q0 + c < q_len) {
-    bf16_t* op = O + b * o_bstride + (long)(q0 + c) * ldo + h * AM_HD + g * 4;
+    const long off = b * o_bstride + (long)(q0 + c) * ldo + h * AM_HD + g * 4;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<uint2*>(op + dt * 16) =
-          uint2{pack2bf(o[dt][0] * inv, o[dt][1] * inv), pack2bf(o[dt][2] * inv, o[dt][3] * inv)};
+    for (int dt = 0; dt < 4; ++dt) {
+      if (out_is_f32)
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(Ov) + off + dt * 16) =
+            float4{o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+      else
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Ov) + off + dt * 16) =
+            uint2{pack2bf(o[dt][0] * inv, o[dt][1] * inv), pack2bf(o[dt][2] * inv, o[dt][3] * inv)};
+    }
   }
 }
 
-extern "C" int deer_attn_mfma_hd64(const void* Q, const void* K, const void* V, void* O, int batch, int heads,
-                                   int q_len, int kv_len, int ldq, int ldk, int ldv, int ldo, long q_bstride,
-                                   long k_bstride, long v_bstride, long o_bstride, float scale, void* stream) {
+static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O, int batch, int heads, int q_len, int kv_len,
+                            int ldq, int ldk, int ldv, int ldo, long q_bstride, long k_bstride, long v_bstride, long o_bstride,
+                            float scale, int q_slabs, long q_slab_stride, const int* text_time, int n_per_media, int out_is_f32,
+                            const int* ctl, void* stream) {
   if (q_len <= 0 || kv_len <= 0 || kv_len > AM_MAXT * 16 || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3))
     return DEER_ERR_SHAPE;
   const int kvpad = (kv_len + 31) & ~31;
@@ -161,12 +189,31 @@ extern "C" int deer_attn_mfma_hd64(const void* Q, const void* K, const void* V, 
     attr_set = true;
   }
   dim3 grid((q_len + 63) / 64, heads, batch);
-  hipLaunchKernelGGL(attn_mfma_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const bf16_t*>(Q), reinterpret_cast<const bf16_t*>(K),
-                     reinterpret_cast<const bf16_t*>(V), reinterpret_cast<bf16_t*>(O), q_len, kv_len, ldq, ldk, ldv, ldo,
-                     q_bstride, k_bstride, v_bstride, o_bstride, scale);
+  hipLaunchKernelGGL(attn_mfma_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), Q,
+                     reinterpret_cast<const bf16_t*>(K), reinterpret_cast<const bf16_t*>(V), O, q_len, kv_len, ldq, ldk, ldv, ldo,
+                     q_bstride, k_bstride, v_bstride, o_bstride, scale, q_slabs, q_slab_stride, text_time, n_per_media, out_is_f32,
+                     ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
+}
+
+extern "C" int deer_attn_mfma_hd64(const void* Q, const void* K, const void* V, void* O, int batch, int heads,
+                                   int q_len, int kv_len, int ldq, int ldk, int ldv, int ldo, long q_bstride,
+                                   long k_bstride, long v_bstride, long o_bstride, float scale, void* stream) {
+  return launch_attn_mfma(Q, K, V, O, batch, heads, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride,
+                          scale, 0, 0, nullptr, 1, 0, nullptr, stream);
+}
+
+// MaskedCrossAttention core on the MFMA kernel: q = sum_s qslab[s] (f32 [batch*T, ldqs], head h at column h*64),
+// kv bf16 [batch*n_kv, ldkv] (k at column h*64, v at inner + h*64), media mask from text_time, out f32/bf16 [batch*T, ldo].
+extern "C" int deer_xattn_mfma(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv, int inner,
+                               const int* text_time, int n_per_media, void* out, int out_is_f32, int ldo, int T, int n_kv,
+                               int heads, int batch, float scale, const int* ctl, void* stream) {
+  if (s_in <= 0 || n_per_media <= 0 || text_time == nullptr) return DEER_ERR_SHAPE;
+  const bf16_t* kvp = reinterpret_cast<const bf16_t*>(kv);
+  return launch_attn_mfma(qslab, kvp, kvp + inner, out, batch, heads, T, n_kv, ldqs, ldkv, ldkv, ldo, (long)T * ldqs,
+                          (long)n_kv * ldkv, (long)n_kv * ldkv, (long)T * ldo, scale, s_in, slab_stride, text_time, n_per_media,
+                          out_is_f32, ctl, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

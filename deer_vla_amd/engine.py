@@ -376,10 +376,10 @@ class DeerEngine:
             self._resadd(R, pending, X["nw"], X["nb"], ctl=ctl)
             S, stride = self._skinny(X["wq"], self.xinner, d, R, self.slab_b, A=self.xn, ctl=ctl)
             kv_off = X["kv_index"] * 2 * self.xinner * 2          # bytes into a kv_all row
-            abi.check(self.lib.deer_xattn_small(abi.ptr(self.slab_b), S, stride, self.xinner, abi.ptr(self.kv_all, kv_off),
+            abi.check(self.lib.deer_xattn_mfma(abi.ptr(self.slab_b), S, stride, self.xinner, abi.ptr(self.kv_all, kv_off),
                                                 self.n_xattn * 2 * self.xinner, self.xinner, abi.ptr(self.text_time),
                                                 cfg.n_media, abi.ptr(self.ao), 1, self.xinner, T, cfg.n_media,
-                                                cfg.xattn_heads, B, cfg.xattn_dim_head ** -0.5, c, st), "deer_xattn_small")
+                                                cfg.xattn_heads, B, cfg.xattn_dim_head ** -0.5, c, st), "deer_xattn_mfma")
             S, stride = self._skinny(X["wo"], d, self.xinner, R, self.slab_a, A=self.ao, lda=self.xinner, ctl=ctl)
             self._resadd(R, (self.slab_a, S, stride, X["ag"]), X["fnw"], X["fnb"], ctl=ctl)
             S, stride = self._skinny(X["w1"], cfg.xattn_ff_mult * d, d, R, self.slab_b, A=self.xn, ctl=ctl)

@@ -100,7 +100,13 @@ int deer_pack_weight_mfma16(const void* W, void* Wp, int N, int K, void* stream)
 int deer_attn_mfma_hd64(const void* Q, const void* K, const void* V, void* O, int batch, int heads, int q_len, int kv_len,
                         int ldq, int ldk, int ldv, int ldo, long q_bstride, long k_bstride, long v_bstride, long o_bstride,
                         float scale, void* stream);
-/* deer_xattn_small: MaskedCrossAttention core (helpers.py:192-232): q from split-K slabs (x scale), kv bf16
+/* deer_xattn_mfma: MaskedCrossAttention core (helpers.py:192-232) on the MFMA attention kernel: q = sum of f32 split-K slabs
+ * [batch*T, ldqs], kv bf16 [batch*n_kv, ldkv] (k at col h*64, v at col inner+h*64), key j visible iff
+ * text_time[t] == j/n_per_media + 1, rows with text_time == 0 zeroed; out f32 or bf16 [batch*T, ldo]. */
+int deer_xattn_mfma(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv, int inner,
+                    const int* text_time, int n_per_media, void* out, int out_is_f32, int ldo, int T, int n_kv, int heads,
+                    int batch, float scale, const int* ctl, void* stream);
+/* deer_xattn_small: the same op as fp32 VALU code (kept as a second implementation for cross-checks) (helpers.py:192-232): q from split-K slabs (x scale), kv bf16
  * [n_kv, ldkv] (k at col h*64, v at col inner+h*64), mask text_time[t] == j/n_per_media + 1, rows with
  * text_time == 0 zeroed; out bf16 or f32 [T, ldo]. */
 int deer_xattn_small(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv, int inner,

@@ -379,3 +379,39 @@ def test_batched_small_attention_and_embedding(lib):
     torch.cuda.synchronize()
     assert torch.equal(x, wte[ids.reshape(-1)].float())
     assert t2.view(B, T).tolist() == [[1, 1, 1, 2, 2, 2, 2, 2, 2], [0, 0, 1, 1, 1, 1, 1, 1, 1], [1] * 9]
+
+
+def test_xattn_mfma_matches_fp32_implementation(lib):
+    """The MFMA x-attn path (q reduced from f32 slabs -> bf16, P in bf16) against the fp32 VALU implementation and torch."""
+    B, T, n_kv, heads, inner = 3, 14, 128, 8, 512
+    ldkv = 2 * inner * 2                                     # two layers' K/V side by side; use the second
+    s_in = 4
+    qs = dev(rnd(s_in, 64, inner, seed=61))
+    kv = dev(rnd(B * n_kv, ldkv, seed=62), torch.bfloat16)
+    tt = torch.ones(B * T, dtype=torch.int32, device="cuda")
+    tt[T + 2] = 0                                            # env 1, token 2: no preceding media -> zero row
+    off = 2 * inner
+    o_ref = torch.zeros(B * T, inner, device="cuda")
+    o_mf = torch.zeros(B * T, inner, device="cuda")
+    args = (abi.ptr(qs), s_in, 64 * inner, inner, abi.ptr(kv, off * 2), ldkv, inner, abi.ptr(tt), 128)
+    abi.check(lib.deer_xattn_small(*args, abi.ptr(o_ref), 1, inner, T, n_kv, heads, B, 64 ** -0.5, None, st()), "small")
+    abi.check(lib.deer_xattn_mfma(*args, abi.ptr(o_mf), 1, inner, T, n_kv, heads, B, 64 ** -0.5, None, st()), "mfma")
+    torch.cuda.synchronize()
+    assert rel_err(o_mf, o_ref) < 6e-3
+    assert float(o_mf[T + 2].abs().max()) == 0.0
+    for b in range(B):
+        q = qs.sum(0)[b * T:(b + 1) * T].view(T, heads, 64).transpose(0, 1) * 64 ** -0.5
+        kb = kv[b * n_kv:(b + 1) * n_kv, off:off + 2 * inner]
+        k = kb[:, :inner].float().view(n_kv, heads, 64).transpose(0, 1)
+        v = kb[:, inner:].float().view(n_kv, heads, 64).transpose(0, 1)
+        ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(0, 1).reshape(T, inner)
+        if b == 1:
+            ref[2] = 0
+        assert rel_err(o_mf[b * T:(b + 1) * T], ref) < 6e-3, b
+    # bf16 output + exit flag
+    ob = torch.full((B * T, inner), 3.0, device="cuda", dtype=torch.bfloat16)
+    ctl = torch.zeros(abi.CTL_WORDS, dtype=torch.int32, device="cuda")
+    ctl[abi.CTL_ALL_EXITED] = 1
+    abi.check(lib.deer_xattn_mfma(*args, abi.ptr(ob), 0, inner, T, n_kv, heads, B, 64 ** -0.5, abi.ptr(ctl), st()), "mfma")
+    torch.cuda.synchronize()
+    assert float(ob.float().min()) == 3.0
