@@ -25,6 +25,7 @@
 // Optional extras (gated x-attn inside the LLM, helpers.py:192-232): Q given as f32 split-K partial slabs
 // (q_slabs > 0: Q points to f32, reduced while loading), keys masked by media time (text_time[q] == key/n_per_media + 1,
 // rows with text_time == 0 zeroed), f32 output, early-exit control block.
+template <bool XATTN>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(const void* __restrict__ Qv, const bf16_t* __restrict__ Kp,
                                                         const bf16_t* __restrict__ V, void* __restrict__ Ov,
                                                         int q_len, int kv_len, int ldq, int ldk, int ldv, int ldo,
@@ -44,32 +45,16 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const void* __restrict__
   const bf16_t* Kb = Kp + b * k_bstride + h * AM_HD;
   const bf16_t* Vb = V + b * v_bstride + h * AM_HD;
 
-  // ---- stage K (row-major) and V (transposed) for this head; rows >= kv_len are zero ----
-  for (int idx = tid; idx < kvpad * 8; idx += 256) {
-    const int row = idx >> 3, seg = idx & 7;
-    uint4 kv = uint4{0, 0, 0, 0}, vv = uint4{0, 0, 0, 0};
-    if (row < kv_len) {
-      kv = *reinterpret_cast<const uint4*>(Kb + (long)row * ldk + seg * 8);
-      vv = *reinterpret_cast<const uint4*>(Vb + (long)row * ldv + seg * 8);
-    }
-    *reinterpret_cast<uint4*>(Ks + row * AM_KPITCH + seg * 8) = kv;
-    const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) Vt[(seg * 8 + e) * vpitch + row] = ve[e];
-  }
-  __syncthreads();
-
   const int q0 = blockIdx.x * 64 + wave * 16;
-  if (q0 >= q_len) return;
-  const int nt = kvpad >> 4;
 
-  // Q fragments (MFMA "B" operand: B[k = d][n = query]); rows >= q_len are zero
+  // Q fragments first (MFMA "B" operand: B[k = d][n = query]; rows >= q_len are zero): their global-load latency
+  // overlaps the K/V staging below instead of following the barrier
   bf16x8 qf[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     uint4 v = uint4{0, 0, 0, 0};
     if (q0 + c < q_len) {
-      if (q_slabs > 0) {                                     // f32 split-K partials -> sum -> bf16
+      if (XATTN) {                                           // f32 split-K partials -> sum -> bf16
         const float* qp = reinterpret_cast<const float*>(Qv) + b * q_bstride + h * AM_HD + (long)(q0 + c) * ldq + ks * 32 + g * 8;
         float4 a0 = float4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
         for (int si = 0; si < q_slabs; ++si) {
@@ -86,7 +71,39 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const void* __restrict__
     }
     qf[ks] = __builtin_bit_cast(bf16x8, v);
   }
-  const int tt_q = (text_time != nullptr && q0 + c < q_len) ? text_time[b * q_len + q0 + c] : -1;
+  // media-time mask (x-attn only): key j is visible iff text_time[q] == j / n_per_media + 1, i.e. j in [klo, khi)
+  const int tt_q = (XATTN && q0 + c < q_len) ? text_time[b * q_len + q0 + c] : 1;
+  const int klo = (tt_q - 1) * n_per_media, khi = tt_q * n_per_media;
+
+  // ---- stage K (row-major) and V (transposed) for this head; rows >= kv_len are zero ----
+  // two key rows per thread: K rows are copied as they are, V is transposed with 32-bit LDS stores that carry the
+  // same d of two adjacent keys (half the store instructions of a per-element transpose)
+  for (int idx = tid; idx < (kvpad >> 1) * 8; idx += 256) {
+    const int row = (idx >> 3) * 2, seg = idx & 7;
+    uint4 k0 = uint4{0, 0, 0, 0}, k1 = k0, v0 = k0, v1 = k0;
+    if (row < kv_len) {
+      k0 = *reinterpret_cast<const uint4*>(Kb + (long)row * ldk + seg * 8);
+      v0 = *reinterpret_cast<const uint4*>(Vb + (long)row * ldv + seg * 8);
+    }
+    if (row + 1 < kv_len) {
+      k1 = *reinterpret_cast<const uint4*>(Kb + (long)(row + 1) * ldk + seg * 8);
+      v1 = *reinterpret_cast<const uint4*>(Vb + (long)(row + 1) * ldv + seg * 8);
+    }
+    *reinterpret_cast<uint4*>(Ks + row * AM_KPITCH + seg * 8) = k0;
+    *reinterpret_cast<uint4*>(Ks + (row + 1) * AM_KPITCH + seg * 8) = k1;
+    const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bq[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t even = (a[e] & 0xffffu) | (bq[e] << 16);          // d = seg*8 + 2e   : (key row, key row+1)
+      const uint32_t odd = (a[e] >> 16) | (bq[e] & 0xffff0000u);       // d = seg*8 + 2e+1
+      *reinterpret_cast<uint32_t*>(Vt + (seg * 8 + 2 * e) * vpitch + row) = even;
+      *reinterpret_cast<uint32_t*>(Vt + (seg * 8 + 2 * e + 1) * vpitch + row) = odd;
+    }
+  }
+  __syncthreads();
+
+  if (q0 >= q_len) return;
+  const int nt = kvpad >> 4;
 
   // ---- S^T tiles: s[t][r] = S[q = c][key = t*16 + g*4 + r] ----
   f32x4 s[AM_MAXT];
@@ -110,7 +127,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const void* __restrict__
       for (int r = 0; r < 4; ++r) {
         const int key = t * 16 + g * 4 + r;
         float v = (key < kv_len) ? s[t][r] * scale : -INFINITY;
-        if (tt_q >= 0 && key < kv_len && tt_q != key / n_per_media + 1) v = -3.4028234663852886e38f;   // helpers.py:218
+        if (XATTN && key < kv_len && (key < klo || key >= khi)) v = -3.4028234663852886e38f;   // helpers.py:218
         s[t][r] = v;
         mx = fmaxf(mx, v);
       }
@@ -132,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const void* __restrict__
   }
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
-  const float inv = (tt_q == 0) ? 0.f : 1.f / sum;         // helpers.py:223-229: no preceding media -> zero row
+  const float inv = (XATTN && tt_q == 0) ? 0.f : 1.f / sum;   // helpers.py:223-229: no preceding media -> zero row
 
   // ---- O^T = V^T * P^T : k-slot (g, j<4) <-> key 32*ch + g*4 + j ; (g, j>=4) <-> key 32*ch + 16 + g*4 + (j-4) ----
   f32x4 o[4];
@@ -182,17 +199,25 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
   const int kvpad = (kv_len + 31) & ~31;
   const int smem = (kvpad * AM_KPITCH + AM_HD * (kvpad + 8)) * (int)sizeof(bf16_t);
   static bool attr_set = false;
+  constexpr int max_smem = (AM_MAXT * 16 * AM_KPITCH + AM_HD * (AM_MAXT * 16 + 8)) * 2;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (AM_MAXT * 16 * AM_KPITCH + AM_HD * (AM_MAXT * 16 + 8)) * 2) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            max_smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            max_smem) != hipSuccess)
       return DEER_ERR_LAUNCH;
     attr_set = true;
   }
   dim3 grid((q_len + 63) / 64, heads, batch);
-  hipLaunchKernelGGL(attn_mfma_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), Q,
-                     reinterpret_cast<const bf16_t*>(K), reinterpret_cast<const bf16_t*>(V), O, q_len, kv_len, ldq, ldk, ldv, ldo,
-                     q_bstride, k_bstride, v_bstride, o_bstride, scale, q_slabs, q_slab_stride, text_time, n_per_media, out_is_f32,
-                     ctl);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bf16_t* kp = reinterpret_cast<const bf16_t*>(K);
+  const bf16_t* vp = reinterpret_cast<const bf16_t*>(V);
+  if (q_slabs > 0)
+    hipLaunchKernelGGL(attn_mfma_kernel<true>, grid, dim3(256), smem, st, Q, kp, vp, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride,
+                       k_bstride, v_bstride, o_bstride, scale, q_slabs, q_slab_stride, text_time, n_per_media, out_is_f32, ctl);
+  else
+    hipLaunchKernelGGL(attn_mfma_kernel<false>, grid, dim3(256), smem, st, Q, kp, vp, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride,
+                       k_bstride, v_bstride, o_bstride, scale, q_slabs, q_slab_stride, text_time, n_per_media, out_is_f32, ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

@@ -6,42 +6,41 @@
 // ---- LayerNorm over rows: f32 in -> bf16 out (GEMM A operand) and/or f32 out -------------------------
 // Row r of batch b is read at  x + b*in_bstride + r*in_rstride  and written at  out + b*out_bstride + r*out_rstride
 // (lets the Perceiver write LN_media(x) and LN_latents(latents) into one [x; latents] buffer, helpers.py:51).
-// one WAVE per row (4 rows per workgroup): the row lives in registers, statistics by wave shuffles only (no LDS, no
-// block barrier) - these launches are latency-bound (514 rows x 1024), so the dependent-step count is what matters.
+// one workgroup per row; the row lives in registers (float4 per thread), two block reductions.
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, long in_rstride, long in_bstride,
                                                       int rows_per_batch, int total_rows, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, bf16_t* __restrict__ out_bf,
                                                       float* __restrict__ out_f32, long out_rstride, long out_bstride,
                                                       int C, float eps) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= total_rows) return;
+  __shared__ float red[16];
+  const int row = blockIdx.x;
   const int b = row / rows_per_batch, r = row - b * rows_per_batch;
   const float* xr = x + b * in_bstride + r * in_rstride;
   const int n4 = C >> 2;
-  float4 v[16];                                            // C <= 4096
+  float4 v[4];                                             // C <= 4096
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int i4 = lane + j * 64;
+  for (int j = 0; j < 4; ++j) {
+    const int i4 = threadIdx.x + j * 256;
     v[j] = float4{0.f, 0.f, 0.f, 0.f};
     if (i4 < n4) {
       v[j] = *reinterpret_cast<const float4*>(xr + (long)i4 * 4);
       s += v[j].x + v[j].y + v[j].z + v[j].w;
     }
   }
-  const float mean = wave_sum(s) / C;
+  const float mean = block_sum(s, red) / C;
   float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
-    if (lane + j * 64 < n4) {
+  for (int j = 0; j < 4; ++j)
+    if (threadIdx.x + j * 256 < n4) {
       const float a = v[j].x - mean, bb = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
       q += a * a + bb * bb + c * c + d * d;
     }
-  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+  const float rstd = rsqrtf(block_sum(q, red) / C + eps);
   const long o = b * out_bstride + r * out_rstride;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int i4 = lane + j * 64;
+  for (int j = 0; j < 4; ++j) {
+    const int i4 = threadIdx.x + j * 256;
     if (i4 < n4) {
       const float4 g = *reinterpret_cast<const float4*>(gamma + (long)i4 * 4);
       float4 y;
@@ -64,7 +63,7 @@ extern "C" int deer_layernorm_rows(const float* x, long in_rstride, long in_bstr
       (out_bf16 == nullptr && out_f32 == nullptr) || (in_rstride & 3) || (in_bstride & 3) || (out_rstride & 3) || (out_bstride & 3))
     return DEER_ERR_SHAPE;
   const int total = rows_per_batch * batch;
-  hipLaunchKernelGGL(ln_rows_kernel, dim3((total + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(ln_rows_kernel, dim3(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      x, in_rstride, in_bstride, rows_per_batch, total, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16),
                      out_f32, out_rstride, out_bstride, C, eps);
   DEER_LAUNCH_CHECK();
