@@ -403,9 +403,9 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
                                                              void* __restrict__ out, int out_is_f32, int ldo, int T,
                                                              const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
-  __shared__ float qs[MA_MAXT][128 + 1];
-  __shared__ float ks[MA_MAXT][128 + 1];
-  __shared__ float vs[MA_MAXT][128 + 1];
+  __shared__ __attribute__((aligned(16))) float qs[MA_MAXT][128 + 4];
+  __shared__ __attribute__((aligned(16))) float ks[MA_MAXT][128 + 4];
+  __shared__ __attribute__((aligned(16))) float vs[MA_MAXT][128 + 4];
   __shared__ float sim[MA_MAXT][MA_MAXT + 1];
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * d_model;
@@ -413,12 +413,13 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
   if (key_mask != nullptr) key_mask += blockIdx.y * T;
   out = out_is_f32 ? (void*)(reinterpret_cast<float*>(out) + (long)blockIdx.y * T * ldo)
                    : (void*)(reinterpret_cast<bf16_t*>(out) + (long)blockIdx.y * T * ldo);
-  for (int idx = tid; idx < T * hd; idx += 256) {
-    const int t = idx / hd, d = idx - t * hd;
+  const int hd4 = hd >> 2;
+  for (int idx = tid; idx < T * hd4; idx += 256) {
+    const int t = idx / hd4, d = (idx - t * hd4) * 4;
     const float* p = qkv + (long)t * ld + h * hd + d;
-    qs[t][d] = p[0];
-    ks[t][d] = p[d_model];
-    vs[t][d] = p[2 * d_model];
+    *reinterpret_cast<float4*>(&qs[t][d]) = *reinterpret_cast<const float4*>(p);
+    *reinterpret_cast<float4*>(&ks[t][d]) = *reinterpret_cast<const float4*>(p + d_model);
+    *reinterpret_cast<float4*>(&vs[t][d]) = *reinterpret_cast<const float4*>(p + 2 * d_model);
   }
   __syncthreads();
   const float sc = rsqrtf((float)hd);
@@ -426,7 +427,12 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
   for (int idx = tid; idx < T * T; idx += 256) {
     const int i = idx / T, j = idx - i * T;
     float a = 0.f;
-    for (int d = 0; d < hd; ++d) a += qs[i][d] * ks[j][d];
+    if (j <= i)
+      for (int d = 0; d < hd; d += 4) {
+        const float4 qv = *reinterpret_cast<const float4*>(&qs[i][d]);
+        const float4 kv = *reinterpret_cast<const float4*>(&ks[j][d]);
+        a += qv.x * kv.x + qv.y * kv.y + qv.z * kv.z + qv.w * kv.w;
+      }
     a = a * sc - (float)(T - 1 - j) * slope;
     if (j > i || (key_mask != nullptr && key_mask[j] == 0)) a = -INFINITY;
     sim[i][j] = a;
@@ -455,7 +461,7 @@ extern "C" int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_str
                                    float alibi_bias_max, float* qkv_ws, void* out, int out_is_f32, int ldo, int T, int batch,
                                    const int* ctl, void* stream) {
   const int hd = d_model / n_heads;
-  if (T <= 0 || T > MA_MAXT || hd > 128 || hd * n_heads != d_model || s_in <= 0 || (d_model & 3) || d_model > 4096 ||
+  if (T <= 0 || T > MA_MAXT || hd > 128 || (hd & 3) || hd * n_heads != d_model || s_in <= 0 || (d_model & 3) || d_model > 4096 ||
       qkv_ws == nullptr || batch <= 0)
     return DEER_ERR_SHAPE;
   if ((q_ln_w == nullptr) != (k_ln_w == nullptr)) return DEER_ERR_SHAPE;

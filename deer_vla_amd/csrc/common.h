@@ -34,16 +34,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even, NaN preserved (same as torch .to(bfloat16))
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-
+// fp32 -> bf16, round-to-nearest-even, on the gfx950 packed converter (v_cvt_pk_bf16_f32: one VALU op per PAIR; the
+// integer bit-trick version costs ~7 ops per value and made the fp32->hi/lo staging of the skinny GEMM VALU-bound).
+typedef __bf16 deer_bf2 __attribute__((ext_vector_type(2)));
+typedef float deer_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((deer_f2){lo, hi}, deer_bf2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

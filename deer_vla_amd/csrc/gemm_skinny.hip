@@ -78,12 +78,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
           if (a_mode == A_SLABS_GELU) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
         }
       }
-      const bf16_t h0 = f2bf(s.x), h1 = f2bf(s.y), h2 = f2bf(s.z), h3 = f2bf(s.w);
-      *reinterpret_cast<uint2*>(As + row * pitch + seg * 4) =
-          uint2{(uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16)};
+      const uint32_t h01 = pack2bf(s.x, s.y), h23 = pack2bf(s.z, s.w);
+      *reinterpret_cast<uint2*>(As + row * pitch + seg * 4) = uint2{h01, h23};
       if (SPLIT)
         *reinterpret_cast<uint2*>(Al + row * pitch + seg * 4) =
-            uint2{pack2bf(s.x - bf2f(h0), s.y - bf2f(h1)), pack2bf(s.z - bf2f(h2), s.w - bf2f(h3))};
+            uint2{pack2bf(s.x - __uint_as_float(h01 << 16), s.y - __uint_as_float(h01 & 0xffff0000u)),
+                  pack2bf(s.z - __uint_as_float(h23 << 16), s.w - __uint_as_float(h23 & 0xffff0000u))};
     }
   }
   __syncthreads();
