@@ -9,7 +9,9 @@ __global__ __launch_bounds__(256) void rd(const u32x4* __restrict__ src, unsigne
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long w = (long)blockIdx.x * 4 + wave;
   const u32x4* p = src + w * frags_per_wave * 64 + lane;
+  extern __shared__ unsigned sm[];
   unsigned acc = 0;
+  if (rot == 77) sm[threadIdx.x] = 1;
   const int r = rot ? (int)(w & (UN - 1)) : 0;
   for (int kt = 0; kt < frags_per_wave; kt += UN) {
     u32x4 v[UN];
@@ -23,6 +25,9 @@ __global__ __launch_bounds__(256) void rd(const u32x4* __restrict__ src, unsigne
 int main(int argc, char** argv) {
   const long bytes = (argc > 1 ? atol(argv[1]) : 32) << 20;
   const int fpw = argc > 2 ? atoi(argv[2]) : 16;
+  const int lds = argc > 3 ? atoi(argv[3]) : 0;
+  const int rep_each = argc > 4 ? atoi(argv[4]) : 1;   // read every buffer this many times back to back (MALL/L2 reuse probe)
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&rd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const long pool = 1L << 30;
   char* buf; unsigned* out;
   hipMalloc(&buf, pool + bytes); hipMalloc(&out, 4);
@@ -30,6 +35,19 @@ int main(int argc, char** argv) {
   const int ncopy = (int)(pool / bytes);
   const long waves = bytes / (1024L * fpw);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  {  // same launches as graph nodes (what the engine replays)
+    hipStream_t st; hipStreamCreate(&st);
+    hipGraph_t g; hipGraphExec_t ge;
+    hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+    for (int i = 0; i < ncopy; ++i)
+      hipLaunchKernelGGL(rd<8>, dim3(waves / 4), dim3(256), lds, st, reinterpret_cast<const u32x4*>(buf + (long)(i / rep_each) * bytes), out, fpw, 0);
+    hipStreamEndCapture(st, &g);
+    hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphLaunch(ge, st); hipStreamSynchronize(st);
+    hipEventRecord(e0, st); hipGraphLaunch(ge, st); hipEventRecord(e1, st); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("GRAPH rep %d lds %d bytes %ld MB frags/wave %d unroll 8: %.2f us/launch  %.2f TB/s\n", rep_each, lds, bytes >> 20, fpw, 1e3 * ms / ncopy, bytes / (1e3 * ms / ncopy) / 1e6);
+  }
   for (int un : {8, 16}) for (int rot : {0, 1}) {
     if (fpw % un) continue;
     for (int rep = 0; rep < 2; ++rep) {
