@@ -92,6 +92,7 @@ def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
         if p == 0:
             continue                                      # first pass warms caches / clocks
         for name, e0, e1, fl, by in prof:
+            name = {"deer_gemm_bf16_nt_splitk": "deer_gemm_bf16_nt"}.get(name, name)   # same kernel, split-K grid
             d = agg.setdefault(name, dict(us=0.0, n=0, flops=0.0, bytes=0.0))
             d["us"] += max(1e3 * e0.elapsed_time(e1) - overhead_us, 0.0)
             d["n"] += 1

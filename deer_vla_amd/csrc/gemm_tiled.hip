@@ -21,7 +21,7 @@ enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_QGELU_BF16 = 2, EPI_GELU_BF16 = 3, EPI_RES
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
-                                                         const bf16_t* __restrict__ W, int ldw,
+                                                         const bf16_t* __restrict__ W, int ldw, long strideW,
                                                          const float* __restrict__ bias, void* __restrict__ Cv,
                                                          int ldc, long strideC, int M, int N, int K, int epi,
                                                          const float* __restrict__ gate, const int* ctl) {
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restric
   const int c = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   A += (long)blockIdx.z * strideA;
+  W += (long)blockIdx.z * strideW;                                  // split-K: z selects the K slice of both operands
 
   f32x4 acc[TN][TM];
 #pragma unroll
@@ -162,7 +163,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // that two workgroups fit on a CU.
 template <int BM, int BN, int WM, int WN, int D, int DBG = 0>   // DBG (ablation only): 1 = no MFMA/ds_read, 2 = no DMA in the loop
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
-                                                                        const bf16_t* __restrict__ W, int ldw,
+                                                                        const bf16_t* __restrict__ W, int ldw, long strideW,
                                                                         const float* __restrict__ bias,
                                                                         void* __restrict__ Cv, int ldc, long strideC,
                                                                         int M, int N, int K, int epi,
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
   if ((gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int m0 = blockIdx.y * BM, n0 = bx * BN;
   A += (long)blockIdx.z * strideA;
+  W += (long)blockIdx.z * strideW;                                  // split-K: z selects the K slice of both operands
 
   // DMA chunk q = wave + i*NW: rows 8q..8q+7 of [A tile ; W tile]; lane: row 8q + (lane>>3), slot (lane&7) ^ (row&7)
   const int lr = lane >> 3, ls = ((lane & 7) ^ lr) * 8;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
 }
 
 template <int BM, int BN, int WM, int WN, int D, int DBG = 0>
-static int launch_ring(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, const float* bias, void* C,
+static int launch_ring(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
                        int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate,
                        const int* ctl, hipStream_t st) {
   constexpr int smem = D * (BM + BN) * 128;
@@ -285,14 +287,14 @@ static int launch_ring(const bf16_t* A, int lda, long strideA, const bf16_t* W, 
     attr_set = true;
   }
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, st, A, lda, strideA, W, ldw, bias, C, ldc, strideC, M, N, K, epi, gate,
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, st, A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, epi, gate,
                      ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
 
 template <int BM, int BN>
-static int launch_tiled(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, const float* bias, void* C,
+static int launch_tiled(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
                         int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate,
                         const int* ctl, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * GT_PITCH * (int)sizeof(bf16_t);
@@ -304,7 +306,7 @@ static int launch_tiled(const bf16_t* A, int lda, long strideA, const bf16_t* W,
     attr_set = true;
   }
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, A, lda, strideA, W, ldw, bias, C, ldc, strideC, M, N, K, epi, gate, ctl);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, epi, gate, ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
@@ -313,9 +315,9 @@ static int launch_tiled(const bf16_t* A, int lda, long strideA, const bf16_t* W,
 //       LDS-ring DMA kernels (K % 64 == 0): 4 = 64x64 / 8 waves / 4 stages, 5 = 128x64 / 8 waves / 3 stages,
 //       6 = 64x64 / 16 waves / 6 stages, 7 = 128x128 / 16 waves / 3 stages, 8 = 64x128 / 8 waves / 3 stages,
 //       9 = 32x64 / 4 waves... (see switch)
-extern "C" int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const void* W, int ldw, const float* bias,
-                                 void* C, int ldc, long strideC, int M, int N, int K, int batch, int epi,
-                                 const float* gate, int tile, const int* ctl, void* stream) {
+static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, int ldw, long strideW, const float* bias,
+                         void* C, int ldc, long strideC, int M, int N, int K, int batch, int epi,
+                         const float* gate, int tile, const int* ctl, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 15) || (lda & 7) || (ldw & 7) || (ldc & 3) || epi < 0 || epi > 4)
     return DEER_ERR_SHAPE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -332,7 +334,7 @@ extern "C" int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const voi
   }
   const bf16_t* a = reinterpret_cast<const bf16_t*>(A);
   const bf16_t* w = reinterpret_cast<const bf16_t*>(W);
-#define DEER_ARGS a, lda, strideA, w, ldw, bias, C, ldc, strideC, M, N, K, batch, epi, gate, ctl, st
+#define DEER_ARGS a, lda, strideA, w, ldw, strideW, bias, C, ldc, strideC, M, N, K, batch, epi, gate, ctl, st
   switch (tile) {
     case 1: return launch_tiled<64, 64>(DEER_ARGS);
     case 2: return launch_tiled<64, 128>(DEER_ARGS);
@@ -350,4 +352,21 @@ extern "C" int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const voi
     default: return DEER_ERR_SHAPE;
   }
 #undef DEER_ARGS
+}
+
+extern "C" int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const void* W, int ldw, const float* bias,
+                                 void* C, int ldc, long strideC, int M, int N, int K, int batch, int epi,
+                                 const float* gate, int tile, const int* ctl, void* stream) {
+  return gemm_dispatch(A, lda, strideA, W, ldw, 0, bias, C, ldc, strideC, M, N, K, batch, epi, gate, tile, ctl, stream);
+}
+
+// Split-K form for the latency-bound shapes (few output tiles, long K: ViT c_proj 514x1024x4096 leaves 112 CUs idle
+// for 64 K-steps): slab[s][M][N] (f32) = A[:, Ks] * W[:, Ks]^T, s = 0..splitk-1, reduced by the consumer
+// (deer_resadd_ln, which also adds the bias) - deterministic, no atomics.
+extern "C" int deer_gemm_bf16_nt_splitk(const void* A, int lda, const void* W, int ldw, float* slab, int M, int N, int K,
+                                        int splitk, int tile, const int* ctl, void* stream) {
+  if (splitk <= 0 || K % splitk != 0 || ((K / splitk) & 7)) return DEER_ERR_SHAPE;
+  const int ks = K / splitk;
+  return gemm_dispatch(A, lda, ks, W, ldw, ks, nullptr, slab, N, (long)M * N, M, N, ks, splitk, EPI_F32, nullptr, tile, ctl,
+                       stream);
 }

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
                                                         long slab_stride, const float* __restrict__ gate,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         bf16_t* __restrict__ out_bf, float* __restrict__ out_f32,
-                                                        float* __restrict__ x_copy, int d, float eps, const int* ctl) {
+                                                        float* __restrict__ x_copy, int d, float eps, const int* ctl,
+                                                        const float* __restrict__ bias) {
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ float red[16];
   const int r = blockIdx.x;
@@ -96,6 +97,10 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
 #pragma unroll 4
         for (int s = 0; s < s_in; ++s) {
           const float4 t = *reinterpret_cast<const float4*>(p + (long)s * slab_stride);
+          a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        if (bias != nullptr) {
+          const float4 t = *reinterpret_cast<const float4*>(bias + (long)i4 * 4);
           a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
         }
       }
@@ -139,13 +144,13 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
 }
 
 extern "C" int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_stride, const float* gate,
-                              const float* gamma, const float* beta, void* out_bf16, float* out_f32, float* x_copy, int T,
+                              const float* bias, const float* gamma, const float* beta, void* out_bf16, float* out_f32, float* x_copy, int T,
                               int d, float eps, const int* ctl, void* stream) {
   if (T <= 0 || d <= 0 || (d & 3) || d > 4096 || (slab != nullptr && s_in <= 0) ||
       (gamma != nullptr && out_bf16 == nullptr && out_f32 == nullptr))
     return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(resadd_ln_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in,
-                     slab_stride, gate, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl);
+                     slab_stride, gate, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl, bias);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

@@ -16,6 +16,7 @@ runs in this repo's hand-written gfx950 kernels.
 from __future__ import annotations
 
 import ctypes
+import os
 from contextlib import contextmanager
 from typing import Dict, List, Optional, Sequence
 
@@ -26,6 +27,16 @@ from .config import DeerConfig
 from .synthetic import mlp_layer_indices
 
 EPS = 1e-5
+
+
+def _pick_split(M: int, N: int, K: int, target_blocks: int = 320, max_split: int = 8) -> int:
+    """Split-K factor for a projection whose 64x64 output tiles alone cannot fill 256 CUs: double while the grid stays
+    under ~1.25 workgroups per CU (the f32 slabs cost HBM traffic: measured optimum 2,2 for ViT-L at 514 rows) and every slice keeps >= 2 K-steps of 64."""
+    blocks = ((M + 63) // 64) * ((N + 63) // 64)
+    S = 1
+    while S * 2 <= max_split and blocks * S * 2 <= target_blocks and K % (S * 2 * 64) == 0 and K // (S * 2) >= 128:
+        S *= 2
+    return S
 
 
 def _cur_stream():
@@ -228,6 +239,14 @@ class DeerEngine:
         self.v_ao = z(R, W, dt=bf)
         self.v_h = z(R, cfg.vit_mlp, dt=bf)
         nl, inner = cfg.perc_latents, cfg.perc_heads * cfg.perc_dim_head
+        # split-K factors of the residual projections (measured on MI355X, tools/bench_gemm.py; DEER_VIT_SPLIT overrides)
+        self.vit_split = (_pick_split(R, W, W), _pick_split(R, W, cfg.vit_mlp))
+        self.perc_split = (_pick_split(N * nl, W, inner), _pick_split(N * nl, W, cfg.perc_ff_mult * W))
+        ov = os.environ.get("DEER_VIT_SPLIT")
+        if ov:
+            v = [int(t) for t in ov.split(",")]
+            self.vit_split, self.perc_split = (v[0], v[1]), (v[2], v[3])
+        self.v_slab = z(max(max(self.vit_split) * R, max(self.perc_split) * N * nl) * W)
         self.p_lat = z(N, nl, W)
         self.p_kvin = z(N, P + nl, W, dt=bf)
         self.p_q = z(N * nl, inner, dt=bf)
@@ -284,6 +303,18 @@ class DeerEngine:
                                                  ldc, strideC, M, N, K, batch, epi, abi.ptr(gate), tile, None, _cur_stream()),
                       "deer_gemm_bf16_nt")
 
+    def _gemm_splitk(self, A, W, slab, M, N, K, S, tile=0):
+        assert S * M * N <= slab.numel(), (S, M, N, slab.numel())
+        with self._rec("gemm_tiled", 2.0 * M * N * K, 2.0 * (M * K + N * K) + 4.0 * S * M * N):
+            abi.check(self.lib.deer_gemm_bf16_nt_splitk(abi.ptr(A), K, abi.ptr(W), K, abi.ptr(slab), M, N, K, S, tile, None,
+                                                        _cur_stream()), "deer_gemm_bf16_nt_splitk")
+
+    def _vresadd(self, x, slab, S, rows, C, bias=None, gamma=None, beta=None, out_bf=None):
+        """x += sum_s slab[s] + bias, then (optionally) LayerNorm -> bf16: closes a split-K projection of the vision tower."""
+        abi.check(self.lib.deer_resadd_ln(abi.ptr(x), abi.ptr(slab), S, rows * C, None, abi.ptr(bias), abi.ptr(gamma), abi.ptr(beta),
+                                          abi.ptr(out_bf) if gamma is not None else None, None, None, rows, C, EPS, None,
+                                          _cur_stream()), "deer_resadd_ln")
+
     def _ln(self, x, gamma, beta, out_bf, rows, C, in_rstride=None, in_bstride=0, batch=1, out_rstride=None, out_bstride=0,
             x_off=0, out_off=0, out_f32=None):
         in_rstride = C if in_rstride is None else in_rstride
@@ -308,16 +339,24 @@ class DeerEngine:
                                            EPS, st), "vit_embed")
         H = cfg.vit_heads
         tok = P + 1
-        for L in self.vit_layers:
-            self._ln(self.vx, L["ln1w"], L["ln1b"], self.v_ln, R, W)
+        # c_proj / out_proj run split-K (few output tiles, long K) into f32 slabs; the slab reduction, bias, residual add
+        # and the NEXT LayerNorm are one launch (deer_resadd_ln), so a block is 7 launches and no projection leaves CUs idle.
+        So, Sp = self.vit_split
+        self._ln(self.vx, self.vit_layers[0]["ln1w"], self.vit_layers[0]["ln1b"], self.v_ln, R, W)
+        for li, L in enumerate(self.vit_layers):
+            nxt = self.vit_layers[li + 1] if li + 1 < len(self.vit_layers) else None
             self._gemm(self.v_ln, L["wqkv"], self.v_qkv, R, 3 * W, W, abi.EPI_BF16, bias=L["bqkv"])
             abi.check(lib.deer_attn_mfma_hd64(abi.ptr(self.v_qkv), abi.ptr(self.v_qkv, 2 * W), abi.ptr(self.v_qkv, 4 * W),
                                               abi.ptr(self.v_ao), N, H, tok, tok, 3 * W, 3 * W, 3 * W, W, tok * 3 * W, tok * 3 * W,
                                               tok * 3 * W, tok * W, 64 ** -0.5, st), "vit attn")
-            self._gemm(self.v_ao, L["wo"], self.vx, R, W, W, abi.EPI_RESADD_F32, bias=L["bo"])
-            self._ln(self.vx, L["ln2w"], L["ln2b"], self.v_ln, R, W)
+            self._gemm_splitk(self.v_ao, L["wo"], self.v_slab, R, W, W, So)
+            self._vresadd(self.vx, self.v_slab, So, R, W, bias=L["bo"], gamma=L["ln2w"], beta=L["ln2b"], out_bf=self.v_ln)
             self._gemm(self.v_ln, L["wfc"], self.v_h, R, cfg.vit_mlp, W, abi.EPI_QGELU_BF16, bias=L["bfc"])
-            self._gemm(self.v_h, L["wpr"], self.vx, R, W, cfg.vit_mlp, abi.EPI_RESADD_F32, bias=L["bpr"])
+            self._gemm_splitk(self.v_h, L["wpr"], self.v_slab, R, W, cfg.vit_mlp, Sp)
+            if nxt is not None:
+                self._vresadd(self.vx, self.v_slab, Sp, R, W, bias=L["bpr"], gamma=nxt["ln1w"], beta=nxt["ln1b"], out_bf=self.v_ln)
+            else:
+                self._vresadd(self.vx, self.v_slab, Sp, R, W, bias=L["bpr"])
         # ---- Perceiver (helpers.py:107-132) on the patch tokens x[:, 1:] of each camera ----
         nl, inner = cfg.perc_latents, cfg.perc_heads * cfg.perc_dim_head
         kvr = P + nl
@@ -333,10 +372,12 @@ class DeerEngine:
             abi.check(lib.deer_attn_mfma_hd64(abi.ptr(self.p_q), abi.ptr(self.p_kv), abi.ptr(self.p_kv, inner * 2), abi.ptr(self.p_ao),
                                               N, cfg.perc_heads, nl, kvr, inner, 2 * inner, 2 * inner, inner, nl * inner,
                                               kvr * 2 * inner, kvr * 2 * inner, nl * inner, cfg.perc_dim_head ** -0.5, st), "perc attn")
-            self._gemm(self.p_ao, L["wo"], self.p_lat, N * nl, W, inner, abi.EPI_RESADD_F32)
-            self._ln(self.p_lat, L["fnw"], L["fnb"], self.p_ln, N * nl, W)
+            Pa, Pf = self.perc_split
+            self._gemm_splitk(self.p_ao, L["wo"], self.v_slab, N * nl, W, inner, Pa)
+            self._vresadd(self.p_lat, self.v_slab, Pa, N * nl, W, gamma=L["fnw"], beta=L["fnb"], out_bf=self.p_ln)
             self._gemm(self.p_ln, L["w1"], self.p_h, N * nl, cfg.perc_ff_mult * W, W, abi.EPI_GELU_BF16)
-            self._gemm(self.p_h, L["w2"], self.p_lat, N * nl, W, cfg.perc_ff_mult * W, abi.EPI_RESADD_F32)
+            self._gemm_splitk(self.p_h, L["w2"], self.v_slab, N * nl, W, cfg.perc_ff_mult * W, Pf)
+            self._vresadd(self.p_lat, self.v_slab, Pf, N * nl, W)
         self._ln(self.p_lat, self.perc["normw"], self.perc["normb"], self.vis_x, N * nl, W, out_f32=self.vis_x_f32)
         if self.n_xattn:
             self._gemm(self.vis_x, self.wkv_all, self.kv_all, N * nl, self.n_xattn * 2 * self.xinner, W, abi.EPI_BF16)
@@ -354,7 +395,7 @@ class DeerEngine:
 
     def _resadd(self, T, pending, gamma=None, beta=None, x_copy=None, ctl=True):
         slab, S, stride, gate = pending if pending is not None else (None, 0, 0, None)
-        abi.check(self.lib.deer_resadd_ln(abi.ptr(self.x), abi.ptr(slab), S, stride, abi.ptr(gate), abi.ptr(gamma), abi.ptr(beta),
+        abi.check(self.lib.deer_resadd_ln(abi.ptr(self.x), abi.ptr(slab), S, stride, abi.ptr(gate), None, abi.ptr(gamma), abi.ptr(beta),
                                           None, abi.ptr(self.xn) if gamma is not None else None, abi.ptr(x_copy), T, self.cfg.d_model, EPS,
                                           abi.ptr(self.ctl) if ctl else None, _cur_stream()), "deer_resadd_ln")
 

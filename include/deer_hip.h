@@ -79,6 +79,12 @@ int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const void* W, int l
                       long strideC, int M, int N, int K, int batch, int epi, const float* gate, int tile, const int* ctl,
                       void* stream);
 
+/* Split-K form of deer_gemm_bf16_nt for the latency-bound ViT / Perceiver projections that end in a residual add
+ * (open_clip c_proj / out_proj, helpers.py:71 to_out, :22 FeedForward out): slab[s][M][N] (f32) = A[:, Ks] W[:, Ks]^T;
+ * the consumer (deer_resadd_ln) sums the slabs, adds the bias and applies the residual + following LayerNorm. */
+int deer_gemm_bf16_nt_splitk(const void* A, int lda, const void* W, int ldw, float* slab, int M, int N, int K, int splitk,
+                             int tile, const int* ctl, void* stream);
+
 /* ---- MFMA GEMM, M <= 32 (weight-streaming): part[ks][Mpad][N] = A[:, Kslice ks] * W[:, Kslice ks]^T -------
  * Replaces the bias-free nn.Linear calls of the MPT GPTBlock (EXTERNAL; constructed mosaic_gpt_3b.py:104-106,
  * called :413-417) and of GatedCrossAttentionBlock (helpers.py:188,231,15-22) at T<=32 text tokens.
@@ -126,9 +132,10 @@ int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_stride, int d_
 int deer_layernorm_rows(const float* x, long in_rstride, long in_bstride, int rows_per_batch, int batch, const float* gamma,
                         const float* beta, void* out_bf16, float* out_f32, long out_rstride, long out_bstride, int C,
                         float eps, void* stream);
-/* deer_resadd_ln: x += tanh(*gate or 1) * sum_s slab[s]; optional copy of x (hidden_states[i], mosaic_gpt_3b.py:424-427);
+/* deer_resadd_ln: x += tanh(*gate or 1) * (sum_s slab[s] + bias or 0); optional copy of x (hidden_states[i], mosaic_gpt_3b.py:424-427);
  * optional LayerNorm -> bf16 and/or f32 (helpers.py:267-279 gated residuals; MPT block residuals + ln_1/ln_2). */
-int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* gamma,
+int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
+                   const float* gamma,
                    const float* beta, void* out_bf16, float* out_f32, float* x_copy, int T, int d, float eps, const int* ctl,
                    void* stream);
 /* ViT patch embedding (open_clip conv1 + class/positional embedding + ln_pre) */

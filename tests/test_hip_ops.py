@@ -269,7 +269,7 @@ def test_resadd_ln(lib):
     out = torch.zeros(T, d, device="cuda", dtype=torch.bfloat16)
     outf = torch.zeros(T, d, device="cuda")
     cp = torch.zeros(T, d, device="cuda")
-    abi.check(lib.deer_resadd_ln(abi.ptr(x), abi.ptr(slab), s_in, 16 * d, abi.ptr(gate), abi.ptr(g), None, abi.ptr(out), abi.ptr(outf), abi.ptr(cp), T, d, 1e-5,
+    abi.check(lib.deer_resadd_ln(abi.ptr(x), abi.ptr(slab), s_in, 16 * d, abi.ptr(gate), None, abi.ptr(g), None, abi.ptr(out), abi.ptr(outf), abi.ptr(cp), T, d, 1e-5,
                                  None, st()), "resadd")
     torch.cuda.synchronize()
     xr = x0 + math.tanh(-0.3) * slab.sum(0)[:T]
@@ -278,9 +278,31 @@ def test_resadd_ln(lib):
     assert rel_err(outf, torch.nn.functional.layer_norm(xr, (d,), g)) < 1e-5
     # no slab, no LN: pure copy
     x2 = x0.clone()
-    abi.check(lib.deer_resadd_ln(abi.ptr(x2), None, 0, 0, None, None, None, None, None, abi.ptr(cp), T, d, 1e-5, None, st()), "resadd")
+    abi.check(lib.deer_resadd_ln(abi.ptr(x2), None, 0, 0, None, None, None, None, None, None, abi.ptr(cp), T, d, 1e-5, None, st()), "resadd")
     torch.cuda.synchronize()
     assert torch.equal(cp, x0)
+
+
+@pytest.mark.parametrize("M,N,K,S", [(514, 1024, 4096, 4), (514, 1024, 1024, 2), (128, 1024, 4096, 8), (33, 256, 512, 2),
+                                     (70, 128, 48, 2)])
+def test_gemm_splitk_resadd_bias(lib, M, N, K, S):
+    """Split-K slabs + deer_resadd_ln (bias, residual, LayerNorm) == x + A W^T + b, then LN (ViT c_proj / out_proj)."""
+    A = dev(rnd(M, K, seed=61)).bfloat16()
+    W = dev(rnd(N, K, seed=62, scale=K ** -0.5)).bfloat16()
+    b = dev(rnd(N, seed=63))
+    g, be = dev(1 + 0.1 * rnd(N, seed=64)), dev(0.1 * rnd(N, seed=65))
+    x0 = dev(rnd(M, N, seed=66))
+    slab = torch.full((S, M, N), float("nan"), device="cuda")
+    abi.check(lib.deer_gemm_bf16_nt_splitk(abi.ptr(A), K, abi.ptr(W), K, abi.ptr(slab), M, N, K, S, 0, None, st()), "splitk")
+    x = x0.clone()
+    out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    abi.check(lib.deer_resadd_ln(abi.ptr(x), abi.ptr(slab), S, M * N, None, abi.ptr(b), abi.ptr(g), abi.ptr(be), abi.ptr(out), None, None,
+                                 M, N, 1e-5, None, st()), "resadd")
+    torch.cuda.synchronize()
+    ref = x0 + A.float() @ W.float().t() + b
+    assert rel_err(x, ref) < 2e-5
+    assert rel_err(out.float(), torch.nn.functional.layer_norm(ref, (N,), g, be)) < 4e-3
+    assert lib.deer_gemm_bf16_nt_splitk(abi.ptr(A), K, abi.ptr(W), K, abi.ptr(slab), M, N, K, 3 if K % 3 else 7, 0, None, st()) == 1
 
 
 def test_vit_patch_embed(lib):

@@ -20,7 +20,7 @@ def timeit(fn, n=200, label=""):
 timeit(lambda: lib.deer_ctl_begin_step(abi.ptr(ctl), None, 1, st()), label="trivial kernel (1 block x 64 threads)")
 x = torch.zeros(14, 2048, device="cuda"); o = torch.zeros(14, 2048, device="cuda")
 g_ = torch.ones(2048, device="cuda")
-timeit(lambda: lib.deer_resadd_ln(abi.ptr(x), None, 0, 0, None, abi.ptr(g_), None, None, abi.ptr(o), None, 14, 2048, 1e-5, None, st()), label="resadd_ln 14x2048 (no slabs)")
+timeit(lambda: lib.deer_resadd_ln(abi.ptr(x), None, 0, 0, None, None, abi.ptr(g_), None, None, abi.ptr(o), None, 14, 2048, 1e-5, None, st()), label="resadd_ln 14x2048 (no slabs)")
 A = torch.randn(14, 2048, device="cuda"); W = torch.randn(512, 2048, device="cuda").bfloat16(); Wp = torch.empty_like(W)
 lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), 512, 2048, st())
 part = torch.zeros(8, 16, 512, device="cuda")
