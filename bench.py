@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--full-depth-only", type=int, default=0, metavar="K",
+                    help="profiling aid: run K eager full-depth control steps (every kernel executes, no exit skipping) and "
+                         "leave - the workload of the rocprofv3 --pmc passes (tools/profile_bench.sh)")
     return ap.parse_args()
 
 
@@ -114,11 +117,28 @@ def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
         achieved, peak, unit = d["flops"] / d["us"] / 1e6, MFMA_PEAK_TF, "TFLOP/s"
     else:
         achieved, peak, unit = d["bytes"] / d["us"] / 1e3, HBM_PEAK_GBS, "GB/s"
+    traffic, traffic_src = pmc_traffic(dom)
     return {"kernel": dom, "bound": KERNEL_BOUND[dom], "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-            "frac": round(achieved / peak, 4), "traffic": None,
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)",
+            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]),
             "avg_launch_us": round(d["us"] / d["n"], 2), "launches_per_step": d["n"] // (n_pass - 1),
             "event_overhead_us": round(overhead_us, 2), "gpu_us_per_full_depth_step": round(total_us / (n_pass - 1), 1),
             "classes": classes}
+
+
+def pmc_traffic(kernel_class):
+    """HBM-side bytes per launch of a kernel class from the committed rocprofv3 --pmc summary (FETCH_SIZE and WRITE_SIZE
+    are collected in separate passes by tools/profile_bench.sh over full-depth steps of this same workload; bench.py
+    cannot run PMC passes on itself).  None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        t = json.load(fh)
+    c = t.get("classes", {}).get(kernel_class)
+    if not c:
+        return None, None
+    return c["hbm_bytes_per_launch"], "profiles/pmc_traffic.json (%s)" % t.get("note", "")
 
 
 def cpu_baseline(cfg, sd, ctl, budget_s, threads, rank):
@@ -201,6 +221,17 @@ def main():
             eng.cur_step = 0
         rgb, grip = frames[i % POOL]
         return eng.step(rgb, grip, ids, None, use_graph=use_graph and not args.no_graph, sync=sync, shadow=shadow)
+
+    if args.full_depth_only:
+        for p in range(args.full_depth_only):
+            rgb, grip = frames[p % POOL]
+            eng.reset()
+            eng.load_inputs(rgb, grip, ids, None)
+            eng.hold_dev.fill_(0)
+            eng._enqueue_step(T, False, eng.ctl_max_layer)
+            torch.cuda.synchronize()
+        print(json.dumps({"full_depth_steps": args.full_depth_only}))
+        return
 
     # ---- threshold calibration for --exit-ratio (value_net.py:185-264 solver) -------------------------------
     # Fixed-point on-policy calibration: in shadow mode every exit's delta is recorded at every step while the LSTM

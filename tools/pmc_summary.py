@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Per-kernel mean of rocprofv3 --pmc counters from its CSV output (counter_collection.csv).
+usage: pmc_summary.py <dir-or-csv> [out.txt]
+       pmc_summary.py --traffic <fetch-dir> <write-dir> <out.json>    (per-class HBM bytes per launch for bench.py)   (FETCH_SIZE/WRITE_SIZE are reported in KiB by rocprofv3; gfx950 FETCH_SIZE
+under-reports wide coalesced reads by 2x - see /opt/skills/guides/MI355X_MICROARCH.md 'HBM' - the x2 column applies it)"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+CLASS_OF = (("gemm_tiled", "deer_gemm_bf16_nt"), ("gemm_skinny", "deer_gemm_skinny"), ("attn_mfma_kernel<false>", "deer_attn_mfma_hd64"),
+            ("attn_mfma_kernel<true>", "deer_xattn_mfma"), ("resadd_ln", "deer_resadd_ln"), ("ln_rows", "deer_layernorm_rows"),
+            ("head_lstm", "deer_head_lstm_layer"))
+
+
+def per_class(src):
+    import json
+    files = glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)
+    agg = defaultdict(lambda: [0.0, 0])
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                name = row.get("Kernel_Name", "")
+                for key, cls in CLASS_OF:
+                    if key in name:
+                        agg[cls][0] += float(row.get("Counter_Value", 0) or 0)
+                        agg[cls][1] += 1
+                        break
+    return agg
+
+
+def traffic(fetch_dir, write_dir, out):
+    import json
+    f, w = per_class(fetch_dir), per_class(write_dir)
+    classes = {}
+    for cls in f:
+        fk = f[cls][0] / max(f[cls][1], 1)                     # KiB per dispatch as reported
+        wk = w[cls][0] / max(w[cls][1], 1) if cls in w else 0.0
+        classes[cls] = {"fetch_kib_reported": round(fk, 1), "write_kib_reported": round(wk, 1), "dispatches": f[cls][1],
+                        "hbm_bytes_per_launch": int(round((2.0 * fk + wk) * 1024))}
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, full-depth steps; FETCH_SIZE x2 (gfx950 "
+                       "128-B requests tallied at 64 B), WRITE_SIZE as reported", "classes": classes}, open(out, "w"), indent=1)
+    print(json.dumps(classes, indent=1))
+
+
+def main():
+    if sys.argv[1] == "--traffic":
+        return traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+    src = sys.argv[1]
+    files = [src] if src.endswith(".csv") else glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)
+    agg = defaultdict(lambda: [0.0, 0])
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = (row.get("Kernel_Name", "?")[:80], row.get("Counter_Name", "?"))
+                agg[k][0] += float(row.get("Counter_Value", 0) or 0)
+                agg[k][1] += 1
+    lines = [f"{'kernel':80s} {'counter':14s} {'dispatches':>10s} {'mean':>14s} {'mean_x2':>14s} {'total':>16s}"]
+    for (k, c), (tot, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        lines.append(f"{k:80s} {c:14s} {n:10d} {tot / n:14.2f} {2 * tot / n:14.2f} {tot:16.1f}")
+    txt = "\n".join(lines)
+    print(txt)
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "w").write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()
