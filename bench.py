@@ -102,6 +102,18 @@ def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
             d["flops"] += fl
             d["bytes"] += by
     total_us = sum(d["us"] for d in agg.values())
+    # cross-check of the event brackets: the same full-depth step replayed as ONE graph, timed end to end
+    rgb, grip = frames[0]
+    for _ in range(3):
+        eng.step(rgb, grip, ids, None, exit_id=exit_id, sync=False)
+    torch.cuda.synchronize()
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g0.record()
+    for _ in range(20):
+        eng.step(rgb, grip, ids, None, exit_id=exit_id, sync=False)
+    g1.record()
+    torch.cuda.synchronize()
+    graph_us = 1e3 * g0.elapsed_time(g1) / 20
     classes = {}
     for name, d in sorted(agg.items(), key=lambda kv: -kv[1]["us"]):
         avg = d["us"] / d["n"]
@@ -123,6 +135,7 @@ def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]),
             "avg_launch_us": round(d["us"] / d["n"], 2), "launches_per_step": d["n"] // (n_pass - 1),
             "event_overhead_us": round(overhead_us, 2), "gpu_us_per_full_depth_step": round(total_us / (n_pass - 1), 1),
+            "graph_us_per_full_depth_step": round(graph_us, 1),
             "classes": classes}
 
 
