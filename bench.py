@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--envs-per-gpu", type=int, default=1,
                     help="independent environments evaluated per control step on each GPU (one env batch per rank); "
                          "1 = the reference's one-environment-per-process latency mode")
+    ap.add_argument("--batched-envs", type=int, default=4,
+                    help="also report the env-batched throughput (this many environments per GPU) in the `batched` object; "
+                         "0/1 disables")
     ap.add_argument("--calib-steps", type=int, default=128)
     ap.add_argument("--calib-iters", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,32 +190,15 @@ def cpu_baseline(cfg, sd, ctl, budget_s, threads, rank):
                       f"{os.cpu_count()}-logical-core host), avg exit layer {sum(exits) / len(exits):.2f}, {dt:.1f} s"}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
+def run_workload(args, cfg, sd_dev, B, rank, world, local_rank, dist, max_layer, timed_steps, warmup):
+    """Build an engine for B environments per GPU, calibrate thresholds on-policy for --exit-ratio, and time
+    `timed_steps` control steps (contract: barrier + synchronize on both sides, MAX over ranks)."""
     from deer_vla_amd import synthetic as syn
-    from deer_vla_amd.config import deer_3b
     from deer_vla_amd.engine import DeerEngine
     from deer_vla_amd.value_net import ExitController
 
-    max_layer = 12 if args.workload == "deer_b" else 4
-    cfg = deer_3b(max_layer=max_layer)
     t0 = time.time()
-    sd = syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True)
-    B = args.envs_per_gpu
-    eng = DeerEngine(cfg, sd, device=f"cuda:{local_rank}", n_envs=B)
-    if rank != 0 or args.no_cpu_baseline or world > 1:
-        sd = None                                         # only rank 0 at N=1 needs the fp32 host copy (cpu_baseline)
+    eng = DeerEngine(cfg, sd_dev, device=f"cuda:{local_rank}", n_envs=B)
     ctl = ExitController(None, cfg.exit_ids(), steps_per_stage=1, max_layer=max_layer)
     eng.configure_exit(ctl.exit_id_list, max_layer, 1)
     setup_s = time.time() - t0
@@ -243,8 +229,7 @@ def main():
             eng.hold_dev.fill_(0)
             eng._enqueue_step(T, False, eng.ctl_max_layer)
             torch.cuda.synchronize()
-        print(json.dumps({"full_depth_steps": args.full_depth_only}))
-        return
+        return None
 
     # ---- threshold calibration for --exit-ratio (value_net.py:185-264 solver) -------------------------------
     # Fixed-point on-policy calibration: in shadow mode every exit's delta is recorded at every step while the LSTM
@@ -265,7 +250,7 @@ def main():
     eng.set_thresholds(thr)
 
     # ---- timed region ----
-    for i in range(args.warmup):
+    for i in range(warmup):
         run_step(i)
     torch.cuda.synchronize()
     if dist is not None:
@@ -273,7 +258,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     exit_sum, hist = 0, [0] * cfg.n_layers
-    for i in range(args.steps):
+    for i in range(timed_steps):
         r = run_step(i)
         for re in (r if B > 1 else [r]):
             exit_sum += re["exit_layer"] + 1
@@ -284,34 +269,77 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    stats = torch.tensor([elapsed, float(exit_sum), float(args.steps * B)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, float(exit_sum), float(timed_steps * B)], dtype=torch.float64, device=dev)
     if dist is not None:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)         # one tiny RCCL all-reduce: the only exchange of the path
         stats[0] = tmax[0]
     t_max, exits, n_steps = float(stats[0]), float(stats[1]), float(stats[2])
-    value = n_steps / t_max
-    avg_exit = exits / n_steps
+    return dict(eng=eng, ctl=ctl, frames=frames, ids=ids, T=T, t_max=t_max, value=n_steps / t_max, avg_exit=exits / n_steps,
+                hist=hist, setup_s=setup_s)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from deer_vla_amd import synthetic as syn
+    from deer_vla_amd.config import deer_3b
+
+    max_layer = 12 if args.workload == "deer_b" else 4
+    cfg = deer_3b(max_layer=max_layer)
+    sd = syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True)
+    B = args.envs_per_gpu
+    res = run_workload(args, cfg, sd, B, rank, world, local_rank, dist, max_layer, args.steps, args.warmup)
+    if res is None:
+        print(json.dumps({"full_depth_steps": args.full_depth_only}))
+        return
+    eng, ctl, T = res["eng"], res["ctl"], res["T"]
+    t_max, value = res["t_max"], res["value"]
 
     out = {
         "metric": "action-steps/sec (whole job) + avg exit-layer, MPT-1B max_layer=%d, synthetic CALVIN-D-shaped inputs" % max_layer,
         "value": round(value, 2), "unit": "action-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "avg_exit_layer": round(avg_exit, 3),
+        "avg_exit_layer": round(res["avg_exit"], 3),
         "config": {"workload": "OpenFlamingo-3B/MPT-1B DeeR-%s max_layer=%d exit_ratio=%.2f, step mode, %d env(s)/GPU per control "
                                "step, 2x224x224 frames + %d text tokens per env, LSTM history carried over %d-step episodes"
                                % ("B" if max_layer == 12 else "S", max_layer, args.exit_ratio, B, T, EP_LEN),
                    "envs_per_gpu": B, "ms_per_env_step": round(1e3 * t_max / (args.steps * B), 4),
-                   "exit_hist": hist if world == 1 else None, "per_gpu_steps_per_s": round(value / world, 2),
+                   "exit_hist": res["hist"] if world == 1 else None, "per_gpu_steps_per_s": round(value / world, 2),
                    "graph": not args.no_graph, "weights_gb": round(eng.weight_bytes() / 1e9, 3),
-                   "thresholds": [round(x, 6) for x in ctl.threshold_list()], "setup_s": round(setup_s, 1)},
+                   "thresholds": [round(x, 6) for x in ctl.threshold_list()], "setup_s": round(res["setup_s"], 1)},
     }
+    if rank == 0 and not args.no_roofline:
+        out["roofline"] = measure_roofline(eng, cfg, res["frames"], res["ids"])
+    # ---- the same workload with one ENV BATCH per rank (north_star: "one env batch per rank"): every weight byte and
+    #      every kernel boundary is shared by the environments of the batch.  Reported beside `value`, never as it. ----
+    if args.batched_envs > 1 and B == 1:
+        del eng
+        res["eng"] = None
+        torch.cuda.empty_cache()
+        nb = max(args.steps // 3, 20)
+        rb = run_workload(args, cfg, sd, args.batched_envs, rank, world, local_rank, dist, max_layer, nb, max(args.warmup // 3, 5))
+        out["batched"] = {"envs_per_gpu": args.batched_envs, "value": round(rb["value"], 2), "unit": "action-steps/s",
+                          "steps": nb, "ms_per_step": round(1e3 * rb["t_max"] / nb, 4),
+                          "ms_per_env_step": round(1e3 * rb["t_max"] / (nb * args.batched_envs), 4),
+                          "avg_exit_layer": round(rb["avg_exit"], 3),
+                          "note": "all environments of a rank advance in lock step through one graph replay; same kernels, "
+                                  "same thresholds solver, per-environment exit decisions on the device"}
+        rb["eng"] = None
     if rank == 0:
-        if not args.no_roofline:
-            out["roofline"] = measure_roofline(eng, cfg, frames, ids)
-        if sd is not None:
+        if not (args.no_cpu_baseline or world > 1):
             out["cpu_baseline"] = cpu_baseline(cfg, sd, ctl, args.cpu_budget_s, args.cpu_threads, rank)
         print(json.dumps(out))
     if dist is not None:
