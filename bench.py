@@ -59,6 +59,8 @@ def parse():
 
 
 # kernel class (C-ABI entry point) -> which roofline bounds it
+SAME_KERNEL = {"deer_gemm_bf16_nt_splitk": "deer_gemm_bf16_nt", "deer_gemm_bf16_nt_wbatch": "deer_gemm_bf16_nt",
+               "deer_attn_mfma_hd64_2seg": "deer_attn_mfma_hd64", "deer_layernorm_rows_multi": "deer_layernorm_rows"}
 KERNEL_BOUND = {"deer_gemm_bf16_nt": "mfma", "deer_attn_mfma_hd64": "mfma", "deer_gemm_skinny": "hbm"}
 
 
@@ -98,7 +100,7 @@ def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
         if p == 0:
             continue                                      # first pass warms caches / clocks
         for name, e0, e1, fl, by in prof:
-            name = {"deer_gemm_bf16_nt_splitk": "deer_gemm_bf16_nt"}.get(name, name)   # same kernel, split-K grid
+            name = SAME_KERNEL.get(name, name)                  # entry points that launch the same kernel
             d = agg.setdefault(name, dict(us=0.0, n=0, flops=0.0, bytes=0.0))
             d["us"] += max(1e3 * e0.elapsed_time(e1) - overhead_us, 0.0)
             d["n"] += 1

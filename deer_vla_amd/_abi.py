@@ -20,15 +20,18 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 # name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/deer_hip.h one to one
 SIGNATURES = {
     "deer_gemm_bf16_nt": [P, I, L, P, I, P, P, I, L, I, I, I, I, I, P, I, P, P],
+    "deer_gemm_bf16_nt_wbatch": [P, I, L, P, I, L, P, P, I, L, I, I, I, I, I, I, P, P],
     "deer_gemm_bf16_nt_splitk": [P, I, P, I, P, I, I, I, I, I, P, P],
     "deer_gemm_skinny": [P, I, P, I, L, I, P, P, I, I, I, I, P, P],
     "deer_skinny_splitk": [I, I, I],
     "deer_pack_weight_mfma16": [P, P, I, I, P],
     "deer_attn_mfma_hd64": [P, P, P, P, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
+    "deer_attn_mfma_hd64_2seg": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
     "deer_xattn_mfma": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, I, I, F, P, P],
     "deer_xattn_small": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, I, I, F, P, P],
     "deer_mpt_attn_small": [P, I, L, I, I, P, P, F, P, F, P, P, I, I, I, I, P, P],
     "deer_layernorm_rows": [P, L, L, I, I, P, P, P, P, L, L, I, F, P],
+    "deer_layernorm_rows_multi": [P, L, L, I, I, P, P, I, L, P, L, L, L, I, F, P],
     "deer_resadd_ln": [P, P, I, L, P, P, P, P, P, P, P, I, I, F, P, P],
     "deer_vit_im2col": [P, I, I, I, I, P, I, P],
     "deer_vit_embed_lnpre": [P, P, P, P, P, P, I, I, I, F, P],

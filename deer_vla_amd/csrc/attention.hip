@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const void* __restrict__
                                                         long q_bstride, long k_bstride, long v_bstride, long o_bstride,
                                                         float scale, int q_slabs, long q_slab_stride,
                                                         const int* __restrict__ text_time, int n_per_media, int out_is_f32,
-                                                        const int* ctl) {
+                                                        const int* ctl, const bf16_t* __restrict__ K2,
+                                                        const bf16_t* __restrict__ V2, int kv1, int ld2, long bstride2) {
   DEER_RETURN_IF_EXITED(ctl);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int kvpad = (kv_len + 31) & ~31;
@@ -44,6 +45,9 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const void* __restrict__
   const int h = blockIdx.y, b = blockIdx.z;
   const bf16_t* Kb = Kp + b * k_bstride + h * AM_HD;
   const bf16_t* Vb = V + b * v_bstride + h * AM_HD;
+  // optional second key/value segment (keys kv1..kv_len-1; Perceiver: [media K/V of this layer ; latent K/V])
+  const bf16_t* Kb2 = K2 != nullptr ? K2 + b * bstride2 + h * AM_HD : nullptr;
+  const bf16_t* Vb2 = V2 != nullptr ? V2 + b * bstride2 + h * AM_HD : nullptr;
 
   const int q0 = blockIdx.x * 64 + wave * 16;
 
@@ -82,12 +86,14 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const void* __restrict__
     const int row = (idx >> 3) * 2, seg = idx & 7;
     uint4 k0 = uint4{0, 0, 0, 0}, k1 = k0, v0 = k0, v1 = k0;
     if (row < kv_len) {
-      k0 = *reinterpret_cast<const uint4*>(Kb + (long)row * ldk + seg * 8);
-      v0 = *reinterpret_cast<const uint4*>(Vb + (long)row * ldv + seg * 8);
+      const bool s2 = row >= kv1;
+      k0 = *reinterpret_cast<const uint4*>((s2 ? Kb2 + (long)(row - kv1) * ld2 : Kb + (long)row * ldk) + seg * 8);
+      v0 = *reinterpret_cast<const uint4*>((s2 ? Vb2 + (long)(row - kv1) * ld2 : Vb + (long)row * ldv) + seg * 8);
     }
     if (row + 1 < kv_len) {
-      k1 = *reinterpret_cast<const uint4*>(Kb + (long)(row + 1) * ldk + seg * 8);
-      v1 = *reinterpret_cast<const uint4*>(Vb + (long)(row + 1) * ldv + seg * 8);
+      const bool s2 = row + 1 >= kv1;
+      k1 = *reinterpret_cast<const uint4*>((s2 ? Kb2 + (long)(row + 1 - kv1) * ld2 : Kb + (long)(row + 1) * ldk) + seg * 8);
+      v1 = *reinterpret_cast<const uint4*>((s2 ? Vb2 + (long)(row + 1 - kv1) * ld2 : Vb + (long)(row + 1) * ldv) + seg * 8);
     }
     *reinterpret_cast<uint4*>(Ks + row * AM_KPITCH + seg * 8) = k0;
     *reinterpret_cast<uint4*>(Ks + (row + 1) * AM_KPITCH + seg * 8) = k1;
@@ -193,9 +199,14 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const void* __restrict__
 static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O, int batch, int heads, int q_len, int kv_len,
                             int ldq, int ldk, int ldv, int ldo, long q_bstride, long k_bstride, long v_bstride, long o_bstride,
                             float scale, int q_slabs, long q_slab_stride, const int* text_time, int n_per_media, int out_is_f32,
-                            const int* ctl, void* stream) {
+                            const int* ctl, void* stream, const void* K2 = nullptr, const void* V2 = nullptr, int kv1 = -1,
+                            int ld2 = 0, long bstride2 = 0) {
   if (q_len <= 0 || kv_len <= 0 || kv_len > AM_MAXT * 16 || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3))
     return DEER_ERR_SHAPE;
+  if (K2 == nullptr) kv1 = kv_len;                         // single segment
+  else if (V2 == nullptr || kv1 < 0 || kv1 > kv_len || (ld2 & 7)) return DEER_ERR_SHAPE;
+  const bf16_t* k2 = reinterpret_cast<const bf16_t*>(K2);
+  const bf16_t* v2 = reinterpret_cast<const bf16_t*>(V2);
   const int kvpad = (kv_len + 31) & ~31;
   const int smem = (kvpad * AM_KPITCH + AM_HD * (kvpad + 8)) * (int)sizeof(bf16_t);
   static bool attr_set = false;
@@ -214,10 +225,10 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
   const bf16_t* vp = reinterpret_cast<const bf16_t*>(V);
   if (q_slabs > 0)
     hipLaunchKernelGGL(attn_mfma_kernel<true>, grid, dim3(256), smem, st, Q, kp, vp, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride,
-                       k_bstride, v_bstride, o_bstride, scale, q_slabs, q_slab_stride, text_time, n_per_media, out_is_f32, ctl);
+                       k_bstride, v_bstride, o_bstride, scale, q_slabs, q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2);
   else
     hipLaunchKernelGGL(attn_mfma_kernel<false>, grid, dim3(256), smem, st, Q, kp, vp, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride,
-                       k_bstride, v_bstride, o_bstride, scale, q_slabs, q_slab_stride, text_time, n_per_media, out_is_f32, ctl);
+                       k_bstride, v_bstride, o_bstride, scale, q_slabs, q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
@@ -227,6 +238,18 @@ extern "C" int deer_attn_mfma_hd64(const void* Q, const void* K, const void* V, 
                                    long k_bstride, long v_bstride, long o_bstride, float scale, void* stream) {
   return launch_attn_mfma(Q, K, V, O, batch, heads, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride,
                           scale, 0, 0, nullptr, 1, 0, nullptr, stream);
+}
+
+// Keys/values in two segments: keys [0, kv1) from (K1, V1), keys [kv1, kv1+kv2) from (K2, V2).  PerceiverAttention
+// (helpers.py:47-73) attends over [media tokens ; latents]; the media K/V of every layer are produced up front by one
+// batched GEMM (media tokens are layer-invariant), the latent K/V by the per-layer q|k|v projection of the latents.
+extern "C" int deer_attn_mfma_hd64_2seg(const void* Q, const void* K1, const void* V1, const void* K2, const void* V2, void* O,
+                                        int batch, int heads, int q_len, int kv1, int kv2, int ldq, int ld1, int ld2, int ldo,
+                                        long q_bstride, long bstride1, long bstride2, long o_bstride, float scale,
+                                        void* stream) {
+  if (K2 == nullptr || V2 == nullptr || kv1 < 0 || kv2 <= 0) return DEER_ERR_SHAPE;
+  return launch_attn_mfma(Q, K1, V1, O, batch, heads, q_len, kv1 + kv2, ldq, ld1, ld1, ldo, q_bstride, bstride1, bstride1, o_bstride,
+                          scale, 0, 0, nullptr, 1, 0, nullptr, stream, K2, V2, kv1, ld2, bstride2);
 }
 
 // MaskedCrossAttention core on the MFMA kernel: q = sum_s qslab[s] (f32 [batch*T, ldqs], head h at column h*64),

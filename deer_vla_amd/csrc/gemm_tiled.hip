@@ -360,6 +360,13 @@ extern "C" int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const voi
   return gemm_dispatch(A, lda, strideA, W, ldw, 0, bias, C, ldc, strideC, M, N, K, batch, epi, gate, tile, ctl, stream);
 }
 
+// Batched form with a per-batch weight: C[z] = A[z] * W[z]^T (Perceiver to_kv of all layers on their own norm_media output).
+extern "C" int deer_gemm_bf16_nt_wbatch(const void* A, int lda, long strideA, const void* W, int ldw, long strideW,
+                                        const float* bias, void* C, int ldc, long strideC, int M, int N, int K, int batch,
+                                        int epi, int tile, const int* ctl, void* stream) {
+  return gemm_dispatch(A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, batch, epi, nullptr, tile, ctl, stream);
+}
+
 // Split-K form for the latency-bound shapes (few output tiles, long K: ViT c_proj 514x1024x4096 leaves 112 CUs idle
 // for 64 K-steps): slab[s][M][N] (f32) = A[:, Ks] * W[:, Ks]^T, s = 0..splitk-1, reduced by the consumer
 // (deer_resadd_ln, which also adds the bias) - deterministic, no atomics.

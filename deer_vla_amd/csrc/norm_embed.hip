@@ -11,7 +11,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
                                                       int rows_per_batch, int total_rows, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, bf16_t* __restrict__ out_bf,
                                                       float* __restrict__ out_f32, long out_rstride, long out_bstride,
-                                                      int C, float eps) {
+                                                      int C, float eps, int n_sets, long param_stride, long out_set_stride) {
   __shared__ float red[16];
   const int row = blockIdx.x;
   const int b = row / rows_per_batch, r = row - b * rows_per_batch;
@@ -37,21 +37,26 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
       q += a * a + bb * bb + c * c + d * d;
     }
   const float rstd = rsqrtf(block_sum(q, red) / C + eps);
-  const long o = b * out_bstride + r * out_rstride;
+  // n_sets > 1: the same normalised row under several (gamma, beta) pairs - statistics once (Perceiver norm_media of all layers)
+  for (int ps = 0; ps < n_sets; ++ps) {
+    const long o = ps * out_set_stride + b * out_bstride + r * out_rstride;
+    const float* gm = gamma + ps * param_stride;
+    const float* bt_ = beta != nullptr ? beta + ps * param_stride : nullptr;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int i4 = threadIdx.x + j * 256;
-    if (i4 < n4) {
-      const float4 g = *reinterpret_cast<const float4*>(gamma + (long)i4 * 4);
-      float4 y;
-      y.x = (v[j].x - mean) * rstd * g.x; y.y = (v[j].y - mean) * rstd * g.y;
-      y.z = (v[j].z - mean) * rstd * g.z; y.w = (v[j].w - mean) * rstd * g.w;
-      if (beta != nullptr) {
-        const float4 bt = *reinterpret_cast<const float4*>(beta + (long)i4 * 4);
-        y.x += bt.x; y.y += bt.y; y.z += bt.z; y.w += bt.w;
+    for (int j = 0; j < 4; ++j) {
+      const int i4 = threadIdx.x + j * 256;
+      if (i4 < n4) {
+        const float4 g = *reinterpret_cast<const float4*>(gm + (long)i4 * 4);
+        float4 y;
+        y.x = (v[j].x - mean) * rstd * g.x; y.y = (v[j].y - mean) * rstd * g.y;
+        y.z = (v[j].z - mean) * rstd * g.z; y.w = (v[j].w - mean) * rstd * g.w;
+        if (bt_ != nullptr) {
+          const float4 bt = *reinterpret_cast<const float4*>(bt_ + (long)i4 * 4);
+          y.x += bt.x; y.y += bt.y; y.z += bt.z; y.w += bt.w;
+        }
+        if (out_bf != nullptr) *reinterpret_cast<uint2*>(out_bf + o + (long)i4 * 4) = uint2{pack2bf(y.x, y.y), pack2bf(y.z, y.w)};
+        if (out_f32 != nullptr) *reinterpret_cast<float4*>(out_f32 + o + (long)i4 * 4) = y;
       }
-      if (out_bf != nullptr) *reinterpret_cast<uint2*>(out_bf + o + (long)i4 * 4) = uint2{pack2bf(y.x, y.y), pack2bf(y.z, y.w)};
-      if (out_f32 != nullptr) *reinterpret_cast<float4*>(out_f32 + o + (long)i4 * 4) = y;
     }
   }
 }
@@ -65,7 +70,26 @@ extern "C" int deer_layernorm_rows(const float* x, long in_rstride, long in_bstr
   const int total = rows_per_batch * batch;
   hipLaunchKernelGGL(ln_rows_kernel, dim3(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      x, in_rstride, in_bstride, rows_per_batch, total, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16),
-                     out_f32, out_rstride, out_bstride, C, eps);
+                     out_f32, out_rstride, out_bstride, C, eps, 1, 0L, 0L);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// One pass of statistics, n_sets affine outputs: out[s] = LN(x) * gamma[s] + beta[s] (gamma/beta rows param_stride apart,
+// outputs out_set_stride apart).  The Perceiver applies a different norm_media to the SAME media tokens in each of its
+// layers (helpers.py:47), so all of them are produced up front.
+extern "C" int deer_layernorm_rows_multi(const float* x, long in_rstride, long in_bstride, int rows_per_batch, int batch,
+                                         const float* gamma, const float* beta, int n_sets, long param_stride, void* out_bf16,
+                                         long out_set_stride, long out_rstride, long out_bstride, int C, float eps,
+                                         void* stream) {
+  if (rows_per_batch <= 0 || batch <= 0 || C <= 0 || (C & 3) || C > 4096 || gamma == nullptr || out_bf16 == nullptr ||
+      n_sets <= 0 || (param_stride & 3) || (out_set_stride & 3) || (in_rstride & 3) || (in_bstride & 3) || (out_rstride & 3) ||
+      (out_bstride & 3))
+    return DEER_ERR_SHAPE;
+  const int total = rows_per_batch * batch;
+  hipLaunchKernelGGL(ln_rows_kernel, dim3(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     x, in_rstride, in_bstride, rows_per_batch, total, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16),
+                     (float*)nullptr, out_rstride, out_bstride, C, eps, n_sets, param_stride, out_set_stride);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

@@ -152,11 +152,16 @@ class DeerEngine:
         for l in range(cfg.perc_depth):
             a, f = f"perceiver.layers.{l}.0.", f"perceiver.layers.{l}.1."
             self.perc_layers.append(dict(
-                nmw=self._f32(g(a + "norm_media.weight")), nmb=self._f32(g(a + "norm_media.bias")),
                 nlw=self._f32(g(a + "norm_latents.weight")), nlb=self._f32(g(a + "norm_latents.bias")),
-                wq=self._bf(g(a + "to_q.weight")), wkv=self._bf(g(a + "to_kv.weight")), wo=self._bf(g(a + "to_out.weight")),
+                # latents are projected to q | k | v in one GEMM: [to_q ; to_kv] stacked on the output dimension
+                wqkv=self._bf(torch.cat([g(a + "to_q.weight"), g(a + "to_kv.weight")], 0)), wo=self._bf(g(a + "to_out.weight")),
                 fnw=self._f32(g(f + "0.weight")), fnb=self._f32(g(f + "0.bias")),
                 w1=self._bf(g(f + "1.weight")), w2=self._bf(g(f + "3.weight"))))
+        # the media tokens are the same in every Perceiver layer: norm_media / to_kv of ALL layers are applied up front
+        pl = [f"perceiver.layers.{l}.0." for l in range(cfg.perc_depth)]
+        self.perc_nm_w = self._f32(torch.stack([g(a + "norm_media.weight") for a in pl]))
+        self.perc_nm_b = self._f32(torch.stack([g(a + "norm_media.bias") for a in pl]))
+        self.perc_wkv_all = self._bf(torch.stack([g(a + "to_kv.weight") for a in pl]))        # [L][2*inner][W]
         # ---- LLM ----
         self.wte = self._bf(g("lang_encoder.transformer.wte.weight"))
         nine_b = cfg.llm_name == "mpt_9b"
@@ -248,9 +253,11 @@ class DeerEngine:
             self.vit_split, self.perc_split = (v[0], v[1]), (v[2], v[3])
         self.v_slab = z(max(max(self.vit_split) * R, max(self.perc_split) * N * nl) * W)
         self.p_lat = z(N, nl, W)
-        self.p_kvin = z(N, P + nl, W, dt=bf)
-        self.p_q = z(N * nl, inner, dt=bf)
-        self.p_kv = z(N * (P + nl), 2 * inner, dt=bf)
+        Lp = cfg.perc_depth
+        self.p_mln = z(Lp, N * P, W, dt=bf)                  # norm_media_l(x) for every layer l
+        self.p_mkv = z(Lp, N * P, 2 * inner, dt=bf)          # to_kv_l of it: media K | V of every layer
+        self.p_latln = z(N * nl, W, dt=bf)                   # norm_latents(latents) of the current layer
+        self.p_qkv = z(N * nl, 3 * inner, dt=bf)             # q | k | v of the latents
         self.p_ao = z(N * nl, inner, dt=bf)
         self.p_ln = z(N * nl, W, dt=bf)
         self.p_h = z(N * nl, cfg.perc_ff_mult * W, dt=bf)
@@ -309,10 +316,11 @@ class DeerEngine:
             abi.check(self.lib.deer_gemm_bf16_nt_splitk(abi.ptr(A), K, abi.ptr(W), K, abi.ptr(slab), M, N, K, S, tile, None,
                                                         _cur_stream()), "deer_gemm_bf16_nt_splitk")
 
-    def _vresadd(self, x, slab, S, rows, C, bias=None, gamma=None, beta=None, out_bf=None):
+    def _vresadd(self, x, slab, S, rows, C, bias=None, gamma=None, beta=None, out_bf=None, out_f32=None):
         """x += sum_s slab[s] + bias, then (optionally) LayerNorm -> bf16: closes a split-K projection of the vision tower."""
         abi.check(self.lib.deer_resadd_ln(abi.ptr(x), abi.ptr(slab), S, rows * C, None, abi.ptr(bias), abi.ptr(gamma), abi.ptr(beta),
-                                          abi.ptr(out_bf) if gamma is not None else None, None, None, rows, C, EPS, None,
+                                          abi.ptr(out_bf) if gamma is not None else None,
+                                          abi.ptr(out_f32) if gamma is not None else None, None, rows, C, EPS, None,
                                           _cur_stream()), "deer_resadd_ln")
 
     def _ln(self, x, gamma, beta, out_bf, rows, C, in_rstride=None, in_bstride=0, batch=1, out_rstride=None, out_bstride=0,
@@ -358,27 +366,40 @@ class DeerEngine:
             else:
                 self._vresadd(self.vx, self.v_slab, Sp, R, W, bias=L["bpr"])
         # ---- Perceiver (helpers.py:107-132) on the patch tokens x[:, 1:] of each camera ----
-        nl, inner = cfg.perc_latents, cfg.perc_heads * cfg.perc_dim_head
-        kvr = P + nl
+        # Media side once for all layers: one LayerNorm pass with every layer's norm_media affine, one batched GEMM with every
+        # layer's to_kv.  Per layer only the 64 latents move: q|k|v projection, attention over [media K/V ; latent K/V] (two
+        # segments, helpers.py:51 without the concat), to_out and the FF - each residual projection split-K, closed by the
+        # reducer that also applies the NEXT LayerNorm (7 launches per layer).
+        nl, inner, Lp = cfg.perc_latents, cfg.perc_heads * cfg.perc_dim_head, cfg.perc_depth
         abi.check(lib.deer_broadcast_rows(abi.ptr(self.perc["latents"]), abi.ptr(self.p_lat), nl * W, N, st), "latents")
-        for L in self.perc_layers:
-            # kv_in = [LN_media(x) ; LN_latents(latents)]  (helpers.py:47-51)
-            self._ln(self.vx, L["nmw"], L["nmb"], self.p_kvin, P, W, in_bstride=tok * W, batch=N, out_bstride=kvr * W, x_off=W * 4)
-            self._ln(self.p_lat, L["nlw"], L["nlb"], self.p_kvin, nl, W, in_bstride=nl * W, batch=N, out_bstride=kvr * W,
-                     out_off=P * W * 2)
-            self._gemm(self.p_kvin, L["wkv"], self.p_kv, N * kvr, 2 * inner, W, abi.EPI_BF16)
-            self._gemm(self.p_kvin, L["wq"], self.p_q, nl, inner, W, abi.EPI_BF16, batch=N, strideA=kvr * W, strideC=nl * inner,
-                       a_off=P * W * 2)
-            abi.check(lib.deer_attn_mfma_hd64(abi.ptr(self.p_q), abi.ptr(self.p_kv), abi.ptr(self.p_kv, inner * 2), abi.ptr(self.p_ao),
-                                              N, cfg.perc_heads, nl, kvr, inner, 2 * inner, 2 * inner, inner, nl * inner,
-                                              kvr * 2 * inner, kvr * 2 * inner, nl * inner, cfg.perc_dim_head ** -0.5, st), "perc attn")
-            Pa, Pf = self.perc_split
+        with self._rec("layernorm_rows", 8.0 * N * P * W, (4.0 + 2.0 * Lp) * N * P * W):
+            abi.check(lib.deer_layernorm_rows_multi(abi.ptr(self.vx, W * 4), W, tok * W, P, N, abi.ptr(self.perc_nm_w),
+                                                    abi.ptr(self.perc_nm_b), Lp, W, abi.ptr(self.p_mln), N * P * W, W, P * W, W,
+                                                    EPS, st), "norm_media (all layers)")
+        with self._rec("gemm_tiled", 2.0 * Lp * N * P * 2 * inner * W, 2.0 * Lp * (N * P * W + 2 * inner * W + N * P * 2 * inner)):
+            abi.check(lib.deer_gemm_bf16_nt_wbatch(abi.ptr(self.p_mln), W, N * P * W, abi.ptr(self.perc_wkv_all), W, 2 * inner * W,
+                                                   None, abi.ptr(self.p_mkv), 2 * inner, N * P * 2 * inner, N * P, 2 * inner, W, Lp,
+                                                   abi.EPI_BF16, 0, None, st), "to_kv (all layers)")
+        self._ln(self.p_lat, self.perc_layers[0]["nlw"], self.perc_layers[0]["nlb"], self.p_latln, N * nl, W)
+        Pa, Pf = self.perc_split
+        for li, L in enumerate(self.perc_layers):
+            self._gemm(self.p_latln, L["wqkv"], self.p_qkv, N * nl, 3 * inner, W, abi.EPI_BF16)
+            mkv = li * N * P * 2 * inner * 2                   # byte offset of this layer's media K | V
+            abi.check(lib.deer_attn_mfma_hd64_2seg(abi.ptr(self.p_qkv), abi.ptr(self.p_mkv, mkv), abi.ptr(self.p_mkv, mkv + inner * 2),
+                                                   abi.ptr(self.p_qkv, inner * 2), abi.ptr(self.p_qkv, 2 * inner * 2), abi.ptr(self.p_ao),
+                                                   N, cfg.perc_heads, nl, P, nl, 3 * inner, 2 * inner, 3 * inner, inner,
+                                                   nl * 3 * inner, P * 2 * inner, nl * 3 * inner, nl * inner,
+                                                   cfg.perc_dim_head ** -0.5, st), "perc attn")
             self._gemm_splitk(self.p_ao, L["wo"], self.v_slab, N * nl, W, inner, Pa)
             self._vresadd(self.p_lat, self.v_slab, Pa, N * nl, W, gamma=L["fnw"], beta=L["fnb"], out_bf=self.p_ln)
             self._gemm(self.p_ln, L["w1"], self.p_h, N * nl, cfg.perc_ff_mult * W, W, abi.EPI_GELU_BF16)
             self._gemm_splitk(self.p_h, L["w2"], self.v_slab, N * nl, W, cfg.perc_ff_mult * W, Pf)
-            self._vresadd(self.p_lat, self.v_slab, Pf, N * nl, W)
-        self._ln(self.p_lat, self.perc["normw"], self.perc["normb"], self.vis_x, N * nl, W, out_f32=self.vis_x_f32)
+            if li + 1 < Lp:
+                nx = self.perc_layers[li + 1]
+                self._vresadd(self.p_lat, self.v_slab, Pf, N * nl, W, gamma=nx["nlw"], beta=nx["nlb"], out_bf=self.p_latln)
+            else:                                              # closing perceiver.norm -> media tokens (bf16 for K/V, f32 kept)
+                self._vresadd(self.p_lat, self.v_slab, Pf, N * nl, W, gamma=self.perc["normw"], beta=self.perc["normb"],
+                              out_bf=self.vis_x, out_f32=self.vis_x_f32)
         if self.n_xattn:
             self._gemm(self.vis_x, self.wkv_all, self.kv_all, N * nl, self.n_xattn * 2 * self.xinner, W, abi.EPI_BF16)
 

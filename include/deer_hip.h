@@ -79,6 +79,11 @@ int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const void* W, int l
                       long strideC, int M, int N, int K, int batch, int epi, const float* gate, int tile, const int* ctl,
                       void* stream);
 
+/* Batched form with one weight matrix per batch entry: C[z] = epi(A[z] W[z]^T) (Perceiver to_kv of every layer applied to
+ * that layer's norm_media(x), helpers.py:47-55: the media tokens do not change across layers). */
+int deer_gemm_bf16_nt_wbatch(const void* A, int lda, long strideA, const void* W, int ldw, long strideW, const float* bias,
+                             void* C, int ldc, long strideC, int M, int N, int K, int batch, int epi, int tile, const int* ctl,
+                             void* stream);
 /* Split-K form of deer_gemm_bf16_nt for the latency-bound ViT / Perceiver projections that end in a residual add
  * (open_clip c_proj / out_proj, helpers.py:71 to_out, :22 FeedForward out): slab[s][M][N] (f32) = A[:, Ks] W[:, Ks]^T;
  * the consumer (deer_resadd_ln) sums the slabs, adds the bias and applies the residual + following LayerNorm. */
@@ -106,6 +111,11 @@ int deer_pack_weight_mfma16(const void* W, void* Wp, int N, int K, void* stream)
 int deer_attn_mfma_hd64(const void* Q, const void* K, const void* V, void* O, int batch, int heads, int q_len, int kv_len,
                         int ldq, int ldk, int ldv, int ldo, long q_bstride, long k_bstride, long v_bstride, long o_bstride,
                         float scale, void* stream);
+/* Same with the keys/values in two segments ([0,kv1) from K1/V1 with row stride ld1, [kv1,kv1+kv2) from K2/V2 with ld2):
+ * PerceiverAttention's kv = [media ; latents] (helpers.py:51) without materialising the concatenation. */
+int deer_attn_mfma_hd64_2seg(const void* Q, const void* K1, const void* V1, const void* K2, const void* V2, void* O, int batch,
+                             int heads, int q_len, int kv1, int kv2, int ldq, int ld1, int ld2, int ldo, long q_bstride,
+                             long bstride1, long bstride2, long o_bstride, float scale, void* stream);
 /* deer_xattn_mfma: MaskedCrossAttention core (helpers.py:192-232) on the MFMA attention kernel: q = sum of f32 split-K slabs
  * [batch*T, ldqs], kv bf16 [batch*n_kv, ldkv] (k at col h*64, v at col inner+h*64), key j visible iff
  * text_time[t] == j/n_per_media + 1, rows with text_time == 0 zeroed; out f32 or bf16 [batch*T, ldo]. */
@@ -132,6 +142,11 @@ int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_stride, int d_
 int deer_layernorm_rows(const float* x, long in_rstride, long in_bstride, int rows_per_batch, int batch, const float* gamma,
                         const float* beta, void* out_bf16, float* out_f32, long out_rstride, long out_bstride, int C,
                         float eps, void* stream);
+/* deer_layernorm_rows_multi: one pass of statistics, n_sets affine outputs out[s] = LN(x)*gamma[s]+beta[s] (Perceiver
+ * norm_media of all layers on the same media tokens, helpers.py:32,47). */
+int deer_layernorm_rows_multi(const float* x, long in_rstride, long in_bstride, int rows_per_batch, int batch,
+                              const float* gamma, const float* beta, int n_sets, long param_stride, void* out_bf16,
+                              long out_set_stride, long out_rstride, long out_bstride, int C, float eps, void* stream);
 /* deer_resadd_ln: x += tanh(*gate or 1) * (sum_s slab[s] + bias or 0); optional copy of x (hidden_states[i], mosaic_gpt_3b.py:424-427);
  * optional LayerNorm -> bf16 and/or f32 (helpers.py:267-279 gated residuals; MPT block residuals + ln_1/ln_2). */
 int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,

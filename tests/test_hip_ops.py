@@ -182,6 +182,31 @@ def test_attn_mfma(lib, B, H, q_len, kv_len):
     assert float((o.float() - ref).abs().max()) < 3e-2
 
 
+@pytest.mark.parametrize("B,H,q_len,kv1,kv2", [(2, 8, 64, 256, 64), (1, 2, 16, 16, 16), (2, 2, 64, 17, 5), (1, 1, 5, 0, 33)])
+def test_attn_mfma_two_segments(lib, B, H, q_len, kv1, kv2):
+    """Perceiver attention over [media K/V ; latent K/V] without the concat; q|k|v of the latents share one buffer."""
+    hd = 64
+    inner = H * hd
+    qkv = dev(rnd(B, q_len, 3 * inner, seed=71), torch.bfloat16)           # kv2 == q_len in the Perceiver; general here
+    kv2buf = qkv if kv2 == q_len else dev(rnd(B, kv2, 3 * inner, seed=72), torch.bfloat16)
+    mkv = dev(rnd(B, max(kv1, 1), 2 * inner, seed=73), torch.bfloat16)
+    o = torch.zeros(B, q_len, inner, device="cuda", dtype=torch.bfloat16)
+    scale = hd ** -0.5
+    abi.check(lib.deer_attn_mfma_hd64_2seg(abi.ptr(qkv), abi.ptr(mkv), abi.ptr(mkv, inner * 2), abi.ptr(kv2buf, inner * 2),
+                                           abi.ptr(kv2buf, 2 * inner * 2), abi.ptr(o), B, H, q_len, kv1, kv2, 3 * inner, 2 * inner,
+                                           3 * inner, inner, q_len * 3 * inner, max(kv1, 1) * 2 * inner, kv2 * 3 * inner, q_len * inner,
+                                           scale, st()), "attn 2seg")
+    torch.cuda.synchronize()
+    qf = qkv[..., :inner].float().view(B, q_len, H, hd).transpose(1, 2)
+    k = torch.cat([mkv[:, :kv1, :inner], kv2buf[..., inner:2 * inner]], 1).float()
+    v = torch.cat([mkv[:, :kv1, inner:], kv2buf[..., 2 * inner:]], 1).float()
+    kf = k.view(B, kv1 + kv2, H, hd).transpose(1, 2)
+    vf = v.view(B, kv1 + kv2, H, hd).transpose(1, 2)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * scale, -1) @ vf).transpose(1, 2).reshape(B, q_len, inner)
+    assert rel_err(o.float(), ref) < 8e-3
+    assert float((o.float() - ref).abs().max()) < 3e-2
+
+
 def test_xattn_small(lib):
     T, n_kv, heads, inner, ldkv = 14, 128, 8, 512, 3 * 1024
     s_in = 3
@@ -257,6 +282,33 @@ def test_layernorm_rows_and_strides(lib):
     assert float((outf[:, 2:R + 2] - ref).abs().max()) < 2e-5
     assert rel_err(out[:, 2:R + 2].float(), ref) < 4e-3
     assert float(out[:, :2].abs().max()) == 0 and float(out[:, R + 2:].abs().max()) == 0
+
+
+def test_layernorm_rows_multi(lib):
+    """One statistics pass, L affine outputs (Perceiver norm_media of every layer); skips the class token row."""
+    N, P, C, L = 2, 16, 1024, 6
+    x = dev(rnd(N, P + 1, C, seed=81))
+    g, b = dev(1 + 0.1 * rnd(L, C, seed=82)), dev(0.1 * rnd(L, C, seed=83))
+    out = torch.zeros(L, N * P, C, device="cuda", dtype=torch.bfloat16)
+    abi.check(lib.deer_layernorm_rows_multi(abi.ptr(x, C * 4), C, (P + 1) * C, P, N, abi.ptr(g), abi.ptr(b), L, C, abi.ptr(out),
+                                            N * P * C, C, P * C, C, 1e-5, st()), "ln multi")
+    torch.cuda.synchronize()
+    for l in range(L):
+        ref = torch.nn.functional.layer_norm(x[:, 1:], (C,), g[l], b[l]).reshape(N * P, C)
+        assert rel_err(out[l].float(), ref) < 4e-3
+
+
+def test_gemm_weight_batched(lib):
+    """C[z] = A[z] W[z]^T with one weight per batch entry (Perceiver to_kv of all layers)."""
+    L, M, N, K = 6, 96, 128, 256
+    A = dev(rnd(L, M, K, seed=84)).bfloat16()
+    W = dev(rnd(L, N, K, seed=85, scale=K ** -0.5)).bfloat16()
+    C = torch.zeros(L, M, N, device="cuda", dtype=torch.bfloat16)
+    abi.check(lib.deer_gemm_bf16_nt_wbatch(abi.ptr(A), K, M * K, abi.ptr(W), K, N * K, None, abi.ptr(C), N, M * N, M, N, K, L,
+                                           abi.EPI_BF16, 0, None, st()), "wbatch")
+    torch.cuda.synchronize()
+    ref = torch.einsum("lmk,lnk->lmn", A.float(), W.float())
+    assert rel_err(C.float(), ref) < 6e-3
 
 
 def test_resadd_ln(lib):
