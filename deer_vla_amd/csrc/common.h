@@ -29,6 +29,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CTL_OUT_ACTION 16   // float[8]: committed action (pose6, gripper prob, gripper logit)
 #define CTL_DELTAS 24       // float[16]: delta per exit slot of this step (NaN = not evaluated)
 #define CTL_N_EXITED 40     // (block 0 only) number of environments that exited in this step
+#define CTL_SEQ 41          // (block 0 only) sequence number of the current control step (from step_info)
+#define CTL_HOST_PTR 42     // (block 0 only) 2 words: host-visible mirror (pinned, system-coherent) or 0 - see head.hip
+#define CTL_EVALS_DONE 44   // (block 0 only) environments that finished the current exit check
+// host mirror layout (int32 words): [0] = seq*64 + number of exit checks completed in this step ("progress"),
+// [1] = seq once every environment has exited ("done"), [64*(1+b) .. +64) = copy of environment b's control block at its exit
+#define HOSTM_PROGRESS 0
+#define HOSTM_DONE 1
 #define CTL_WORDS 64
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }

@@ -41,6 +41,30 @@ __device__ __forceinline__ bool head_skip(const int* ctl, int kind, int layer, i
   return false;
 }
 
+// ---- host-visible mirror ------------------------------------------------------------------------------------------------
+// The exit decision is taken on the device, and the device never waits for the host.  So that the HOST can stop feeding
+// work once the step is over (instead of replaying ~100 launches that all return at entry, 1.6 us each), the last kernel of
+// every exit check publishes its verdict into pinned, system-coherent host memory: the host replays the step as one graph
+// segment per exit with a look-ahead of one segment and polls these words between replays (engine.py::_step_segmented).
+__device__ __forceinline__ int* host_mirror(const int* ctl0) {
+  return *reinterpret_cast<int* const*>(ctl0 + CTL_HOST_PTR);
+}
+__device__ __forceinline__ void host_store(int* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// called once per environment at the end of an exit check (thread 0): the last environment publishes "check `slot` complete"
+__device__ __forceinline__ void check_done(int* ctl0, int slot, int B) {
+  int* hm = host_mirror(ctl0);
+  if (hm == nullptr) return;
+  __threadfence_system();
+  if (atomicAdd(&ctl0[CTL_EVALS_DONE], 1) + 1 == B) {
+    ctl0[CTL_EVALS_DONE] = 0;
+    __threadfence_system();
+    if (((volatile int*)ctl0)[CTL_ALL_EXITED] != 0) host_store(hm + HOSTM_DONE, ctl0[CTL_SEQ]);
+    host_store(hm + HOSTM_PROGRESS, ctl0[CTL_SEQ] * 64 + slot + 1);
+  }
+}
+
 __device__ __forceinline__ float dot8(const uint4 w, const float* x) {
   const uint32_t u[4] = {w.x, w.y, w.z, w.w};
   float a = 0.f;
@@ -294,13 +318,20 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
                                                          const float* __restrict__ c_tmp, float* __restrict__ h_state,
                                                          float* __restrict__ c_state, int L, int H, int B,
                                                          float* __restrict__ action_dbg, float eps) {
-  if (head_skip(ctl0, kind, layer, B)) return;
   const int b = blockIdx.x;
+  if (head_skip(ctl0, kind, layer, B)) {
+    // a check nobody needed (stage hold): the host still learns that this segment is over
+    if (kind == KIND_CHECK && threadIdx.x == 0 && ((volatile int*)ctl0)[CTL_ALL_EXITED] == 0) check_done(ctl0, slot, B);
+    return;
+  }
   int* ctl = (ctl0 != nullptr) ? ctl0 + b * CTL_WORDS : nullptr;
   if (ctl != nullptr) {
     // this environment already exited in this step, or (stage hold) does not need this evaluation
-    if (ctl[CTL_EXIT_FLAG] != 0) return;
-    if (ctl0[CTL_HOLD] != 0 && (kind == KIND_PSEUDO || (kind == KIND_CHECK && layer < ctl[CTL_CUR_EXIT_ID]))) return;
+    if (ctl[CTL_EXIT_FLAG] != 0 ||
+        (ctl0[CTL_HOLD] != 0 && (kind == KIND_PSEUDO || (kind == KIND_CHECK && layer < ctl[CTL_CUR_EXIT_ID])))) {
+      if (kind == KIND_CHECK && threadIdx.x == 0) check_done(ctl0, slot, B);
+      return;
+    }
   }
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xa = lds;                    // actions-head input [in_dim]
@@ -392,10 +423,15 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
         for (int i = 0; i < 8; ++i) outa[i] = cur[i];
         ctl[CTL_EXIT_LAYER] = layer;
         ctl[CTL_EXIT_FLAG] = 1;
+        int* hm = host_mirror(ctl0);
+        if (hm != nullptr)                               // this environment's verdict, readable by the host right away
+          for (int i = 0; i < CTL_WORDS; ++i) hm[CTL_WORDS * (1 + b) + i] = ctl[i];
         // last environment of the batch to exit raises the batch-global flag (one workgroup per environment runs
         // concurrently, hence the device-scope atomic)
+        __threadfence_system();
         if (atomicAdd(&ctl0[CTL_N_EXITED], 1) + 1 == B) ctl0[CTL_ALL_EXITED] = 1;
       }
+      if (kind == KIND_CHECK) check_done(ctl0, slot, B);
     }
     *flag = commit ? 1 : 0;
   }
@@ -427,7 +463,8 @@ extern "C" int deer_head_final(const float* src, int src_stride, int in_dim, int
 }
 
 // ---- per-step control-block reset (start of every control step) ----------------------------------------
-// hold_src: device int written by the host before the step: 1 iff cur_step % steps_per_stage != 0.
+// step_info: device int32[4] written by the host before the step: {hold (1 iff cur_step % steps_per_stage != 0), step sequence
+// number, host mirror pointer lo, hi (0 = no mirror)}.
 __global__ void ctl_begin_step_kernel(int* ctl0, const int* hold_src, int B) {
   const int b = blockIdx.x;
   int* ctl = ctl0 + b * CTL_WORDS;
@@ -437,9 +474,13 @@ __global__ void ctl_begin_step_kernel(int* ctl0, const int* hold_src, int B) {
     ctl[CTL_N_EVALS] = 0;
     ctl[CTL_COMMITTED] = 0;
     if (b == 0) {
-      ctl[CTL_HOLD] = (hold_src != nullptr) ? *hold_src : 0;
+      ctl[CTL_HOLD] = (hold_src != nullptr) ? hold_src[0] : 0;
+      ctl[CTL_SEQ] = (hold_src != nullptr) ? hold_src[1] : 0;
+      ctl[CTL_HOST_PTR] = (hold_src != nullptr) ? hold_src[2] : 0;
+      ctl[CTL_HOST_PTR + 1] = (hold_src != nullptr) ? hold_src[3] : 0;
       ctl[CTL_ALL_EXITED] = 0;
       ctl[CTL_N_EXITED] = 0;
+      ctl[CTL_EVALS_DONE] = 0;
     }
   }
   if (threadIdx.x < 16) reinterpret_cast<float*>(ctl + CTL_DELTAS)[threadIdx.x] = __int_as_float(0x7fc00000);

@@ -39,6 +39,12 @@ def _pick_split(M: int, N: int, K: int, target_blocks: int = 320, max_split: int
     return S
 
 
+def _i32(v: int) -> int:
+    """two's-complement wrap into int32 (halves of a pointer stored in an int32 tensor)"""
+    v &= 0xFFFFFFFF
+    return v - (1 << 32) if v >= (1 << 31) else v
+
+
 def _cur_stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -71,7 +77,7 @@ class _ProfiledLib:
 
 class DeerEngine:
     def __init__(self, cfg: DeerConfig, state_dict: Dict[str, torch.Tensor], device="cuda", max_text_len: int = 32,
-                 n_envs: int = 1, threshold_type: str = "L2", leq: bool = True):
+                 n_envs: int = 1, threshold_type: str = "L2", leq: bool = True, segmented: bool = True):
         """n_envs: independent environments evaluated per control step (one "env batch" per rank).  They share every
         weight read: the ViT sees M = 514*n_envs rows, the LLM n_envs*T rows, each environment keeps its own LSTM state,
         thresholds are shared and every environment exits at its own layer (device side)."""
@@ -96,6 +102,8 @@ class DeerEngine:
         self._load_weights(state_dict)
         self._alloc_workspace()
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
+        self.segmented = segmented                    # dynamic steps: one graph segment per exit, host stops feeding at the exit
+        self._seq = 0
         # controller configuration (set by configure_exit)
         self.exit_ids = cfg.exit_ids()
         self.ctl_max_layer = self.exit_ids[-1]
@@ -288,7 +296,11 @@ class DeerEngine:
         self.pooled = z(B, d)                                     # max/avg-pooled features of the current head evaluation
         self.ctl = torch.zeros(B * abi.CTL_WORDS, dtype=torch.int32, device=dev)   # one control block per environment
         self.ctl_host = torch.zeros(B * abi.CTL_WORDS, dtype=torch.int32).pin_memory()
-        self.hold_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.hold_dev = torch.zeros(4, dtype=torch.int32, device=dev)      # step_info: {hold, seq, host mirror ptr lo, hi}
+        self.step_info_host = torch.zeros(8, 4, dtype=torch.int32).pin_memory()   # ring: an async upload may still be pending
+        # host mirror of the verdicts (pinned => device-visible and system-coherent): see csrc/head.hip::check_done
+        self.host_mirror = torch.zeros((1 + B) * abi.CTL_WORDS, dtype=torch.int32).pin_memory()
+        self._hm = self.host_mirror.numpy()                                 # polled by the host between graph segments
         self.thresholds = torch.full((16,), 1e8, dtype=torch.float32, device=dev)
         self.action_dbg = z(B, 8)
 
@@ -538,23 +550,35 @@ class DeerEngine:
         self._shadow_on = False
         self.cur_step = 0
 
-    def enqueue_llm_dynamic(self, T, use_mask, shadow: bool = False):
-        """MosaicGPT.forward loop with an exit controller (mosaic_gpt_3b.py:397-443), device-predicated."""
+    def dynamic_segments(self) -> List[range]:
+        """Layer ranges of the dynamic step, one per exit: segment k ends with the exit check of exit k."""
+        exits = [e for e in self.exit_ids if e <= self.ctl_max_layer]
+        segs, lo = [], 0
+        for e in exits:
+            segs.append(range(lo, e + 1))
+            lo = e + 1
+        return segs
+
+    def enqueue_llm_dynamic(self, T, use_mask, shadow: bool = False, segment: Optional[int] = None):
+        """MosaicGPT.forward loop with an exit controller (mosaic_gpt_3b.py:397-443), device-predicated.
+        segment=None: the whole loop; segment=k: only the layers (and head evaluations) of segment k."""
         cfg = self.cfg
         interval = cfg.exit_interval
-        self.enqueue_embed(T)
-        pending = None
-        for i in range(cfg.n_layers):
-            need_pseudo = ((i + 1) in self.exit_ids) and ((i + 1) - interval < 0) and (i + 1) <= self.ctl_max_layer
-            is_exit = (i in self.exit_ids) and i <= self.ctl_max_layer
-            pending = self.enqueue_llm_layer(i, T, pending, use_mask, finalize=(need_pseudo or is_exit))
-            if need_pseudo:
-                self.enqueue_head(i, T, abi.KIND_PSEUDO)
-            if is_exit:
-                self.enqueue_head(i, T, abi.KIND_CHECK, slot=self.exit_ids.index(i), force=(i >= self.ctl_max_layer),
-                                  shadow=shadow)
-            if i >= self.ctl_max_layer:
-                break
+        segs = self.dynamic_segments()
+        todo = range(len(segs)) if segment is None else [segment]
+        for k in todo:
+            if k == 0:
+                self.enqueue_embed(T)
+                self._pending = None
+            for i in segs[k]:
+                need_pseudo = ((i + 1) in self.exit_ids) and ((i + 1) - interval < 0) and (i + 1) <= self.ctl_max_layer
+                is_exit = (i in self.exit_ids) and i <= self.ctl_max_layer
+                self._pending = self.enqueue_llm_layer(i, T, self._pending, use_mask, finalize=(need_pseudo or is_exit))
+                if need_pseudo:
+                    self.enqueue_head(i, T, abi.KIND_PSEUDO)
+                if is_exit:
+                    self.enqueue_head(i, T, abi.KIND_CHECK, slot=self.exit_ids.index(i), force=(i >= self.ctl_max_layer),
+                                      shadow=shadow)
 
     def enqueue_llm_static(self, T, use_mask, exit_id):
         """exit_id given (flamingo_mpt.py:402-411,446-461): run layers 0..exit_id, committing head call."""
@@ -564,11 +588,13 @@ class DeerEngine:
             pending = self.enqueue_llm_layer(i, T, pending, use_mask, finalize=True, ctl=False)
         self.enqueue_head(exit_id, T, abi.KIND_COMMIT, use_ctl=False)
 
-    def _enqueue_step(self, T, use_mask, exit_id, shadow: bool = False):
-        abi.check(self.lib.deer_ctl_begin_step(abi.ptr(self.ctl), abi.ptr(self.hold_dev), self.B, _cur_stream()), "ctl_begin_step")
-        self.enqueue_vision()
+    def _enqueue_step(self, T, use_mask, exit_id, shadow: bool = False, segment: Optional[int] = None):
+        """segment (dynamic steps only): None = whole step, k = only segment k (segment 0 includes vision + embedding)."""
+        if segment is None or segment == 0:
+            abi.check(self.lib.deer_ctl_begin_step(abi.ptr(self.ctl), abi.ptr(self.hold_dev), self.B, _cur_stream()), "ctl_begin_step")
+            self.enqueue_vision()
         if exit_id is None:
-            self.enqueue_llm_dynamic(T, use_mask, shadow)
+            self.enqueue_llm_dynamic(T, use_mask, shadow, segment)
         else:
             self.enqueue_llm_static(T, use_mask, exit_id)
 
@@ -604,7 +630,20 @@ class DeerEngine:
         if exit_id is not None and exit_id < 0:
             exit_id += self.cfg.n_layers
         hold = 1 if (exit_id is None and self.cur_step % self.steps_per_stage != 0) else 0
-        self.hold_dev.fill_(hold)
+        seg_mode = self.segmented and use_graph and sync and exit_id is None and not shadow
+        self._seq = (self._seq + 1) & 0xFFFFFF
+        if self._seq == 0:                                        # wrap: stale mirror words would compare as "newer"
+            torch.cuda.current_stream().synchronize()
+            self._hm[:2] = 0
+            self._seq = 1
+        si = self.step_info_host[self._seq & 7]
+        si[0], si[1] = hold, self._seq
+        mptr = self.host_mirror.data_ptr() if seg_mode else 0
+        si[2], si[3] = _i32(mptr & 0xFFFFFFFF), _i32(mptr >> 32)
+        self.hold_dev.copy_(si, non_blocking=True)
+        if seg_mode:
+            self.cur_step += 1
+            return self._step_segmented(T, use_mask)
         key = (T, use_mask, exit_id, bool(shadow))
         if use_graph:
             g = self._graphs.get(key)
@@ -626,6 +665,55 @@ class DeerEngine:
         self.cur_step += 1
         if not sync:
             return None
+        torch.cuda.current_stream().synchronize()
+        return self.read_result()
+
+    def _step_segmented(self, T, use_mask):
+        """Dynamic step as one graph segment per exit, replayed with a look-ahead of ONE segment: while segment k runs the
+        host already queued segment k+1, then polls the pinned mirror for segment k's verdict (csrc/head.hip::check_done).
+        The device never waits for the host (the next segment is always queued before the verdict of the previous one is
+        read); when the verdict is "exit" the host simply stops enqueueing, so at most one segment of launches returns at
+        entry instead of all the remaining ones.  The action is on the host as soon as the exit check stored it."""
+        key = (T, use_mask, "seg")
+        segs = self._graphs.get(key)
+        hm, seq = self._hm, self._seq
+        nseg = len(self.dynamic_segments())
+        if segs is None:
+            self._enqueue_step(T, use_mask, None)                 # eager warm-up of the whole step - a real step
+            torch.cuda.current_stream().synchronize()
+            segs = []
+            for k in range(nseg):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._enqueue_step(T, use_mask, None, segment=k)
+                segs.append(g)
+            self._graphs[key] = segs
+        else:
+            W = abi.CTL_WORDS
+            segs[0].replay()
+            k = 1
+            t_dead = None
+            while True:
+                if k < nseg:
+                    segs[k].replay()
+                want = seq * 64 + min(k, nseg)                     # verdict of segment k-1
+                spins = 0
+                while hm[abi.HOSTM_DONE] != seq and hm[abi.HOSTM_PROGRESS] < want:
+                    spins += 1
+                    if spins & 0xFFFF == 0:
+                        import time
+                        t_dead = t_dead or time.monotonic() + 20.0
+                        if time.monotonic() > t_dead:
+                            raise abi.DeerHipError("no exit verdict from the device within 20 s (segment %d)" % (k - 1))
+                if hm[abi.HOSTM_DONE] == seq or k >= nseg:
+                    break
+                k += 1
+            if hm[abi.HOSTM_DONE] != seq:                          # forced exit at the last segment always fires
+                raise abi.DeerHipError("dynamic step finished without an exit verdict")
+            self.ctl_host.copy_(self.host_mirror[W:])
+            return self.read_result()
+        # first call (eager warm-up path): verdict through the ordinary read-back
+        self.ctl_host.copy_(self.ctl, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         return self.read_result()
 

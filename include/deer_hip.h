@@ -39,6 +39,14 @@ extern "C" {
 #define DEER_CTL_OUT_ACTION 16   /* float[8]: pose[6], gripper prob, gripper logit */
 #define DEER_CTL_DELTAS 24       /* float[16] */
 #define DEER_CTL_N_EXITED 40   /* block 0: environments exited so far in this step */
+#define DEER_CTL_SEQ 41        /* block 0: sequence number of the current control step (from step_info) */
+#define DEER_CTL_HOST_PTR 42   /* block 0, 2 words: pinned host mirror the verdicts are published to, or 0 */
+#define DEER_CTL_EVALS_DONE 44 /* block 0: environments that finished the current exit check */
+/* host mirror (int32 words, pinned + system-coherent): [0] = seq*64 + exit checks completed this step, [1] = seq once every
+ * environment exited, [64*(1+b), +64) = environment b's control block at its exit.  Lets the host stop enqueueing the
+ * remaining graph segments of a step without the device ever waiting for the host. */
+#define DEER_HOSTM_PROGRESS 0
+#define DEER_HOSTM_DONE 1
 #define DEER_CTL_WORDS 64
 
 /* GEMM epilogues (deer_gemm_bf16_nt) */
@@ -179,7 +187,9 @@ int deer_head_final(const float* src, int src_stride, int in_dim, int pro, const
                     int layer, int slot, const float* thresholds, int force, int thr_type, int leq, const float* h_tmp,
                     const float* c_tmp, float* h_state, float* c_state, int L, int H, int B, float* action_dbg, float eps,
                     void* stream);
-int deer_ctl_begin_step(int* ctl, const int* hold_src, int B, void* stream);   /* ExitController.set_timestep, eval_utils.py:662-663 */
+/* ExitController.set_timestep (eval_utils.py:662-663) + per-step reset.  step_info: device int32[4] = {hold, step sequence
+ * number, host mirror pointer lo, hi} or NULL (no stage hold, no mirror). */
+int deer_ctl_begin_step(int* ctl, const int* step_info, int B, void* stream);
 
 /* keeps `stream` busy for ~us microseconds (profiling aid: lets the host enqueue ahead of the GPU) */
 int deer_spin_us(int us, void* stream);
