@@ -19,6 +19,7 @@ import ctypes
 import os
 import time
 from contextlib import contextmanager
+from types import SimpleNamespace
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -244,40 +245,63 @@ class DeerEngine:
         return H
 
     # ---------------------------------------------------------------------------------------- workspace
+    def _vision_ws(self, n, img=None, vis_x=None, vis_x_f32=None, splits=None):
+        """Activation buffers of the vision tower for n camera frames (SimpleNamespace; see enqueue_vision)."""
+        cfg, dev = self.cfg, self.dev
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        bf = torch.bfloat16
+        P, W, S = cfg.n_patches, cfg.vit_width, cfg.image_size
+        nl, inner, Lp = cfg.perc_latents, cfg.perc_heads * cfg.perc_dim_head, cfg.perc_depth
+        R = n * (P + 1)
+        ws = SimpleNamespace(n=n)
+        ws.img = z(n, 3, S, S, dt=bf) if img is None else img     # static input buffer (camera frames batched)
+        ws.im2col = z(n * P, self.patch_kpad, dt=bf)
+        ws.patch_out = z(n * P, W)
+        ws.vx = z(n, P + 1, W)                                    # ViT residual stream (fp32)
+        ws.v_ln = z(R, W, dt=bf)
+        ws.v_qkv = z(R, 3 * W, dt=bf)
+        ws.v_ao = z(R, W, dt=bf)
+        ws.v_h = z(R, cfg.vit_mlp, dt=bf)
+        # split-K factors of the residual projections (measured on MI355X, tools/bench_gemm.py; DEER_VIT_SPLIT overrides)
+        ws.vit_split = (_pick_split(R, W, W), _pick_split(R, W, cfg.vit_mlp))
+        ws.perc_split = (_pick_split(n * nl, W, inner), _pick_split(n * nl, W, cfg.perc_ff_mult * W))
+        ov = os.environ.get("DEER_VIT_SPLIT")
+        if ov:
+            v = [int(t) for t in ov.split(",")]
+            ws.vit_split, ws.perc_split = (v[0], v[1]), (v[2], v[3])
+        if splits is not None:                                    # same summation order as the batched schedule: results of
+            ws.vit_split, ws.perc_split = splits.vit_split, splits.perc_split   # all schedules are bit-identical
+        ws.v_slab = z(max(max(ws.vit_split) * R, max(ws.perc_split) * n * nl) * W)
+        ws.p_lat = z(n, nl, W)
+        ws.p_mln = z(Lp, n * P, W, dt=bf)                         # norm_media_l(x) for every layer l
+        ws.p_mkv = z(Lp, n * P, 2 * inner, dt=bf)                 # to_kv_l of it: media K | V of every layer
+        ws.p_latln = z(n * nl, W, dt=bf)                          # norm_latents(latents) of the current layer
+        ws.p_qkv = z(n * nl, 3 * inner, dt=bf)                    # q | k | v of the latents
+        ws.p_ao = z(n * nl, inner, dt=bf)
+        ws.p_ln = z(n * nl, W, dt=bf)
+        ws.p_h = z(n * nl, cfg.perc_ff_mult * W, dt=bf)
+        ws.vis_x = z(n * nl, W, dt=bf) if vis_x is None else vis_x            # media tokens [rgb latents ; gripper latents]
+        ws.vis_x_f32 = z(n * nl, W) if vis_x_f32 is None else vis_x_f32
+        return ws
+
     def _alloc_workspace(self):
         cfg, dev = self.cfg, self.dev
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
         bf = torch.bfloat16
         N, P, W, S = self.n_cams, cfg.n_patches, cfg.vit_width, cfg.image_size
-        R = N * (P + 1)
-        self.img = z(N, 3, S, S, dt=bf)                      # static input buffer (both cameras batched)
-        self.im2col = z(N * P, self.patch_kpad, dt=bf)
-        self.patch_out = z(N * P, W)
-        self.vx = z(N, P + 1, W)                             # ViT residual stream (fp32)
-        self.v_ln = z(R, W, dt=bf)
-        self.v_qkv = z(R, 3 * W, dt=bf)
-        self.v_ao = z(R, W, dt=bf)
-        self.v_h = z(R, cfg.vit_mlp, dt=bf)
         nl, inner = cfg.perc_latents, cfg.perc_heads * cfg.perc_dim_head
-        # split-K factors of the residual projections (measured on MI355X, tools/bench_gemm.py; DEER_VIT_SPLIT overrides)
-        self.vit_split = (_pick_split(R, W, W), _pick_split(R, W, cfg.vit_mlp))
-        self.perc_split = (_pick_split(N * nl, W, inner), _pick_split(N * nl, W, cfg.perc_ff_mult * W))
-        ov = os.environ.get("DEER_VIT_SPLIT")
-        if ov:
-            v = [int(t) for t in ov.split(",")]
-            self.vit_split, self.perc_split = (v[0], v[1]), (v[2], v[3])
-        self.v_slab = z(max(max(self.vit_split) * R, max(self.perc_split) * N * nl) * W)
-        self.p_lat = z(N, nl, W)
-        Lp = cfg.perc_depth
-        self.p_mln = z(Lp, N * P, W, dt=bf)                  # norm_media_l(x) for every layer l
-        self.p_mkv = z(Lp, N * P, 2 * inner, dt=bf)          # to_kv_l of it: media K | V of every layer
-        self.p_latln = z(N * nl, W, dt=bf)                   # norm_latents(latents) of the current layer
-        self.p_qkv = z(N * nl, 3 * inner, dt=bf)             # q | k | v of the latents
-        self.p_ao = z(N * nl, inner, dt=bf)
-        self.p_ln = z(N * nl, W, dt=bf)
-        self.p_h = z(N * nl, cfg.perc_ff_mult * W, dt=bf)
-        self.vis_x = z(N * nl, W, dt=bf)                     # media tokens [rgb latents ; gripper latents]
-        self.vis_x_f32 = z(N * nl, W)
+        # vision workspace: one set for all camera frames batched (single-stream schedules), and one PRIVATE set per chain of
+        # the two-stream schedule (the camera frames are independent until the media tokens are concatenated; chains share
+        # only the input frames and the media-token output, as row ranges)
+        self.vws = self._vision_ws(N)
+        self.img, self.vx, self.vis_x, self.vis_x_f32 = self.vws.img, self.vws.vx, self.vws.vis_x, self.vws.vis_x_f32
+        self.vchains = []
+        n_ch = 2 if N >= 2 else 1
+        per = (N + n_ch - 1) // n_ch
+        for c in range(n_ch):
+            lo, hi = c * per, min(N, (c + 1) * per)
+            self.vchains.append(self._vision_ws(hi - lo, img=self.img[lo:hi], vis_x=self.vis_x[lo * nl: hi * nl],
+                                                vis_x_f32=self.vis_x_f32[lo * nl: hi * nl], splits=self.vws))
         self.kv_all = z(N * nl, max(self.n_xattn, 1) * 2 * self.xinner, dt=bf)
         d = cfg.d_model
         T = min(self.B * self.max_T, 64)                     # LLM rows = n_envs * text length
@@ -359,56 +383,59 @@ class DeerEngine:
     # ------------------------------------------------------------------------------------------ vision
     VIT_HEAD_LAYERS = 3      # ViT blocks in the first graph piece of a step (short to submit; see _step_segmented)
 
-    def enqueue_vision(self, part: str = "all"):
+    def enqueue_vision(self, part: str = "all", ws=None, kv_all: bool = True):
         """ViT-L/14 on both camera frames (batched, the reference runs them separately: flamingo_mpt.py:626,633),
         Perceiver on each, concat -> vis_x, then K/V of every x-attn layer.
         part: "all", or "head" (patch embedding + the first VIT_HEAD_LAYERS blocks) / "tail" (the rest)."""
         cfg, lib, st = self.cfg, self.lib, _cur_stream()
-        N, P, W = self.n_cams, cfg.n_patches, cfg.vit_width
+        ws = self.vws if ws is None else ws
+        N, P, W = ws.n, cfg.n_patches, cfg.vit_width
         R = N * (P + 1)
         n_head = min(self.VIT_HEAD_LAYERS, len(self.vit_layers) - 1)
         lo, hi = {"all": (0, len(self.vit_layers)), "head": (0, n_head), "tail": (n_head, len(self.vit_layers))}[part]
         if part != "tail":
-            self._enqueue_patch_embed()
+            self._enqueue_patch_embed(ws)
         H = cfg.vit_heads
         tok = P + 1
-        So, Sp = self.vit_split
+        So, Sp = ws.vit_split
         for li in range(lo, hi):
             L = self.vit_layers[li]
             nxt = self.vit_layers[li + 1] if li + 1 < len(self.vit_layers) else None
-            self._gemm(self.v_ln, L["wqkv"], self.v_qkv, R, 3 * W, W, abi.EPI_BF16, bias=L["bqkv"])
-            abi.check(lib.deer_attn_mfma_hd64(abi.ptr(self.v_qkv), abi.ptr(self.v_qkv, 2 * W), abi.ptr(self.v_qkv, 4 * W),
-                                              abi.ptr(self.v_ao), N, H, tok, tok, 3 * W, 3 * W, 3 * W, W, tok * 3 * W, tok * 3 * W,
+            self._gemm(ws.v_ln, L["wqkv"], ws.v_qkv, R, 3 * W, W, abi.EPI_BF16, bias=L["bqkv"])
+            abi.check(lib.deer_attn_mfma_hd64(abi.ptr(ws.v_qkv), abi.ptr(ws.v_qkv, 2 * W), abi.ptr(ws.v_qkv, 4 * W),
+                                              abi.ptr(ws.v_ao), N, H, tok, tok, 3 * W, 3 * W, 3 * W, W, tok * 3 * W, tok * 3 * W,
                                               tok * 3 * W, tok * W, 64 ** -0.5, st), "vit attn")
-            self._gemm_splitk(self.v_ao, L["wo"], self.v_slab, R, W, W, So)
-            self._vresadd(self.vx, self.v_slab, So, R, W, bias=L["bo"], gamma=L["ln2w"], beta=L["ln2b"], out_bf=self.v_ln)
-            self._gemm(self.v_ln, L["wfc"], self.v_h, R, cfg.vit_mlp, W, abi.EPI_QGELU_BF16, bias=L["bfc"])
-            self._gemm_splitk(self.v_h, L["wpr"], self.v_slab, R, W, cfg.vit_mlp, Sp)
+            self._gemm_splitk(ws.v_ao, L["wo"], ws.v_slab, R, W, W, So)
+            self._vresadd(ws.vx, ws.v_slab, So, R, W, bias=L["bo"], gamma=L["ln2w"], beta=L["ln2b"], out_bf=ws.v_ln)
+            self._gemm(ws.v_ln, L["wfc"], ws.v_h, R, cfg.vit_mlp, W, abi.EPI_QGELU_BF16, bias=L["bfc"])
+            self._gemm_splitk(ws.v_h, L["wpr"], ws.v_slab, R, W, cfg.vit_mlp, Sp)
             if nxt is not None:
-                self._vresadd(self.vx, self.v_slab, Sp, R, W, bias=L["bpr"], gamma=nxt["ln1w"], beta=nxt["ln1b"], out_bf=self.v_ln)
+                self._vresadd(ws.vx, ws.v_slab, Sp, R, W, bias=L["bpr"], gamma=nxt["ln1w"], beta=nxt["ln1b"], out_bf=ws.v_ln)
             else:
-                self._vresadd(self.vx, self.v_slab, Sp, R, W, bias=L["bpr"])
+                self._vresadd(ws.vx, ws.v_slab, Sp, R, W, bias=L["bpr"])
         if part != "head":
-            self._enqueue_perceiver()
+            self._enqueue_perceiver(ws)
+            if kv_all:
+                self._enqueue_media_kv()
 
-    def _enqueue_patch_embed(self):
+    def _enqueue_patch_embed(self, ws):
         """conv1 as im2col + GEMM, class/positional embedding + ln_pre, ln_1 of the first block."""
         cfg, lib, st = self.cfg, self.lib, _cur_stream()
-        N, P, W = self.n_cams, cfg.n_patches, cfg.vit_width
+        N, P, W = ws.n, cfg.n_patches, cfg.vit_width
         R = N * (P + 1)
-        abi.check(lib.deer_vit_im2col(abi.ptr(self.img), 1, N, cfg.image_size, cfg.patch_size, abi.ptr(self.im2col),
+        abi.check(lib.deer_vit_im2col(abi.ptr(ws.img), 1, N, cfg.image_size, cfg.patch_size, abi.ptr(ws.im2col),
                                       self.patch_kpad, st), "im2col")
-        self._gemm(self.im2col, self.vit["conv"], self.patch_out, N * P, W, self.patch_kpad, abi.EPI_F32)
-        abi.check(lib.deer_vit_embed_lnpre(abi.ptr(self.patch_out), abi.ptr(self.vit["cls"]), abi.ptr(self.vit["pos"]),
-                                           abi.ptr(self.vit["ln_pre_w"]), abi.ptr(self.vit["ln_pre_b"]), abi.ptr(self.vx), N, P, W,
+        self._gemm(ws.im2col, self.vit["conv"], ws.patch_out, N * P, W, self.patch_kpad, abi.EPI_F32)
+        abi.check(lib.deer_vit_embed_lnpre(abi.ptr(ws.patch_out), abi.ptr(self.vit["cls"]), abi.ptr(self.vit["pos"]),
+                                           abi.ptr(self.vit["ln_pre_w"]), abi.ptr(self.vit["ln_pre_b"]), abi.ptr(ws.vx), N, P, W,
                                            EPS, st), "vit_embed")
         # c_proj / out_proj run split-K (few output tiles, long K) into f32 slabs; the slab reduction, bias, residual add
         # and the NEXT LayerNorm are one launch (deer_resadd_ln), so a block is 7 launches and no projection leaves CUs idle.
-        self._ln(self.vx, self.vit_layers[0]["ln1w"], self.vit_layers[0]["ln1b"], self.v_ln, R, W)
+        self._ln(ws.vx, self.vit_layers[0]["ln1w"], self.vit_layers[0]["ln1b"], ws.v_ln, R, W)
 
-    def _enqueue_perceiver(self):
+    def _enqueue_perceiver(self, ws):
         cfg, lib, st = self.cfg, self.lib, _cur_stream()
-        N, P, W = self.n_cams, cfg.n_patches, cfg.vit_width
+        N, P, W = ws.n, cfg.n_patches, cfg.vit_width
         tok = P + 1
         # ---- Perceiver (helpers.py:107-132) on the patch tokens x[:, 1:] of each camera ----
         # Media side once for all layers: one LayerNorm pass with every layer's norm_media affine, one batched GEMM with every
@@ -416,37 +443,42 @@ class DeerEngine:
         # segments, helpers.py:51 without the concat), to_out and the FF - each residual projection split-K, closed by the
         # reducer that also applies the NEXT LayerNorm (7 launches per layer).
         nl, inner, Lp = cfg.perc_latents, cfg.perc_heads * cfg.perc_dim_head, cfg.perc_depth
-        abi.check(lib.deer_broadcast_rows(abi.ptr(self.perc["latents"]), abi.ptr(self.p_lat), nl * W, N, st), "latents")
+        abi.check(lib.deer_broadcast_rows(abi.ptr(self.perc["latents"]), abi.ptr(ws.p_lat), nl * W, N, st), "latents")
         with self._rec("layernorm_rows", 8.0 * N * P * W, (4.0 + 2.0 * Lp) * N * P * W):
-            abi.check(lib.deer_layernorm_rows_multi(abi.ptr(self.vx, W * 4), W, tok * W, P, N, abi.ptr(self.perc_nm_w),
-                                                    abi.ptr(self.perc_nm_b), Lp, W, abi.ptr(self.p_mln), N * P * W, W, P * W, W,
+            abi.check(lib.deer_layernorm_rows_multi(abi.ptr(ws.vx, W * 4), W, tok * W, P, N, abi.ptr(self.perc_nm_w),
+                                                    abi.ptr(self.perc_nm_b), Lp, W, abi.ptr(ws.p_mln), N * P * W, W, P * W, W,
                                                     EPS, st), "norm_media (all layers)")
         with self._rec("gemm_tiled", 2.0 * Lp * N * P * 2 * inner * W, 2.0 * Lp * (N * P * W + 2 * inner * W + N * P * 2 * inner)):
-            abi.check(lib.deer_gemm_bf16_nt_wbatch(abi.ptr(self.p_mln), W, N * P * W, abi.ptr(self.perc_wkv_all), W, 2 * inner * W,
-                                                   None, abi.ptr(self.p_mkv), 2 * inner, N * P * 2 * inner, N * P, 2 * inner, W, Lp,
+            abi.check(lib.deer_gemm_bf16_nt_wbatch(abi.ptr(ws.p_mln), W, N * P * W, abi.ptr(self.perc_wkv_all), W, 2 * inner * W,
+                                                   None, abi.ptr(ws.p_mkv), 2 * inner, N * P * 2 * inner, N * P, 2 * inner, W, Lp,
                                                    abi.EPI_BF16, 0, None, st), "to_kv (all layers)")
-        self._ln(self.p_lat, self.perc_layers[0]["nlw"], self.perc_layers[0]["nlb"], self.p_latln, N * nl, W)
-        Pa, Pf = self.perc_split
+        self._ln(ws.p_lat, self.perc_layers[0]["nlw"], self.perc_layers[0]["nlb"], ws.p_latln, N * nl, W)
+        Pa, Pf = ws.perc_split
         for li, L in enumerate(self.perc_layers):
-            self._gemm(self.p_latln, L["wqkv"], self.p_qkv, N * nl, 3 * inner, W, abi.EPI_BF16)
+            self._gemm(ws.p_latln, L["wqkv"], ws.p_qkv, N * nl, 3 * inner, W, abi.EPI_BF16)
             mkv = li * N * P * 2 * inner * 2                   # byte offset of this layer's media K | V
-            abi.check(lib.deer_attn_mfma_hd64_2seg(abi.ptr(self.p_qkv), abi.ptr(self.p_mkv, mkv), abi.ptr(self.p_mkv, mkv + inner * 2),
-                                                   abi.ptr(self.p_qkv, inner * 2), abi.ptr(self.p_qkv, 2 * inner * 2), abi.ptr(self.p_ao),
+            abi.check(lib.deer_attn_mfma_hd64_2seg(abi.ptr(ws.p_qkv), abi.ptr(ws.p_mkv, mkv), abi.ptr(ws.p_mkv, mkv + inner * 2),
+                                                   abi.ptr(ws.p_qkv, inner * 2), abi.ptr(ws.p_qkv, 2 * inner * 2), abi.ptr(ws.p_ao),
                                                    N, cfg.perc_heads, nl, P, nl, 3 * inner, 2 * inner, 3 * inner, inner,
                                                    nl * 3 * inner, P * 2 * inner, nl * 3 * inner, nl * inner,
                                                    cfg.perc_dim_head ** -0.5, st), "perc attn")
-            self._gemm_splitk(self.p_ao, L["wo"], self.v_slab, N * nl, W, inner, Pa)
-            self._vresadd(self.p_lat, self.v_slab, Pa, N * nl, W, gamma=L["fnw"], beta=L["fnb"], out_bf=self.p_ln)
-            self._gemm(self.p_ln, L["w1"], self.p_h, N * nl, cfg.perc_ff_mult * W, W, abi.EPI_GELU_BF16)
-            self._gemm_splitk(self.p_h, L["w2"], self.v_slab, N * nl, W, cfg.perc_ff_mult * W, Pf)
+            self._gemm_splitk(ws.p_ao, L["wo"], ws.v_slab, N * nl, W, inner, Pa)
+            self._vresadd(ws.p_lat, ws.v_slab, Pa, N * nl, W, gamma=L["fnw"], beta=L["fnb"], out_bf=ws.p_ln)
+            self._gemm(ws.p_ln, L["w1"], ws.p_h, N * nl, cfg.perc_ff_mult * W, W, abi.EPI_GELU_BF16)
+            self._gemm_splitk(ws.p_h, L["w2"], ws.v_slab, N * nl, W, cfg.perc_ff_mult * W, Pf)
             if li + 1 < Lp:
                 nx = self.perc_layers[li + 1]
-                self._vresadd(self.p_lat, self.v_slab, Pf, N * nl, W, gamma=nx["nlw"], beta=nx["nlb"], out_bf=self.p_latln)
+                self._vresadd(ws.p_lat, ws.v_slab, Pf, N * nl, W, gamma=nx["nlw"], beta=nx["nlb"], out_bf=ws.p_latln)
             else:                                              # closing perceiver.norm -> media tokens (bf16 for K/V, f32 kept)
-                self._vresadd(self.p_lat, self.v_slab, Pf, N * nl, W, gamma=self.perc["normw"], beta=self.perc["normb"],
-                              out_bf=self.vis_x, out_f32=self.vis_x_f32)
+                self._vresadd(ws.p_lat, ws.v_slab, Pf, N * nl, W, gamma=self.perc["normw"], beta=self.perc["normb"],
+                              out_bf=ws.vis_x, out_f32=ws.vis_x_f32)
+
+    def _enqueue_media_kv(self):
+        """K | V of every gated x-attn layer from the media tokens of ALL frames, one GEMM (helpers.py:196-197)."""
+        cfg = self.cfg
         if self.n_xattn:
-            self._gemm(self.vis_x, self.wkv_all, self.kv_all, N * nl, self.n_xattn * 2 * self.xinner, W, abi.EPI_BF16)
+            self._gemm(self.vis_x, self.wkv_all, self.kv_all, self.n_cams * cfg.perc_latents, self.n_xattn * 2 * self.xinner,
+                       cfg.vit_width, abi.EPI_BF16)
 
     # --------------------------------------------------------------------------------------------- LLM
     def _skinny(self, Wp, N, K, T, out_slab, A=None, a_slab=None, s_in=0, a_mode=abi.A_F32, lda=None, ctl=True):
@@ -631,6 +663,14 @@ class DeerEngine:
             abi.check(self.lib.deer_ctl_begin_step(abi.ptr(self.ctl), abi.ptr(info), self.B, _cur_stream()), "ctl_begin_step")
         self.enqueue_vision(part)
 
+    def _enqueue_chain(self, c: int, part: str):
+        """Vision tower of chain c of the two-stream schedule; chain 0's first piece also resets the control blocks (from
+        the pinned step info)."""
+        if c == 0 and part == "head":
+            abi.check(self.lib.deer_ctl_begin_step(abi.ptr(self.ctl), abi.ptr(self.step_info_pinned), self.B, _cur_stream()),
+                      "ctl_begin_step")
+        self.enqueue_vision(part, ws=self.vchains[c], kv_all=False)
+
     def _enqueue_step(self, T, use_mask, exit_id, shadow: bool = False):
         self._enqueue_front()
         if exit_id is None:
@@ -741,15 +781,21 @@ class DeerEngine:
             P = {"main": [], "head": {}, "ev": {}}
             # the first piece is SHORT (begin + patch embedding + a few ViT blocks): submitting a graph costs the host
             # ~12 us + 0.3 us per node, and the GPU idles until the first piece of a step is submitted
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._enqueue_front("head", info=self.step_info_pinned)
-            P["front"] = g
+            # The vision tower runs as independent CHAINS of camera frames (chain 0 on the main stream, the others on the side
+            # stream): each chain's launch boundaries and latency-bound kernels are hidden behind the other chain's work.
+            def cap(fn):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fn()
+                return g
+            P["chain_head"] = [cap(lambda c=c: self._enqueue_chain(c, "head")) for c in range(len(self.vchains))]
+            P["chain_tail"] = [cap(lambda c=c: self._enqueue_chain(c, "tail")) for c in range(len(self.vchains))]
+            P["ev_in"], P["ev_join"] = torch.cuda.Event(), torch.cuda.Event()
             for i, need_pseudo, is_exit, _ in plan:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     if i == 0:
-                        self._enqueue_front("tail")
+                        self._enqueue_media_kv()
                     self.enqueue_dynamic_main(T, use_mask, i)
                 P["main"].append(g)
                 if need_pseudo or is_exit:
@@ -783,7 +829,26 @@ class DeerEngine:
                         raise abi.DeerHipError("no exit verdict from the device within 20 s (check %d)" % (n_checks - 1))
             return hm[abi.HOSTM_DONE] == seq
 
-        P["front"].replay()
+        # vision: chain 0 on the main stream, the other chains on the side stream (they start once the inputs are in place)
+        nch = len(self.vchains)
+        if nch > 1:
+            P["ev_in"].record(main_st)
+            side.wait_event(P["ev_in"])
+        P["chain_head"][0].replay()
+        if nch > 1:
+            with torch.cuda.stream(side):
+                for c in range(1, nch):
+                    P["chain_head"][c].replay()
+        P["chain_tail"][0].replay()
+        if nch > 1:
+            with torch.cuda.stream(side):
+                for c in range(1, nch):
+                    P["chain_tail"][c].replay()
+                P["ev_join"].record(side)
+            if self._trace is not None:
+                self._trace.append(("chain0 (main)", self._mark(main_st), time.perf_counter()))
+                self._trace.append(("chain1 (side)", self._mark(side), time.perf_counter()))
+            main_st.wait_event(P["ev_join"])
         for i, need_pseudo, is_exit, _ in plan:
             # keep at most LOOKAHEAD trunk layers in flight beyond an undecided check
             while decided < len(exits) and exits[decided] + LOOK < i:
