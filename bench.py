@@ -337,7 +337,7 @@ def main():
                           "steps": nb, "ms_per_step": round(1e3 * rb["t_max"] / nb, 4),
                           "ms_per_env_step": round(1e3 * rb["t_max"] / (nb * args.batched_envs), 4),
                           "avg_exit_layer": round(rb["avg_exit"], 3),
-                          "note": "all environments of a rank advance in lock step through one graph replay; same kernels, "
+                          "note": "all environments of a rank advance in lock step through the same graph pieces; same kernels, "
                                   "same thresholds solver, per-environment exit decisions on the device"}
         rb["eng"] = None
     if rank == 0:
