@@ -15,6 +15,7 @@ from golden_util import load  # noqa: E402
 from deer_vla_amd import synthetic as syn  # noqa: E402
 from deer_vla_amd.config import deer_tiny, deer_3b  # noqa: E402
 from deer_vla_amd.engine import DeerEngine  # noqa: E402
+from deer_vla_amd import _abi as abi  # noqa: E402
 from oracle import deer_oracle as orc  # noqa: E402
 
 ACTION_TOL = 1e-2
@@ -210,20 +211,50 @@ def test_shadow_calibration_mode_records_every_exit_on_policy(tiny):
 
 
 def test_graph_replay_is_bit_identical_to_eager(tiny):
+    """Three schedules of the same dynamic step - eager launches, ONE graph with device-side skipping, and the pipelined
+    pieces (two-chain vision, head evaluations on a side stream, host stops feeding at the published verdict) - give
+    bit-identical actions, exit layers and deltas."""
     cfg, sd, eng = tiny
-    inputs = make_inputs(cfg, 6)
+    inputs = make_inputs(cfg, 24, text_len=11)
+    thr, _ = probe_thresholds(cfg, sd, inputs, 12, 1)              # thresholds that make the episode exit at several layers
     eng.configure_exit(cfg.exit_ids(), 12, 1)
-    eng.set_thresholds([0.05] * (eng.real_num_exit - 1) + [1e5])
+    eng.set_thresholds(thr)
     res = []
-    for use_graph in (False, True):
-        eng.reset()
-        out = []
-        for s, (rgb, grip, ids, mask) in enumerate(inputs):
-            r = eng.step(rgb, grip, ids, mask, use_graph=use_graph)
-            out.append((r["exit_layer"], r["pose"].clone(), r["gripper"]))
-        res.append(out)
-    for a, b in zip(*res):
-        assert a[0] == b[0] and torch.equal(a[1], b[1]) and a[2] == b[2]
+    try:
+        for use_graph, pieces in ((False, False), (True, False), (True, True)):
+            eng.segmented = pieces
+            eng.reset()
+            out = []
+            for s, (rgb, grip, ids, mask) in enumerate(inputs):
+                r = eng.step(rgb, grip, ids, mask, use_graph=use_graph)
+                out.append((r["exit_layer"], r["pose"].clone(), r["gripper"], r["deltas"].clone(), r["n_evals"]))
+            res.append(out)
+    finally:
+        eng.segmented = True
+    assert len({o[0] for o in res[0]}) > 1                      # exits at different layers within the episode
+    for a, b, c in zip(*res):
+        for x in (b, c):
+            assert a[0] == x[0] and torch.equal(a[1], x[1]) and a[2] == x[2] and a[4] == x[4]
+            assert torch.equal(torch.nan_to_num(a[3], nan=-1.0), torch.nan_to_num(x[3], nan=-1.0))
+
+
+def test_pipelined_step_publishes_verdicts_to_the_host_mirror(tiny):
+    """The pinned mirror carries, for the last step: done == sequence number, progress == seq*64 + checks evaluated, and the
+    exiting environment's control block (csrc/head.hip::check_done)."""
+    cfg, sd, eng = tiny
+    inputs = make_inputs(cfg, 4)
+    eng.configure_exit(cfg.exit_ids(), 12, 1)
+    eng.set_thresholds([-1.0] * (eng.real_num_exit - 1) + [1e5])     # never below threshold: forced exit at the last check
+    eng.reset()
+    for rgb, grip, ids, mask in inputs:
+        r = eng.step(rgb, grip, ids, mask)
+    torch.cuda.synchronize()
+    hm = eng.host_mirror
+    assert int(hm[abi.HOSTM_DONE]) == eng._seq
+    assert int(hm[abi.HOSTM_PROGRESS]) == eng._seq * 64 + eng.real_num_exit
+    blk = hm[abi.CTL_WORDS: 2 * abi.CTL_WORDS]
+    assert int(blk[abi.CTL_EXIT_LAYER]) == r["exit_layer"] == eng.ctl_max_layer
+    assert int(blk[abi.CTL_EXIT_FLAG]) == 1
 
 
 def test_padding_mask_and_text_lengths(tiny):
