@@ -47,7 +47,7 @@ def pack_metrics(results: Sequence[int], exit_layers: Sequence[int], n_layers: i
     return t
 
 
-def reduce_metrics(packed: torch.Tensor, device=None) -> Dict[str, float]:
+def reduce_metrics(packed: torch.Tensor, device=None, n_extra: int = 0) -> Dict[str, float]:
     """all_reduce(SUM) over ranks (a few hundred bytes: latency-bound, xGMI bandwidth is irrelevant) -> metrics of
     ``print_and_save`` (eval_utils.py:71-118): avg successful length, chain success rates 1-5, avg exit layer (+1)."""
     t = packed.clone()
@@ -55,11 +55,17 @@ def reduce_metrics(packed: torch.Tensor, device=None) -> Dict[str, float]:
         t = t.to(device) if device is not None else t
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         t = t.cpu()
+    extra = None
+    if n_extra:                                                   # caller-defined sums appended to the packed vector
+        extra = [float(v) for v in t[-n_extra:]]
+        t = t[:-n_extra]
     n_chains, n_steps = max(float(t[1]), 1.0), max(float(t[8]), 1.0)
     out = {"avg_seq_len": float(t[0]) / n_chains, "n_chains": int(t[1]), "n_steps": int(t[8]),
            "avg_exit": float(t[7]) / n_steps, "llm_time": float(t[9]),
            "chain_sr": [float(t[1 + k]) / n_chains for k in range(1, 6)],
            "exit_hist": [int(v) for v in t[len(METRIC_FIELDS):]]}
+    if extra is not None:
+        out["extra"] = extra
     return out
 
 

@@ -1,0 +1,278 @@
+"""Closed-loop rollout harness around the engine: the reference's ``ModelWrapper`` and the sequence/rollout drivers of
+``robot_flamingo/eval/eval_utils.py``, for the configuration DeeR evaluates (deterministic LSTM head, ``pad_length == -1``
+step mode, ``fusion_mode == 'post'``, one action per step).
+
+* ``ModelWrapper``                 (eval_utils.py:180-491)  obs dict + instruction -> 7-DoF action (float16 numpy, gripper in
+                                    {-1, +1}), ``current_exit_layer``; same constructor arguments and ``reset()/step()`` protocol.
+* ``preprocess_image`` / ``preprocess_text_calvin``          (robot_flamingo/data/data.py:898-919).
+* ``DebugEnv``                     (eval_utils.py:152-175)  the reference's constant-observation stand-in for the CALVIN
+                                    simulator; ``SyntheticEnv`` is a seeded variant whose frames change every step and whose
+                                    sub-tasks "succeed" after a fixed number of steps, so the success/exit bookkeeping is exercised.
+* ``rollout`` / ``evaluate_sequence`` / ``evaluate_policy_ddp`` (eval_utils.py:494-700): sequences sharded by rank exactly like
+  the reference (``eval_sequences[rank*N/W:(rank+1)*N/W]``), results reduced with ONE packed all-reduce instead of a pickled
+  ``gather_object`` (deer_vla_amd/distributed.py).
+
+The CALVIN simulator, its task oracle and hydra configs are not part of the hot path (out of scope): the drivers
+take the environment and a ``task_checker`` callable as arguments, so the real ones plug in unchanged.
+"""
+from __future__ import annotations
+
+import functools
+import time
+from collections import Counter, deque
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import distributed as ddist
+
+EP_LEN = 360            # eval_utils.py:44
+NUM_SEQUENCES = 1000    # eval_utils.py:45 (overridden by --num_seq)
+
+
+# ---------------------------------------------------------------------------------------------- preprocessing
+def preprocess_image(sample, image_processor) -> torch.Tensor:
+    """data.py:898-902: stack of processed frames, (n, 3, S, S)."""
+    return torch.cat([image_processor(s).unsqueeze(0) for s in sample], dim=0)
+
+
+def preprocess_text_calvin(sample, tokenizer):
+    """data.py:905-919: ``<image>{instruction}<|endofchunk|>{eos}``, right padded, max_length 32."""
+    tokenizer.padding_side = "right"
+    sample = [f"<image>{s.strip()}<|endofchunk|>{tokenizer.eos_token}" for s in sample]
+    text = tokenizer(sample, max_length=32, padding="longest", truncation="only_first", return_tensors="pt")
+    return text["input_ids"], text["attention_mask"]
+
+
+# ---------------------------------------------------------------------------------------------- environments
+class DebugEnv:
+    """eval_utils.py:152-175 (constant frames)."""
+
+    def get_random_obs(self):
+        return {"rgb_obs": {"rgb_static": np.ones((200, 200, 3), dtype=np.uint8),
+                            "rgb_gripper": np.ones((84, 84, 3), dtype=np.uint8)},
+                "robot_obs": np.ones(15, dtype=np.float32)}
+
+    def get_obs(self):
+        return self.get_random_obs()
+
+    def step(self, action):
+        return self.get_random_obs(), 0.0, False, None
+
+    def reset(self, **kwargs):
+        return
+
+    def get_info(self):
+        return None
+
+
+class SyntheticEnv(DebugEnv):
+    """Seeded moving-texture frames; the observation depends on the step count and (weakly) on the actions applied, so
+    the LSTM history, the exit layers and the actions vary over an episode.  ``info`` is the number of steps since the
+    last reset - pair it with ``steps_task_checker``."""
+
+    def __init__(self, seed: int = 0):
+        self.rng = np.random.default_rng(seed)
+        self.base_s = self.rng.integers(0, 255, size=(200, 200, 3), dtype=np.uint8)
+        self.base_g = self.rng.integers(0, 255, size=(84, 84, 3), dtype=np.uint8)
+        self.t = 0
+        self.shift = 0
+
+    def get_obs(self):
+        s = np.roll(self.base_s, (self.t * 3 + self.shift) % 200, axis=1)
+        g = np.roll(self.base_g, (self.t * 2 + self.shift) % 84, axis=0)
+        return {"rgb_obs": {"rgb_static": s, "rgb_gripper": g}, "robot_obs": np.full(15, self.t, dtype=np.float32)}
+
+    def step(self, action):
+        self.t += 1
+        self.shift = (self.shift + int(abs(float(np.asarray(action, dtype=np.float32)[0])) * 7)) % 200
+        return self.get_obs(), 0.0, False, self.get_info()
+
+    def reset(self, **kwargs):
+        self.t = 0
+
+    def get_info(self):
+        return self.t
+
+
+def steps_task_checker(n_steps: int) -> Callable:
+    """Task oracle stand-in: a sub-task is solved once ``n_steps`` environment steps have passed since it started."""
+    def check(start_info, current_info, subtask) -> bool:
+        return (current_info - start_info) >= n_steps
+    return check
+
+
+# ---------------------------------------------------------------------------------------------- model wrapper
+class ModelWrapper:
+    """``ModelWrapper`` of the reference harness (eval_utils.py:180-491), DeeR configuration."""
+
+    def __init__(self, model, tokenizer, image_processor, cast_dtype, use_diff=False, history_len=None, future_act_len=-1,
+                 amp=False, exit_id=None, early_exit=False, exit_controller=None, multi_execution=1, use_action_ensemble=False):
+        m = model.module
+        if use_diff or m.head_type == "diffusion":
+            raise NotImplementedError("diffusion head: not on the DeeR path (SURVEY §8, out of scope)")
+        if use_action_ensemble:
+            raise NotImplementedError("action ensembling over exits: not on the DeeR path")
+        if m.pad_length != -1:                                     # eval_utils.py:204
+            raise AssertionError("Padding for multi-exit net is not implemented. It requires store feature_cache for each exit separately.")
+        if m.fusion_mode in ("two_way", "vit_concat"):
+            raise NotImplementedError("fusion_mode %r: the reference asserts out of it for dynamic exit (eval_utils.py:424)" % m.fusion_mode)
+        if m.act_step != 1:
+            raise NotImplementedError("multi-step action heads are not part of DeeR's released configuration")
+        self.model = model
+        self.replan = m.replan
+        self.decoder_type = m.decoder_type
+        self.cast_type = cast_dtype
+        self.use_diff = False
+        self.text_process_fn = functools.partial(preprocess_text_calvin, tokenizer=tokenizer)
+        self.image_process_fn = functools.partial(preprocess_image, image_processor=image_processor)
+        self.fusion_mode = m.fusion_mode
+        self.amp = amp                                             # the engine computes in bf16/fp32 regardless
+        self.head_type = m.head_type
+        self.exit_id = exit_id
+        self.dynamic_early_exit = early_exit
+        self.exit_controller = exit_controller
+        self.multi_execution = multi_execution
+        self.use_action_ensemble = False
+        self.current_exit_layer = exit_id if isinstance(exit_id, int) else -1
+        self._text_cache: Tuple[Optional[str], Optional[torch.Tensor], Optional[torch.Tensor]] = (None, None, None)
+        self.reset()
+
+    def reset(self):
+        """Called at the start of every sub-task rollout (eval_utils.py:252-277)."""
+        hist = self.model.module.window_size
+        self.img_queue, self.gripper_queue = deque(maxlen=hist), deque(maxlen=hist)
+        self.mask_queue, self.text_queue = deque(maxlen=hist), deque(maxlen=hist)
+        self.model.module.clear_all_exit_memory()
+        if self.exit_controller is not None:
+            vn = self.exit_controller.module.value_net
+            if vn is not None:
+                vn.hidden_state = None
+                vn.history_memory = []
+
+    def step(self, obs, goal, get_action=True):
+        if not get_action:
+            return None
+        m = self.model.module
+        image_x = self.image_process_fn([obs["rgb_obs"]["rgb_static"]]).unsqueeze(1).unsqueeze(1).to(dtype=self.cast_type)
+        if goal != self._text_cache[0]:                            # one instruction per sub-task: tokenise / upload once
+            ids, mask = self.text_process_fn([goal])
+            self._text_cache = (goal, ids.cuda(), mask.cuda())
+        _, text_x, mask = self._text_cache
+        # step mode: the LSTM heads run with window_size 1 and carry their hidden state (eval_utils.py:313-320)
+        window_size = m.set_all_exit_window_size(1)
+        if self.exit_controller is not None and self.exit_controller.module.value_net is not None:
+            self.exit_controller.module.value_net.window_size = 1
+        gripper = None
+        if m.use_gripper:
+            gripper = self.image_process_fn([obs["rgb_obs"]["rgb_gripper"]]).unsqueeze(1).unsqueeze(1).to(dtype=self.cast_type)
+        with torch.no_grad():
+            image_x = image_x.cuda(non_blocking=True)
+            gripper = gripper.cuda(non_blocking=True) if gripper is not None else None
+            self.img_queue.append(image_x)
+            self.gripper_queue.append(gripper)
+            out = self.model(vision_x=image_x, lang_x=text_x, attention_mask=mask, vision_gripper=gripper, state_tensor=None,
+                             return_feature=True, deterministic=True, exit_id=self.exit_id,
+                             dynamic_early_exit=self.dynamic_early_exit, exit_controller=self.exit_controller)
+            if hasattr(out, "exit_layer"):
+                self.current_exit_layer = out.exit_layer
+            # eval_utils.py:454-462: [pose6, gripper > 0.5] of the last time step, gripper scaled to -1 / +1
+            action = torch.concat((out.logits[0], (out.logits[1] > 0.5).to(out.logits[0].dtype)), dim=2).squeeze(0)[-1]
+            action[-1] = (action[-1] - 0.5) * 2
+            action = torch.stack([action] * self.multi_execution, dim=0)
+            action = action.cpu().detach().to(dtype=torch.float16).numpy()
+        m.set_all_exit_window_size(window_size)
+        if m.tcp_rel:
+            raise NotImplementedError                               # eval_utils.py:481-482
+        return action
+
+
+# ---------------------------------------------------------------------------------------------- drivers
+def count_success(results: Sequence[int]) -> List[float]:
+    """eval_utils.py:53-60."""
+    count = Counter(results)
+    return [sum(count[j] for j in reversed(range(i, 6))) / len(results) for i in range(1, 6)]
+
+
+def count_exit_ratio(exit_results: Sequence[int], n_layers: int) -> List[float]:
+    """eval_utils.py:62-68."""
+    count = Counter(exit_results)
+    return [count[i] / max(len(exit_results), 1) for i in range(n_layers)]
+
+
+def rollout(env, model: ModelWrapper, task_checker: Callable, subtask: str, lang_annotation: str, ep_len: int = EP_LEN):
+    """One sub-task (one instruction): eval_utils.py:618-684.  Returns (success, exit_layers, n_steps, llm_times)."""
+    planned_actions: List[np.ndarray] = []
+    exit_layers, llm_times = [], []
+    obs = env.get_obs()
+    lang_annotation = lang_annotation.split("\n")[0]
+    model.reset()
+    start_info = env.get_info()
+    step = -1
+    for step in range(ep_len):
+        if model.replan != -1 and step % model.replan == 0:
+            model.reset()
+        if model.exit_controller is not None:
+            model.exit_controller.module.set_timestep(step)      # eval_utils.py:662-663
+        action = model.step(obs, lang_annotation, len(planned_actions) == 0)
+        exit_layers.append(model.current_exit_layer)
+        llm_times.append(model.model.module.llm_inference_time)
+        if len(planned_actions) == 0:
+            if action.shape == (7,):
+                planned_actions.append(action)
+            else:
+                planned_actions.extend([action[i] for i in range(action.shape[0])])
+        action = planned_actions.pop(0)
+        obs, _, _, current_info = env.step(action)
+        if task_checker(start_info, current_info, subtask):
+            return True, exit_layers, step + 1, llm_times
+    return False, exit_layers, step + 1, llm_times
+
+
+def evaluate_sequence(env, model: ModelWrapper, task_checker, eval_sequence: Sequence[str], annotations: Dict[str, List[str]],
+                      ep_len: int = EP_LEN, initial_state=None):
+    """A chain of up to five instructions; stops at the first failure (eval_utils.py:572-615)."""
+    env.reset() if initial_state is None else env.reset(**initial_state)
+    n_ok, ok_exits, fail_exits, ok_steps = 0, [], [], []
+    for subtask in eval_sequence:
+        success, exits, n_steps, _ = rollout(env, model, task_checker, subtask, annotations[subtask][0], ep_len)
+        if success:
+            n_ok += 1
+            ok_steps.append(n_steps)
+            ok_exits.extend(exits)
+        else:
+            fail_exits.extend(exits)
+            break
+    return n_ok, ok_exits, fail_exits, ok_steps
+
+
+def evaluate_policy_ddp(model: ModelWrapper, env, eval_sequences: Sequence[Tuple[object, Sequence[str]]],
+                        annotations: Dict[str, List[str]], task_checker, ep_len: int = EP_LEN) -> Optional[dict]:
+    """eval_utils.py:494-569: this rank's slice of the evaluation chains, then a reduction on rank 0.  Returns the result
+    dict on rank 0 (avg successful sequence length, chain success rates, exit-layer histogram of the successful steps,
+    steps/s of this job), None elsewhere."""
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    mine = ddist.shard_sequences(list(eval_sequences), rank, world)
+    n_layer = model.model.module.lang_encoder.config.n_layers
+    results, ok_exits, fail_exits, ok_steps = [], [], [], []
+    t0 = time.perf_counter()
+    for initial_state, seq in mine:
+        n_ok, oe, fe, st = evaluate_sequence(env, model, task_checker, seq, annotations, ep_len, initial_state)
+        results.append(n_ok)
+        ok_exits.extend(oe)
+        fail_exits.extend(fe)
+        ok_steps.extend(st)
+    wall = time.perf_counter() - t0
+    # exit statistics over the steps of SUCCESSFUL sub-tasks, like print_and_save (eval_utils.py:83-91); the `llm_time` slot
+    # carries this rank's wall time, so steps/s of the whole job = n_steps_all / (sum of walls / world)
+    packed = ddist.pack_metrics(results, ok_exits, n_layer, wall)
+    extra = torch.tensor([float(len(ok_exits) + len(fail_exits))], dtype=torch.float64)
+    out = ddist.reduce_metrics(torch.cat([packed, extra]), n_extra=1)   # ONE all-reduce (SUM) over RCCL / gloo
+    out["n_steps_all"] = int(out.pop("extra")[0])
+    out["wall_s_mean"] = out.pop("llm_time") / world
+    out["steps_per_s"] = out["n_steps_all"] / max(out["wall_s_mean"], 1e-9)
+    out["avg_steps_per_success"] = float(np.mean(ok_steps)) if ok_steps else float("nan")   # this rank's sub-tasks
+    return out if rank == 0 else None

@@ -65,6 +65,8 @@ def test_single_process_fallbacks():
     assert dd.world_info() == (0, 1)
     m = dd.reduce_metrics(dd.pack_metrics([5, 0], [1, 11], 12))
     assert m["avg_seq_len"] == 2.5 and m["avg_exit"] == 7.0
+    m = dd.reduce_metrics(torch.cat([dd.pack_metrics([5, 0], [1, 11], 12), torch.tensor([42.0], dtype=torch.float64)]), n_extra=1)
+    assert m["extra"] == [42.0] and m["avg_exit"] == 7.0 and len(m["exit_hist"]) == 12
     v = torch.ones(2, 3)
     assert dd.all_gather_values(v) is v
     try:

@@ -1,0 +1,98 @@
+"""Closed-loop rollout harness (deer_vla_amd/rollout.py) on the MI355X: ModelWrapper protocol, sub-task / chain drivers,
+metric reduction.  Reference: robot_flamingo/eval/eval_utils.py:152-700."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deer_vla_amd import rollout as ro  # noqa: E402
+from deer_vla_amd import synthetic as syn  # noqa: E402
+from deer_vla_amd.config import deer_tiny  # noqa: E402
+
+
+def test_preprocess_text_and_counts_cpu():
+    from deer_vla_amd.factory import SyntheticTokenizer, ClipImageProcessor
+    cfg = deer_tiny()
+    tok = SyntheticTokenizer(cfg)
+    ids, mask = ro.preprocess_text_calvin(["push the red block  "], tok)
+    assert ids.shape == mask.shape and ids.shape[0] == 1
+    assert int(ids[0, 0]) == cfg.media_token_id and int(ids[0, -2]) == cfg.eoc_token_id and int(ids[0, -1]) == tok.eos_token_id
+    img = ro.preprocess_image([np.ones((200, 200, 3), dtype=np.uint8)], ClipImageProcessor(cfg.image_size))
+    assert img.shape == (1, 3, cfg.image_size, cfg.image_size)
+    assert ro.count_success([5, 0, 3, 1]) == [0.75, 0.5, 0.5, 0.25, 0.25]
+    assert ro.count_exit_ratio([1, 1, 3], 4) == [0.0, 2 / 3, 0.0, 1 / 3]
+    env = ro.SyntheticEnv(seed=3)
+    o0 = env.get_obs()
+    o1, _, _, info = env.step(np.zeros(7, dtype=np.float16))
+    assert info == 1 and not np.array_equal(o0["rgb_obs"]["rgb_static"], o1["rgb_obs"]["rgb_static"])
+    assert ro.steps_task_checker(2)(0, 2, "x") and not ro.steps_task_checker(2)(0, 1, "x")
+
+
+@pytest.fixture(scope="module")
+def harness():
+    from deer_vla_amd.factory import create_model_and_transforms
+    from deer_vla_amd.value_net import ExitController, ActionValueNet
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, seed=5, std="fanin")
+    model, image_processor, tokenizer = create_model_and_transforms(
+        "ViT-L-14", "openai", "", "", cross_attn_every_n_layers=1, window_size=12, use_gripper=True, fusion_mode="post",
+        llm_name="mpt_dolly_3b", state_dict=sd, cfg=cfg)
+    vn = ActionValueNet(model.get_all_exit_idx(), model.extra_exit, cfg.exit_interval, 12, "L2")
+    ctl = ExitController(vn, model.get_all_exit_idx(), steps_per_stage=1, leq=True, max_layer=cfg.early_exit_layer + 1)
+    ctl._set_threshold_value([0.02] * (ctl.real_num_exit - 1) + [1e5])
+    return cfg, model, image_processor, tokenizer, ctl
+
+
+@pytest.mark.gpu
+def test_model_wrapper_step_protocol(harness):
+    cfg, model, image_processor, tokenizer, ctl = harness
+    w = ro.ModelWrapper(model, tokenizer, image_processor, torch.float32, use_diff=False, amp=True, exit_id=None, early_exit=True,
+                        exit_controller=ctl, multi_execution=1)
+    env = ro.SyntheticEnv(seed=1)
+    obs = env.get_obs()
+    w.reset()
+    acts, exits = [], []
+    for t in range(6):
+        ctl.module.set_timestep(t)
+        a = w.step(obs, "lift the blue block")
+        assert a.shape == (1, 7) and a.dtype == np.float16
+        assert a[0, 6] in (-1.0, 1.0) and np.all(np.abs(a[0, :6]) <= 1.0)          # tanh pose, gripper in {-1, +1}
+        assert w.current_exit_layer in model.get_all_exit_idx()
+        acts.append(a[0].copy())
+        exits.append(w.current_exit_layer)
+        obs, _, _, _ = env.step(a[0])
+    assert w.step(obs, "lift the blue block", get_action=False) is None
+    # the same observations through a fresh wrapper reproduce the episode (reset clears the LSTM / controller state)
+    env.reset()
+    env.shift = 0
+    obs = env.get_obs()
+    w.reset()
+    for t in range(6):
+        ctl.module.set_timestep(t)
+        a = w.step(obs, "lift the blue block")
+        assert np.array_equal(a[0], acts[t]) and w.current_exit_layer == exits[t]
+        obs, _, _, _ = env.step(a[0])
+    # a static exit_id wrapper always reports that layer
+    ws = ro.ModelWrapper(model, tokenizer, image_processor, torch.float32, exit_id=model.get_all_exit_idx()[0], early_exit=False)
+    ws.step(obs, "lift the blue block")
+    assert ws.current_exit_layer == model.get_all_exit_idx()[0]
+
+
+@pytest.mark.gpu
+def test_chain_evaluation_and_metrics(harness):
+    cfg, model, image_processor, tokenizer, ctl = harness
+    w = ro.ModelWrapper(model, tokenizer, image_processor, torch.float32, early_exit=True, exit_controller=ctl)
+    env = ro.SyntheticEnv(seed=2)
+    ann = {"a": ["open the drawer"], "b": ["turn on the light"], "c": ["push the block left"]}
+    seqs = [(None, ["a", "b", "c"]), (None, ["b", "a"]), (None, ["c"]), (None, ["a", "c", "b"])]
+    ok = ro.steps_task_checker(4)                      # every sub-task "succeeds" after 4 steps
+    out = ro.evaluate_policy_ddp(w, env, seqs, ann, ok, ep_len=6)
+    assert out["n_chains"] == 4 and out["avg_seq_len"] == (3 + 2 + 1 + 3) / 4
+    assert out["n_steps"] == out["n_steps_all"] == 4 * 9 and sum(out["exit_hist"]) == 36
+    assert out["chain_sr"][:3] == [1.0, 0.75, 0.5] and out["steps_per_s"] > 0
+    never = ro.steps_task_checker(10 ** 6)
+    out = ro.evaluate_policy_ddp(w, env, seqs[:2], ann, never, ep_len=5)
+    assert out["avg_seq_len"] == 0.0 and out["n_steps"] == 0 and out["n_steps_all"] == 2 * 5
