@@ -175,6 +175,30 @@ def test_tiny_dynamic_exit_episode_vs_oracle(tiny, max_layer, sps):
     assert exits == [x[0] for x in ref]
 
 
+def test_mpt7b_shaped_variant_dynamic_episode_vs_oracle():
+    """OpenFlamingo-9B / MPT-7B structure (BASELINE configs[4]) at reduced width: no q/k LayerNorm, ``norm_1/norm_2`` and
+    ``ffn.up_proj/down_proj`` parameter names, gated x-attn only in front of every 4th decoder layer, exits every 2 layers."""
+    cfg = deer_tiny(llm_name="mpt_9b", attn_qk_ln=False, cross_attn_every_n_layers=4, n_layers_total=12, early_exit_layer=9)
+    assert [i for i in range(cfg.n_layers) if cfg.has_xattn(i)] not in ([], list(range(cfg.n_layers)))
+    sd = syn.make_synthetic_state(cfg, 7, bf16_round=True)
+    assert any(".norm_1." in k for k in sd) and any("ffn.up_proj" in k for k in sd) and not any("q_ln" in k for k in sd)
+    eng = DeerEngine(cfg, sd)
+    inputs = make_inputs(cfg, 16, text_len=9)
+    thr, margin = probe_thresholds(cfg, sd, inputs, 12, 1)
+    assert margin > 0.01, margin
+    ref, _, _ = oracle_episode(cfg, sd, inputs, thr, 12, 1)
+    eng.configure_exit(cfg.exit_ids(), 12, 1)
+    eng.set_thresholds(thr)
+    eng.reset()
+    exits = []
+    for s, (rgb, grip, ids, mask) in enumerate(inputs):
+        r = eng.step(rgb, grip, ids, mask, use_graph=(s >= 2))
+        exits.append(r["exit_layer"])
+        assert r["exit_layer"] == ref[s][0], (s, exits, [x[0] for x in ref])
+        assert float((r["pose"] - ref[s][1]).abs().max()) < ACTION_TOL, s
+        assert abs(r["gripper"] - ref[s][2]) < ACTION_TOL
+
+
 def test_shadow_calibration_mode_records_every_exit_on_policy(tiny):
     """Shadow mode (bench.py calibration): all exits are evaluated every step, the state is committed at the first
     exit that fires.  Reference semantics restated with the oracle head/controller pieces."""
