@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --batched-envs 0"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 SMALL="python $ROOT/bench.py --full-depth-only 12 --no-cpu-baseline"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $SMALL > $OUT/fetch_bench.json 2> $OUT/fetch.err
