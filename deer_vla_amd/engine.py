@@ -879,6 +879,61 @@ class DeerEngine:
         self._ctl_host_np[:] = hm[W:]                            # keep the ordinary read-back buffer current (ctl_host users)
         return self.read_result()
 
+    # ------------------------------------------------------------------------- calibration (window mode)
+    def window_hidden_states(self, rgb_seq: torch.Tensor, grip_seq: torch.Tensor, ids: torch.Tensor, mask=None) -> torch.Tensor:
+        """hidden_states of EVERY layer for each frame pair of a calibration window (the ``hidden_states`` the reference's
+        forward hands to ``ActionValueNet(mode='generate')``, value_net.py:386).  rgb_seq / grip_seq: (W, 3, S, S); returns
+        (W, n_layers, T, d) fp32 on the device.  n_envs must be 1."""
+        assert self.B == 1
+        W = rgb_seq.shape[0]
+        last = self.cfg.n_layers - 1
+        out = None
+        torch.cuda.current_stream().wait_stream(self._side_stream)
+        for t in range(W):
+            T, use_mask = self.load_inputs(rgb_seq[t], grip_seq[t], ids, mask)
+            self.hold_dev.zero_()
+            self._enqueue_step(T, use_mask, last)                 # static full depth: every layer's output is kept
+            if out is None:
+                out = torch.empty(W, self.cfg.n_layers, T, self.cfg.d_model, device=self.dev)
+            out[t].copy_(self.hidden[:, :T])
+        return out
+
+    def _head_eval(self, feats: torch.Tensor, commit: bool) -> torch.Tensor:
+        """One DeterministicDecoder step on ``feats`` (T, d) from the current LSTM state; commit=True stores the new state
+        (update_hidden_state protocol, action_head.py:548-558).  Returns the device row [pose6, gripper prob, logit]."""
+        self.enqueue_head(0, feats.shape[0], abi.KIND_COMMIT, use_ctl=False, feats=feats, no_ctl_final=True)
+        if commit:
+            self.h_state.copy_(self.h_tmp)
+            self.c_state.copy_(self.c_tmp)
+        return self.action_dbg[0].clone()
+
+    def generate_values(self, hidden: torch.Tensor, rand_layers: Sequence[int], threshold_type: str = "L2") -> torch.Tensor:
+        """``ActionValueNet.forward(mode='generate')`` (value_net.py:134-160) for ONE window: for the time steps seq_id in
+        [W/2-1, W-1) the action of layer 0 and of every exit is predicted from [history = features of the random exit layers
+        ``rand_layers[:seq_id]`` ; this layer's feature at seq_id] with the LSTM run from a zero state (window mode == the
+        carried-state steps below); returns the deltas between consecutive exits, (n_exit, W - W/2) on the host."""
+        W = hidden.shape[0]
+        layers = [0] + list(self.exit_ids)
+        self.h_state.zero_()
+        self.c_state.zero_()
+        acts = []
+        for t in range(W - 1):
+            if t >= W // 2 - 1:
+                acts.append(torch.stack([self._head_eval(hidden[t, i].contiguous(), commit=False) for i in layers]))
+            self._head_eval(hidden[t, int(rand_layers[t])].contiguous(), commit=True)
+        a = torch.stack(acts, dim=1)[..., :6].cpu()                # (n_exit+1, W/2, 6)
+        prev, last = a[:-1], a[1:]
+        d = (prev - last).abs()
+        if threshold_type == "mean":
+            return d.mean(-1)
+        if threshold_type == "L2":
+            return d.pow(2).mean(-1).pow(0.5)
+        if threshold_type == "max":
+            return d.max(-1)[0]
+        if threshold_type == "cosine":
+            return 1 - torch.nn.functional.cosine_similarity(prev, last, dim=-1, eps=1e-5)
+        raise NotImplementedError(threshold_type)
+
     @staticmethod
     def _mark(stream):
         e = torch.cuda.Event(enable_timing=True)

@@ -107,8 +107,11 @@ class ExitController:
         return values
 
     def set_threshold(self, args, model, dataloader, exit_ratio, model_name, values=None):
+        """value_net.py:185-264: deltas over the calibration loader (every rank its share, all-gathered), then the solver."""
         if values is None:
-            raise NotImplementedError("calibration over a CALVIN dataloader is a 'next' row (SURVEY §8f.1); pass `values`")
+            from .distributed import all_gather_values
+            pred, _ = generate_action_values(args, model, self.value_net, dataloader, device_id=None)
+            values = all_gather_values(pred)
         return self.set_threshold_from_values(values, exit_ratio, model_name)
 
     def set_timestep(self, t):
@@ -122,3 +125,27 @@ class ExitController:
 
     def to(self, *a, **k):
         return self
+
+
+def generate_action_values(args, model, value_net: ActionValueNet, calvin_loader, device_id=None, generator=None):
+    """value_net.py:301-397 on the native engine.  ``calvin_loader`` yields the reference's CALVIN batches:
+    ``batch[0]`` images (bs, W, 3, S, S), ``batch[1]`` = (input_ids (bs, T), attention_mask (bs, T)), ``batch[3]`` gripper
+    frames (bs, W, 3, S, S); W must equal ``value_net.window_size``.  For every window the trunk is run at full depth on each
+    frame pair, the history fed to the head comes from a random exit layer per time step (flamingo_mpt.py:486-490,
+    ``generator`` seeds the choice) and ``DeerEngine.generate_values`` evaluates the window-mode deltas.
+    Returns (values (n_exit, n_windows * (W - W/2)), None) like the reference."""
+    eng = model.module.engine
+    exit_ids = list(value_net.exit_list)
+    W = value_net.window_size
+    out = []
+    for batch in calvin_loader:
+        images, (input_ids, attention_mask), gripper = batch[0], batch[1], batch[3]
+        assert images.shape[1] == W, (images.shape, W)
+        for b in range(images.shape[0]):
+            idx = torch.randint(0, len(exit_ids), (W,), generator=generator)
+            rand_layers = [exit_ids[int(i)] for i in idx]
+            ids = input_ids[b:b + 1].to(eng.dev)
+            mask = attention_mask[b:b + 1].to(eng.dev) if attention_mask is not None else None
+            hid = eng.window_hidden_states(images[b].to(eng.dev, torch.bfloat16), gripper[b].to(eng.dev, torch.bfloat16), ids, mask)
+            out.append(eng.generate_values(hid, rand_layers, value_net.threshold_type))
+    return torch.cat(out, dim=1), None

@@ -295,6 +295,33 @@ def gen_controller(name, n_layers, max_layer, steps_per_stage, threshold_type="L
          threshold_type=np.frombuffer(threshold_type.encode(), dtype=np.uint8), ctl_max_layer=ctl.max_layer)
 
 
+def gen_valuenet_generate(name="valuenet_generate.npz", threshold_type="L2"):
+    """Calibration ('generate') mode of the reference ActionValueNet (value_net.py:134-160): for the time steps in the second
+    half of a window, every exit's action is predicted in WINDOW mode from [history features of random exit layers ; this
+    exit's feature at the step]; deltas between consecutive exits (starting from layer 0's pseudo action)."""
+    _dist_init()
+    cfg, seed = small_cfg(early_exit_layer=7, window_size=8), 9
+    sd = syn.make_synthetic_state(cfg, seed)
+    head = build_ref_head(cfg, sd)
+    ws, bs, T = cfg.window_size, 2, 5
+    head.window_size = ws
+    exit_ids = cfg.exit_ids()
+    vn = ActionValueNet(exit_list=exit_ids, exit_head=head, interval=cfg.exit_interval, window_size=ws, threshold_type=threshold_type)
+    n_layers = cfg.n_layers
+    feats = seeded("gen.feats", (n_layers, bs * ws, T, cfg.d_model))
+    for l in range(1, n_layers):
+        feats[l] = feats[l - 1] + feats[l] * (0.6 ** l)
+    g = torch.Generator().manual_seed(11)
+    idx = torch.randint(0, len(exit_ids), (bs * ws,), generator=g)               # flamingo_mpt.py:486-490 (sampling strategy 1)
+    rand_layers = torch.tensor([exit_ids[int(i)] for i in idx])
+    rand_feat = torch.stack([feats[int(rand_layers[j]), j] for j in range(bs * ws)])
+    with torch.no_grad():
+        delta = vn(tuple(feats[l] for l in range(n_layers)), mode="generate", rand_layer_feat=rand_feat)
+    print(f"  {name}: delta {tuple(delta.shape)} mean per exit {delta.mean(1).numpy().round(4).tolist()}")
+    save(name, cfg, seed, feats=feats, rand_layers=rand_layers.numpy(), delta=delta, bs=bs,
+         threshold_type=np.frombuffer(threshold_type.encode(), dtype=np.uint8))
+
+
 def gen_thresholds():
     _dist_init()
     cfg = small_cfg(early_exit_layer=11)
@@ -531,6 +558,7 @@ if __name__ == "__main__":
     gen_controller("controller_s4.npz", n_layers=5, max_layer=4, steps_per_stage=1)
     gen_controller("controller_sps3.npz", n_layers=12, max_layer=12, steps_per_stage=3)
     gen_controller("controller_max.npz", n_layers=12, max_layer=8, steps_per_stage=1, threshold_type="max")
+    gen_valuenet_generate()
     gen_thresholds()
     gen_mosaic_loop()
     gen_deer_forward()

@@ -234,6 +234,55 @@ def test_shadow_calibration_mode_records_every_exit_on_policy(tiny):
     assert r["n_evals"] <= len(exit_ids) + 1
 
 
+def test_window_mode_calibration_values_vs_oracle(tiny):
+    """``generate_action_values`` / ``ExitController.set_threshold`` (value_net.py:185-264,301-397): window-mode deltas of a
+    calibration batch on the engine == the oracle's generate mode (pinned against the reference: valuenet_generate.npz)."""
+    from deer_vla_amd.value_net import ActionValueNet, ExitController, generate_action_values
+    cfg, sd, eng = tiny
+    W, bs = 8, 2
+    exit_ids = cfg.exit_ids()
+    gen = torch.Generator().manual_seed(4)
+    frames = [[syn.synthetic_step_inputs(cfg, 10 * b + t, text_len=9) for t in range(W)] for b in range(bs)]
+    images = torch.stack([torch.stack([f[0].reshape(3, cfg.image_size, cfg.image_size) for f in fr]) for fr in frames])
+    gripper = torch.stack([torch.stack([f[1].reshape(3, cfg.image_size, cfg.image_size) for f in fr]) for fr in frames])
+    ids = torch.cat([fr[0][2] for fr in frames])                       # (bs, T)
+    batch = (images, (ids, torch.ones_like(ids)), None, gripper)
+    # --- oracle: hidden states of every layer for every frame, same random history layers ---
+    model = orc.OracleDeer(sd, cfg)
+    head = model.extra_exit
+    head.window_size = W
+    vn_o = orc.OracleValueNet(exit_ids, head, cfg.exit_interval, W, "L2")
+    g2 = torch.Generator().manual_seed(4)
+    ref = []
+    for b in range(bs):
+        idx = torch.randint(0, len(exit_ids), (W,), generator=g2)
+        rl = [exit_ids[int(i)] for i in idx]
+        hid = []
+        for t in range(W):
+            rgb, grip, ids_t, mask = frames[b][t]
+            h, _ = orc.llm_forward(sd, cfg, ids_t, mask, model.encode_vision(rgb, grip), exit_id=cfg.n_layers - 1)
+            hid.append(torch.stack([x[0] for x in h]))                  # (L, T, d)
+        hid = torch.stack(hid)                                          # (W, L, T, d)
+        feats = tuple(hid[:, l] for l in range(cfg.n_layers))           # per layer: (bs*W = W, T, d)
+        rand_feat = torch.stack([hid[t, rl[t]] for t in range(W)])
+        ref.append(vn_o(feats, mode="generate", rand_layer_feat=rand_feat))
+    ref = torch.cat(ref, dim=1)
+
+    class _M:                                                           # the bits of MPTFlamingo generate_action_values touches
+        def __init__(self, e):
+            self.module, self.engine = self, e
+    eng.configure_exit(exit_ids, 12, 1)
+    vn = ActionValueNet(exit_ids, None, cfg.exit_interval, W, "L2")
+    vals, _ = generate_action_values(None, _M(eng), vn, [batch], generator=gen)
+    assert vals.shape == ref.shape == (len(exit_ids), bs * (W - W // 2))
+    assert float((vals - ref).abs().max()) < 5e-3, (vals, ref)
+    # and the controller solves thresholds from them exactly like from reference values
+    ctl = ExitController(vn, exit_ids, max_layer=12)
+    ctl.set_threshold(None, _M(eng), [batch], 0.8, cfg.llm_name, values=None)
+    ctl_ref = orc.OracleExitController(None, exit_ids, max_layer=12)
+    assert len(ctl.threshold_list()) == ctl_ref.real_num_exit and ctl.threshold_list()[-1] >= 1e7
+
+
 def test_graph_replay_is_bit_identical_to_eager(tiny):
     """Three schedules of the same dynamic step - eager launches, ONE graph with device-side skipping, and the pipelined
     pieces (two-chain vision, head evaluations on a side stream, host stops feeding at the published verdict) - give

@@ -77,6 +77,21 @@ def test_action_head_matches_reference(name):
     close(logits, g["wgrip_logits"], atol=1e-5)
 
 
+def test_value_net_generate_mode_matches_reference():
+    """Calibration deltas (value_net.py:134-160) over a window batch: history from random exit layers, window-mode head."""
+    cfg, seed, g = load("valuenet_generate.npz")
+    sd = state(cfg, seed)
+    head = orc.OracleHead(sd, cfg)
+    head.window_size = cfg.window_size
+    vn = orc.OracleValueNet(cfg.exit_ids(), head, cfg.exit_interval, cfg.window_size, s2str(g["threshold_type"]))
+    feats = g["feats"]
+    rl = g["rand_layers"]
+    rand_feat = torch.stack([feats[int(rl[j]), j] for j in range(feats.shape[1])])
+    delta = vn(tuple(feats[l] for l in range(feats.shape[0])), mode="generate", rand_layer_feat=rand_feat)
+    assert delta.shape == g["delta"].shape == (len(cfg.exit_ids()), int(g["bs"]) * (cfg.window_size - cfg.window_size // 2))
+    assert float((delta - g["delta"]).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("name", ["controller_b12.npz", "controller_s4.npz", "controller_sps3.npz",
                                   "controller_max.npz"])
 def test_exit_controller_trace_matches_reference(name):
