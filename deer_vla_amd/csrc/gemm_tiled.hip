@@ -13,6 +13,7 @@
 //  * LDS rows are padded by one 16-byte access (pitch 72 bf16) to spread ds_read_b128 over banks.
 //  * Epilogues fuse bias, QuickGELU / exact GELU, and the residual update x += tanh(gate) * y.
 #include "common.h"
+#include <cstdlib>
 
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_QGELU_BF16 = 2, EPI_GELU_BF16 = 3, EPI_RESADD_F32 = 4 };
 
@@ -161,7 +162,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // of WAVES issuing loads on it (~8-9 GB/s per wave: 4 waves 8 TB/s chip-wide, 8 waves 16 TB/s, 16 waves 20 TB/s),
 // not by how many loads each wave keeps in flight - so these kernels run 8-16 waves per workgroup and are sized so
 // that two workgroups fit on a CU.
-template <int BM, int BN, int WM, int WN, int D, int DBG = 0>   // DBG (ablation only): 1 = no MFMA/ds_read, 2 = no DMA in the loop
+template <int BM, int BN, int WM, int WN, int D, int DBG = 0, int U = 1>   // DBG (ablation only): 1 = no MFMA/ds_read, 2 = no DMA in the loop
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
                                                                         const bf16_t* __restrict__ W, int ldw, long strideW,
                                                                         const float* __restrict__ bias,
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
   static_assert(CH % NW == 0, "every wave must issue the same number of DMA loads (static vmcnt)");
   static_assert((BM / WM) % 16 == 0 && (BN / WN) % 16 == 0, "wave tile");
   static_assert((D - 2) * CPW <= 63, "vmcnt field");
+  static_assert(U >= 1 && D >= 2 * U, "U stages are consumed per barrier: U free slots + U landing + the rest in flight");
   constexpr int STAGE = (BM + BN) * 128;                            // bytes per ring stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -215,26 +217,36 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
   const int a_row = (wm * (BM / WM) + c) * 128, w_row = (BM + wn * (BN / WN) + c) * 128;
   const int sw0 = ((0 * 4 + g) ^ (c & 7)) << 4, sw1 = ((1 * 4 + g) ^ (c & 7)) << 4;
 
+  // U K-steps per barrier: with <= ~1 workgroup per CU (M = 257 / 514) nothing hides the wait -> barrier -> ds_read -> MFMA
+  // chain of a K-step, so U > 1 amortises it (D - U stages in flight at the loop top, U slots free behind the barrier).
+  constexpr int INFLIGHT = (U == 1) ? D - 1 : D - U;
 #pragma unroll
-  for (int t = 0; t < D - 1; ++t) issue(t);
-  for (int kt = 0; kt < nk; ++kt) {
-    wait_vmcnt<(D - 2) * CPW>();                // this wave's part of tile kt has landed
-    __builtin_amdgcn_s_barrier();               // ... everybody's part; and everybody finished reading tile kt-1
-    if (DBG != 2) issue(kt + D - 1);            // refill the slot of tile kt-1
-    const unsigned char* st = smem + (kt % D) * STAGE;
+  for (int t = 0; t < INFLIGHT; ++t) issue(t);
+  for (int kt = 0; kt < nk; kt += U) {
+    wait_vmcnt<(INFLIGHT - U) * CPW>();         // this wave's part of tiles kt .. kt+U-1 has landed
+    __builtin_amdgcn_s_barrier();               // ... everybody's part; and everybody finished reading the tiles before kt
+    if (DBG != 2) {
 #pragma unroll
-    for (int kk = 0; kk < (DBG == 1 ? 0 : 2); ++kk) {
-      const int sw = kk ? sw1 : sw0;
-      bf16x8 af[TM], wf[TN];
+      for (int u = 0; u < U; ++u) issue(kt + INFLIGHT + u);   // refill the slots freed by the previous iteration
+    }
 #pragma unroll
-      for (int j = 0; j < TM; ++j) af[j] = *reinterpret_cast<const bf16x8*>(st + a_row + j * 16 * 128 + sw);
+    for (int u = 0; u < U; ++u) {
+      if (U > 1 && kt + u >= nk) break;
+      const unsigned char* st = smem + ((kt + u) % D) * STAGE;
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + w_row + i * 16 * 128 + sw);
+      for (int kk = 0; kk < (DBG == 1 ? 0 : 2); ++kk) {
+        const int sw = kk ? sw1 : sw0;
+        bf16x8 af[TM], wf[TN];
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+        for (int j = 0; j < TM; ++j) af[j] = *reinterpret_cast<const bf16x8*>(st + a_row + j * 16 * 128 + sw);
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + w_row + i * 16 * 128 + sw);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+      }
     }
   }
 
@@ -273,14 +285,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
   }
 }
 
-template <int BM, int BN, int WM, int WN, int D, int DBG = 0>
+template <int BM, int BN, int WM, int WN, int D, int DBG = 0, int U = 1>
 static int launch_ring(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
                        int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate,
                        const int* ctl, hipStream_t st) {
   constexpr int smem = D * (BM + BN) * 128;
   static_assert(smem <= 160 * 1024, "LDS");
   static bool attr_set = false;
-  auto kern = &gemm_tiled_ring_kernel<BM, BN, WM, WN, D, DBG>;
+  auto kern = &gemm_tiled_ring_kernel<BM, BN, WM, WN, D, DBG, U>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return DEER_ERR_LAUNCH;
@@ -324,12 +336,14 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
   const bool ring_ok = (K % GT_BK) == 0;
   if (!ring_ok && tile >= 4) return DEER_ERR_SHAPE;
   if (tile < 0 || tile > 44) return DEER_ERR_SHAPE;
+  static const bool u2_ok = [] { const char* e = getenv("DEER_GEMM_U2"); return e == nullptr || e[0] != '0'; }();
   if (tile == 0) {
     // fill the 256 CUs first, then grow the tile (less L2->LDS traffic per flop)
     auto nblk = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
     if (!ring_ok) tile = (nblk(64, 128) >= 256) ? 2 : 1;
     else if (nblk(128, 128) >= 512) tile = 7;          // large M (window / calibration mode): MFMA-bound regime
-    else if (nblk(64, 64) > 512) tile = 8;             // measured on MI355X at M = 514 (tools/bench_gemm.py):
+    else if (nblk(64, 64) > 512) tile = 8;             // measured on MI355X at M = 257 / 514 (tools/bench_gemm.py):
+    else if (nblk(64, 64) > 256 && u2_ok) tile = 16;   //   two co-resident workgroups per CU: two K-steps per barrier (-8..10 %)
     else tile = 4;                                     //   64x64 / 8 waves wins whenever it gives <= 2 workgroups per CU
   }
   const bf16_t* a = reinterpret_cast<const bf16_t*>(A);
@@ -346,6 +360,11 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     case 8: return launch_ring<64, 128, 2, 4, 3>(DEER_ARGS);
     case 9: return launch_ring<32, 64, 2, 2, 6>(DEER_ARGS);
     case 10: return launch_ring<128, 128, 2, 4, 3>(DEER_ARGS);
+    case 12: return launch_ring<64, 64, 2, 4, 6, 0, 2>(DEER_ARGS);   // two K-steps per barrier
+    case 13: return launch_ring<64, 64, 2, 4, 8, 0, 2>(DEER_ARGS);
+    case 14: return launch_ring<64, 64, 2, 4, 8, 0, 4>(DEER_ARGS);   // four K-steps per barrier
+    case 15: return launch_ring<64, 128, 2, 4, 4, 0, 2>(DEER_ARGS);
+    case 16: return launch_ring<64, 64, 2, 4, 4, 0, 2>(DEER_ARGS);
     case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)
     case 34: return launch_ring<64, 64, 2, 4, 4, 2>(DEER_ARGS);
     case 44: return launch_ring<64, 64, 2, 4, 8>(DEER_ARGS);      // deeper ring

@@ -13,14 +13,15 @@ SHAPES = [("vit qkv", 514, 3072, 1024), ("vit out", 514, 1024, 1024), ("vit fc1"
           ("patch", 512, 1024, 640), ("perc kv", 640, 1024, 1024), ("perc q", 128, 512, 1024), ("perc ff1", 128, 4096, 1024),
           ("perc ff2", 128, 1024, 4096), ("media kv", 128, 12288, 1024)]
 NCOPY = 24
+TILES = tuple(int(t) for t in _s.argv[2].split(',')) if len(_s.argv) > 2 else (4, 5, 7, 8, 10, 0)
 for name, M, N, K in SHAPES:
-    M = M * MB
+    M = MB if MB > 16 else M * MB                      # argv[1] > 16: absolute row count (257 = one camera frame)
     A = torch.randn(M, K, device="cuda").bfloat16()
     Ws = [torch.randn(N, K, device="cuda").bfloat16() * K ** -0.5 for _ in range(NCOPY)]
     C = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
     ref = (A.float() @ Ws[0].float().t())
     line = f"{name:9s} M={M:4d} N={N:5d} K={K:4d} |"
-    for tile in (4, 5, 7, 8, 10, 0):
+    for tile in TILES:
         rc = lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(Ws[0]), K, None, abi.ptr(C), N, 0, M, N, K, 1, abi.EPI_BF16, None, tile, None, st())
         if rc != 0:
             line += f" t{tile}:  n/a "
@@ -38,5 +39,5 @@ for name, M, N, K in SHAPES:
         e1.record()
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / NCOPY
-        line += f" t{tile}:{us:6.1f}us"
+        line += f" t{tile}:{us:6.1f}us" + ("" if err < 5e-3 else f"(ERR {err:.1e})")
     print(line + f" | {2.0 * M * N * K / 1e6:8.0f} MF", flush=True)
