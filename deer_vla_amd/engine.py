@@ -109,6 +109,7 @@ class DeerEngine:
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self.segmented = segmented                    # dynamic steps fed in per-layer graph pieces (see _step_segmented)
         self._side_stream = torch.cuda.Stream(device=self.dev)
+        self._extra_streams: List[torch.cuda.Stream] = []
         self._seq = 0
         self._ids_tag = None
         self._trace = None                            # debugging aid: list of (label, event, host time) per piece
@@ -296,7 +297,7 @@ class DeerEngine:
         self.vws = self._vision_ws(N)
         self.img, self.vx, self.vis_x, self.vis_x_f32 = self.vws.img, self.vws.vx, self.vws.vis_x, self.vws.vis_x_f32
         self.vchains = []
-        n_ch = 2 if N >= 2 else 1
+        n_ch = max(1, min(N, int(os.environ.get("DEER_CHAINS", "2"))))
         per = (N + n_ch - 1) // n_ch
         for c in range(n_ch):
             lo, hi = c * per, min(N, (c + 1) * per)
@@ -663,6 +664,12 @@ class DeerEngine:
             abi.check(self.lib.deer_ctl_begin_step(abi.ptr(self.ctl), abi.ptr(info), self.B, _cur_stream()), "ctl_begin_step")
         self.enqueue_vision(part)
 
+    def _chain_stream(self, c: int):
+        """stream of vision chain c >= 2 (chain 0: caller's stream, chain 1: the side stream)"""
+        while len(self._extra_streams) < c - 1:
+            self._extra_streams.append(torch.cuda.Stream(device=self.dev))
+        return self._extra_streams[c - 2]
+
     def _enqueue_chain(self, c: int, part: str):
         """Vision tower of chain c of the two-stream schedule; chain 0's first piece also resets the control blocks (from
         the pinned step info)."""
@@ -790,7 +797,7 @@ class DeerEngine:
                 return g
             P["chain_head"] = [cap(lambda c=c: self._enqueue_chain(c, "head")) for c in range(len(self.vchains))]
             P["chain_tail"] = [cap(lambda c=c: self._enqueue_chain(c, "tail")) for c in range(len(self.vchains))]
-            P["ev_in"], P["ev_join"] = torch.cuda.Event(), torch.cuda.Event()
+            P["ev_in"], P["ev_join"] = torch.cuda.Event(), [torch.cuda.Event() for _ in self.vchains]
             for i, need_pseudo, is_exit, _ in plan:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -831,24 +838,27 @@ class DeerEngine:
 
         # vision: chain 0 on the main stream, the other chains on the side stream (they start once the inputs are in place)
         nch = len(self.vchains)
+        cst = [main_st] + [side if side is main_st or c == 1 else self._chain_stream(c) for c in range(1, nch)]
         if nch > 1:
             P["ev_in"].record(main_st)
-            side.wait_event(P["ev_in"])
-        P["chain_head"][0].replay()
+            for c in range(1, nch):
+                cst[c].wait_event(P["ev_in"])
+        for part in ("chain_head", "chain_tail"):
+            for c in range(nch):
+                if c == 0:
+                    P[part][0].replay()
+                else:
+                    with torch.cuda.stream(cst[c]):
+                        P[part][c].replay()
         if nch > 1:
-            with torch.cuda.stream(side):
-                for c in range(1, nch):
-                    P["chain_head"][c].replay()
-        P["chain_tail"][0].replay()
-        if nch > 1:
-            with torch.cuda.stream(side):
-                for c in range(1, nch):
-                    P["chain_tail"][c].replay()
-                P["ev_join"].record(side)
             if self._trace is not None:
                 self._trace.append(("chain0 (main)", self._mark(main_st), time.perf_counter()))
-                self._trace.append(("chain1 (side)", self._mark(side), time.perf_counter()))
-            main_st.wait_event(P["ev_join"])
+                self._trace.append(("chain1 (side)", self._mark(cst[1]), time.perf_counter()))
+            for c in range(1, nch):
+                if cst[c] is not main_st:
+                    ev = P["ev_join"][c]
+                    ev.record(cst[c])
+                    main_st.wait_event(ev)
         for i, need_pseudo, is_exit, _ in plan:
             # keep at most LOOKAHEAD trunk layers in flight beyond an undecided check
             while decided < len(exits) and exits[decided] + LOOK < i:
