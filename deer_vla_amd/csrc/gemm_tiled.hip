@@ -341,7 +341,8 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     // fill the 256 CUs first, then grow the tile (less L2->LDS traffic per flop)
     auto nblk = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
     if (!ring_ok) tile = (nblk(64, 128) >= 256) ? 2 : 1;
-    else if (nblk(128, 128) >= 512) tile = 7;          // large M (window / calibration mode): MFMA-bound regime
+    else if (nblk(128, 128) >= 256) tile = 17;         // big M (env batch / calibration): 128x128 with a SHALLOW ring (64 KB) so two
+                                                       //   workgroups share a CU and one's ds_read phase overlaps the other's MFMAs
     else if (nblk(64, 64) > 512) tile = 8;             // measured on MI355X at M = 257 / 514 (tools/bench_gemm.py):
     else if (nblk(64, 64) > 256 && u2_ok) tile = 16;   //   two co-resident workgroups per CU: two K-steps per barrier (-8..10 %)
     else tile = 4;                                     //   64x64 / 8 waves wins whenever it gives <= 2 workgroups per CU
@@ -365,6 +366,9 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     case 14: return launch_ring<64, 64, 2, 4, 8, 0, 4>(DEER_ARGS);   // four K-steps per barrier
     case 15: return launch_ring<64, 128, 2, 4, 4, 0, 2>(DEER_ARGS);
     case 16: return launch_ring<64, 64, 2, 4, 4, 0, 2>(DEER_ARGS);
+    case 17: return launch_ring<128, 128, 4, 4, 2>(DEER_ARGS);       // shallow ring, two workgroups per CU (64 KB LDS each)
+    case 18: return launch_ring<128, 128, 2, 4, 2>(DEER_ARGS);
+    case 19: return launch_ring<128, 128, 2, 2, 2>(DEER_ARGS);
     case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)
     case 34: return launch_ring<64, 64, 2, 4, 4, 2>(DEER_ARGS);
     case 44: return launch_ring<64, 64, 2, 4, 8>(DEER_ARGS);      // deeper ring

@@ -16,13 +16,15 @@ NCOPY = 24
 TILES = tuple(int(t) for t in _s.argv[2].split(',')) if len(_s.argv) > 2 else (4, 5, 7, 8, 10, 0)
 for name, M, N, K in SHAPES:
     M = MB if MB > 16 else M * MB                      # argv[1] > 16: absolute row count (257 = one camera frame)
-    A = torch.randn(M, K, device="cuda").bfloat16()
-    Ws = [torch.randn(N, K, device="cuda").bfloat16() * K ** -0.5 for _ in range(NCOPY)]
+    PAD = int(os.environ.get("PAD", "0"))                 # extra bf16 elements per row (row pitch K + PAD): L2 channel spread
+    LD = K + PAD
+    A = torch.randn(M, LD, device="cuda").bfloat16()
+    Ws = [torch.randn(N, LD, device="cuda").bfloat16() * K ** -0.5 for _ in range(NCOPY)]
     C = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
-    ref = (A.float() @ Ws[0].float().t())
+    ref = (A[:, :K].float() @ Ws[0][:, :K].float().t())
     line = f"{name:9s} M={M:4d} N={N:5d} K={K:4d} |"
     for tile in TILES:
-        rc = lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(Ws[0]), K, None, abi.ptr(C), N, 0, M, N, K, 1, abi.EPI_BF16, None, tile, None, st())
+        rc = lib.deer_gemm_bf16_nt(abi.ptr(A), LD, 0, abi.ptr(Ws[0]), LD, None, abi.ptr(C), N, 0, M, N, K, 1, abi.EPI_BF16, None, tile, None, st())
         if rc != 0:
             line += f" t{tile}:  n/a "
             continue
@@ -32,7 +34,7 @@ for name, M, N, K in SHAPES:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):                      # graph replay: no host launch cost in the measurement
             for w in Ws:
-                lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(w), K, None, abi.ptr(C), N, 0, M, N, K, 1, abi.EPI_BF16, None, tile, None, st())
+                lib.deer_gemm_bf16_nt(abi.ptr(A), LD, 0, abi.ptr(w), LD, None, abi.ptr(C), N, 0, M, N, K, 1, abi.EPI_BF16, None, tile, None, st())
         g.replay()
         e0.record()
         g.replay()

@@ -1,0 +1,26 @@
+#!/bin/bash
+# PMC passes over one GEMM shape.  usage: tools/gemm_pmc.sh M N K tile
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/gemm_pmc_$1_$2_$3_t$4
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAVES" \
+           "TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr TCP_TA_TCP_STATE_READ_sum" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
+           "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python $ROOT/tools/gemm_one.py $1 $2 $3 $4 > /dev/null 2> $OUT/p$i.err
+done
+python - <<PY
+import csv, glob, collections
+agg = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "gemm_tiled" in r["Kernel_Name"]:
+            a = agg[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+for k, (t, n) in sorted(agg.items()):
+    print(f"{k:40s} {t / n:16.1f}  (per dispatch, {n} dispatches)")
+PY
+tail -3 $OUT/p1.err
