@@ -162,7 +162,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // of WAVES issuing loads on it (~8-9 GB/s per wave: 4 waves 8 TB/s chip-wide, 8 waves 16 TB/s, 16 waves 20 TB/s),
 // not by how many loads each wave keeps in flight - so these kernels run 8-16 waves per workgroup and are sized so
 // that two workgroups fit on a CU.
-template <int BM, int BN, int WM, int WN, int D, int DBG = 0, int U = 1>   // DBG (ablation only): 1 = no MFMA/ds_read, 2 = no DMA in the loop
+template <int BM, int BN, int WM, int WN, int D, int DBG = 0, int U = 1, int PIPE = 0>   // DBG (ablation only): 1 = no MFMA/ds_read, 2 = no DMA in the loop
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
                                                                         const bf16_t* __restrict__ W, int ldw, long strideW,
                                                                         const float* __restrict__ bias,
@@ -217,6 +217,51 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
   const int a_row = (wm * (BM / WM) + c) * 128, w_row = (BM + wn * (BN / WN) + c) * 128;
   const int sw0 = ((0 * 4 + g) ^ (c & 7)) << 4, sw1 = ((1 * 4 + g) ^ (c & 7)) << 4;
 
+  if constexpr (PIPE) {
+    // Register-pipelined K loop: the fragments of K-step k+1 are read from LDS WHILE the MFMAs of K-step k run (two
+    // fragment sets, loop unrolled by two).  In the plain loop every wave leaves the barrier, reads its fragments, waits,
+    // then issues MFMAs - with one workgroup per CU the LDS phase and the MFMA phase of a K-step never overlap (PMC: MFMA
+    // 18 % busy, 55 % of wave cycles at s_waitcnt/s_barrier).  Here barrier k guarantees tile k+1 has landed, so the
+    // prefetch distance is D-2 K-steps and D is chosen deep (K-steps get ~2x shorter, the L2 latency does not).
+    static_assert(D >= 3 && U == 1, "pipelined loop: tile k+1 must be resident at barrier k");
+    bf16x8 fa[2][2][TM], fw[2][2][TN];
+    auto load_frags = [&](int set, int tile) {
+      const unsigned char* st = smem + (tile % D) * STAGE;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int sw = kk ? sw1 : sw0;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) fa[set][kk][j] = *reinterpret_cast<const bf16x8*>(st + a_row + j * 16 * 128 + sw);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fw[set][kk][i] = *reinterpret_cast<const bf16x8*>(st + w_row + i * 16 * 128 + sw);
+      }
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[set][kk][i], fa[set][kk][j], acc[i][j], 0, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < D - 1; ++t) issue(t);
+    wait_vmcnt<(D - 2) * CPW>();
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0);
+    for (int kt = 0; kt < nk; kt += 2) {            // nk is even (checked by the launcher)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = kt + h;
+        wait_vmcnt<(D - 3) * CPW>();                // this wave's part of tile k+1 has landed
+        __builtin_amdgcn_s_barrier();               // ... everybody's; and everybody has read tile k-1 (its slot is refilled now)
+        issue(k + D - 1);
+        if (k + 1 < nk) load_frags(h ^ 1, k + 1);
+        mma(h);
+      }
+    }
+  } else {
   // U K-steps per barrier: with <= ~1 workgroup per CU (M = 257 / 514) nothing hides the wait -> barrier -> ds_read -> MFMA
   // chain of a K-step, so U > 1 amortises it (D - U stages in flight at the loop top, U slots free behind the barrier).
   constexpr int INFLIGHT = (U == 1) ? D - 1 : D - U;
@@ -248,6 +293,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
       }
     }
+  }
+
   }
 
   const float gs = (epi == EPI_RESADD_F32 && gate != nullptr) ? tanhf(*gate) : 1.f;
@@ -285,14 +332,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
   }
 }
 
-template <int BM, int BN, int WM, int WN, int D, int DBG = 0, int U = 1>
+template <int BM, int BN, int WM, int WN, int D, int DBG = 0, int U = 1, int PIPE = 0>
 static int launch_ring(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
                        int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate,
                        const int* ctl, hipStream_t st) {
   constexpr int smem = D * (BM + BN) * 128;
   static_assert(smem <= 160 * 1024, "LDS");
   static bool attr_set = false;
-  auto kern = &gemm_tiled_ring_kernel<BM, BN, WM, WN, D, DBG, U>;
+  if (PIPE && ((K / GT_BK) & 1)) return DEER_ERR_SHAPE;   // pipelined loop is unrolled by two K-steps
+  auto kern = &gemm_tiled_ring_kernel<BM, BN, WM, WN, D, DBG, U, PIPE>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return DEER_ERR_LAUNCH;
@@ -345,7 +393,8 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
                                                        //   workgroups share a CU and one's ds_read phase overlaps the other's MFMAs
     else if (nblk(64, 64) > 512) tile = 8;             // measured on MI355X at M = 257 / 514 (tools/bench_gemm.py):
     else if (nblk(64, 64) > 256 && u2_ok) tile = 16;   //   two co-resident workgroups per CU: two K-steps per barrier (-8..10 %)
-    else tile = 4;                                     //   64x64 / 8 waves wins whenever it gives <= 2 workgroups per CU
+    else tile = 4;                                     //   64x64 / 8 waves wins whenever it gives <= 2 workgroups per CU (the
+                                                       //   register-pipelined loop, tile 26, is within noise of it end to end)
   }
   const bf16_t* a = reinterpret_cast<const bf16_t*>(A);
   const bf16_t* w = reinterpret_cast<const bf16_t*>(W);
@@ -367,8 +416,7 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     case 15: return launch_ring<64, 128, 2, 4, 4, 0, 2>(DEER_ARGS);
     case 16: return launch_ring<64, 64, 2, 4, 4, 0, 2>(DEER_ARGS);
     case 17: return launch_ring<128, 128, 4, 4, 2>(DEER_ARGS);       // shallow ring, two workgroups per CU (64 KB LDS each)
-    case 18: return launch_ring<128, 128, 2, 4, 2>(DEER_ARGS);
-    case 19: return launch_ring<128, 128, 2, 2, 2>(DEER_ARGS);
+    case 26: return launch_ring<64, 64, 2, 4, 4, 0, 1, 1>(DEER_ARGS);    // register-pipelined K loop (fragments of k+1 read under the MFMAs of k)
     case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)
     case 34: return launch_ring<64, 64, 2, 4, 4, 2>(DEER_ARGS);
     case 44: return launch_ring<64, 64, 2, 4, 8>(DEER_ARGS);      // deeper ring
