@@ -110,6 +110,8 @@ class DeerEngine:
         self.segmented = segmented                    # dynamic steps fed in per-layer graph pieces (see _step_segmented)
         self._side_stream = torch.cuda.Stream(device=self.dev)
         self._extra_streams: List[torch.cuda.Stream] = []
+        self._use_side = os.environ.get("DEER_SIDE", "1") == "1"          # debugging knobs (README)
+        self._lookahead = int(os.environ.get("DEER_LOOKAHEAD", self.LOOKAHEAD))
         self._seq = 0
         self._ids_tag = None
         self._trace = None                            # debugging aid: list of (label, event, host time) per piece
@@ -819,8 +821,8 @@ class DeerEngine:
         hm, seq, W = self._hm, self._seq, abi.CTL_WORDS
         if self._trace is not None:
             self._trace.append(("start", self._mark(main_st), time.perf_counter()))
-        side = self._side_stream if os.environ.get("DEER_SIDE", "1") == "1" else main_st
-        LOOK = int(os.environ.get("DEER_LOOKAHEAD", self.LOOKAHEAD))
+        side = self._side_stream if self._use_side else main_st
+        LOOK = self._lookahead
         exits = [i for i, _, is_exit, _ in plan if is_exit]      # exit k is decided by the check at layer exits[k]
         decided = 0                                              # number of exit checks whose verdict the host has seen
         done = False
