@@ -46,7 +46,7 @@ def parse():
                     help="also report the env-batched throughput (this many environments per GPU) in the `batched` object; "
                          "0/1 disables")
     ap.add_argument("--calib-steps", type=int, default=128)
-    ap.add_argument("--calib-iters", type=int, default=4)
+    ap.add_argument("--calib-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -242,7 +242,7 @@ def run_workload(args, cfg, sd_dev, B, rank, world, local_rank, dist, max_layer,
     # ---- threshold calibration for --exit-ratio (value_net.py:185-264 solver) -------------------------------
     # Fixed-point on-policy calibration: in shadow mode every exit's delta is recorded at every step while the LSTM
     # state follows the CURRENT exit policy; thresholds are re-solved for the target exit distribution
-    # p_k ~ exit_ratio^k until the policy's own delta distribution is the one the thresholds were solved on.
+    # p_k ~ exit_ratio^k (damped) until the policy's own delta distribution is the one the thresholds were solved on.
     real = ctl.real_num_exit
     thr = [-1.0] * (real - 1) + [1e5]
     for it in range(args.calib_iters):
@@ -254,7 +254,11 @@ def run_workload(args, cfg, sd_dev, B, rank, world, local_rank, dist, max_layer,
                 vals.append(re["deltas"][:real].clone())
         values = torch.stack(vals, dim=1)                  # (n_exit, n_samples)
         ctl.set_threshold_from_values(values, args.exit_ratio, cfg.llm_name)
-        thr = ctl.threshold_list()
+        new = ctl.threshold_list()
+        # damped update: with random weights the policy feeds back into its own deltas through the LSTM history so strongly
+        # that the undamped iteration oscillates between "everything exits at 1" and "nothing does" (tools/calib_check.py)
+        thr = new if it == 0 else [(0.7 * a + 0.3 * b) if b < 1e4 else b for a, b in zip(thr, new)]
+    ctl._set_threshold_value(thr)
     eng.set_thresholds(thr)
 
     # ---- timed region ----
