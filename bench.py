@@ -298,12 +298,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if os.environ.get("DEER_BENCH_SINGLE_DEVICE") == "1":   # test hook: all ranks on GPU 0 (with DEER_BENCH_BACKEND=gloo) to
+        local_rank = 0                                        # exercise the N>1 code path on a one-GPU box
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("DEER_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from deer_vla_amd import synthetic as syn
     from deer_vla_amd.config import deer_3b

@@ -320,8 +320,11 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
                                                          float* __restrict__ action_dbg, float eps) {
   const int b = blockIdx.x;
   if (head_skip(ctl0, kind, layer, B)) {
-    // a check nobody needed (stage hold): the host still learns that this segment is over
-    if (kind == KIND_CHECK && threadIdx.x == 0 && ((volatile int*)ctl0)[CTL_ALL_EXITED] == 0) check_done(ctl0, slot, B);
+    // Every workgroup of a CHECK launch reports exactly once, whatever path it takes: a check nobody needed (stage hold)
+    // still tells the host that this segment is over, and a workgroup that starts late may see ALL_EXITED raised by a
+    // sibling of the SAME launch - if it left silently the arrival counter would never reach B and no verdict would be
+    // published (seen with two processes time-slicing one GPU).
+    if (kind == KIND_CHECK && threadIdx.x == 0) check_done(ctl0, slot, B);
     return;
   }
   int* ctl = (ctl0 != nullptr) ? ctl0 + b * CTL_WORDS : nullptr;

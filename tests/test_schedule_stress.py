@@ -16,3 +16,16 @@ def test_pipelined_and_single_graph_schedules_never_diverge(steps, n_envs):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches 0" in r.stdout
+
+
+@pytest.mark.gpu
+def test_two_processes_sharing_the_gpu_do_not_lose_verdicts():
+    """Two engines in two processes time-slice the GPU: workgroups of one exit check start at very different times, which is
+    what exposed a lost verdict (a late workgroup saw ALL_EXITED raised by a sibling of the same launch and left without
+    reporting).  Both runs must finish (no 20 s verdict timeout) with zero mismatches."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "stress_schedules.py"), "tiny"]
+    ps = [subprocess.Popen(cmd + [str(n), str(b)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+          for n, b in ((1500, 4), (1500, 3))]
+    outs = [p.communicate(timeout=600)[0] for p in ps]
+    for p, o in zip(ps, outs):
+        assert p.returncode == 0 and "mismatches 0" in o, o[-2000:]
