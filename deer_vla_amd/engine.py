@@ -612,6 +612,9 @@ class DeerEngine:
 
     def reset(self):
         """Episode start: ``clear_all_exit_memory`` + controller state (eval_utils.py:252-277)."""
+        # a speculative head evaluation of the last step may still be queued on the side stream; it returns at entry only
+        # while that step's ALL_EXITED is set, so the control blocks / LSTM state must not be cleared underneath it
+        self._drain_side_streams()
         self.h_state.zero_()
         self.c_state.zero_()
         self.ctl.zero_()
@@ -666,6 +669,12 @@ class DeerEngine:
             abi.check(self.lib.deer_ctl_begin_step(abi.ptr(self.ctl), abi.ptr(info), self.B, _cur_stream()), "ctl_begin_step")
         self.enqueue_vision(part)
 
+    def _drain_side_streams(self):
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self._side_stream)
+        for st in self._extra_streams:
+            cur.wait_stream(st)
+
     def _chain_stream(self, c: int):
         """stream of vision chain c >= 2 (chain 0: caller's stream, chain 1: the side stream)"""
         while len(self._extra_streams) < c - 1:
@@ -719,7 +728,7 @@ class DeerEngine:
         committed at the first exit whose criterion fires, but the step never terminates early."""
         # speculative head evaluations of the previous step may still be draining on the side stream (they return at entry,
         # but only while that step's ALL_EXITED is still set): nothing of this step may start before they are gone
-        torch.cuda.current_stream().wait_stream(self._side_stream)
+        self._drain_side_streams()
         T, use_mask = self.load_inputs(rgb, gripper, ids, mask)
         if bool(shadow) != getattr(self, "_shadow_on", False):
             self.ctl[abi.CTL_SHADOW] = 1 if shadow else 0
@@ -900,7 +909,7 @@ class DeerEngine:
         W = rgb_seq.shape[0]
         last = self.cfg.n_layers - 1
         out = None
-        torch.cuda.current_stream().wait_stream(self._side_stream)
+        self._drain_side_streams()
         for t in range(W):
             T, use_mask = self.load_inputs(rgb_seq[t], grip_seq[t], ids, mask)
             self.hold_dev.zero_()

@@ -10,9 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("steps,n_envs", [(1500, 1), (800, 3)])
-def test_pipelined_and_single_graph_schedules_never_diverge(steps, n_envs):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_schedules.py"), "tiny", str(steps), str(n_envs)],
+@pytest.mark.parametrize("steps,n_envs,extra", [(1500, 1, []), (800, 3, []),
+                                                 (1500, 1, ["4", "5"]), (800, 2, ["4", "3"])])   # exits {1,3,4}, reset every few steps
+def test_pipelined_and_single_graph_schedules_never_diverge(steps, n_envs, extra):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_schedules.py"), "tiny", str(steps), str(n_envs)] + extra,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches 0" in r.stdout

@@ -1,6 +1,8 @@
 """Race hunt: the pipelined schedule (pieces on two streams, host polling the verdict mirror) against the single-graph
 schedule on identical inputs, step by step, for thousands of control steps with exits that keep changing.
-usage: stress_schedules.py [tiny|full] [steps] [n_envs]"""
+usage: stress_schedules.py [tiny|full] [steps] [n_envs] [early_exit_layer (tiny only)] [reset period]
+(early_exit_layer 4 gives exits {1,3,4}: after an exit at layer 3 a speculative head evaluation for layer 4 is still queued
+when the host moves on - the case reset() must drain)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +13,9 @@ from deer_vla_amd.engine import DeerEngine
 which = sys.argv[1] if len(sys.argv) > 1 else "tiny"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-cfg = deer_tiny() if which == "tiny" else deer_3b(max_layer=12)
+EEL = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+RESET = int(sys.argv[5]) if len(sys.argv) > 5 else 211
+cfg = deer_tiny(early_exit_layer=EEL) if which == "tiny" else deer_3b(max_layer=12)
 sd = syn.make_synthetic_state(cfg, seed=1, std="fanin" if which == "tiny" else "0.02", bf16_round=True)
 a = DeerEngine(cfg, sd, n_envs=B, segmented=True)
 b = DeerEngine(cfg, sd, n_envs=B, segmented=False)
@@ -41,7 +45,7 @@ for s in range(steps):
     if s % 37 == 0:
         thr = [float(med[k]) * float(torch.empty(1).uniform_(0.3, 3.0, generator=g)) for k in range(real - 1)] + [1e5]
         a.set_thresholds(thr); b.set_thresholds(thr)
-    if s % 211 == 0:
+    if s % RESET == 0:
         a.reset(); b.reset()
     rgb, grip = frames[s % POOL]
     ra = a.step(rgb, grip, ids, None)
