@@ -597,6 +597,8 @@ class DeerEngine:
         self.exit_ids = list(exit_ids)
         self.ctl_max_layer = min(max_layer - 1, self.exit_ids[-1])
         self.steps_per_stage = steps_per_stage
+        if self._graphs:
+            torch.cuda.synchronize(self.dev)                      # pieces of the last step may still be replaying
         self._graphs.clear()
 
     @property
