@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--batched-envs", type=int, default=4,
                     help="also report the env-batched throughput (this many environments per GPU) in the `batched` object; "
                          "0/1 disables")
+    ap.add_argument("--scripted-steps", type=int, default=200,
+                    help="also time this many steps of the scripted exit schedule (`scripted` object); 0 disables")
     ap.add_argument("--calib-steps", type=int, default=128)
     ap.add_argument("--calib-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -339,6 +341,47 @@ def main():
                    "graph": not args.no_graph, "weights_gb": round(eng.weight_bytes() / 1e9, 3),
                    "thresholds": [round(x, 6) for x in ctl.threshold_list()], "setup_s": round(res["setup_s"], 1)},
     }
+    # whole-step rooflines (the step is HBM-bound overall at one environment per GPU; both fractions reported):
+    # F(e) = 347.1 + 2.68 e + 0.082 n_head GFLOP and Bytes(e) = 0.814 + 0.174 e GB for e = avg number of trunk layers run
+    e_avg = res["avg_exit"]
+    xs = [e for e in cfg.exit_ids() if e <= eng.ctl_max_layer]
+    n_steps_h = max(sum(res["hist"]), 1)
+    n_head = 2.0 + (sum((xs.index(l) + 1) * h for l, h in enumerate(res["hist"]) if h and l in xs) / n_steps_h if world == 1 else 2.0)
+    gflop = 347.1 + 2.68 * e_avg + 0.082 * n_head
+    gbyte = 0.814 + 0.174 * e_avg
+    out["whole_step"] = {"algorithmic_gflop_per_step": round(gflop, 1), "algorithmic_gb_per_step": round(gbyte, 3),
+                         "TFLOP/s": round(gflop * value / world / 1e3, 1), "mfma_frac": round(gflop * value / world / 1e3 / MFMA_PEAK_TF, 4),
+                         "GB/s": round(gbyte * value / world, 1), "hbm_frac": round(gbyte * value / world / HBM_PEAK_GBS, 4),
+                         "note": "per GPU; weights counted once per step (bf16), SURVEY.md 8(d)"}
+    # scripted exit schedule: static exit ids drawn (seed 99) from p_k ~ exit_ratio^k, independent of the
+    # synthetic model's own (chaotic) delta statistics - a throughput figure that is comparable at a KNOWN average depth
+    if args.scripted_steps > 0 and B == 1 and max_layer == 12:
+        exits = [e for e in cfg.exit_ids() if e <= eng.ctl_max_layer]
+        pk = torch.tensor([args.exit_ratio ** k for k in range(1, len(exits) + 1)], dtype=torch.float64)
+        draw = torch.multinomial(pk / pk.sum(), args.scripted_steps, replacement=True, generator=torch.Generator().manual_seed(99))
+        sched = [exits[int(i)] for i in draw]
+        frames, ids_ = res["frames"], res["ids"]
+        eng.reset()
+        for e in exits:                                           # capture one graph per exit id
+            eng.step(frames[0][0], frames[0][1], ids_, None, exit_id=e)
+            eng.step(frames[0][0], frames[0][1], ids_, None, exit_id=e)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i, e in enumerate(sched):
+            eng.step(frames[i % len(frames)][0], frames[i % len(frames)][1], ids_, None, exit_id=e)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        st = torch.tensor([dt], dtype=torch.float64, device=eng.dev)
+        if dist is not None:
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        out["scripted"] = {"value": round(world * len(sched) / float(st[0]), 2), "unit": "action-steps/s", "steps": len(sched),
+                           "avg_exit_layer": round(sum(e + 1 for e in sched) / len(sched), 3),
+                           "note": "static exit_id per step drawn from p_k ~ exit_ratio^k (seed 99); single-graph schedule per "
+                                   "exit id, host reads the action after every step"}
     if rank == 0 and not args.no_roofline:
         out["roofline"] = measure_roofline(eng, cfg, res["frames"], res["ids"])
     # ---- the same workload with one ENV BATCH per rank (north_star: "one env batch per rank"): every weight byte and
