@@ -380,8 +380,8 @@ def main():
             dist.all_reduce(st, op=dist.ReduceOp.MAX)
         out["scripted"] = {"value": round(world * len(sched) / float(st[0]), 2), "unit": "action-steps/s", "steps": len(sched),
                            "avg_exit_layer": round(sum(e + 1 for e in sched) / len(sched), 3),
-                           "note": "static exit_id per step drawn from p_k ~ exit_ratio^k (seed 99); single-graph schedule per "
-                                   "exit id, host reads the action after every step"}
+                           "note": "static exit_id per step drawn from p_k ~ exit_ratio^k (seed 99); two-chain vision + one trunk "
+                                   "graph per exit id, host reads the action after every step"}
     if rank == 0 and not args.no_roofline:
         out["roofline"] = measure_roofline(eng, cfg, res["frames"], res["ids"])
     # ---- the same workload with one ENV BATCH per rank (north_star: "one env batch per rank"): every weight byte and

@@ -744,13 +744,14 @@ class DeerEngine:
             torch.cuda.current_stream().synchronize()
             self._hm[:2] = 0
             self._seq = 1
-        if seg_mode:
+        static_pieces = self.segmented and use_graph and sync and exit_id is not None and not shadow
+        if seg_mode or static_pieces:
             # the step info is read by ctl_begin_step straight from pinned host memory (no upload launch); the host only
             # rewrites it after the previous step's verdict, i.e. after that step's ctl_begin_step ran
             si = self._si_np
             si[0], si[1] = hold, self._seq
             self.cur_step += 1
-            return self._step_segmented(T, use_mask)
+            return self._step_segmented(T, use_mask) if seg_mode else self._step_static_pieces(T, use_mask, exit_id)
         si = self.step_info_host[self._seq & 7]
         si[0], si[1], si[2], si[3] = hold, self._seq, 0, 0
         self.hold_dev.copy_(si, non_blocking=True)
@@ -778,6 +779,75 @@ class DeerEngine:
         torch.cuda.current_stream().synchronize()
         return self.read_result()
 
+    def _vision_chain_graphs(self):
+        """Graphs of the vision tower as independent CHAINS of camera frames (chain 0 replays on the caller's stream, the
+        others on side streams): each chain's launch boundaries and latency-bound kernels hide behind the other chain's
+        work.  Every chain is two graphs, the first one SHORT (begin + patch embedding + a few ViT blocks): submitting a
+        graph costs the host ~12 us + 0.3 us per node and the GPU idles until the first piece of a step is submitted.
+        Captured once (the tower does not depend on the text length); the caller must have run the tower eagerly before."""
+        C = self._graphs.get("chains")
+        if C is None:
+            def cap(fn):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fn()
+                return g
+            C = {"chain_head": [cap(lambda c=c: self._enqueue_chain(c, "head")) for c in range(len(self.vchains))],
+                 "chain_tail": [cap(lambda c=c: self._enqueue_chain(c, "tail")) for c in range(len(self.vchains))],
+                 "ev_in": torch.cuda.Event(), "ev_join": [torch.cuda.Event() for _ in self.vchains]}
+            self._graphs["chains"] = C
+        return C
+
+    def _replay_vision_chains(self, main_st, side):
+        """chain 0 on the main stream, the other chains on the side stream(s) (they start once the inputs are in place);
+        the main stream continues after all of them (media tokens complete)."""
+        C = self._graphs["chains"]
+        nch = len(self.vchains)
+        cst = [main_st] + [side if side is main_st or c == 1 else self._chain_stream(c) for c in range(1, nch)]
+        if nch > 1:
+            C["ev_in"].record(main_st)
+            for c in range(1, nch):
+                cst[c].wait_event(C["ev_in"])
+        for part in ("chain_head", "chain_tail"):
+            for c in range(nch):
+                if c == 0:
+                    C[part][0].replay()
+                else:
+                    with torch.cuda.stream(cst[c]):
+                        C[part][c].replay()
+        if nch > 1:
+            if self._trace is not None:
+                self._trace.append(("chain0 (main)", self._mark(main_st), time.perf_counter()))
+                self._trace.append(("chain1 (side)", self._mark(cst[1]), time.perf_counter()))
+            for c in range(1, nch):
+                if cst[c] is not main_st:
+                    ev = C["ev_join"][c]
+                    ev.record(cst[c])
+                    main_st.wait_event(ev)
+
+    def _step_static_pieces(self, T, use_mask, exit_id):
+        """Static ``exit_id`` step with the two-chain vision tower: chain graphs, then ONE graph for the media K/V GEMM,
+        the embedding, layers 0..exit_id and the committing head call.  Same results as the single-graph schedule."""
+        key = (T, use_mask, "static", exit_id)
+        g = self._graphs.get(key)
+        main_st = torch.cuda.current_stream()
+        if g is None:
+            self.hold_dev.copy_(self.step_info_pinned, non_blocking=True)
+            self._enqueue_step(T, use_mask, exit_id)              # eager warm-up - a real step
+            main_st.synchronize()
+            self._vision_chain_graphs()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue_media_kv()
+                self.enqueue_llm_static(T, use_mask, exit_id)
+            self._graphs[key] = g
+        else:
+            self._replay_vision_chains(main_st, self._side_stream if self._use_side else main_st)
+            g.replay()
+        self.ctl_host.copy_(self.ctl, non_blocking=True)
+        main_st.synchronize()
+        return self.read_result()
+
     def _step_segmented(self, T, use_mask):
         """Dynamic step, host-fed in PIECES: one graph per trunk layer (piece 0 = vision + embedding + layer 0) on the main
         stream, one graph per head evaluation on a side stream.
@@ -799,18 +869,7 @@ class DeerEngine:
             self._enqueue_step(T, use_mask, None)                 # eager warm-up of the whole step - a real step
             main_st.synchronize()
             P = {"main": [], "head": {}, "ev": {}}
-            # the first piece is SHORT (begin + patch embedding + a few ViT blocks): submitting a graph costs the host
-            # ~12 us + 0.3 us per node, and the GPU idles until the first piece of a step is submitted
-            # The vision tower runs as independent CHAINS of camera frames (chain 0 on the main stream, the others on the side
-            # stream): each chain's launch boundaries and latency-bound kernels are hidden behind the other chain's work.
-            def cap(fn):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    fn()
-                return g
-            P["chain_head"] = [cap(lambda c=c: self._enqueue_chain(c, "head")) for c in range(len(self.vchains))]
-            P["chain_tail"] = [cap(lambda c=c: self._enqueue_chain(c, "tail")) for c in range(len(self.vchains))]
-            P["ev_in"], P["ev_join"] = torch.cuda.Event(), [torch.cuda.Event() for _ in self.vchains]
+            self._vision_chain_graphs()
             for i, need_pseudo, is_exit, _ in plan:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -849,29 +908,7 @@ class DeerEngine:
                         raise abi.DeerHipError("no exit verdict from the device within 20 s (check %d)" % (n_checks - 1))
             return hm[abi.HOSTM_DONE] == seq
 
-        # vision: chain 0 on the main stream, the other chains on the side stream (they start once the inputs are in place)
-        nch = len(self.vchains)
-        cst = [main_st] + [side if side is main_st or c == 1 else self._chain_stream(c) for c in range(1, nch)]
-        if nch > 1:
-            P["ev_in"].record(main_st)
-            for c in range(1, nch):
-                cst[c].wait_event(P["ev_in"])
-        for part in ("chain_head", "chain_tail"):
-            for c in range(nch):
-                if c == 0:
-                    P[part][0].replay()
-                else:
-                    with torch.cuda.stream(cst[c]):
-                        P[part][c].replay()
-        if nch > 1:
-            if self._trace is not None:
-                self._trace.append(("chain0 (main)", self._mark(main_st), time.perf_counter()))
-                self._trace.append(("chain1 (side)", self._mark(cst[1]), time.perf_counter()))
-            for c in range(1, nch):
-                if cst[c] is not main_st:
-                    ev = P["ev_join"][c]
-                    ev.record(cst[c])
-                    main_st.wait_event(ev)
+        self._replay_vision_chains(main_st, side)
         for i, need_pseudo, is_exit, _ in plan:
             # keep at most LOOKAHEAD trunk layers in flight beyond an undecided check
             while decided < len(exits) and exits[decided] + LOOK < i:
