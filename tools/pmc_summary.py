@@ -45,9 +45,38 @@ def traffic(fetch_dir, write_dir, out):
     print(json.dumps(classes, indent=1))
 
 
+def mfma(src, out):
+    """MFMA-busy % per kernel: SQ_VALU_MFMA_BUSY_CYCLES (busy cycles summed over the 1024 SIMDs) / (kernel-active cycles x
+    1024 SIMDs); GRBM_GUI_ACTIVE is summed over the 8 XCDs, so active cycles = GRBM_GUI_ACTIVE / 8."""
+    files = glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)
+    per = defaultdict(lambda: defaultdict(float))
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = (row.get("Kernel_Name", "?")[:90], row.get("Dispatch_Id", "0"))
+                per[k][row.get("Counter_Name", "?")] += float(row.get("Counter_Value", 0) or 0)
+    agg = defaultdict(lambda: [0.0, 0.0, 0])
+    for (name, _), c in per.items():
+        act = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        if act > 0:
+            a = agg[name]
+            a[0] += c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+            a[1] += act * 1024.0
+            a[2] += 1
+    lines = [f"{'kernel':90s} {'dispatches':>10s} {'active_us/dispatch':>18s} {'MFMA busy %':>12s}"]
+    for name, (busy, cap, n) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        lines.append(f"{name:90s} {n:10d} {cap / 1024.0 / n / 2400.0:18.2f} {100.0 * busy / cap:12.2f}")
+    txt = "\n".join(lines)
+    print(txt)
+    open(out, "w").write("# MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); active_us assumes 2.4 GHz; PMC serialises dispatches\n"
+                         + txt + "\n")
+
+
 def main():
     if sys.argv[1] == "--traffic":
         return traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+    if sys.argv[1] == "--mfma":
+        return mfma(sys.argv[2], sys.argv[3])
     src = sys.argv[1]
     files = [src] if src.endswith(".csv") else glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)
     agg = defaultdict(lambda: [0.0, 0])

@@ -12,10 +12,12 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 SMALL="python $ROOT/bench.py --full-depth-only 12 --no-cpu-baseline"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $SMALL > $OUT/fetch_bench.json 2> $OUT/fetch.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $SMALL > $OUT/write_bench.json 2> $OUT/write.err
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- $SMALL > $OUT/mfma_bench.json 2> $OUT/mfma.err
 find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 python $ROOT/tools/pmc_summary.py $OUT/fetch $OUT/pmc_fetch.txt > /dev/null
 python $ROOT/tools/pmc_summary.py $OUT/write $OUT/pmc_write.txt > /dev/null
 python $ROOT/tools/pmc_summary.py --traffic $OUT/fetch $OUT/write $OUT/pmc_traffic.json > /dev/null
+python $ROOT/tools/pmc_summary.py --mfma $OUT/mfma $OUT/pmc_mfma_busy.txt > /dev/null
 # raw per-dispatch tables are large: keep only the summaries
 find $OUT -name "*.csv" ! -name "kernel_stats.csv" -size +2M -delete
 find $OUT -name "*.db" -delete
