@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--workload", default="deer_b", choices=["deer_b", "deer_s"],
+    ap.add_argument("--workload", default="deer_b", choices=["deer_b", "deer_s", "deer_9b"],
                     help="deer_b: MPT-1B max_layer=12 exit_ratio 0.8 (the metric's config); deer_s: max_layer=4")
     ap.add_argument("--exit-ratio", type=float, default=0.8)
     ap.add_argument("--envs-per-gpu", type=int, default=1,
@@ -316,8 +316,12 @@ def main():
     from deer_vla_amd import synthetic as syn
     from deer_vla_amd.config import deer_3b
 
-    max_layer = 12 if args.workload == "deer_b" else 4
-    cfg = deer_3b(max_layer=max_layer)
+    max_layer = 4 if args.workload == "deer_s" else 12
+    if args.workload == "deer_9b":                             # BASELINE configs[4]: OpenFlamingo-9B / MPT-7B trunk, max_layer 12
+        from deer_vla_amd.config import deer_9b
+        cfg = deer_9b(max_layer=max_layer)
+    else:
+        cfg = deer_3b(max_layer=max_layer)
     sd = syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True)
     B = args.envs_per_gpu
     res = run_workload(args, cfg, sd, B, rank, world, local_rank, dist, max_layer, args.steps, args.warmup)
@@ -328,14 +332,16 @@ def main():
     t_max, value = res["t_max"], res["value"]
 
     out = {
-        "metric": "action-steps/sec (whole job) + avg exit-layer, MPT-1B max_layer=%d, synthetic CALVIN-D-shaped inputs" % max_layer,
+        "metric": "action-steps/sec (whole job) + avg exit-layer, %s max_layer=%d, synthetic CALVIN-D-shaped inputs"
+                  % ("MPT-7B" if args.workload == "deer_9b" else "MPT-1B", max_layer),
         "value": round(value, 2), "unit": "action-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "avg_exit_layer": round(res["avg_exit"], 3),
-        "config": {"workload": "OpenFlamingo-3B/MPT-1B DeeR-%s max_layer=%d exit_ratio=%.2f, step mode, %d env(s)/GPU per control "
+        "config": {"workload": "%s DeeR-%s max_layer=%d exit_ratio=%.2f, step mode, %d env(s)/GPU per control "
                                "step, 2x224x224 frames + %d text tokens per env, LSTM history carried over %d-step episodes"
-                               % ("B" if max_layer == 12 else "S", max_layer, args.exit_ratio, B, T, EP_LEN),
+                               % ("OpenFlamingo-9B/MPT-7B" if args.workload == "deer_9b" else "OpenFlamingo-3B/MPT-1B",
+                                  "B" if max_layer == 12 else "S", max_layer, args.exit_ratio, B, T, EP_LEN),
                    "envs_per_gpu": B, "ms_per_env_step": round(1e3 * t_max / (args.steps * B), 4),
                    "exit_hist": res["hist"] if world == 1 else None, "per_gpu_steps_per_s": round(value / world, 2),
                    "graph": not args.no_graph, "weights_gb": round(eng.weight_bytes() / 1e9, 3),
@@ -349,10 +355,12 @@ def main():
     n_head = 2.0 + (sum((xs.index(l) + 1) * h for l, h in enumerate(res["hist"]) if h and l in xs) / n_steps_h if world == 1 else 2.0)
     gflop = 347.1 + 2.68 * e_avg + 0.082 * n_head
     gbyte = 0.814 + 0.174 * e_avg
-    out["whole_step"] = {"algorithmic_gflop_per_step": round(gflop, 1), "algorithmic_gb_per_step": round(gbyte, 3),
-                         "TFLOP/s": round(gflop * value / world / 1e3, 1), "mfma_frac": round(gflop * value / world / 1e3 / MFMA_PEAK_TF, 4),
-                         "GB/s": round(gbyte * value / world, 1), "hbm_frac": round(gbyte * value / world / HBM_PEAK_GBS, 4),
-                         "note": "per GPU; weights counted once per step (bf16), SURVEY.md 8(d)"}
+    if args.workload != "deer_9b":                             # the constants above are the 3B model's
+        out["whole_step"] = {"algorithmic_gflop_per_step": round(gflop, 1), "algorithmic_gb_per_step": round(gbyte, 3),
+                             "TFLOP/s": round(gflop * value / world / 1e3, 1),
+                             "mfma_frac": round(gflop * value / world / 1e3 / MFMA_PEAK_TF, 4),
+                             "GB/s": round(gbyte * value / world, 1), "hbm_frac": round(gbyte * value / world / HBM_PEAK_GBS, 4),
+                             "note": "per GPU; weights counted once per step (bf16), SURVEY.md 8(d)"}
     # scripted exit schedule: static exit ids drawn (seed 99) from p_k ~ exit_ratio^k, independent of the
     # synthetic model's own (chaotic) delta statistics - a throughput figure that is comparable at a KNOWN average depth
     if args.scripted_steps > 0 and B == 1 and max_layer == 12:

@@ -413,3 +413,37 @@ def test_full_size_mpt1b_vitl14_steps_vs_oracle():
         rr = eng.step(rgb, grip, ids, mask, use_graph=False)
         assert rr["exit_layer"] == ref[s][0], (s, rr["exit_layer"], ref[s][0], rr["deltas"][:6], thr)
         assert float((rr["pose"] - ref[s][1]).abs().max()) < ACTION_TOL
+
+
+def test_full_size_mpt7b_openflamingo9b_steps_vs_oracle():
+    """BASELINE configs[4] at FULL size (MPT-7B trunk: d=4096, 32 heads x 128, FF 16384, gated x-attn in front of every 4th
+    layer, no q/k LayerNorm; 13 layers for max_layer=12): hidden states, static exits and a dynamic episode (pipelined
+    schedule included) against the fp32 CPU oracle."""
+    from deer_vla_amd.config import deer_9b
+    cfg = deer_9b(max_layer=12)
+    sd = syn.make_synthetic_state(cfg, 0, std="0.02", bf16_round=True)
+    eng = DeerEngine(cfg, sd)
+    inputs = make_inputs(cfg, 4)
+    model = orc.OracleDeer(sd, cfg)
+    model.set_all_exit_window_size(1)
+    rgb, grip, ids, mask = inputs[0]
+    last = cfg.n_layers - 1
+    o = model.forward(rgb, ids, mask, grip, exit_id=last)
+    eng.reset()
+    r = eng.step(rgb, grip, ids, mask, exit_id=last, use_graph=False)
+    for i in (0, 3, 7, last):                                  # 3, 7: layers with a gated x-attn block in front
+        a, b = eng.hidden[i, :ids.shape[1]].cpu(), o["hidden_states"][i][0]
+        assert float((a - b).norm() / b.norm()) < 2e-2, i
+    assert float((r["pose"] - o["logits"][0].reshape(-1)).abs().max()) < ACTION_TOL
+    assert abs(r["gripper"] - float(o["logits"][1])) < ACTION_TOL
+    thr, margin = probe_thresholds(cfg, sd, inputs, 12, iters=1)
+    ref, _, _ = oracle_episode(cfg, sd, inputs, thr, 12)
+    eng.configure_exit(cfg.exit_ids(), 12, 1)
+    eng.set_thresholds(thr)
+    for use_graph in (False, True, True):                      # eager, graph capture, pipelined replay
+        eng.reset()
+        for s, (rgb, grip, ids, mask) in enumerate(inputs):
+            rr = eng.step(rgb, grip, ids, mask, use_graph=use_graph)
+            assert rr["exit_layer"] == ref[s][0], (use_graph, s, rr["exit_layer"], ref[s][0], rr["deltas"][:7], thr)
+            assert float((rr["pose"] - ref[s][1]).abs().max()) < ACTION_TOL
+
