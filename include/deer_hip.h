@@ -12,8 +12,10 @@
  *   - bf16 data is passed as `const void*` (uint16 storage); f32 as float*
  *   - every function only ENQUEUES work on `stream` (graph-capturable, no allocation, no sync) and
  *     returns 0 on success, DEER_ERR_SHAPE (1) for an invalid argument, DEER_ERR_LAUNCH (2) if the launch failed
- *   - `ctl` is the device control block (int32[DEER_CTL_WORDS]); kernels on the early-exit path return at
- *     entry once ctl[DEER_CTL_EXIT_FLAG] != 0  (device-side termination, no host round trip per layer)
+ *   - `ctl` is the device control block array (int32[DEER_CTL_WORDS] per environment); kernels on the early-exit path
+ *     return at entry once ctl[DEER_CTL_ALL_EXITED] != 0 (device-side termination, no host round trip per layer); the
+ *     exit checks also publish their verdict into a pinned host mirror (DEER_CTL_HOST_PTR) so that the host can stop
+ *     enqueueing the remaining graph pieces of the step without the device ever waiting for it
  */
 #ifndef DEER_HIP_H
 #define DEER_HIP_H

@@ -46,5 +46,7 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "tiny"
     if which == "tiny":
         run(deer_tiny(), 3, "fanin", 5)
+    elif which == "full_fanin":                             # full size with fan-in scaled weights: O(1) activations everywhere
+        run(deer_3b(12), 0, "fanin", 11)
     else:
         run(deer_3b(12), 0, "0.02", 11)
