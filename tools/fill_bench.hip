@@ -59,8 +59,22 @@ void run(const char* name, const uint4* src, long n_vec, int blocks, int waves, 
          UNROLL, row_stride_vec, n_vec * 16 / 1e6, bytes / ms / 1e9, bytes / ms / 1e6 / blocks);
 }
 
-int main() {
+int main(int argc, char** argv) {
   unsigned* sink; hipMalloc(&sink, 4);
+  if (argc > 1) {   // "layout" mode: does a CONTIGUOUS 1 KiB per wave-load fill faster than 8 rows x 128 B at a 2 KiB pitch?
+    for (long mb : {1L, 8L, 64L}) {
+      long nv = mb * (1 << 20) / 16;
+      uint4* s2; hipMalloc(&s2, nv * 16); hipMemset(s2, 1, nv * 16);
+      for (int waves : {8, 16}) {
+        run<2, 4>("dma rows", s2, nv, 256, waves, 128, sink);
+        run<2, 4>("dma contig", s2, nv, 256, waves, 0, sink);
+        run<0, 8>("vgpr rows", s2, nv, 256, waves, 128, sink);
+        run<0, 8>("vgpr contig", s2, nv, 256, waves, 0, sink);
+      }
+      hipFree(s2);
+    }
+    return 0;
+  }
   long n_vec = 1L * (1 << 20) / 16;
   uint4* src; hipMalloc(&src, n_vec * 16); hipMemset(src, 1, n_vec * 16);
   for (int waves : {4, 8}) {
