@@ -10,6 +10,7 @@
 // (2) and (3) read their q / qkv input as split-K partial slabs of the skinny GEMM and reduce them while
 // loading (launch-boundary reduce), and write a bf16 activation that is the A operand of the next GEMM.
 #include "common.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // (1) MFMA attention, head_dim 64, kv_len <= 320.
@@ -25,8 +26,8 @@
 // Optional extras (gated x-attn inside the LLM, helpers.py:192-232): Q given as f32 split-K partial slabs
 // (q_slabs > 0: Q points to f32, reduced while loading), keys masked by media time (text_time[q] == key/n_per_media + 1,
 // rows with text_time == 0 zeroed), f32 output, early-exit control block.
-template <bool XATTN>
-__global__ __launch_bounds__(256) void attn_mfma_kernel(const void* __restrict__ Qv, const bf16_t* __restrict__ Kp,
+template <bool XATTN, int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __restrict__ Qv, const bf16_t* __restrict__ Kp,
                                                         const bf16_t* __restrict__ V, void* __restrict__ Ov,
                                                         int q_len, int kv_len, int ldq, int ldk, int ldv, int ldo,
                                                         long q_bstride, long k_bstride, long v_bstride, long o_bstride,
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const void* __restrict__
   const bf16_t* Kb2 = K2 != nullptr ? K2 + b * bstride2 + h * AM_HD : nullptr;
   const bf16_t* Vb2 = V2 != nullptr ? V2 + b * bstride2 + h * AM_HD : nullptr;
 
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = blockIdx.x * (16 * NWAVE) + wave * 16;
 
   // Q fragments first (MFMA "B" operand: B[k = d][n = query]; rows >= q_len are zero): their global-load latency
   // overlaps the K/V staging below instead of following the barrier
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const void* __restrict__
   // ---- stage K (row-major) and V (transposed) for this head; rows >= kv_len are zero ----
   // two key rows per thread: K rows are copied as they are, V is transposed with 32-bit LDS stores that carry the
   // same d of two adjacent keys (half the store instructions of a per-element transpose)
-  for (int idx = tid; idx < (kvpad >> 1) * 8; idx += 256) {
+  for (int idx = tid; idx < (kvpad >> 1) * 8; idx += 64 * NWAVE) {
     const int row = (idx >> 3) * 2, seg = idx & 7;
     uint4 k0 = uint4{0, 0, 0, 0}, k1 = k0, v0 = k0, v1 = k0;
     if (row < kv_len) {
@@ -212,23 +213,32 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
   static bool attr_set = false;
   constexpr int max_smem = (AM_MAXT * 16 * AM_KPITCH + AM_HD * (AM_MAXT * 16 + 8)) * 2;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             max_smem) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            max_smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             max_smem) != hipSuccess)
       return DEER_ERR_LAUNCH;
     attr_set = true;
   }
-  dim3 grid((q_len + 63) / 64, heads, batch);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bf16_t* kp = reinterpret_cast<const bf16_t*>(K);
   const bf16_t* vp = reinterpret_cast<const bf16_t*>(V);
+  // 8 waves (128 queries) per workgroup when there are many queries: the K/V staging of a head is shared by twice as many
+  // queries and is pulled by twice as many waves (the per-CU fill rate grows with the number of waves issuing loads)
+  static const bool wide_ok = [] { const char* e = getenv("DEER_ATTN_WIDE"); return e == nullptr || e[0] != '0'; }();
+  const bool wide = wide_ok && q_slabs == 0 && q_len > 64;
+  dim3 grid((q_len + (wide ? 127 : 63)) / (wide ? 128 : 64), heads, batch);
+#define DEER_ATTN_ARGS Q, kp, vp, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride, scale, q_slabs, \
+                       q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2
   if (q_slabs > 0)
-    hipLaunchKernelGGL(attn_mfma_kernel<true>, grid, dim3(256), smem, st, Q, kp, vp, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride,
-                       k_bstride, v_bstride, o_bstride, scale, q_slabs, q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2);
+    hipLaunchKernelGGL((attn_mfma_kernel<true, 4>), grid, dim3(256), smem, st, DEER_ATTN_ARGS);
+  else if (wide)
+    hipLaunchKernelGGL((attn_mfma_kernel<false, 8>), grid, dim3(512), smem, st, DEER_ATTN_ARGS);
   else
-    hipLaunchKernelGGL(attn_mfma_kernel<false>, grid, dim3(256), smem, st, Q, kp, vp, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride,
-                       k_bstride, v_bstride, o_bstride, scale, q_slabs, q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2);
+    hipLaunchKernelGGL((attn_mfma_kernel<false, 4>), grid, dim3(256), smem, st, DEER_ATTN_ARGS);
+#undef DEER_ATTN_ARGS
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
