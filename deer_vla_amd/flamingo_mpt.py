@@ -97,6 +97,29 @@ class LangEncoder:
     def get_input_embeddings(self):
         return self._m.engine.wte
 
+    # ---- construction-time mixin API (flamingo_lm.py:136-202, factory.py:139-159); the native model is built finished ----
+    def init_flamingo(self, media_token_id, lang_hidden_size=None, vis_hidden_size=None, cross_attn_every_n_layers=None,
+                      gradient_checkpointing=False):
+        """Already initialised by the factory; accepted for call-site compatibility (the structure is fixed by the config)."""
+        cfg = self._m.cfg
+        if media_token_id != cfg.media_token_id or (cross_attn_every_n_layers not in (None, cfg.cross_attn_every_n_layers)):
+            raise NotImplementedError("the native model's media token / x-attn spacing come from its DeerConfig")
+        self.initialized_flamingo = True
+
+    def _set_decoder_layers(self, value):
+        raise NotImplementedError("decoder layers are device-resident weights of the engine, not Python modules")
+
+    def _delete_decoder_layers(self, indices):
+        """flamingo_mpt.py:191-198 truncates the LLM to early_exit_layer+1 layers; the native config is built truncated."""
+        if any(i < self._m.cfg.n_layers for i in indices):
+            raise NotImplementedError("rebuild the model with a smaller early_exit_layer instead")
+
+    def resize_token_embeddings(self, new_num_tokens=None):
+        """factory.py:148: grows wte for the added <image>/<|endofchunk|>/<PAD> tokens; the native wte already has them."""
+        if new_num_tokens is not None and new_num_tokens > self._m.cfg.vocab_size:
+            raise NotImplementedError("vocabulary larger than the configured %d" % self._m.cfg.vocab_size)
+        return self.get_input_embeddings()
+
     def forward(self, input_ids, attention_mask=None, past_key_values=None, prefix_mask=None, sequence_id=None,
                 return_dict=None, output_attentions=None, output_hidden_states=None, use_cache=None,
                 exit_controller=None, exit_id=None, all_hidden_states=None, eval_flop=False, eval_time=False):

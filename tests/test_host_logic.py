@@ -92,6 +92,17 @@ def test_factory_surface_and_state_dict_contract_on_cpu():
         state_dict=sd, cfg=cfg)
     assert model.module is model and model.get_all_exit_idx() == cfg.exit_ids()
     assert model.lang_encoder.config.n_layers == cfg.n_layers and model.lang_encoder.config.d_model == cfg.d_model
+    # construction-time mixin API of the reference (flamingo_lm.py:136-202, factory.py:139-159) is accepted on the finished model
+    le = model.lang_encoder
+    le.init_flamingo(media_token_id=cfg.media_token_id, lang_hidden_size=cfg.d_model, vis_hidden_size=cfg.vit_width,
+                     cross_attn_every_n_layers=cfg.cross_attn_every_n_layers, gradient_checkpointing=False)
+    le._delete_decoder_layers(list(range(cfg.n_layers, cfg.n_layers + 4)))
+    assert len(le._get_decoder_layers()) == cfg.n_layers == len(le.gated_cross_attn_layers) == len(le.old_decoder_blocks)
+    assert le.initialized_flamingo and not le.is_conditioned()
+    with pytest.raises(NotImplementedError):
+        le._delete_decoder_layers([0])
+    with pytest.raises(NotImplementedError):
+        le.init_flamingo(media_token_id=cfg.media_token_id + 1)
     # DeeR ckpt style keys
     k = "lang_encoder.transformer.blocks.1.gated_cross_attn_layer.attn.to_q.weight"
     new = torch.full_like(sd[k], 0.25)
