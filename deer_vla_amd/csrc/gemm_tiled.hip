@@ -416,6 +416,15 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     case 15: return launch_ring<64, 128, 2, 4, 4, 0, 2>(DEER_ARGS);
     case 16: return launch_ring<64, 64, 2, 4, 4, 0, 2>(DEER_ARGS);
     case 17: return launch_ring<128, 128, 4, 4, 2>(DEER_ARGS);       // shallow ring, two workgroups per CU (64 KB LDS each)
+    // 64x64 WAVE tiles (4x4 MFMA tiles per wave): one ds_read_b128 per two MFMAs instead of one per MFMA - the 32x32 wave tiles of
+    // tiles 7/17 spend as many LDS cycles on fragment reads as the SIMDs spend on MFMAs (16 waves x 4 reads x 4 clk = 4 x 4 MFMAs x 16 clk)
+    case 18: return launch_ring<128, 128, 2, 2, 2>(DEER_ARGS);       // 4 waves, 64 KB: two workgroups per CU
+    case 19: return launch_ring<128, 128, 2, 2, 4>(DEER_ARGS);       // 4 waves, 128 KB ring
+    case 20: return launch_ring<256, 128, 4, 2, 3>(DEER_ARGS);       // 8 waves, 144 KB ring
+    case 21: return launch_ring<256, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves, 96 KB
+    case 22: return launch_ring<128, 256, 2, 4, 3>(DEER_ARGS);       // 8 waves, 144 KB ring
+    case 23: return launch_ring<256, 256, 4, 4, 2>(DEER_ARGS);       // 16 waves, 128 KB
+    case 25: return launch_ring<128, 128, 2, 2, 3>(DEER_ARGS);       // 4 waves, 96 KB
     case 26: return launch_ring<64, 64, 2, 4, 4, 0, 1, 1>(DEER_ARGS);    // register-pipelined K loop (fragments of k+1 read under the MFMAs of k)
     case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)
     case 34: return launch_ring<64, 64, 2, 4, 4, 2>(DEER_ARGS);

@@ -1,0 +1,89 @@
+"""Full-size 360-step episodes of the HIP engine against committed fp32-oracle traces (tests/golden/episode_full.npz, made by
+tests/golden/make_episode_goldens.py): thresholds come from the REAL solver (value_net.py:203-260) at exit_ratio 0.8 and 1.0
+for DeeR-B max_layer=12 (BASELINE.json configs[2], configs[3]) and 0.8 for DeeR-S max_layer=4 (configs[1]).
+
+Gate (SURVEY.md §8d / BASELINE north_star): actions within 1e-2 at every step; exit layer identical at every step whose
+oracle decision is not knife-edge (relative margin |delta - thr| / thr > 1e-2 at every exit check the oracle evaluated).
+Knife-edge steps are COUNTED and reported; when the engine's decision differs on one of them the step is replayed with the
+oracle's exit layer (static ``exit_id``) from the pre-step LSTM state, so the two trajectories stay aligned and every later
+step remains a like-for-like comparison.  A mismatch outside the band fails the test."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from deer_vla_amd import synthetic as syn  # noqa: E402
+from deer_vla_amd.config import DeerConfig  # noqa: E402
+from deer_vla_amd.engine import DeerEngine  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "episode_full.npz")
+ACTION_TOL = 1e-2
+BAND = 1e-2
+REPORT = {}
+
+
+def _dump_report():
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "episode_parity_report.json"), "w") as fh:
+            json.dump(REPORT, fh, indent=1)
+
+
+def replay_episode(z, tag, n_steps=None, n_envs=1):
+    cfg = DeerConfig(**json.loads(bytes(z[tag + "_cfg_json"]).decode()))
+    max_layer = int(z[tag + "_max_layer"])
+    thr = [float(t) for t in z[tag + "_thr"]]
+    ref_exit, ref_act, margin = z[tag + "_exit"], z[tag + "_action"], z[tag + "_margin"]
+    n = int(z["n_steps"]) if n_steps is None else min(n_steps, int(z["n_steps"]))
+    sd = syn.make_synthetic_state(cfg, int(z["seed"]), std="0.02", bf16_round=True)
+    eng = DeerEngine(cfg, sd)
+    eng.configure_exit(cfg.exit_ids(), max_layer, 1)
+    eng.set_thresholds(thr)
+    eng.reset()
+    outside, flips, worst, worst_at = [], [], 0.0, -1
+    hist = {}
+    for s in range(n):
+        rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, s)
+        h0, c0 = eng.h_state.clone(), eng.c_state.clone()
+        r = eng.step(rgb, grip, ids, mask)
+        e_ref = int(ref_exit[s])
+        if r["exit_layer"] != e_ref:
+            rec = dict(step=s, engine=r["exit_layer"], oracle=e_ref, margin=float(margin[s]),
+                       engine_deltas=[round(float(v), 6) for v in r["deltas"][:len(thr)]])
+            (flips if margin[s] <= BAND else outside).append(rec)
+            torch.cuda.synchronize()
+            eng.h_state.copy_(h0)
+            eng.c_state.copy_(c0)
+            r = eng.step(rgb, grip, ids, mask, exit_id=e_ref)       # re-align on the oracle's trajectory
+        hist[r["exit_layer"]] = hist.get(r["exit_layer"], 0) + 1
+        err = max(float((r["pose"] - torch.from_numpy(ref_act[s, :6])).abs().max()), abs(r["gripper"] - float(ref_act[s, 6])))
+        if err > worst:
+            worst, worst_at = err, s
+    rep = dict(steps=n, thresholds=thr, exit_hist={int(k): v for k, v in sorted(hist.items())},
+               knife_edge_steps=int((margin[:n] <= BAND).sum()), knife_edge_flips=flips, mismatches_outside_band=outside,
+               worst_action_err=worst, worst_action_err_step=worst_at, band=BAND)
+    REPORT[tag] = rep
+    _dump_report()
+    print(f"\n[{tag}] {n} steps, exits {rep['exit_hist']}, knife-edge steps {rep['knife_edge_steps']} "
+          f"(engine decided differently on {len(flips)}), mismatches outside the band {len(outside)}, "
+          f"worst |action - oracle| {worst:.2e} at step {worst_at}")
+    return rep
+
+
+@pytest.fixture(scope="module")
+def golden():
+    assert os.path.exists(GOLD), "tests/golden/episode_full.npz missing (run tests/golden/make_episode_goldens.py)"
+    return np.load(GOLD)
+
+
+@pytest.mark.parametrize("tag", ["b08", "b10", "s08"])
+def test_full_size_360_step_episode_matches_oracle_trace(golden, tag):
+    rep = replay_episode(golden, tag)
+    assert rep["worst_action_err"] < ACTION_TOL, rep
+    assert not rep["mismatches_outside_band"], rep["mismatches_outside_band"]
+    assert len(rep["exit_hist"]) > 1 or tag == "s08", rep["exit_hist"]
