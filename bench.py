@@ -97,17 +97,16 @@ def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
         eng.load_inputs(rgb, grip, ids, None)
         eng.hold_dev.fill_(0)
         torch.cuda.synchronize()
-        eng._prof = []
+        eng.prof_begin()
         lib.deer_spin_us(12000, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         eng._enqueue_step(T, False, exit_id)
-        torch.cuda.synchronize()
-        prof, eng._prof = eng._prof, None
+        prof = eng.prof_end()
         if p == 0:
             continue                                      # first pass warms caches / clocks
-        for name, e0, e1, fl, by in prof:
+        for name, us, fl, by in prof:
             name = SAME_KERNEL.get(name, name)                  # entry points that launch the same kernel
             d = agg.setdefault(name, dict(us=0.0, n=0, flops=0.0, bytes=0.0))
-            d["us"] += max(1e3 * e0.elapsed_time(e1) - overhead_us, 0.0)
+            d["us"] += max(us - overhead_us, 0.0)
             d["n"] += 1
             d["flops"] += fl
             d["bytes"] += by

@@ -37,7 +37,7 @@ SIGNATURES = {
     "deer_vit_embed_lnpre": [P, P, P, P, P, P, I, I, I, F, P],
     "deer_embed_tokens": [P, P, P, P, I, I, I, I, I, P],
     "deer_broadcast_rows": [P, P, L, I, P],
-    "deer_head_pool": [P, P, I, I, I, I, P, I, I, P],
+    "deer_head_pool": [P, P, I, I, I, I, P, P, I, I, P],
     "deer_head_lstm_layer": [P, L, I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, P, I, I, P],
     "deer_head_fc": [P, I, I, I, P, P, P, P, P, P, P, P, I, P, I, F, P, I, I, P],
     "deer_head_final": [P, I, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, I, I, P, F, P],
@@ -45,8 +45,36 @@ SIGNATURES = {
     "deer_spin_us": [I, P],
     "deer_hip_arch": [],
     "deer_hip_abi_version": [],
+    # ---- the native spine (include/deer_model.h) ----
+    "deer_model_create": [P, P],
+    "deer_model_destroy": [P],
+    "deer_model_arena_bytes": [P],
+    "deer_model_workspace_bytes": [P],
+    "deer_model_bind": [P, P, P],
+    "deer_model_load_tensor": [P, c_char_p, P, I, L, P],
+    "deer_model_knows_tensor": [P, c_char_p],
+    "deer_model_missing_tensors": [P, P, I],
+    "deer_model_buffer": [P, I, c_char_p, P, P],
+    "deer_model_configure_exit": [P, P, I, I, I, I],
+    "deer_model_real_num_exit": [P],
+    "deer_vit_l14_encode": [P, P, I, P, P],
+    "deer_perceiver_resample": [P, P, I, P, P, P],
+    "deer_llm_early_exit": [P, P, P, I, P, I, I, P, P, P],
+    "deer_begin_step": [P, P, P],
+    "deer_vision": [P, I, I, I, P],
+    "deer_media_kv": [P, P],
+    "deer_llm_embed": [P, I, P],
+    "deer_llm_layer": [P, I, I, I, I, I, I, P],
+    "deer_head_eval": [P, I, I, I, I, I, I, I, I, P, I, P],
+    "deer_step_enqueue": [P, I, I, I, I, P, P],
+    "deer_dynamic_plan": [P, P, P, P, I],
+    "deer_model_n_chains": [P],
+    "deer_prof_enable": [P, I],
+    "deer_prof_count": [P],
+    "deer_prof_get": [P, I, P, I, P, P, P],
 }
-_RESTYPE = {"deer_hip_arch": c_char_p}
+_RESTYPE = {"deer_hip_arch": c_char_p, "deer_model_arena_bytes": c_long, "deer_model_workspace_bytes": c_long,
+            "deer_model_destroy": None}
 
 # constants of include/deer_hip.h
 CTL_EXIT_FLAG, CTL_EXIT_LAYER, CTL_CUR_EXIT_ID, CTL_HOLD, CTL_N_EVALS, CTL_SHADOW, CTL_COMMITTED, CTL_ALL_EXITED = 0, 1, 2, 3, 4, 5, 6, 7
@@ -61,6 +89,11 @@ KIND_PSEUDO, KIND_CHECK, KIND_COMMIT = 0, 1, 2
 THR_TYPES = {"L2": 0, "mean": 1, "max": 2, "cosine": 3}
 
 _lib = None
+
+
+def skinny_mpad(M: int) -> int:
+    """Row count of one f32 partial slab of deer_gemm_skinny: M rounded up to whole 16-row MFMA tiles."""
+    return 16 * ((M + 15) // 16)
 
 
 class DeerHipError(RuntimeError):

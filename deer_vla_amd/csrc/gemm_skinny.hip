@@ -22,116 +22,135 @@
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-#define GS_UNROLL 8
-
 enum { A_BF16 = 0, A_SLABS_GELU = 1, A_SLABS = 2, A_F32 = 3 };
 
 // SPLIT: the f32 activation is represented as bf16 hi + bf16 lo (hi = bf16(a), lo = bf16(a - hi)) and each weight
-// fragment feeds two MFMAs.  The GEMM is HBM-bound (MFMA pipe <5% busy), so the second MFMA is free and the
+// fragment feeds two MFMAs.  The GEMM is HBM-bound (MFMA pipe <5% busy at 16 rows), so the second MFMA is free and the
 // activation side of the product keeps ~16 mantissa bits: the LLM trunk then differs from an fp32 reference only
 // through the bf16 weights it shares with it -> robust exit decisions (SURVEY §7 "exit-index exactness").
-// NW waves per workgroup = NW 16-column tiles sharing one staged activation slice.  With more than 16 activation rows
-// the slice (rows x KS x 4 B) outweighs the weights a 4-wave workgroup streams, so wide (16-wave) workgroups are used
-// to amortise it (measured: 56 rows, 33 MB of weights: 28 us with 4 waves).
-template <int MT, bool SPLIT, int NW>
+//
+// Work decomposition: workgroup (x, y) owns NW 16-column tiles (one per wave) over the K RANGE [y*KR, (y+1)*KR) and walks it
+// in CHUNKS of KC = 32*WU columns: stage the activation chunk [MPAD rows x KC] in LDS (hi + lo), barrier, WU weight fragments
+// x MT row tiles of MFMAs, barrier.  The accumulators live across chunks, so the split-K factor (= number of f32 slabs the
+// consumer has to sum) is decoupled from the LDS slice: with 112 rows (8 environments) a 128-column chunk fills the LDS,
+// but the K range per workgroup stays 512-2048 columns (<= 16 slabs instead of 64).
+// Weight fragments are double-buffered in registers (wA / wB): the loads of chunk c+1 are issued BEFORE the MFMAs of chunk
+// c and fly during its barriers and the staging of chunk c+1; the first chunk's loads are issued before anything else, so the
+// activation staging (L2 latency) hides under the first HBM round trip instead of preceding it.
+template <int MT, bool SPLIT, int NW, int WU>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __restrict__ Av, int lda,
                                                           const float* __restrict__ Aslab, int s_in, long slab_stride_in,
                                                           int a_mode, const bf16_t* __restrict__ Wp,
-                                                          float* __restrict__ part, int M, int N, int K, int KS,
+                                                          float* __restrict__ part, int M, int N, int K, int KR,
                                                           const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
   constexpr int MPAD = MT * 16;
+  constexpr int KC = 32 * WU;
+  constexpr int pitch = KC + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int pitch = KS + 8;
-  bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);      // hi: [MPAD][KS + 8]
-  bf16_t* Al = As + MPAD * pitch;                         // lo: [MPAD][KS + 8] (SPLIT only)
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);      // hi: [MPAD][KC + 8]
+  bf16_t* Al = As + MPAD * pitch;                         // lo: [MPAD][KC + 8] (SPLIT only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int ks = blockIdx.y, k0 = ks * KS;
-  const int klen = min(KS, K - k0);                       // multiple of 32
+  const int ks = blockIdx.y, k_begin = ks * KR;
+  const int k_end = min(K, k_begin + KR);                 // multiple of 32
+  const int nchunks = (k_end - k_begin + KC - 1) / KC;
 
-  // ---- stage the activation slice (rows >= M are zero) ----
-  if (a_mode == A_BF16) {
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(Av);
-    const int segs = klen >> 3;
-    for (int idx = tid; idx < MPAD * segs; idx += 64 * NW) {
-      const int row = idx / segs, seg = idx - row * segs;
-      uint4 v = uint4{0, 0, 0, 0};
-      if (row < M) v = *reinterpret_cast<const uint4*>(A + (long)row * lda + k0 + seg * 8);
-      *reinterpret_cast<uint4*>(As + row * pitch + seg * 8) = v;
-      if (SPLIT) *reinterpret_cast<uint4*>(Al + row * pitch + seg * 8) = uint4{0, 0, 0, 0};
-    }
-  } else {
-    const int segs = klen >> 2;
-    for (int idx = tid; idx < MPAD * segs; idx += 64 * NW) {
-      const int row = idx / segs, seg = idx - row * segs;
-      float4 s = float4{0.f, 0.f, 0.f, 0.f};
-      if (row < M) {
-        if (a_mode == A_F32) {
-          s = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Av) + (long)row * lda + k0 + seg * 4);
-        } else {
-          const float* p = Aslab + (long)row * K + k0 + seg * 4;
-          for (int i = 0; i < s_in; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(p + (long)i * slab_stride_in);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-          }
-          if (a_mode == A_SLABS_GELU) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
-        }
-      }
-      const uint32_t h01 = pack2bf(s.x, s.y), h23 = pack2bf(s.z, s.w);
-      *reinterpret_cast<uint2*>(As + row * pitch + seg * 4) = uint2{h01, h23};
-      if (SPLIT)
-        *reinterpret_cast<uint2*>(Al + row * pitch + seg * 4) =
-            uint2{pack2bf(s.x - __uint_as_float(h01 << 16), s.y - __uint_as_float(h01 & 0xffff0000u)),
-                  pack2bf(s.z - __uint_as_float(h23 << 16), s.w - __uint_as_float(h23 & 0xffff0000u))};
-    }
-  }
-  __syncthreads();
-
-  const int tile = blockIdx.x * NW + wave;                // 16-column tile of this wave
-  if (tile * 16 >= N) return;
   const int ktiles = K >> 5;
-  const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + ((long)tile * ktiles + (k0 >> 5)) * 64 + lane;
-  const bf16_t* as = As + c * pitch + g * 8;
-  const bf16_t* al = Al + c * pitch + g * 8;
+  // waves beyond N (last workgroup of a ragged N) stream tile 0 and never store: keeps barriers and loads uniform
+  const int tile_raw = blockIdx.x * NW + wave;
+  const bool tile_ok = tile_raw * 16 < N;
+  const int tile = tile_ok ? tile_raw : 0;
+  const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + (long)tile * ktiles * 64 + lane;
+  const int kt_last = (k_end >> 5) - 1;
+
+  u32x4 wA[WU], wB[WU];
+  auto issue = [&](u32x4 (&w)[WU], int chunk) {           // fragments of chunk (clamped: loads stay branch-free)
+    const int kt0 = (k_begin >> 5) + chunk * WU;
+#pragma unroll
+    for (int u = 0; u < WU; ++u) w[u] = __builtin_nontemporal_load(wp + (long)min(kt0 + u, kt_last) * 64);
+  };
+  auto stage = [&](int chunk) {                            // activation chunk -> LDS (rows >= M and columns >= k_end are zero)
+    const int k0 = k_begin + chunk * KC;
+    const int klen = min(KC, k_end - k0);
+    if (a_mode == A_BF16) {
+      const bf16_t* A = reinterpret_cast<const bf16_t*>(Av);
+      constexpr int segs = KC >> 3;
+      for (int idx = tid; idx < MPAD * segs; idx += 64 * NW) {
+        const int row = idx / segs, seg = idx - row * segs;
+        uint4 v = uint4{0, 0, 0, 0};
+        if (row < M && seg * 8 < klen) v = *reinterpret_cast<const uint4*>(A + (long)row * lda + k0 + seg * 8);
+        *reinterpret_cast<uint4*>(As + row * pitch + seg * 8) = v;
+        if (SPLIT) *reinterpret_cast<uint4*>(Al + row * pitch + seg * 8) = uint4{0, 0, 0, 0};
+      }
+    } else {
+      constexpr int segs = KC >> 2;
+      for (int idx = tid; idx < MPAD * segs; idx += 64 * NW) {
+        const int row = idx / segs, seg = idx - row * segs;
+        float4 s = float4{0.f, 0.f, 0.f, 0.f};
+        if (row < M && seg * 4 < klen) {
+          if (a_mode == A_F32) {
+            s = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Av) + (long)row * lda + k0 + seg * 4);
+          } else {
+            const float* p = Aslab + (long)row * K + k0 + seg * 4;
+            for (int i = 0; i < s_in; ++i) {
+              const float4 v = *reinterpret_cast<const float4*>(p + (long)i * slab_stride_in);
+              s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            if (a_mode == A_SLABS_GELU) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
+          }
+        }
+        const uint32_t h01 = pack2bf(s.x, s.y), h23 = pack2bf(s.z, s.w);
+        *reinterpret_cast<uint2*>(As + row * pitch + seg * 4) = uint2{h01, h23};
+        if (SPLIT)
+          *reinterpret_cast<uint2*>(Al + row * pitch + seg * 4) =
+              uint2{pack2bf(s.x - __uint_as_float(h01 << 16), s.y - __uint_as_float(h01 & 0xffff0000u)),
+                    pack2bf(s.z - __uint_as_float(h23 << 16), s.w - __uint_as_float(h23 & 0xffff0000u))};
+      }
+    }
+  };
 
   f32x4 acc[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nkt = klen >> 5;
-  int kt = 0;
-  for (; kt + GS_UNROLL <= nkt; kt += GS_UNROLL) {
-    u32x4 w[GS_UNROLL];
+  const bf16_t* as = As + c * pitch + g * 8;
+  const bf16_t* al = Al + c * pitch + g * 8;
+  auto mma = [&](const u32x4 (&w)[WU], int chunk) {
+    const int nkt = min(WU, ((k_end - k_begin) >> 5) - chunk * WU);      // fragments of this chunk that are inside the K range
 #pragma unroll
-    for (int u = 0; u < GS_UNROLL; ++u) w[u] = __builtin_nontemporal_load(wp + (long)(kt + u) * 64);
-    __builtin_amdgcn_sched_barrier(0);   // keep all GS_UNROLL weight loads in flight before the first MFMA
+    for (int u = 0; u < WU; ++u) {
+      if (u < nkt) {
+        const bf16x8 wf = __builtin_bit_cast(bf16x8, w[u]);
 #pragma unroll
-    for (int u = 0; u < GS_UNROLL; ++u) {
-      const bf16x8 wf = __builtin_bit_cast(bf16x8, w[u]);
-#pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(as + j * 16 * pitch + (kt + u) * 32);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[j], 0, 0, 0);
-        if (SPLIT) {
-          const bf16x8 lf = *reinterpret_cast<const bf16x8*>(al + j * 16 * pitch + (kt + u) * 32);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, lf, acc[j], 0, 0, 0);
+        for (int j = 0; j < MT; ++j) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(as + j * 16 * pitch + u * 32);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[j], 0, 0, 0);
+          if (SPLIT) {
+            const bf16x8 lf = *reinterpret_cast<const bf16x8*>(al + j * 16 * pitch + u * 32);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, lf, acc[j], 0, 0, 0);
+          }
         }
       }
     }
+  };
+
+  issue(wA, 0);                                            // weights first: they do not depend on the activation
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    stage(ch);
+    __syncthreads();
+    if (ch + 1 < nchunks) issue(wB, ch + 1);
+    __builtin_amdgcn_sched_barrier(0);                     // keep the next chunk's loads ahead of this chunk's MFMAs
+    mma(wA, ch);
+    __syncthreads();
+    if (ch + 1 >= nchunks) break;
+    stage(ch + 1);
+    __syncthreads();
+    if (ch + 2 < nchunks) issue(wA, ch + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(wB, ch + 1);
+    __syncthreads();
   }
-  for (; kt < nkt; ++kt) {
-    const bf16x8 wf = __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(wp + (long)kt * 64));
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(as + j * 16 * pitch + kt * 32);
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[j], 0, 0, 0);
-      if (SPLIT) {
-        const bf16x8 lf = *reinterpret_cast<const bf16x8*>(al + j * 16 * pitch + kt * 32);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, lf, acc[j], 0, 0, 0);
-      }
-    }
-  }
+  if (!tile_ok) return;
   // lane holds part[m = j*16 + c][n = tile*16 + g*4 .. +3]
   float* dst = part + ((long)ks * MPAD) * N + tile * 16 + g * 4;
 #pragma unroll
@@ -160,49 +179,68 @@ extern "C" int deer_pack_weight_mfma16(const void* W, void* Wp, int N, int K, vo
   return DEER_OK;
 }
 
-// Suggested split-K for a skinny GEMM: enough workgroups to cover the chip (~2 per CU) while each wave
-// still streams >= 8 KiB, and an LDS slice (hi + lo) <= 33 KiB.  Deterministic function of the shape.
+// Row-tile count / workgroup shape for M rows: up to 16 rows 4 waves (64 columns) per workgroup, beyond that 16 waves (256
+// columns) so that the staged activation chunk is amortised over more weight bytes.
+static inline int skinny_mt(int M) { return (M + 15) >> 4; }
+static inline int skinny_wu(int mt) { return mt > 4 ? 4 : 8; }                 // chunk = 32*WU columns: LDS (hi + lo) <= 70 KB
+
+// Suggested split-K (= number of f32 partial slabs the consumer sums).  Measured on MI355X (tools/bench_skinny.py, 14 / 56 / 112
+// rows): 4-wave workgroups (<= 16 rows) want ~512 workgroups, 16-wave ones ~192-256, and a K range per workgroup of >= 128
+// columns; beyond that more slabs cost more (slab stores + the consumer's reduction) than the extra parallelism returns.
 extern "C" int deer_skinny_splitk(int M, int N, int K) {
-  const int mt = (M > 32) ? 4 : ((M > 16) ? 2 : 1);
-  const int max_ks = (mt == 4) ? 256 : 512 / mt;
-  const int cols = (mt == 1) ? 64 : 256;                   // 4-wave workgroups up to 16 rows, 16-wave beyond
+  const int mt = skinny_mt(M);
+  const int cols = (mt == 1) ? 64 : 256;
   const int groups = (N + cols - 1) / cols;
+  const int want = (mt == 1) ? 512 : 192;
   int s = 1;
-  while ((K / s) > max_ks && (K % (s * 2 * 32)) == 0) s *= 2;
-  while (groups * s < (mt == 1 ? 512 : 192) && (K / (s * 2)) >= (mt == 1 ? 256 : 128) && (K % (s * 2 * 32)) == 0) s *= 2;
+  while (groups * s < want && (K / (s * 2)) >= 128 && (K % (s * 2 * 32)) == 0) s *= 2;
   return s;
 }
 
 extern "C" int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int s_in, long slab_stride_in, int a_mode,
                                 const void* Wp, float* part, int M, int N, int K, int splitk, const int* ctl,
                                 void* stream) {
-  if (M <= 0 || M > 64 || N <= 0 || (N & 15) || K <= 0 || (K & 31) || splitk <= 0 || (K % (splitk * 32)) != 0)
+  if (M <= 0 || M > 128 || N <= 0 || (N & 15) || K <= 0 || (K & 31) || splitk <= 0 || (K % (splitk * 32)) != 0)
     return DEER_ERR_SHAPE;
   if (a_mode < 0 || a_mode > 3) return DEER_ERR_SHAPE;
   if (a_mode == A_BF16 && (A == nullptr || (lda & 7))) return DEER_ERR_SHAPE;
   if (a_mode == A_F32 && (A == nullptr || (lda & 3))) return DEER_ERR_SHAPE;
   if ((a_mode == A_SLABS || a_mode == A_SLABS_GELU) && (Aslab == nullptr || s_in <= 0)) return DEER_ERR_SHAPE;
-  const int KS = K / splitk;
-  const int mt = (M > 32) ? 4 : ((M > 16) ? 2 : 1);
+  const int KR = K / splitk;
+  const int mt = skinny_mt(M);
   const bool split = (a_mode != A_BF16);
-  const int smem = (split ? 2 : 1) * mt * 16 * (KS + 8) * (int)sizeof(bf16_t);
-  if (smem > 72 * 1024) return DEER_ERR_SHAPE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<4, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<4, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-    attr_set = true;
-  }
+  const int wu = skinny_wu(mt);
+  const int smem = (split ? 2 : 1) * mt * 16 * (32 * wu + 8) * (int)sizeof(bf16_t);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nw = (mt == 1) ? 4 : 16;
   dim3 grid((N + 16 * nw - 1) / (16 * nw), splitk);
   const bf16_t* wp = reinterpret_cast<const bf16_t*>(Wp);
-#define DEER_SK_LAUNCH(MT_, SP_, NW_)                                                                                         \
-  hipLaunchKernelGGL((gemm_skinny_kernel<MT_, SP_, NW_>), grid, dim3(64 * NW_), smem, st, A, lda, Aslab, s_in, slab_stride_in, \
-                     a_mode, wp, part, M, N, K, KS, ctl)
-  if (mt == 1)      { if (split) DEER_SK_LAUNCH(1, true, 4); else DEER_SK_LAUNCH(1, false, 4); }
-  else if (mt == 2) { if (split) DEER_SK_LAUNCH(2, true, 16); else DEER_SK_LAUNCH(2, false, 16); }
-  else              { if (split) DEER_SK_LAUNCH(4, true, 16); else DEER_SK_LAUNCH(4, false, 16); }
+#define DEER_SK_LAUNCH(MT_, SP_, NW_, WU_)                                                                                     \
+  do {                                                                                                                         \
+    static bool attr_set = false;                                                                                              \
+    auto kern = &gemm_skinny_kernel<MT_, SP_, NW_, WU_>;                                                                       \
+    if (!attr_set) {                                                                                                           \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) !=  \
+          hipSuccess) return DEER_ERR_LAUNCH;                                                                                  \
+      attr_set = true;                                                                                                         \
+    }                                                                                                                          \
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW_), smem, st, A, lda, Aslab, s_in, slab_stride_in, a_mode, wp, part, M, N, K,  \
+                       KR, ctl);                                                                                               \
+  } while (0)
+#define DEER_SK_CASE(MT_, NW_, WU_) \
+  case MT_: if (split) DEER_SK_LAUNCH(MT_, true, NW_, WU_); else DEER_SK_LAUNCH(MT_, false, NW_, WU_); break
+  switch (mt) {
+    DEER_SK_CASE(1, 4, 8);
+    DEER_SK_CASE(2, 16, 8);
+    DEER_SK_CASE(3, 16, 8);
+    DEER_SK_CASE(4, 16, 8);
+    DEER_SK_CASE(5, 16, 4);
+    DEER_SK_CASE(6, 16, 4);
+    DEER_SK_CASE(7, 16, 4);
+    DEER_SK_CASE(8, 16, 4);
+    default: return DEER_ERR_SHAPE;
+  }
+#undef DEER_SK_CASE
 #undef DEER_SK_LAUNCH
   DEER_LAUNCH_CHECK();
   return DEER_OK;

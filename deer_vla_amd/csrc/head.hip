@@ -97,27 +97,34 @@ __device__ __forceinline__ void block_ln(const float* __restrict__ src, float* d
 // ---- token pooling (AdaptiveMaxPool1d / AvgPool over the T text tokens, action_head.py:480-483,519-520) --------------
 // feats: [B][T][d] (env b at feats + b*T*d) -> pooled [B][d].  One launch per head evaluation, so that the 256
 // workgroups of the first LSTM layer do not each re-read B*T*d features.
+// key_mask (uint8 [B][T], 0 = right-padding) or NULL: instructions of an environment batch are right-padded to a common T,
+// and the reference - which runs every environment alone (B = 1, padding="longest", data.py:905-919) - never sees those
+// rows, so they are left out of the pool (max: skipped; avg: divided by the number of valid tokens).
 __global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict__ feats, float* __restrict__ pooled, int T, int d,
-                                                        int avg, int B, const int* ctl, int kind, int layer) {
+                                                        int avg, int B, const unsigned char* __restrict__ key_mask,
+                                                        const int* ctl, int kind, int layer) {
   if (head_skip(ctl, kind, layer, B)) return;
   const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   if (i >= d) return;
   const float* x = feats + ((long)b * T) * d + i;
-  float a = x[0];
-  if (avg) {
-    for (int t = 1; t < T; ++t) a += x[(long)t * d];
-    a /= (float)T;
-  } else {
-    for (int t = 1; t < T; ++t) a = fmaxf(a, x[(long)t * d]);
+  const unsigned char* km = key_mask != nullptr ? key_mask + b * T : nullptr;
+  float a = avg ? 0.f : -INFINITY;
+  int n = 0;
+  for (int t = 0; t < T; ++t) {
+    if (km != nullptr && km[t] == 0) continue;
+    const float v = x[(long)t * d];
+    a = avg ? a + v : fmaxf(a, v);
+    ++n;
   }
+  if (avg) a /= (float)max(n, 1);
   pooled[(long)b * d + i] = a;
 }
 
-extern "C" int deer_head_pool(const float* feats, float* pooled, int T, int d, int avg, int B, const int* ctl, int kind, int layer,
-                              void* stream) {
+extern "C" int deer_head_pool(const float* feats, float* pooled, int T, int d, int avg, int B, const unsigned char* key_mask,
+                              const int* ctl, int kind, int layer, void* stream) {
   if (T <= 0 || d <= 0 || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(head_pool_kernel, dim3((d + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), feats, pooled, T, d,
-                     avg, B, ctl, kind, layer);
+                     avg, B, key_mask, ctl, kind, layer);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

@@ -1,0 +1,1099 @@
+// The native spine (include/deer_model.h): weight-arena layout + ingestion by reference state-dict name, workspace layout,
+// and the ORDER in which the gfx950 kernels are enqueued for one DeeR-VLA control step:
+//   2x ViT-L/14 (robot_flamingo/models/flamingo_mpt.py:556-583; open_clip arithmetic SURVEY App. B.2)
+//   -> 2x PerceiverResampler (open_flamingo/src/helpers.py:107-132) -> media tokens (flamingo_mpt.py:661)
+//   -> MPT layers with gated x-attn (open_flamingo/src/flamingo_lm.py:46-83, helpers.py:260-279)
+//   -> per-exit LSTM action head + exit gate (robot_flamingo/models/action_head.py:499-611, value_net.py:120-133,277-297).
+// Host code only (plus two small conversion kernels for weight ingestion); every FLOP of the step is in the other .hip files.
+#include "common.h"
+#include "../../include/deer_hip.h"
+#include "../../include/deer_model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+constexpr float kEps = 1e-5f;
+constexpr int kVitHeadLayers = 3;   // ViT blocks in the first piece of a vision chain (short graph: the GPU idles until it is submitted)
+constexpr int kMaxRows = 128;       // LLM rows (n_envs * T) the skinny GEMM takes
+constexpr int kMaxSplit = 32;
+
+// ---- weight ingestion kernels -------------------------------------------------------------------------------------------
+template <typename SrcT>
+__device__ __forceinline__ float ld_as_f32(const SrcT* p, long i);
+template <>
+__device__ __forceinline__ float ld_as_f32<float>(const float* p, long i) { return p[i]; }
+template <>
+__device__ __forceinline__ float ld_as_f32<bf16_t>(const bf16_t* p, long i) { return bf2f(p[i]); }
+
+// dst[r][c] (pitch dst_pitch, element type f32 or bf16) = src[r][c], r < rows, c < cols; columns cols..dst_cols-1 = 0
+template <typename SrcT, bool DST_BF16>
+__global__ void ingest_rows_kernel(const SrcT* __restrict__ src, void* __restrict__ dst, long rows, int cols, int dst_cols, long dst_pitch) {
+  const long total = rows * dst_cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / dst_cols;
+    const int c = (int)(i - r * dst_cols);
+    const float v = c < cols ? ld_as_f32<SrcT>(src, r * cols + c) : 0.f;
+    if (DST_BF16) reinterpret_cast<bf16_t*>(dst)[r * dst_pitch + c] = f2bf(v);
+    else reinterpret_cast<float*>(dst)[r * dst_pitch + c] = v;
+  }
+}
+
+// row-major W[N,K] (f32 or bf16) -> MFMA-fragment order Wp[N/16][K/32][64 lanes][8] bf16 (the layout deer_gemm_skinny streams)
+template <typename SrcT>
+__global__ void ingest_pack_kernel(const SrcT* __restrict__ W, bf16_t* __restrict__ Wp, int N, int K) {
+  const long total = (long)(N >> 4) * (K >> 5) * 64;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    const long tk = idx >> 6;
+    const int kt = (int)(tk % (K >> 5));
+    const int tile = (int)(tk / (K >> 5));
+    const int n = tile * 16 + (lane & 15), k = kt * 32 + (lane >> 4) * 8;
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = pack2bf(ld_as_f32<SrcT>(W, (long)n * K + k + 2 * e), ld_as_f32<SrcT>(W, (long)n * K + k + 2 * e + 1));
+    *reinterpret_cast<uint4*>(Wp + idx * 8) = uint4{o[0], o[1], o[2], o[3]};
+  }
+}
+
+enum SlotKind { SK_F32 = 0, SK_BF16 = 1, SK_PACK = 2 };
+
+struct Slot {
+  int kind;
+  long rows;
+  int cols;          // source row length
+  int dst_cols;      // destination row length (>= cols: zero padded)
+  long dst_pitch;    // destination row pitch (elements)
+  size_t dst[2];     // arena offsets (second destination optional: dst[1] == SIZE_MAX when unused)
+  long dst2_pitch;
+  bool required;
+  bool loaded;
+};
+
+struct Layout {
+  size_t cur = 0;
+  size_t add(size_t bytes) {
+    const size_t o = cur;
+    cur += (bytes + 255) & ~size_t(255);
+    return o;
+  }
+};
+
+struct VitLayerW { size_t ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr; };
+struct PercLayerW { size_t nlw, nlb, wqkv, wo, fnw, fnb, w1, w2; };
+struct XattnW { size_t nw, nb, wq, wo, ag, fg, fnw, fnb, w1, w2; int kv_index; };
+struct LlmLayerW {
+  bool has_xa;
+  XattnW xa;
+  size_t ln1w, ln1b, wqkv, qlnw, klnw, wo, ln2w, ln2b, wup, wdown;
+  std::string ln1b_name, ln2b_name;
+};
+struct LstmW { size_t wih, whh, bih, bhh, lnw, lnb; };
+struct FcW { size_t w[2], b[2], lnw[2], lnb[2]; };
+
+// activation buffers of the vision tower for n camera frames (offsets into the workspace)
+struct VisionWS {
+  int n = 0, first = 0;                       // number of frames, index of the first one in the step's frame list
+  size_t im2col, patch_out, vx, v_ln, v_qkv, v_ao, v_h, v_slab, p_lat, p_mln, p_mkv, p_latln, p_qkv, p_ao, p_ln, p_h;
+  size_t vis_x, vis_x_f32;                    // row ranges of the step's media-token buffers
+  int vit_split[2], perc_split[2];
+};
+
+int pick_split(long M, long N, long K, int target_blocks = 320, int max_split = 8) {
+  // split-K factor for a projection whose 64x64 output tiles alone cannot fill 256 CUs (measured optimum 2,2 for ViT-L at 514 rows)
+  const long blocks = ((M + 63) / 64) * ((N + 63) / 64);
+  int S = 1;
+  while (S * 2 <= max_split && blocks * S * 2 <= target_blocks && K % (S * 2 * 64) == 0 && K / (S * 2) >= 128) S *= 2;
+  return S;
+}
+
+}  // namespace
+
+struct ProfRec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
+
+struct deer_model {
+  deer_config c;
+  // derived
+  int P, tok, W, kpad, nl, p_inner, Lp, d, xinner, n_xattn, H, Lh, B, N, n_fc;
+  int fc_dims[3];
+  // arena
+  Layout al;
+  std::unordered_map<std::string, Slot> slots;
+  std::vector<std::string> slot_order;
+  size_t conv, cls, pos, ln_pre_w, ln_pre_b;
+  std::vector<VitLayerW> vit;
+  size_t latents, perc_normw, perc_normb, perc_nm_w, perc_nm_b, perc_wkv_all;
+  std::vector<PercLayerW> perc;
+  size_t wte, wkv_all;
+  std::vector<LlmLayerW> llm;
+  std::vector<LstmW> lstm;
+  std::vector<FcW> fc;
+  size_t wa, ba, wg, bg;
+  // workspace
+  Layout wl;
+  std::unordered_map<std::string, std::pair<size_t, size_t>> ws_named;
+  VisionWS vws;
+  std::vector<VisionWS> chains;
+  size_t img, vis_x, vis_x_f32, kv_all, ids, key_mask, text_time, x, xn, ao, slab_a, slab_b, qkv_ws, hidden, h_state, c_state, h_tmp,
+      c_tmp, h_shadow, c_shadow, pooled, ctl, step_info, thresholds, action_dbg;
+  size_t slab_a_elems, slab_b_elems;
+  size_t z_fc[3];
+  char* arena = nullptr;
+  char* ws = nullptr;
+  // controller
+  std::vector<int> exit_ids;
+  int ctl_max_layer = 0, thr_type = 0, leq = 1;
+  // per-call overrides of the coarse operators
+  const void* img_override = nullptr;
+  const float* tokens_override = nullptr;
+  const void* media_override = nullptr;
+  const long long* ids_override = nullptr;
+  const unsigned char* mask_override = nullptr;
+  const float* thr_override = nullptr;
+  // profiler
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_next = 0;
+
+  template <typename T> T* A(size_t off) const { return off == SIZE_MAX ? nullptr : reinterpret_cast<T*>(arena + off); }
+  template <typename T> T* Wk(size_t off) const { return off == SIZE_MAX ? nullptr : reinterpret_cast<T*>(ws + off); }
+  bool loaded(const std::string& n) const {
+    auto it = slots.find(n);
+    return it != slots.end() && it->second.loaded;
+  }
+};
+
+namespace {
+
+hipEvent_t get_event(deer_model* m) {
+  if (m->ev_next == m->ev_pool.size()) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    m->ev_pool.push_back(e);
+  }
+  return m->ev_pool[m->ev_next++];
+}
+
+// bracket one kernel-launching call with two events when the profiler is on
+struct Bracket {
+  deer_model* m;
+  hipStream_t st;
+  bool on;
+  Bracket(deer_model* m_, const char* name, double flops, double bytes, void* stream) : m(m_), st((hipStream_t)stream), on(m_->prof_on) {
+    if (!on) return;
+    ProfRec r{name, get_event(m), get_event(m), flops, bytes};
+    (void)hipEventRecord(r.e0, st);
+    m->prof.push_back(r);
+  }
+  ~Bracket() {
+    if (on) (void)hipEventRecord(m->prof.back().e1, st);
+  }
+};
+
+#define DEER_TRY(expr)            \
+  do {                            \
+    const int rc_ = (expr);       \
+    if (rc_ != DEER_OK) return rc_; \
+  } while (0)
+
+// ---- arena layout -----------------------------------------------------------------------------------------------------
+size_t add_slot(deer_model* m, const std::string& name, int kind, long rows, int cols, bool required = true, int dst_cols = -1,
+                size_t existing = SIZE_MAX, long pitch = -1) {
+  if (dst_cols < 0) dst_cols = cols;
+  if (pitch < 0) pitch = dst_cols;
+  const size_t esz = kind == SK_F32 ? 4 : 2;
+  const size_t off = existing != SIZE_MAX ? existing : m->al.add((size_t)rows * pitch * esz);
+  Slot s{kind, rows, cols, dst_cols, pitch, {off, SIZE_MAX}, 0, required, false};
+  m->slots[name] = s;
+  m->slot_order.push_back(name);
+  return off;
+}
+
+void build_arena(deer_model* m) {
+  const deer_config& c = m->c;
+  const int W = m->W;
+  const std::string v = "vision_encoder.visual.";
+  const int kk = 3 * c.patch_size * c.patch_size;
+  m->conv = add_slot(m, v + "conv1.weight", SK_BF16, W, kk, true, m->kpad);
+  m->cls = add_slot(m, v + "class_embedding", SK_F32, 1, W);
+  m->pos = add_slot(m, v + "positional_embedding", SK_F32, m->tok, W);
+  m->ln_pre_w = add_slot(m, v + "ln_pre.weight", SK_F32, 1, W);
+  m->ln_pre_b = add_slot(m, v + "ln_pre.bias", SK_F32, 1, W);
+  m->vit.resize(c.vit_layers);
+  for (int l = 0; l < c.vit_layers; ++l) {
+    const std::string p = v + "transformer.resblocks." + std::to_string(l) + ".";
+    VitLayerW& L = m->vit[l];
+    L.ln1w = add_slot(m, p + "ln_1.weight", SK_F32, 1, W);
+    L.ln1b = add_slot(m, p + "ln_1.bias", SK_F32, 1, W);
+    L.wqkv = add_slot(m, p + "attn.in_proj_weight", SK_BF16, 3 * W, W);
+    L.bqkv = add_slot(m, p + "attn.in_proj_bias", SK_F32, 1, 3 * W);
+    L.wo = add_slot(m, p + "attn.out_proj.weight", SK_BF16, W, W);
+    L.bo = add_slot(m, p + "attn.out_proj.bias", SK_F32, 1, W);
+    L.ln2w = add_slot(m, p + "ln_2.weight", SK_F32, 1, W);
+    L.ln2b = add_slot(m, p + "ln_2.bias", SK_F32, 1, W);
+    L.wfc = add_slot(m, p + "mlp.c_fc.weight", SK_BF16, c.vit_mlp, W);
+    L.bfc = add_slot(m, p + "mlp.c_fc.bias", SK_F32, 1, c.vit_mlp);
+    L.wpr = add_slot(m, p + "mlp.c_proj.weight", SK_BF16, W, c.vit_mlp);
+    L.bpr = add_slot(m, p + "mlp.c_proj.bias", SK_F32, 1, W);
+  }
+  // ---- Perceiver: the media tokens are the same in every layer, so norm_media / to_kv of ALL layers are stacked (applied up
+  // front by one LayerNorm pass + one batched GEMM); the latents are projected to q | k | v by [to_q ; to_kv] in one GEMM
+  const int inner = m->p_inner, Lp = m->Lp;
+  m->latents = add_slot(m, "perceiver.latents", SK_F32, m->nl, W);
+  m->perc_normw = add_slot(m, "perceiver.norm.weight", SK_F32, 1, W);
+  m->perc_normb = add_slot(m, "perceiver.norm.bias", SK_F32, 1, W);
+  m->perc_nm_w = m->al.add((size_t)Lp * W * 4);
+  m->perc_nm_b = m->al.add((size_t)Lp * W * 4);
+  m->perc_wkv_all = m->al.add((size_t)Lp * 2 * inner * W * 2);
+  m->perc.resize(Lp);
+  for (int l = 0; l < Lp; ++l) {
+    const std::string a = "perceiver.layers." + std::to_string(l) + ".0.", f = "perceiver.layers." + std::to_string(l) + ".1.";
+    PercLayerW& L = m->perc[l];
+    add_slot(m, a + "norm_media.weight", SK_F32, 1, W, true, -1, m->perc_nm_w + (size_t)l * W * 4);
+    add_slot(m, a + "norm_media.bias", SK_F32, 1, W, true, -1, m->perc_nm_b + (size_t)l * W * 4);
+    L.nlw = add_slot(m, a + "norm_latents.weight", SK_F32, 1, W);
+    L.nlb = add_slot(m, a + "norm_latents.bias", SK_F32, 1, W);
+    L.wqkv = m->al.add((size_t)3 * inner * W * 2);
+    add_slot(m, a + "to_q.weight", SK_BF16, inner, W, true, -1, L.wqkv);
+    add_slot(m, a + "to_kv.weight", SK_BF16, 2 * inner, W, true, -1, L.wqkv + (size_t)inner * W * 2);
+    m->slots[a + "to_kv.weight"].dst[1] = m->perc_wkv_all + (size_t)l * 2 * inner * W * 2;
+    m->slots[a + "to_kv.weight"].dst2_pitch = W;
+    L.wo = add_slot(m, a + "to_out.weight", SK_BF16, W, inner);
+    L.fnw = add_slot(m, f + "0.weight", SK_F32, 1, W);
+    L.fnb = add_slot(m, f + "0.bias", SK_F32, 1, W);
+    L.w1 = add_slot(m, f + "1.weight", SK_BF16, (long)c.perc_ff_mult * W, W);
+    L.w2 = add_slot(m, f + "3.weight", SK_BF16, W, c.perc_ff_mult * W);
+  }
+  // ---- LLM: projections pre-packed in MFMA-fragment order; to_kv of all x-attn layers concatenated (media is layer-invariant)
+  const int d = m->d, xin = m->xinner;
+  m->wte = add_slot(m, "lang_encoder.transformer.wte.weight", SK_BF16, c.vocab_size, d);
+  m->n_xattn = 0;
+  for (int n = 0; n < c.n_layers; ++n)
+    if ((n + 1) % c.cross_attn_every_n_layers == 0) ++m->n_xattn;
+  m->wkv_all = m->n_xattn ? m->al.add((size_t)m->n_xattn * 2 * xin * W * 2) : SIZE_MAX;
+  m->llm.resize(c.n_layers);
+  int kv_index = 0;
+  const char* ln1 = c.mpt7b_names ? "norm_1" : "ln_1";
+  const char* ln2 = c.mpt7b_names ? "norm_2" : "ln_2";
+  const char* up = c.mpt7b_names ? "ffn.up_proj" : "mlp.mlp_up";
+  const char* down = c.mpt7b_names ? "ffn.down_proj" : "mlp.mlp_down";
+  for (int n = 0; n < c.n_layers; ++n) {
+    const std::string blk = "lang_encoder.transformer.blocks." + std::to_string(n) + ".";
+    LlmLayerW& L = m->llm[n];
+    L.has_xa = (n + 1) % c.cross_attn_every_n_layers == 0;
+    if (L.has_xa) {
+      const std::string x = blk + "gated_cross_attn_layer.";
+      XattnW& X = L.xa;
+      X.nw = add_slot(m, x + "attn.norm.weight", SK_F32, 1, d);
+      X.nb = add_slot(m, x + "attn.norm.bias", SK_F32, 1, d);
+      X.wq = add_slot(m, x + "attn.to_q.weight", SK_PACK, xin, d);
+      add_slot(m, x + "attn.to_kv.weight", SK_BF16, 2 * xin, W, true, -1, m->wkv_all + (size_t)kv_index * 2 * xin * W * 2);
+      X.kv_index = kv_index++;
+      X.wo = add_slot(m, x + "attn.to_out.weight", SK_PACK, d, xin);
+      X.ag = add_slot(m, x + "attn_gate", SK_F32, 1, 1);
+      X.fg = add_slot(m, x + "ff_gate", SK_F32, 1, 1);
+      X.fnw = add_slot(m, x + "ff.0.weight", SK_F32, 1, d);
+      X.fnb = add_slot(m, x + "ff.0.bias", SK_F32, 1, d);
+      X.w1 = add_slot(m, x + "ff.1.weight", SK_PACK, (long)c.xattn_ff_mult * d, d);
+      X.w2 = add_slot(m, x + "ff.3.weight", SK_PACK, d, c.xattn_ff_mult * d);
+    }
+    const std::string mm = blk + "decoder_layer.";
+    L.ln1w = add_slot(m, mm + ln1 + ".weight", SK_F32, 1, d);
+    L.ln1b_name = mm + ln1 + ".bias";
+    L.ln1b = add_slot(m, L.ln1b_name, SK_F32, 1, d, false);          // no_bias models strip it (mosaic_gpt_3b.py:147-153)
+    L.wqkv = add_slot(m, mm + "attn.Wqkv.weight", SK_PACK, 3L * d, d);
+    L.qlnw = L.klnw = SIZE_MAX;
+    if (c.attn_qk_ln) {
+      L.qlnw = add_slot(m, mm + "attn.q_ln.weight", SK_F32, 1, d);
+      L.klnw = add_slot(m, mm + "attn.k_ln.weight", SK_F32, 1, d);
+    }
+    L.wo = add_slot(m, mm + "attn.out_proj.weight", SK_PACK, d, d);
+    L.ln2w = add_slot(m, mm + ln2 + ".weight", SK_F32, 1, d);
+    L.ln2b_name = mm + ln2 + ".bias";
+    L.ln2b = add_slot(m, L.ln2b_name, SK_F32, 1, d, false);
+    L.wup = add_slot(m, mm + up + ".weight", SK_PACK, (long)c.mlp_ratio * d, d);
+    L.wdown = add_slot(m, mm + down + ".weight", SK_PACK, d, c.mlp_ratio * d);
+  }
+  // ---- action head (DeterministicDecoder, action_head.py:408-497): LN-LSTM = [LSTM, LN, Dropout] x L under rnn.layers.{3l, 3l+1}
+  const std::string p = "extra_exit.";
+  const int H = m->H;
+  m->lstm.resize(m->Lh);
+  int in_f = d;
+  for (int l = 0; l < m->Lh; ++l) {
+    std::string r, sfx;
+    if (c.lstm_layernorm) { r = p + "rnn.layers." + std::to_string(3 * l) + "."; sfx = "_l0"; }
+    else { r = p + "rnn."; sfx = "_l" + std::to_string(l); }
+    LstmW& Lw = m->lstm[l];
+    Lw.wih = add_slot(m, r + "weight_ih" + sfx, SK_BF16, 4L * H, in_f);
+    Lw.whh = add_slot(m, r + "weight_hh" + sfx, SK_BF16, 4L * H, H);
+    Lw.bih = add_slot(m, r + "bias_ih" + sfx, SK_F32, 1, 4 * H);
+    Lw.bhh = add_slot(m, r + "bias_hh" + sfx, SK_F32, 1, 4 * H);
+    Lw.lnw = Lw.lnb = SIZE_MAX;
+    if (c.lstm_layernorm) {
+      Lw.lnw = add_slot(m, p + "rnn.layers." + std::to_string(3 * l + 1) + ".weight", SK_F32, 1, H);
+      Lw.lnb = add_slot(m, p + "rnn.layers." + std::to_string(3 * l + 1) + ".bias", SK_F32, 1, H);
+    }
+    in_f = H;
+  }
+  // MLP heads, dropout_mode='layerwise' (action_head.py:86-116): [Drop, (Lin, LN|Id, ReLU, Drop) x n_hidden, Lin, Tanh|Sigmoid]
+  m->fc.resize(m->n_fc);
+  const char* heads[2] = {"actions", "gripper"};
+  for (int g = 0; g < 2; ++g) {
+    int cur = H;
+    for (int i = 0; i < m->n_fc; ++i) {
+      const std::string li = p + heads[g] + ".mlp." + std::to_string(1 + 4 * i) + ".";
+      const std::string ni = p + heads[g] + ".mlp." + std::to_string(2 + 4 * i) + ".";
+      m->fc[i].w[g] = add_slot(m, li + "weight", SK_BF16, m->fc_dims[i], cur);
+      m->fc[i].b[g] = add_slot(m, li + "bias", SK_F32, 1, m->fc_dims[i]);
+      m->fc[i].lnw[g] = m->fc[i].lnb[g] = SIZE_MAX;
+      if (c.mlp_layernorm) {
+        m->fc[i].lnw[g] = add_slot(m, ni + "weight", SK_F32, 1, m->fc_dims[i]);
+        m->fc[i].lnb[g] = add_slot(m, ni + "bias", SK_F32, 1, m->fc_dims[i]);
+      }
+      cur = m->fc_dims[i];
+    }
+    const std::string lo = p + heads[g] + ".mlp." + std::to_string(1 + 4 * m->n_fc) + ".";
+    const int n_out = g == 0 ? 6 : 1;
+    (g == 0 ? m->wa : m->wg) = add_slot(m, lo + "weight", SK_BF16, n_out, cur);
+    (g == 0 ? m->ba : m->bg) = add_slot(m, lo + "bias", SK_F32, 1, n_out);
+  }
+}
+
+// ---- workspace layout -------------------------------------------------------------------------------------------------
+void build_vision_ws(deer_model* m, VisionWS& ws, int n, int first, const VisionWS* splits) {
+  const deer_config& c = m->c;
+  const int P = m->P, W = m->W, nl = m->nl, inner = m->p_inner, Lp = m->Lp;
+  const long R = (long)n * (P + 1);
+  ws.n = n;
+  ws.first = first;
+  ws.im2col = m->wl.add((size_t)n * P * m->kpad * 2);
+  ws.patch_out = m->wl.add((size_t)n * P * W * 4);
+  ws.vx = m->wl.add((size_t)R * W * 4);
+  ws.v_ln = m->wl.add((size_t)R * W * 2);
+  ws.v_qkv = m->wl.add((size_t)R * 3 * W * 2);
+  ws.v_ao = m->wl.add((size_t)R * W * 2);
+  ws.v_h = m->wl.add((size_t)R * c.vit_mlp * 2);
+  if (splits == nullptr) {
+    ws.vit_split[0] = pick_split(R, W, W);
+    ws.vit_split[1] = pick_split(R, W, c.vit_mlp);
+    ws.perc_split[0] = pick_split((long)n * nl, W, inner);
+    ws.perc_split[1] = pick_split((long)n * nl, W, (long)c.perc_ff_mult * W);
+    if (const char* ov = getenv("DEER_VIT_SPLIT")) {
+      int v[4];
+      if (sscanf(ov, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) {
+        ws.vit_split[0] = v[0]; ws.vit_split[1] = v[1]; ws.perc_split[0] = v[2]; ws.perc_split[1] = v[3];
+      }
+    }
+  } else {   // same summation order as the batched schedule: the results of all schedules are bit-identical
+    memcpy(ws.vit_split, splits->vit_split, sizeof(ws.vit_split));
+    memcpy(ws.perc_split, splits->perc_split, sizeof(ws.perc_split));
+  }
+  const long slab = std::max((long)std::max(ws.vit_split[0], ws.vit_split[1]) * R, (long)std::max(ws.perc_split[0], ws.perc_split[1]) * n * nl);
+  ws.v_slab = m->wl.add((size_t)slab * W * 4);
+  ws.p_lat = m->wl.add((size_t)n * nl * W * 4);
+  ws.p_mln = m->wl.add((size_t)Lp * n * P * W * 2);
+  ws.p_mkv = m->wl.add((size_t)Lp * n * P * 2 * inner * 2);
+  ws.p_latln = m->wl.add((size_t)n * nl * W * 2);
+  ws.p_qkv = m->wl.add((size_t)n * nl * 3 * inner * 2);
+  ws.p_ao = m->wl.add((size_t)n * nl * inner * 2);
+  ws.p_ln = m->wl.add((size_t)n * nl * W * 2);
+  ws.p_h = m->wl.add((size_t)n * nl * c.perc_ff_mult * W * 2);
+  ws.vis_x = m->vis_x + (size_t)first * nl * W * 2;
+  ws.vis_x_f32 = m->vis_x_f32 + (size_t)first * nl * W * 4;
+}
+
+size_t named(deer_model* m, const char* name, size_t bytes) {
+  const size_t off = m->wl.add(bytes);
+  m->ws_named[name] = {off, bytes};
+  return off;
+}
+
+void build_workspace(deer_model* m) {
+  const deer_config& c = m->c;
+  const int N = m->N, W = m->W, nl = m->nl, d = m->d, B = m->B, S = c.image_size;
+  m->img = named(m, "img", (size_t)N * 3 * S * S * 2);
+  m->vis_x = named(m, "vis_x", (size_t)N * nl * W * 2);
+  m->vis_x_f32 = named(m, "vis_x_f32", (size_t)N * nl * W * 4);
+  build_vision_ws(m, m->vws, N, 0, nullptr);
+  m->ws_named["vx"] = {m->vws.vx, (size_t)N * (m->P + 1) * W * 4};
+  int n_ch = c.n_chains > 0 ? c.n_chains : 2;
+  if (const char* e = getenv("DEER_CHAINS")) n_ch = atoi(e);
+  n_ch = std::max(1, std::min(N, n_ch));
+  const int per = (N + n_ch - 1) / n_ch;
+  for (int ch = 0; ch < n_ch; ++ch) {
+    const int lo = ch * per, hi = std::min(N, (ch + 1) * per);
+    if (hi <= lo) break;
+    m->chains.emplace_back();
+    build_vision_ws(m, m->chains.back(), hi - lo, lo, &m->vws);
+  }
+  m->kv_all = named(m, "kv_all", (size_t)N * nl * std::max(m->n_xattn, 1) * 2 * m->xinner * 2);
+  const int T = std::min(B * c.max_text_len, kMaxRows);
+  m->ids = named(m, "ids", (size_t)T * 8);
+  m->key_mask = named(m, "key_mask", (size_t)T);
+  m->text_time = named(m, "text_time", (size_t)T * 4);
+  m->x = named(m, "x", (size_t)T * d * 4);
+  m->xn = named(m, "xn", (size_t)T * d * 4);
+  m->ao = named(m, "ao", (size_t)T * std::max(d, m->xinner) * 4);
+  const long max_n = std::max(std::max((long)c.mlp_ratio * d, (long)c.xattn_ff_mult * d), 3L * d);
+  const int mpad = 16 * ((T + 15) / 16);
+  m->slab_a_elems = (size_t)kMaxSplit * mpad * d;
+  m->slab_b_elems = (size_t)16 * mpad * max_n;
+  m->slab_a = named(m, "slab_a", m->slab_a_elems * 4);
+  m->slab_b = named(m, "slab_b", m->slab_b_elems * 4);
+  m->qkv_ws = named(m, "qkv_ws", (size_t)T * 3 * d * 4);
+  m->hidden = named(m, "hidden", (size_t)c.n_layers * T * d * 4);
+  const size_t st = (size_t)m->Lh * B * m->H * 4;
+  m->h_state = named(m, "h_state", st);
+  m->c_state = named(m, "c_state", st);
+  m->h_tmp = named(m, "h_tmp", st);
+  m->c_tmp = named(m, "c_tmp", st);
+  m->h_shadow = named(m, "h_shadow", st);
+  m->c_shadow = named(m, "c_shadow", st);
+  for (int i = 0; i < m->n_fc; ++i) m->z_fc[i] = m->wl.add((size_t)B * 2 * m->fc_dims[i] * 4);
+  m->pooled = named(m, "pooled", (size_t)B * d * 4);
+  m->ctl = named(m, "ctl", (size_t)B * CTL_WORDS * 4);
+  m->step_info = named(m, "step_info", 16);
+  m->thresholds = named(m, "thresholds", 16 * 4);
+  m->action_dbg = named(m, "action_dbg", (size_t)B * 8 * 4);
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------------------------------
+int gemm(deer_model* m, const void* A, const void* Wt, void* C, long M, long N, long K, int epi, const float* bias, void* st,
+         int lda = -1, int ldc = -1) {
+  if (lda < 0) lda = (int)K;
+  if (ldc < 0) ldc = (int)N;
+  const double out_b = (epi == DEER_EPI_F32 || epi == DEER_EPI_RESADD_F32) ? 4.0 : 2.0;
+  Bracket b(m, "deer_gemm_bf16_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + out_b * M * N, st);
+  return deer_gemm_bf16_nt(A, lda, 0, Wt, (int)K, bias, C, ldc, 0, (int)M, (int)N, (int)K, 1, epi, nullptr, 0, nullptr, st);
+}
+
+int gemm_splitk(deer_model* m, const void* A, const void* Wt, float* slab, long M, long N, long K, int S, void* st) {
+  Bracket b(m, "deer_gemm_bf16_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + 4.0 * S * M * N, st);
+  return deer_gemm_bf16_nt_splitk(A, (int)K, Wt, (int)K, slab, (int)M, (int)N, (int)K, S, 0, nullptr, st);
+}
+
+// x += sum_s slab[s] + bias, then (optionally) LayerNorm -> bf16 / f32: closes a split-K projection of the vision tower
+int vresadd(deer_model* m, float* x, const float* slab, int S, long rows, int C, const float* bias, const float* gamma, const float* beta,
+            void* out_bf, float* out_f32, void* st) {
+  Bracket b(m, "deer_resadd_ln", 0, 4.0 * rows * C * (S + 2) + (out_bf ? 2.0 : 0.0) * rows * C, st);
+  return deer_resadd_ln(x, slab, S, rows * C, nullptr, bias, gamma, beta, gamma ? out_bf : nullptr, gamma ? out_f32 : nullptr, nullptr,
+                        (int)rows, C, kEps, nullptr, st);
+}
+
+int ln_rows(deer_model* m, const float* x, const float* gamma, const float* beta, void* out_bf, long rows, int C, void* st) {
+  Bracket b(m, "deer_layernorm_rows", 8.0 * rows * C, 6.0 * rows * C, st);
+  return deer_layernorm_rows(x, C, 0, (int)rows, 1, gamma, beta, out_bf, nullptr, C, 0, C, kEps, st);
+}
+
+const void* step_images(const deer_model* m) { return m->img_override ? m->img_override : m->Wk<void>(m->img); }
+
+int patch_embed(deer_model* m, const VisionWS& ws, void* st) {
+  const deer_config& c = m->c;
+  const int P = m->P, W = m->W;
+  const long R = (long)ws.n * (P + 1);
+  const char* img = reinterpret_cast<const char*>(step_images(m)) + (size_t)ws.first * 3 * c.image_size * c.image_size * 2;
+  {
+    Bracket b(m, "deer_vit_im2col", 0, 0, st);
+    DEER_TRY(deer_vit_im2col(img, 1, ws.n, c.image_size, c.patch_size, m->Wk<void>(ws.im2col), m->kpad, st));
+  }
+  DEER_TRY(gemm(m, m->Wk<void>(ws.im2col), m->A<void>(m->conv), m->Wk<void>(ws.patch_out), (long)ws.n * P, W, m->kpad, DEER_EPI_F32, nullptr, st));
+  {
+    Bracket b(m, "deer_vit_embed_lnpre", 0, 0, st);
+    DEER_TRY(deer_vit_embed_lnpre(m->Wk<float>(ws.patch_out), m->A<float>(m->cls), m->A<float>(m->pos), m->A<float>(m->ln_pre_w),
+                                  m->A<float>(m->ln_pre_b), m->Wk<float>(ws.vx), ws.n, P, W, kEps, st));
+  }
+  // out_proj / c_proj run split-K into f32 slabs; the slab reduction, bias, residual add and the NEXT LayerNorm are one launch
+  // (deer_resadd_ln), so a block is 7 launches and no projection leaves CUs idle
+  return ln_rows(m, m->Wk<float>(ws.vx), m->A<float>(m->vit[0].ln1w), m->A<float>(m->vit[0].ln1b), m->Wk<void>(ws.v_ln), R, W, st);
+}
+
+int perceiver(deer_model* m, const VisionWS& ws, void* st) {
+  const deer_config& c = m->c;
+  const int P = m->P, W = m->W, tok = m->tok, nl = m->nl, inner = m->p_inner, Lp = m->Lp, N = ws.n;
+  // Media side once for all layers: one LayerNorm pass with every layer's norm_media affine, one batched GEMM with every layer's
+  // to_kv.  Per layer only the 64 latents move: q|k|v projection, attention over [media K/V ; latent K/V] (two segments,
+  // helpers.py:51 without the concat), to_out and the FF - each residual projection split-K, closed by the reducer that also
+  // applies the NEXT LayerNorm.
+  {
+    Bracket b(m, "deer_broadcast_rows", 0, 0, st);
+    DEER_TRY(deer_broadcast_rows(m->A<float>(m->latents), m->Wk<float>(ws.p_lat), (long)nl * W, N, st));
+  }
+  const float* tokens = m->tokens_override ? m->tokens_override + (size_t)ws.first * P * W : m->Wk<float>(ws.vx) + W;   // skip the cls row
+  const long tok_bstride = m->tokens_override ? (long)P * W : (long)tok * W;
+  {
+    Bracket b(m, "deer_layernorm_rows", 8.0 * N * P * W, (4.0 + 2.0 * Lp) * N * P * W, st);
+    DEER_TRY(deer_layernorm_rows_multi(tokens, W, tok_bstride, P, N, m->A<float>(m->perc_nm_w), m->A<float>(m->perc_nm_b), Lp, W,
+                                       m->Wk<void>(ws.p_mln), (long)N * P * W, W, (long)P * W, W, kEps, st));
+  }
+  {
+    Bracket b(m, "deer_gemm_bf16_nt", 2.0 * Lp * N * P * 2 * inner * W, 2.0 * Lp * ((double)N * P * W + 2.0 * inner * W + (double)N * P * 2 * inner), st);
+    DEER_TRY(deer_gemm_bf16_nt_wbatch(m->Wk<void>(ws.p_mln), W, (long)N * P * W, m->A<void>(m->perc_wkv_all), W, 2L * inner * W, nullptr,
+                                      m->Wk<void>(ws.p_mkv), 2 * inner, (long)N * P * 2 * inner, N * P, 2 * inner, W, Lp, DEER_EPI_BF16, 0,
+                                      nullptr, st));
+  }
+  DEER_TRY(ln_rows(m, m->Wk<float>(ws.p_lat), m->A<float>(m->perc[0].nlw), m->A<float>(m->perc[0].nlb), m->Wk<void>(ws.p_latln), (long)N * nl, W, st));
+  const int Pa = ws.perc_split[0], Pf = ws.perc_split[1];
+  char* qkv = m->Wk<char>(ws.p_qkv);
+  for (int li = 0; li < Lp; ++li) {
+    const PercLayerW& L = m->perc[li];
+    DEER_TRY(gemm(m, m->Wk<void>(ws.p_latln), m->A<void>(L.wqkv), qkv, (long)N * nl, 3 * inner, W, DEER_EPI_BF16, nullptr, st));
+    const char* mkv = m->Wk<char>(ws.p_mkv) + (size_t)li * N * P * 2 * inner * 2;
+    {
+      Bracket b(m, "deer_attn_mfma_hd64", 4.0 * N * c.perc_heads * nl * (P + nl) * 64, 0, st);
+      DEER_TRY(deer_attn_mfma_hd64_2seg(qkv, mkv, mkv + (size_t)inner * 2, qkv + (size_t)inner * 2, qkv + (size_t)2 * inner * 2, m->Wk<void>(ws.p_ao), N,
+                                        c.perc_heads, nl, P, nl, 3 * inner, 2 * inner, 3 * inner, inner, (long)nl * 3 * inner, (long)P * 2 * inner,
+                                        (long)nl * 3 * inner, (long)nl * inner, 1.0f / sqrtf((float)c.perc_dim_head), st));
+    }
+    DEER_TRY(gemm_splitk(m, m->Wk<void>(ws.p_ao), m->A<void>(L.wo), m->Wk<float>(ws.v_slab), (long)N * nl, W, inner, Pa, st));
+    DEER_TRY(vresadd(m, m->Wk<float>(ws.p_lat), m->Wk<float>(ws.v_slab), Pa, (long)N * nl, W, nullptr, m->A<float>(L.fnw), m->A<float>(L.fnb),
+                     m->Wk<void>(ws.p_ln), nullptr, st));
+    DEER_TRY(gemm(m, m->Wk<void>(ws.p_ln), m->A<void>(L.w1), m->Wk<void>(ws.p_h), (long)N * nl, (long)c.perc_ff_mult * W, W, DEER_EPI_GELU_BF16, nullptr, st));
+    DEER_TRY(gemm_splitk(m, m->Wk<void>(ws.p_h), m->A<void>(L.w2), m->Wk<float>(ws.v_slab), (long)N * nl, W, (long)c.perc_ff_mult * W, Pf, st));
+    if (li + 1 < Lp) {
+      const PercLayerW& nx = m->perc[li + 1];
+      DEER_TRY(vresadd(m, m->Wk<float>(ws.p_lat), m->Wk<float>(ws.v_slab), Pf, (long)N * nl, W, nullptr, m->A<float>(nx.nlw), m->A<float>(nx.nlb),
+                       m->Wk<void>(ws.p_latln), nullptr, st));
+    } else {   // closing perceiver.norm -> media tokens (bf16 for the K/V GEMM, f32 kept)
+      DEER_TRY(vresadd(m, m->Wk<float>(ws.p_lat), m->Wk<float>(ws.v_slab), Pf, (long)N * nl, W, nullptr, m->A<float>(m->perc_normw),
+                       m->A<float>(m->perc_normb), m->Wk<void>(ws.vis_x), m->Wk<float>(ws.vis_x_f32), st));
+    }
+  }
+  return DEER_OK;
+}
+
+int vit_blocks(deer_model* m, const VisionWS& ws, int lo, int hi, void* st) {
+  const deer_config& c = m->c;
+  const int W = m->W, tok = m->tok, H = c.vit_heads, N = ws.n;
+  const long R = (long)N * tok;
+  const int So = ws.vit_split[0], Sp = ws.vit_split[1];
+  char* qkv = m->Wk<char>(ws.v_qkv);
+  for (int li = lo; li < hi; ++li) {
+    const VitLayerW& L = m->vit[li];
+    DEER_TRY(gemm(m, m->Wk<void>(ws.v_ln), m->A<void>(L.wqkv), qkv, R, 3 * W, W, DEER_EPI_BF16, m->A<float>(L.bqkv), st));
+    {
+      Bracket b(m, "deer_attn_mfma_hd64", 4.0 * N * H * tok * tok * 64, 0, st);
+      DEER_TRY(deer_attn_mfma_hd64(qkv, qkv + (size_t)W * 2, qkv + (size_t)2 * W * 2, m->Wk<void>(ws.v_ao), N, H, tok, tok, 3 * W, 3 * W, 3 * W, W,
+                                   (long)tok * 3 * W, (long)tok * 3 * W, (long)tok * 3 * W, (long)tok * W, 0.125f, st));
+    }
+    DEER_TRY(gemm_splitk(m, m->Wk<void>(ws.v_ao), m->A<void>(L.wo), m->Wk<float>(ws.v_slab), R, W, W, So, st));
+    DEER_TRY(vresadd(m, m->Wk<float>(ws.vx), m->Wk<float>(ws.v_slab), So, R, W, m->A<float>(L.bo), m->A<float>(L.ln2w), m->A<float>(L.ln2b),
+                     m->Wk<void>(ws.v_ln), nullptr, st));
+    DEER_TRY(gemm(m, m->Wk<void>(ws.v_ln), m->A<void>(L.wfc), m->Wk<void>(ws.v_h), R, c.vit_mlp, W, DEER_EPI_QGELU_BF16, m->A<float>(L.bfc), st));
+    DEER_TRY(gemm_splitk(m, m->Wk<void>(ws.v_h), m->A<void>(L.wpr), m->Wk<float>(ws.v_slab), R, W, c.vit_mlp, Sp, st));
+    if (li + 1 < c.vit_layers) {
+      const VitLayerW& nx = m->vit[li + 1];
+      DEER_TRY(vresadd(m, m->Wk<float>(ws.vx), m->Wk<float>(ws.v_slab), Sp, R, W, m->A<float>(L.bpr), m->A<float>(nx.ln1w), m->A<float>(nx.ln1b),
+                       m->Wk<void>(ws.v_ln), nullptr, st));
+    } else {
+      DEER_TRY(vresadd(m, m->Wk<float>(ws.vx), m->Wk<float>(ws.v_slab), Sp, R, W, m->A<float>(L.bpr), nullptr, nullptr, nullptr, nullptr, st));
+    }
+  }
+  return DEER_OK;
+}
+
+int media_kv(deer_model* m, void* st) {
+  if (!m->n_xattn) return DEER_OK;
+  const void* media = m->media_override ? m->media_override : m->Wk<void>(m->vis_x);
+  return gemm(m, media, m->A<void>(m->wkv_all), m->Wk<void>(m->kv_all), (long)m->N * m->nl, (long)m->n_xattn * 2 * m->xinner, m->W, DEER_EPI_BF16,
+              nullptr, st);
+}
+
+// ---- LLM ----------------------------------------------------------------------------------------------------------------
+struct Pending { const float* slab; int S; long stride; const float* gate; };
+
+int skinny(deer_model* m, const void* Wp, long N, long K, int R, float* out_slab, size_t out_elems, const void* A, int lda, const float* a_slab, int s_in,
+           int a_mode, const int* ctl, void* st, int* S_out, long* stride_out) {
+  const int S = deer_skinny_splitk(R, (int)N, (int)K);
+  const int mpad = 16 * ((R + 15) / 16);
+  if ((size_t)S * mpad * N > out_elems) return DEER_ERR_SHAPE;
+  Bracket b(m, "deer_gemm_skinny", 2.0 * R * N * K, 2.0 * N * K, st);    // algorithmic bytes = the bf16 weights, once
+  *S_out = S;
+  *stride_out = (long)mpad * N;
+  return deer_gemm_skinny(A, lda, a_slab, s_in, (long)mpad * K, a_mode, Wp, out_slab, R, (int)N, (int)K, S, ctl, st);
+}
+
+int resadd(deer_model* m, int R, const Pending* p, const float* gamma, const float* beta, float* x_copy, const int* ctl, void* st) {
+  Bracket b(m, "deer_resadd_ln", 0, 4.0 * R * m->d * ((p ? p->S : 0) + 3), st);
+  return deer_resadd_ln(m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma, beta, nullptr,
+                        gamma ? m->Wk<float>(m->xn) : nullptr, x_copy, R, m->d, kEps, ctl, st);
+}
+
+// the residual branch a layer leaves un-applied when it is not finalized: the down-projection slabs (shape-determined)
+Pending pending_of_down(const deer_model* m, int R) {
+  const long K = (long)m->c.mlp_ratio * m->d;
+  const int S = deer_skinny_splitk(R, m->d, (int)K);
+  return Pending{m->Wk<float>(m->slab_a), S, (long)(16 * ((R + 15) / 16)) * m->d, nullptr};
+}
+
+// FlamingoLayer.forward (flamingo_lm.py:46-83): gated x-attn (helpers.py:260-279) then the MPT block on
+// R = n_envs*T rows
+int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool finalize, bool use_ctl, void* st) {
+  const deer_config& c = m->c;
+  const LlmLayerW& L = m->llm[i];
+  const int d = m->d, B = m->B, R = B * T, xin = m->xinner;
+  const int* ctl = use_ctl ? m->Wk<int>(m->ctl) : nullptr;
+  float* slab_a = m->Wk<float>(m->slab_a);
+  float* slab_b = m->Wk<float>(m->slab_b);
+  float* xn = m->Wk<float>(m->xn);
+  float* ao = m->Wk<float>(m->ao);
+  Pending pend{}, *pp = nullptr;
+  // a layer that was not finalized leaves its last residual branch to this layer's first row op, which then ALSO writes the
+  // completed x out as hidden_states[i-1] (no extra launch): every hidden state up to the exit layer is real
+  float* prev_hidden = nullptr;
+  if (pending_in) {
+    pend = pending_of_down(m, R);
+    pp = &pend;
+    prev_hidden = m->Wk<float>(m->hidden) + (size_t)(i - 1) * std::min(B * c.max_text_len, kMaxRows) * d;
+  }
+  int S;
+  long stride;
+  if (L.has_xa) {
+    const XattnW& X = L.xa;
+    DEER_TRY(resadd(m, R, pp, m->A<float>(X.nw), m->A<float>(X.nb), prev_hidden, ctl, st));
+    prev_hidden = nullptr;
+    DEER_TRY(skinny(m, m->A<void>(X.wq), xin, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
+    {
+      Bracket b(m, "deer_xattn_mfma", 0, 0, st);
+      const char* kv = m->Wk<char>(m->kv_all) + (size_t)X.kv_index * 2 * xin * 2;
+      const int n_media = 2 * m->nl;
+      DEER_TRY(deer_xattn_mfma(slab_b, S, stride, xin, kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, ao, 1, xin, T, n_media,
+                               c.xattn_heads, B, 1.0f / sqrtf((float)c.xattn_dim_head), ctl, st));
+    }
+    DEER_TRY(skinny(m, m->A<void>(X.wo), d, xin, R, slab_a, m->slab_a_elems, ao, xin, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
+    pend = Pending{slab_a, S, stride, m->A<float>(X.ag)};
+    DEER_TRY(resadd(m, R, &pend, m->A<float>(X.fnw), m->A<float>(X.fnb), nullptr, ctl, st));
+    DEER_TRY(skinny(m, m->A<void>(X.w1), (long)c.xattn_ff_mult * d, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
+    DEER_TRY(skinny(m, m->A<void>(X.w2), d, (long)c.xattn_ff_mult * d, R, slab_a, m->slab_a_elems, nullptr, 0, slab_b, S, DEER_A_SLABS_GELU, ctl, st, &S,
+                    &stride));
+    pend = Pending{slab_a, S, stride, m->A<float>(X.fg)};
+    pp = &pend;
+  }
+  const float* ln1b = m->loaded(L.ln1b_name) ? m->A<float>(L.ln1b) : nullptr;
+  const float* ln2b = m->loaded(L.ln2b_name) ? m->A<float>(L.ln2b) : nullptr;
+  DEER_TRY(resadd(m, R, pp, m->A<float>(L.ln1w), ln1b, prev_hidden, ctl, st));
+  DEER_TRY(skinny(m, m->A<void>(L.wqkv), 3L * d, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
+  {
+    Bracket b(m, "deer_mpt_attn_small", 0, 0, st);
+    const unsigned char* km = m->mask_override ? m->mask_override : m->Wk<unsigned char>(m->key_mask);
+    DEER_TRY(deer_mpt_attn_small(slab_b, S, stride, d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
+                                 (float)c.alibi_bias_max, m->Wk<float>(m->qkv_ws), ao, 1, d, T, B, ctl, st));
+  }
+  DEER_TRY(skinny(m, m->A<void>(L.wo), d, d, R, slab_a, m->slab_a_elems, ao, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
+  pend = Pending{slab_a, S, stride, nullptr};
+  DEER_TRY(resadd(m, R, &pend, m->A<float>(L.ln2w), ln2b, nullptr, ctl, st));
+  DEER_TRY(skinny(m, m->A<void>(L.wup), (long)c.mlp_ratio * d, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
+  DEER_TRY(skinny(m, m->A<void>(L.wdown), d, (long)c.mlp_ratio * d, R, slab_a, m->slab_a_elems, nullptr, 0, slab_b, S, DEER_A_SLABS_GELU, ctl, st, &S, &stride));
+  if (finalize) {   // hidden_states[i] = output of layer i (mosaic_gpt_3b.py:424-427)
+    pend = Pending{slab_a, S, stride, nullptr};
+    const size_t rows_cap = std::min(B * c.max_text_len, kMaxRows);
+    DEER_TRY(resadd(m, R, &pend, nullptr, nullptr, m->Wk<float>(m->hidden) + (size_t)i * rows_cap * d, ctl, st));
+  }
+  return DEER_OK;
+}
+
+// One DeterministicDecoder evaluation on hidden_states[layer] (action_head.py:499-611) followed by the exit gate
+// (value_net.py:120-133,277-297).  kind: PSEUDO (prev action from layer i-1, value_net.py:122-125), CHECK (delta <= threshold ->
+// exit + commit LSTM state), COMMIT (static exit_id / committing call)
+int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, bool use_ctl, bool shadow, bool no_ctl_final, const float* feats,
+              bool use_mask, void* st) {
+  const deer_config& c = m->c;
+  const int H = m->H, d = m->d, B = m->B;
+  const int* ctl = use_ctl ? m->Wk<int>(m->ctl) : nullptr;
+  const size_t rows_cap = std::min(B * c.max_text_len, kMaxRows);
+  if (feats == nullptr) feats = m->Wk<float>(m->hidden) + (size_t)layer * rows_cap * d;     // [B*T, d]: env b owns rows b*T .. b*T+T-1
+  const unsigned char* km = use_mask ? (m->mask_override ? m->mask_override : m->Wk<unsigned char>(m->key_mask)) : nullptr;
+  float* pooled = m->Wk<float>(m->pooled);
+  {
+    Bracket b(m, "deer_head_pool", 0, 0, st);
+    DEER_TRY(deer_head_pool(feats, pooled, T, d, c.pooling_avg, B, km, ctl, kind, layer, st));
+  }
+  float* h_tmp = m->Wk<float>(m->h_tmp);
+  float* c_tmp = m->Wk<float>(m->c_tmp);
+  const float* h_prev = m->Wk<float>(m->h_state);
+  const float* c_prev = m->Wk<float>(m->c_state);
+  const size_t lst = (size_t)B * H;
+  for (int l = 0; l < m->Lh; ++l) {
+    const LstmW& Lw = m->lstm[l];
+    const float* src;
+    long bstride;
+    int mode, in_dim;
+    const float *lnw = nullptr, *lnb = nullptr;
+    if (l == 0) { src = pooled; bstride = d; mode = DEER_X_RAW; in_dim = d; }
+    else {
+      src = h_tmp + (l - 1) * lst; bstride = H; in_dim = H;
+      if (c.lstm_layernorm) { mode = DEER_X_LN; lnw = m->A<float>(m->lstm[l - 1].lnw); lnb = m->A<float>(m->lstm[l - 1].lnb); }
+      else mode = DEER_X_RAW;
+    }
+    Bracket b(m, "deer_head_lstm_layer", 0, 2.0 * 4 * H * (in_dim + H), st);
+    DEER_TRY(deer_head_lstm_layer(src, bstride, mode, T, in_dim, lnw, lnb, m->A<void>(Lw.wih), m->A<void>(Lw.whh), m->A<float>(Lw.bih), m->A<float>(Lw.bhh),
+                                  h_prev + l * lst, c_prev + l * lst, h_tmp + l * lst, c_tmp + l * lst, H, B, kEps, ctl, kind, layer, st));
+  }
+  const float* src = h_tmp + (m->Lh - 1) * lst;
+  int in_dim = H, sstride = H, pro = DEER_PRO_RAW;
+  const float* ln[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (c.lstm_layernorm) { pro = DEER_PRO_LN; ln[0] = m->A<float>(m->lstm.back().lnw); ln[1] = m->A<float>(m->lstm.back().lnb); }
+  for (int fi = 0; fi < m->n_fc; ++fi) {
+    const FcW& F = m->fc[fi];
+    const int dim = m->fc_dims[fi];
+    float* z = m->Wk<float>(m->z_fc[fi]);
+    {
+      Bracket b(m, "deer_head_fc", 0, 0, st);
+      DEER_TRY(deer_head_fc(src, sstride, in_dim, pro, ln[0], ln[1], ln[2], ln[3], m->A<void>(F.w[0]), m->A<float>(F.b[0]), m->A<void>(F.w[1]),
+                            m->A<float>(F.b[1]), dim, z, B, kEps, ctl, kind, layer, st));
+    }
+    src = z; in_dim = dim; sstride = 2 * dim;
+    if (c.mlp_layernorm) { pro = DEER_PRO_GROUP_LN_RELU; ln[0] = m->A<float>(F.lnw[0]); ln[1] = m->A<float>(F.lnb[0]); ln[2] = m->A<float>(F.lnw[1]); ln[3] = m->A<float>(F.lnb[1]); }
+    else { pro = DEER_PRO_GROUP_RELU; ln[0] = ln[1] = ln[2] = ln[3] = nullptr; }
+  }
+  Bracket b(m, "deer_head_final", 0, 0, st);
+  const float* thr = m->thr_override ? m->thr_override : m->Wk<float>(m->thresholds);
+  return deer_head_final(src, sstride, in_dim, pro, ln[0], ln[1], ln[2], ln[3], m->A<void>(m->wa), m->A<float>(m->ba), m->A<void>(m->wg), m->A<float>(m->bg),
+                         no_ctl_final ? nullptr : m->Wk<int>(m->ctl), kind, layer, slot, thr, force ? 1 : 0, m->thr_type, m->leq, h_tmp, c_tmp,
+                         m->Wk<float>(shadow ? m->h_shadow : m->h_state), m->Wk<float>(shadow ? m->c_shadow : m->c_state), m->Lh, H, B,
+                         m->Wk<float>(m->action_dbg), kEps, st);
+}
+
+struct PlanRow { int need_pseudo, is_exit, slot; };
+
+// per layer of the dynamic step: (need_pseudo, is_exit, exit slot) - mosaic_gpt_3b.py:397-443, value_net.py:122-125
+std::vector<PlanRow> dynamic_plan(const deer_model* m) {
+  std::vector<PlanRow> plan;
+  auto find = [&](int v) { return (int)(std::find(m->exit_ids.begin(), m->exit_ids.end(), v) - m->exit_ids.begin()); };
+  const int ne = (int)m->exit_ids.size();
+  for (int i = 0; i < m->c.n_layers; ++i) {
+    const bool need_pseudo = find(i + 1) < ne && (i + 1) - m->c.exit_interval < 0 && (i + 1) <= m->ctl_max_layer;
+    const int k = find(i);
+    const bool is_exit = k < ne && i <= m->ctl_max_layer;
+    plan.push_back(PlanRow{need_pseudo ? 1 : 0, is_exit ? 1 : 0, is_exit ? k : -1});
+    if (i >= m->ctl_max_layer) break;
+  }
+  return plan;
+}
+
+int embed(deer_model* m, int T, void* st) {
+  Bracket b(m, "deer_embed_tokens", 0, 0, st);
+  const long long* ids = m->ids_override ? m->ids_override : m->Wk<long long>(m->ids);
+  return deer_embed_tokens(ids, m->A<void>(m->wte), m->Wk<float>(m->x), m->Wk<int>(m->text_time), T, m->B, m->d, m->c.vocab_size, m->c.media_token_id, st);
+}
+
+int llm_dynamic(deer_model* m, int T, bool use_mask, bool shadow, void* st) {
+  const std::vector<PlanRow> plan = dynamic_plan(m);
+  bool pending = false;
+  DEER_TRY(embed(m, T, st));
+  for (int i = 0; i < (int)plan.size(); ++i) {
+    const bool fin = plan[i].need_pseudo || plan[i].is_exit;
+    DEER_TRY(llm_layer(m, i, T, use_mask, pending, fin, true, st));
+    pending = !fin;
+    // rows that are right-padding of an ENV BATCH stay out of the token pool (an independent single-environment run never has
+    // them); with one environment the pool covers all T rows like the reference's (action_head.py:519-520)
+    const bool pm = use_mask && m->B > 1;
+    if (plan[i].need_pseudo) DEER_TRY(head_eval(m, i, T, DEER_KIND_PSEUDO, -1, false, true, false, false, nullptr, pm, st));
+    if (plan[i].is_exit)
+      DEER_TRY(head_eval(m, i, T, DEER_KIND_CHECK, plan[i].slot, i >= m->ctl_max_layer, true, shadow, false, nullptr, pm, st));
+  }
+  return DEER_OK;
+}
+
+int llm_static(deer_model* m, int T, bool use_mask, int exit_id, void* st) {
+  DEER_TRY(embed(m, T, st));
+  for (int i = 0; i <= exit_id; ++i) DEER_TRY(llm_layer(m, i, T, use_mask, false, true, false, st));
+  return head_eval(m, exit_id, T, DEER_KIND_COMMIT, -1, false, false, false, false, nullptr, use_mask && m->B > 1, st);
+}
+
+int vision(deer_model* m, const VisionWS& ws, int part, bool with_kv, void* st) {
+  const int nv = m->c.vit_layers;
+  const int n_head = std::min(kVitHeadLayers, nv - 1);
+  const int lo = part == 2 ? n_head : 0, hi = part == 1 ? n_head : nv;
+  if (part != 2) DEER_TRY(patch_embed(m, ws, st));
+  DEER_TRY(vit_blocks(m, ws, lo, hi, st));
+  if (part != 1) {
+    DEER_TRY(perceiver(m, ws, st));
+    if (with_kv) DEER_TRY(media_kv(m, st));
+  }
+  return DEER_OK;
+}
+
+}  // namespace
+
+// ====================================================================================================================
+extern "C" {
+
+int deer_model_create(const deer_config* cfg, deer_model** out) {
+  if (cfg == nullptr || out == nullptr) return DEER_ERR_SHAPE;
+  const deer_config& c = *cfg;
+  if (c.n_envs < 1 || c.n_envs > 8 || c.max_text_len < 1 || c.n_layers < 1 || c.vit_layers < 1 || c.perc_depth < 1) return DEER_ERR_SHAPE;
+  if (c.image_size % c.patch_size) return DEER_ERR_SHAPE;
+  if (c.vit_width % c.vit_heads || c.vit_width / c.vit_heads != 64 || c.perc_dim_head != 64 || c.xattn_dim_head != 64) return DEER_ERR_SHAPE;
+  if (c.d_model % 32 || c.d_model / c.n_heads > 128 || 2 * c.perc_latents > 128) return DEER_ERR_SHAPE;
+  if (c.mlp_num_hidden_layers < 0 || c.mlp_num_hidden_layers > 3 || c.lstm_num_layers < 1) return DEER_ERR_SHAPE;
+  deer_model* m = new deer_model();
+  m->c = c;
+  const int g = c.image_size / c.patch_size;
+  m->P = g * g;
+  m->tok = m->P + 1;
+  m->W = c.vit_width;
+  m->kpad = (3 * c.patch_size * c.patch_size + 63) / 64 * 64;
+  m->nl = c.perc_latents;
+  m->p_inner = c.perc_heads * c.perc_dim_head;
+  m->Lp = c.perc_depth;
+  m->d = c.d_model;
+  m->xinner = c.xattn_heads * c.xattn_dim_head;
+  m->H = c.head_hidden;
+  m->Lh = c.lstm_num_layers;
+  m->B = c.n_envs;
+  m->N = 2 * c.n_envs;
+  m->n_fc = c.mlp_num_hidden_layers;
+  const int dims[3] = {1024, 512, 256};                      // action_head.py:87-89
+  for (int i = 0; i < 3; ++i) m->fc_dims[i] = dims[i];
+  build_arena(m);
+  build_workspace(m);
+  // default controller: exits every exit_interval layers + the last layer (flamingo_mpt.py:239-250,268-270)
+  for (int i = c.exit_interval - 1; i < c.n_layers - 1; i += c.exit_interval) m->exit_ids.push_back(i);
+  m->exit_ids.push_back(c.n_layers - 1);
+  m->ctl_max_layer = m->exit_ids.back();
+  *out = m;
+  return DEER_OK;
+}
+
+void deer_model_destroy(deer_model* m) {
+  if (m == nullptr) return;
+  for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
+  delete m;
+}
+
+long deer_model_arena_bytes(const deer_model* m) { return (long)m->al.cur; }
+long deer_model_workspace_bytes(const deer_model* m) { return (long)m->wl.cur; }
+
+int deer_model_bind(deer_model* m, void* arena, void* workspace) {
+  if (arena == nullptr || workspace == nullptr || ((uintptr_t)arena & 255) || ((uintptr_t)workspace & 255)) return DEER_ERR_SHAPE;
+  m->arena = reinterpret_cast<char*>(arena);
+  m->ws = reinterpret_cast<char*>(workspace);
+  return DEER_OK;
+}
+
+int deer_model_knows_tensor(const deer_model* m, const char* name) { return m->slots.count(name) ? 1 : 0; }
+
+int deer_model_load_tensor(deer_model* m, const char* name, const void* src, int src_is_bf16, long numel, void* stream) {
+  if (m->arena == nullptr || src == nullptr) return DEER_ERR_SHAPE;
+  auto it = m->slots.find(name);
+  if (it == m->slots.end()) return DEER_ERR_SHAPE;
+  Slot& s = it->second;
+  if (numel != s.rows * s.cols) return DEER_ERR_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long total = s.rows * s.dst_cols;
+  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+  if (s.kind == SK_PACK) {
+    if ((s.rows & 15) || (s.cols & 31)) return DEER_ERR_SHAPE;
+    const long tot = (s.rows >> 4) * (s.cols >> 5) * 64;
+    const int pb = (int)std::min<long>((tot + 255) / 256, 4096);
+    if (src_is_bf16) hipLaunchKernelGGL(ingest_pack_kernel<bf16_t>, dim3(pb), dim3(256), 0, st, (const bf16_t*)src, m->A<bf16_t>(s.dst[0]), (int)s.rows, s.cols);
+    else hipLaunchKernelGGL(ingest_pack_kernel<float>, dim3(pb), dim3(256), 0, st, (const float*)src, m->A<bf16_t>(s.dst[0]), (int)s.rows, s.cols);
+  } else {
+    for (int k = 0; k < 2; ++k) {
+      if (s.dst[k] == SIZE_MAX) continue;
+      void* dst = m->A<void>(s.dst[k]);
+      const long pitch = k == 0 ? s.dst_pitch : s.dst2_pitch;
+      if (s.kind == SK_BF16) {
+        if (src_is_bf16) hipLaunchKernelGGL((ingest_rows_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, dst, s.rows, s.cols, s.dst_cols, pitch);
+        else hipLaunchKernelGGL((ingest_rows_kernel<float, true>), dim3(blocks), dim3(256), 0, st, (const float*)src, dst, s.rows, s.cols, s.dst_cols, pitch);
+      } else {
+        if (src_is_bf16) hipLaunchKernelGGL((ingest_rows_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, dst, s.rows, s.cols, s.dst_cols, pitch);
+        else hipLaunchKernelGGL((ingest_rows_kernel<float, false>), dim3(blocks), dim3(256), 0, st, (const float*)src, dst, s.rows, s.cols, s.dst_cols, pitch);
+      }
+    }
+  }
+  DEER_LAUNCH_CHECK();
+  s.loaded = true;
+  return DEER_OK;
+}
+
+int deer_model_missing_tensors(const deer_model* m, char* buf, int buflen) {
+  int n = 0;
+  std::string out;
+  for (const std::string& name : m->slot_order) {
+    const Slot& s = m->slots.at(name);
+    if (s.required && !s.loaded) {
+      ++n;
+      out += name;
+      out += '\n';
+    }
+  }
+  if (buf != nullptr && buflen > 0) {
+    strncpy(buf, out.c_str(), (size_t)buflen - 1);
+    buf[buflen - 1] = 0;
+  }
+  return n;
+}
+
+int deer_model_buffer(const deer_model* m, int which, const char* name, long* offset, long* bytes) {
+  if (which == 1) {
+    auto it = m->ws_named.find(name);
+    if (it == m->ws_named.end()) return DEER_ERR_SHAPE;
+    if (offset) *offset = (long)it->second.first;
+    if (bytes) *bytes = (long)it->second.second;
+    return DEER_OK;
+  }
+  auto it = m->slots.find(name);
+  if (it == m->slots.end()) return DEER_ERR_SHAPE;
+  const Slot& s = it->second;
+  if (offset) *offset = (long)s.dst[0];
+  if (bytes) *bytes = (long)(s.rows * s.dst_pitch * (s.kind == SK_F32 ? 4 : 2));
+  return DEER_OK;
+}
+
+int deer_model_configure_exit(deer_model* m, const int* exit_ids, int n_exit, int max_layer, int thr_type, int leq) {
+  if (exit_ids == nullptr || n_exit <= 0 || n_exit > 16 || thr_type < 0 || thr_type > 3) return DEER_ERR_SHAPE;
+  for (int i = 0; i < n_exit; ++i)
+    if (exit_ids[i] < 0 || exit_ids[i] >= m->c.n_layers || (i && exit_ids[i] <= exit_ids[i - 1])) return DEER_ERR_SHAPE;
+  const int cm = std::min(max_layer - 1, exit_ids[n_exit - 1]);               // value_net.py:173
+  // some exit must be reachable, and the deepest reachable layer must BE an exit: otherwise no check would ever be forced and a
+  // step would end without a verdict (the reference raises KeyError on thresholds[i] in that situation)
+  bool ok = false;
+  for (int i = 0; i < n_exit; ++i) ok = ok || exit_ids[i] == cm;
+  if (!ok) return DEER_ERR_SHAPE;
+  m->exit_ids.assign(exit_ids, exit_ids + n_exit);
+  m->ctl_max_layer = cm;
+  m->thr_type = thr_type;
+  m->leq = leq ? 1 : 0;
+  return DEER_OK;
+}
+
+int deer_model_real_num_exit(const deer_model* m) {
+  int n = 0;
+  for (int e : m->exit_ids) n += e <= m->ctl_max_layer ? 1 : 0;
+  return n;
+}
+
+int deer_model_n_chains(const deer_model* m) { return (int)m->chains.size(); }
+
+int deer_dynamic_plan(const deer_model* m, int* need_pseudo, int* is_exit, int* slot, int cap) {
+  const std::vector<PlanRow> plan = dynamic_plan(m);
+  for (int i = 0; i < (int)plan.size() && i < cap; ++i) {
+    if (need_pseudo) need_pseudo[i] = plan[i].need_pseudo;
+    if (is_exit) is_exit[i] = plan[i].is_exit;
+    if (slot) slot[i] = plan[i].slot;
+  }
+  return (int)plan.size();
+}
+
+// ---- pieces -------------------------------------------------------------------------------------------------------------
+int deer_begin_step(deer_model* m, const int* step_info, void* stream) {
+  if (m->ws == nullptr) return DEER_ERR_SHAPE;
+  Bracket b(m, "deer_ctl_begin_step", 0, 0, stream);
+  return deer_ctl_begin_step(m->Wk<int>(m->ctl), step_info ? step_info : m->Wk<int>(m->step_info), m->B, stream);
+}
+
+int deer_vision(deer_model* m, int chain, int part, int with_kv, void* stream) {
+  if (m->ws == nullptr || part < 0 || part > 2 || chain >= (int)m->chains.size()) return DEER_ERR_SHAPE;
+  return vision(m, chain < 0 ? m->vws : m->chains[chain], part, with_kv != 0, stream);
+}
+
+int deer_media_kv(deer_model* m, void* stream) { return m->ws ? media_kv(m, stream) : DEER_ERR_SHAPE; }
+
+int deer_llm_embed(deer_model* m, int T, void* stream) {
+  if (m->ws == nullptr || T <= 0 || T > m->c.max_text_len || m->B * T > kMaxRows) return DEER_ERR_SHAPE;
+  return embed(m, T, stream);
+}
+
+int deer_llm_layer(deer_model* m, int layer, int T, int use_mask, int pending_in, int finalize, int use_ctl, void* stream) {
+  if (m->ws == nullptr || layer < 0 || layer >= m->c.n_layers || T <= 0 || T > m->c.max_text_len || m->B * T > kMaxRows) return DEER_ERR_SHAPE;
+  return llm_layer(m, layer, T, use_mask != 0, pending_in != 0, finalize != 0, use_ctl != 0, stream);
+}
+
+int deer_head_eval(deer_model* m, int layer, int T, int kind, int slot, int force, int use_ctl, int shadow, int no_ctl_final, const float* feats,
+                   int use_mask, void* stream) {
+  if (m->ws == nullptr || layer < 0 || layer >= m->c.n_layers || T <= 0 || kind < 0 || kind > 2) return DEER_ERR_SHAPE;
+  return head_eval(m, layer, T, kind, slot, force != 0, use_ctl != 0, shadow != 0, no_ctl_final != 0, feats, use_mask != 0, stream);
+}
+
+int deer_step_enqueue(deer_model* m, int T, int use_mask, int exit_id, int shadow, const int* step_info, void* stream) {
+  if (m->ws == nullptr || T <= 0 || T > m->c.max_text_len || m->B * T > kMaxRows || exit_id >= m->c.n_layers) return DEER_ERR_SHAPE;
+  DEER_TRY(deer_begin_step(m, step_info, stream));
+  DEER_TRY(vision(m, m->vws, 0, true, stream));
+  return exit_id < 0 ? llm_dynamic(m, T, use_mask != 0, shadow != 0, stream) : llm_static(m, T, use_mask != 0, exit_id, stream);
+}
+
+// ---- the three coarse operators ----------------------------------------------------------------------------
+int deer_vit_l14_encode(deer_model* m, const void* images_bf16, int n_images, float* tokens_out, void* stream) {
+  if (m->ws == nullptr || images_bf16 == nullptr || n_images != m->N) return DEER_ERR_SHAPE;
+  m->img_override = images_bf16;
+  int rc = patch_embed(m, m->vws, stream);
+  if (rc == DEER_OK) rc = vit_blocks(m, m->vws, 0, m->c.vit_layers, stream);
+  m->img_override = nullptr;
+  if (rc != DEER_OK) return rc;
+  if (tokens_out != nullptr) {   // patch tokens x[:, 1:] of every image, without ln_post (flamingo_mpt.py:580)
+    const size_t row = (size_t)m->W * 4;
+    for (int n = 0; n < n_images; ++n)
+      if (hipMemcpyAsync(tokens_out + (size_t)n * m->P * m->W, m->Wk<float>(m->vws.vx) + ((size_t)n * m->tok + 1) * m->W, row * m->P, hipMemcpyDeviceToDevice,
+                         (hipStream_t)stream) != hipSuccess)
+        return DEER_ERR_LAUNCH;
+  }
+  return DEER_OK;
+}
+
+int deer_perceiver_resample(deer_model* m, const float* tokens, int n_images, void* media_bf16_out, float* media_f32_out, void* stream) {
+  if (m->ws == nullptr || n_images != m->N) return DEER_ERR_SHAPE;
+  m->tokens_override = tokens;
+  const int rc = perceiver(m, m->vws, stream);
+  m->tokens_override = nullptr;
+  if (rc != DEER_OK) return rc;
+  const size_t n = (size_t)m->N * m->nl * m->W;
+  if (media_bf16_out && hipMemcpyAsync(media_bf16_out, m->Wk<void>(m->vis_x), n * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return DEER_ERR_LAUNCH;
+  if (media_f32_out && hipMemcpyAsync(media_f32_out, m->Wk<void>(m->vis_x_f32), n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return DEER_ERR_LAUNCH;
+  return DEER_OK;
+}
+
+int deer_llm_early_exit(deer_model* m, const long long* ids, const unsigned char* key_mask, int T, const void* media_bf16, int exit_id, int shadow,
+                        const float* thresholds, const int* step_info, void* stream) {
+  if (m->ws == nullptr || ids == nullptr || T <= 0 || T > m->c.max_text_len || m->B * T > kMaxRows || exit_id >= m->c.n_layers) return DEER_ERR_SHAPE;
+  m->ids_override = ids;
+  m->mask_override = key_mask;
+  m->media_override = media_bf16;
+  m->thr_override = thresholds;
+  int rc = deer_begin_step(m, step_info, stream);
+  if (rc == DEER_OK) rc = media_kv(m, stream);
+  if (rc == DEER_OK) rc = exit_id < 0 ? llm_dynamic(m, T, key_mask != nullptr, shadow != 0, stream) : llm_static(m, T, key_mask != nullptr, exit_id, stream);
+  m->ids_override = nullptr;
+  m->mask_override = nullptr;
+  m->media_override = nullptr;
+  m->thr_override = nullptr;
+  return rc;
+}
+
+// ---- profiler -------------------------------------------------------------------------------------------------------------
+int deer_prof_enable(deer_model* m, int on) {
+  m->prof_on = on != 0;
+  if (on) {
+    m->prof.clear();
+    m->ev_next = 0;
+  }
+  return DEER_OK;
+}
+
+int deer_prof_count(const deer_model* m) { return (int)m->prof.size(); }
+
+int deer_prof_get(deer_model* m, int i, char* name, int name_len, float* us, double* flops, double* bytes) {
+  if (i < 0 || i >= (int)m->prof.size()) return DEER_ERR_SHAPE;
+  const ProfRec& r = m->prof[i];
+  if (name && name_len > 0) {
+    strncpy(name, r.name.c_str(), (size_t)name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  float ms = 0.f;
+  if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return DEER_ERR_LAUNCH;
+  if (us) *us = ms * 1e3f;
+  if (flops) *flops = r.flops;
+  if (bytes) *bytes = r.bytes;
+  return DEER_OK;
+}
+
+}  // extern "C"

@@ -32,16 +32,6 @@ from .synthetic import mlp_layer_indices
 EPS = 1e-5
 
 
-def _pick_split(M: int, N: int, K: int, target_blocks: int = 320, max_split: int = 8) -> int:
-    """Split-K factor for a projection whose 64x64 output tiles alone cannot fill 256 CUs: double while the grid stays
-    under ~1.25 workgroups per CU (the f32 slabs cost HBM traffic: measured optimum 2,2 for ViT-L at 514 rows) and every slice keeps >= 2 K-steps of 64."""
-    blocks = ((M + 63) // 64) * ((N + 63) // 64)
-    S = 1
-    while S * 2 <= max_split and blocks * S * 2 <= target_blocks and K % (S * 2 * 64) == 0 and K // (S * 2) >= 128:
-        S *= 2
-    return S
-
-
 def _i32(v: int) -> int:
     """two's-complement wrap into int32 (halves of a pointer stored in an int32 tensor)"""
     v &= 0xFFFFFFFF
@@ -52,33 +42,39 @@ def _cur_stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-class _ProfiledLib:
-    """Proxy around the ctypes library: when ``engine._prof`` is a list every kernel-launching ABI call is bracketed
-    by two HIP events on the current stream (bench.py's in-situ roofline pass).  Pass-through otherwise."""
-    _HOST_ONLY = ("deer_skinny_splitk", "deer_hip_arch", "deer_hip_abi_version")
+class _DeerConfigC(ctypes.Structure):
+    """``deer_config`` of include/deer_model.h (field order must match)."""
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "image_size", "patch_size", "vit_width", "vit_layers", "vit_heads", "vit_mlp",
+        "perc_depth", "perc_heads", "perc_dim_head", "perc_latents", "perc_ff_mult",
+        "vocab_size", "d_model", "n_heads", "n_layers", "mlp_ratio", "attn_qk_ln", "alibi_bias_max",
+        "cross_attn_every_n_layers", "xattn_heads", "xattn_dim_head", "xattn_ff_mult", "media_token_id",
+        "mpt7b_names", "exit_interval",
+        "head_hidden", "lstm_num_layers", "lstm_layernorm", "mlp_layernorm", "mlp_num_hidden_layers", "pooling_avg",
+        "n_envs", "max_text_len", "n_chains")]
 
-    def __init__(self, lib, eng):
-        self._lib, self._eng = lib, eng
 
-    def __getattr__(self, name):
-        fn = getattr(self._lib, name)
-        if name in self._HOST_ONLY:
-            return fn
-        eng = self._eng
-
-        def call(*a):
-            if eng._prof is None:
-                return fn(*a)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            rc = fn(*a)
-            e1.record()
-            eng._prof.append((name, e0, e1) + eng._cost)
-            return rc
-        return call
+def config_to_c(cfg: DeerConfig, n_envs: int, max_text_len: int, n_chains: int = 0) -> _DeerConfigC:
+    c = _DeerConfigC()
+    for k in ("image_size", "patch_size", "vit_width", "vit_layers", "vit_heads", "vit_mlp", "perc_depth", "perc_heads",
+              "perc_dim_head", "perc_latents", "perc_ff_mult", "vocab_size", "d_model", "n_heads", "mlp_ratio",
+              "alibi_bias_max", "cross_attn_every_n_layers", "xattn_heads", "xattn_dim_head", "xattn_ff_mult",
+              "media_token_id", "exit_interval", "head_hidden", "lstm_num_layers", "mlp_num_hidden_layers"):
+        setattr(c, k, int(getattr(cfg, k)))
+    c.n_layers = cfg.n_layers
+    c.attn_qk_ln = 1 if cfg.attn_qk_ln else 0
+    c.mpt7b_names = 1 if cfg.llm_name == "mpt_9b" else 0
+    c.lstm_layernorm = 1 if cfg.lstm_layernorm else 0
+    c.mlp_layernorm = 1 if cfg.mlp_layernorm else 0
+    c.pooling_avg = 0 if cfg.pooling == "max" else 1
+    c.n_envs, c.max_text_len, c.n_chains = n_envs, max_text_len, n_chains
+    return c
 
 
 class DeerEngine:
+    """Python host of the native spine (csrc/model.hip, include/deer_model.h): owns the two device allocations (weight arena,
+    workspace) and the pinned host buffers, ingests the reference state dict by name, and feeds the step to the GPU as HIP-graph
+    pieces.  The kernel ORDER of every piece lives in the C++ model object; nothing here touches a kernel directly."""
     LOOKAHEAD = 1        # trunk layers the host keeps in flight beyond an undecided exit check
 
     def __init__(self, cfg: DeerConfig, state_dict: Dict[str, torch.Tensor], device="cuda", max_text_len: int = 32,
@@ -88,24 +84,27 @@ class DeerEngine:
         thresholds are shared and every environment exits at its own layer (device side)."""
         if not torch.cuda.is_available():
             raise abi.DeerHipError("DeerEngine needs a HIP device (no CPU fallback exists in deer_vla_amd)")
-        self._prof = None            # when a list: every launch is bracketed by HIP events (bench roofline pass)
-        self._cost = (0.0, 0.0)
-        self.lib = _ProfiledLib(abi.lib(), self)
+        self.lib = abi.lib()
         self.cfg = cfg
         self.dev = torch.device(device)
+        if self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
         assert 1 <= n_envs <= 8
         self.B = n_envs
         self.n_cams = 2 * n_envs                       # images per step: (rgb, gripper) of every environment
-        self.max_T = max_text_len
-        assert n_envs * 14 <= 64, "skinny GEMM handles <= 64 rows"
-        self.thr_type = abi.THR_TYPES[threshold_type]
-        self.leq = 1 if leq else 0
-        assert cfg.vit_head_dim == 64 and cfg.perc_dim_head == 64 and cfg.xattn_dim_head == 64, "head_dim 64 kernels"
-        assert cfg.head_dim <= 128 and cfg.d_model % 32 == 0
-        assert cfg.n_media <= 128, "xattn_small kernel holds <=128 media tokens"
-        self._keep: List[torch.Tensor] = []
-        self._load_weights(state_dict)
-        self._alloc_workspace()
+        self.max_T = min(max_text_len, 128 // n_envs)  # the skinny GEMM takes n_envs * T <= 128 rows
+        assert self.max_T >= 14, "n_envs * T must fit 128 LLM rows"
+        self._thr_type = abi.THR_TYPES[threshold_type]
+        self._leq = 1 if leq else 0
+        self._h = ctypes.c_void_p()
+        cc = config_to_c(cfg, n_envs, self.max_T)
+        abi.check(self.lib.deer_model_create(ctypes.byref(cc), ctypes.byref(self._h)), "deer_model_create")
+        with torch.cuda.device(self.dev):
+            self.arena = torch.zeros(self.lib.deer_model_arena_bytes(self._h), dtype=torch.uint8, device=self.dev)
+            self.workspace = torch.zeros(self.lib.deer_model_workspace_bytes(self._h), dtype=torch.uint8, device=self.dev)
+            abi.check(self.lib.deer_model_bind(self._h, abi.ptr(self.arena), abi.ptr(self.workspace)), "deer_model_bind")
+            self._load_weights(state_dict)
+            self._make_views()
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self.segmented = segmented                    # dynamic steps fed in per-layer graph pieces (see _step_segmented)
         self._side_stream = torch.cuda.Stream(device=self.dev)
@@ -118,220 +117,74 @@ class DeerEngine:
         # controller configuration (set by configure_exit)
         self.exit_ids = cfg.exit_ids()
         self.ctl_max_layer = self.exit_ids[-1]
+        self._max_layer_arg = self.exit_ids[-1] + 1
         self.steps_per_stage = 1
+        self._apply_controller()
         self.reset()
 
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                torch.cuda.synchronize(self.dev)
+                self.lib.deer_model_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:                              # interpreter shutdown
+            pass
+
     # ------------------------------------------------------------------------------------------ weights
-    def _dev(self, t: torch.Tensor, dtype) -> torch.Tensor:
-        return t.detach().to(device=self.dev, dtype=dtype).contiguous()
-
-    def _bf(self, t):
-        return self._dev(t, torch.bfloat16)
-
-    def _f32(self, t):
-        return self._dev(t, torch.float32)
-
-    def _packed(self, t: torch.Tensor) -> torch.Tensor:
-        """row-major [N,K] -> MFMA-fragment order for the skinny GEMM (deer_pack_weight_mfma16)."""
-        w = self._bf(t)
-        N, K = w.shape
-        out = torch.empty_like(w)
-        abi.check(self.lib.deer_pack_weight_mfma16(abi.ptr(w), abi.ptr(out), N, K, _cur_stream()), "pack_weight")
-        torch.cuda.current_stream().synchronize()
-        return out
-
     def _load_weights(self, sd: Dict[str, torch.Tensor]):
-        cfg = self.cfg
-        W = cfg.vit_width
-        g = lambda k: sd[k]
-        self.vit = {}
-        v = "vision_encoder.visual."
-        kk = 3 * cfg.patch_size ** 2
-        self.patch_kpad = (kk + 63) // 64 * 64
-        conv = g(v + "conv1.weight").reshape(W, kk)
-        convp = torch.zeros(W, self.patch_kpad, dtype=conv.dtype, device=conv.device)
-        convp[:, :kk] = conv
-        self.vit["conv"] = self._bf(convp)
-        self.vit["cls"] = self._f32(g(v + "class_embedding"))
-        self.vit["pos"] = self._f32(g(v + "positional_embedding"))
-        self.vit["ln_pre_w"], self.vit["ln_pre_b"] = self._f32(g(v + "ln_pre.weight")), self._f32(g(v + "ln_pre.bias"))
-        self.vit_layers = []
-        for l in range(cfg.vit_layers):
-            p = f"{v}transformer.resblocks.{l}."
-            self.vit_layers.append(dict(
-                ln1w=self._f32(g(p + "ln_1.weight")), ln1b=self._f32(g(p + "ln_1.bias")),
-                wqkv=self._bf(g(p + "attn.in_proj_weight")), bqkv=self._f32(g(p + "attn.in_proj_bias")),
-                wo=self._bf(g(p + "attn.out_proj.weight")), bo=self._f32(g(p + "attn.out_proj.bias")),
-                ln2w=self._f32(g(p + "ln_2.weight")), ln2b=self._f32(g(p + "ln_2.bias")),
-                wfc=self._bf(g(p + "mlp.c_fc.weight")), bfc=self._f32(g(p + "mlp.c_fc.bias")),
-                wpr=self._bf(g(p + "mlp.c_proj.weight")), bpr=self._f32(g(p + "mlp.c_proj.bias"))))
-        self.perc = dict(latents=self._f32(g("perceiver.latents")), normw=self._f32(g("perceiver.norm.weight")),
-                         normb=self._f32(g("perceiver.norm.bias")))
-        self.perc_layers = []
-        for l in range(cfg.perc_depth):
-            a, f = f"perceiver.layers.{l}.0.", f"perceiver.layers.{l}.1."
-            self.perc_layers.append(dict(
-                nlw=self._f32(g(a + "norm_latents.weight")), nlb=self._f32(g(a + "norm_latents.bias")),
-                # latents are projected to q | k | v in one GEMM: [to_q ; to_kv] stacked on the output dimension
-                wqkv=self._bf(torch.cat([g(a + "to_q.weight"), g(a + "to_kv.weight")], 0)), wo=self._bf(g(a + "to_out.weight")),
-                fnw=self._f32(g(f + "0.weight")), fnb=self._f32(g(f + "0.bias")),
-                w1=self._bf(g(f + "1.weight")), w2=self._bf(g(f + "3.weight"))))
-        # the media tokens are the same in every Perceiver layer: norm_media / to_kv of ALL layers are applied up front
-        pl = [f"perceiver.layers.{l}.0." for l in range(cfg.perc_depth)]
-        self.perc_nm_w = self._f32(torch.stack([g(a + "norm_media.weight") for a in pl]))
-        self.perc_nm_b = self._f32(torch.stack([g(a + "norm_media.bias") for a in pl]))
-        self.perc_wkv_all = self._bf(torch.stack([g(a + "to_kv.weight") for a in pl]))        # [L][2*inner][W]
-        # ---- LLM ----
-        self.wte = self._bf(g("lang_encoder.transformer.wte.weight"))
-        nine_b = cfg.llm_name == "mpt_9b"
-        ln1, ln2 = ("norm_1", "norm_2") if nine_b else ("ln_1", "ln_2")
-        up, down = ("ffn.up_proj", "ffn.down_proj") if nine_b else ("mlp.mlp_up", "mlp.mlp_down")
-        self.llm_layers = []
-        kv_rows = []
-        for n in range(cfg.n_layers):
-            blk = f"lang_encoder.transformer.blocks.{n}."
-            L = {}
-            if cfg.has_xattn(n):
-                x = blk + "gated_cross_attn_layer."
-                L["xa"] = dict(nw=self._f32(g(x + "attn.norm.weight")), nb=self._f32(g(x + "attn.norm.bias")),
-                               wq=self._packed(g(x + "attn.to_q.weight")), wo=self._packed(g(x + "attn.to_out.weight")),
-                               ag=self._f32(g(x + "attn_gate")), fg=self._f32(g(x + "ff_gate")),
-                               fnw=self._f32(g(x + "ff.0.weight")), fnb=self._f32(g(x + "ff.0.bias")),
-                               w1=self._packed(g(x + "ff.1.weight")), w2=self._packed(g(x + "ff.3.weight")),
-                               kv_index=len(kv_rows))
-                kv_rows.append(g(x + "attn.to_kv.weight"))
-            m = blk + "decoder_layer."
-            L["ln1w"] = self._f32(g(m + ln1 + ".weight"))
-            L["ln1b"] = self._f32(sd[m + ln1 + ".bias"]) if (m + ln1 + ".bias") in sd else None
-            L["wqkv"] = self._packed(g(m + "attn.Wqkv.weight"))
-            L["qlnw"] = self._f32(g(m + "attn.q_ln.weight")) if cfg.attn_qk_ln else None
-            L["klnw"] = self._f32(g(m + "attn.k_ln.weight")) if cfg.attn_qk_ln else None
-            L["wo"] = self._packed(g(m + "attn.out_proj.weight"))
-            L["ln2w"] = self._f32(g(m + ln2 + ".weight"))
-            L["ln2b"] = self._f32(sd[m + ln2 + ".bias"]) if (m + ln2 + ".bias") in sd else None
-            L["wup"] = self._packed(g(m + up + ".weight"))
-            L["wdown"] = self._packed(g(m + down + ".weight"))
-            self.llm_layers.append(L)
-        # K/V projections of the media tokens for ALL x-attn layers in one GEMM (media is layer-invariant)
-        self.n_xattn = len(kv_rows)
-        self.xinner = cfg.xattn_heads * cfg.xattn_dim_head
-        self.wkv_all = self._bf(torch.cat(kv_rows, dim=0)) if kv_rows else None
-        # ---- head ----
-        self.head = self._load_head(sd, "extra_exit.")
+        """Every tensor of the reference state dict the model knows is uploaded and handed to ``deer_model_load_tensor``,
+        which converts / re-lays it out on the device (bf16, MFMA-fragment packing, stacking: csrc/model.hip)."""
+        st = _cur_stream()
+        for name, t in sd.items():
+            if not self.lib.deer_model_knows_tensor(self._h, name.encode()):
+                continue
+            t = t.detach()
+            is_bf = t.dtype == torch.bfloat16
+            src = t.to(device=self.dev, dtype=torch.bfloat16 if is_bf else torch.float32).contiguous()
+            abi.check(self.lib.deer_model_load_tensor(self._h, name.encode(), abi.ptr(src), 1 if is_bf else 0, src.numel(), st),
+                      f"deer_model_load_tensor({name}, shape {tuple(t.shape)})")
+            torch.cuda.current_stream().synchronize()            # src may be freed once the conversion ran
+        buf = ctypes.create_string_buffer(4096)
+        n = self.lib.deer_model_missing_tensors(self._h, buf, len(buf))
+        if n:
+            raise abi.DeerHipError(f"{n} required parameters missing from the state dict, e.g. {buf.value.decode().split()[:4]}")
 
-    def _load_head(self, sd, p):
-        cfg = self.cfg
-        H = {"lstm": [], "fc": []}
-        for l in range(cfg.lstm_num_layers):
-            if cfg.lstm_layernorm:
-                r, sfx = f"{p}rnn.layers.{3 * l}.", "_l0"
-            else:
-                r, sfx = f"{p}rnn.", f"_l{l}"
-            d = dict(wih=self._bf(sd[r + "weight_ih" + sfx]), whh=self._bf(sd[r + "weight_hh" + sfx]),
-                     bih=self._f32(sd[r + "bias_ih" + sfx]), bhh=self._f32(sd[r + "bias_hh" + sfx]))
-            if cfg.lstm_layernorm:
-                d["lnw"] = self._f32(sd[f"{p}rnn.layers.{3 * l + 1}.weight"])
-                d["lnb"] = self._f32(sd[f"{p}rnn.layers.{3 * l + 1}.bias"])
-            H["lstm"].append(d)
-        lin, ln, out = mlp_layer_indices(cfg.mlp_num_hidden_layers)
-        for li, ni in zip(lin, ln):
-            d = {}
-            for gi, hname in enumerate(("actions", "gripper")):
-                d[f"w{gi}"] = self._bf(sd[f"{p}{hname}.mlp.{li}.weight"])
-                d[f"b{gi}"] = self._f32(sd[f"{p}{hname}.mlp.{li}.bias"])
-                if cfg.mlp_layernorm:
-                    d[f"lnw{gi}"] = self._f32(sd[f"{p}{hname}.mlp.{ni}.weight"])
-                    d[f"lnb{gi}"] = self._f32(sd[f"{p}{hname}.mlp.{ni}.bias"])
-            H["fc"].append(d)
-        H["wa"], H["ba"] = self._bf(sd[f"{p}actions.mlp.{out}.weight"]), self._f32(sd[f"{p}actions.mlp.{out}.bias"])
-        H["wg"], H["bg"] = self._bf(sd[f"{p}gripper.mlp.{out}.weight"]), self._f32(sd[f"{p}gripper.mlp.{out}.bias"])
-        return H
+    def _buf(self, name: str, which: int = 1):
+        off, nbytes = ctypes.c_long(), ctypes.c_long()
+        abi.check(self.lib.deer_model_buffer(self._h, which, name.encode(), ctypes.byref(off), ctypes.byref(nbytes)), f"buffer {name}")
+        base = self.workspace if which == 1 else self.arena
+        return base[off.value: off.value + nbytes.value]
 
-    # ---------------------------------------------------------------------------------------- workspace
-    def _vision_ws(self, n, img=None, vis_x=None, vis_x_f32=None, splits=None):
-        """Activation buffers of the vision tower for n camera frames (SimpleNamespace; see enqueue_vision)."""
-        cfg, dev = self.cfg, self.dev
-        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
-        bf = torch.bfloat16
-        P, W, S = cfg.n_patches, cfg.vit_width, cfg.image_size
-        nl, inner, Lp = cfg.perc_latents, cfg.perc_heads * cfg.perc_dim_head, cfg.perc_depth
-        R = n * (P + 1)
-        ws = SimpleNamespace(n=n)
-        ws.img = z(n, 3, S, S, dt=bf) if img is None else img     # static input buffer (camera frames batched)
-        ws.im2col = z(n * P, self.patch_kpad, dt=bf)
-        ws.patch_out = z(n * P, W)
-        ws.vx = z(n, P + 1, W)                                    # ViT residual stream (fp32)
-        ws.v_ln = z(R, W, dt=bf)
-        ws.v_qkv = z(R, 3 * W, dt=bf)
-        ws.v_ao = z(R, W, dt=bf)
-        ws.v_h = z(R, cfg.vit_mlp, dt=bf)
-        # split-K factors of the residual projections (measured on MI355X, tools/bench_gemm.py; DEER_VIT_SPLIT overrides)
-        ws.vit_split = (_pick_split(R, W, W), _pick_split(R, W, cfg.vit_mlp))
-        ws.perc_split = (_pick_split(n * nl, W, inner), _pick_split(n * nl, W, cfg.perc_ff_mult * W))
-        ov = os.environ.get("DEER_VIT_SPLIT")
-        if ov:
-            v = [int(t) for t in ov.split(",")]
-            ws.vit_split, ws.perc_split = (v[0], v[1]), (v[2], v[3])
-        if splits is not None:                                    # same summation order as the batched schedule: results of
-            ws.vit_split, ws.perc_split = splits.vit_split, splits.perc_split   # all schedules are bit-identical
-        ws.v_slab = z(max(max(ws.vit_split) * R, max(ws.perc_split) * n * nl) * W)
-        ws.p_lat = z(n, nl, W)
-        ws.p_mln = z(Lp, n * P, W, dt=bf)                         # norm_media_l(x) for every layer l
-        ws.p_mkv = z(Lp, n * P, 2 * inner, dt=bf)                 # to_kv_l of it: media K | V of every layer
-        ws.p_latln = z(n * nl, W, dt=bf)                          # norm_latents(latents) of the current layer
-        ws.p_qkv = z(n * nl, 3 * inner, dt=bf)                    # q | k | v of the latents
-        ws.p_ao = z(n * nl, inner, dt=bf)
-        ws.p_ln = z(n * nl, W, dt=bf)
-        ws.p_h = z(n * nl, cfg.perc_ff_mult * W, dt=bf)
-        ws.vis_x = z(n * nl, W, dt=bf) if vis_x is None else vis_x            # media tokens [rgb latents ; gripper latents]
-        ws.vis_x_f32 = z(n * nl, W) if vis_x_f32 is None else vis_x_f32
-        return ws
-
-    def _alloc_workspace(self):
-        cfg, dev = self.cfg, self.dev
-        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
-        bf = torch.bfloat16
-        N, P, W, S = self.n_cams, cfg.n_patches, cfg.vit_width, cfg.image_size
-        nl, inner = cfg.perc_latents, cfg.perc_heads * cfg.perc_dim_head
-        # vision workspace: one set for all camera frames batched (single-stream schedules), and one PRIVATE set per chain of
-        # the two-stream schedule (the camera frames are independent until the media tokens are concatenated; chains share
-        # only the input frames and the media-token output, as row ranges)
-        self.vws = self._vision_ws(N)
-        self.img, self.vx, self.vis_x, self.vis_x_f32 = self.vws.img, self.vws.vx, self.vws.vis_x, self.vws.vis_x_f32
-        self.vchains = []
-        n_ch = max(1, min(N, int(os.environ.get("DEER_CHAINS", "2"))))
-        per = (N + n_ch - 1) // n_ch
-        for c in range(n_ch):
-            lo, hi = c * per, min(N, (c + 1) * per)
-            self.vchains.append(self._vision_ws(hi - lo, img=self.img[lo:hi], vis_x=self.vis_x[lo * nl: hi * nl],
-                                                vis_x_f32=self.vis_x_f32[lo * nl: hi * nl], splits=self.vws))
-        self.kv_all = z(N * nl, max(self.n_xattn, 1) * 2 * self.xinner, dt=bf)
-        d = cfg.d_model
-        T = min(self.B * self.max_T, 64)                     # LLM rows = n_envs * text length
-        self.max_rows = T
-        self.ids = torch.zeros(T, dtype=torch.int64, device=dev)
-        self.key_mask = torch.ones(T, dtype=torch.uint8, device=dev)
-        self.text_time = torch.zeros(T, dtype=torch.int32, device=dev)
-        self.x = z(T, d)
-        self.xn = z(T, d)                                   # LN(x), fp32 (split into bf16 hi+lo inside the GEMM)
-        self.ao = z(T, max(d, self.xinner))                 # attention outputs, fp32
-        max_n = max(cfg.mlp_ratio * d, cfg.xattn_ff_mult * d, 3 * d)
-        self.max_split = 32
-        self.slab_a = z(self.max_split * 64 * d)             # outputs of width d (residual branches)
-        self.slab_b = z(16 * 64 * max_n)                     # outputs of width 3d / 4d / inner
-        self.qkv_ws = z(T, 3 * d)                            # reduced (+ q/k-normalised) qkv of the MPT attention
-        self.hidden = z(cfg.n_layers, T, d)                  # hidden_states[i] = output of layer i
-        Lh, H, B = cfg.lstm_num_layers, cfg.head_hidden, self.B
-        self.h_state, self.c_state = z(Lh, B, H), z(Lh, B, H)     # LSTM state of every environment: [layer][env][H]
-        self.h_tmp, self.c_tmp = z(Lh, B, H), z(Lh, B, H)
-        self.h_shadow, self.c_shadow = z(Lh, B, H), z(Lh, B, H)   # commit target in shadow (calibration) mode
-        dims = cfg.mlp_hidden_dims
-        self.z_fc = [z(B, 2 * dm) for dm in dims]
-        self.pooled = z(B, d)                                     # max/avg-pooled features of the current head evaluation
-        self.ctl = torch.zeros(B * abi.CTL_WORDS, dtype=torch.int32, device=dev)   # one control block per environment
+    def _make_views(self):
+        cfg, B = self.cfg, self.B
+        N, S, W, nl, d = self.n_cams, cfg.image_size, cfg.vit_width, cfg.perc_latents, cfg.d_model
+        rows = min(B * self.max_T, 128)
+        self.max_rows = rows
+        v = lambda name, dt: self._buf(name).view(dt)
+        self.img = v("img", torch.bfloat16).view(N, 3, S, S)               # static input buffer (camera frames batched)
+        self.vx = v("vx", torch.float32).view(N, cfg.n_patches + 1, W)     # ViT residual stream (fp32)
+        self.vis_x = v("vis_x", torch.bfloat16).view(N * nl, W)            # media tokens [rgb latents ; gripper latents] per env
+        self.vis_x_f32 = v("vis_x_f32", torch.float32).view(N * nl, W)
+        self.kv_all = v("kv_all", torch.bfloat16)
+        self.ids = v("ids", torch.int64)
+        self.key_mask = v("key_mask", torch.uint8)
+        self.key_mask.fill_(1)
+        self.text_time = v("text_time", torch.int32)
+        self.x = v("x", torch.float32).view(rows, d)
+        self.hidden = v("hidden", torch.float32).view(cfg.n_layers, rows, d)   # hidden_states[i] = output of layer i
+        Lh, H = cfg.lstm_num_layers, cfg.head_hidden
+        for n in ("h_state", "c_state", "h_tmp", "c_tmp", "h_shadow", "c_shadow"):   # LSTM state: [layer][env][H]
+            setattr(self, n, v(n, torch.float32).view(Lh, B, H))
+        self.pooled = v("pooled", torch.float32).view(B, d)
+        self.ctl = v("ctl", torch.int32)                                   # one control block per environment
+        self.hold_dev = v("step_info", torch.int32)                        # step_info: {hold, seq, host mirror ptr lo, hi}
+        self.thresholds = v("thresholds", torch.float32)
+        self.thresholds.fill_(1e8)
+        self.action_dbg = v("action_dbg", torch.float32).view(B, 8)
+        self.wte = self._buf("lang_encoder.transformer.wte.weight", 0).view(torch.bfloat16).view(cfg.vocab_size, d)
         self.ctl_host = torch.zeros(B * abi.CTL_WORDS, dtype=torch.int32).pin_memory()
         self._ctl_host_np = self.ctl_host.numpy()
-        self.hold_dev = torch.zeros(4, dtype=torch.int32, device=dev)      # step_info: {hold, seq, host mirror ptr lo, hi}
         self.step_info_host = torch.zeros(8, 4, dtype=torch.int32).pin_memory()   # ring: an async upload may still be pending
         # host mirror of the verdicts (pinned => device-visible and system-coherent): see csrc/head.hip::check_done
         self.host_mirror = torch.zeros((1 + B) * abi.CTL_WORDS, dtype=torch.int32).pin_memory()
@@ -340,266 +193,83 @@ class DeerEngine:
         self._si_np = self.step_info_pinned.numpy()
         mptr = self.host_mirror.data_ptr()
         self._si_np[2], self._si_np[3] = _i32(mptr & 0xFFFFFFFF), _i32(mptr >> 32)
-        self.thresholds = torch.full((16,), 1e8, dtype=torch.float32, device=dev)
-        self.action_dbg = z(B, 8)
 
-    # ------------------------------------------------------------------------------------- small helpers
-    @contextmanager
-    def _rec(self, name, flops=0.0, nbytes=0.0):
-        """Attach algorithmic flops / bytes to the next launch (consumed by the profiling proxy, if active)."""
-        self._cost = (float(flops), float(nbytes))
-        yield
-        self._cost = (0.0, 0.0)
-
-    def _gemm(self, A, W, C, M, N, K, epi, bias=None, gate=None, lda=None, ldc=None, batch=1, strideA=0, strideC=0,
-              tile=0, a_off=0, c_off=0):
-        lda = K if lda is None else lda
-        ldc = N if ldc is None else ldc
-        out_b = 4 if epi in (abi.EPI_F32, abi.EPI_RESADD_F32) else 2
-        with self._rec("gemm_tiled", 2.0 * M * N * K * batch, 2.0 * (M * K * batch + N * K) + out_b * M * N * batch):
-            abi.check(self.lib.deer_gemm_bf16_nt(abi.ptr(A, a_off), lda, strideA, abi.ptr(W), K, abi.ptr(bias), abi.ptr(C, c_off),
-                                                 ldc, strideC, M, N, K, batch, epi, abi.ptr(gate), tile, None, _cur_stream()),
-                      "deer_gemm_bf16_nt")
-
-    def _gemm_splitk(self, A, W, slab, M, N, K, S, tile=0):
-        assert S * M * N <= slab.numel(), (S, M, N, slab.numel())
-        with self._rec("gemm_tiled", 2.0 * M * N * K, 2.0 * (M * K + N * K) + 4.0 * S * M * N):
-            abi.check(self.lib.deer_gemm_bf16_nt_splitk(abi.ptr(A), K, abi.ptr(W), K, abi.ptr(slab), M, N, K, S, tile, None,
-                                                        _cur_stream()), "deer_gemm_bf16_nt_splitk")
-
-    def _vresadd(self, x, slab, S, rows, C, bias=None, gamma=None, beta=None, out_bf=None, out_f32=None):
-        """x += sum_s slab[s] + bias, then (optionally) LayerNorm -> bf16: closes a split-K projection of the vision tower."""
-        abi.check(self.lib.deer_resadd_ln(abi.ptr(x), abi.ptr(slab), S, rows * C, None, abi.ptr(bias), abi.ptr(gamma), abi.ptr(beta),
-                                          abi.ptr(out_bf) if gamma is not None else None,
-                                          abi.ptr(out_f32) if gamma is not None else None, None, rows, C, EPS, None,
-                                          _cur_stream()), "deer_resadd_ln")
-
-    def _ln(self, x, gamma, beta, out_bf, rows, C, in_rstride=None, in_bstride=0, batch=1, out_rstride=None, out_bstride=0,
-            x_off=0, out_off=0, out_f32=None):
-        in_rstride = C if in_rstride is None else in_rstride
-        out_rstride = C if out_rstride is None else out_rstride
-        with self._rec("layernorm_rows", 8.0 * rows * batch * C, 6.0 * rows * batch * C):
-            abi.check(self.lib.deer_layernorm_rows(abi.ptr(x, x_off), in_rstride, in_bstride, rows, batch, abi.ptr(gamma), abi.ptr(beta),
-                                                   abi.ptr(out_bf, out_off), abi.ptr(out_f32), out_rstride, out_bstride, C, EPS,
-                                                   _cur_stream()), "deer_layernorm_rows")
-
-    # ------------------------------------------------------------------------------------------ vision
-    VIT_HEAD_LAYERS = 3      # ViT blocks in the first graph piece of a step (short to submit; see _step_segmented)
-
-    def enqueue_vision(self, part: str = "all", ws=None, kv_all: bool = True):
-        """ViT-L/14 on both camera frames (batched, the reference runs them separately: flamingo_mpt.py:626,633),
-        Perceiver on each, concat -> vis_x, then K/V of every x-attn layer.
-        part: "all", or "head" (patch embedding + the first VIT_HEAD_LAYERS blocks) / "tail" (the rest)."""
-        cfg, lib, st = self.cfg, self.lib, _cur_stream()
-        ws = self.vws if ws is None else ws
-        N, P, W = ws.n, cfg.n_patches, cfg.vit_width
-        R = N * (P + 1)
-        n_head = min(self.VIT_HEAD_LAYERS, len(self.vit_layers) - 1)
-        lo, hi = {"all": (0, len(self.vit_layers)), "head": (0, n_head), "tail": (n_head, len(self.vit_layers))}[part]
-        if part != "tail":
-            self._enqueue_patch_embed(ws)
-        H = cfg.vit_heads
-        tok = P + 1
-        So, Sp = ws.vit_split
-        for li in range(lo, hi):
-            L = self.vit_layers[li]
-            nxt = self.vit_layers[li + 1] if li + 1 < len(self.vit_layers) else None
-            self._gemm(ws.v_ln, L["wqkv"], ws.v_qkv, R, 3 * W, W, abi.EPI_BF16, bias=L["bqkv"])
-            abi.check(lib.deer_attn_mfma_hd64(abi.ptr(ws.v_qkv), abi.ptr(ws.v_qkv, 2 * W), abi.ptr(ws.v_qkv, 4 * W),
-                                              abi.ptr(ws.v_ao), N, H, tok, tok, 3 * W, 3 * W, 3 * W, W, tok * 3 * W, tok * 3 * W,
-                                              tok * 3 * W, tok * W, 64 ** -0.5, st), "vit attn")
-            self._gemm_splitk(ws.v_ao, L["wo"], ws.v_slab, R, W, W, So)
-            self._vresadd(ws.vx, ws.v_slab, So, R, W, bias=L["bo"], gamma=L["ln2w"], beta=L["ln2b"], out_bf=ws.v_ln)
-            self._gemm(ws.v_ln, L["wfc"], ws.v_h, R, cfg.vit_mlp, W, abi.EPI_QGELU_BF16, bias=L["bfc"])
-            self._gemm_splitk(ws.v_h, L["wpr"], ws.v_slab, R, W, cfg.vit_mlp, Sp)
-            if nxt is not None:
-                self._vresadd(ws.vx, ws.v_slab, Sp, R, W, bias=L["bpr"], gamma=nxt["ln1w"], beta=nxt["ln1b"], out_bf=ws.v_ln)
-            else:
-                self._vresadd(ws.vx, ws.v_slab, Sp, R, W, bias=L["bpr"])
-        if part != "head":
-            self._enqueue_perceiver(ws)
-            if kv_all:
-                self._enqueue_media_kv()
-
-    def _enqueue_patch_embed(self, ws):
-        """conv1 as im2col + GEMM, class/positional embedding + ln_pre, ln_1 of the first block."""
-        cfg, lib, st = self.cfg, self.lib, _cur_stream()
-        N, P, W = ws.n, cfg.n_patches, cfg.vit_width
-        R = N * (P + 1)
-        abi.check(lib.deer_vit_im2col(abi.ptr(ws.img), 1, N, cfg.image_size, cfg.patch_size, abi.ptr(ws.im2col),
-                                      self.patch_kpad, st), "im2col")
-        self._gemm(ws.im2col, self.vit["conv"], ws.patch_out, N * P, W, self.patch_kpad, abi.EPI_F32)
-        abi.check(lib.deer_vit_embed_lnpre(abi.ptr(ws.patch_out), abi.ptr(self.vit["cls"]), abi.ptr(self.vit["pos"]),
-                                           abi.ptr(self.vit["ln_pre_w"]), abi.ptr(self.vit["ln_pre_b"]), abi.ptr(ws.vx), N, P, W,
-                                           EPS, st), "vit_embed")
-        # c_proj / out_proj run split-K (few output tiles, long K) into f32 slabs; the slab reduction, bias, residual add
-        # and the NEXT LayerNorm are one launch (deer_resadd_ln), so a block is 7 launches and no projection leaves CUs idle.
-        self._ln(ws.vx, self.vit_layers[0]["ln1w"], self.vit_layers[0]["ln1b"], ws.v_ln, R, W)
-
-    def _enqueue_perceiver(self, ws):
-        cfg, lib, st = self.cfg, self.lib, _cur_stream()
-        N, P, W = ws.n, cfg.n_patches, cfg.vit_width
-        tok = P + 1
-        # ---- Perceiver (helpers.py:107-132) on the patch tokens x[:, 1:] of each camera ----
-        # Media side once for all layers: one LayerNorm pass with every layer's norm_media affine, one batched GEMM with every
-        # layer's to_kv.  Per layer only the 64 latents move: q|k|v projection, attention over [media K/V ; latent K/V] (two
-        # segments, helpers.py:51 without the concat), to_out and the FF - each residual projection split-K, closed by the
-        # reducer that also applies the NEXT LayerNorm (7 launches per layer).
-        nl, inner, Lp = cfg.perc_latents, cfg.perc_heads * cfg.perc_dim_head, cfg.perc_depth
-        abi.check(lib.deer_broadcast_rows(abi.ptr(self.perc["latents"]), abi.ptr(ws.p_lat), nl * W, N, st), "latents")
-        with self._rec("layernorm_rows", 8.0 * N * P * W, (4.0 + 2.0 * Lp) * N * P * W):
-            abi.check(lib.deer_layernorm_rows_multi(abi.ptr(ws.vx, W * 4), W, tok * W, P, N, abi.ptr(self.perc_nm_w),
-                                                    abi.ptr(self.perc_nm_b), Lp, W, abi.ptr(ws.p_mln), N * P * W, W, P * W, W,
-                                                    EPS, st), "norm_media (all layers)")
-        with self._rec("gemm_tiled", 2.0 * Lp * N * P * 2 * inner * W, 2.0 * Lp * (N * P * W + 2 * inner * W + N * P * 2 * inner)):
-            abi.check(lib.deer_gemm_bf16_nt_wbatch(abi.ptr(ws.p_mln), W, N * P * W, abi.ptr(self.perc_wkv_all), W, 2 * inner * W,
-                                                   None, abi.ptr(ws.p_mkv), 2 * inner, N * P * 2 * inner, N * P, 2 * inner, W, Lp,
-                                                   abi.EPI_BF16, 0, None, st), "to_kv (all layers)")
-        self._ln(ws.p_lat, self.perc_layers[0]["nlw"], self.perc_layers[0]["nlb"], ws.p_latln, N * nl, W)
-        Pa, Pf = ws.perc_split
-        for li, L in enumerate(self.perc_layers):
-            self._gemm(ws.p_latln, L["wqkv"], ws.p_qkv, N * nl, 3 * inner, W, abi.EPI_BF16)
-            mkv = li * N * P * 2 * inner * 2                   # byte offset of this layer's media K | V
-            abi.check(lib.deer_attn_mfma_hd64_2seg(abi.ptr(ws.p_qkv), abi.ptr(ws.p_mkv, mkv), abi.ptr(ws.p_mkv, mkv + inner * 2),
-                                                   abi.ptr(ws.p_qkv, inner * 2), abi.ptr(ws.p_qkv, 2 * inner * 2), abi.ptr(ws.p_ao),
-                                                   N, cfg.perc_heads, nl, P, nl, 3 * inner, 2 * inner, 3 * inner, inner,
-                                                   nl * 3 * inner, P * 2 * inner, nl * 3 * inner, nl * inner,
-                                                   cfg.perc_dim_head ** -0.5, st), "perc attn")
-            self._gemm_splitk(ws.p_ao, L["wo"], ws.v_slab, N * nl, W, inner, Pa)
-            self._vresadd(ws.p_lat, ws.v_slab, Pa, N * nl, W, gamma=L["fnw"], beta=L["fnb"], out_bf=ws.p_ln)
-            self._gemm(ws.p_ln, L["w1"], ws.p_h, N * nl, cfg.perc_ff_mult * W, W, abi.EPI_GELU_BF16)
-            self._gemm_splitk(ws.p_h, L["w2"], ws.v_slab, N * nl, W, cfg.perc_ff_mult * W, Pf)
-            if li + 1 < Lp:
-                nx = self.perc_layers[li + 1]
-                self._vresadd(ws.p_lat, ws.v_slab, Pf, N * nl, W, gamma=nx["nlw"], beta=nx["nlb"], out_bf=ws.p_latln)
-            else:                                              # closing perceiver.norm -> media tokens (bf16 for K/V, f32 kept)
-                self._vresadd(ws.p_lat, ws.v_slab, Pf, N * nl, W, gamma=self.perc["normw"], beta=self.perc["normb"],
-                              out_bf=ws.vis_x, out_f32=ws.vis_x_f32)
+    # ----------------------------------------------------------------------------- pieces (thin calls into the spine)
+    def enqueue_vision(self, part: str = "all", chain: int = -1, kv_all: bool = True):
+        """ViT-L/14 on the camera frames (batched; the reference runs them separately: flamingo_mpt.py:626,633), Perceiver on
+        each, concat -> vis_x, then K/V of every x-attn layer.  part: "all" | "head" | "tail"; chain >= 0: one chain of the
+        multi-stream schedule."""
+        abi.check(self.lib.deer_vision(self._h, chain, {"all": 0, "head": 1, "tail": 2}[part], 1 if kv_all else 0, _cur_stream()),
+                  "deer_vision")
 
     def _enqueue_media_kv(self):
-        """K | V of every gated x-attn layer from the media tokens of ALL frames, one GEMM (helpers.py:196-197)."""
-        cfg = self.cfg
-        if self.n_xattn:
-            self._gemm(self.vis_x, self.wkv_all, self.kv_all, self.n_cams * cfg.perc_latents, self.n_xattn * 2 * self.xinner,
-                       cfg.vit_width, abi.EPI_BF16)
-
-    # --------------------------------------------------------------------------------------------- LLM
-    def _skinny(self, Wp, N, K, T, out_slab, A=None, a_slab=None, s_in=0, a_mode=abi.A_F32, lda=None, ctl=True):
-        S = self.lib.deer_skinny_splitk(T, N, K)
-        mpad = 16 if T <= 16 else (32 if T <= 32 else 64)
-        assert S * mpad * N <= out_slab.numel(), (S, mpad, N, out_slab.numel())
-        with self._rec("gemm_skinny", 2.0 * T * N * K, 2.0 * N * K):      # algorithmic bytes = the bf16 weights, once
-            abi.check(self.lib.deer_gemm_skinny(abi.ptr(A), (K if lda is None else lda), abi.ptr(a_slab), s_in,
-                                                mpad * K, a_mode, abi.ptr(Wp), abi.ptr(out_slab), T, N, K, S,
-                                                abi.ptr(self.ctl) if ctl else None, _cur_stream()), "deer_gemm_skinny")
-        return S, mpad * N
-
-    def _resadd(self, T, pending, gamma=None, beta=None, x_copy=None, ctl=True):
-        slab, S, stride, gate = pending if pending is not None else (None, 0, 0, None)
-        abi.check(self.lib.deer_resadd_ln(abi.ptr(self.x), abi.ptr(slab), S, stride, abi.ptr(gate), None, abi.ptr(gamma), abi.ptr(beta),
-                                          None, abi.ptr(self.xn) if gamma is not None else None, abi.ptr(x_copy), T, self.cfg.d_model, EPS,
-                                          abi.ptr(self.ctl) if ctl else None, _cur_stream()), "deer_resadd_ln")
+        abi.check(self.lib.deer_media_kv(self._h, _cur_stream()), "deer_media_kv")
 
     def enqueue_embed(self, T):
-        cfg = self.cfg
-        abi.check(self.lib.deer_embed_tokens(abi.ptr(self.ids), abi.ptr(self.wte), abi.ptr(self.x), abi.ptr(self.text_time), T,
-                                             self.B, cfg.d_model, cfg.vocab_size, cfg.media_token_id, _cur_stream()), "embed_tokens")
+        abi.check(self.lib.deer_llm_embed(self._h, T, _cur_stream()), "deer_llm_embed")
 
     def enqueue_llm_layer(self, i, T, pending, use_mask: bool, finalize: bool, ctl=True):
-        """FlamingoLayer.forward (flamingo_lm.py:46-83): gated x-attn (helpers.py:260-279) then the MPT block
-         on R = n_envs*T rows.  ``pending`` = not-yet-applied residual branch of the previous op
-        (split-K slabs + gate)."""
-        cfg, L, st = self.cfg, self.llm_layers[i], _cur_stream()
-        d, B = cfg.d_model, self.B
-        R = B * T
-        c = abi.ptr(self.ctl) if ctl else None
-        if "xa" in L:
-            X = L["xa"]
-            self._resadd(R, pending, X["nw"], X["nb"], ctl=ctl)
-            S, stride = self._skinny(X["wq"], self.xinner, d, R, self.slab_b, A=self.xn, ctl=ctl)
-            kv_off = X["kv_index"] * 2 * self.xinner * 2          # bytes into a kv_all row
-            abi.check(self.lib.deer_xattn_mfma(abi.ptr(self.slab_b), S, stride, self.xinner, abi.ptr(self.kv_all, kv_off),
-                                                self.n_xattn * 2 * self.xinner, self.xinner, abi.ptr(self.text_time),
-                                                cfg.n_media, abi.ptr(self.ao), 1, self.xinner, T, cfg.n_media,
-                                                cfg.xattn_heads, B, cfg.xattn_dim_head ** -0.5, c, st), "deer_xattn_mfma")
-            S, stride = self._skinny(X["wo"], d, self.xinner, R, self.slab_a, A=self.ao, lda=self.xinner, ctl=ctl)
-            self._resadd(R, (self.slab_a, S, stride, X["ag"]), X["fnw"], X["fnb"], ctl=ctl)
-            S, stride = self._skinny(X["w1"], cfg.xattn_ff_mult * d, d, R, self.slab_b, A=self.xn, ctl=ctl)
-            S, stride = self._skinny(X["w2"], d, cfg.xattn_ff_mult * d, R, self.slab_a, a_slab=self.slab_b, s_in=S,
-                                     a_mode=abi.A_SLABS_GELU, ctl=ctl)
-            pending = (self.slab_a, S, stride, X["fg"])
-        self._resadd(R, pending, L["ln1w"], L["ln1b"], ctl=ctl)
-        S, stride = self._skinny(L["wqkv"], 3 * d, d, R, self.slab_b, A=self.xn, ctl=ctl)
-        abi.check(self.lib.deer_mpt_attn_small(abi.ptr(self.slab_b), S, stride, d, cfg.n_heads, abi.ptr(L["qlnw"]), abi.ptr(L["klnw"]),
-                                               EPS, abi.ptr(self.key_mask) if use_mask else None, float(cfg.alibi_bias_max),
-                                               abi.ptr(self.qkv_ws), abi.ptr(self.ao), 1, d, T, B, c, st), "deer_mpt_attn_small")
-        S, stride = self._skinny(L["wo"], d, d, R, self.slab_a, A=self.ao, lda=d, ctl=ctl)
-        self._resadd(R, (self.slab_a, S, stride, None), L["ln2w"], L["ln2b"], ctl=ctl)
-        S, stride = self._skinny(L["wup"], cfg.mlp_ratio * d, d, R, self.slab_b, A=self.xn, ctl=ctl)
-        S, stride = self._skinny(L["wdown"], d, cfg.mlp_ratio * d, R, self.slab_a, a_slab=self.slab_b, s_in=S,
-                                 a_mode=abi.A_SLABS_GELU, ctl=ctl)
-        pending = (self.slab_a, S, stride, None)
-        if finalize:                                            # hidden_states[i] = output of layer i (mosaic_gpt_3b.py:424-427)
-            self._resadd(R, pending, None, None, x_copy=self.hidden[i], ctl=ctl)
-            pending = None
-        return pending
+        """FlamingoLayer.forward (flamingo_lm.py:46-83) on n_envs*T rows.  ``pending``: truthy when the previous layer left
+        its last residual branch un-applied (it was not finalized); returns the same marker for this layer."""
+        abi.check(self.lib.deer_llm_layer(self._h, i, T, 1 if use_mask else 0, 1 if pending else 0, 1 if finalize else 0,
+                                          1 if ctl else 0, _cur_stream()), "deer_llm_layer")
+        return None if finalize else True
 
-    # -------------------------------------------------------------------------------------------- head
     def enqueue_head(self, layer: int, T: int, kind: int, slot: int = -1, force: bool = False, use_ctl: bool = True,
-                     feats: Optional[torch.Tensor] = None, h_prev=None, c_prev=None, shadow: bool = False,
-                     no_ctl_final: bool = False):
-        """One DeterministicDecoder evaluation on hidden_states[layer] (action_head.py:499-611) followed by the
-        exit gate (value_net.py:120-133,277-297).  kind: PSEUDO (prev action from layer i-1, value_net.py:122-125),
-        CHECK (delta <= threshold -> exit + commit LSTM state), COMMIT (static exit_id / committing call)."""
-        cfg, Hd, lib, st = self.cfg, self.head, self.lib, _cur_stream()
-        c = abi.ptr(self.ctl) if use_ctl else None
-        H, d, B = cfg.head_hidden, cfg.d_model, self.B
-        feats = self.hidden[layer] if feats is None else feats      # [B*T, d]: environment b owns rows b*T .. b*T+T-1
-        h_prev = self.h_state if h_prev is None else h_prev
-        c_prev = self.c_state if c_prev is None else c_prev
-        abi.check(lib.deer_head_pool(abi.ptr(feats), abi.ptr(self.pooled), T, d, 0 if cfg.pooling == "max" else 1, B, c, kind, layer, st),
-                  "deer_head_pool")
-        for l, Lw in enumerate(Hd["lstm"]):
-            if l == 0:
-                src, bstride, mode, in_dim, lnw, lnb = self.pooled, d, abi.X_RAW, d, None, None
-            else:
-                prev = Hd["lstm"][l - 1]
-                src, bstride, in_dim = self.h_tmp[l - 1], H, H
-                mode, lnw, lnb = (abi.X_LN, prev["lnw"], prev["lnb"]) if cfg.lstm_layernorm else (abi.X_RAW, None, None)
-            abi.check(lib.deer_head_lstm_layer(abi.ptr(src), bstride, mode, T, in_dim, abi.ptr(lnw), abi.ptr(lnb), abi.ptr(Lw["wih"]),
-                                               abi.ptr(Lw["whh"]), abi.ptr(Lw["bih"]), abi.ptr(Lw["bhh"]), abi.ptr(h_prev[l]),
-                                               abi.ptr(c_prev[l]), abi.ptr(self.h_tmp[l]), abi.ptr(self.c_tmp[l]), H, B, EPS, c, kind,
-                                               layer, st), "deer_head_lstm_layer")
-        src, in_dim, sstride = self.h_tmp[cfg.lstm_num_layers - 1], H, H
-        last = Hd["lstm"][-1]
-        pro, ln = (abi.PRO_LN, (last["lnw"], last["lnb"], None, None)) if cfg.lstm_layernorm else (abi.PRO_RAW, (None,) * 4)
-        for fi, (Fw, dim) in enumerate(zip(Hd["fc"], cfg.mlp_hidden_dims)):
-            abi.check(lib.deer_head_fc(abi.ptr(src), sstride, in_dim, pro, abi.ptr(ln[0]), abi.ptr(ln[1]), abi.ptr(ln[2]), abi.ptr(ln[3]),
-                                       abi.ptr(Fw["w0"]), abi.ptr(Fw["b0"]), abi.ptr(Fw["w1"]), abi.ptr(Fw["b1"]), dim,
-                                       abi.ptr(self.z_fc[fi]), B, EPS, c, kind, layer, st), "deer_head_fc")
-            src, in_dim, sstride = self.z_fc[fi], dim, 2 * dim
-            if cfg.mlp_layernorm:
-                pro, ln = abi.PRO_GROUP_LN_RELU, (Fw["lnw0"], Fw["lnb0"], Fw["lnw1"], Fw["lnb1"])
-            else:
-                pro, ln = abi.PRO_GROUP_RELU, (None,) * 4
-        abi.check(lib.deer_head_final(abi.ptr(src), sstride, in_dim, pro, abi.ptr(ln[0]), abi.ptr(ln[1]), abi.ptr(ln[2]), abi.ptr(ln[3]),
-                                      abi.ptr(Hd["wa"]), abi.ptr(Hd["ba"]), abi.ptr(Hd["wg"]), abi.ptr(Hd["bg"]),
-                                      None if no_ctl_final else abi.ptr(self.ctl), kind, layer, slot, abi.ptr(self.thresholds),
-                                      1 if force else 0, self.thr_type, self.leq, abi.ptr(self.h_tmp), abi.ptr(self.c_tmp),
-                                      abi.ptr(self.h_shadow if shadow else self.h_state),
-                                      abi.ptr(self.c_shadow if shadow else self.c_state), cfg.lstm_num_layers, H, B,
-                                      abi.ptr(self.action_dbg), EPS, st),
-                  "deer_head_final")
+                     feats: Optional[torch.Tensor] = None, shadow: bool = False, no_ctl_final: bool = False,
+                     use_mask: bool = False):
+        """One DeterministicDecoder evaluation on hidden_states[layer] (action_head.py:499-611) followed by the exit gate
+        (value_net.py:120-133,277-297).  kind: PSEUDO / CHECK / COMMIT (include/deer_hip.h)."""
+        abi.check(self.lib.deer_head_eval(self._h, layer, T, kind, slot, 1 if force else 0, 1 if use_ctl else 0, 1 if shadow else 0,
+                                          1 if no_ctl_final else 0, abi.ptr(feats), 1 if use_mask else 0, _cur_stream()),
+                  "deer_head_eval")
 
     # ------------------------------------------------------------------------------------- step assembly
+    def _apply_controller(self):
+        ids = (ctypes.c_int * len(self.exit_ids))(*self.exit_ids)
+        rc = self.lib.deer_model_configure_exit(self._h, ids, len(self.exit_ids), self._max_layer_arg, self._thr_type, self._leq)
+        if rc != 0:
+            raise ValueError(f"invalid exit configuration: exit ids {self.exit_ids}, max_layer {self._max_layer_arg} -> the deepest "
+                             f"reachable layer {min(self._max_layer_arg - 1, self.exit_ids[-1])} must be one of the exits (otherwise no "
+                             "exit check is ever forced; the reference raises KeyError on thresholds[i] there)")
+
     def configure_exit(self, exit_ids: Sequence[int], max_layer: int, steps_per_stage: int = 1):
         """``ExitController.__init__`` (value_net.py:164-173): max_layer = min(max_layer-1, last exit)."""
+        old = (self.exit_ids, self._max_layer_arg)
         self.exit_ids = list(exit_ids)
+        self._max_layer_arg = max_layer
+        try:
+            self._apply_controller()
+        except ValueError:
+            self.exit_ids, self._max_layer_arg = old
+            raise
         self.ctl_max_layer = min(max_layer - 1, self.exit_ids[-1])
         self.steps_per_stage = steps_per_stage
         if self._graphs:
             torch.cuda.synchronize(self.dev)                      # pieces of the last step may still be replaying
         self._graphs.clear()
+
+    @property
+    def thr_type(self) -> int:
+        return self._thr_type
+
+    @thr_type.setter
+    def thr_type(self, v: int):
+        if v != self._thr_type:
+            self._thr_type = int(v)
+            self._apply_controller()
+            self._graphs.clear()
+
+    @property
+    def leq(self) -> int:
+        return self._leq
+
+    @leq.setter
+    def leq(self, v):
+        if int(bool(v)) != self._leq:
+            self._leq = int(bool(v))
+            self._apply_controller()
+            self._graphs.clear()
 
     @property
     def real_num_exit(self) -> int:
@@ -624,52 +294,37 @@ class DeerEngine:
         self.cur_step = 0
 
     def dynamic_plan(self):
-        """Per layer of the dynamic step: (layer, need_pseudo, is_exit, exit slot).  mosaic_gpt_3b.py:397-443."""
-        cfg, plan = self.cfg, []
-        for i in range(cfg.n_layers):
-            need_pseudo = ((i + 1) in self.exit_ids) and ((i + 1) - cfg.exit_interval < 0) and (i + 1) <= self.ctl_max_layer
-            is_exit = (i in self.exit_ids) and i <= self.ctl_max_layer
-            plan.append((i, need_pseudo, is_exit, self.exit_ids.index(i) if is_exit else -1))
-            if i >= self.ctl_max_layer:
-                break
-        return plan
+        """Per layer of the dynamic step: (layer, need_pseudo, is_exit, exit slot).  mosaic_gpt_3b.py:397-443; computed by
+        the spine (deer_dynamic_plan)."""
+        n = self.cfg.n_layers
+        a, b, c = (ctypes.c_int * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
+        k = self.lib.deer_dynamic_plan(self._h, a, b, c, n)
+        return [(i, bool(a[i]), bool(b[i]), int(c[i])) for i in range(k)]
 
     def enqueue_dynamic_main(self, T, use_mask, i):
         """Trunk part of layer i of the dynamic step (layer 0 also embeds the tokens)."""
-        _, need_pseudo, is_exit, _ = self.dynamic_plan()[i]
+        plan = self.dynamic_plan()
+        _, need_pseudo, is_exit, _ = plan[i]
         if i == 0:
             self.enqueue_embed(T)
-            self._pending = None
-        self._pending = self.enqueue_llm_layer(i, T, self._pending, use_mask, finalize=(need_pseudo or is_exit))
+        prev_open = i > 0 and not (plan[i - 1][1] or plan[i - 1][2])          # previous layer not finalized -> residual pending
+        self.enqueue_llm_layer(i, T, prev_open, use_mask, finalize=(need_pseudo or is_exit))
 
-    def enqueue_dynamic_heads(self, T, i, shadow: bool = False):
+    def enqueue_dynamic_heads(self, T, i, shadow: bool = False, use_mask: bool = False):
         """Head evaluations that read hidden_states[i]: the layer-0 pseudo action and/or the exit check."""
         _, need_pseudo, is_exit, slot = self.dynamic_plan()[i]
+        pm = use_mask and self.B > 1          # rows of an env batch that are right-padding stay out of the token pool
         if need_pseudo:
-            self.enqueue_head(i, T, abi.KIND_PSEUDO)
+            self.enqueue_head(i, T, abi.KIND_PSEUDO, use_mask=pm)
         if is_exit:
-            self.enqueue_head(i, T, abi.KIND_CHECK, slot=slot, force=(i >= self.ctl_max_layer), shadow=shadow)
-
-    def enqueue_llm_dynamic(self, T, use_mask, shadow: bool = False):
-        """MosaicGPT.forward loop with an exit controller (mosaic_gpt_3b.py:397-443), device-predicated, one stream."""
-        for i, need_pseudo, is_exit, _ in self.dynamic_plan():
-            self.enqueue_dynamic_main(T, use_mask, i)
-            if need_pseudo or is_exit:
-                self.enqueue_dynamic_heads(T, i, shadow)
+            self.enqueue_head(i, T, abi.KIND_CHECK, slot=slot, force=(i >= self.ctl_max_layer), shadow=shadow, use_mask=pm)
 
     def enqueue_llm_static(self, T, use_mask, exit_id):
         """exit_id given (flamingo_mpt.py:402-411,446-461): run layers 0..exit_id, committing head call."""
         self.enqueue_embed(T)
-        pending = None
         for i in range(exit_id + 1):
-            pending = self.enqueue_llm_layer(i, T, pending, use_mask, finalize=True, ctl=False)
-        self.enqueue_head(exit_id, T, abi.KIND_COMMIT, use_ctl=False)
-
-    def _enqueue_front(self, part: str = "all", info=None):
-        if part != "tail":
-            info = self.hold_dev if info is None else info
-            abi.check(self.lib.deer_ctl_begin_step(abi.ptr(self.ctl), abi.ptr(info), self.B, _cur_stream()), "ctl_begin_step")
-        self.enqueue_vision(part)
+            self.enqueue_llm_layer(i, T, None, use_mask, finalize=True, ctl=False)
+        self.enqueue_head(exit_id, T, abi.KIND_COMMIT, use_ctl=False, use_mask=use_mask and self.B > 1)
 
     def _drain_side_streams(self):
         cur = torch.cuda.current_stream()
@@ -683,20 +338,37 @@ class DeerEngine:
             self._extra_streams.append(torch.cuda.Stream(device=self.dev))
         return self._extra_streams[c - 2]
 
+    @property
+    def n_chains(self) -> int:
+        return self.lib.deer_model_n_chains(self._h)
+
     def _enqueue_chain(self, c: int, part: str):
         """Vision tower of chain c of the two-stream schedule; chain 0's first piece also resets the control blocks (from
         the pinned step info)."""
         if c == 0 and part == "head":
-            abi.check(self.lib.deer_ctl_begin_step(abi.ptr(self.ctl), abi.ptr(self.step_info_pinned), self.B, _cur_stream()),
-                      "ctl_begin_step")
-        self.enqueue_vision(part, ws=self.vchains[c], kv_all=False)
+            abi.check(self.lib.deer_begin_step(self._h, abi.ptr(self.step_info_pinned), _cur_stream()), "deer_begin_step")
+        self.enqueue_vision(part, chain=c, kv_all=False)
 
     def _enqueue_step(self, T, use_mask, exit_id, shadow: bool = False):
-        self._enqueue_front()
-        if exit_id is None:
-            self.enqueue_llm_dynamic(T, use_mask, shadow)
-        else:
-            self.enqueue_llm_static(T, use_mask, exit_id)
+        """the whole control step on the current stream (vision batched): one call into the spine"""
+        abi.check(self.lib.deer_step_enqueue(self._h, T, 1 if use_mask else 0, -1 if exit_id is None else exit_id, 1 if shadow else 0,
+                                             None, _cur_stream()), "deer_step_enqueue")
+
+    # ----------------------------------------------------------------------------- in-situ profiler (bench.py roofline pass)
+    def prof_begin(self):
+        self.lib.deer_prof_enable(self._h, 1)
+
+    def prof_end(self):
+        """-> list of (kernel class = C-ABI entry point, microseconds, algorithmic flops, algorithmic bytes) per launch"""
+        torch.cuda.synchronize(self.dev)
+        self.lib.deer_prof_enable(self._h, 0)
+        out = []
+        name = ctypes.create_string_buffer(64)
+        us, fl, by = ctypes.c_float(), ctypes.c_double(), ctypes.c_double()
+        for i in range(self.lib.deer_prof_count(self._h)):
+            abi.check(self.lib.deer_prof_get(self._h, i, name, 64, ctypes.byref(us), ctypes.byref(fl), ctypes.byref(by)), "deer_prof_get")
+            out.append((name.value.decode(), us.value, fl.value, by.value))
+        return out
 
     # ---------------------------------------------------------------------------------------- host API
     def load_inputs(self, rgb: torch.Tensor, gripper: torch.Tensor, ids: torch.Tensor, mask: Optional[torch.Tensor] = None):
@@ -792,9 +464,9 @@ class DeerEngine:
                 with torch.cuda.graph(g):
                     fn()
                 return g
-            C = {"chain_head": [cap(lambda c=c: self._enqueue_chain(c, "head")) for c in range(len(self.vchains))],
-                 "chain_tail": [cap(lambda c=c: self._enqueue_chain(c, "tail")) for c in range(len(self.vchains))],
-                 "ev_in": torch.cuda.Event(), "ev_join": [torch.cuda.Event() for _ in self.vchains]}
+            C = {"chain_head": [cap(lambda c=c: self._enqueue_chain(c, "head")) for c in range(self.n_chains)],
+                 "chain_tail": [cap(lambda c=c: self._enqueue_chain(c, "tail")) for c in range(self.n_chains)],
+                 "ev_in": torch.cuda.Event(), "ev_join": [torch.cuda.Event() for _ in range(self.n_chains)]}
             self._graphs["chains"] = C
         return C
 
@@ -802,7 +474,7 @@ class DeerEngine:
         """chain 0 on the main stream, the other chains on the side stream(s) (they start once the inputs are in place);
         the main stream continues after all of them (media tokens complete)."""
         C = self._graphs["chains"]
-        nch = len(self.vchains)
+        nch = self.n_chains
         cst = [main_st] + [side if side is main_st or c == 1 else self._chain_stream(c) for c in range(1, nch)]
         if nch > 1:
             C["ev_in"].record(main_st)
@@ -880,7 +552,7 @@ class DeerEngine:
                 if need_pseudo or is_exit:
                     gh = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gh):
-                        self.enqueue_dynamic_heads(T, i)
+                        self.enqueue_dynamic_heads(T, i, use_mask=use_mask)
                     P["head"][i] = gh
                     P["ev"][i] = torch.cuda.Event()
             self._graphs[key] = P
@@ -1015,21 +687,5 @@ class DeerEngine:
         return out[0] if self.B == 1 else out
 
     def weight_bytes(self) -> int:
-        tot = 0
-        seen = set()
-
-        def walk(o):
-            nonlocal tot
-            if torch.is_tensor(o):
-                if o.data_ptr() not in seen:
-                    seen.add(o.data_ptr())
-                    tot += o.numel() * o.element_size()
-            elif isinstance(o, dict):
-                for v in o.values():
-                    walk(v)
-            elif isinstance(o, (list, tuple)):
-                for v in o:
-                    walk(v)
-        for o in (self.vit, self.vit_layers, self.perc, self.perc_layers, self.wte, self.llm_layers, self.wkv_all, self.head):
-            walk(o)
-        return tot
+        """device bytes of the weight arena (bf16 GEMM operands, f32 norms / biases / gates)"""
+        return int(self.arena.numel())

@@ -259,6 +259,8 @@ class MPTFlamingo(nn.Module):
         ids = input_ids.reshape(-1)
         T = ids.numel()
         e.ids[:T].copy_(ids)
+        e._ids_tag = None                 # the engine's "same instruction tensor as last step" shortcut no longer holds
+        e._shadow_on = False              # ctl is zeroed below (shadow flag included)
         use_mask = False
         if attention_mask is not None:
             m = attention_mask.reshape(-1).to(torch.uint8)
@@ -330,7 +332,10 @@ class MPTFlamingo(nn.Module):
             a = e.ctl.view(torch.float32)[abi.CTL_OUT_ACTION: abi.CTL_OUT_ACTION + 8].clone()
         else:
             a = e.action_dbg[0].clone()
-        hidden = tuple(e.hidden[i, :T].unsqueeze(0) for i in range(exit_layer + 1))
+        # every layer's output up to the exit is real (the spine writes hidden[i] of a non-exit layer with the first row op
+        # of layer i+1); ONE copy, so that the tuple survives the next step overwriting the engine's buffers
+        hs = e.hidden[: exit_layer + 1, :T].clone()
+        hidden = tuple(hs[i].unsqueeze(0) for i in range(exit_layer + 1))
         assert len(hidden) == exit_layer + 1                                                # flamingo_mpt.py:458
         pose, grip = a[:6].view(1, 1, 6), a[6:7].view(1, 1, 1)
         logits = (pose, (grip, a[7:8].view(1, 1, 1))) if with_gripper_logits else (pose, grip)

@@ -100,10 +100,10 @@ int deer_gemm_bf16_nt_wbatch(const void* A, int lda, long strideA, const void* W
 int deer_gemm_bf16_nt_splitk(const void* A, int lda, const void* W, int ldw, float* slab, int M, int N, int K, int splitk,
                              int tile, const int* ctl, void* stream);
 
-/* ---- MFMA GEMM, M <= 32 (weight-streaming): part[ks][Mpad][N] = A[:, Kslice ks] * W[:, Kslice ks]^T -------
+/* ---- MFMA GEMM, M <= 128 (weight-streaming): part[ks][Mpad][N] = A[:, Kslice ks] * W[:, Kslice ks]^T ------
  * Replaces the bias-free nn.Linear calls of the MPT GPTBlock (EXTERNAL; constructed mosaic_gpt_3b.py:104-106,
  * called :413-417) and of GatedCrossAttentionBlock (helpers.py:188,231,15-22) at T<=32 text tokens.
- * Wp = deer_pack_weight_mfma16(W).  Mpad = 16 (M<=16) or 32.  a_mode: DEER_A_BF16 reads A (bf16 [M,lda]);
+ * Wp = deer_pack_weight_mfma16(W).  Mpad = M rounded up to a multiple of 16.  a_mode: DEER_A_BF16 reads A (bf16 [M,lda]);
  * DEER_A_F32 reads A (f32 [M,lda]); DEER_A_SLABS(_GELU) reads sum_s Aslab[s*slab_stride_in + m*K + k] (optionally
  * through exact GELU).  f32 sources are fed to the MFMA as bf16 hi + bf16 lo (two MFMAs per weight fragment; free
  * on this HBM-bound kernel), so the activation keeps ~16 mantissa bits.
@@ -175,8 +175,9 @@ int deer_broadcast_rows(const float* src, float* dst, long n, int batch, void* s
 /* ---- action head + exit gate (robot_flamingo/models/action_head.py:499-611, value_net.py:105-133,277-297) -----
  * All three evaluate a BATCH of B <= 8 independent environments per launch (weights read once): features [B][T][d],
  * LSTM state tensors [L][B][H], control blocks ctl + b*DEER_CTL_WORDS, exit decision per environment. */
-int deer_head_pool(const float* feats, float* pooled, int T, int d, int avg, int B, const int* ctl, int kind, int layer,
-                   void* stream);   /* AdaptiveMax/AvgPool1d over the text tokens (action_head.py:480-483,519-520) */
+int deer_head_pool(const float* feats, float* pooled, int T, int d, int avg, int B, const unsigned char* key_mask, const int* ctl,
+                   int kind, int layer, void* stream);   /* AdaptiveMax/AvgPool1d over the text tokens (action_head.py:480-483,
+                   519-520); key_mask (uint8 [B][T], 0 = right-padding of an env batch, data.py:905-919) or NULL */
 int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w, const float* ln_b,
                          const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh, const float* h_prev,
                          const float* c_prev, float* h_out, float* c_out, int H, int B, float eps, const int* ctl, int kind,

@@ -1,0 +1,111 @@
+/* deer_model.h - the native spine of the DeeR-VLA early-exit forward path on MI355X: a model object that owns the weight
+ * arena layout, the workspace, the device-side exit control blocks and the ORDER in which the gfx950 kernels of
+ * deer_hip.h are enqueued.  C ABI (plain pointers / sizes / hipStream_t as void*, no torch types).
+ *
+ * What it replaces in the reference (paths relative to the reference repo):
+ *   deer_vit_l14_encode      open_clip ViT-L/14 `vision_encoder.visual(x)[1]`          robot_flamingo/models/flamingo_mpt.py:556-583
+ *   deer_perceiver_resample  PerceiverResampler.forward                                open_flamingo/src/helpers.py:107-132
+ *   deer_llm_early_exit      FlamingoLMMixin.forward -> MosaicGPT.forward layer loop   open_flamingo/src/flamingo_lm.py:204-233,
+ *                            with the exit controller + action head at the exits       mosaic_gpt_3b.py:274-449, value_net.py:120-133,
+ *                                                                                      277-297, action_head.py:499-611,
+ *                                                                                      flamingo_mpt.py:443-461
+ * (SURVEY.md §8b "What the HIP extension exports").  The piece-wise entry points below them are what a host uses to feed
+ * the step as graph pieces (deer_vla_amd/engine.py) - same kernels, same order.
+ *
+ * Every function only ENQUEUES on `stream` (graph-capturable; no allocation, no synchronisation) unless it says "host only".
+ * Return codes: 0 ok, DEER_ERR_SHAPE (1) invalid argument / state, DEER_ERR_LAUNCH (2) a kernel launch failed.
+ */
+#ifndef DEER_MODEL_H
+#define DEER_MODEL_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Shape description of one model (mirrors deer_vla_amd/config.py::DeerConfig; the reference scatters these over
+ * robot_flamingo/models/factory.py:13-26, the HF config.json of the MPT repos, open_clip's ViT-L-14 config and the DeeR
+ * checkpoint dict, robot_flamingo/eval/eval_calvin.py:455-476). */
+typedef struct deer_config {
+  int image_size, patch_size, vit_width, vit_layers, vit_heads, vit_mlp;
+  int perc_depth, perc_heads, perc_dim_head, perc_latents, perc_ff_mult;
+  int vocab_size, d_model, n_heads, n_layers, mlp_ratio, attn_qk_ln, alibi_bias_max;
+  int cross_attn_every_n_layers, xattn_heads, xattn_dim_head, xattn_ff_mult, media_token_id;
+  int mpt7b_names;          /* 1: norm_1 / ffn.up_proj / ffn.down_proj parameter names (modeling_gpt_9b.py), 0: ln_1 / mlp.mlp_up */
+  int exit_interval;
+  int head_hidden, lstm_num_layers, lstm_layernorm, mlp_layernorm, mlp_num_hidden_layers, pooling_avg;
+  int n_envs;               /* environments evaluated per control step (1..8) */
+  int max_text_len;         /* longest instruction (tokens); n_envs * T must be <= 128 rows */
+  int n_chains;             /* independent vision chains of the two-stream schedule (0 = default 2) */
+} deer_config;
+
+typedef struct deer_model deer_model;
+
+/* ---- construction (host only) ---------------------------------------------------------------------------------- */
+int deer_model_create(const deer_config* cfg, deer_model** out);
+void deer_model_destroy(deer_model* m);
+long deer_model_arena_bytes(const deer_model* m);      /* device bytes for the weights (bf16 GEMM operands, f32 norms/biases) */
+long deer_model_workspace_bytes(const deer_model* m);  /* device bytes for activations, slabs, LSTM state, control blocks */
+/* arena / workspace: device allocations of at least the sizes above, 256-byte aligned, owned by the caller */
+int deer_model_bind(deer_model* m, void* arena, void* workspace);
+/* Ingest one tensor of the REFERENCE's state dict (names of SURVEY.md §8b "Weight/ckpt format", e.g.
+ * "vision_encoder.visual.transformer.resblocks.3.attn.in_proj_weight", "perceiver.layers.0.0.to_kv.weight",
+ * "lang_encoder.transformer.blocks.5.decoder_layer.attn.Wqkv.weight", "extra_exit.rnn.layers.0.weight_ih_l0").
+ * src: DEVICE pointer, f32 (src_is_bf16 = 0) or bf16 (1), `numel` elements in the reference's layout; the model converts
+ * and re-lays it out (bf16; MFMA-fragment packing for the LLM projections; conv1 reshaped + zero-padded; Perceiver
+ * to_q/to_kv stacked; x-attn to_kv of all layers concatenated).  Returns DEER_ERR_SHAPE for an unknown name / wrong size. */
+int deer_model_load_tensor(deer_model* m, const char* name, const void* src, int src_is_bf16, long numel, void* stream);
+int deer_model_knows_tensor(const deer_model* m, const char* name);              /* host only: 1 if `name` is a parameter of this model */
+int deer_model_missing_tensors(const deer_model* m, char* buf, int buflen);      /* host only: count of REQUIRED tensors not loaded; names (newline separated) into buf */
+/* host only: location of a named buffer (bytes from the base).  which = 0 arena, 1 workspace.  Workspace names: "img", "vx",
+ * "vis_x", "vis_x_f32", "kv_all", "ids", "key_mask", "text_time", "x", "hidden", "h_state", "c_state", "h_tmp", "c_tmp",
+ * "h_shadow", "c_shadow", "pooled", "ctl", "thresholds", "step_info", "action_dbg". */
+int deer_model_buffer(const deer_model* m, int which, const char* name, long* offset, long* bytes);
+
+/* ---- exit controller configuration (ExitController.__init__ / _set_threshold_value, value_net.py:164-183) ------- */
+/* host only.  max_layer as given to the reference's controller (the controller uses min(max_layer - 1, last exit)). */
+int deer_model_configure_exit(deer_model* m, const int* exit_ids, int n_exit, int max_layer, int thr_type, int leq);
+int deer_model_real_num_exit(const deer_model* m);
+
+/* ---- the three coarse operators of SURVEY.md §8b ------------------------------------------------------------------ */
+/* images: bf16 [n_images,3,S,S] (already CLIP-normalised); tokens_out: f32 [n_images,256,W] patch tokens (x[:,1:], no ln_post)
+ * or NULL to leave them in the workspace only (the Perceiver reads them there). */
+int deer_vit_l14_encode(deer_model* m, const void* images_bf16, int n_images, float* tokens_out, void* stream);
+/* tokens: f32 [n_images,256,W] or NULL (= the workspace tokens of the last deer_vit_l14_encode); media_bf16_out / media_f32_out:
+ * [n_images*64, W] latents of every image in image order (rgb, gripper per environment = the post-fusion concat of
+ * flamingo_mpt.py:661) or NULL to leave them in the workspace. */
+int deer_perceiver_resample(deer_model* m, const float* tokens, int n_images, void* media_bf16_out, float* media_f32_out,
+                            void* stream);
+/* ids: int64 [n_envs,T] device; key_mask: uint8 [n_envs,T] (0 = padding) or NULL; media_bf16: [n_envs*128, W] or NULL (workspace);
+ * exit_id >= 0: static exit (flamingo_mpt.py:446-461), exit_id < 0: dynamic exit with the configured controller;
+ * thresholds: device f32[16] or NULL (= the model's own "thresholds" buffer); step_info: device-visible int32[4]
+ * {hold, sequence number, host mirror ptr lo, hi} or NULL.  Results: control blocks ("ctl": exit layer, action, deltas per
+ * environment), hidden states ("hidden"), committed LSTM state ("h_state"/"c_state"). */
+int deer_llm_early_exit(deer_model* m, const long long* ids, const unsigned char* key_mask, int T, const void* media_bf16,
+                        int exit_id, int shadow, const float* thresholds, const int* step_info, void* stream);
+
+/* ---- pieces (the same work in host-schedulable units; engine.py replays them as HIP-graph pieces) ------------------ */
+int deer_begin_step(deer_model* m, const int* step_info, void* stream);
+/* chain: -1 = all camera frames batched on one stream, c >= 0 = chain c of the multi-stream schedule (its own workspace);
+ * part: 0 whole tower, 1 patch embedding + first blocks, 2 the rest + Perceiver; media_kv: also project K|V of every x-attn layer */
+int deer_vision(deer_model* m, int chain, int part, int media_kv, void* stream);
+int deer_media_kv(deer_model* m, void* stream);
+int deer_llm_embed(deer_model* m, int T, void* stream);
+/* pending_in: the previous layer left its last residual branch un-applied (it was not finalized); finalize: write hidden[i] */
+int deer_llm_layer(deer_model* m, int layer, int T, int use_mask, int pending_in, int finalize, int use_ctl, void* stream);
+/* one DeterministicDecoder evaluation + exit gate.  feats: NULL = hidden[layer]; kind DEER_KIND_*; slot = exit index */
+int deer_head_eval(deer_model* m, int layer, int T, int kind, int slot, int force, int use_ctl, int shadow, int no_ctl_final,
+                   const float* feats, int use_mask, void* stream);
+/* whole control step on ONE stream (vision batched): begin + vision + media K/V + trunk + heads */
+int deer_step_enqueue(deer_model* m, int T, int use_mask, int exit_id, int shadow, const int* step_info, void* stream);
+/* layers of the dynamic step: returns n and fills need_pseudo[i], is_exit[i], slot[i] for i < n (host only) */
+int deer_dynamic_plan(const deer_model* m, int* need_pseudo, int* is_exit, int* slot, int cap);
+int deer_model_n_chains(const deer_model* m);
+
+/* ---- in-situ profiler: HIP events around every kernel-launching call of the spine (bench.py roofline pass) --------- */
+int deer_prof_enable(deer_model* m, int on);                      /* host only; on = 1 clears the record list */
+int deer_prof_count(const deer_model* m);
+int deer_prof_get(deer_model* m, int i, char* name, int name_len, float* us, double* flops, double* bytes);  /* syncs the events */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEER_MODEL_H */

@@ -38,7 +38,7 @@ def lib():
 
 
 # ------------------------------------------------------------------------------------------ skinny GEMM
-@pytest.mark.parametrize("M", [1, 14, 16, 17, 32, 33, 56, 64])
+@pytest.mark.parametrize("M", [1, 14, 16, 17, 32, 33, 56, 64, 70, 84, 98, 112, 128])
 @pytest.mark.parametrize("N,K", [(512, 2048), (2048, 512), (6144, 2048), (2048, 8192), (64, 32), (48, 96)])
 def test_gemm_skinny_packed(lib, M, N, K):
     A = dev(rnd(M, K, seed=1), torch.bfloat16)
@@ -47,7 +47,7 @@ def test_gemm_skinny_packed(lib, M, N, K):
     abi.check(lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), N, K, st()), "pack")
     S = lib.deer_skinny_splitk(M, N, K)
     assert S >= 1 and K % (S * 32) == 0
-    mpad = 16 if M <= 16 else (32 if M <= 32 else 64)
+    mpad = abi.skinny_mpad(M)
     part = torch.full((S, mpad, N), float("nan"), device="cuda")
     abi.check(lib.deer_gemm_skinny(abi.ptr(A), K, None, 0, 0, abi.A_BF16, abi.ptr(Wp), abi.ptr(part), M, N, K, S, None, st()), "skinny")
     torch.cuda.synchronize()
@@ -59,7 +59,7 @@ def test_gemm_skinny_packed(lib, M, N, K):
         assert float(part[:, M:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,N,K", [(14, 2048, 2048), (32, 512, 2048), (3, 64, 96), (56, 2048, 2048), (42, 8192, 2048)])
+@pytest.mark.parametrize("M,N,K", [(14, 2048, 2048), (32, 512, 2048), (3, 64, 96), (56, 2048, 2048), (42, 8192, 2048), (112, 2048, 8192), (112, 6144, 2048), (98, 512, 2048), (14, 2048, 8192)])
 def test_gemm_skinny_f32_split_activation(lib, M, N, K):
     """f32 activations enter the MFMA as bf16 hi + lo: result ~fp32-accurate w.r.t. the bf16 weights."""
     A = dev(rnd(M, K, seed=41))
@@ -67,7 +67,7 @@ def test_gemm_skinny_f32_split_activation(lib, M, N, K):
     Wp = torch.empty_like(W)
     abi.check(lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), N, K, st()), "pack")
     S = lib.deer_skinny_splitk(M, N, K)
-    mpad = 16 if M <= 16 else (32 if M <= 32 else 64)
+    mpad = abi.skinny_mpad(M)
     part = torch.zeros(S, mpad, N, device="cuda")
     abi.check(lib.deer_gemm_skinny(abi.ptr(A), K, None, 0, 0, abi.A_F32, abi.ptr(Wp), abi.ptr(part), M, N, K, S, None, st()), "skinny")
     torch.cuda.synchronize()

@@ -10,7 +10,7 @@ SHAPES = [("xa q", 512, 2048), ("xa out", 2048, 512), ("xa ff1", 8192, 2048), ("
           ("out", 2048, 2048), ("up", 8192, 2048), ("down", 2048, 8192)]
 import sys as _s
 T = int(_s.argv[1]) if len(_s.argv) > 1 else 14
-MP = 16 if T <= 16 else (32 if T <= 32 else 64)
+MP = abi.skinny_mpad(T)
 print('rows', T)
 for name, N, K in SHAPES:
     ncopy = max(4, int(600e6 / (N * K * 2)))
@@ -25,8 +25,8 @@ for name, N, K in SHAPES:
     torch.cuda.synchronize()
     line = f"{name:7s} N={N:5d} K={K:5d} {N*K*2/1e6:5.1f}MB |"
     S0 = lib.deer_skinny_splitk(T, N, K)
-    for S in sorted(set([1, 2, 4, 8, 16, S0])):
-        if K % (S * 32) or (K // S) > (512 if MP == 16 else 256):
+    for S in sorted(set([1, 2, 4, 8, 16, 32, S0])):
+        if K % (S * 32) or (K // S) < 128:
             continue
         part = torch.zeros(S, MP, N, device="cuda")
         def run(w):
