@@ -96,6 +96,35 @@ def skinny_mpad(M: int) -> int:
     return 16 * ((M + 15) // 16)
 
 
+class DeerConfigC(ctypes.Structure):
+    """``deer_config`` of include/deer_model.h (field order must match)."""
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "image_size", "patch_size", "vit_width", "vit_layers", "vit_heads", "vit_mlp",
+        "perc_depth", "perc_heads", "perc_dim_head", "perc_latents", "perc_ff_mult",
+        "vocab_size", "d_model", "n_heads", "n_layers", "mlp_ratio", "attn_qk_ln", "alibi_bias_max",
+        "cross_attn_every_n_layers", "xattn_heads", "xattn_dim_head", "xattn_ff_mult", "media_token_id",
+        "mpt7b_names", "exit_interval",
+        "head_hidden", "lstm_num_layers", "lstm_layernorm", "mlp_layernorm", "mlp_num_hidden_layers", "pooling_avg",
+        "n_envs", "max_text_len", "n_chains")]
+
+
+def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0) -> DeerConfigC:
+    c = DeerConfigC()
+    for k in ("image_size", "patch_size", "vit_width", "vit_layers", "vit_heads", "vit_mlp", "perc_depth", "perc_heads",
+              "perc_dim_head", "perc_latents", "perc_ff_mult", "vocab_size", "d_model", "n_heads", "mlp_ratio",
+              "alibi_bias_max", "cross_attn_every_n_layers", "xattn_heads", "xattn_dim_head", "xattn_ff_mult",
+              "media_token_id", "exit_interval", "head_hidden", "lstm_num_layers", "mlp_num_hidden_layers"):
+        setattr(c, k, int(getattr(cfg, k)))
+    c.n_layers = cfg.n_layers
+    c.attn_qk_ln = 1 if cfg.attn_qk_ln else 0
+    c.mpt7b_names = 1 if cfg.llm_name == "mpt_9b" else 0
+    c.lstm_layernorm = 1 if cfg.lstm_layernorm else 0
+    c.mlp_layernorm = 1 if cfg.mlp_layernorm else 0
+    c.pooling_avg = 0 if cfg.pooling == "max" else 1
+    c.n_envs, c.max_text_len, c.n_chains = n_envs, max_text_len, n_chains
+    return c
+
+
 class DeerHipError(RuntimeError):
     pass
 

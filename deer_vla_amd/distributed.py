@@ -19,6 +19,16 @@ def world_info():
     return 0, 1
 
 
+def collective_device(device=None):
+    """Device the tensors of a collective must live on: RCCL ("nccl" on ROCm) only moves device memory - a CPU tensor handed to
+    all_reduce / all_gather raises - while gloo (CPU tests) takes host tensors.  None = leave the tensor where it is."""
+    if device is not None:
+        return torch.device(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return None
+
+
 def shard_sequences(seqs: Sequence, rank: int, world: int) -> List:
     """eval_utils.py:523-527: ``assert NUM_SEQUENCES % device_num == 0``; rank r takes a contiguous block."""
     n = len(seqs)
@@ -52,7 +62,8 @@ def reduce_metrics(packed: torch.Tensor, device=None, n_extra: int = 0) -> Dict[
     ``print_and_save`` (eval_utils.py:71-118): avg successful length, chain success rates 1-5, avg exit layer (+1)."""
     t = packed.clone()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        t = t.to(device) if device is not None else t
+        dev = collective_device(device)
+        t = t.to(dev) if dev is not None else t
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         t = t.cpu()
     extra = None
@@ -73,6 +84,8 @@ def all_gather_values(values: torch.Tensor) -> torch.Tensor:
     """value_net.py:195-201: gather the (n_exit, n_local) delta matrices of all ranks along dim 1."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return values
-    parts = [torch.zeros_like(values) for _ in range(dist.get_world_size())]
-    dist.all_gather(parts, values)
-    return torch.cat(parts, dim=1)
+    dev = collective_device()
+    src = values.to(dev) if dev is not None else values
+    parts = [torch.zeros_like(src) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, src.contiguous())
+    return torch.cat(parts, dim=1).to(values.device)

@@ -74,3 +74,50 @@ def test_single_process_fallbacks():
         assert False
     except AssertionError:
         pass
+
+
+# ---- the same helpers over RCCL (backend "nccl"): CPU tensors must be staged through the device ------------------------
+import pytest  # noqa: E402
+
+
+def _nccl_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        torch.cuda.set_device(0)                                  # both ranks on the one GPU of the test box
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        m = dd.reduce_metrics(dd.pack_metrics([rank + 1], [1 + 2 * rank] * 3, 12))      # CPU tensor in, as rollout.py passes it
+        vals = torch.arange(6 * 4, dtype=torch.float32).view(6, 4) + 100 * rank           # CPU deltas, as generate_values returns
+        g = dd.all_gather_values(vals)
+        q.put((rank, "ok", m["n_chains"], m["avg_seq_len"], tuple(g.shape), float(g[0, 4]), g.device.type))
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, "error", repr(e)))
+
+
+@pytest.mark.gpu
+def test_two_rank_nccl_collectives_accept_cpu_tensors():
+    """NCCL/RCCL cannot reduce CPU tensors; reduce_metrics / all_gather_values now stage them through the device."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        out = sorted([q.get(timeout=180) for _ in range(world)])
+    except Exception:
+        for p in procs:
+            p.kill()
+        pytest.skip("RCCL did not come up with two ranks on one device within 180 s")
+    for p in procs:
+        p.join(30)
+        if p.is_alive():
+            p.kill()
+    if any(o[1] == "error" for o in out):
+        msg = " | ".join(o[2] for o in out if o[1] == "error")
+        if "uplicate" in msg or "invalid usage" in msg.lower() or "ncclInvalidUsage" in msg:
+            pytest.skip("RCCL refuses two ranks on one device: " + msg[:200])
+        raise AssertionError(msg)
+    for r, _, n_chains, avg_len, shp, g04, devtype in out:
+        assert n_chains == 2 and abs(avg_len - 1.5) < 1e-12 and shp == (6, 8) and g04 == 100.0 and devtype == "cpu"

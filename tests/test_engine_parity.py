@@ -33,7 +33,8 @@ def gap_threshold(vals, lo=0.2, hi=0.8):
 class RecVN(orc.OracleValueNet):
     def __call__(self, feats, i=None, mode="infer", rand_layer_feat=None):
         v = super().__call__(feats, i, mode, rand_layer_feat)
-        self.rec = getattr(self, "rec", [])
+        if not hasattr(self, "rec"):
+            self.rec = []
         self.rec.append((i, float(v)))
         return v
 
@@ -346,41 +347,97 @@ def test_padding_mask_and_text_lengths(tiny):
         assert float((r["pose"] - ref["logits"][0].reshape(-1)).abs().max()) < ACTION_TOL
 
 
-@pytest.mark.parametrize("B,sps", [(2, 1), (4, 1), (3, 2)])
+def oracle_episode_margins(cfg, sd, inputs, thresholds, max_layer, steps_per_stage=1):
+    """oracle_episode + the relative margin |delta - thr| / thr of the tightest exit check the oracle evaluated at each step"""
+    model = orc.OracleDeer(sd, cfg)
+    model.set_all_exit_window_size(1)
+    vn = RecVN(cfg.exit_ids(), model.extra_exit, cfg.exit_interval, 1, "L2")
+    vn.rec = []
+    ctl = orc.OracleExitController(vn, cfg.exit_ids(), steps_per_stage=steps_per_stage, max_layer=max_layer)
+    ctl._set_threshold_value(thresholds)
+    thr_by_exit = dict(zip(cfg.exit_ids(), thresholds))
+    outs = []
+    for s, (rgb, grip, ids, mask) in enumerate(inputs):
+        ctl.set_timestep(s)
+        n0 = len(vn.rec)
+        o = model.forward(rgb, ids, mask, grip, dynamic_early_exit=True, exit_controller=ctl)
+        m = [abs(v - thr_by_exit[i]) / thr_by_exit[i] for (i, v) in vn.rec[n0:] if thr_by_exit[i] < 1e4]
+        outs.append((o["exit_layer"], o["logits"][0].reshape(-1), float(o["logits"][1]), min(m) if m else float("inf")))
+    return outs
+
+
+BAND = 1e-2
+
+
+def run_env_batch_against_independent_oracles(cfg, sd, eng, env_inputs, thr, sps, n_steps, B):
+    """Every environment of the batch must behave exactly like an independent single-environment oracle run.  Rule (the same
+    as tests/test_episode_parity.py): exit layers are compared at every step whose oracle decision is not knife-edge (margin >
+    1e-2); an environment whose knife-edge decision flips is reported and left out FROM THAT STEP ON (its LSTM history
+    diverged; a batch cannot be re-aligned per environment).  Returns (#compared env-steps, flips, seen exit layers)."""
+    refs = [oracle_episode_margins(cfg, sd, env_inputs[e], thr, 12, sps) for e in range(B)]
+    eng.configure_exit(cfg.exit_ids(), 12, sps)
+    eng.set_thresholds(thr)
+    eng.reset()
+    seen, flips, compared = set(), [], 0
+    alive = [True] * B
+    for s in range(n_steps):
+        rgb = torch.stack([env_inputs[e][s][0] for e in range(B)])
+        grip = torch.stack([env_inputs[e][s][1] for e in range(B)])
+        T = max(env_inputs[e][s][2].shape[1] for e in range(B))
+        ids = torch.zeros(B, T, dtype=torch.long)
+        mask = torch.zeros(B, T, dtype=torch.bool)
+        for e in range(B):                                         # right-pad to the longest instruction of the batch
+            te = env_inputs[e][s][2].shape[1]
+            ids[e, :te], mask[e, :te] = env_inputs[e][s][2][0], True
+        out = eng.step(rgb, grip, ids, mask, use_graph=(s >= 2))
+        out = out if isinstance(out, list) else [out]
+        assert len(out) == B
+        for e in range(B):
+            if not alive[e]:
+                continue
+            ex, pose, g, margin = refs[e][s]
+            if out[e]["exit_layer"] != ex:
+                assert margin <= BAND, ("exit mismatch outside the knife-edge band", e, s, out[e]["exit_layer"], ex, margin)
+                flips.append((e, s, margin))
+                alive[e] = False
+                continue
+            assert float((out[e]["pose"] - pose).abs().max()) < ACTION_TOL, (e, s)
+            assert abs(out[e]["gripper"] - g) < ACTION_TOL
+            compared += 1
+            seen.add(ex)
+    print(f"\n[env batch B={B}] compared {compared}/{B * n_steps} env-steps, knife-edge flips {flips}")
+    return compared, flips, seen
+
+
+@pytest.mark.parametrize("B,sps", [(2, 1), (4, 1), (3, 2), (8, 1)])
 def test_batched_environments_match_independent_oracle_runs(B, sps):
     """n_envs environments per step (one env batch per rank): every environment must behave exactly like an
     independent single-environment run - its own exit layer (exact), action (1e-2), LSTM carry - while sharing the
-    weight stream.  B=2 -> 22 LLM rows (2 MFMA row tiles), B=4 -> 44 rows (4 row tiles)."""
+    weight stream.  B=2 -> 22 LLM rows (2 MFMA row tiles), B=4 -> 44 rows, B=8 -> 88 rows (6 row tiles)."""
     cfg = deer_tiny()
     sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
     eng = DeerEngine(cfg, sd, n_envs=B)
     n_steps, T = 12, 11
     env_inputs = [[syn.synthetic_step_inputs(cfg, s, rank=e, text_len=T, text_seed=7 + e) for s in range(n_steps)] for e in range(B)]
     thr, _ = probe_thresholds(cfg, sd, env_inputs[0], 12, sps)
-    refs, margins = [], []
-    for e in range(B):
-        ref, rec, _ = oracle_episode(cfg, sd, env_inputs[e], thr, 12, sps)
-        refs.append(ref)
-        margins.append(min_margin(rec, dict(zip(cfg.exit_ids(), thr))))
-    eng.configure_exit(cfg.exit_ids(), 12, sps)
-    eng.set_thresholds(thr)
-    eng.reset()
-    seen = set()
-    for s in range(n_steps):
-        rgb = torch.stack([env_inputs[e][s][0] for e in range(B)])
-        grip = torch.stack([env_inputs[e][s][1] for e in range(B)])
-        ids = torch.cat([env_inputs[e][s][2] for e in range(B)])
-        mask = torch.cat([env_inputs[e][s][3] for e in range(B)])
-        out = eng.step(rgb, grip, ids, mask, use_graph=(s >= 2))
-        assert len(out) == B
-        for e in range(B):
-            if margins[e] > 0.01:                           # knife-edge thresholds for this env's data are not a parity statement
-                assert out[e]["exit_layer"] == refs[e][s][0], (e, s, out[e]["exit_layer"], refs[e][s][0], margins)
-                assert float((out[e]["pose"] - refs[e][s][1]).abs().max()) < ACTION_TOL, (e, s)
-                assert abs(out[e]["gripper"] - refs[e][s][2]) < ACTION_TOL
-            seen.add(out[e]["exit_layer"])
-    assert sum(m > 0.01 for m in margins) >= max(1, B - 1), margins
+    compared, flips, seen = run_env_batch_against_independent_oracles(cfg, sd, eng, env_inputs, thr, sps, n_steps, B)
+    assert compared >= 0.8 * B * n_steps, (compared, flips)
     assert len(seen) > 1
+
+
+def test_batched_environments_with_different_instruction_lengths():
+    """Instructions of an env batch are right-padded to the longest one; an environment with a shorter instruction must still
+    match its own UNPADDED single-environment oracle run: padded key rows are masked in the attention and stay out of the
+    head's token pool (head_pool_kernel pooled over pad rows)."""
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
+    B, n_steps = 3, 8
+    lens = [14, 9, 11]
+    eng = DeerEngine(cfg, sd, n_envs=B)
+    env_inputs = [[syn.synthetic_step_inputs(cfg, s, rank=e, text_len=lens[e], text_seed=7 + e) for s in range(n_steps)] for e in range(B)]
+    thr, _ = probe_thresholds(cfg, sd, env_inputs[0], 12, 1)
+    compared, flips, seen = run_env_batch_against_independent_oracles(cfg, sd, eng, env_inputs, thr, 1, n_steps, B)
+    assert compared >= 0.8 * B * n_steps, (compared, flips)
 
 
 def test_full_size_mpt1b_vitl14_steps_vs_oracle():
