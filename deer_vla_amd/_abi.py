@@ -52,6 +52,7 @@ SIGNATURES = {
     "deer_model_workspace_bytes": [P],
     "deer_model_bind": [P, P, P],
     "deer_model_load_tensor": [P, c_char_p, P, I, L, P],
+    "deer_model_share_weights": [P, P],
     "deer_model_knows_tensor": [P, c_char_p],
     "deer_model_missing_tensors": [P, P, I],
     "deer_model_buffer": [P, I, c_char_p, P, P],

@@ -880,6 +880,19 @@ int deer_model_bind(deer_model* m, void* arena, void* workspace) {
   return DEER_OK;
 }
 
+int deer_model_share_weights(deer_model* m, const deer_model* src) {
+  // a second model object (e.g. another n_envs: the window-mode / env-batch sibling) over the SAME weight arena: the arena layout
+  // depends on the shape description only, so the already-ingested tensors are simply adopted
+  if (src == nullptr || src->arena == nullptr || m->al.cur != src->al.cur || m->slots.size() != src->slots.size()) return DEER_ERR_SHAPE;
+  for (auto& kv : m->slots) {
+    auto it = src->slots.find(kv.first);
+    if (it == src->slots.end() || it->second.dst[0] != kv.second.dst[0]) return DEER_ERR_SHAPE;
+    kv.second.loaded = it->second.loaded;
+  }
+  m->arena = src->arena;
+  return DEER_OK;
+}
+
 int deer_model_knows_tensor(const deer_model* m, const char* name) { return m->slots.count(name) ? 1 : 0; }
 
 int deer_model_load_tensor(deer_model* m, const char* name, const void* src, int src_is_bf16, long numel, void* stream) {

@@ -49,8 +49,9 @@ class DeerEngine:
     pieces.  The kernel ORDER of every piece lives in the C++ model object; nothing here touches a kernel directly."""
     LOOKAHEAD = 1        # trunk layers the host keeps in flight beyond an undecided exit check
 
-    def __init__(self, cfg: DeerConfig, state_dict: Dict[str, torch.Tensor], device="cuda", max_text_len: int = 32,
-                 n_envs: int = 1, threshold_type: str = "L2", leq: bool = True, segmented: bool = True):
+    def __init__(self, cfg: DeerConfig, state_dict: Optional[Dict[str, torch.Tensor]], device="cuda", max_text_len: int = 32,
+                 n_envs: int = 1, threshold_type: str = "L2", leq: bool = True, segmented: bool = True,
+                 weights_from: Optional["DeerEngine"] = None):
         """n_envs: independent environments evaluated per control step (one "env batch" per rank).  They share every
         weight read: the ViT sees M = 514*n_envs rows, the LLM n_envs*T rows, each environment keeps its own LSTM state,
         thresholds are shared and every environment exits at its own layer (device side)."""
@@ -72,11 +73,18 @@ class DeerEngine:
         cc = config_to_c(cfg, n_envs, self.max_T)
         abi.check(self.lib.deer_model_create(ctypes.byref(cc), ctypes.byref(self._h)), "deer_model_create")
         with torch.cuda.device(self.dev):
-            self.arena = torch.zeros(self.lib.deer_model_arena_bytes(self._h), dtype=torch.uint8, device=self.dev)
             self.workspace = torch.zeros(self.lib.deer_model_workspace_bytes(self._h), dtype=torch.uint8, device=self.dev)
-            abi.check(self.lib.deer_model_bind(self._h, abi.ptr(self.arena), abi.ptr(self.workspace)), "deer_model_bind")
-            self._load_weights(state_dict)
+            if weights_from is None:
+                self.arena = torch.zeros(self.lib.deer_model_arena_bytes(self._h), dtype=torch.uint8, device=self.dev)
+                abi.check(self.lib.deer_model_bind(self._h, abi.ptr(self.arena), abi.ptr(self.workspace)), "deer_model_bind")
+                self._load_weights(state_dict)
+            else:                                      # ONE copy of the weights serves every engine built on the same config
+                self.arena = weights_from.arena
+                abi.check(self.lib.deer_model_bind(self._h, abi.ptr(self.arena), abi.ptr(self.workspace)), "deer_model_bind")
+                abi.check(self.lib.deer_model_share_weights(self._h, weights_from._h), "deer_model_share_weights")
+                self._weights_owner = weights_from     # keeps the owner (and its arena) alive
             self._make_views()
+        self._siblings: Dict[int, "DeerEngine"] = {}
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self.segmented = segmented                    # dynamic steps fed in per-layer graph pieces (see _step_segmented)
         self._side_stream = torch.cuda.Stream(device=self.dev)
@@ -584,59 +592,98 @@ class DeerEngine:
         return self.read_result()
 
     # ------------------------------------------------------------------------- calibration (window mode)
-    def window_hidden_states(self, rgb_seq: torch.Tensor, grip_seq: torch.Tensor, ids: torch.Tensor, mask=None) -> torch.Tensor:
-        """hidden_states of EVERY layer for each frame pair of a calibration window (the ``hidden_states`` the reference's
-        forward hands to ``ActionValueNet(mode='generate')``, value_net.py:386).  rgb_seq / grip_seq: (W, 3, S, S); returns
-        (W, n_layers, T, d) fp32 on the device.  n_envs must be 1."""
-        assert self.B == 1
-        W = rgb_seq.shape[0]
+    def sibling(self, n_envs: int) -> "DeerEngine":
+        """An engine for ``n_envs`` environments per step over the SAME weight arena (own workspace / LSTM state / controller)."""
+        if n_envs == self.B:
+            return self
+        e = self._siblings.get(n_envs)
+        if e is None:
+            e = DeerEngine(self.cfg, None, device=self.dev, max_text_len=self.max_T, n_envs=n_envs, weights_from=self, segmented=self.segmented)
+            self._siblings[n_envs] = e
+        return e
+
+    def window_hidden_states(self, rgb_seq: torch.Tensor, grip_seq: torch.Tensor, ids: torch.Tensor, mask=None, group: int = 8) -> torch.Tensor:
+        """hidden_states of EVERY layer for each frame pair of calibration windows (the ``hidden_states`` the reference's window-mode
+        forward hands to ``ActionValueNet(mode='generate')``: flamingo_mpt.py:463-517 on (bs*W) batch rows, value_net.py:375-386).
+        rgb_seq / grip_seq: (F, 3, S, S) frames; ids (F, T) or (1, T) (one instruction for all frames); returns (F, n_layers, T, d)
+        fp32 on the device.  The frames are BATCH ROWS here too: groups of ``group`` frames run through the env-batch sibling
+        engine (ViT at M = 514*group rows, trunk at group*T rows), static full depth, every layer's output kept."""
+        F = rgb_seq.shape[0]
+        ids = ids.reshape(-1, ids.shape[-1])
+        T = ids.shape[1]
+        G = max(1, min(group, 128 // T, F, 8))
+        w = self.sibling(G)
         last = self.cfg.n_layers - 1
-        out = None
-        self._drain_side_streams()
-        for t in range(W):
-            T, use_mask = self.load_inputs(rgb_seq[t], grip_seq[t], ids, mask)
-            self.hold_dev.zero_()
-            self._enqueue_step(T, use_mask, last)                 # static full depth: every layer's output is kept
-            if out is None:
-                out = torch.empty(W, self.cfg.n_layers, T, self.cfg.d_model, device=self.dev)
-            out[t].copy_(self.hidden[:, :T])
+        L, d = self.cfg.n_layers, self.cfg.d_model
+        out = torch.empty(F, L, T, d, device=self.dev)
+        w._drain_side_streams()
+        for f0 in range(0, F, G):
+            idx = [min(f0 + i, F - 1) for i in range(G)]          # the last group is padded with its last frame
+            ids_g = ids[idx] if ids.shape[0] == F else ids.expand(G, T)
+            mask_g = None
+            if mask is not None:
+                m2 = mask.reshape(-1, T)
+                mask_g = m2[idx] if m2.shape[0] == F else m2.expand(G, T)
+            T_, use_mask = w.load_inputs(rgb_seq[idx], grip_seq[idx], ids_g.contiguous(), mask_g)
+            w.hold_dev.zero_()
+            w._enqueue_step(T_, use_mask, last)                   # static full depth: every layer's output is kept
+            n = min(G, F - f0)
+            out[f0:f0 + n].copy_(w.hidden[:, :G * T].view(L, G, T, d).permute(1, 0, 2, 3)[:n])
         return out
 
     def _head_eval(self, feats: torch.Tensor, commit: bool) -> torch.Tensor:
-        """One DeterministicDecoder step on ``feats`` (T, d) from the current LSTM state; commit=True stores the new state
-        (update_hidden_state protocol, action_head.py:548-558).  Returns the device row [pose6, gripper prob, logit]."""
-        self.enqueue_head(0, feats.shape[0], abi.KIND_COMMIT, use_ctl=False, feats=feats, no_ctl_final=True)
+        """One DeterministicDecoder step of all n_envs sequences on ``feats`` (n_envs*T, d) from the current LSTM state; commit=True
+        stores the new state (update_hidden_state protocol, action_head.py:548-558).  Returns the device rows [pose6, gripper prob,
+        logit] per sequence, (n_envs, 8)."""
+        self.enqueue_head(0, feats.shape[0] // self.B, abi.KIND_COMMIT, use_ctl=False, feats=feats, no_ctl_final=True)
         if commit:
             self.h_state.copy_(self.h_tmp)
             self.c_state.copy_(self.c_tmp)
-        return self.action_dbg[0].clone()
+        return self.action_dbg.clone()
 
-    def generate_values(self, hidden: torch.Tensor, rand_layers: Sequence[int], threshold_type: str = "L2") -> torch.Tensor:
-        """``ActionValueNet.forward(mode='generate')`` (value_net.py:134-160) for ONE window: for the time steps seq_id in
-        [W/2-1, W-1) the action of layer 0 and of every exit is predicted from [history = features of the random exit layers
-        ``rand_layers[:seq_id]`` ; this layer's feature at seq_id] with the LSTM run from a zero state (window mode == the
-        carried-state steps below); returns the deltas between consecutive exits, (n_exit, W - W/2) on the host."""
-        W = hidden.shape[0]
+    def generate_values(self, hidden: torch.Tensor, rand_layers, threshold_type: str = "L2", group: int = 8) -> torch.Tensor:
+        """``ActionValueNet.forward(mode='generate')`` (value_net.py:134-160): for the time steps seq_id in [W/2-1, W-1) the action of
+        layer 0 and of every exit is predicted from [history = features of the random exit layers ``rand_layers[:seq_id]`` ; this
+        layer's feature at seq_id] with the LSTM run from a zero state (window mode == carried-state steps); returns the deltas
+        between consecutive exits.  hidden: (W, L, T, d) with rand_layers (W,) -> (n_exit, W - W/2), or a BATCH of windows
+        (bs, W, L, T, d) with rand_layers (bs, W) -> (n_exit, bs * (W - W/2)) in the reference's order (window-major).  The windows
+        of a group are the "environments" of one head evaluation (weights read once per group)."""
+        single = hidden.dim() == 4
+        if single:
+            hidden = hidden.unsqueeze(0)
+        rl = torch.as_tensor(rand_layers).reshape(hidden.shape[0], -1)
+        bs, W, L, T, d = hidden.shape
+        G = max(1, min(group, 128 // T, bs, 8))
+        w = self.sibling(G)
         layers = [0] + list(self.exit_ids)
-        self.h_state.zero_()
-        self.c_state.zero_()
-        acts = []
-        for t in range(W - 1):
-            if t >= W // 2 - 1:
-                acts.append(torch.stack([self._head_eval(hidden[t, i].contiguous(), commit=False) for i in layers]))
-            self._head_eval(hidden[t, int(rand_layers[t])].contiguous(), commit=True)
-        a = torch.stack(acts, dim=1)[..., :6].cpu()                # (n_exit+1, W/2, 6)
+        per_window = []
+        for b0 in range(0, bs, G):
+            idx = [min(b0 + i, bs - 1) for i in range(G)]
+            hg = hidden[idx]                                                   # (G, W, L, T, d)
+            w.h_state.zero_()
+            w.c_state.zero_()
+            acts = []
+            for t in range(W - 1):
+                if t >= W // 2 - 1:
+                    acts.append(torch.stack([w._head_eval(hg[:, t, i].reshape(G * T, d).contiguous(), commit=False) for i in layers]))
+                sel = torch.stack([hg[g, t, int(rl[idx[g], t])] for g in range(G)])                  # each window's own random layer
+                w._head_eval(sel.reshape(G * T, d).contiguous(), commit=True)
+            a = torch.stack(acts, dim=2)[..., :6]                              # (n_exit+1, G, W/2, 6)
+            per_window.append(a[:, : min(G, bs - b0)])
+        a = torch.cat(per_window, dim=1).cpu()                                 # (n_exit+1, bs, W/2, 6)
         prev, last = a[:-1], a[1:]
-        d = (prev - last).abs()
+        dlt = (prev - last).abs()
         if threshold_type == "mean":
-            return d.mean(-1)
-        if threshold_type == "L2":
-            return d.pow(2).mean(-1).pow(0.5)
-        if threshold_type == "max":
-            return d.max(-1)[0]
-        if threshold_type == "cosine":
-            return 1 - torch.nn.functional.cosine_similarity(prev, last, dim=-1, eps=1e-5)
-        raise NotImplementedError(threshold_type)
+            v = dlt.mean(-1)
+        elif threshold_type == "L2":
+            v = dlt.pow(2).mean(-1).pow(0.5)
+        elif threshold_type == "max":
+            v = dlt.max(-1)[0]
+        elif threshold_type == "cosine":
+            v = 1 - torch.nn.functional.cosine_similarity(prev, last, dim=-1, eps=1e-5)
+        else:
+            raise NotImplementedError(threshold_type)
+        return v.flatten(1, 2)                                                 # (n_exit, bs * W/2), window-major like value_net.py:160
 
     @staticmethod
     def _mark(stream):

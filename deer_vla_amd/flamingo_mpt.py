@@ -284,6 +284,44 @@ class MPTFlamingo(nn.Module):
                     break
         return CausalLMOutputWithPast(logits=[1.0], hidden_states=hidden, exit_layer=b)
 
+    def _forward_window(self, vision_x, lang_x, attention_mask, vision_gripper, with_gripper_logits=False, generator=None):
+        """Window mode (flamingo_mpt.py:463-517 as ``generate_action_values`` calls it, value_net.py:375-385): the batch rows are
+        bs * window_size frames (one instruction per row); every layer's hidden state is returned, the history fed to
+        ``extra_exit`` comes from a random exit layer per (window, time step) ("sampling strategy 1", :485-497) and the head runs the
+        windows as sequences from a zero state (action_head.py:588-595).  Returns (output, [], extra_exit_output,
+        rand_layer_feat, rand_layer_indices) like the reference with ``return_in_feat=True``.  The frames run as batch rows through
+        the env-batch engine (``DeerEngine.window_hidden_states``), the windows as the environments of the head evaluations."""
+        e, cfg = self.engine, self.cfg
+        Wn = self.window_size
+        F = vision_x.shape[0]
+        assert F % Wn == 0, f"window mode: {F} batch rows are not a multiple of window_size {Wn}"
+        bs, S = F // Wn, cfg.image_size
+        T = lang_x.shape[-1]
+        hid = e.window_hidden_states(vision_x.reshape(F, 3, S, S).to(e.dev, torch.bfloat16),
+                                     vision_gripper.reshape(F, 3, S, S).to(e.dev, torch.bfloat16), lang_x.reshape(F, T).to(e.dev),
+                                     attention_mask.reshape(F, T).to(e.dev) if attention_mask is not None else None)     # (F, L, T, d)
+        hidden = tuple(hid[:, l] for l in range(cfg.n_layers))
+        exit_ids = self.get_all_exit_idx()
+        idx = torch.randint(0, len(exit_ids), (bs, Wn), generator=generator)                 # :485
+        rand_layers = torch.tensor([exit_ids[int(i)] for i in idx.reshape(-1)]).reshape(bs, Wn)
+        rand_feat = hid[torch.arange(F, device=hid.device), rand_layers.reshape(-1).to(hid.device)]      # (F, T, d)
+        # extra_exit on the random-layer features, windows as sequences from a zero LSTM state: groups of <= 8 windows per evaluation
+        G = max(1, min(8, 128 // T, bs))
+        w = e.sibling(G)
+        rows = []
+        rf = rand_feat.view(bs, Wn, T, cfg.d_model)
+        for b0 in range(0, bs, G):
+            gidx = [min(b0 + i, bs - 1) for i in range(G)]
+            w.h_state.zero_()
+            w.c_state.zero_()
+            acts = [w._head_eval(rf[gidx, t].reshape(G * T, cfg.d_model).contiguous(), commit=True) for t in range(Wn)]
+            rows.append(torch.stack(acts, dim=1)[: min(G, bs - b0)])                        # (g, W, 8)
+        a = torch.cat(rows, dim=0)                                                          # (bs, W, 8)
+        pose, grip, glog = a[..., :6], a[..., 6:7], a[..., 7:8]
+        extra = (pose, (grip, glog)) if with_gripper_logits else (pose, grip)
+        out = CausalLMOutputWithPast(logits=extra, hidden_states=hidden, exit_layer=cfg.n_layers - 1)
+        return out, [], extra, rand_feat, rand_layers.to(hid.device)
+
     def forward(self, vision_x: torch.Tensor, lang_x: torch.Tensor, attention_mask: torch.Tensor = None, labels=None,
                 use_cached_vision_x: bool = False, clear_conditioned_layers: bool = True, past_key_values=None,
                 use_cache: bool = False, vision_gripper=None, state_tensor=None, return_feature=False, policy_mask=None,
@@ -295,12 +333,17 @@ class MPTFlamingo(nn.Module):
             raise NotImplementedError("use_cached_vision_x is not used on the DeeR robot path")
         if vision_gripper is None:
             raise ValueError("vision_gripper is required (flamingo_mpt.py:355 clones it unconditionally)")
-        if vision_x.ndim != 6 or vision_x.shape[0] != 1 or vision_x.shape[1] != 1:
-            raise NotImplementedError("native engine: step mode (B=1, T_img=1); window mode is a 'next' row (SURVEY §8f.1)")
+        if vision_x.ndim != 6 or vision_x.shape[1] != 1:
+            raise NotImplementedError("vision_x must be (B, 1, 1, 3, S, S)")
         assert vision_x.shape[2] == 1, "Only single frame supported"
         if exit_id is None and not (dynamic_early_exit and exit_controller is not None):
-            raise NotImplementedError("training branch (all exits, flamingo_mpt.py:463-517) is out of scope; pass exit_id "
-                                      "or dynamic_early_exit=True with an exit_controller")
+            # the all-exits branch (flamingo_mpt.py:463-517): inference-side use = window-mode calibration (value_net.py:375-385)
+            if not (only_extra_exit and return_in_feat):
+                raise NotImplementedError("the training losses of the all-exits branch are out of scope; the calibration call "
+                                          "(only_extra_exit=True, return_in_feat=True, value_net.py:375-385) is supported")
+            return self._forward_window(vision_x, lang_x, attention_mask, vision_gripper, with_gripper_logits)
+        if vision_x.shape[0] != 1:
+            raise NotImplementedError("step mode takes one frame pair (B=1); batches of frames go through the window-mode call")
         e, cfg = self.engine, self.cfg
         ctl = getattr(exit_controller, "module", exit_controller)
         native = isinstance(ctl, ExitController)

@@ -201,6 +201,54 @@ def count_exit_ratio(exit_results: Sequence[int], n_layers: int) -> List[float]:
     return [count[i] / max(len(exit_results), 1) for i in range(n_layers)]
 
 
+def merge_multi_list(res):
+    """eval_utils.py:47-51."""
+    return [x for l in res for x in l]
+
+
+def print_and_save(results, success_exit_results, fail_exit_results, step_results, success_llm_time_list, fail_llm_time_list,
+                   sequences, log_dir, n_layer, epoch=None, return_data: bool = False):
+    """The end-of-run report of the reference harness (eval_utils.py:71-118; pinned by tests/golden/metrics.json, which holds the
+    output of the reference's own function): average successful sequence length, chain success rates, exit statistics of the
+    steps of successful sub-tasks, per-task success counts.  Returns (avg_seq_len, avg exit layer + 1) like the reference
+    (+ the ``data`` dict it builds when ``return_data``)."""
+    print(f"Results for Epoch {epoch}:")
+    steps = np.asarray(step_results)
+    avg_seq_len = np.mean(results)
+    chain_sr = {i + 1: sr for i, sr in enumerate(count_success(results))}
+    print(f"Average successful sequence length: {avg_seq_len}")
+    print("Success rates for i instructions in a row:")
+    for i, sr in chain_sr.items():
+        print(f"{i}: {sr * 100:.1f}%")
+    ok_ratio = count_exit_ratio(success_exit_results, n_layer)
+    avg_exit = np.mean(success_exit_results) + 1
+    print(f"Early Exit (success tasks) | Total steps : {len(success_exit_results)} | VLM n_layer: {n_layer} | Average : {avg_exit:.1f} "
+          f"| Min : {np.min(success_exit_results)+1} | Max : {np.max(success_exit_results)+1} | AVG LLM time: {np.mean(success_llm_time_list)*1000:.1f}ms")
+    print(f"Total Successful steps: {np.sum(steps)} | Avg steps per successful subtask: {np.mean(steps):.1f} | Min: {np.min(steps)} | Max: {np.max(steps)}")
+    print("Early exit rates for layer i in successful tasks:")
+    for i, r in enumerate(ok_ratio):
+        print(f"{i+1}: {r * 100:.1f}%")
+    ok, bad = Counter(), Counter()
+    for n_ok, (_, chain) in zip(results, sequences):
+        ok.update(chain[:n_ok])
+        if n_ok < len(chain):
+            bad[chain[n_ok]] += 1                                  # the chain stops at its first failed sub-task
+    total = ok + bad
+    task_info = {}
+    for task in sorted(total):
+        task_info[task] = {"success": ok[task], "total": total[task]}
+        print(f"{task}: {ok[task]} / {total[task]} |  SR: {ok[task] / total[task] * 100:.1f}%")
+    data = {"avg_seq_len": avg_seq_len, "chain_sr": chain_sr, "task_info": task_info}
+    return (avg_seq_len, avg_exit, data) if return_data else (avg_seq_len, avg_exit)
+
+
+def pick_annotation(annotations, subtask: str, subtask_i: int, sequence_i: int) -> str:
+    """eval_utils.py:638-644: ``new_playtable_validation`` style dict (task -> [instruction, ...]) or the enriched per-chain list
+    of ``lang_annotation_cache.json`` (``diverse_inst``: annotations[sequence_i][subtask_i])."""
+    ann = annotations[subtask][0] if isinstance(annotations, dict) else annotations[sequence_i][subtask_i]
+    return ann.split("\n")[0]
+
+
 def rollout(env, model: ModelWrapper, task_checker: Callable, subtask: str, lang_annotation: str, ep_len: int = EP_LEN):
     """One sub-task (one instruction): eval_utils.py:618-684.  Returns (success, exit_layers, n_steps, llm_times)."""
     planned_actions: List[np.ndarray] = []
@@ -230,41 +278,49 @@ def rollout(env, model: ModelWrapper, task_checker: Callable, subtask: str, lang
     return False, exit_layers, step + 1, llm_times
 
 
-def evaluate_sequence(env, model: ModelWrapper, task_checker, eval_sequence: Sequence[str], annotations: Dict[str, List[str]],
-                      ep_len: int = EP_LEN, initial_state=None):
-    """A chain of up to five instructions; stops at the first failure (eval_utils.py:572-615)."""
+def evaluate_sequence(env, model: ModelWrapper, task_checker, eval_sequence: Sequence[str], annotations,
+                      ep_len: int = EP_LEN, initial_state=None, sequence_i: int = -1):
+    """A chain of up to five instructions; stops at the first failure (eval_utils.py:583-624).  Returns (n_ok, exit layers of the
+    successful sub-tasks, of the failed one, steps per successful sub-task, llm times of successful / failed sub-tasks)."""
     env.reset() if initial_state is None else env.reset(**initial_state)
-    n_ok, ok_exits, fail_exits, ok_steps = 0, [], [], []
-    for subtask in eval_sequence:
-        success, exits, n_steps, _ = rollout(env, model, task_checker, subtask, annotations[subtask][0], ep_len)
+    n_ok, ok_exits, fail_exits, ok_steps, ok_llm, fail_llm = 0, [], [], [], [], []
+    for subtask_i, subtask in enumerate(eval_sequence):
+        success, exits, n_steps, llm = rollout(env, model, task_checker, subtask, pick_annotation(annotations, subtask, subtask_i, sequence_i), ep_len)
         if success:
             n_ok += 1
             ok_steps.append(n_steps)
             ok_exits.extend(exits)
+            ok_llm.extend(llm)
         else:
             fail_exits.extend(exits)
+            fail_llm.extend(llm)
             break
-    return n_ok, ok_exits, fail_exits, ok_steps
+    return n_ok, ok_exits, fail_exits, ok_steps, ok_llm, fail_llm
 
 
 def evaluate_policy_ddp(model: ModelWrapper, env, eval_sequences: Sequence[Tuple[object, Sequence[str]]],
-                        annotations: Dict[str, List[str]], task_checker, ep_len: int = EP_LEN) -> Optional[dict]:
-    """eval_utils.py:494-569: this rank's slice of the evaluation chains, then a reduction on rank 0.  Returns the result
+                        annotations, task_checker, ep_len: int = EP_LEN, report: bool = False) -> Optional[dict]:
+    """eval_utils.py:494-580: this rank's slice of the evaluation chains, then a reduction on rank 0.  Returns the result
     dict on rank 0 (avg successful sequence length, chain success rates, exit-layer histogram of the successful steps,
-    steps/s of this job), None elsewhere."""
+    steps/s of this job), None elsewhere.  ``annotations``: dict task -> [instruction] or the per-chain list of
+    ``lang_annotation_cache.json`` (the reference's ``diverse_inst``).  ``report``: single-process runs print the reference's
+    ``print_and_save`` report from the raw per-chain lists."""
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     mine = ddist.shard_sequences(list(eval_sequences), rank, world)
+    base = rank * len(mine)
     n_layer = model.model.module.lang_encoder.config.n_layers
-    results, ok_exits, fail_exits, ok_steps = [], [], [], []
+    results, ok_exits, fail_exits, ok_steps, ok_llm, fail_llm = [], [], [], [], [], []
     t0 = time.perf_counter()
-    for initial_state, seq in mine:
-        n_ok, oe, fe, st = evaluate_sequence(env, model, task_checker, seq, annotations, ep_len, initial_state)
+    for local_i, (initial_state, seq) in enumerate(mine):
+        n_ok, oe, fe, st, ol, fl = evaluate_sequence(env, model, task_checker, seq, annotations, ep_len, initial_state, base + local_i)
         results.append(n_ok)
         ok_exits.extend(oe)
         fail_exits.extend(fe)
         ok_steps.extend(st)
+        ok_llm.extend(ol)
+        fail_llm.extend(fl)
     wall = time.perf_counter() - t0
     # exit statistics over the steps of SUCCESSFUL sub-tasks, like print_and_save (eval_utils.py:83-91); the `llm_time` slot
     # carries this rank's wall time, so steps/s of the whole job = n_steps_all / (sum of walls / world)
@@ -275,4 +331,6 @@ def evaluate_policy_ddp(model: ModelWrapper, env, eval_sequences: Sequence[Tuple
     out["wall_s_mean"] = out.pop("llm_time") / world
     out["steps_per_s"] = out["n_steps_all"] / max(out["wall_s_mean"], 1e-9)
     out["avg_steps_per_success"] = float(np.mean(ok_steps)) if ok_steps else float("nan")   # this rank's sub-tasks
+    if report and world == 1 and ok_exits:
+        print_and_save(results, ok_exits, fail_exits, ok_steps, ok_llm, fail_llm, mine, None, n_layer, 0)
     return out if rank == 0 else None

@@ -141,11 +141,18 @@ def generate_action_values(args, model, value_net: ActionValueNet, calvin_loader
     for batch in calvin_loader:
         images, (input_ids, attention_mask), gripper = batch[0], batch[1], batch[3]
         assert images.shape[1] == W, (images.shape, W)
-        for b in range(images.shape[0]):
-            idx = torch.randint(0, len(exit_ids), (W,), generator=generator)
-            rand_layers = [exit_ids[int(i)] for i in idx]
-            ids = input_ids[b:b + 1].to(eng.dev)
-            mask = attention_mask[b:b + 1].to(eng.dev) if attention_mask is not None else None
-            hid = eng.window_hidden_states(images[b].to(eng.dev, torch.bfloat16), gripper[b].to(eng.dev, torch.bfloat16), ids, mask)
-            out.append(eng.generate_values(hid, rand_layers, value_net.threshold_type))
+        bs = images.shape[0]
+        S = images.shape[-1]
+        # the random exit layer of every (window, time step) - drawn window by window, like one flamingo_mpt.py:485-490 call per window
+        rand_layers = torch.stack([torch.tensor([exit_ids[int(i)] for i in torch.randint(0, len(exit_ids), (W,), generator=generator)])
+                                   for _ in range(bs)])
+        # (bs, W) frames -> bs*W batch rows with the instruction repeated per frame (value_net.py:333-358)
+        ids = input_ids.to(eng.dev).unsqueeze(1).expand(bs, W, input_ids.shape[-1]).reshape(bs * W, -1)
+        mask = None
+        if attention_mask is not None:
+            mask = attention_mask.to(eng.dev).unsqueeze(1).expand(bs, W, attention_mask.shape[-1]).reshape(bs * W, -1)
+        hid = eng.window_hidden_states(images.reshape(bs * W, 3, S, S).to(eng.dev, torch.bfloat16),
+                                       gripper.reshape(bs * W, 3, S, S).to(eng.dev, torch.bfloat16), ids, mask)
+        hid = hid.view(bs, W, *hid.shape[1:])
+        out.append(eng.generate_values(hid, rand_layers, value_net.threshold_type))
     return torch.cat(out, dim=1), None

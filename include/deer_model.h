@@ -53,6 +53,11 @@ int deer_model_bind(deer_model* m, void* arena, void* workspace);
  * and re-lays it out (bf16; MFMA-fragment packing for the LLM projections; conv1 reshaped + zero-padded; Perceiver
  * to_q/to_kv stacked; x-attn to_kv of all layers concatenated).  Returns DEER_ERR_SHAPE for an unknown name / wrong size. */
 int deer_model_load_tensor(deer_model* m, const char* name, const void* src, int src_is_bf16, long numel, void* stream);
+/* host only: adopt the weight arena (and the loaded state) of another model built from the same shape description with a
+ * different n_envs / max_text_len - one copy of the weights serves the single-environment engine, the env-batch engine and the
+ * window-mode (calibration) engine.  `m` still needs its own workspace (deer_model_bind with arena = src's arena, or call this
+ * after binding the workspace). */
+int deer_model_share_weights(deer_model* m, const deer_model* src);
 int deer_model_knows_tensor(const deer_model* m, const char* name);              /* host only: 1 if `name` is a parameter of this model */
 int deer_model_missing_tensors(const deer_model* m, char* buf, int buflen);      /* host only: count of REQUIRED tensors not loaded; names (newline separated) into buf */
 /* host only: location of a named buffer (bytes from the base).  which = 0 arena, 1 workspace.  Workspace names: "img", "vx",

@@ -402,6 +402,124 @@ class _OracleVisual(nn.Module):
         return t[:, 0], t
 
 
+def build_ref_mptflamingo(cfg, sd):
+    """The reference's MPTFlamingo around the reference's MosaicGPT loop (stand-in blocks) and the oracle-hosted ViT."""
+    lm, mod = build_ref_lang_encoder(cfg, sd)
+    extend_instance(lm, FlamingoLMMixin)
+    lm.set_decoder_layers_attr_name("transformer.blocks")
+    venc_mod = nn.Module()
+    venc_mod.visual = _OracleVisual(cfg, sd)
+    model = MPTFlamingo(venc_mod, lm, cfg.eoc_token_id, cfg.media_token_id, vis_dim=cfg.vit_width,
+                        cross_attn_every_n_layers=cfg.cross_attn_every_n_layers, window_size=cfg.window_size,
+                        use_gripper=True, fusion_mode="post", llm="mpt_dolly_3b", pooling="max",
+                        early_exit_layer=cfg.early_exit_layer, multi_exit=False, exit_interval=cfg.exit_interval,
+                        mlp_layernorm=True, lstm_layernorm=True, mlp_num_hidden_layers=2, lstm_num_layers=4).eval()
+    return model, lm
+
+
+def gen_ckpt_meta():
+    """tests/golden/ckpt_meta.json: the LAYOUT of the two checkpoint files the reference's eval loads
+    (eval_calvin.py:541-543 OpenFlamingo ``.pt``, strict=False; :572-578 DeeR ``.pth`` dict -> ``model_state_dict`` through the
+    DDP wrapper, strict=False) as the reference's own code produces it: key names + shapes of ``model.state_dict()``, the
+    trainable-only subset ``get_checkpoint`` keeps (train_utils.py:631-638) under the factory's freeze policy
+    (factory.py:203-235, train_params=-1, freeze_embed=False), the ``module.`` prefix DDP adds, and the scalar fields
+    ``save_ckpt`` writes (train_utils.py:31-50).  Data only: no tensor values (weights are seeded, deer_vla_amd.synthetic)."""
+    _dist_init()
+    cfg, seed = llm_cfg(), 7
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
+    model, lm = build_ref_mptflamingo(cfg, sd)
+    # factory.py:203-235
+    model.requires_grad_(False)
+    model.lang_encoder.gated_cross_attn_layers.requires_grad_(True)
+    model.perceiver.requires_grad_(True)
+    # factory.py:227 `get_input_embeddings()`: resolved by transformers-4.x to transformer.wte (this container's 5.x needs the override)
+    model.lang_encoder.transformer.wte.requires_grad_(True)
+    model.lang_encoder.lm_head.requires_grad_(True)
+    if model.sep_lm_head:
+        model.lm_head.requires_grad_(True)
+    if len(model.lm_exits) > 0:
+        model.lm_exit_modules.requires_grad_(True)
+    model.extra_exit.requires_grad_(True)
+    full = model.state_dict()
+    # train_utils.py:631-638 get_checkpoint on the DDP-wrapped model (keys carry the "module." prefix)
+    trainable = {"module." + k: v for k, v in full.items()}
+    for name, p_ in model.named_parameters():
+        if not p_.requires_grad and "normalizer" not in name:
+            del trainable["module." + name]
+    # which state-dict keys are aliases of the same storage (x-attn layers are registered twice: flamingo_lm.py:160-176)
+    by_ptr = {}
+    for k, v in full.items():
+        by_ptr.setdefault(v.data_ptr(), []).append(k)
+    aliases = [ks for ks in by_ptr.values() if len(ks) > 1]
+    meta = {
+        "cfg": cfg.to_dict(), "seed": seed,
+        "full_state_dict": {k: list(v.shape) for k, v in full.items()},
+        "deer_model_state_dict": {k: list(v.shape) for k, v in trainable.items()},
+        "alias_groups": aliases,
+        # train_utils.py:31-50 (what eval_calvin.py:455-476 reads back), values of the released DeeR configuration
+        "deer_ckpt_fields": {"epoch": 3, "head_type": "deterministic", "early_exit_layer": cfg.early_exit_layer, "multi_exit": True,
+                             "share_exit": False, "exit_interval": cfg.exit_interval, "exit_dropout": 0.4, "lstm_dropout": 0.3,
+                             "dropout_mode": "layerwise", "mlp_layernorm": True, "lstm_layernorm": True, "mlp_num_hidden_layers": 2,
+                             "lstm_num_layers": 4, "pooling": "max", "precision": "fp32"},
+    }
+    with open(os.path.join(HERE, "ckpt_meta.json"), "w") as fh:
+        json.dump(meta, fh, indent=0)
+    print("ckpt_meta.json:", len(full), "state-dict keys,", len(trainable), "in the DeeR model_state_dict,", len(aliases), "alias groups")
+
+
+def gen_metrics():
+    """tests/golden/metrics.json: the reference's OWN metric functions (robot_flamingo/eval/eval_utils.py:47-118 ``merge_multi_list``,
+    ``count_success``, ``count_exit_ratio``, ``print_and_save``) executed on seeded per-chain results.  The module itself cannot be
+    imported (calvin_agent / hydra / calvin_env are absent), so the four function definitions are taken from the file where it
+    lies with ``ast`` and compiled as they are.  The evaluation chains are the first 16 entries of the reference's data file
+    ``eval_sequences.json`` with the matching entries of ``lang_annotation_cache.json`` (data files, kept as a fixture)."""
+    import ast
+    import contextlib
+    import io
+    from collections import Counter
+    src = open("/root/reference/robot_flamingo/eval/eval_utils.py").read()
+    tree = ast.parse(src)
+    want = {"merge_multi_list", "count_success", "count_exit_ratio", "print_and_save"}
+    mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want], type_ignores=[])
+    ns = {"Counter": Counter, "np": np}
+    exec(compile(mod, "eval_utils.py[47-118]", "exec"), ns)
+    seqs = json.load(open("/root/reference/eval_sequences.json"))[:16]
+    ann_all = json.load(open("/root/reference/lang_annotation_cache.json"))
+    tasks = sorted({t for _, chain in seqs for t in chain})
+    ann = {t: ann_all[t] for t in tasks} if isinstance(ann_all, dict) else ann_all[:16]   # per-chain enriched instructions
+    g = torch.Generator().manual_seed(11)
+    n_layer = 12
+    exits = [1, 3, 5, 7, 9, 11]
+    per_chain = []
+    for _, chain in seqs:
+        n_ok = int(torch.randint(0, 6, (1,), generator=g))
+        ok_exits, fail_exits, ok_steps, ok_llm, fail_llm = [], [], [], [], []
+        for k in range(min(n_ok + 1, 5)):
+            n_steps = int(torch.randint(20, 120, (1,), generator=g)) if k < n_ok else 360
+            ex = [exits[int(i)] for i in torch.randint(0, 6, (n_steps,), generator=g)]
+            tm = [round(float(t), 5) for t in (torch.rand(n_steps, generator=g) * 4e-3)]
+            if k < n_ok:
+                ok_exits.extend(ex); ok_steps.append(n_steps); ok_llm.extend(tm)
+            else:
+                fail_exits.extend(ex); fail_llm.extend(tm)
+        per_chain.append((n_ok, ok_exits, fail_exits, ok_steps, ok_llm, fail_llm))
+    res_list, success_exit_list, fail_exit_list, step_list, ok_llm_list, fail_llm_list = map(list, zip(*per_chain))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):                      # eval_utils.py:575-577
+        ret = ns["print_and_save"](res_list, ns["merge_multi_list"](success_exit_list), ns["merge_multi_list"](fail_exit_list),
+                                   ns["merge_multi_list"](step_list), ns["merge_multi_list"](ok_llm_list), ns["merge_multi_list"](fail_llm_list),
+                                   seqs, None, n_layer, 0)
+    out = {"n_layer": n_layer, "sequences": seqs, "annotations": ann,
+           "per_chain": [{"n_ok": a, "ok_exits": b, "fail_exits": c, "ok_steps": d, "ok_llm": e, "fail_llm": f} for a, b, c, d, e, f in per_chain],
+           "count_success": ns["count_success"](res_list),
+           "count_exit_ratio_success": ns["count_exit_ratio"](ns["merge_multi_list"](success_exit_list), n_layer),
+           "print_and_save_return": [float(ret[0]), float(ret[1])],
+           "print_and_save_stdout": buf.getvalue()}
+    with open(os.path.join(HERE, "metrics.json"), "w") as fh:
+        json.dump(out, fh)
+    print("metrics.json: avg_seq_len %.3f avg exit %.3f, %d stdout lines" % (ret[0], ret[1], buf.getvalue().count("\n")))
+
+
 def gen_deer_forward():
     """The reference's own MPTFlamingo.forward (+FlamingoLMMixin +MosaicGPT loop +Perceiver +x-attn
     +DeterministicDecoder +ExitController) end to end on CPU."""
@@ -548,6 +666,12 @@ def gen_hf_clip():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                                   # e.g. `make_golden.py gen_ckpt_meta`: regenerate one fixture
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
+    gen_ckpt_meta()
+    gen_metrics()
     gen_perceiver()
     gen_xattn()
     gen_flamingo_layer()

@@ -1,0 +1,135 @@
+"""Checkpoint loader: files in the REFERENCE's formats - an OpenFlamingo ``.pt`` (flat state dict), a DeeR ``.pth``
+(``save_ckpt`` dict, ``module.``-prefixed trainable-only ``model_state_dict``), an open_clip and an HF-MPT state dict - are written
+from the layout the reference's own code produced (tests/golden/ckpt_meta.json, made by make_golden.py::gen_ckpt_meta from the
+reference's ``state_dict()`` / ``get_checkpoint``) filled with seeded tensors, loaded back through deer_vla_amd.checkpoint, and
+(GPU) the loaded engine must reproduce the reference's own forward (tests/golden/deer_forward.npz: same config and seed)."""
+import json
+import os
+
+import pytest
+import torch
+
+from deer_vla_amd import checkpoint as ck
+from deer_vla_amd import synthetic as syn
+from deer_vla_amd.config import DeerConfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CKPT_NAME = "RobotFlamingoDBG_mpt_dolly_3b_ws_12_mtp_aug_10_4_traj_cons_ws_12_mpt_dolly_3b_layer_5_multie_intv=2_mlpdrp=0.4_layerwise_lstmdrp=0.3_aug_10_4_3.pth"
+
+
+def write_reference_format_files(tmp_path):
+    meta = json.load(open(os.path.join(HERE, "golden", "ckpt_meta.json")))
+    cfg = DeerConfig(**meta["cfg"])
+    sd = syn.make_synthetic_state(cfg, meta["seed"], bf16_round=True)
+    other = syn.make_synthetic_state(cfg, meta["seed"] + 1)                  # values that must be OVERRIDDEN by the later file
+
+    def value(key, src):
+        c = ck.canonical_key(key)
+        if c in src:
+            return src[c].clone()
+        return torch.randn(meta["full_state_dict"].get(key[len("module."):] if key.startswith("module.") else key, [1]))
+
+    # DeeR .pth: save_ckpt dict (train_utils.py:31-50), DDP-prefixed trainable-only state dict (+ alias names of frozen tensors)
+    deer = dict(meta["deer_ckpt_fields"])
+    deer["model_state_dict"] = {k: value(k, sd) for k in meta["deer_model_state_dict"]}
+    deer["optimizer_state_dict"], deer["lr_scheduler_state_dict"] = {}, {}
+    deer["values"] = torch.rand(3, 40)
+    p_deer = os.path.join(tmp_path, CKPT_NAME)
+    torch.save(deer, p_deer)
+    # OpenFlamingo .pt: flat state dict of the perceiver + x-attn layers under their registered (alias) names; values differ
+    of = {k: value(k, other) for k in meta["full_state_dict"] if k.startswith("perceiver.") or k.startswith("lang_encoder.gated_cross_attn_layers.")}
+    p_of = os.path.join(tmp_path, "checkpoint.pt")
+    torch.save(of, p_of)
+    # open_clip state dict: visual.* (+ a text-tower key that must be ignored)
+    clip = {k[len("vision_encoder."):]: v.clone() for k, v in sd.items() if k.startswith("vision_encoder.")}
+    clip["visual.class_embedding"] = clip["visual.class_embedding"].reshape(-1)
+    clip["text_projection"] = torch.randn(4, 4)
+    p_clip = os.path.join(tmp_path, "open_clip_vitl14.pt")
+    torch.save(clip, p_clip)
+    # HF MPT state dict: transformer.blocks.N.* of the UNTRUNCATED model (more layers than DeeR builds) + wte with the
+    # pre-resize vocabulary (3 rows fewer: <|endofchunk|>, <image>, <PAD> are added by the factory)
+    mpt = {}
+    for k, v in other.items():
+        if ".decoder_layer." in k:
+            n = int(k.split(".")[3])
+            mpt["transformer.blocks.%d.%s" % (n, k.split(".decoder_layer.")[1])] = v.clone()
+    for k in list(mpt):
+        if k.startswith("transformer.blocks.0."):
+            mpt[k.replace("blocks.0.", "blocks.%d." % (cfg.n_layers + 2))] = mpt[k].clone()    # a layer beyond early_exit_layer
+    mpt["transformer.wte.weight"] = other["lang_encoder.transformer.wte.weight"][:-3].clone()
+    p_mpt = os.path.join(tmp_path, "mpt.pt")
+    torch.save(mpt, p_mpt)
+    return meta, cfg, sd, other, (p_deer, p_of, p_clip, p_mpt)
+
+
+def test_hyper_parameters_from_file_name_and_checkpoint_dict():
+    a = ck.args_from_checkpoint_name("/ckpts/" + CKPT_NAME)
+    assert a["llm_name"] == "mpt_dolly_3b" and a["window_size"] == 12 and (a["rgb_pad"], a["gripper_pad"]) == (10, 4)
+    assert a["traj_cons"] and not a["text_aug"] and a["multi_step_action"] == 1 and not a["tcp_rel"]
+    b = ck.args_from_checkpoint_name("run_mpt_9b_ws_8_tcp_2_step_latent_4_0.pth")
+    assert b["llm_name"] == "mpt_9b" and b["window_size"] == 8 and b["tcp_rel"] and b["multi_step_action"] == 2 and b["global_latent"] == 4
+    # checkpoint dict: defaults of eval_calvin.py:455-476, the old 'layernorm' key, negative early_exit_layer, max_layer default
+    d = ck.args_from_checkpoint_dict({}, "mpt_dolly_3b")
+    assert d["early_exit_layer"] == 23 and d["max_layer"] == 24 and d["mlp_num_hidden_layers"] == 3 and d["exit_interval"] == 1
+    d = ck.args_from_checkpoint_dict({"early_exit_layer": 11, "exit_interval": 2, "layernorm": True, "lstm_layernorm": True,
+                                      "mlp_num_hidden_layers": 2}, "mpt_dolly_3b", max_layer=4)
+    assert d["mlp_layernorm"] is True and d["max_layer"] == 4
+    cfg = ck.config_from_args(ck.args_from_checkpoint_name(CKPT_NAME), d)
+    assert cfg.early_exit_layer == 4 and cfg.exit_ids() == [1, 3, 4] and cfg.lstm_layernorm and cfg.mlp_num_hidden_layers == 2
+    d9 = ck.args_from_checkpoint_dict({"early_exit_layer": -17, "exit_interval": 2}, "mpt_9b", max_layer=12)
+    c9 = ck.config_from_args({"llm_name": "mpt_9b", "window_size": 12}, d9)
+    assert c9.early_exit_layer == 12 and c9.d_model == 4096 and c9.cross_attn_every_n_layers == 4
+
+
+def test_reference_format_files_round_trip_into_the_canonical_state_dict(tmp_path):
+    meta, cfg0, sd, other, (p_deer, p_of, p_clip, p_mpt) = write_reference_format_files(str(tmp_path))
+    # the reference's DeeR checkpoint layout: DDP prefix, no vision tower, the frozen trunk present only under its alias name
+    keys = list(meta["deer_model_state_dict"])
+    assert all(k.startswith("module.") for k in keys)
+    assert not any("vision_encoder" in k for k in keys)
+    assert any(k.startswith("module.lang_encoder.old_decoder_blocks.") for k in keys)
+    assert not any(".decoder_layer." in k for k in keys)
+    from dataclasses import replace
+    trunk = replace(cfg0, early_exit_layer=99, exit_interval=1, lstm_layernorm=False, mlp_layernorm=False, window_size=3)
+    cfg, sd2, rep = ck.load_checkpoint_files(p_deer, p_of, p_clip, p_mpt, trunk=trunk)
+    # everything the checkpoint determines is recovered from the file name / the checkpoint dict, not from `trunk`
+    cfg0.llm_name = "mpt_dolly_3b"
+    assert cfg.to_dict() == cfg0.to_dict()
+    assert rep["values"].shape == (3, 40) and rep["name_args"]["rgb_pad"] == 10 and rep["ckpt_args"]["dropout_mode"] == "layerwise"
+    # the assembled state dict must be EXACTLY the seeded one: the DeeR file overrides OpenFlamingo / HF MPT (load order of
+    # eval_calvin.py:541-543 then :572-578)
+    assert not rep["missing"], rep["missing"][:5]
+    for k, v in sd.items():
+        assert torch.equal(sd2[k].reshape(v.shape), v), k
+    srcs = [("open_clip", ck.map_open_clip_keys(torch.load(p_clip))), ("hf_mpt", ck.map_hf_mpt_keys(torch.load(p_mpt))),
+            ("openflamingo", torch.load(p_of)), ("deer", torch.load(p_deer, weights_only=False)["model_state_dict"])]
+    assert rep["origin"]["vision_encoder.visual.conv1.weight"] == "open_clip"
+    assert rep["origin"]["perceiver.latents"] == "deer" and rep["origin"]["lang_encoder.transformer.blocks.0.decoder_layer.attn.Wqkv.weight"] == "deer"
+    assert any(k.startswith("module.lm_head.") for k in rep["ignored"]["deer"])           # the sep_lm_head twin of extra_exit is not on the path
+    assert any("blocks.%d." % (cfg0.n_layers + 2) in k for k in rep["ignored"]["hf_mpt"])  # layers beyond early_exit_layer are dropped
+    assert "text_projection" not in sd2
+    # without the DeeR file the OpenFlamingo / HF values would be in place (override order matters)
+    sd3, _ = ck.assemble_state_dict(cfg0, srcs[:3])
+    assert torch.equal(sd3["perceiver.latents"], other["perceiver.latents"])
+    wte = sd3["lang_encoder.transformer.wte.weight"]
+    assert wte.shape[0] == cfg0.vocab_size and float(wte[-3:].abs().sum()) == 0.0           # resized vocabulary: new rows zero
+
+
+@pytest.mark.gpu
+def test_engine_loaded_from_reference_format_files_reproduces_the_reference_forward(tmp_path):
+    from golden_util import load
+    from deer_vla_amd.flamingo_mpt import MPTFlamingo
+    meta, cfg0, sd, other, (p_deer, p_of, p_clip, p_mpt) = write_reference_format_files(str(tmp_path))
+    cfg_g, seed, g = load("deer_forward.npz")
+    assert cfg_g.to_dict() == cfg0.to_dict() and seed == meta["seed"]
+    model, info = ck.build_model_from_checkpoint(p_deer, p_of, p_clip, p_mpt, trunk=cfg0)
+    assert isinstance(model, MPTFlamingo) and model.window_size == 12 and not info["missing"]
+    ids, mask = g["ids"].long(), g["mask"].bool()
+    for eid in (3, -1):
+        model.clear_all_exit_memory()
+        o = model(vision_x=g["rgb"][0].cuda(), lang_x=ids.cuda(), attention_mask=mask.cuda(), vision_gripper=g["grip"][0].cuda(),
+                  exit_id=eid)
+        tag = f"static{eid}"
+        assert o.exit_layer == int(g[tag + "_exit"])
+        assert float((o.logits[0].cpu().reshape(-1) - g[tag + "_pose"].reshape(-1)).abs().max()) < 1e-2
+        assert abs(float(o.logits[1]) - float(g[tag + "_grip"])) < 1e-2

@@ -504,3 +504,80 @@ def test_full_size_mpt7b_openflamingo9b_steps_vs_oracle():
             assert rr["exit_layer"] == ref[s][0], (use_graph, s, rr["exit_layer"], ref[s][0], rr["deltas"][:7], thr)
             assert float((rr["pose"] - ref[s][1]).abs().max()) < ACTION_TOL
 
+
+
+def _window_reference(cfg, sd, frames, W):
+    """oracle hidden states of every layer for every frame of every window: (bs, W, L, T, d)"""
+    model = orc.OracleDeer(sd, cfg)
+    out = []
+    for fr in frames:
+        hid = []
+        for t in range(W):
+            rgb, grip, ids_t, mask = fr[t]
+            h, _ = orc.llm_forward(sd, cfg, ids_t, mask, model.encode_vision(rgb, grip), exit_id=cfg.n_layers - 1)
+            hid.append(torch.stack([x[0] for x in h]))
+        out.append(torch.stack(hid))
+    return torch.stack(out)
+
+
+def test_window_mode_forward_frames_as_batch_rows_vs_oracle(tiny):
+    """MPTFlamingo.forward in window mode (flamingo_mpt.py:463-517 as value_net.py:375-385 calls it): bs*W frames as batch rows,
+    hidden states of every layer, extra_exit over the random-layer history as sequences from a zero state (action_head.py:588-595)."""
+    from deer_vla_amd.flamingo_mpt import MPTFlamingo
+    cfg, sd, _ = tiny
+    W, bs = 4, 3
+    model = MPTFlamingo(cfg, sd, window_size=W)
+    frames = [[syn.synthetic_step_inputs(cfg, 7 * b + t, text_len=9, text_seed=7 + b) for t in range(W)] for b in range(bs)]
+    S = cfg.image_size
+    vx = torch.stack([f[0].reshape(1, 1, 3, S, S) for fr in frames for f in fr])
+    vg = torch.stack([f[1].reshape(1, 1, 3, S, S) for fr in frames for f in fr])
+    ids = torch.cat([f[2] for fr in frames for f in fr])
+    mask = torch.ones_like(ids)
+    out, exit_outputs, extra, rand_feat, rand_idx = model._forward_window(vx, ids, mask, vg, with_gripper_logits=True,
+                                                                         generator=torch.Generator().manual_seed(5))
+    ref = _window_reference(cfg, sd, frames, W)                                  # (bs, W, L, T, d)
+    got = torch.stack(out.hidden_states, dim=1).cpu().view(bs, W, cfg.n_layers, -1, cfg.d_model)
+    assert len(out.hidden_states) == cfg.n_layers and exit_outputs == []
+    assert float((got - ref).norm() / ref.norm()) < 1e-2
+    # the head over the windows: oracle DeterministicDecoder in window mode on the SAME random layers
+    rl = rand_idx.cpu()
+    head = orc.OracleHead(sd, cfg, "extra_exit.")
+    head.window_size = W
+    rf = torch.stack([ref[b, t, int(rl[b, t])] for b in range(bs) for t in range(W)])            # (bs*W, T, d)
+    a_ref, g_ref = head(rf)
+    assert float((extra[0].cpu() - a_ref).abs().max()) < ACTION_TOL and float((extra[1][0].cpu() - g_ref).abs().max()) < ACTION_TOL
+    assert tuple(extra[0].shape) == (bs, W, 6) and tuple(rand_feat.shape) == (bs * W, ids.shape[1], cfg.d_model)
+    # and through the public forward signature (the call of value_net.py:375-385)
+    o2 = model(vision_x=vx.cuda(), lang_x=ids.cuda(), attention_mask=mask.cuda(), vision_gripper=vg.cuda(), with_gripper_logits=True,
+               return_in_feat=True, only_extra_exit=True)
+    assert len(o2) == 5 and len(o2[0].hidden_states) == cfg.n_layers and torch.equal(torch.stack(o2[0].hidden_states), torch.stack(out.hidden_states))
+
+
+def test_window_mode_calibration_full_size_batched_vs_oracle():
+    """the 12-frame history window as batch rows at FULL size (ViT at M = 8*514 rows, trunk at 112 rows):
+    calibration deltas (value_net.py:134-160) of one 12-step window against the fp32 oracle."""
+    cfg = deer_3b(max_layer=12)
+    sd = syn.make_synthetic_state(cfg, 0, std="0.02", bf16_round=True)
+    eng = DeerEngine(cfg, sd)
+    W = 12
+    exit_ids = cfg.exit_ids()
+    frames = [[syn.synthetic_step_inputs(cfg, 100 + t) for t in range(W)]]
+    S = cfg.image_size
+    images = torch.stack([f[0].reshape(3, S, S) for f in frames[0]]).cuda().bfloat16()
+    gripper = torch.stack([f[1].reshape(3, S, S) for f in frames[0]]).cuda().bfloat16()
+    ids = frames[0][0][2].cuda()
+    hid = eng.window_hidden_states(images, gripper, ids, None)                   # (W, L, T, d): two groups of 8 / 4 frames
+    ref = _window_reference(cfg, sd, frames, W)[0]
+    for l in (0, 5, 11):
+        assert float((hid[:, l].cpu() - ref[:, l]).norm() / ref[:, l].norm()) < 2e-2, l
+    g = torch.Generator().manual_seed(4)
+    rl = [exit_ids[int(i)] for i in torch.randint(0, len(exit_ids), (W,), generator=g)]
+    eng.configure_exit(exit_ids, 12, 1)
+    vals = eng.generate_values(hid, rl, "L2")
+    head = orc.OracleHead(sd, cfg, "extra_exit.")
+    head.window_size = W
+    vn = orc.OracleValueNet(exit_ids, head, cfg.exit_interval, W, "L2")
+    feats = tuple(ref[:, l] for l in range(cfg.n_layers))
+    vref = vn(feats, mode="generate", rand_layer_feat=torch.stack([ref[t, rl[t]] for t in range(W)]))
+    assert vals.shape == vref.shape == (len(exit_ids), W - W // 2)
+    assert float((vals - vref).abs().max()) < 5e-3, (vals, vref)
