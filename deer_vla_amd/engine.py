@@ -94,6 +94,8 @@ class DeerEngine:
         self._seq = 0
         self._ids_tag = None
         self._trace = None                            # debugging aid: list of (label, event, host time) per piece
+        self._time_stages = False                     # per-stage GPU times of pipelined steps -> last_stage_ms (eval_time hook)
+        self.last_stage_ms: Dict[str, float] = {}
         # controller configuration (set by configure_exit)
         self.exit_ids = cfg.exit_ids()
         self.ctl_max_layer = self.exit_ids[-1]
@@ -272,6 +274,19 @@ class DeerEngine:
         self.ctl.zero_()
         self._shadow_on = False
         self.cur_step = 0
+
+    def reset_env(self, b: int):
+        """Episode start of ONE environment of the batch (its sub-task changed): clears its LSTM state and control block; the
+        other environments carry on."""
+        self._drain_side_streams()
+        self.h_state[:, b].zero_()
+        self.c_state[:, b].zero_()
+        W = abi.CTL_WORDS
+        keep = self.ctl[:W].clone() if b == 0 else None            # block 0 also holds the batch-global words (shadow flag, host ptr)
+        self.ctl[b * W:(b + 1) * W].zero_()
+        if keep is not None:
+            for k in (abi.CTL_SHADOW, abi.CTL_HOST_PTR, abi.CTL_HOST_PTR + 1):
+                self.ctl[k] = keep[k]
 
     def dynamic_plan(self):
         """Per layer of the dynamic step: (layer, need_pseudo, is_exit, exit slot).  mosaic_gpt_3b.py:397-443; computed by
@@ -494,10 +509,20 @@ class DeerEngine:
                 self.enqueue_llm_static(T, use_mask, exit_id)
             self._graphs[key] = g
         else:
+            tm = self._time_stages
+            if tm:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record(main_st)
             self._replay_vision_chains(main_st, self._side_stream if self._use_side else main_st)
+            if tm:
+                ev[1].record(main_st)
             g.replay()
+            if tm:
+                ev[2].record(main_st)
         self.ctl_host.copy_(self.ctl, non_blocking=True)
         main_st.synchronize()
+        if self._time_stages and "ev" in locals():
+            self.last_stage_ms = {"vision": ev[0].elapsed_time(ev[1]), "llm_and_exit_checks": ev[1].elapsed_time(ev[2])}
         return self.read_result()
 
     def _step_segmented(self, T, use_mask):
@@ -560,7 +585,13 @@ class DeerEngine:
                         raise abi.DeerHipError("no exit verdict from the device within 20 s (check %d)" % (n_checks - 1))
             return hm[abi.HOSTM_DONE] == seq
 
+        tm = self._time_stages
+        if tm:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record(main_st)
         self._replay_vision_chains(main_st, side)
+        if tm:
+            ev[1].record(main_st)
         for i, need_pseudo, is_exit, _ in plan:
             # keep at most LOOKAHEAD trunk layers in flight beyond an undecided check
             while decided < len(exits) and exits[decided] + LOOK < i:
@@ -588,6 +619,11 @@ class DeerEngine:
             done = poll(len(exits))
         if not done:                                             # the forced exit at the last check always fires
             raise abi.DeerHipError("dynamic step finished without an exit verdict")
+        if tm:                                                   # per-stage GPU time of this step (reference hooks: eval_time)
+            main_st.wait_stream(side)
+            ev[2].record(main_st)
+            ev[2].synchronize()
+            self.last_stage_ms = {"vision": ev[0].elapsed_time(ev[1]), "llm_and_exit_checks": ev[1].elapsed_time(ev[2])}
         self._ctl_host_np[:] = hm[W:]                            # keep the ordinary read-back buffer current (ctl_host users)
         return self.read_result()
 

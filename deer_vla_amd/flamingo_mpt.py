@@ -134,12 +134,13 @@ class LangEncoder:
 
 class MPTFlamingo(nn.Module):
     def __init__(self, cfg: DeerConfig, state_dict: Optional[Dict[str, torch.Tensor]] = None, window_size: int = 12,
-                 use_gripper: bool = True, fusion_mode: str = "post", device="cuda", **unused):
+                 use_gripper: bool = True, fusion_mode: str = "post", device="cuda", n_envs: int = 1, **unused):
         super().__init__()
         if not use_gripper or fusion_mode != "post":
             raise NotImplementedError("released DeeR checkpoints use use_gripper=True, fusion_mode='post' (flamingo_mpt.py:380-381)")
         self.cfg = cfg
         self._device = device
+        self.n_envs = n_envs                                      # environments per control step ("one env batch per rank")
         self._sd: Dict[str, torch.Tensor] = dict(state_dict) if state_dict is not None else {}
         self._engine: Optional[DeerEngine] = None
         # attributes read by the CALVIN harness through `.module` (eval_utils.py:192-247,300-331,456,480)
@@ -173,7 +174,7 @@ class MPTFlamingo(nn.Module):
             missing = [k for k in param_shapes(self.cfg) if k not in self._sd]
             if missing:
                 raise RuntimeError(f"{len(missing)} parameters missing before the first forward, e.g. {missing[:3]}")
-            self._engine = DeerEngine(self.cfg, self._sd, device=self._device)
+            self._engine = DeerEngine(self.cfg, self._sd, device=self._device, n_envs=self.n_envs)
             self.extra_exit = DeterministicDecoder(self._engine, self.window_size)
             self.lm_head = self.extra_exit
         return self._engine
@@ -284,6 +285,19 @@ class MPTFlamingo(nn.Module):
                     break
         return CausalLMOutputWithPast(logits=[1.0], hidden_states=hidden, exit_layer=b)
 
+    def step_env_batch(self, vision_x, lang_x, attention_mask, vision_gripper, exit_controller=None, exit_id=None):
+        """One control step of ALL n_envs environments (north_star: one env batch per rank): vision_x / vision_gripper
+        (n_envs, ..., 3, S, S), lang_x / attention_mask (n_envs, T) right-padded.  Returns (pose (n_envs, 6), gripper prob (n_envs,),
+        exit layers list).  Every environment exits at its own layer on the device; LSTM state per environment."""
+        e = self.engine
+        ctl = getattr(exit_controller, "module", exit_controller)
+        if exit_id is None:
+            assert isinstance(ctl, ExitController), "env batches take the native controller (device-side exit gate)"
+            self._sync_controller(ctl)
+        r = e.step(vision_x, vision_gripper, lang_x, attention_mask, exit_id=exit_id)
+        r = r if isinstance(r, list) else [r]
+        return torch.stack([x["pose"] for x in r]), torch.tensor([x["gripper"] for x in r]), [x["exit_layer"] for x in r]
+
     def _forward_window(self, vision_x, lang_x, attention_mask, vision_gripper, with_gripper_logits=False, generator=None):
         """Window mode (flamingo_mpt.py:463-517 as ``generate_action_values`` calls it, value_net.py:375-385): the batch rows are
         bs * window_size frames (one instruction per row); every layer's hidden state is returned, the history fed to
@@ -352,6 +366,7 @@ class MPTFlamingo(nn.Module):
             torch.cuda.synchronize()
             import time
             t0 = time.time()
+            e._time_stages = True                                   # GPU time of the vision tower / trunk + exit checks of this step
         if exit_id is not None or native:
             if native and exit_id is None:
                 self._sync_controller(ctl)
@@ -369,7 +384,12 @@ class MPTFlamingo(nn.Module):
             e.ctl_host.copy_(e.ctl)
         if eval_time:
             torch.cuda.synchronize()
-            self.llm_inference_time = time.time() - t0
+            e._time_stages = False
+            self.forward_time = time.time() - t0
+            st = e.last_stage_ms
+            # the reference times the lang_encoder call only (flamingo_mpt.py:386-417); the vision tower is reported beside it
+            self.llm_inference_time = st["llm_and_exit_checks"] / 1e3 if st else self.forward_time
+            self.vision_time = st["vision"] / 1e3 if st else float("nan")
         T = lang_x.reshape(-1).numel()
         if exit_id is not None or native:
             a = e.ctl.view(torch.float32)[abi.CTL_OUT_ACTION: abi.CTL_OUT_ACTION + 8].clone()

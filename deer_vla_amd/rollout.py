@@ -334,3 +334,126 @@ def evaluate_policy_ddp(model: ModelWrapper, env, eval_sequences: Sequence[Tuple
     if report and world == 1 and ok_exits:
         print_and_save(results, ok_exits, fail_exits, ok_steps, ok_llm, fail_llm, mine, None, n_layer, 0)
     return out if rank == 0 else None
+
+
+# ---------------------------------------------------------------------------------------------- env batch per rank
+class BatchedModelWrapper:
+    """``ModelWrapper`` for ONE ENV BATCH PER RANK (BASELINE north_star): n_envs environments advance in lock step through one
+    control step of the engine; every environment has its own instruction, LSTM history and exit layer.  ``step`` takes the
+    observations / goals of all slots (None for an idle slot) and returns one (7,) float16 action per slot."""
+
+    def __init__(self, model, tokenizer, image_processor, cast_dtype, exit_controller=None, exit_id=None):
+        m = model.module
+        assert m.n_envs > 1, "build the model with n_envs > 1 (create_model_and_transforms(..., n_envs=B))"
+        self.model, self.B = model, m.n_envs
+        self.cast_type = cast_dtype
+        self.text_process_fn = functools.partial(preprocess_text_calvin, tokenizer=tokenizer)
+        self.image_process_fn = functools.partial(preprocess_image, image_processor=image_processor)
+        self.exit_controller, self.exit_id = exit_controller, exit_id
+        self.replan = m.replan
+        self.current_exit_layers = [-1] * self.B
+        self._goals: List[Optional[str]] = [None] * self.B
+        self._text = None
+        self._blank = None
+
+    def reset_env(self, b: int):
+        """start of a sub-task in slot b (eval_utils.py:252-277 for that environment only)"""
+        self.model.module.engine.reset_env(b)
+
+    def step(self, obs_list, goals):
+        S = self.model.module.cfg.image_size
+        if self._blank is None:
+            self._blank = torch.zeros(3, S, S)
+        rgb = torch.stack([self.image_process_fn([o["rgb_obs"]["rgb_static"]])[0] if o is not None else self._blank for o in obs_list])
+        grip = torch.stack([self.image_process_fn([o["rgb_obs"]["rgb_gripper"]])[0] if o is not None else self._blank for o in obs_list])
+        goals = [g if g is not None else "idle" for g in goals]
+        if goals != self._goals:                                   # instructions change only between sub-tasks
+            ids, mask = self.text_process_fn(goals)
+            self._text = (ids.cuda(), mask.cuda())
+            self._goals = list(goals)
+        ids, mask = self._text
+        with torch.no_grad():
+            pose, g, exits = self.model.module.step_env_batch(rgb.to(self.cast_type).cuda(non_blocking=True), ids, mask,
+                                                              grip.to(self.cast_type).cuda(non_blocking=True),
+                                                              exit_controller=self.exit_controller, exit_id=self.exit_id)
+        self.current_exit_layers = exits
+        act = torch.cat([pose, ((g > 0.5).to(pose.dtype).unsqueeze(1) - 0.5) * 2], dim=1)      # eval_utils.py:454-464
+        return act.to(torch.float16).numpy()
+
+
+def evaluate_policy_batched(model: BatchedModelWrapper, envs: Sequence, eval_sequences, annotations, task_checker, ep_len: int = EP_LEN,
+                            report: bool = False) -> Optional[dict]:
+    """``evaluate_policy_ddp`` with one env batch per rank: this rank's chains (same slicing, eval_utils.py:523-527) are dealt
+    to the n_envs slots, which run them concurrently - per slot exactly the reference's chain / sub-task / step loop
+    (eval_utils.py:583-684), per step ONE engine call for all slots.  Metrics reduce like evaluate_policy_ddp."""
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    mine = ddist.shard_sequences(list(eval_sequences), rank, world)
+    base = rank * len(mine)
+    B = model.B
+    assert len(envs) == B
+    n_layer = model.model.module.lang_encoder.config.n_layers
+    queue = list(enumerate(mine))
+    results: Dict[int, int] = {}
+    ok_exits, fail_exits, ok_steps = [], [], []
+    slot = [None] * B                                              # per slot: dict(seq_i, chain, k, step, start, exits, n_ok)
+
+    def start_subtask(b):
+        st = slot[b]
+        envs[b].reset() if st["k"] == 0 else None                 # chain start: environment reset (initial state is the simulator's)
+        model.reset_env(b)
+        st["step"], st["exits"], st["start"] = 0, [], envs[b].get_info()
+        st["goal"] = pick_annotation(annotations, st["chain"][st["k"]], st["k"], base + st["seq_i"])
+
+    def next_chain(b):
+        if not queue:
+            slot[b] = None
+            return
+        i, (_, chain) = queue.pop(0)
+        slot[b] = dict(seq_i=i, chain=list(chain), k=0, n_ok=0)
+        start_subtask(b)
+
+    for b in range(B):
+        next_chain(b)
+    t0 = time.perf_counter()
+    n_steps_all = 0
+    while any(s is not None for s in slot):
+        if model.exit_controller is not None:                      # eval_utils.py:662-663; steps_per_stage == 1 on this path
+            model.exit_controller.module.set_timestep(0)
+        obs = [envs[b].get_obs() if slot[b] is not None else None for b in range(B)]
+        acts = model.step(obs, [slot[b]["goal"] if slot[b] is not None else None for b in range(B)])
+        for b in range(B):
+            st = slot[b]
+            if st is None:
+                continue
+            n_steps_all += 1
+            st["exits"].append(model.current_exit_layers[b])
+            st["step"] += 1
+            _, _, _, info = envs[b].step(acts[b])
+            done_ok = task_checker(st["start"], info, st["chain"][st["k"]])
+            if done_ok or st["step"] >= ep_len:
+                if done_ok:
+                    st["n_ok"] += 1
+                    ok_exits.extend(st["exits"])
+                    ok_steps.append(st["step"])
+                    st["k"] += 1
+                    if st["k"] < len(st["chain"]):
+                        start_subtask(b)
+                        continue
+                else:
+                    fail_exits.extend(st["exits"])
+                results[st["seq_i"]] = st["n_ok"]
+                next_chain(b)
+    wall = time.perf_counter() - t0
+    res = [results[i] for i in range(len(mine))]
+    packed = ddist.pack_metrics(res, ok_exits, n_layer, wall)
+    extra = torch.tensor([float(n_steps_all)], dtype=torch.float64)
+    out = ddist.reduce_metrics(torch.cat([packed, extra]), n_extra=1)
+    out["n_steps_all"] = int(out.pop("extra")[0])
+    out["wall_s_mean"] = out.pop("llm_time") / world
+    out["steps_per_s"] = out["n_steps_all"] / max(out["wall_s_mean"], 1e-9)
+    out["envs_per_rank"] = B
+    if report and world == 1 and ok_exits:
+        print_and_save(res, ok_exits, fail_exits, ok_steps, [0.0], [0.0], mine, None, n_layer, 0)
+    return out if rank == 0 else None

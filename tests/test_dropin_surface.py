@@ -94,3 +94,19 @@ def test_forward_argument_errors(setup):
         model(vision_x=g["rgb"][0].cuda(), lang_x=ids, attention_mask=mask, vision_gripper=g["grip"][0].cuda())
     with pytest.raises(AssertionError):                            # mosaic_gpt_3b.py:300
         model.lang_encoder(ids, mask, exit_controller=lambda h, b: True, exit_id=1)
+
+
+@pytest.mark.gpu
+def test_eval_time_hook_reports_per_stage_gpu_times():
+    """flamingo_mpt.py:386-417: ``eval_time=True`` -> ``llm_inference_time`` = time of the lang_encoder call (here: GPU time of the
+    trunk + exit checks of the step), with the vision tower reported beside it."""
+    from deer_vla_amd import synthetic as syn
+    from deer_vla_amd.config import deer_tiny
+    from deer_vla_amd.flamingo_mpt import MPTFlamingo
+    cfg = deer_tiny()
+    model = MPTFlamingo(cfg, syn.make_synthetic_state(cfg, 3, bf16_round=True))
+    rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, 0)
+    for _ in range(3):                                       # graphs are captured on the first calls
+        o = model(vision_x=rgb.cuda(), lang_x=ids.cuda(), attention_mask=mask.cuda(), vision_gripper=grip.cuda(), exit_id=3, eval_time=True)
+    assert o.exit_layer == 3
+    assert 0.0 < model.llm_inference_time < model.forward_time and 0.0 < model.vision_time < model.forward_time

@@ -96,3 +96,36 @@ def test_chain_evaluation_and_metrics(harness):
     never = ro.steps_task_checker(10 ** 6)
     out = ro.evaluate_policy_ddp(w, env, seqs[:2], ann, never, ep_len=5)
     assert out["avg_seq_len"] == 0.0 and out["n_steps"] == 0 and out["n_steps_all"] == 2 * 5
+
+
+@pytest.mark.gpu
+def test_env_batch_per_rank_evaluation_matches_sequential_bookkeeping():
+    """One env batch per rank through the public surface: create_model_and_transforms(n_envs=3) -> BatchedModelWrapper ->
+    evaluate_policy_batched gives the same chain / step bookkeeping as the one-environment harness on the same chains."""
+    from deer_vla_amd import synthetic as syn
+    from deer_vla_amd.config import deer_tiny
+    from deer_vla_amd.factory import create_model_and_transforms
+    from deer_vla_amd.value_net import ActionValueNet, ExitController
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
+    ann = {"a": ["open the drawer"], "b": ["turn on the light bulb now"], "c": ["push the block left"]}
+    seqs = [(None, ["a", "b", "c"]), (None, ["b", "a"]), (None, ["c"]), (None, ["a", "c", "b"]), (None, ["c", "b"])]
+    outs = []
+    for B in (1, 3):
+        model, proc, tok = create_model_and_transforms("ViT-L-14", "openai", "", "", window_size=12, use_gripper=True, fusion_mode="post",
+                                                       llm_name="mpt_dolly_3b", state_dict=sd, cfg=cfg, n_envs=B)
+        vn = ActionValueNet(model.get_all_exit_idx(), None, cfg.exit_interval, 12, "L2")
+        ctl = ExitController(vn, model.get_all_exit_idx(), max_layer=cfg.early_exit_layer + 1)
+        ctl._set_threshold_value([0.02] * (ctl.real_num_exit - 1) + [1e5])
+        ok = ro.steps_task_checker(4)
+        if B == 1:
+            w = ro.ModelWrapper(model, tok, proc, torch.float32, early_exit=True, exit_controller=ctl)
+            outs.append(ro.evaluate_policy_ddp(w, ro.SyntheticEnv(seed=2), seqs, ann, ok, ep_len=6))
+        else:
+            w = ro.BatchedModelWrapper(model, tok, proc, torch.float32, exit_controller=ctl)
+            outs.append(ro.evaluate_policy_batched(w, [ro.SyntheticEnv(seed=2 + b) for b in range(B)], seqs, ann, ok, ep_len=6))
+    a, b = outs
+    assert a["n_chains"] == b["n_chains"] == 5 and a["avg_seq_len"] == b["avg_seq_len"] == (3 + 2 + 1 + 3 + 2) / 5
+    assert a["n_steps"] == b["n_steps"] == 11 * 4 and b["n_steps_all"] == 44 and b["envs_per_rank"] == 3
+    assert a["chain_sr"] == b["chain_sr"] and sum(b["exit_hist"]) == 44
+    assert all(b["exit_hist"][i] == 0 for i in range(cfg.n_layers) if i not in cfg.exit_ids())
