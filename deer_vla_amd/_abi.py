@@ -42,6 +42,8 @@ SIGNATURES = {
     "deer_head_fc": [P, I, I, I, P, P, P, P, P, P, P, P, I, P, I, F, P, I, I, P],
     "deer_head_final": [P, I, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, I, I, P, F, P],
     "deer_ctl_begin_step": [P, P, I, P],
+    "deer_preprocess_frames": [P, I, I, I, I, P, P, P, P, P, P],
+    "deer_preprocess_scratch_bytes": [I, I, I, I],
     "deer_spin_us": [I, P],
     "deer_hip_arch": [],
     "deer_hip_abi_version": [],
@@ -74,7 +76,7 @@ SIGNATURES = {
     "deer_prof_count": [P],
     "deer_prof_get": [P, I, P, I, P, P, P],
 }
-_RESTYPE = {"deer_hip_arch": c_char_p, "deer_model_arena_bytes": c_long, "deer_model_workspace_bytes": c_long,
+_RESTYPE = {"deer_hip_arch": c_char_p, "deer_model_arena_bytes": c_long, "deer_model_workspace_bytes": c_long, "deer_preprocess_scratch_bytes": c_long,
             "deer_model_destroy": None}
 
 # constants of include/deer_hip.h

@@ -61,13 +61,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
     if (q0 + c < q_len) {
       if (XATTN) {                                           // f32 split-K partials -> sum -> bf16
         const float* qp = reinterpret_cast<const float*>(Qv) + b * q_bstride + h * AM_HD + (long)(q0 + c) * ldq + ks * 32 + g * 8;
-        float4 a0 = float4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-        for (int si = 0; si < q_slabs; ++si) {
-          const float4 x0 = *reinterpret_cast<const float4*>(qp + (long)si * q_slab_stride);
-          const float4 x1 = *reinterpret_cast<const float4*>(qp + (long)si * q_slab_stride + 4);
-          a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
-          a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
-        }
+        const float4 a0 = slab_sum4(qp, q_slabs, q_slab_stride), a1 = slab_sum4(qp + 4, q_slabs, q_slab_stride);
         v = uint4{pack2bf(a0.x, a0.y), pack2bf(a0.z, a0.w), pack2bf(a1.x, a1.y), pack2bf(a1.z, a1.w)};
       } else {
         v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(Qv) + b * q_bstride + h * AM_HD +
@@ -303,12 +297,7 @@ __global__ __launch_bounds__(256) void xattn_small_kernel(const float* __restric
   for (int idx = tid; idx < T * 16; idx += 256) {
     const int t = idx >> 4, d4 = (idx & 15) * 4;
     const float* p = qslab + (long)t * ldqs + h * 64 + d4;
-    float4 a = float4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int s = 0; s < s_in; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(p + (long)s * slab_stride);
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
+    const float4 a = slab_sum4(p, s_in, slab_stride);
     qs[t][d4] = a.x * scale; qs[t][d4 + 1] = a.y * scale; qs[t][d4 + 2] = a.z * scale; qs[t][d4 + 3] = a.w * scale;
   }
   // k, v of this head: 16-byte loads (8 bf16), 8 per media row
@@ -391,12 +380,7 @@ __global__ __launch_bounds__(256) void qkv_reduce_ln_kernel(const float* __restr
     v[j] = float4{0.f, 0.f, 0.f, 0.f};
     const int i4 = threadIdx.x + j * 256;
     if (i4 < n4) {
-      const float* p = slab + base + (long)i4 * 4;
-#pragma unroll 4
-      for (int s = 0; s < s_in; ++s) {
-        const float4 a = *reinterpret_cast<const float4*>(p + (long)s * slab_stride);
-        v[j].x += a.x; v[j].y += a.y; v[j].z += a.z; v[j].w += a.w;
-      }
+      v[j] = slab_sum4(slab + base + (long)i4 * 4, s_in, slab_stride);
     }
   }
   const float* w = (part == 0) ? q_ln_w : (part == 1 ? k_ln_w : nullptr);

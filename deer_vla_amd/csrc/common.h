@@ -83,6 +83,34 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
+// Sum of s_in f32 split-K partial slabs (float4 at p + s*stride), in slab order (deterministic).  The loads are issued in batches
+// of 8 independent requests: one L2 round trip per batch instead of one per slab (the consumers of the skinny GEMM - residual
+// + LayerNorm rows, attention prologues, the next GEMM's staging - are latency-bound on exactly this chain).
+__device__ __forceinline__ float4 slab_sum4(const float* __restrict__ p, int s_in, long stride) {
+  float4 a = float4{0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= s_in; s += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(s + u) * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+  }
+  if (s + 4 <= s_in) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(s + u) * stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    s += 4;
+  }
+  for (; s < s_in; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (long)s * stride);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  return a;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }

@@ -19,6 +19,7 @@
 //    in-kernel cross-workgroup hand-off: deterministic, and a kernel boundary (~1.5 us) is cheaper than
 //    a grid barrier on this chip (MI355X_MICROARCH price list).
 #include "common.h"
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
                                                           const float* __restrict__ Aslab, int s_in, long slab_stride_in,
                                                           int a_mode, const bf16_t* __restrict__ Wp,
                                                           float* __restrict__ part, int M, int N, int K, int KR,
-                                                          const int* ctl) {
+                                                          const int* ctl, int dbg) {
   DEER_RETURN_IF_EXITED(ctl);
   constexpr int MPAD = MT * 16;
   constexpr int KC = 32 * WU;
@@ -92,11 +93,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
           if (a_mode == A_F32) {
             s = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Av) + (long)row * lda + k0 + seg * 4);
           } else {
-            const float* p = Aslab + (long)row * K + k0 + seg * 4;
-            for (int i = 0; i < s_in; ++i) {
-              const float4 v = *reinterpret_cast<const float4*>(p + (long)i * slab_stride_in);
-              s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            }
+            s = slab_sum4(Aslab + (long)row * K + k0 + seg * 4, s_in, slab_stride_in);
             if (a_mode == A_SLABS_GELU) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
           }
         }
@@ -136,18 +133,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
 
   issue(wA, 0);                                            // weights first: they do not depend on the activation
   for (int ch = 0; ch < nchunks; ch += 2) {
-    stage(ch);
+    if (!(dbg & 1)) stage(ch);
     __syncthreads();
     if (ch + 1 < nchunks) issue(wB, ch + 1);
     __builtin_amdgcn_sched_barrier(0);                     // keep the next chunk's loads ahead of this chunk's MFMAs
-    mma(wA, ch);
+    if (!(dbg & 2)) mma(wA, ch); else { for (int u = 0; u < WU; ++u) acc[0][0] += __uint_as_float(wA[u][0]); }
     __syncthreads();
     if (ch + 1 >= nchunks) break;
-    stage(ch + 1);
+    if (!(dbg & 1)) stage(ch + 1);
     __syncthreads();
     if (ch + 2 < nchunks) issue(wA, ch + 2);
     __builtin_amdgcn_sched_barrier(0);
-    mma(wB, ch + 1);
+    if (!(dbg & 2)) mma(wB, ch + 1); else { for (int u = 0; u < WU; ++u) acc[0][0] += __uint_as_float(wB[u][0]); }
     __syncthreads();
   }
   if (!tile_ok) return;
@@ -191,7 +188,8 @@ extern "C" int deer_skinny_splitk(int M, int N, int K) {
   const int mt = skinny_mt(M);
   const int cols = (mt == 1) ? 64 : 256;
   const int groups = (N + cols - 1) / cols;
-  const int want = (mt == 1) ? 512 : 192;
+  static const int want_wide = [] { const char* e = getenv("DEER_SKINNY_WANT"); return e ? atoi(e) : 192; }();   // tuning knob
+  const int want = (mt == 1) ? 512 : want_wide;
   int s = 1;
   while (groups * s < want && (K / (s * 2)) >= 128 && (K % (s * 2 * 32)) == 0) s *= 2;
   return s;
@@ -206,6 +204,7 @@ extern "C" int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int 
   if (a_mode == A_BF16 && (A == nullptr || (lda & 7))) return DEER_ERR_SHAPE;
   if (a_mode == A_F32 && (A == nullptr || (lda & 3))) return DEER_ERR_SHAPE;
   if ((a_mode == A_SLABS || a_mode == A_SLABS_GELU) && (Aslab == nullptr || s_in <= 0)) return DEER_ERR_SHAPE;
+  static const int dbg = [] { const char* e = getenv("DEER_SKINNY_DBG"); return e ? atoi(e) : 0; }();   // ablation only (tools/)
   const int KR = K / splitk;
   const int mt = skinny_mt(M);
   const bool split = (a_mode != A_BF16);
@@ -225,7 +224,7 @@ extern "C" int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int 
       attr_set = true;                                                                                                         \
     }                                                                                                                          \
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW_), smem, st, A, lda, Aslab, s_in, slab_stride_in, a_mode, wp, part, M, N, K,  \
-                       KR, ctl);                                                                                               \
+                       KR, ctl, dbg);                                                                                          \
   } while (0)
 #define DEER_SK_CASE(MT_, NW_, WU_) \
   case MT_: if (split) DEER_SK_LAUNCH(MT_, true, NW_, WU_); else DEER_SK_LAUNCH(MT_, false, NW_, WU_); break

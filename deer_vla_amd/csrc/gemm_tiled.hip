@@ -384,12 +384,13 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
   const bool ring_ok = (K % GT_BK) == 0;
   if (!ring_ok && tile >= 4) return DEER_ERR_SHAPE;
   if (tile < 0 || tile > 44) return DEER_ERR_SHAPE;
+  static const int big_tile = [] { const char* e = getenv("DEER_GEMM_BIG"); return e ? atoi(e) : 17; }();   // 17: 16 waves 32x32 (best in situ, tools/graph_time.py); 28: 8 waves 32x64 (+5 % in the microbenchmark only)
   static const bool u2_ok = [] { const char* e = getenv("DEER_GEMM_U2"); return e == nullptr || e[0] != '0'; }();
   if (tile == 0) {
     // fill the 256 CUs first, then grow the tile (less L2->LDS traffic per flop)
     auto nblk = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
     if (!ring_ok) tile = (nblk(64, 128) >= 256) ? 2 : 1;
-    else if (nblk(128, 128) >= 256) tile = 17;         // big M (env batch / calibration): 128x128 with a SHALLOW ring (64 KB) so two
+    else if (nblk(128, 128) >= 256) tile = big_tile;         // big M (env batch / calibration): 128x128 with a SHALLOW ring (64 KB) so two
                                                        //   workgroups share a CU and one's ds_read phase overlaps the other's MFMAs
     else if (nblk(64, 64) > 512) tile = 8;             // measured on MI355X at M = 257 / 514 (tools/bench_gemm.py):
     else if (nblk(64, 64) > 256 && u2_ok) tile = 16;   //   two co-resident workgroups per CU: two K-steps per barrier (-8..10 %)
@@ -425,6 +426,10 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     case 22: return launch_ring<128, 256, 2, 4, 3>(DEER_ARGS);       // 8 waves, 144 KB ring
     case 23: return launch_ring<256, 256, 4, 4, 2>(DEER_ARGS);       // 16 waves, 128 KB
     case 25: return launch_ring<128, 128, 2, 2, 3>(DEER_ARGS);       // 4 waves, 96 KB
+    case 27: return launch_ring<128, 128, 2, 4, 2>(DEER_ARGS);       // 8 waves (64x32 wave tiles), 64 KB: two workgroups per CU
+    case 28: return launch_ring<128, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves (32x64 wave tiles), 64 KB
+    case 29: return launch_ring<128, 256, 2, 4, 2>(DEER_ARGS);       // 8 waves (64x64), 96 KB
+    case 30: return launch_ring<256, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves (64x64), 96 KB
     case 26: return launch_ring<64, 64, 2, 4, 4, 0, 1, 1>(DEER_ARGS);    // register-pipelined K loop (fragments of k+1 read under the MFMAs of k)
     case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)
     case 34: return launch_ring<64, 64, 2, 4, 4, 2>(DEER_ARGS);

@@ -117,12 +117,7 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
     if (i4 < n4) {
       float4 a = float4{0.f, 0.f, 0.f, 0.f};
       if (slab != nullptr) {
-        const float* p = slab + (long)r * d + (long)i4 * 4;
-#pragma unroll 4
-        for (int s = 0; s < s_in; ++s) {
-          const float4 t = *reinterpret_cast<const float4*>(p + (long)s * slab_stride);
-          a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-        }
+        a = slab_sum4(slab + (long)r * d + (long)i4 * 4, s_in, slab_stride);
         if (bias != nullptr) {
           const float4 t = *reinterpret_cast<const float4*>(bias + (long)i4 * 4);
           a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;

@@ -48,15 +48,49 @@ class ClipImageProcessor:
             img = Image.fromarray(np.asarray(img))
         img = img.convert("RGB")
         w, h = img.size
-        s = self.size / min(w, h)
-        nw, nh = max(self.size, round(w * s)), max(self.size, round(h * s))
+        # torchvision Resize(size): shorter side -> size, longer side int(size * long / short); center_crop offsets int(round(.))
+        nw, nh = (self.size, int(self.size * h / w)) if w <= h else (int(self.size * w / h), self.size)
         img = img.resize((nw, nh), Image.BICUBIC)
-        l, t = (nw - self.size) // 2, (nh - self.size) // 2
+        l, t = int(round((nw - self.size) / 2.0)), int(round((nh - self.size) / 2.0))
         img = img.crop((l, t, l + self.size, t + self.size))
         x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
         mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
         std = torch.tensor(CLIP_STD).view(3, 1, 1)
         return (x - mean) / std
+
+
+class GpuImageProcessor:
+    """The same transform as ``ClipImageProcessor`` on the GPU (csrc/preprocess.hip: PIL's two-pass fixed-point bicubic resampler
+    restated bit-exactly + crop + normalise, two launches per call): uint8 frames (H, W, 3) or (N, H, W, 3) -> (N, 3, S, S) bf16 on the
+    device.  ``on_device = True`` tells ``ModelWrapper`` to hand the raw camera frames over instead of running PIL on the host."""
+    on_device = True
+
+    def __init__(self, size: int = 224, device="cuda"):
+        from . import _abi as abi
+        self.size, self.dev, self.lib, self._abi = size, torch.device(device), abi.lib(), abi
+        import ctypes
+        self._mean = (ctypes.c_float * 3)(*CLIP_MEAN)
+        self._std = (ctypes.c_float * 3)(*CLIP_STD)
+        self._tmp = None
+
+    def __call__(self, frames, out_f32: bool = False) -> torch.Tensor:
+        import ctypes
+        import numpy as np
+        x = torch.as_tensor(np.ascontiguousarray(frames)) if not torch.is_tensor(frames) else frames
+        if x.dim() == 3:
+            x = x.unsqueeze(0)
+        assert x.dtype == torch.uint8 and x.shape[-1] == 3, "uint8 (N, H, W, 3) frames"
+        x = x.to(self.dev, non_blocking=True).contiguous()
+        N, H, W, _ = x.shape
+        need = self.lib.deer_preprocess_scratch_bytes(N, H, W, self.size)
+        if self._tmp is None or self._tmp.numel() < need:
+            self._tmp = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        out = torch.empty(N, 3, self.size, self.size, dtype=torch.float32 if out_f32 else torch.bfloat16, device=self.dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        abi = self._abi
+        abi.check(self.lib.deer_preprocess_frames(abi.ptr(x), N, H, W, self.size, self._mean, self._std, abi.ptr(self._tmp),
+                                                  None if out_f32 else abi.ptr(out), abi.ptr(out) if out_f32 else None, st), "deer_preprocess_frames")
+        return out
 
 
 class SyntheticTokenizer:

@@ -33,7 +33,10 @@ NUM_SEQUENCES = 1000    # eval_utils.py:45 (overridden by --num_seq)
 
 # ---------------------------------------------------------------------------------------------- preprocessing
 def preprocess_image(sample, image_processor) -> torch.Tensor:
-    """data.py:898-902: stack of processed frames, (n, 3, S, S)."""
+    """data.py:898-902: stack of processed frames, (n, 3, S, S).  A processor with ``on_device`` (factory.GpuImageProcessor) takes the
+    raw uint8 frames of the whole list in one call and returns device tensors."""
+    if getattr(image_processor, "on_device", False):
+        return image_processor(np.stack([np.asarray(s) for s in sample]))
     return torch.cat([image_processor(s).unsqueeze(0) for s in sample], dim=0)
 
 

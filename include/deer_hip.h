@@ -194,6 +194,14 @@ int deer_head_final(const float* src, int src_stride, int in_dim, int pro, const
  * number, host mirror pointer lo, hi} or NULL (no stage hold, no mirror). */
 int deer_ctl_begin_step(int* ctl, const int* step_info, int B, void* stream);
 
+/* ---- camera-frame preprocessing (robot_flamingo/data/data.py:898-902 + open_clip eval transform, factory.py:109-112) ----------
+ * uint8 frames [N][H][W][3] -> Resize(S, bicubic, shorter side) -> CenterCrop(S) -> /255 -> Normalize(mean, std) as [N][3][S][S] bf16
+ * and/or f32, bit-exact w.r.t. PIL's two-pass fixed-point resampler (the reference runs PIL on the host).  tmp: device scratch of
+ * deer_preprocess_scratch_bytes(N, H, W, S) bytes; mean / std_: HOST float[3]. */
+int deer_preprocess_frames(const unsigned char* src, int N, int H, int W, int S, const float* mean, const float* std_,
+                           unsigned char* tmp, void* out_bf16, float* out_f32, void* stream);
+long deer_preprocess_scratch_bytes(int N, int H, int W, int S);
+
 /* keeps `stream` busy for ~us microseconds (profiling aid: lets the host enqueue ahead of the GPU) */
 int deer_spin_us(int us, void* stream);
 

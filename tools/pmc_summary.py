@@ -40,8 +40,11 @@ def traffic(fetch_dir, write_dir, out):
         wk = w[cls][0] / max(w[cls][1], 1) if cls in w else 0.0
         classes[cls] = {"fetch_kib_reported": round(fk, 1), "write_kib_reported": round(wk, 1), "dispatches": f[cls][1],
                         "hbm_bytes_per_launch": int(round((2.0 * fk + wk) * 1024))}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench                                          # the stamp bench.py checks: hash of the kernel sources profiled
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, full-depth steps; FETCH_SIZE x2 (gfx950 "
-                       "128-B requests tallied at 64 B), WRITE_SIZE as reported", "classes": classes}, open(out, "w"), indent=1)
+                       "128-B requests tallied at 64 B), WRITE_SIZE as reported", "kernel_source_hash": bench.kernel_source_hash(),
+               "classes": classes}, open(out, "w"), indent=1)
     print(json.dumps(classes, indent=1))
 
 
