@@ -389,6 +389,44 @@ def gen_mosaic_loop():
          ctl=torch.stack(o_ctl.hidden_states), ctl_exit=o_ctl.exit_layer, ctl_calls=np.asarray(calls))
 
 
+def gen_mpt9b_loop():
+    """The reference's own ``MPTModel.forward`` multi-exit loop of the 9B variant (modeling_gpt_9b.py:352-503: fp32 attn bias with
+    the key-padding mask kept as ``attention_mask``, 3-tuple block returns, ``norm_f`` + one extra hidden state only when NO exit
+    fires) on stand-in MPT-7B blocks; no x-attn here."""
+    mod = ref_import.load_mpt_9b()
+    st = sys.modules["deer_mpt7b_pkg._standins"]
+    cfg = DeerConfig(image_size=28, patch_size=14, vit_width=64, vit_layers=1, vit_heads=1, vit_mlp=128, llm_name="mpt_9b",
+                     d_model=128, n_heads=4, n_layers_total=8, vocab_size=100, media_token_id=98, eoc_token_id=97, attn_qk_ln=False,
+                     cross_attn_every_n_layers=10 ** 6, early_exit_layer=5, head_hidden=1024)
+    seed = 9
+    sd = syn.make_synthetic_state(cfg, seed)
+    hf = st.MPTConfig(d_model=cfg.d_model, n_heads=cfg.n_heads, n_layers=cfg.n_layers, max_seq_len=32, vocab_size=cfg.vocab_size)
+    lm = mod.MPTModel(hf).eval()
+    s = {k[len("lang_encoder.transformer."):].replace(".decoder_layer.", "."): v for k, v in sd.items()
+         if k.startswith("lang_encoder.transformer.")}
+    missing, unexpected = lm.load_state_dict(s, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("norm_f") for k in missing), missing
+    with torch.no_grad():
+        lm.norm_f.weight.fill_(1.0)
+    ids = torch.randint(0, 90, (2, 9), generator=torch.Generator().manual_seed(3))
+    mask = torch.ones(2, 9, dtype=torch.bool)
+    mask[1, 6:] = False
+    o_full = lm(ids, attention_mask=mask, output_hidden_states=True, return_dict=True)
+    o_e2 = lm(ids, attention_mask=mask, output_hidden_states=True, return_dict=True, exit_id=2)
+    calls = []
+
+    def ctl(hidden, b):
+        calls.append((len(hidden), b))
+        return b == 3
+    o_ctl = lm(ids, attention_mask=mask, output_hidden_states=True, return_dict=True, exit_controller=ctl)
+    save("mpt9b_loop.npz", cfg, seed, ids=ids, mask=mask,
+         full=torch.stack(o_full.hidden_states), full_exit=o_full.exit_layer,
+         e2=torch.stack(o_e2.hidden_states), e2_exit=o_e2.exit_layer,
+         ctl=torch.stack(o_ctl.hidden_states), ctl_exit=o_ctl.exit_layer, ctl_calls=np.asarray(calls))
+    print("mpt9b_loop.npz: full run", len(o_full.hidden_states), "hidden states (n_layers + norm_f), exit", o_full.exit_layer)
+
+
 class _OracleVisual(nn.Module):
     """Hosts the (un-vendored) ViT inside the reference's MPTFlamingo: ``visual(x) -> (pooled, tokens)``."""
 
@@ -685,6 +723,7 @@ if __name__ == "__main__":
     gen_valuenet_generate()
     gen_thresholds()
     gen_mosaic_loop()
+    gen_mpt9b_loop()
     gen_deer_forward()
     gen_hf_mpt_block()
     gen_hf_clip()

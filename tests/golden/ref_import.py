@@ -83,3 +83,38 @@ def load_mosaic_gpt():
     sys.modules[spec.name] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_mpt_9b():
+    """Returns the module object of the reference's modeling_gpt_9b.py (the MPT-7B / OpenFlamingo-9B variant of the multi-exit
+    loop, :352-503), imported as ``deer_mpt7b_pkg.modeling_gpt_9b`` with this repo's stand-ins (mpt7b_standins.py) as its sibling
+    modules.  transformers-5.x no longer has the two llama rotary classes the file imports by name (unused here: rope is off for
+    MPT-7B, ALiBi): they are aliased to the remaining one."""
+    install_stubs()
+    here = os.path.dirname(os.path.abspath(__file__))
+    pkg_name = "deer_mpt7b_pkg"
+    if pkg_name + ".modeling_gpt_9b" in sys.modules:
+        return sys.modules[pkg_name + ".modeling_gpt_9b"]
+    import transformers.models.llama.modeling_llama as ml
+    for n in ("LlamaDynamicNTKScalingRotaryEmbedding", "LlamaLinearScalingRotaryEmbedding"):
+        if not hasattr(ml, n):
+            setattr(ml, n, ml.LlamaRotaryEmbedding)
+    pkg = types.ModuleType(pkg_name)
+    pkg.__path__ = []
+    sys.modules[pkg_name] = pkg
+    spec = importlib.util.spec_from_file_location(pkg_name + "._standins", os.path.join(here, "mpt7b_standins.py"))
+    st = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = st
+    spec.loader.exec_module(st)
+    for sib in ("attention", "blocks", "custom_embedding", "fc", "ffn", "norm", "configuration_mpt", "adapt_tokenizer",
+                "hf_prefixlm_converter", "meta_init_context", "param_init_fns"):
+        m = types.ModuleType(f"{pkg_name}.{sib}")
+        for k in dir(st):
+            if not k.startswith("__"):
+                setattr(m, k, getattr(st, k))
+        sys.modules[m.__name__] = m
+    spec = importlib.util.spec_from_file_location(pkg_name + ".modeling_gpt_9b", os.path.join(REF, "modeling_gpt_9b.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    return mod

@@ -170,6 +170,32 @@ def test_multi_exit_loop_matches_reference_mosaic_gpt():
         orc.llm_forward(sd, cfg, ids, mask, None, exit_controller=ctl, exit_id=1)
 
 
+def test_multi_exit_loop_matches_reference_mpt_9b_variant():
+    """modeling_gpt_9b.py:352-503 (MPT-7B / OpenFlamingo-9B): the reference's own loop on stand-in blocks - MPT-7B parameter names
+    (norm_1 / ffn.up_proj), no q/k LayerNorm, key-padding mask kept beside the fp32 ALiBi bias, exit_id and exit_controller
+    returns; without an exit the reference appends norm_f(x) as one EXTRA hidden state (training only, :498-501)."""
+    cfg, seed, g = load("mpt9b_loop.npz")
+    assert cfg.llm_name == "mpt_9b" and not cfg.attn_qk_ln
+    sd = state(cfg, seed)
+    ids, mask = g["ids"].long(), g["mask"].bool()
+    hid, ex = orc.llm_forward(sd, cfg, ids, mask, None)
+    assert ex == int(g["full_exit"]) == cfg.n_layers - 1
+    assert g["full"].shape[0] == cfg.n_layers + 1                      # + norm_f(x): never produced on an exit path
+    close(torch.stack(hid), g["full"][: cfg.n_layers], atol=1e-5)
+    hid, ex = orc.llm_forward(sd, cfg, ids, mask, None, exit_id=2)
+    assert ex == int(g["e2_exit"]) == 2 and len(hid) == 3
+    close(torch.stack(hid), g["e2"], atol=1e-5)
+    calls = []
+
+    def ctl(hidden, b):
+        calls.append((len(hidden), b))
+        return b == 3
+    hid, ex = orc.llm_forward(sd, cfg, ids, mask, None, exit_controller=ctl)
+    assert ex == int(g["ctl_exit"]) == 3
+    assert calls == [tuple(c) for c in g["ctl_calls"].tolist()]
+    close(torch.stack(hid), g["ctl"], atol=1e-5)
+
+
 def test_full_forward_matches_reference_mptflamingo():
     """BASELINE config[0] (fixed exit, B=1, CPU) and the dynamic-exit step protocol, against the
     reference's own MPTFlamingo.forward."""
