@@ -413,7 +413,8 @@ def main():
                                     "realised": [round(res["hist"][e] / tot_, 3) for e in xs_],
                                     "target_avg_layers": round(sum((e + 1) * p for e, p in zip(xs_, pk_)) / sum(pk_), 2)}
     if world > 1:   # lets the driver verify that RCCL really saw N ranks on N distinct devices
-        info = torch.tensor([rank, local_rank, torch.cuda.current_device()], dtype=torch.int64, device=eng.dev)
+        info = torch.tensor([rank, local_rank, torch.cuda.current_device()], dtype=torch.int64,
+                            device=eng.dev if dist.get_backend() == "nccl" else "cpu")
         allinfo = [torch.zeros_like(info) for _ in range(world)]
         dist.all_gather(allinfo, info)
         out["rccl_world"] = dist.get_world_size()
