@@ -381,6 +381,7 @@ def main():
         print(json.dumps({"full_depth_steps": args.full_depth_only}))
         return
     eng, ctl, T = res["eng"], res["ctl"], res["T"]
+    eng_ctl_max = eng.ctl_max_layer
     t_max, value = res["t_max"], res["value"]
 
     out = {
@@ -497,7 +498,20 @@ def main():
         rb["eng"] = None
     if rank == 0:
         if not (args.no_cpu_baseline or world > 1):
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, ctl, args.cpu_budget_s, args.cpu_threads, rank)
+            cb = cpu_baseline(cfg, sd, ctl, args.cpu_budget_s, args.cpu_threads, rank)
+            # the CPU sample starts at the episode start (deep exits while the LSTM warms up), the GPU window sits mid-episode:
+            # a like-for-like figure at the GPU run's realised depth, from the CPU per-stage times
+            ps = cb["per_stage_ms"]
+            xs2 = [e for e in cfg.exit_ids() if e <= eng_ctl_max]
+            tot = max(sum(res["hist"]), 1)
+            e_layers = sum((l + 1) * h for l, h in enumerate(res["hist"])) / tot
+            e_heads = 2.0 + sum((xs2.index(l) + 1) * h for l, h in enumerate(res["hist"]) if h and l in xs2) / tot
+            ms = ps["vision_tower_2xViT_2xPerceiver"] + e_layers * ps["llm_layer"] + e_heads * ps["head_evaluation"]
+            cb["at_matched_depth"] = {"value": round(1e3 / ms, 4), "unit": "action-steps/s", "avg_layers": round(e_layers, 2),
+                                      "head_evaluations": round(e_heads, 2),
+                                      "note": "from per_stage_ms at the exit histogram of the timed GPU window (the CPU sample itself "
+                                              "covers the first steps of an episode, where exits are deep)"}
+            out["cpu_baseline"] = cb
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
