@@ -430,6 +430,8 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     case 28: return launch_ring<128, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves (32x64 wave tiles), 64 KB
     case 29: return launch_ring<128, 256, 2, 4, 2>(DEER_ARGS);       // 8 waves (64x64), 96 KB
     case 30: return launch_ring<256, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves (64x64), 96 KB
+    case 32: return launch_ring<256, 256, 2, 4, 2>(DEER_ARGS);       // 8 waves, 128x64 wave tiles (64 MFMAs per wave per barrier), 128 KB
+    case 33: return launch_ring<256, 128, 2, 4, 3>(DEER_ARGS);       // 8 waves, 128x32 wave tiles, 144 KB ring
     case 26: return launch_ring<64, 64, 2, 4, 4, 0, 1, 1>(DEER_ARGS);    // register-pipelined K loop (fragments of k+1 read under the MFMAs of k)
     case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)
     case 34: return launch_ring<64, 64, 2, 4, 4, 2>(DEER_ARGS);

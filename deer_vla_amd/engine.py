@@ -735,6 +735,8 @@ class DeerEngine:
         out = []
         for b in range(self.B):
             c, f = ci[b], cf[b]
+            if int(c[abi.CTL_EXIT_LAYER]) < 0:
+                raise abi.DeerHipError(f"environment {b}: the step ended without an exit verdict (no exit check was forced)")
             a = f[abi.CTL_OUT_ACTION: abi.CTL_OUT_ACTION + 8].copy()
             out.append(dict(exit_layer=int(c[abi.CTL_EXIT_LAYER]), n_evals=int(c[abi.CTL_N_EVALS]),
                             pose=torch.from_numpy(a[:6]), gripper=float(a[6]), gripper_logit=float(a[7]),
