@@ -28,6 +28,7 @@ SIGNATURES = {
     "deer_attn_mfma_hd64": [P, P, P, P, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
     "deer_attn_mfma_hd64_2seg": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
     "deer_xattn_mfma": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, I, I, F, P, P],
+    "deer_xattn_fused": [P, I, P, P, I, I, P, I, I, P, P, L, I, I, I, F, P, P],
     "deer_xattn_small": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, I, I, F, P, P],
     "deer_mpt_attn_small": [P, I, L, I, I, P, P, F, P, F, P, P, I, I, I, I, P, P],
     "deer_layernorm_rows": [P, L, L, I, I, P, P, P, P, L, L, I, F, P],

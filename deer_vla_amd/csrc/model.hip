@@ -660,15 +660,27 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
     const XattnW& X = L.xa;
     DEER_TRY(resadd(m, R, pp, m->A<float>(X.nw), m->A<float>(X.nb), prev_hidden, ctl, st));
     prev_hidden = nullptr;
-    DEER_TRY(skinny(m, m->A<void>(X.wq), xin, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
-    {
-      Bracket b(m, "deer_xattn_mfma", 0, 0, st);
-      const char* kv = m->Wk<char>(m->kv_all) + (size_t)X.kv_index * 2 * xin * 2;
-      const int n_media = 2 * m->nl;
-      DEER_TRY(deer_xattn_mfma(slab_b, S, stride, xin, kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, ao, 1, xin, T, n_media,
-                               c.xattn_heads, B, 1.0f / sqrtf((float)c.xattn_dim_head), ctl, st));
+    static const bool fused = [] { const char* e = getenv("DEER_XATTN_FUSED"); return e == nullptr || e[0] != '0'; }();
+    const int n_media = 2 * m->nl;
+    const char* kv = m->Wk<char>(m->kv_all) + (size_t)X.kv_index * 2 * xin * 2;
+    if (fused && T <= 32 && (d & 127) == 0) {
+      // to_q -> attention -> to_out in ONE launch; output = one f32 slab per head (xattn_fused.hip)
+      const int mpad = 16 * ((R + 15) / 16);
+      if ((size_t)c.xattn_heads * mpad * d > m->slab_a_elems) return DEER_ERR_SHAPE;
+      Bracket b(m, "deer_xattn_fused", 2.0 * R * d * xin * 2, 2.0 * 2 * xin * d, st);
+      DEER_TRY(deer_xattn_fused(xn, d, m->A<void>(X.wq), kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, n_media, m->A<void>(X.wo),
+                                slab_a, (long)mpad * d, T, c.xattn_heads, B, 1.0f / sqrtf((float)c.xattn_dim_head), ctl, st));
+      S = c.xattn_heads;
+      stride = (long)mpad * d;
+    } else {
+      DEER_TRY(skinny(m, m->A<void>(X.wq), xin, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
+      {
+        Bracket b(m, "deer_xattn_mfma", 0, 0, st);
+        DEER_TRY(deer_xattn_mfma(slab_b, S, stride, xin, kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, ao, 1, xin, T, n_media,
+                                 c.xattn_heads, B, 1.0f / sqrtf((float)c.xattn_dim_head), ctl, st));
+      }
+      DEER_TRY(skinny(m, m->A<void>(X.wo), d, xin, R, slab_a, m->slab_a_elems, ao, xin, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
     }
-    DEER_TRY(skinny(m, m->A<void>(X.wo), d, xin, R, slab_a, m->slab_a_elems, ao, xin, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
     pend = Pending{slab_a, S, stride, m->A<float>(X.ag)};
     DEER_TRY(resadd(m, R, &pend, m->A<float>(X.fnw), m->A<float>(X.fnb), nullptr, ctl, st));
     DEER_TRY(skinny(m, m->A<void>(X.w1), (long)c.xattn_ff_mult * d, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));

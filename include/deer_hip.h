@@ -132,6 +132,13 @@ int deer_attn_mfma_hd64_2seg(const void* Q, const void* K1, const void* V1, cons
 int deer_xattn_mfma(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv, int inner,
                     const int* text_time, int n_per_media, void* out, int out_is_f32, int ldo, int T, int n_kv, int heads,
                     int batch, float scale, const int* ctl, void* stream);
+/* deer_xattn_fused: to_q -> masked cross-attention -> to_out of MaskedCrossAttention (helpers.py:184-233) as ONE launch.  xn: f32
+ * [batch*T, d] (= attn.norm(x)); Wq_p / Wo_p: to_q [inner,d] / to_out [d,inner] packed by deer_pack_weight_mfma16; kv as above;
+ * out: f32 [heads][slab_stride]: slab h = head h's contribution to y = Attn(x) for all rows (the consumer deer_resadd_ln sums
+ * the `heads` slabs, s_in = heads).  T <= 32, n_kv <= 128, d % 128 == 0. */
+int deer_xattn_fused(const float* xn, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
+                     int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch,
+                     float scale, const int* ctl, void* stream);
 /* deer_xattn_small: the same op as fp32 VALU code (kept as a second implementation for cross-checks) (helpers.py:192-232): q from split-K slabs (x scale), kv bf16
  * [n_kv, ldkv] (k at col h*64, v at col inner+h*64), mask text_time[t] == j/n_per_media + 1, rows with
  * text_time == 0 zeroed; out bf16 or f32 [T, ldo]. */

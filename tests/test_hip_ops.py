@@ -489,3 +489,64 @@ def test_xattn_mfma_matches_fp32_implementation(lib):
     abi.check(lib.deer_xattn_mfma(*args, abi.ptr(ob), 0, inner, T, n_kv, heads, B, 64 ** -0.5, abi.ptr(ctl), st()), "mfma")
     torch.cuda.synchronize()
     assert float(ob.float().min()) == 3.0
+
+
+@pytest.mark.parametrize("B,T,d", [(1, 14, 2048), (3, 11, 256), (2, 20, 2048), (8, 14, 2048), (1, 14, 4096)])
+def test_xattn_fused_matches_torch_and_the_three_kernel_path(lib, B, T, d):
+    """to_q -> masked cross-attention -> to_out (helpers.py:184-233) as ONE launch, one f32 slab per head: against fp64 torch
+    math on the same bf16 weights, and against the unfused path (skinny to_q, deer_xattn_mfma, skinny to_out)."""
+    heads, inner, n_kv = 8, 512, 128
+    ldkv = 2 * inner * 2
+    off = 2 * inner
+    R = B * T
+    xn = dev(rnd(R, d, seed=71))
+    Wq = dev(rnd(inner, d, seed=72, scale=d ** -0.5), torch.bfloat16)
+    Wo = dev(rnd(d, inner, seed=73, scale=inner ** -0.5), torch.bfloat16)
+    kv = dev(rnd(B * n_kv, ldkv, seed=74), torch.bfloat16)
+    tt = torch.ones(R, dtype=torch.int32, device="cuda")
+    tt[R - 3] = 0                                            # a token without preceding media -> zero attention row
+    Wq_p, Wo_p = torch.empty_like(Wq), torch.empty_like(Wo)
+    abi.check(lib.deer_pack_weight_mfma16(abi.ptr(Wq), abi.ptr(Wq_p), inner, d, st()), "pack")
+    abi.check(lib.deer_pack_weight_mfma16(abi.ptr(Wo), abi.ptr(Wo_p), d, inner, st()), "pack")
+    mpad = abi.skinny_mpad(R)
+    out = torch.full((heads, mpad, d), float("nan"), device="cuda")
+    abi.check(lib.deer_xattn_fused(abi.ptr(xn), d, abi.ptr(Wq_p), abi.ptr(kv, off * 2), ldkv, inner, abi.ptr(tt), 128, n_kv, abi.ptr(Wo_p),
+                                   abi.ptr(out), mpad * d, T, heads, B, 64 ** -0.5, None, st()), "fused")
+    torch.cuda.synchronize()
+    y = out[:, :R].sum(0)
+    assert torch.isfinite(y).all()
+    # fp64 reference
+    ref = torch.zeros(R, d, dtype=torch.float64, device="cuda")
+    for b in range(B):
+        q = (xn[b * T:(b + 1) * T].double() @ Wq.double().t()).view(T, heads, 64).transpose(0, 1) * 64 ** -0.5
+        kb = kv[b * n_kv:(b + 1) * n_kv, off:off + 2 * inner].double()
+        k = kb[:, :inner].view(n_kv, heads, 64).transpose(0, 1)
+        v = kb[:, inner:].view(n_kv, heads, 64).transpose(0, 1)
+        a = torch.softmax(q @ k.transpose(-1, -2), -1)
+        o = (a @ v).transpose(0, 1).reshape(T, inner)
+        for t in range(T):
+            if int(tt[b * T + t]) == 0:
+                o[t] = 0
+        ref[b * T:(b + 1) * T] = o @ Wo.double().t()
+    assert rel_err(y, ref.float()) < 8e-3                   # q and P enter the MFMAs as bf16 (like the unfused kernels)
+    assert float(y[R - 3].abs().max()) == 0.0
+    # unfused path on the same inputs
+    S = lib.deer_skinny_splitk(R, inner, d)
+    qslab = torch.zeros(S, mpad, inner, device="cuda")
+    abi.check(lib.deer_gemm_skinny(abi.ptr(xn), d, None, 0, 0, abi.A_F32, abi.ptr(Wq_p), abi.ptr(qslab), R, inner, d, S, None, st()), "q")
+    ao = torch.zeros(R, inner, device="cuda")
+    abi.check(lib.deer_xattn_mfma(abi.ptr(qslab), S, mpad * inner, inner, abi.ptr(kv, off * 2), ldkv, inner, abi.ptr(tt), 128, abi.ptr(ao), 1, inner,
+                                  T, n_kv, heads, B, 64 ** -0.5, None, st()), "xattn")
+    S2 = lib.deer_skinny_splitk(R, d, inner)
+    yslab = torch.zeros(S2, mpad, d, device="cuda")
+    abi.check(lib.deer_gemm_skinny(abi.ptr(ao), inner, None, 0, 0, abi.A_F32, abi.ptr(Wo_p), abi.ptr(yslab), R, d, inner, S2, None, st()), "o")
+    torch.cuda.synchronize()
+    assert rel_err(y, yslab.sum(0)[:R]) < 2e-3              # same arithmetic, different summation order of the q projection
+    # exit flag: nothing is written
+    ctl = torch.zeros(abi.CTL_WORDS, dtype=torch.int32, device="cuda")
+    ctl[abi.CTL_ALL_EXITED] = 1
+    out2 = torch.full((heads, mpad, d), 7.0, device="cuda")
+    abi.check(lib.deer_xattn_fused(abi.ptr(xn), d, abi.ptr(Wq_p), abi.ptr(kv, off * 2), ldkv, inner, abi.ptr(tt), 128, n_kv, abi.ptr(Wo_p),
+                                   abi.ptr(out2), mpad * d, T, heads, B, 64 ** -0.5, abi.ptr(ctl), st()), "fused")
+    torch.cuda.synchronize()
+    assert float(out2.min()) == 7.0
