@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--window-reps", type=int, default=10,
+                    help="window-mode (threshold calibration) leg: windows of cfg.window_size frame pairs timed as batch rows (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--full-depth-only", type=int, default=0, metavar="K",
@@ -154,6 +156,45 @@ def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
                              "camera frames batched, M=514); the timed region replays the same kernels as two concurrent "
                              "per-frame chains + head evaluations on a side stream (DESIGN.md 4.1)",
             "classes": classes}
+
+
+def window_leg(eng, cfg, frames, ids, reps):
+    """Window mode (flamingo_mpt.py:485-497 + value_net.py:134-160,375-386): the W frame pairs of a calibration window run as BATCH ROWS
+    (ViT at M = 514*G, trunk at G*T rows, every layer's output kept), then the head replays the window in sequence mode for every
+    exit.  Timed: `reps` windows end to end, inputs resident in HBM.  Its own roofline: the dominant kernel class of the batched
+    full-depth pass, measured in situ with the same event brackets as the step-mode roofline."""
+    W = cfg.window_size
+    G = next(g for g in (8, 7, 6, 5, 4, 3, 2, 1) if W % g == 0 and g * ids.shape[-1] <= 128)
+    rgb = torch.cat([frames[i % len(frames)][0][:1] for i in range(W)])
+    grip = torch.cat([frames[i % len(frames)][1][:1] for i in range(W)])
+    ids1 = ids.reshape(-1, ids.shape[-1])[:1]
+    gen = torch.Generator().manual_seed(7)
+    rl = torch.randint(0, len(eng.exit_ids), (W,), generator=gen)
+    rand_layers = torch.tensor([eng.exit_ids[int(k)] for k in rl])
+    def one(values):
+        hid = eng.window_hidden_states(rgb, grip, ids1, None, group=G)
+        return eng.generate_values(hid, rand_layers, group=G) if values else hid
+    for _ in range(2):
+        one(True)
+    out = {}
+    for key, values in (("hidden_states_only", False), ("with_value_generation", True)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one(values)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[key] = {"windows_per_s": round(reps / dt, 2), "frame_pairs_per_s": round(reps * W / dt, 1), "ms_per_window": round(1e3 * dt / reps, 3)}
+    w = eng.sibling(G)
+    pool = [(torch.cat([frames[(p + i) % len(frames)][0][:1] for i in range(G)]), torch.cat([frames[(p + i) % len(frames)][1][:1] for i in range(G)]))
+            for p in range(4)]
+    ids_g = ids1.expand(G, -1).contiguous()
+    w.configure_exit(eng.exit_ids, eng._max_layer_arg, 1)
+    r = measure_roofline(w, cfg, pool, ids_g)
+    r.pop("schedule_note", None)
+    return {"window_size": W, "frames_per_group": G, "rows": {"vit": 514 * G, "trunk": int(G * ids1.shape[1])}, "reps": reps, **out, "roofline": r,
+            "note": "frames of a window are batch rows of the env-batch engine (same kernels, same arena); value generation = "
+                    "ActionValueNet(mode='generate') with the windows' time steps replayed through the LSTM head"}
 
 
 def lib_hash():
@@ -495,6 +536,8 @@ def main():
                           "avg_exit_layer": round(rb["avg_exit"], 3),
                           "note": "all environments of a rank advance in lock step through the same graph pieces; same kernels, "
                                   "same thresholds solver, per-environment exit decisions on the device"}
+        if args.window_reps > 0 and rank == 0 and world == 1 and rb.get("eng") is not None:
+            out["window"] = window_leg(rb["eng"], cfg, rb["frames"], rb["ids"], args.window_reps)
         rb["eng"] = None
     if rank == 0:
         if not (args.no_cpu_baseline or world > 1):
