@@ -56,6 +56,13 @@ __device__ __forceinline__ void host_store(int* p, int v) {
 __device__ __forceinline__ void check_done(int* ctl0, int slot, int B) {
   int* hm = host_mirror(ctl0);
   if (hm == nullptr) return;
+  if (B == 1) {
+    // one environment = one workgroup: this thread wrote the mirror words itself, and the system-scope RELEASE stores below order
+    // them (an extra __threadfence_system() is a second L2 write-back + wait, ~2 us on the critical path of every exit check)
+    if (((volatile int*)ctl0)[CTL_ALL_EXITED] != 0) host_store(hm + HOSTM_DONE, ctl0[CTL_SEQ]);
+    host_store(hm + HOSTM_PROGRESS, ctl0[CTL_SEQ] * 64 + slot + 1);
+    return;
+  }
   __threadfence_system();
   if (atomicAdd(&ctl0[CTL_EVALS_DONE], 1) + 1 == B) {
     ctl0[CTL_EVALS_DONE] = 0;
@@ -63,6 +70,13 @@ __device__ __forceinline__ void check_done(int* ctl0, int slot, int B) {
     if (((volatile int*)ctl0)[CTL_ALL_EXITED] != 0) host_store(hm + HOSTM_DONE, ctl0[CTL_SEQ]);
     host_store(hm + HOSTM_PROGRESS, ctl0[CTL_SEQ] * 64 + slot + 1);
   }
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned int head_u32x4;
+// 16-byte streaming load (weights are read once per launch: do not displace L2 lines the trunk kernels re-use)
+__device__ __forceinline__ uint4 ld_stream16(const bf16_t* p) {
+  const head_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const head_u32x4*>(p));
+  return uint4{v.x, v.y, v.z, v.w};
 }
 
 __device__ __forceinline__ float dot8(const uint4 w, const float* x) {
@@ -91,6 +105,90 @@ __device__ __forceinline__ void block_ln(const float* __restrict__ src, float* d
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     float y = (src[i] - mean) * rstd * w[i] + b[i];
     dst[i] = relu ? fmaxf(y, 0.f) : y;
+  }
+}
+
+// Staging of activation rows into LDS.  Every load of a batch is requested before the first LDS store: a plain
+// `for (i..) dst[i] = src[i]` loop compiles to one exposed L2 round trip per iteration, which for an 8-environment batch
+// (32-64 iterations per thread) cost more than the weight stream of the whole launch.
+//  * block_copy_to_lds: n contiguous floats (n % 4 == 0, 16-byte aligned), all threads, optional ReLU
+//  * rows_ln_to_lds: LayerNorm of B rows (row b at src + b*stride, n <= 2048, n % 4 == 0): wave w takes rows w, w + nw, ...,
+//    the row lives in registers and the statistics are reduced inside the wave - no block barrier per row.
+__device__ __forceinline__ void block_copy_to_lds(const float* __restrict__ src, float* dst, int n, bool relu) {
+  const int step = blockDim.x * 4;
+  for (int base = threadIdx.x * 4; base < n; base += step * 8) {
+    float4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * step;
+      t[u] = i < n ? *reinterpret_cast<const float4*>(src + i) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * step;
+      if (i < n) {
+        float4 v = t[u];
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(dst + i) = v;
+      }
+    }
+  }
+}
+
+#define HEAD_LN_MAXE 8    // float4 per lane: rows of up to 2048 values
+__device__ __forceinline__ void rows_ln_to_lds(const float* __restrict__ src, long stride, float* dst, int n, int B,
+                                               const float* __restrict__ w, const float* __restrict__ bta, float eps, bool relu) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float4 gw[HEAD_LN_MAXE], gb[HEAD_LN_MAXE];            // gamma / beta do not depend on the row: requested once, up front
+#pragma unroll
+  for (int e = 0; e < HEAD_LN_MAXE; ++e) {
+    const int i = (lane + 64 * e) * 4;
+    gw[e] = i < n ? *reinterpret_cast<const float4*>(w + i) : float4{0.f, 0.f, 0.f, 0.f};
+    gb[e] = i < n ? *reinterpret_cast<const float4*>(bta + i) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int b = wave; b < B; b += nw) {
+    const float* s = src + (long)b * stride;
+    float* d = dst + b * n;
+    float4 v[HEAD_LN_MAXE];
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < HEAD_LN_MAXE; ++e) {
+      const int i = (lane + 64 * e) * 4;
+      v[e] = i < n ? *reinterpret_cast<const float4*>(s + i) : float4{0.f, 0.f, 0.f, 0.f};
+      sum += v[e].x + v[e].y + v[e].z + v[e].w;
+    }
+    const float mean = wave_sum(sum) / n;
+    float var = 0.f;
+#pragma unroll
+    for (int e = 0; e < HEAD_LN_MAXE; ++e)
+      if ((lane + 64 * e) * 4 < n) {
+        const float a = v[e].x - mean, bq = v[e].y - mean, c = v[e].z - mean, dd = v[e].w - mean;
+        var += a * a + bq * bq + c * c + dd * dd;
+      }
+    const float rstd = rsqrtf(wave_sum(var) / n + eps);
+#pragma unroll
+    for (int e = 0; e < HEAD_LN_MAXE; ++e) {
+      const int i = (lane + 64 * e) * 4;
+      if (i < n) {
+        float4 y;
+        y.x = (v[e].x - mean) * rstd * gw[e].x + gb[e].x; y.y = (v[e].y - mean) * rstd * gw[e].y + gb[e].y;
+        y.z = (v[e].z - mean) * rstd * gw[e].z + gb[e].z; y.w = (v[e].w - mean) * rstd * gw[e].w + gb[e].w;
+        if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+        *reinterpret_cast<float4*>(d + i) = y;
+      }
+    }
+  }
+}
+
+// rows (row b at src + b*stride) -> dst [B][n]: LayerNorm'ed, or copied (one block-wide copy when the rows are contiguous)
+__device__ __forceinline__ void rows_to_lds(const float* __restrict__ src, long stride, float* dst, int n, int B, bool ln,
+                                            const float* __restrict__ w, const float* __restrict__ bta, float eps, bool relu) {
+  if (ln) {
+    rows_ln_to_lds(src, stride, dst, n, B, w, bta, eps, relu);
+  } else if (stride == n) {
+    block_copy_to_lds(src, dst, B * n, relu);
+  } else {
+    for (int b = 0; b < B; ++b) block_copy_to_lds(src + (long)b * stride, dst + b * n, n, relu);
   }
 }
 
@@ -145,15 +243,34 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;                    // [B][in_dim]
   float* hs = lds + B * in_dim;       // [B][H]
-  float* red = hs + B * H;            // [16]
-  for (int b = 0; b < B; ++b) {
-    const float* xb = x_src + b * x_bstride;
-    float* xd = xs + b * in_dim;
-    if (x_mode == X_LN) {
-      block_ln(xb, xd, in_dim, ln_w, ln_b, eps, false, red);
-    } else if (x_mode == X_RAW) {
-      for (int i = threadIdx.x; i < in_dim; i += 256) xd[i] = xb[i];
-    } else {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + wave;
+  const int jr = j < H ? j : H - 1;
+  // The launch is latency-bound (24 KB of weights per wave): the first LSTM_PF k-steps of W_ih and the first two of W_hh are
+  // issued BEFORE the activations are staged (pool / LayerNorm / copy into LDS), so the HBM round trip overlaps the staging and
+  // there is one exposed memory latency per launch instead of one per k-step.
+  constexpr int LSTM_PF = 4;
+  uint4 wi[LSTM_PF][4], wh[2][4];
+#pragma unroll
+  for (int u = 0; u < LSTM_PF; ++u) {
+    const int k = u * 512 + lane * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      wi[u][q] = k < in_dim ? ld_stream16(w_ih + ((long)q * H + jr) * in_dim + k) : uint4{0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = u * 512 + lane * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      wh[u][q] = k < H ? ld_stream16(w_hh + ((long)q * H + jr) * H + k) : uint4{0, 0, 0, 0};
+  }
+  if (x_mode == X_LN || x_mode == X_RAW) {
+    rows_to_lds(x_src, x_bstride, xs, in_dim, B, x_mode == X_LN, ln_w, ln_b, eps, false);
+  } else {
+    for (int b = 0; b < B; ++b) {
+      const float* xb = x_src + b * x_bstride;
+      float* xd = xs + b * in_dim;
       for (int i = threadIdx.x; i < in_dim; i += 256) {
         float a = xb[i];
         if (x_mode == X_POOL_MAX) {
@@ -166,18 +283,28 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
       }
     }
   }
-  for (int i = threadIdx.x; i < B * H; i += 256) hs[i] = h_prev[i];
+  block_copy_to_lds(h_prev, hs, B * H, false);
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = blockIdx.x * 4 + wave;
   if (j >= H) return;
   float acc[4][HB_MAX];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int b = 0; b < HB_MAX; ++b) acc[q][b] = 0.f;
-  for (int k = lane * 8; k < in_dim; k += 512) {
+#pragma unroll
+  for (int u = 0; u < LSTM_PF; ++u) {
+    const int k = u * 512 + lane * 8;
+    if (k < in_dim) {
+#pragma unroll
+      for (int b = 0; b < HB_MAX; ++b)
+        if (b < B) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q][b] += dot8(wi[u][q], xs + b * in_dim + k);
+        }
+    }
+  }
+  for (int k = LSTM_PF * 512 + lane * 8; k < in_dim; k += 512) {
     uint4 w[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const uint4*>(w_ih + ((long)q * H + j) * in_dim + k);
@@ -188,7 +315,19 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
         for (int q = 0; q < 4; ++q) acc[q][b] += dot8(w[q], xs + b * in_dim + k);
       }
   }
-  for (int k = lane * 8; k < H; k += 512) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = u * 512 + lane * 8;
+    if (k < H) {
+#pragma unroll
+      for (int b = 0; b < HB_MAX; ++b)
+        if (b < B) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q][b] += dot8(wh[u][q], hs + b * H + k);
+        }
+    }
+  }
+  for (int k = 2 * 512 + lane * 8; k < H; k += 512) {
     uint4 w[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const uint4*>(w_hh + ((long)q * H + j) * H + k);
@@ -199,28 +338,32 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
         for (int q = 0; q < 4; ++q) acc[q][b] += dot8(w[q], hs + b * H + k);
       }
   }
+  // wave totals land in every lane; lane b then does environment b's gate arithmetic (B transcendental chains in parallel)
+  float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
 #pragma unroll
   for (int b = 0; b < HB_MAX; ++b)
     if (b < B) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q][b] = wave_sum(acc[q][b]);
-      if (lane == 0) {
-        const float gi = acc[0][b] + b_ih[j] + b_hh[j];
-        const float gf = acc[1][b] + b_ih[H + j] + b_hh[H + j];
-        const float gg = acc[2][b] + b_ih[2 * H + j] + b_hh[2 * H + j];
-        const float go = acc[3][b] + b_ih[3 * H + j] + b_hh[3 * H + j];
-        const float c2 = sigmoidf_(gf) * c_prev[b * H + j] + sigmoidf_(gi) * tanhf(gg);
-        c_out[b * H + j] = c2;
-        h_out[b * H + j] = sigmoidf_(go) * tanhf(c2);
-      }
+      const float t0 = wave_sum(acc[0][b]), t1 = wave_sum(acc[1][b]), t2 = wave_sum(acc[2][b]), t3 = wave_sum(acc[3][b]);
+      if (lane == b) { gi = t0; gf = t1; gg = t2; go = t3; }
     }
+  if (lane < B) {
+    const int b = lane;
+    gi += b_ih[j] + b_hh[j];
+    gf += b_ih[H + j] + b_hh[H + j];
+    gg += b_ih[2 * H + j] + b_hh[2 * H + j];
+    go += b_ih[3 * H + j] + b_hh[3 * H + j];
+    const float c2 = sigmoidf_(gf) * c_prev[b * H + j] + sigmoidf_(gi) * tanhf(gg);
+    c_out[b * H + j] = c2;
+    h_out[b * H + j] = sigmoidf_(go) * tanhf(c2);
+  }
 }
 
 extern "C" int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w,
                                     const float* ln_b, const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh,
                                     const float* h_prev, const float* c_prev, float* h_out, float* c_out, int H, int B, float eps,
                                     const int* ctl, int kind, int layer, void* stream) {
-  if (in_dim <= 0 || (in_dim & 7) || H <= 0 || (H & 7) || x_mode < 0 || x_mode > 3 || (x_mode == X_LN && ln_w == nullptr) ||
+  if (in_dim <= 0 || (in_dim & 7) || H <= 0 || (H & 7) || x_mode < 0 || x_mode > 3 || (x_mode == X_LN && (ln_w == nullptr || in_dim > 2048)) ||
+      ((x_mode == X_LN || x_mode == X_RAW) && (x_bstride & 3)) ||
       ((x_mode == X_POOL_MAX || x_mode == X_POOL_AVG) && T <= 0) || B <= 0 || B > HB_MAX)
     return DEER_ERR_SHAPE;
   const int smem = (B * (in_dim + H) + 16) * (int)sizeof(float);
@@ -253,31 +396,46 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
   if (head_skip(ctl, kind, layer, B)) return;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;                     // [B][in_dim]
-  float* red = lds + B * in_dim;
   const int grp = blockIdx.y;
   const bool grouped = (pro == PRO_GROUP_LN_RELU || pro == PRO_GROUP_RELU);
-  for (int b = 0; b < B; ++b) {
-    const float* s = src + (long)b * src_stride + (grouped ? (long)grp * in_dim : 0);
-    float* xd = xs + b * in_dim;
-    if (pro == PRO_LN) {
-      block_ln(s, xd, in_dim, lnw0, lnb0, eps, false, red);
-    } else if (pro == PRO_GROUP_LN_RELU) {
-      block_ln(s, xd, in_dim, grp ? lnw1 : lnw0, grp ? lnb1 : lnb0, eps, true, red);
-    } else {
-      for (int i = threadIdx.x; i < in_dim; i += 256) xd[i] = (pro == PRO_GROUP_RELU) ? fmaxf(s[i], 0.f) : s[i];
-    }
-  }
-  __syncthreads();
   const bf16_t* W = grp ? W1 : W0;
   const float* bb = grp ? b1 : b0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = (blockIdx.x * 4 + wave) * 2;
-  if (n0 >= out_dim) return;
-  const bool two = (n0 + 1 < out_dim);
+  const bool live = n0 < out_dim, two = (n0 + 1 < out_dim);
+  // weights of the first two k-steps are requested before the LayerNorm staging (one exposed HBM latency per launch)
+  uint4 pw0[2], pw1[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = u * 512 + lane * 8;
+    pw0[u] = (live && k < in_dim) ? ld_stream16(W + (long)n0 * in_dim + k) : uint4{0, 0, 0, 0};
+    pw1[u] = (two && k < in_dim) ? ld_stream16(W + (long)(n0 + 1) * in_dim + k) : uint4{0, 0, 0, 0};
+  }
+  {
+    const float* s0 = src + (grouped ? (long)grp * in_dim : 0);
+    const bool ln = (pro == PRO_LN || pro == PRO_GROUP_LN_RELU);
+    const float* lw = (pro == PRO_GROUP_LN_RELU && grp) ? lnw1 : lnw0;
+    const float* lb = (pro == PRO_GROUP_LN_RELU && grp) ? lnb1 : lnb0;
+    rows_to_lds(s0, src_stride, xs, in_dim, B, ln, lw, lb, eps, pro == PRO_GROUP_LN_RELU || pro == PRO_GROUP_RELU);
+  }
+  __syncthreads();
+  if (!live) return;
   float a0[HB_MAX], a1[HB_MAX];
 #pragma unroll
   for (int b = 0; b < HB_MAX; ++b) a0[b] = a1[b] = 0.f;
-  for (int k = lane * 8; k < in_dim; k += 512) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = u * 512 + lane * 8;
+    if (k < in_dim) {
+#pragma unroll
+      for (int b = 0; b < HB_MAX; ++b)
+        if (b < B) {
+          a0[b] += dot8(pw0[u], xs + b * in_dim + k);
+          a1[b] += dot8(pw1[u], xs + b * in_dim + k);
+        }
+    }
+  }
+  for (int k = 2 * 512 + lane * 8; k < in_dim; k += 512) {
     const uint4 w0 = *reinterpret_cast<const uint4*>(W + (long)n0 * in_dim + k);
     const uint4 w1 = two ? *reinterpret_cast<const uint4*>(W + (long)(n0 + 1) * in_dim + k) : uint4{0, 0, 0, 0};
 #pragma unroll
@@ -301,7 +459,9 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
 extern "C" int deer_head_fc(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0,
                             const float* lnw1, const float* lnb1, const void* W0, const float* b0, const void* W1, const float* b1,
                             int out_dim, float* dst, int B, float eps, const int* ctl, int kind, int layer, void* stream) {
-  if (in_dim <= 0 || (in_dim & 7) || out_dim <= 0 || pro < 0 || pro > 3 || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
+  if (in_dim <= 0 || (in_dim & 7) || out_dim <= 0 || pro < 0 || pro > 3 || B <= 0 || B > HB_MAX || (src_stride & 3) ||
+      ((pro == PRO_LN || pro == PRO_GROUP_LN_RELU) && in_dim > 2048))
+    return DEER_ERR_SHAPE;
   const int smem = (B * in_dim + 16) * (int)sizeof(float);
   if (smem > 64 * 1024) return DEER_ERR_SHAPE;
   dim3 grid((out_dim + 7) / 8, 2);
@@ -343,6 +503,14 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
       return;
     }
   }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bf16_t* Wrow = (wave < 6) ? Wa + (long)wave * in_dim : Wg;
+  uint4 pw[2];                        // first two k-steps of this wave's output row, requested before the LayerNorm staging
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = u * 512 + lane * 8;
+    pw[u] = (wave < 7 && k < in_dim) ? *reinterpret_cast<const uint4*>(Wrow + k) : uint4{0, 0, 0, 0};
+  }
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xa = lds;                    // actions-head input [in_dim]
   float* xg = lds + in_dim;           // gripper-head input [in_dim]
@@ -367,12 +535,15 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
   }
   if (threadIdx.x == 0) *flag = 0;
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (wave < 7) {
-    const bf16_t* W = (wave < 6) ? Wa + (long)wave * in_dim : Wg;
     const float* x = (wave < 6) ? xa : xg;
     float a = 0.f;
-    for (int k = lane * 8; k < in_dim; k += 512) a += dot8(*reinterpret_cast<const uint4*>(W + k), x + k);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = u * 512 + lane * 8;
+      if (k < in_dim) a += dot8(pw[u], x + k);
+    }
+    for (int k = 2 * 512 + lane * 8; k < in_dim; k += 512) a += dot8(*reinterpret_cast<const uint4*>(Wrow + k), x + k);
     a = wave_sum(a);
     if (lane == 0) outv[wave] = a + ((wave < 6) ? ba[wave] : bg[0]);
   }
@@ -438,8 +609,12 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
           for (int i = 0; i < CTL_WORDS; ++i) hm[CTL_WORDS * (1 + b) + i] = ctl[i];
         // last environment of the batch to exit raises the batch-global flag (one workgroup per environment runs
         // concurrently, hence the device-scope atomic)
-        __threadfence_system();
-        if (atomicAdd(&ctl0[CTL_N_EXITED], 1) + 1 == B) ctl0[CTL_ALL_EXITED] = 1;
+        if (B == 1) {
+          ctl0[CTL_ALL_EXITED] = 1;
+        } else {
+          __threadfence_system();
+          if (atomicAdd(&ctl0[CTL_N_EXITED], 1) + 1 == B) ctl0[CTL_ALL_EXITED] = 1;
+        }
       }
       if (kind == KIND_CHECK) check_done(ctl0, slot, B);
     }
