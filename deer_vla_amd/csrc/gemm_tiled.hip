@@ -383,15 +383,27 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool ring_ok = (K % GT_BK) == 0;
   if (!ring_ok && tile >= 4) return DEER_ERR_SHAPE;
-  if (tile < 0 || tile > 44) return DEER_ERR_SHAPE;
+  if (tile < 0 || tile > 63) return DEER_ERR_SHAPE;
   static const int big_tile = [] { const char* e = getenv("DEER_GEMM_BIG"); return e ? atoi(e) : 17; }();   // 17: 16 waves 32x32 (best in situ, tools/graph_time.py); 28: 8 waves 32x64 (+5 % in the microbenchmark only)
+  static const bool big_sel = [] { const char* e = getenv("DEER_GEMM_SEL"); return e == nullptr || e[0] != '0'; }();
   static const bool u2_ok = [] { const char* e = getenv("DEER_GEMM_U2"); return e == nullptr || e[0] != '0'; }();
   if (tile == 0) {
     // fill the 256 CUs first, then grow the tile (less L2->LDS traffic per flop)
     auto nblk = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
     if (!ring_ok) tile = (nblk(64, 128) >= 256) ? 2 : 1;
-    else if (nblk(128, 128) >= 256) tile = big_tile;         // big M (env batch / calibration): 128x128 with a SHALLOW ring (64 KB) so two
-                                                       //   workgroups share a CU and one's ds_read phase overlaps the other's MFMAs
+    else if (nblk(128, 128) >= 256) {
+      // big M (env batch / calibration window): 64-80 KB rings so that two workgroups share a CU and one's ds_read phase overlaps the
+      // other's MFMAs.  M = 257 * images is always a power of two plus a little, so the choice between 128x128 (16 waves) and the
+      // 192x128 / 128x192 tiles (8 waves, 48x64 wave tiles: 14 fragment reads per 24 MFMAs instead of 8 per 8) is made on the
+      // number of half-rounds each needs on the 256 CUs; a 192-row/column tile costs ~1.35x a 128x128 one (tools/bench_vendor_gemm.py)
+      tile = big_tile;
+      if (big_sel) {
+        auto cost = [&](int bm, int bn, float rel) { return (float)((nblk(bm, bn) + 255) / 256) * rel; };
+        float best = cost(128, 128, 1.0f);
+        if (cost(192, 128, 1.35f) < best) { best = cost(192, 128, 1.35f); tile = 39; }
+        if (cost(128, 192, 1.35f) < best) { best = cost(128, 192, 1.35f); tile = 45; }
+      }
+    }
     else if (nblk(64, 64) > 512) tile = 8;             // measured on MI355X at M = 257 / 514 (tools/bench_gemm.py):
     else if (nblk(64, 64) > 256 && u2_ok) tile = 16;   //   two co-resident workgroups per CU: two K-steps per barrier (-8..10 %)
     else tile = 4;                                     //   64x64 / 8 waves wins whenever it gives <= 2 workgroups per CU (the
@@ -432,6 +444,19 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     case 30: return launch_ring<256, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves (64x64), 96 KB
     case 32: return launch_ring<256, 256, 2, 4, 2>(DEER_ARGS);       // 8 waves, 128x64 wave tiles (64 MFMAs per wave per barrier), 128 KB
     case 33: return launch_ring<256, 128, 2, 4, 3>(DEER_ARGS);       // 8 waves, 128x32 wave tiles, 144 KB ring
+    // row tiles that are NOT a power of two: M = 257 * images is always "a power of two plus a bit" (2056, 4112), so 128-row tiles end
+    // in a nearly empty extra row of workgroups (17 x 32 = 544 for the fc1 of 8 images: one more than the 512 co-resident slots)
+    case 35: return launch_ring<160, 128, 2, 2, 2>(DEER_ARGS);       // 4 waves (80x64 wave tiles), 72 KB: two workgroups per CU
+    case 36: return launch_ring<160, 128, 2, 2, 3>(DEER_ARGS);       // same, 108 KB ring
+    case 37: return launch_ring<160, 64, 2, 2, 2>(DEER_ARGS);        // 4 waves (80x32), 56 KB
+    case 38: return launch_ring<192, 128, 2, 2, 2>(DEER_ARGS);       // 4 waves (96x64), 80 KB
+    case 39: return launch_ring<192, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves (48x64), 80 KB
+    case 40: return launch_ring<192, 128, 2, 4, 2>(DEER_ARGS);       // 8 waves (96x32), 80 KB
+    case 41: return launch_ring<96, 128, 2, 2, 2>(DEER_ARGS);        // 4 waves (48x64), 56 KB
+    case 42: return launch_ring<192, 64, 4, 1, 2>(DEER_ARGS);        // 4 waves (48x64), 64 KB
+    case 43: return launch_ring<128, 192, 2, 4, 2>(DEER_ARGS);       // 8 waves (64x48), 80 KB
+    case 45: return launch_ring<128, 192, 4, 2, 2>(DEER_ARGS);       // 8 waves (32x96), 80 KB
+    case 46: return launch_ring<96, 128, 2, 2, 3>(DEER_ARGS);        // 4 waves (48x64), 84 KB
     case 26: return launch_ring<64, 64, 2, 4, 4, 0, 1, 1>(DEER_ARGS);    // register-pipelined K loop (fragments of k+1 read under the MFMAs of k)
     case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)
     case 34: return launch_ring<64, 64, 2, 4, 4, 2>(DEER_ARGS);

@@ -112,6 +112,10 @@ int pick_split(long M, long N, long K, int target_blocks = 320, int max_split = 
   const long blocks = ((M + 63) / 64) * ((N + 63) / 64);
   int S = 1;
   while (S * 2 <= max_split && blocks * S * 2 <= target_blocks && K % (S * 2 * 64) == 0 && K / (S * 2) >= 128) S *= 2;
+  // env batches (>= 2048 rows): the long-K projection (ViT c_proj, K = 4096) is 128x128-tiled into only 136-264 workgroups of 64
+  // K-steps each; two K halves measured -17 % at 2056 rows, -13 % at 3084, -7 % at 4112 (tools/bench_splitk.py), the short-K
+  // out_proj gains nothing
+  if (S == 1 && M >= 2048 && K >= 4096 && K % 128 == 0) S = 2;
   return S;
 }
 
