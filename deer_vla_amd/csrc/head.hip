@@ -237,9 +237,12 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
                                                               const bf16_t* __restrict__ w_hh, const float* __restrict__ b_ih,
                                                               const float* __restrict__ b_hh, const float* __restrict__ h_prev,
                                                               const float* __restrict__ c_prev, float* __restrict__ h_out,
-                                                              float* __restrict__ c_out, int H, int B, float eps, const int* ctl,
-                                                              int kind, int layer) {
-  if (head_skip(ctl, kind, layer, B)) return;
+                                                              float* __restrict__ c_out, int H, int B_all, int b0, int B, float eps,
+                                                              const int* ctl, int kind, int layer) {
+  // environments b0 .. b0+B-1 of a batch of B_all (the launcher splits a batch whose activations do not fit the LDS)
+  if (head_skip(ctl, kind, layer, B_all)) return;
+  x_src += (long)b0 * x_bstride;
+  h_prev += (long)b0 * H; c_prev += (long)b0 * H; h_out += (long)b0 * H; c_out += (long)b0 * H;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;                    // [B][in_dim]
   float* hs = lds + B * in_dim;       // [B][H]
@@ -366,8 +369,11 @@ extern "C" int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mo
       ((x_mode == X_LN || x_mode == X_RAW) && (x_bstride & 3)) ||
       ((x_mode == X_POOL_MAX || x_mode == X_POOL_AVG) && T <= 0) || B <= 0 || B > HB_MAX)
     return DEER_ERR_SHAPE;
-  const int smem = (B * (in_dim + H) + 16) * (int)sizeof(float);
-  if (smem > 150 * 1024) return DEER_ERR_SHAPE;
+  // [B][in_dim + H] f32 of activations live in LDS: a batch that does not fit 150 KB goes in several launches (8 environments of
+  // the 9B model: in_dim 4096 -> 2 x 4)
+  const int per_env = (in_dim + H) * (int)sizeof(float);
+  const int nb_max = (150 * 1024 - 64) / per_env;
+  if (nb_max < 1) return DEER_ERR_SHAPE;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&head_lstm_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -375,9 +381,14 @@ extern "C" int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mo
       return DEER_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(head_lstm_layer_kernel, dim3((H + 3) / 4), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), x_src,
-                     x_bstride, x_mode, T, in_dim, ln_w, ln_b, reinterpret_cast<const bf16_t*>(w_ih),
-                     reinterpret_cast<const bf16_t*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, eps, ctl, kind, layer);
+  const int chunks = (B + nb_max - 1) / nb_max, nb_even = (B + chunks - 1) / chunks;
+  for (int b0 = 0; b0 < B; b0 += nb_even) {
+    const int nb = B - b0 < nb_even ? B - b0 : nb_even;
+    const int smem = nb * per_env + 64;
+    hipLaunchKernelGGL(head_lstm_layer_kernel, dim3((H + 3) / 4), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), x_src,
+                       x_bstride, x_mode, T, in_dim, ln_w, ln_b, reinterpret_cast<const bf16_t*>(w_ih),
+                       reinterpret_cast<const bf16_t*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, b0, nb, eps, ctl, kind, layer);
+  }
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

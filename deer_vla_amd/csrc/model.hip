@@ -203,10 +203,14 @@ struct Bracket {
   }
 };
 
-#define DEER_TRY(expr)            \
-  do {                            \
-    const int rc_ = (expr);       \
-    if (rc_ != DEER_OK) return rc_; \
+// a failing launch wrapper is exceptional: say which one (the C ABI itself only returns the code)
+#define DEER_TRY(expr)                                                                              \
+  do {                                                                                              \
+    const int rc_ = (expr);                                                                         \
+    if (rc_ != DEER_OK) {                                                                           \
+      fprintf(stderr, "deer_model: %s -> %d (%s:%d)\n", #expr, rc_, __FILE__, __LINE__);             \
+      return rc_;                                                                                   \
+    }                                                                                               \
   } while (0)
 
 // ---- arena layout -----------------------------------------------------------------------------------------------------

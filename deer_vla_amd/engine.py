@@ -295,10 +295,14 @@ class DeerEngine:
     def dynamic_plan(self):
         """Per layer of the dynamic step: (layer, need_pseudo, is_exit, exit slot).  mosaic_gpt_3b.py:397-443; computed by
         the spine (deer_dynamic_plan)."""
-        n = self.cfg.n_layers
-        a, b, c = (ctypes.c_int * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
-        k = self.lib.deer_dynamic_plan(self._h, a, b, c, n)
-        return [(i, bool(a[i]), bool(b[i]), int(c[i])) for i in range(k)]
+        key = (tuple(self.exit_ids), self._max_layer_arg)
+        if getattr(self, "_plan_key", None) != key:               # on the per-step path: ask the spine once per configuration
+            n = self.cfg.n_layers
+            a, b, c = (ctypes.c_int * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
+            k = self.lib.deer_dynamic_plan(self._h, a, b, c, n)
+            self._plan = [(i, bool(a[i]), bool(b[i]), int(c[i])) for i in range(k)]
+            self._plan_key = key
+        return self._plan
 
     def enqueue_dynamic_main(self, T, use_mask, i):
         """Trunk part of layer i of the dynamic step (layer 0 also embeds the tokens)."""
@@ -326,10 +330,11 @@ class DeerEngine:
         self.enqueue_head(exit_id, T, abi.KIND_COMMIT, use_ctl=False, use_mask=use_mask and self.B > 1)
 
     def _drain_side_streams(self):
-        cur = torch.cuda.current_stream()
-        cur.wait_stream(self._side_stream)
-        for st in self._extra_streams:
-            cur.wait_stream(st)
+        cur = None
+        for st in (self._side_stream, *self._extra_streams):
+            if not st.query():                                    # usually idle: the verdict came from the last thing queued on it
+                cur = cur or torch.cuda.current_stream()
+                cur.wait_stream(st)
 
     def _chain_stream(self, c: int):
         """stream of vision chain c >= 2 (chain 0: caller's stream, chain 1: the side stream)"""
@@ -374,9 +379,12 @@ class DeerEngine:
         """rgb / gripper: (B, ..., 3, S, S) one frame per environment (any singleton dims in between; B may be omitted
         when n_envs == 1); ids (B, T) int64 (right-padded to a common T); mask (B, T) bool."""
         S, B = self.cfg.image_size, self.B
-        img = self.img.view(B, 2, 3, S, S)
-        img[:, 0].copy_(rgb.reshape(B, 3, S, S), non_blocking=True)
-        img[:, 1].copy_(gripper.reshape(B, 3, S, S), non_blocking=True)
+        iv = getattr(self, "_img_views", None)
+        if iv is None:
+            img = self.img.view(B, 2, 3, S, S)
+            iv = self._img_views = (img[:, 0], img[:, 1])
+        iv[0].copy_(rgb.view(B, 3, S, S) if rgb.is_contiguous() else rgb.reshape(B, 3, S, S), non_blocking=True)
+        iv[1].copy_(gripper.view(B, 3, S, S) if gripper.is_contiguous() else gripper.reshape(B, 3, S, S), non_blocking=True)
         ids = ids.reshape(B, -1)
         T = ids.shape[1]
         assert 0 < T <= self.max_T and B * T <= self.max_rows
@@ -410,11 +418,6 @@ class DeerEngine:
             exit_id += self.cfg.n_layers
         hold = 1 if (exit_id is None and self.cur_step % self.steps_per_stage != 0) else 0
         seg_mode = self.segmented and use_graph and sync and exit_id is None and not shadow
-        if seg_mode and self._one_graph:
-            si = self._si_np
-            si[0], si[1] = hold, self._seq
-            self.cur_step += 1
-            return self._step_one_graph(T, use_mask)
         self._seq = (self._seq + 1) & 0xFFFFFF
         if self._seq == 0:                                        # wrap: stale mirror words would compare as "newer"
             torch.cuda.current_stream().synchronize()
@@ -427,6 +430,8 @@ class DeerEngine:
             si = self._si_np
             si[0], si[1] = hold, self._seq
             self.cur_step += 1
+            if seg_mode and self._one_graph:
+                return self._step_one_graph(T, use_mask)
             return self._step_segmented(T, use_mask) if seg_mode else self._step_static_pieces(T, use_mask, exit_id)
         si = self.step_info_host[self._seq & 7]
         si[0], si[1], si[2], si[3] = hold, self._seq, 0, 0

@@ -550,3 +550,30 @@ def test_xattn_fused_matches_torch_and_the_three_kernel_path(lib, B, T, d):
                                    abi.ptr(out2), mpad * d, T, heads, B, 64 ** -0.5, abi.ptr(ctl), st()), "fused")
     torch.cuda.synchronize()
     assert float(out2.min()) == 7.0
+
+
+# ------------------------------------------------------------------------------------------ action head, LSTM layer
+@pytest.mark.parametrize("B,in_dim,ln", [(1, 2048, False), (3, 1024, True), (8, 2048, False), (8, 1024, True), (8, 4096, False), (5, 4096, False)])
+def test_head_lstm_layer_env_batch(lib, B, in_dim, ln):
+    """One LSTM cell step for B environments sharing the weight stream (action_head.py:548-558; torch.nn.LSTM gate order i,f,g,o),
+    optional LayerNorm of the input (LayerNormLSTM).  8 x 4096 inputs do not fit the LDS: the launcher splits the batch."""
+    H = 1024
+    x = dev(rnd(B, in_dim, seed=1))
+    h0, c0 = dev(rnd(B, H, seed=2, scale=0.5)), dev(rnd(B, H, seed=3, scale=0.5))
+    wih = dev(rnd(4 * H, in_dim, seed=4, scale=in_dim ** -0.5), torch.bfloat16)
+    whh = dev(rnd(4 * H, H, seed=5, scale=H ** -0.5), torch.bfloat16)
+    bih, bhh = dev(rnd(4 * H, seed=6, scale=0.1)), dev(rnd(4 * H, seed=7, scale=0.1))
+    lw, lb = dev(1.0 + rnd(in_dim, seed=8, scale=0.1)), dev(rnd(in_dim, seed=9, scale=0.1))
+    h1 = torch.full((B, H), float("nan"), device="cuda")
+    c1 = torch.full((B, H), float("nan"), device="cuda")
+    mode = 3 if ln else 0                                  # X_LN / X_RAW
+    abi.check(lib.deer_head_lstm_layer(abi.ptr(x), in_dim, mode, 1, in_dim, abi.ptr(lw) if ln else None, abi.ptr(lb) if ln else None,
+                                       abi.ptr(wih), abi.ptr(whh), abi.ptr(bih), abi.ptr(bhh), abi.ptr(h0), abi.ptr(c0), abi.ptr(h1),
+                                       abi.ptr(c1), H, B, 1e-5, None, 2, 0, st()), "lstm")
+    torch.cuda.synchronize()
+    xin = torch.nn.functional.layer_norm(x, (in_dim,), lw, lb, 1e-5) if ln else x
+    gates = xin @ wih.float().t() + bih + h0 @ whh.float().t() + bhh
+    i, f, g, o = gates.chunk(4, dim=1)
+    c_ref = torch.sigmoid(f) * c0 + torch.sigmoid(i) * torch.tanh(g)
+    h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
+    assert rel_err(c1, c_ref) < 1e-5 and rel_err(h1, h_ref) < 1e-5          # fp32 arithmetic on both sides: summation order only
