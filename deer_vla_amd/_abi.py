@@ -36,7 +36,7 @@ SIGNATURES = {
     "deer_resadd_ln": [P, P, I, L, P, P, P, P, P, P, P, I, I, F, P, P],
     "deer_vit_im2col": [P, I, I, I, I, P, I, P],
     "deer_vit_embed_lnpre": [P, P, P, P, P, P, I, I, I, F, P],
-    "deer_embed_tokens": [P, P, P, P, I, I, I, I, I, P, P],
+    "deer_embed_tokens": [P, P, P, P, I, I, I, I, I, P],
     "deer_broadcast_rows": [P, P, L, I, P],
     "deer_head_pool": [P, P, I, I, I, I, P, P, I, I, P],
     "deer_head_lstm_layer": [P, L, I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, P, I, I, P],

@@ -372,7 +372,6 @@ __global__ __launch_bounds__(256) void qkv_reduce_ln_kernel(const float* __restr
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ float red[16];
   const int t = blockIdx.x, part = blockIdx.y;
-  if (deer_row_exited(ctl, t)) return;                     // env batch: this row's environment already exited
   const long base = (long)t * 3 * d + (long)part * d;
   const int n4 = d >> 2;
   float4 v[4];                                           // d <= 4096
@@ -421,7 +420,6 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
                                                              void* __restrict__ out, int out_is_f32, int ldo, int T,
                                                              const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
-  if (gridDim.y > 1 && deer_env_exited(ctl, blockIdx.y)) return;   // env batch: this environment already exited
   __shared__ __attribute__((aligned(16))) float qs[MA_MAXT][128 + 4];
   __shared__ __attribute__((aligned(16))) float ks[MA_MAXT][128 + 4];
   __shared__ __attribute__((aligned(16))) float vs[MA_MAXT][128 + 4];

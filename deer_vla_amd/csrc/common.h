@@ -32,7 +32,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CTL_SEQ 41          // (block 0 only) sequence number of the current control step (from step_info)
 #define CTL_HOST_PTR 42     // (block 0 only) 2 words: host-visible mirror (pinned, system-coherent) or 0 - see head.hip
 #define CTL_EVALS_DONE 44   // (block 0 only) environments that finished the current exit check
-#define CTL_ROWS_PER_ENV 45 // (block 0 only) trunk rows per environment (T) of the current step, written by deer_embed_tokens; 0 = unknown
 // host mirror layout (int32 words): [0] = seq*64 + number of exit checks completed in this step ("progress"),
 // [1] = seq once every environment has exited ("done"), [64*(1+b) .. +64) = copy of environment b's control block at its exit
 #define HOSTM_PROGRESS 0
@@ -122,18 +121,6 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
   do {                             \
     if ((ctl) != nullptr && ((const volatile int*)(ctl))[CTL_ALL_EXITED] != 0) return; \
   } while (0)
-
-// Per-environment early exit inside an env batch: the trunk rows are [env][T]; once an environment's exit criterion has fired its
-// rows are dead for the rest of the step (its action and LSTM state are committed from the exit layer), so row-wise kernels leave
-// them out.  Needs the rows-per-env word of block 0 (deer_embed_tokens); with one environment EXIT_FLAG == ALL_EXITED.
-__device__ __forceinline__ bool deer_env_exited(const int* ctl, int env) {
-  return ctl != nullptr && ((const volatile int*)ctl)[CTL_ROWS_PER_ENV] > 0 && ((const volatile int*)ctl)[env * CTL_WORDS + CTL_EXIT_FLAG] != 0;
-}
-__device__ __forceinline__ bool deer_row_exited(const int* ctl, int row) {
-  if (ctl == nullptr) return false;
-  const int T = ((const volatile int*)ctl)[CTL_ROWS_PER_ENV];
-  return T > 0 && ((const volatile int*)ctl)[(row / T) * CTL_WORDS + CTL_EXIT_FLAG] != 0;
-}
 
 #define DEER_LAUNCH_CHECK()                                   \
   do {                                                        \

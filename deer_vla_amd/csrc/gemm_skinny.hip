@@ -65,7 +65,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
   const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + (long)tile * ktiles * 64 + lane;
   const int kt_last = (k_end >> 5) - 1;
 
-  unsigned act = (1u << MT) - 1u;                          // live 16-row tiles (env batch, see below)
   u32x4 wA[WU], wB[WU];
   auto issue = [&](u32x4 (&w)[WU], int chunk) {           // fragments of chunk (clamped: loads stay branch-free)
     const int kt0 = (k_begin >> 5) + chunk * WU;
@@ -81,7 +80,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
       for (int idx = tid; idx < MPAD * segs; idx += 64 * NW) {
         const int row = idx / segs, seg = idx - row * segs;
         uint4 v = uint4{0, 0, 0, 0};
-        if (row < M && seg * 8 < klen && ((act >> (row >> 4)) & 1u)) v = *reinterpret_cast<const uint4*>(A + (long)row * lda + k0 + seg * 8);
+        if (row < M && seg * 8 < klen) v = *reinterpret_cast<const uint4*>(A + (long)row * lda + k0 + seg * 8);
         *reinterpret_cast<uint4*>(As + row * pitch + seg * 8) = v;
         if (SPLIT) *reinterpret_cast<uint4*>(Al + row * pitch + seg * 8) = uint4{0, 0, 0, 0};
       }
@@ -90,7 +89,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
       for (int idx = tid; idx < MPAD * segs; idx += 64 * NW) {
         const int row = idx / segs, seg = idx - row * segs;
         float4 s = float4{0.f, 0.f, 0.f, 0.f};
-        if (row < M && seg * 4 < klen && ((act >> (row >> 4)) & 1u)) {
+        if (row < M && seg * 4 < klen) {
           if (a_mode == A_F32) {
             s = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Av) + (long)row * lda + k0 + seg * 4);
           } else {
@@ -121,7 +120,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
         const bf16x8 wf = __builtin_bit_cast(bf16x8, w[u]);
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-          if (MT > 1 && !((act >> j) & 1u)) continue;
           const bf16x8 af = *reinterpret_cast<const bf16x8*>(as + j * 16 * pitch + u * 32);
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[j], 0, 0, 0);
           if (SPLIT) {
@@ -134,22 +132,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
   };
 
   issue(wA, 0);                                            // weights first: they do not depend on the activation
-  // env batch: row tiles whose environments have all exited are neither staged, multiplied nor stored (their slab rows keep
-  // stale values nobody reads) - what remains of the launch is the weight stream plus the live environments' share
-  if (MT > 1 && ctl != nullptr) {
-    const volatile int* cv = ctl;
-    const int Te = cv[CTL_ROWS_PER_ENV];
-    if (Te > 0) {
-      act = 0;
-#pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const int r0 = j * 16, r1 = min(r0 + 15, M - 1);
-        if (r0 < M)
-          for (int e = r0 / Te; e <= r1 / Te; ++e)
-            if (cv[e * CTL_WORDS + CTL_EXIT_FLAG] == 0) act |= 1u << j;
-      }
-    }
-  }
   for (int ch = 0; ch < nchunks; ch += 2) {
     if (!(dbg & 1)) stage(ch);
     __syncthreads();
@@ -170,7 +152,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
   float* dst = part + ((long)ks * MPAD) * N + tile * 16 + g * 4;
 #pragma unroll
   for (int j = 0; j < MT; ++j)
-    if ((act >> j) & 1u) *reinterpret_cast<float4*>(dst + (long)(j * 16 + c) * N) = float4{acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+    *reinterpret_cast<float4*>(dst + (long)(j * 16 + c) * N) = float4{acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
 }
 
 // ---- weight packing: row-major W[N,K] bf16 -> Wp[N/16][K/32][64][8] (done once at load time) ----

@@ -799,16 +799,10 @@ std::vector<PlanRow> dynamic_plan(const deer_model* m) {
   return plan;
 }
 
-// DEER_ENV_SKIP=0: exited environments of an env batch stay in the row-wise trunk kernels (A/B knob; results are identical)
-static bool env_skip() {
-  static const bool on = [] { const char* e = getenv("DEER_ENV_SKIP"); return e == nullptr || atoi(e) != 0; }();
-  return on;
-}
-
 int embed(deer_model* m, int T, void* st) {
   Bracket b(m, "deer_embed_tokens", 0, 0, st);
   const long long* ids = m->ids_override ? m->ids_override : m->Wk<long long>(m->ids);
-  return deer_embed_tokens(ids, m->A<void>(m->wte), m->Wk<float>(m->x), m->Wk<int>(m->text_time), T, m->B, m->d, m->c.vocab_size, m->c.media_token_id, env_skip() ? m->Wk<int>(m->ctl) : nullptr, st);
+  return deer_embed_tokens(ids, m->A<void>(m->wte), m->Wk<float>(m->x), m->Wk<int>(m->text_time), T, m->B, m->d, m->c.vocab_size, m->c.media_token_id, st);
 }
 
 int llm_dynamic(deer_model* m, int T, bool use_mask, bool shadow, void* st) {

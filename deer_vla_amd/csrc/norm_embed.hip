@@ -106,7 +106,6 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ float red[16];
   const int r = blockIdx.x;
-  if (deer_row_exited(ctl, r)) return;                    // env batch: this row's environment already exited
   const int n4 = d >> 2;
   float* xr = x + (long)r * d;
   float4 v[4];                                            // d <= 4096: the row stays in registers
@@ -243,9 +242,8 @@ extern "C" int deer_vit_embed_lnpre(const float* patch, const float* cls, const 
 // x[t] = wte[ids[t]] (bf16 table -> f32 residual stream); text_time[t] = cumsum(ids == media_token_id).
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* __restrict__ ids, const bf16_t* __restrict__ wte,
                                                            float* __restrict__ x, int* __restrict__ text_time, int T, int d,
-                                                           int vocab, int media_id, int* ctl) {
+                                                           int vocab, int media_id) {
   const int row = blockIdx.x, t = row % T, e0 = row - t;   // rows are [env][T]; the media count restarts per environment
-  if (ctl != nullptr && row == 0 && threadIdx.x == 0) ctl[CTL_ROWS_PER_ENV] = T;   // lets row-wise kernels map a row to its env
   long long id = ids[row];
   if (id < 0) id = 0;
   if (id >= vocab) id = vocab - 1;
@@ -258,10 +256,10 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* __re
 }
 
 extern "C" int deer_embed_tokens(const long long* ids, const void* wte, float* x, int* text_time, int T, int batch, int d,
-                                 int vocab, int media_id, int* ctl, void* stream) {
+                                 int vocab, int media_id, void* stream) {
   if (T <= 0 || batch <= 0 || d <= 0 || vocab <= 0) return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(embed_tokens_kernel, dim3(T * batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ids,
-                     reinterpret_cast<const bf16_t*>(wte), x, text_time, T, d, vocab, media_id, ctl);
+                     reinterpret_cast<const bf16_t*>(wte), x, text_time, T, d, vocab, media_id);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

@@ -27,7 +27,6 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
                                                                 const bf16_t* __restrict__ Wo_p, float* __restrict__ out, long slab_stride,
                                                                 int T, int heads, int NS, float scale, const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
-  if (gridDim.y > 1 && deer_env_exited(ctl, blockIdx.y)) return;   // env batch: this environment already exited
   constexpr int MPAD = MT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);                                   // [NW][MPAD][64] f32 partial q

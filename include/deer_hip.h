@@ -41,7 +41,6 @@ extern "C" {
 #define DEER_CTL_OUT_ACTION 16   /* float[8]: pose[6], gripper prob, gripper logit */
 #define DEER_CTL_DELTAS 24       /* float[16] */
 #define DEER_CTL_N_EXITED 40   /* block 0: environments exited so far in this step */
-#define DEER_CTL_ROWS_PER_ENV 45 /* block 0: trunk rows per environment of the current step (deer_embed_tokens) */
 #define DEER_CTL_SEQ 41        /* block 0: sequence number of the current control step (from step_info) */
 #define DEER_CTL_HOST_PTR 42   /* block 0, 2 words: pinned host mirror the verdicts are published to, or 0 */
 #define DEER_CTL_EVALS_DONE 44 /* block 0: environments that finished the current exit check */
@@ -175,11 +174,9 @@ int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_stride, cons
 int deer_vit_im2col(const void* img, int img_is_bf16, int N, int S, int patch, void* out_bf16, int Kpad, void* stream);
 int deer_vit_embed_lnpre(const float* patch, const float* cls, const float* pos, const float* ln_w, const float* ln_b,
                          float* x, int N, int P, int W, float eps, void* stream);
-/* wte lookup (mosaic_gpt_3b.py:341) + text_time = cumsum(ids == media_token_id) (flamingo_lm.py:211, helpers.py:208).
- * ctl (NULL ok): the exit control block; word DEER_CTL_ROWS_PER_ENV of block 0 is set to T so that the row-wise trunk kernels of
- * an env batch can leave out the rows of environments that have already exited in this step. */
+/* wte lookup (mosaic_gpt_3b.py:341) + text_time = cumsum(ids == media_token_id) (flamingo_lm.py:211, helpers.py:208) */
 int deer_embed_tokens(const long long* ids, const void* wte_bf16, float* x, int* text_time, int T, int batch, int d, int vocab,
-                      int media_id, int* ctl, void* stream);
+                      int media_id, void* stream);
 int deer_broadcast_rows(const float* src, float* dst, long n, int batch, void* stream);   /* helpers.py:128 */
 
 /* ---- action head + exit gate (robot_flamingo/models/action_head.py:499-611, value_net.py:105-133,277-297) -----

@@ -389,7 +389,7 @@ def test_embed_tokens_and_text_time(lib):
     ids = torch.tensor([513, 4, 77, 513, 5, 6, 512, 0, 514], device="cuda")
     x = torch.zeros(T, d, device="cuda")
     tt = torch.zeros(T, dtype=torch.int32, device="cuda")
-    abi.check(lib.deer_embed_tokens(abi.ptr(ids), abi.ptr(wte), abi.ptr(x), abi.ptr(tt), T, 1, d, V, 513, None, st()), "embed")
+    abi.check(lib.deer_embed_tokens(abi.ptr(ids), abi.ptr(wte), abi.ptr(x), abi.ptr(tt), T, 1, d, V, 513, st()), "embed")
     torch.cuda.synchronize()
     assert torch.equal(x, wte[ids].float())
     assert tt.tolist() == [1, 1, 1, 2, 2, 2, 2, 2, 2]
@@ -449,7 +449,7 @@ def test_batched_small_attention_and_embedding(lib):
     ids = torch.tensor([[513, 4, 5, 513, 6, 7, 8, 9, 0], [1, 2, 513, 3, 4, 5, 6, 7, 8], [513, 1, 1, 1, 1, 1, 1, 1, 1]], device="cuda")
     x = torch.zeros(B * T, d, device="cuda")
     t2 = torch.zeros(B * T, dtype=torch.int32, device="cuda")
-    abi.check(lib.deer_embed_tokens(abi.ptr(ids), abi.ptr(wte), abi.ptr(x), abi.ptr(t2), T, B, d, V, 513, None, st()), "embed")
+    abi.check(lib.deer_embed_tokens(abi.ptr(ids), abi.ptr(wte), abi.ptr(x), abi.ptr(t2), T, B, d, V, 513, st()), "embed")
     torch.cuda.synchronize()
     assert torch.equal(x, wte[ids.reshape(-1)].float())
     assert t2.view(B, T).tolist() == [[1, 1, 1, 2, 2, 2, 2, 2, 2], [0, 0, 1, 1, 1, 1, 1, 1, 1], [1] * 9]
