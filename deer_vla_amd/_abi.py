@@ -76,9 +76,12 @@ SIGNATURES = {
     "deer_prof_enable": [P, I],
     "deer_prof_count": [P],
     "deer_prof_get": [P, I, P, I, P, P, P],
+    "deer_step_plan_create": [I, P, P, I, P, P, P, I, I, P, P, P],
+    "deer_step_plan_run": [P, I, I, P, P, P, P, P],
+    "deer_step_plan_destroy": [P],
 }
 _RESTYPE = {"deer_hip_arch": c_char_p, "deer_model_arena_bytes": c_long, "deer_model_workspace_bytes": c_long, "deer_preprocess_scratch_bytes": c_long,
-            "deer_model_destroy": None}
+            "deer_model_destroy": None, "deer_step_plan_destroy": None}
 
 # constants of include/deer_hip.h
 CTL_EXIT_FLAG, CTL_EXIT_LAYER, CTL_CUR_EXIT_ID, CTL_HOLD, CTL_N_EVALS, CTL_SHADOW, CTL_COMMITTED, CTL_ALL_EXITED = 0, 1, 2, 3, 4, 5, 6, 7

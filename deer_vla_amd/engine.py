@@ -92,6 +92,8 @@ class DeerEngine:
         # environment, 778 vs 862 at eight)
         self._one_graph = os.environ.get("DEER_ONE_GRAPH") == "1"
         self._side_stream = torch.cuda.Stream(device=self.dev)
+        self._plans = []                                                   # native step plans (own HIP events): freed with the graphs
+        self._native_step = os.environ.get("DEER_NATIVE_STEP", "1") == "1"   # 0: the Python submission / polling loop (debugging)
         self._extra_streams: List[torch.cuda.Stream] = []
         self._use_side = os.environ.get("DEER_SIDE", "1") == "1"          # debugging knobs (README)
         self._lookahead = int(os.environ.get("DEER_LOOKAHEAD", self.LOOKAHEAD))
@@ -112,6 +114,9 @@ class DeerEngine:
         try:
             if getattr(self, "_h", None) and self._h.value:
                 torch.cuda.synchronize(self.dev)
+                for pl in getattr(self, "_plans", []):
+                    self.lib.deer_step_plan_destroy(pl)
+                self._plans = []
                 self.lib.deer_model_destroy(self._h)
                 self._h = ctypes.c_void_p()
         except Exception:                              # interpreter shutdown
@@ -233,7 +238,7 @@ class DeerEngine:
         self.steps_per_stage = steps_per_stage
         if self._graphs:
             torch.cuda.synchronize(self.dev)                      # pieces of the last step may still be replaying
-        self._graphs.clear()
+        self._drop_graphs()
 
     @property
     def thr_type(self) -> int:
@@ -244,7 +249,7 @@ class DeerEngine:
         if v != self._thr_type:
             self._thr_type = int(v)
             self._apply_controller()
-            self._graphs.clear()
+            self._drop_graphs()
 
     @property
     def leq(self) -> int:
@@ -255,7 +260,7 @@ class DeerEngine:
         if int(bool(v)) != self._leq:
             self._leq = int(bool(v))
             self._apply_controller()
-            self._graphs.clear()
+            self._drop_graphs()
 
     @property
     def real_num_exit(self) -> int:
@@ -591,6 +596,36 @@ class DeerEngine:
         main_st.synchronize()
         return self.read_result()
 
+    def _drop_graphs(self):
+        """forget every captured graph (exit configuration changed) together with the native plans built over them"""
+        for pl in self._plans:
+            self.lib.deer_step_plan_destroy(pl)
+        self._plans = []
+        self._graphs.clear()
+
+    def _make_step_plan(self, P, plan):
+        """Hand the captured graph pieces to the native step driver (include/deer_model.h: deer_step_plan_*)."""
+        C = self._graphs["chains"]
+        nch = self.n_chains
+        vp = ctypes.c_void_p
+
+        def execs(gs):
+            return (vp * len(gs))(*[vp(g.raw_cuda_graph_exec()) if g is not None else None for g in gs])
+
+        side = self._side_stream if self._use_side else None
+        cstreams = [self._side_stream if (c == 1 or not self._use_side) else self._chain_stream(c) for c in range(1, nch)]
+        if not self._use_side:                                   # DEER_SIDE=0: everything on the caller's stream
+            cstreams = [None] * (nch - 1)
+        heads = [P["head"].get(i) for i, _, _, _ in plan]
+        is_exit = (ctypes.c_int * len(plan))(*[1 if e else 0 for _, _, e, _ in plan])
+        out = ctypes.c_void_p()
+        abi.check(self.lib.deer_step_plan_create(nch, execs(C["chain_head"]), execs(C["chain_tail"]), len(plan), execs(P["main"]), execs(heads),
+                                                 is_exit, self._lookahead, self.B, abi.ptr(self.step_info_pinned), abi.ptr(self.host_mirror),
+                                                 ctypes.byref(out)), "deer_step_plan_create")
+        self._plans.append(out)
+        return {"plan": out, "chain_streams": (vp * max(nch - 1, 1))(*[vp(st.cuda_stream) if st is not None else None for st in cstreams] or [None]),
+                "head_stream": vp(side.cuda_stream) if side is not None else None, "ctl_out": abi.ptr(self.ctl_host), "keep": (C, P)}
+
     def _step_segmented(self, T, use_mask):
         """Dynamic step, host-fed in PIECES: one graph per trunk layer (piece 0 = vision + embedding + layer 0) on the main
         stream, one graph per head evaluation on a side stream.
@@ -626,9 +661,20 @@ class DeerEngine:
                         self.enqueue_dynamic_heads(T, i, use_mask=use_mask)
                     P["head"][i] = gh
                     P["ev"][i] = torch.cuda.Event()
+            P["native"] = self._make_step_plan(P, plan)
             self._graphs[key] = P
             self.ctl_host.copy_(self.ctl, non_blocking=True)     # first call: verdict through the ordinary read-back
             main_st.synchronize()
+            return self.read_result()
+
+        if self._native_step and self._trace is None and not self._time_stages:
+            # the native driver (csrc/step_driver.hip): the same submission / look-ahead / polling loop as below, one GIL-free call
+            nat = P["native"]
+            rc = self.lib.deer_step_plan_run(nat["plan"], int(self._si_np[0]), self._seq, ctypes.c_void_p(main_st.cuda_stream),
+                                             nat["chain_streams"], nat["head_stream"], nat["ctl_out"], None)
+            if rc == 3:
+                raise abi.DeerHipError("no exit verdict from the device within 20 s")
+            abi.check(rc, "deer_step_plan_run")
             return self.read_result()
 
         hm, seq, W = self._hm, self._seq, abi.CTL_WORDS

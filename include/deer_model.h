@@ -105,6 +105,22 @@ int deer_step_enqueue(deer_model* m, int T, int use_mask, int exit_id, int shado
 int deer_dynamic_plan(const deer_model* m, int* need_pseudo, int* is_exit, int* slot, int cap);
 int deer_model_n_chains(const deer_model* m);
 
+/* ---- native driver of the pipelined dynamic step (csrc/step_driver.hip) -------------------------------------------------
+ * The host binding captures the pieces above as HIP graphs once (two graphs per vision chain, one per trunk layer of the dynamic
+ * plan, one per head evaluation) and hands the hipGraphExec_t handles over; deer_step_plan_run then submits them, keeps at most
+ * `lookahead` trunk layers in flight beyond an undecided exit check, polls the pinned verdict mirror the device writes
+ * (deer_hip.h DEER_HOSTM_*) and stops at the exit - replaces the host loop of the reference (mosaic_gpt_3b.py:397-443, one
+ * `bool(value <= thr)` sync per exit) without a stream synchronisation.  step_info_pinned: pinned int32[4] = {hold, seq, mirror
+ * pointer lo, hi} that the chain-0 head graph's deer_begin_step reads; host_mirror: pinned int32[(1 + n_envs) * 64]. */
+typedef struct deer_step_plan deer_step_plan;
+int deer_step_plan_create(int n_chains, void* const* chain_head, void* const* chain_tail, int n_pieces, void* const* main_graphs,
+                          void* const* head_graphs, const int* is_exit, int lookahead, int n_envs, int* step_info_pinned,
+                          int* host_mirror, deer_step_plan** out);
+/* returns 0, 2 (HIP error) or 3 (no verdict within 20 s); ctl_out: host int32[n_envs * 64]; pieces_out: NULL or trunk pieces submitted */
+int deer_step_plan_run(deer_step_plan* p, int hold, int seq, void* main_stream, void* const* chain_streams, void* head_stream,
+                       int* ctl_out, int* pieces_out);
+void deer_step_plan_destroy(deer_step_plan* p);
+
 /* ---- in-situ profiler: HIP events around every kernel-launching call of the spine (bench.py roofline pass) --------- */
 int deer_prof_enable(deer_model* m, int on);                      /* host only; on = 1 clears the record list */
 int deer_prof_count(const deer_model* m);

@@ -32,7 +32,7 @@ for i in range(N):
     t0 = time.perf_counter()
     r = eng.step(rgb, grip, ids, None)
     t1 = time.perf_counter()
-    pre += marks["submit"] - t0
+    pre += marks.get("submit", t0) - t0
     tot += t1 - t0
     if t_prev_end is not None:
         gap += t0 - t_prev_end
