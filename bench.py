@@ -232,13 +232,17 @@ def pmc_traffic(kernel_class):
 
 
 def kernel_source_hash():
+    """hash of the DEVICE code sources: csrc/*.h and every csrc/*.hip that defines a kernel (host-only files, e.g. the native step
+    driver, do not change what a PMC pass measures)"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "deer_vla_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h")):
             with open(os.path.join(d, f), "rb") as fh:
-                h.update(fh.read())
+                src = fh.read()
+            if f.endswith(".h") or b"__global__" in src:
+                h.update(src)
     return h.hexdigest()[:16]
 
 
