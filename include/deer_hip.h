@@ -154,6 +154,23 @@ int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_stride, int d_
                         const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws,
                         void* out, int out_is_f32, int ldo, int T, int batch, const int* ctl, void* stream);
 
+/* ---- fp32-activation arithmetic (csrc/precise.hip; deer_config.precision = 1): the second arithmetic of the path, for
+ * north_star's "1e-3 fp32" clause.  Activations stay f32 end to end; the weights are the arena's bf16 tensors (exact in f32). */
+/* every nn.Linear / conv of the ViT, the Perceiver and the media K/V projection: C f32 [M,N] (op)= A f32 [M,K] * W[N,K]^T + bias with
+ * the exact-f32 MFMA.  epi: 0 store, 1 QuickGELU, 2 exact GELU, 3 C += (residual add).  K % 8 == 0, N % 4 == 0. */
+int deer_gemm_f32_nt(const float* A, int lda, const void* W_bf16, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
+                     int epi, void* stream);
+/* open_clip MHA core / PerceiverAttention core (helpers.py:47-73) in fp32: q [batch][q_len][ldq] (head h at column h*64), keys and
+ * values in one or two segments ([batch][kv_s][ld_s], pointers at the K / V column offset), out f32 [batch][q_len][ldo].
+ * head_dim 64, kv1 + kv2 <= 352. */
+int deer_attn_f32(const float* Q, const float* K1, const float* V1, const float* K2, const float* V2, float* O, int batch, int heads,
+                  int q_len, int kv1, int kv2, int ldq, int ld1, int ld2, int ldo, long q_bstride, long bstride1, long bstride2,
+                  long o_bstride, float scale, void* stream);
+/* MaskedCrossAttention core (helpers.py:192-232) with f32 K/V: q from split-K slabs, kv f32 [batch][n_kv][ldkv] (k at column h*64, v at
+ * inner + h*64), media-time mask from text_time, out f32 [batch][T][ldo]. */
+int deer_xattn_f32(const float* qslab, int s_in, long slab_stride, int ldqs, const float* kv, int ldkv, int inner, const int* text_time,
+                   int n_per_media, float* out, int ldo, int T, int n_kv, int heads, int batch, float scale, const int* ctl, void* stream);
+
 /* ---- row ops ------------------------------------------------------------------------------------------------
  * deer_layernorm_rows: nn.LayerNorm (ViT ln_1/ln_2, helpers.py:32-33,17,132), f32 in, bf16 and/or f32 out. */
 int deer_layernorm_rows(const float* x, long in_rstride, long in_bstride, int rows_per_batch, int batch, const float* gamma,

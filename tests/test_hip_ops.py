@@ -577,3 +577,64 @@ def test_head_lstm_layer_env_batch(lib, B, in_dim, ln):
     c_ref = torch.sigmoid(f) * c0 + torch.sigmoid(i) * torch.tanh(g)
     h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
     assert rel_err(c1, c_ref) < 1e-5 and rel_err(h1, h_ref) < 1e-5          # fp32 arithmetic on both sides: summation order only
+
+
+# ------------------------------------------------------------------------------------------ fp32-activation arithmetic (precise.hip)
+@pytest.mark.parametrize("M,N,K,epi", [(257, 1024, 1024, 0), (514, 4096, 1024, 1), (128, 1024, 4096, 2), (70, 132, 72, 0), (514, 1024, 1024, 3)])
+def test_gemm_f32_exact_products(lib, M, N, K, epi):
+    """f32 activations x bf16 weights with the exact-f32 MFMA: differs from torch fp32 math by summation order only (1e-6)."""
+    A = dev(rnd(M, K, seed=1))
+    W = dev(rnd(N, K, seed=2, scale=K ** -0.5), torch.bfloat16)
+    bias = dev(rnd(N, seed=3, scale=0.1))
+    C0 = dev(rnd(M, N, seed=4))
+    C = C0.clone()
+    abi.check(lib.deer_gemm_f32_nt(abi.ptr(A), K, abi.ptr(W), K, abi.ptr(bias), abi.ptr(C), N, M, N, K, epi, st()), "gemm_f32")
+    torch.cuda.synchronize()
+    y = A.double() @ W.double().t() + bias.double()
+    if epi == 1:
+        y = y * torch.sigmoid(1.702 * y)
+    elif epi == 2:
+        y = torch.nn.functional.gelu(y)
+    elif epi == 3:
+        y = C0.double() + y
+    assert rel_err(C, y) < 2e-6
+
+
+@pytest.mark.parametrize("q_len,kv1,kv2,heads,batch", [(257, 257, 0, 16, 2), (64, 256, 64, 8, 2), (5, 7, 0, 2, 1)])
+def test_attn_f32_one_and_two_segments(lib, q_len, kv1, kv2, heads, batch):
+    C = heads * 64
+    q = dev(rnd(batch, q_len, C, seed=1))
+    k1, v1 = dev(rnd(batch, kv1, C, seed=2)), dev(rnd(batch, kv1, C, seed=3))
+    k2 = dev(rnd(batch, max(kv2, 1), C, seed=4))
+    v2 = dev(rnd(batch, max(kv2, 1), C, seed=5))
+    out = torch.full((batch, q_len, C), float("nan"), device="cuda")
+    abi.check(lib.deer_attn_f32(abi.ptr(q), abi.ptr(k1), abi.ptr(v1), abi.ptr(k2) if kv2 else None, abi.ptr(v2) if kv2 else None, abi.ptr(out), batch,
+                                heads, q_len, kv1, kv2, C, C, C, C, q_len * C, kv1 * C, max(kv2, 1) * C, q_len * C, 0.125, st()), "attn_f32")
+    torch.cuda.synchronize()
+    kk = torch.cat([k1, k2], 1) if kv2 else k1
+    vv = torch.cat([v1, v2], 1) if kv2 else v1
+    sp = lambda t: t.view(batch, -1, heads, 64).transpose(1, 2).double()
+    ref = (torch.softmax(sp(q) @ sp(kk).transpose(-1, -2) * 0.125, -1) @ sp(vv)).transpose(1, 2).reshape(batch, q_len, C)
+    assert rel_err(out, ref) < 2e-6
+
+
+def test_xattn_f32_matches_the_masked_cross_attention(lib):
+    T, n_kv, heads, batch, npm = 14, 128, 8, 2, 64
+    inner = heads * 64
+    S = 2
+    qs = dev(rnd(S, batch * T, inner, seed=1))
+    kv = dev(rnd(batch, n_kv, 2 * inner, seed=2))
+    tt = torch.tensor([[0, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2], [1] * 14], dtype=torch.int32, device="cuda")
+    out = torch.full((batch, T, inner), float("nan"), device="cuda")
+    abi.check(lib.deer_xattn_f32(abi.ptr(qs), S, batch * T * inner, inner, abi.ptr(kv), 2 * inner, inner, abi.ptr(tt), npm, abi.ptr(out), inner, T, n_kv,
+                                 heads, batch, 0.125, None, st()), "xattn_f32")
+    torch.cuda.synchronize()
+    q = qs.sum(0).view(batch, T, heads, 64).transpose(1, 2).double() * 0.125
+    k = kv[..., :inner].reshape(batch, n_kv, heads, 64).transpose(1, 2).double()
+    v = kv[..., inner:].reshape(batch, n_kv, heads, 64).transpose(1, 2).double()
+    sim = q @ k.transpose(-1, -2)
+    media_time = (torch.arange(n_kv, device="cuda") // npm + 1).view(1, 1, 1, n_kv)
+    sim = sim.masked_fill(tt.view(batch, 1, T, 1) != media_time, -torch.finfo(torch.float32).max)
+    att = torch.softmax(sim, -1).masked_fill((tt == 0).view(batch, 1, T, 1), 0.0)
+    ref = (att @ v).transpose(1, 2).reshape(batch, T, inner)
+    assert rel_err(out, ref) < 2e-6
