@@ -115,10 +115,13 @@ class DeerConfigC(ctypes.Structure):
         "cross_attn_every_n_layers", "xattn_heads", "xattn_dim_head", "xattn_ff_mult", "media_token_id",
         "mpt7b_names", "exit_interval",
         "head_hidden", "lstm_num_layers", "lstm_layernorm", "mlp_layernorm", "mlp_num_hidden_layers", "pooling_avg",
-        "n_envs", "max_text_len", "n_chains")]
+        "n_envs", "max_text_len", "n_chains", "precision")]
 
 
-def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0) -> DeerConfigC:
+PRECISIONS = {"bf16": 0, "fp32": 1}
+
+
+def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0, precision: str = "bf16") -> DeerConfigC:
     c = DeerConfigC()
     for k in ("image_size", "patch_size", "vit_width", "vit_layers", "vit_heads", "vit_mlp", "perc_depth", "perc_heads",
               "perc_dim_head", "perc_latents", "perc_ff_mult", "vocab_size", "d_model", "n_heads", "mlp_ratio",
@@ -132,6 +135,9 @@ def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0) -> DeerC
     c.mlp_layernorm = 1 if cfg.mlp_layernorm else 0
     c.pooling_avg = 0 if cfg.pooling == "max" else 1
     c.n_envs, c.max_text_len, c.n_chains = n_envs, max_text_len, n_chains
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
+    c.precision = PRECISIONS[precision]
     return c
 
 

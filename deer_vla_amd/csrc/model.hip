@@ -99,6 +99,11 @@ struct LlmLayerW {
 struct LstmW { size_t wih, whh, bih, bhh, lnw, lnb; };
 struct FcW { size_t w[2], b[2], lnw[2], lnb[2]; };
 
+// f32 activation buffers of the fp32-activation arithmetic (deer_config.precision = 1; batched single-stream schedule only)
+struct PreciseWS {
+  size_t xn, qkv, ao, h, mln, mkv, latln, pqkv, pao, pln, ph, kv_all;
+};
+
 // activation buffers of the vision tower for n camera frames (offsets into the workspace)
 struct VisionWS {
   int n = 0, first = 0;                       // number of frames, index of the first one in the step's frame list
@@ -145,6 +150,7 @@ struct deer_model {
   Layout wl;
   std::unordered_map<std::string, std::pair<size_t, size_t>> ws_named;
   VisionWS vws;
+  PreciseWS hp{};
   std::vector<VisionWS> chains;
   size_t img, vis_x, vis_x_f32, kv_all, ids, key_mask, text_time, x, xn, ao, slab_a, slab_b, qkv_ws, hidden, h_state, c_state, h_tmp,
       c_tmp, h_shadow, c_shadow, pooled, ctl, step_info, thresholds, action_dbg;
@@ -444,6 +450,21 @@ void build_workspace(deer_model* m) {
     build_vision_ws(m, m->chains.back(), hi - lo, lo, &m->vws);
   }
   m->kv_all = named(m, "kv_all", (size_t)N * nl * std::max(m->n_xattn, 1) * 2 * m->xinner * 2);
+  if (c.precision) {   // f32 twins of the vision tower's activations and of the x-attn K/V (csrc/precise.hip)
+    const long R = (long)N * (m->P + 1), inner = m->p_inner, NL = (long)N * nl, NP = (long)N * m->P;
+    m->hp.xn = m->wl.add((size_t)R * W * 4);
+    m->hp.qkv = m->wl.add((size_t)R * 3 * W * 4);
+    m->hp.ao = m->wl.add((size_t)R * W * 4);
+    m->hp.h = m->wl.add((size_t)R * c.vit_mlp * 4);
+    m->hp.mln = m->wl.add((size_t)NP * W * 4);
+    m->hp.mkv = m->wl.add((size_t)NP * 2 * inner * 4);
+    m->hp.latln = m->wl.add((size_t)NL * W * 4);
+    m->hp.pqkv = m->wl.add((size_t)NL * 3 * inner * 4);
+    m->hp.pao = m->wl.add((size_t)NL * inner * 4);
+    m->hp.pln = m->wl.add((size_t)NL * W * 4);
+    m->hp.ph = m->wl.add((size_t)NL * c.perc_ff_mult * W * 4);
+    m->hp.kv_all = named(m, "kv_all_f32", (size_t)NL * std::max(m->n_xattn, 1) * 2 * m->xinner * 4);
+  }
   const int T = std::min(B * c.max_text_len, kMaxRows);
   m->ids = named(m, "ids", (size_t)T * 8);
   m->key_mask = named(m, "key_mask", (size_t)T);
@@ -608,7 +629,102 @@ int vit_blocks(deer_model* m, const VisionWS& ws, int lo, int hi, void* st) {
   return DEER_OK;
 }
 
+
+// ---- fp32-activation arithmetic of the vision tower (deer_config.precision = 1, csrc/precise.hip) --------------------------
+int gemmf(deer_model* m, const float* A, long lda, const void* Wt, const float* bias, float* C, long ldc, long M, long N, long K, int epi, void* st) {
+  Bracket b(m, "deer_gemm_f32_nt", 2.0 * M * N * K, 4.0 * M * K + 2.0 * N * K + 4.0 * M * N, st);
+  return deer_gemm_f32_nt(A, (int)lda, Wt, (int)K, bias, C, (int)ldc, (int)M, (int)N, (int)K, epi, st);
+}
+
+int ln_rows_f32(deer_model* m, const float* x, const float* gamma, const float* beta, float* out, long rows, int C, void* st) {
+  Bracket b(m, "deer_layernorm_rows", 8.0 * rows * C, 8.0 * rows * C, st);
+  return deer_layernorm_rows(x, C, 0, (int)rows, 1, gamma, beta, nullptr, out, C, 0, C, kEps, st);
+}
+
+int vit_blocks_f32(deer_model* m, const VisionWS& ws, int lo, int hi, void* st) {
+  const deer_config& c = m->c;
+  const int W = m->W, tok = m->tok, H = c.vit_heads, N = ws.n;
+  const long R = (long)N * tok;
+  float* vx = m->Wk<float>(ws.vx);
+  float* xn = m->Wk<float>(m->hp.xn);
+  float* qkv = m->Wk<float>(m->hp.qkv);
+  float* ao = m->Wk<float>(m->hp.ao);
+  float* h = m->Wk<float>(m->hp.h);
+  for (int li = lo; li < hi; ++li) {
+    const VitLayerW& L = m->vit[li];
+    if (li == 0) DEER_TRY(ln_rows_f32(m, vx, m->A<float>(L.ln1w), m->A<float>(L.ln1b), xn, R, W, st));
+    DEER_TRY(gemmf(m, xn, W, m->A<void>(L.wqkv), m->A<float>(L.bqkv), qkv, 3 * W, R, 3 * W, W, 0, st));
+    {
+      Bracket b(m, "deer_attn_f32", 4.0 * N * H * tok * tok * 64, 0, st);
+      DEER_TRY(deer_attn_f32(qkv, qkv + W, qkv + 2 * W, nullptr, nullptr, ao, N, H, tok, tok, 0, 3 * W, 3 * W, 0, W, (long)tok * 3 * W, (long)tok * 3 * W, 0,
+                             (long)tok * W, 0.125f, st));
+    }
+    DEER_TRY(gemmf(m, ao, W, m->A<void>(L.wo), m->A<float>(L.bo), vx, W, R, W, W, 3, st));                       // x += attn(ln_1(x))
+    DEER_TRY(ln_rows_f32(m, vx, m->A<float>(L.ln2w), m->A<float>(L.ln2b), xn, R, W, st));
+    DEER_TRY(gemmf(m, xn, W, m->A<void>(L.wfc), m->A<float>(L.bfc), h, c.vit_mlp, R, c.vit_mlp, W, 1, st));      // QuickGELU
+    DEER_TRY(gemmf(m, h, c.vit_mlp, m->A<void>(L.wpr), m->A<float>(L.bpr), vx, W, R, W, c.vit_mlp, 3, st));      // x += mlp(ln_2(x))
+    if (li + 1 < c.vit_layers) {
+      const VitLayerW& nx = m->vit[li + 1];
+      DEER_TRY(ln_rows_f32(m, vx, m->A<float>(nx.ln1w), m->A<float>(nx.ln1b), xn, R, W, st));
+    }
+  }
+  return DEER_OK;
+}
+
+int perceiver_f32(deer_model* m, const VisionWS& ws, void* st) {
+  const deer_config& c = m->c;
+  const int P = m->P, W = m->W, tok = m->tok, nl = m->nl, inner = m->p_inner, Lp = m->Lp, N = ws.n;
+  const long NL = (long)N * nl, NP = (long)N * P, ffw = (long)c.perc_ff_mult * W;
+  {
+    Bracket b(m, "deer_broadcast_rows", 0, 0, st);
+    DEER_TRY(deer_broadcast_rows(m->A<float>(m->latents), m->Wk<float>(ws.p_lat), (long)nl * W, N, st));
+  }
+  const float* tokens = m->tokens_override ? m->tokens_override + (size_t)ws.first * P * W : m->Wk<float>(ws.vx) + W;   // skip the cls row
+  const long tok_bstride = m->tokens_override ? (long)P * W : (long)tok * W;
+  float* lat = m->Wk<float>(ws.p_lat);
+  float* mln = m->Wk<float>(m->hp.mln);
+  float* mkv = m->Wk<float>(m->hp.mkv);
+  float* latln = m->Wk<float>(m->hp.latln);
+  float* pqkv = m->Wk<float>(m->hp.pqkv);
+  float* pao = m->Wk<float>(m->hp.pao);
+  float* pln = m->Wk<float>(m->hp.pln);
+  float* ph = m->Wk<float>(m->hp.ph);
+  const float scale = 1.0f / sqrtf((float)c.perc_dim_head);
+  for (int li = 0; li < Lp; ++li) {
+    const PercLayerW& L = m->perc[li];
+    {   // norm_media of this layer on the (layer-invariant) media tokens, then its to_kv (helpers.py:47-56)
+      Bracket b(m, "deer_layernorm_rows", 8.0 * NP * W, 8.0 * NP * W, st);
+      DEER_TRY(deer_layernorm_rows(tokens, W, tok_bstride, P, N, m->A<float>(m->perc_nm_w) + (size_t)li * W, m->A<float>(m->perc_nm_b) + (size_t)li * W,
+                                   nullptr, mln, W, (long)P * W, W, kEps, st));
+    }
+    DEER_TRY(gemmf(m, mln, W, m->A<char>(m->perc_wkv_all) + (size_t)li * 2 * inner * W * 2, nullptr, mkv, 2 * inner, NP, 2 * inner, W, 0, st));
+    DEER_TRY(ln_rows_f32(m, lat, m->A<float>(L.nlw), m->A<float>(L.nlb), latln, NL, W, st));
+    DEER_TRY(gemmf(m, latln, W, m->A<void>(L.wqkv), nullptr, pqkv, 3 * inner, NL, 3 * inner, W, 0, st));
+    {
+      Bracket b(m, "deer_attn_f32", 4.0 * N * c.perc_heads * nl * (P + nl) * 64, 0, st);
+      DEER_TRY(deer_attn_f32(pqkv, mkv, mkv + inner, pqkv + inner, pqkv + 2 * inner, pao, N, c.perc_heads, nl, P, nl, 3 * inner, 2 * inner, 3 * inner, inner,
+                             (long)nl * 3 * inner, (long)P * 2 * inner, (long)nl * 3 * inner, (long)nl * inner, scale, st));
+    }
+    DEER_TRY(gemmf(m, pao, inner, m->A<void>(L.wo), nullptr, lat, W, NL, W, inner, 3, st));
+    DEER_TRY(ln_rows_f32(m, lat, m->A<float>(L.fnw), m->A<float>(L.fnb), pln, NL, W, st));
+    DEER_TRY(gemmf(m, pln, W, m->A<void>(L.w1), nullptr, ph, ffw, NL, ffw, W, 2, st));
+    DEER_TRY(gemmf(m, ph, ffw, m->A<void>(L.w2), nullptr, lat, W, NL, W, ffw, 3, st));
+  }
+  // closing perceiver.norm -> media tokens: f32 (this arithmetic) and bf16 (kept current for readers of "vis_x")
+  Bracket b(m, "deer_layernorm_rows", 8.0 * NL * W, 10.0 * NL * W, st);
+  return deer_layernorm_rows(lat, W, 0, (int)NL, 1, m->A<float>(m->perc_normw), m->A<float>(m->perc_normb), m->Wk<void>(ws.vis_x), m->Wk<float>(ws.vis_x_f32),
+                             W, 0, W, kEps, st);
+}
+
+int media_kv_f32(deer_model* m, void* st) {
+  if (!m->n_xattn) return DEER_OK;
+  if (m->media_override != nullptr) return DEER_ERR_SHAPE;      // a bf16 media tensor cannot feed the f32 arithmetic: use the model's own
+  return gemmf(m, m->Wk<float>(m->vis_x_f32), m->W, m->A<void>(m->wkv_all), nullptr, m->Wk<float>(m->hp.kv_all), (long)m->n_xattn * 2 * m->xinner,
+               (long)m->N * m->nl, (long)m->n_xattn * 2 * m->xinner, m->W, 0, st);
+}
+
 int media_kv(deer_model* m, void* st) {
+  if (m->c.precision) return media_kv_f32(m, st);
   if (!m->n_xattn) return DEER_OK;
   const void* media = m->media_override ? m->media_override : m->Wk<void>(m->vis_x);
   return gemm(m, media, m->A<void>(m->wkv_all), m->Wk<void>(m->kv_all), (long)m->N * m->nl, (long)m->n_xattn * 2 * m->xinner, m->W, DEER_EPI_BF16,
@@ -671,7 +787,16 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
     static const bool fused = [] { const char* e = getenv("DEER_XATTN_FUSED"); return e == nullptr || e[0] != '0'; }();
     const int n_media = 2 * m->nl;
     const char* kv = m->Wk<char>(m->kv_all) + (size_t)X.kv_index * 2 * xin * 2;
-    if (fused && T <= 32 && (d & 127) == 0) {
+    if (c.precision) {
+      // fp32-activation arithmetic: q projection (f32 activations as bf16 hi + lo), fp32 attention over the f32 K/V, output projection
+      DEER_TRY(skinny(m, m->A<void>(X.wq), xin, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
+      {
+        Bracket b(m, "deer_xattn_f32", 0, 0, st);
+        DEER_TRY(deer_xattn_f32(slab_b, S, stride, xin, m->Wk<float>(m->hp.kv_all) + (size_t)X.kv_index * 2 * xin, m->n_xattn * 2 * xin, xin,
+                                m->Wk<int>(m->text_time), n_media, ao, xin, T, n_media, c.xattn_heads, B, 1.0f / sqrtf((float)c.xattn_dim_head), ctl, st));
+      }
+      DEER_TRY(skinny(m, m->A<void>(X.wo), d, xin, R, slab_a, m->slab_a_elems, ao, xin, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
+    } else if (fused && T <= 32 && (d & 127) == 0) {
       // to_q -> attention -> to_out in ONE launch; output = one f32 slab per head (xattn_fused.hip)
       const int mpad = 16 * ((R + 15) / 16);
       if ((size_t)c.xattn_heads * mpad * d > m->slab_a_elems) return DEER_ERR_SHAPE;
@@ -834,9 +959,9 @@ int vision(deer_model* m, const VisionWS& ws, int part, bool with_kv, void* st) 
   const int n_head = std::min(kVitHeadLayers, nv - 1);
   const int lo = part == 2 ? n_head : 0, hi = part == 1 ? n_head : nv;
   if (part != 2) DEER_TRY(patch_embed(m, ws, st));
-  DEER_TRY(vit_blocks(m, ws, lo, hi, st));
+  DEER_TRY(m->c.precision ? vit_blocks_f32(m, ws, lo, hi, st) : vit_blocks(m, ws, lo, hi, st));
   if (part != 1) {
-    DEER_TRY(perceiver(m, ws, st));
+    DEER_TRY(m->c.precision ? perceiver_f32(m, ws, st) : perceiver(m, ws, st));
     if (with_kv) DEER_TRY(media_kv(m, st));
   }
   return DEER_OK;
@@ -1060,7 +1185,7 @@ int deer_vit_l14_encode(deer_model* m, const void* images_bf16, int n_images, fl
   if (m->ws == nullptr || images_bf16 == nullptr || n_images != m->N) return DEER_ERR_SHAPE;
   m->img_override = images_bf16;
   int rc = patch_embed(m, m->vws, stream);
-  if (rc == DEER_OK) rc = vit_blocks(m, m->vws, 0, m->c.vit_layers, stream);
+  if (rc == DEER_OK) rc = m->c.precision ? vit_blocks_f32(m, m->vws, 0, m->c.vit_layers, stream) : vit_blocks(m, m->vws, 0, m->c.vit_layers, stream);
   m->img_override = nullptr;
   if (rc != DEER_OK) return rc;
   if (tokens_out != nullptr) {   // patch tokens x[:, 1:] of every image, without ln_post (flamingo_mpt.py:580)
@@ -1076,7 +1201,7 @@ int deer_vit_l14_encode(deer_model* m, const void* images_bf16, int n_images, fl
 int deer_perceiver_resample(deer_model* m, const float* tokens, int n_images, void* media_bf16_out, float* media_f32_out, void* stream) {
   if (m->ws == nullptr || n_images != m->N) return DEER_ERR_SHAPE;
   m->tokens_override = tokens;
-  const int rc = perceiver(m, m->vws, stream);
+  const int rc = m->c.precision ? perceiver_f32(m, m->vws, stream) : perceiver(m, m->vws, stream);
   m->tokens_override = nullptr;
   if (rc != DEER_OK) return rc;
   const size_t n = (size_t)m->N * m->nl * m->W;

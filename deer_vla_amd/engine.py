@@ -50,7 +50,7 @@ class DeerEngine:
     LOOKAHEAD = 1        # trunk layers the host keeps in flight beyond an undecided exit check
 
     def __init__(self, cfg: DeerConfig, state_dict: Optional[Dict[str, torch.Tensor]], device="cuda", max_text_len: int = 32,
-                 n_envs: int = 1, threshold_type: str = "L2", leq: bool = True, segmented: bool = True,
+                 n_envs: int = 1, threshold_type: str = "L2", leq: bool = True, segmented: bool = True, precision: str = "bf16",
                  weights_from: Optional["DeerEngine"] = None):
         """n_envs: independent environments evaluated per control step (one "env batch" per rank).  They share every
         weight read: the ViT sees M = 514*n_envs rows, the LLM n_envs*T rows, each environment keeps its own LSTM state,
@@ -70,7 +70,10 @@ class DeerEngine:
         self._thr_type = abi.THR_TYPES[threshold_type]
         self._leq = 1 if leq else 0
         self._h = ctypes.c_void_p()
-        cc = config_to_c(cfg, n_envs, self.max_T)
+        # precision="fp32": fp32 activations everywhere (csrc/precise.hip) - the parity arithmetic of north_star's 1e-3 clause; single-
+        # stream schedule, one graph per step
+        self.precision = precision
+        cc = config_to_c(cfg, n_envs, self.max_T, precision=precision)
         abi.check(self.lib.deer_model_create(ctypes.byref(cc), ctypes.byref(self._h)), "deer_model_create")
         with torch.cuda.device(self.dev):
             self.workspace = torch.zeros(self.lib.deer_model_workspace_bytes(self._h), dtype=torch.uint8, device=self.dev)
@@ -86,7 +89,7 @@ class DeerEngine:
             self._make_views()
         self._siblings: Dict[int, "DeerEngine"] = {}
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
-        self.segmented = segmented                    # dynamic steps fed in per-layer graph pieces (see _step_segmented)
+        self.segmented = segmented and precision == "bf16"   # dynamic steps fed in per-layer graph pieces (see _step_segmented)
         # DEER_ONE_GRAPH=1: dynamic steps as ONE graph with branches - no host on the decision path at all, but every kernel behind
         # the exit still launches and returns at entry (see _step_one_graph; measured slower: 242 vs 352 steps/s at one
         # environment, 778 vs 862 at eight)
@@ -746,7 +749,7 @@ class DeerEngine:
             return self
         e = self._siblings.get(n_envs)
         if e is None:
-            e = DeerEngine(self.cfg, None, device=self.dev, max_text_len=self.max_T, n_envs=n_envs, weights_from=self, segmented=self.segmented)
+            e = DeerEngine(self.cfg, None, device=self.dev, max_text_len=self.max_T, n_envs=n_envs, weights_from=self, segmented=self.segmented, precision=self.precision)
             self._siblings[n_envs] = e
         return e
 

@@ -32,7 +32,8 @@ class NativeModel:
     """Owner of one ``deer_model``: creates it from a DeerConfig, allocates the weight arena + workspace as torch tensors and
     ingests a reference state dict.  No orchestration here - that is the spine's; ``DeerEngine`` adds graph scheduling on top."""
 
-    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], device="cuda", n_envs: int = 1, max_text_len: int = 32):
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], device="cuda", n_envs: int = 1, max_text_len: int = 32,
+                 precision: str = "bf16"):
         if not torch.cuda.is_available():
             raise abi.DeerHipError("deer_vla_amd needs a HIP device (no CPU fallback)")
         self.lib = abi.lib()
@@ -40,7 +41,8 @@ class NativeModel:
         self.dev = torch.device(device)
         self.max_T = min(max_text_len, 128 // n_envs)
         self._h = ctypes.c_void_p()
-        cc = abi.config_to_c(cfg, n_envs, self.max_T)
+        self.precision = precision
+        cc = abi.config_to_c(cfg, n_envs, self.max_T, precision=precision)
         abi.check(self.lib.deer_model_create(ctypes.byref(cc), ctypes.byref(self._h)), "deer_model_create")
         with torch.cuda.device(self.dev):
             self.arena = torch.zeros(self.lib.deer_model_arena_bytes(self._h), dtype=torch.uint8, device=self.dev)
@@ -144,7 +146,8 @@ def llm_early_exit(ids: torch.Tensor, key_mask: Optional[torch.Tensor], media: t
     ids_c = ids.to(torch.int64).contiguous()
     T = ids_c.reshape(m.B, -1).shape[1]
     km = key_mask.to(torch.uint8).contiguous() if key_mask is not None else None
-    med = media.to(torch.bfloat16).contiguous()
+    # fp32-activation models keep their media tokens in f32 inside the model (the bf16 tensor handed around is only a view of them)
+    med = None if getattr(m, "precision", "bf16") == "fp32" else media.to(torch.bfloat16).contiguous()
     abi.check(m.lib.deer_llm_early_exit(m._h, abi.ptr(ids_c), abi.ptr(km), T, abi.ptr(med), exit_id, 1 if shadow else 0, None, None, _stream()),
               "deer_llm_early_exit")
     rows = min(m.B * m.max_T, 128)

@@ -35,6 +35,8 @@ typedef struct deer_config {
   int n_envs;               /* environments evaluated per control step (1..8) */
   int max_text_len;         /* longest instruction (tokens); n_envs * T must be <= 128 rows */
   int n_chains;             /* independent vision chains of the two-stream schedule (0 = default 2) */
+  int precision;            /* 0: bf16 MFMA operands in the vision tower / x-attn (the product path); 1: fp32 activations everywhere
+                             * (csrc/precise.hip; single-stream schedule; ~1/10 of the vision tower's throughput) */
 } deer_config;
 
 typedef struct deer_model deer_model;
