@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--window-reps", type=int, default=10,
                     help="window-mode (threshold calibration) leg: windows of cfg.window_size frame pairs timed as batch rows (0 = skip)")
+    ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
+                    help="bf16: the product arithmetic (BASELINE's dtype). fp32: the fp32-activation parity arithmetic (csrc/precise.hip) - "
+                         "a separate, slower line for DESIGN.md, never the headline")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--full-depth-only", type=int, default=0, metavar="K",
@@ -70,7 +73,8 @@ def parse():
 # kernel class (C-ABI entry point) -> which roofline bounds it
 SAME_KERNEL = {"deer_gemm_bf16_nt_splitk": "deer_gemm_bf16_nt", "deer_gemm_bf16_nt_wbatch": "deer_gemm_bf16_nt",
                "deer_attn_mfma_hd64_2seg": "deer_attn_mfma_hd64", "deer_layernorm_rows_multi": "deer_layernorm_rows"}
-KERNEL_BOUND = {"deer_gemm_bf16_nt": "mfma", "deer_attn_mfma_hd64": "mfma", "deer_gemm_skinny": "hbm"}
+KERNEL_BOUND = {"deer_gemm_bf16_nt": "mfma", "deer_attn_mfma_hd64": "mfma", "deer_gemm_skinny": "hbm", "deer_gemm_f32_nt": "mfma"}
+MFMA_PEAK_BY_CLASS = {"deer_gemm_f32_nt": 157.3}      # exact-f32 MFMA (v_mfma_f32_16x16x4_f32): 1/16 of the bf16 rate (MI355X_MICROARCH.md)
 
 
 def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
@@ -149,7 +153,7 @@ def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
     dom = max((k for k in agg if k in KERNEL_BOUND), key=lambda k: agg[k]["us"])
     d = agg[dom]
     if KERNEL_BOUND[dom] == "mfma":
-        achieved, peak, unit = d["flops"] / d["us"] / 1e6, MFMA_PEAK_TF, "TFLOP/s"
+        achieved, peak, unit = d["flops"] / d["us"] / 1e6, MFMA_PEAK_BY_CLASS.get(dom, MFMA_PEAK_TF), "TFLOP/s"
     else:
         achieved, peak, unit = d["bytes"] / d["us"] / 1e3, HBM_PEAK_GBS, "GB/s"
     traffic, traffic_src = pmc_traffic(dom)
@@ -307,7 +311,7 @@ def run_workload(args, cfg, sd_dev, B, rank, world, local_rank, dist, max_layer,
     from deer_vla_amd.value_net import ExitController
 
     t0 = time.time()
-    eng = DeerEngine(cfg, sd_dev, device=f"cuda:{local_rank}", n_envs=B)
+    eng = DeerEngine(cfg, sd_dev, device=f"cuda:{local_rank}", n_envs=B, precision=args.precision)
     ctl = ExitController(None, cfg.exit_ids(), steps_per_stage=1, max_layer=max_layer)
     eng.configure_exit(ctl.exit_id_list, max_layer, 1)
     setup_s = time.time() - t0
@@ -441,7 +445,7 @@ def main():
                   % ("MPT-7B" if args.workload == "deer_9b" else "MPT-1B", max_layer),
         "value": round(value, 2), "unit": "action-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32 activations, bf16-representable weights", "data": "synthetic",
         "avg_exit_layer": round(res["avg_exit"], 3),
         "config": {"workload": "%s DeeR-%s max_layer=%d exit_ratio=%.2f, step mode, %d env(s)/GPU per control "
                                "step, 2x224x224 frames + %d text tokens per env, LSTM history carried over %d-step episodes"

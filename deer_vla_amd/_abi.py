@@ -36,6 +36,7 @@ SIGNATURES = {
     "deer_resadd_ln": [P, P, I, L, P, P, P, P, P, P, P, I, I, F, P, P],
     "deer_vit_im2col": [P, I, I, I, I, P, I, P],
     "deer_vit_embed_lnpre": [P, P, P, P, P, P, I, I, I, F, P],
+    "deer_vit_im2col_f32": [P, I, I, I, P, I, P],
     "deer_gemm_f32_nt": [P, I, P, I, P, P, I, I, I, I, I, P],
     "deer_attn_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
     "deer_xattn_f32": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, I, F, P, P],

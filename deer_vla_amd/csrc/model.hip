@@ -101,7 +101,7 @@ struct FcW { size_t w[2], b[2], lnw[2], lnb[2]; };
 
 // f32 activation buffers of the fp32-activation arithmetic (deer_config.precision = 1; batched single-stream schedule only)
 struct PreciseWS {
-  size_t xn, qkv, ao, h, mln, mkv, latln, pqkv, pao, pln, ph, kv_all;
+  size_t im2col, xn, qkv, ao, h, mln, mkv, latln, pqkv, pao, pln, ph, kv_all;
 };
 
 // activation buffers of the vision tower for n camera frames (offsets into the workspace)
@@ -434,7 +434,7 @@ size_t named(deer_model* m, const char* name, size_t bytes) {
 void build_workspace(deer_model* m) {
   const deer_config& c = m->c;
   const int N = m->N, W = m->W, nl = m->nl, d = m->d, B = m->B, S = c.image_size;
-  m->img = named(m, "img", (size_t)N * 3 * S * S * 2);
+  m->img = named(m, "img", (size_t)N * 3 * S * S * (c.precision ? 4 : 2));        // camera frames: bf16, or f32 for the fp32 arithmetic
   m->vis_x = named(m, "vis_x", (size_t)N * nl * W * 2);
   m->vis_x_f32 = named(m, "vis_x_f32", (size_t)N * nl * W * 4);
   build_vision_ws(m, m->vws, N, 0, nullptr);
@@ -452,6 +452,7 @@ void build_workspace(deer_model* m) {
   m->kv_all = named(m, "kv_all", (size_t)N * nl * std::max(m->n_xattn, 1) * 2 * m->xinner * 2);
   if (c.precision) {   // f32 twins of the vision tower's activations and of the x-attn K/V (csrc/precise.hip)
     const long R = (long)N * (m->P + 1), inner = m->p_inner, NL = (long)N * nl, NP = (long)N * m->P;
+    m->hp.im2col = m->wl.add((size_t)NP * m->kpad * 4);
     m->hp.xn = m->wl.add((size_t)R * W * 4);
     m->hp.qkv = m->wl.add((size_t)R * 3 * W * 4);
     m->hp.ao = m->wl.add((size_t)R * W * 4);
@@ -525,16 +526,26 @@ int ln_rows(deer_model* m, const float* x, const float* gamma, const float* beta
 
 const void* step_images(const deer_model* m) { return m->img_override ? m->img_override : m->Wk<void>(m->img); }
 
+int gemmf(deer_model* m, const float* A, long lda, const void* Wt, const float* bias, float* C, long ldc, long M, long N, long K, int epi, void* st);
+
 int patch_embed(deer_model* m, const VisionWS& ws, void* st) {
   const deer_config& c = m->c;
   const int P = m->P, W = m->W;
   const long R = (long)ws.n * (P + 1);
-  const char* img = reinterpret_cast<const char*>(step_images(m)) + (size_t)ws.first * 3 * c.image_size * c.image_size * 2;
-  {
-    Bracket b(m, "deer_vit_im2col", 0, 0, st);
-    DEER_TRY(deer_vit_im2col(img, 1, ws.n, c.image_size, c.patch_size, m->Wk<void>(ws.im2col), m->kpad, st));
+  const char* img = reinterpret_cast<const char*>(step_images(m)) + (size_t)ws.first * 3 * c.image_size * c.image_size * (c.precision ? 4 : 2);
+  if (c.precision) {   // f32 frames -> f32 patches -> exact-f32 MFMA conv (csrc/precise.hip)
+    {
+      Bracket b(m, "deer_vit_im2col", 0, 0, st);
+      DEER_TRY(deer_vit_im2col_f32(reinterpret_cast<const float*>(img), ws.n, c.image_size, c.patch_size, m->Wk<float>(m->hp.im2col), m->kpad, st));
+    }
+    DEER_TRY(gemmf(m, m->Wk<float>(m->hp.im2col), m->kpad, m->A<void>(m->conv), nullptr, m->Wk<float>(ws.patch_out), W, (long)ws.n * P, W, m->kpad, 0, st));
+  } else {
+    {
+      Bracket b(m, "deer_vit_im2col", 0, 0, st);
+      DEER_TRY(deer_vit_im2col(img, 1, ws.n, c.image_size, c.patch_size, m->Wk<void>(ws.im2col), m->kpad, st));
+    }
+    DEER_TRY(gemm(m, m->Wk<void>(ws.im2col), m->A<void>(m->conv), m->Wk<void>(ws.patch_out), (long)ws.n * P, W, m->kpad, DEER_EPI_F32, nullptr, st));
   }
-  DEER_TRY(gemm(m, m->Wk<void>(ws.im2col), m->A<void>(m->conv), m->Wk<void>(ws.patch_out), (long)ws.n * P, W, m->kpad, DEER_EPI_F32, nullptr, st));
   {
     Bracket b(m, "deer_vit_embed_lnpre", 0, 0, st);
     DEER_TRY(deer_vit_embed_lnpre(m->Wk<float>(ws.patch_out), m->A<float>(m->cls), m->A<float>(m->pos), m->A<float>(m->ln_pre_w),

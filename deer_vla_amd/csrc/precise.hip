@@ -318,3 +318,32 @@ extern "C" int deer_xattn_f32(const float* qslab, int s_in, long slab_stride, in
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
+
+// ---- ViT patch embedding, step 1 in f32: im2col of p x p / p patches -> f32 [N*P, Kpad] (k = ch*p*p + py*p + px, zero padded) -----
+__global__ void im2col_f32_kernel(const float* __restrict__ img, int N, int S, int p, int gw, float* __restrict__ out, int Kpad) {
+  const long total = (long)N * gw * gw * Kpad;
+  const int kk = 3 * p * p;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % Kpad);
+    const long row = idx / Kpad;
+    float v = 0.f;
+    if (k < kk) {
+      const int P = gw * gw;
+      const int n = (int)(row / P), pi = (int)(row - (long)n * P);
+      const int gy = pi / gw, gx = pi - gy * gw;
+      const int ch = k / (p * p), rem = k - ch * p * p, py = rem / p, px = rem - py * p;
+      v = img[(((long)n * 3 + ch) * S + (gy * p + py)) * S + gx * p + px];
+    }
+    out[idx] = v;
+  }
+}
+
+extern "C" int deer_vit_im2col_f32(const float* img, int N, int S, int patch, float* out, int Kpad, void* stream) {
+  if (img == nullptr || out == nullptr || N <= 0 || S <= 0 || patch <= 0 || S % patch != 0 || Kpad < 3 * patch * patch) return DEER_ERR_SHAPE;
+  const int gw = S / patch;
+  const long total = (long)N * gw * gw * Kpad;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(im2col_f32_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), img, N, S, patch, gw, out, Kpad);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}

@@ -156,7 +156,7 @@ class DeerEngine:
         rows = min(B * self.max_T, 128)
         self.max_rows = rows
         v = lambda name, dt: self._buf(name).view(dt)
-        self.img = v("img", torch.bfloat16).view(N, 3, S, S)               # static input buffer (camera frames batched)
+        self.img = v("img", torch.float32 if self.precision == "fp32" else torch.bfloat16).view(N, 3, S, S)   # static input buffer (camera frames)
         self.vx = v("vx", torch.float32).view(N, cfg.n_patches + 1, W)     # ViT residual stream (fp32)
         self.vis_x = v("vis_x", torch.bfloat16).view(N * nl, W)            # media tokens [rgb latents ; gripper latents] per env
         self.vis_x_f32 = v("vis_x_f32", torch.float32).view(N * nl, W)

@@ -134,11 +134,12 @@ class LangEncoder:
 
 class MPTFlamingo(nn.Module):
     def __init__(self, cfg: DeerConfig, state_dict: Optional[Dict[str, torch.Tensor]] = None, window_size: int = 12,
-                 use_gripper: bool = True, fusion_mode: str = "post", device="cuda", n_envs: int = 1, **unused):
+                 use_gripper: bool = True, fusion_mode: str = "post", device="cuda", n_envs: int = 1, precision: str = "bf16", **unused):
         super().__init__()
         if not use_gripper or fusion_mode != "post":
             raise NotImplementedError("released DeeR checkpoints use use_gripper=True, fusion_mode='post' (flamingo_mpt.py:380-381)")
         self.cfg = cfg
+        self.precision = precision        # "bf16": the product arithmetic; "fp32": fp32 activations everywhere (parity arithmetic, ~4x slower)
         self._device = device
         self.n_envs = n_envs                                      # environments per control step ("one env batch per rank")
         self._sd: Dict[str, torch.Tensor] = dict(state_dict) if state_dict is not None else {}
@@ -174,7 +175,7 @@ class MPTFlamingo(nn.Module):
             missing = [k for k in param_shapes(self.cfg) if k not in self._sd]
             if missing:
                 raise RuntimeError(f"{len(missing)} parameters missing before the first forward, e.g. {missing[:3]}")
-            self._engine = DeerEngine(self.cfg, self._sd, device=self._device, n_envs=self.n_envs)
+            self._engine = DeerEngine(self.cfg, self._sd, device=self._device, n_envs=self.n_envs, precision=self.precision)
             self.extra_exit = DeterministicDecoder(self._engine, self.window_size)
             self.lm_head = self.extra_exit
         return self._engine
@@ -213,7 +214,19 @@ class MPTFlamingo(nn.Module):
         self._engine = None                                       # weights changed: rebuild on next use
         return missing, unexpected
 
+    def set_precision(self, precision: str):
+        """"bf16" (default) or "fp32" (fp32 activations end to end, csrc/precise.hip).  The reference's ``model.float()`` /
+        ``model.bfloat16()`` casts (eval_calvin.py:559-564) stay no-ops here: they choose the WEIGHT dtype of a module whose
+        compute then runs under autocast, not the arithmetic of the step."""
+        if precision != self.precision:
+            self.precision = precision
+            self._engine = None
+        return self
+
     def to(self, *a, **k):
+        return self
+
+    def float(self):
         return self
 
     def half(self):

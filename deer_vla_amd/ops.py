@@ -106,7 +106,7 @@ def vit_l14_encode(images: torch.Tensor, model: int) -> torch.Tensor:
     """images (N,3,S,S) bf16/f32 CLIP-normalised -> patch tokens (N,256,W) f32 (x[:,1:], no ln_post)."""
     m = _model(model)
     cfg = m.cfg
-    img = images.to(torch.bfloat16).contiguous()
+    img = images.to(torch.float32 if getattr(m, "precision", "bf16") == "fp32" else torch.bfloat16).contiguous()
     out = torch.empty(img.shape[0], cfg.n_patches, cfg.vit_width, dtype=torch.float32, device=img.device)
     abi.check(m.lib.deer_vit_l14_encode(m._h, abi.ptr(img), img.shape[0], abi.ptr(out), _stream()), "deer_vit_l14_encode")
     return out

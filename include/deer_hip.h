@@ -171,6 +171,9 @@ int deer_attn_f32(const float* Q, const float* K1, const float* V1, const float*
 int deer_xattn_f32(const float* qslab, int s_in, long slab_stride, int ldqs, const float* kv, int ldkv, int inner, const int* text_time,
                    int n_per_media, float* out, int ldo, int T, int n_kv, int heads, int batch, float scale, const int* ctl, void* stream);
 
+/* im2col of the camera frames in f32 (deer_vit_im2col keeps bf16): out f32 [N*P, Kpad] */
+int deer_vit_im2col_f32(const float* img, int N, int S, int patch, float* out, int Kpad, void* stream);
+
 /* ---- row ops ------------------------------------------------------------------------------------------------
  * deer_layernorm_rows: nn.LayerNorm (ViT ln_1/ln_2, helpers.py:32-33,17,132), f32 in, bf16 and/or f32 out. */
 int deer_layernorm_rows(const float* x, long in_rstride, long in_bstride, int rows_per_batch, int batch, const float* gamma,

@@ -75,7 +75,7 @@ int deer_model_real_num_exit(const deer_model* m);
 /* ---- the three coarse operators of SURVEY.md §8b ------------------------------------------------------------------ */
 /* images: bf16 [n_images,3,S,S] (already CLIP-normalised); tokens_out: f32 [n_images,256,W] patch tokens (x[:,1:], no ln_post)
  * or NULL to leave them in the workspace only (the Perceiver reads them there). */
-int deer_vit_l14_encode(deer_model* m, const void* images_bf16, int n_images, float* tokens_out, void* stream);
+int deer_vit_l14_encode(deer_model* m, const void* images_bf16, int n_images, float* tokens_out, void* stream);   /* images: f32 when precision = 1 */
 /* tokens: f32 [n_images,256,W] or NULL (= the workspace tokens of the last deer_vit_l14_encode); media_bf16_out / media_f32_out:
  * [n_images*64, W] latents of every image in image order (rgb, gripper per environment = the post-fusion concat of
  * flamingo_mpt.py:661) or NULL to leave them in the workspace. */

@@ -32,7 +32,6 @@ def test_vision_tower_and_media_tokens_fp32_vs_oracle():
     m = ops.NativeModel(cfg, sd, precision="fp32")
     try:
         rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, 0)
-        rgb, grip = rgb.bfloat16().float(), grip.bfloat16().float()
         S = cfg.image_size
         images = torch.stack([rgb.reshape(3, S, S), grip.reshape(3, S, S)]).cuda()
         tok = torch.ops.deer.vit_l14_encode(images, m.handle)
@@ -60,7 +59,6 @@ def test_fp32_precision_actions_and_exits_vs_oracle(full):
     worst = 0.0
     for e in (cfg.exit_ids()[0], cfg.exit_ids()[-1]):
         rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, 1)
-        rgb, grip = rgb.bfloat16().float(), grip.bfloat16().float()
         a_o, _, _ = oracle_step(sd, cfg, rgb, grip, ids, mask, e)
         eng.reset()
         r = eng.step(rgb, grip, ids, mask, exit_id=e)
@@ -71,7 +69,7 @@ def test_fp32_precision_actions_and_exits_vs_oracle(full):
     inputs = []
     for st_ in range(n_steps):
         rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, st_)
-        inputs.append((rgb.bfloat16().float(), grip.bfloat16().float(), ids, mask))
+        inputs.append((rgb, grip, ids, mask))
 
     def oracle_episode(thr):
         od = orc.OracleDeer(sd, cfg)
@@ -111,3 +109,26 @@ def test_fp32_precision_actions_and_exits_vs_oracle(full):
     print(f"\n[fp32 precision, {'3B' if full else 'tiny'}] worst |action - oracle| {worst:.2e}; exits {exits_e}")
     assert exits_e == exits_o, (exits_e, exits_o)
     assert worst < FP32_ACTION_TOL, worst
+
+
+def test_factory_precision_fp32_matches_the_references_own_forward():
+    """drop-in surface with precision="fp32" against the golden outputs of the REFERENCE's MPTFlamingo.forward (fp32, CPU): 1e-3"""
+    from golden_util import load
+    from deer_vla_amd import factory
+    cfg, seed, g = load("deer_forward.npz")
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
+    model, _, _ = factory.create_model_and_transforms("ViT-L-14", "openai", "", "", cross_attn_every_n_layers=1, window_size=12, use_gripper=True,
+                                                       fusion_mode="post", llm_name="mpt_dolly_3b", state_dict=sd, cfg=cfg, precision="fp32")
+    ids, mask = g["ids"].long().cuda(), g["mask"].cuda()
+    worst = 0.0
+    for eid in (3, 4, -1):
+        model.clear_all_exit_memory()
+        o = model(vision_x=g["rgb"][0].cuda(), lang_x=ids, attention_mask=mask, vision_gripper=g["grip"][0].cuda(), return_feature=True,
+                  deterministic=True, exit_id=eid)
+        tag = f"static{eid}"
+        assert o.exit_layer == int(g[tag + "_exit"])
+        worst = max(worst, float((o.logits[0].cpu() - g[tag + "_pose"]).abs().max()), float((o.logits[1].cpu() - g[tag + "_grip"]).abs().max()))
+        ref_h = g[tag + "_hidden"][-1]
+        assert float((o.hidden_states[-1].cpu() - ref_h).abs().max() / ref_h.abs().max()) < 1e-4
+    print(f"\n[fp32 precision vs reference forward goldens] worst |logit - reference| {worst:.2e}")
+    assert worst < FP32_ACTION_TOL
