@@ -36,6 +36,7 @@ SIGNATURES = {
     "deer_resadd_ln": [P, P, I, L, P, P, P, P, P, P, P, I, I, F, P, P],
     "deer_vit_im2col": [P, I, I, I, I, P, I, P],
     "deer_vit_embed_lnpre": [P, P, P, P, P, P, I, I, I, F, P],
+    "deer_embed_tokens_f32": [P, P, P, P, I, I, I, I, I, P],
     "deer_vit_im2col_f32": [P, I, I, I, P, I, P],
     "deer_gemm_f32_nt": [P, I, P, I, P, P, I, I, I, I, I, P],
     "deer_attn_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
@@ -43,9 +44,9 @@ SIGNATURES = {
     "deer_embed_tokens": [P, P, P, P, I, I, I, I, I, P],
     "deer_broadcast_rows": [P, P, L, I, P],
     "deer_head_pool": [P, P, I, I, I, I, P, P, I, I, P],
-    "deer_head_lstm_layer": [P, L, I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, P, I, I, P],
-    "deer_head_fc": [P, I, I, I, P, P, P, P, P, P, P, P, I, P, I, F, P, I, I, P],
-    "deer_head_final": [P, I, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, I, I, P, F, P],
+    "deer_head_lstm_layer": [P, L, I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, P, I, I, I, P],
+    "deer_head_fc": [P, I, I, I, P, P, P, P, P, P, P, P, I, P, I, F, P, I, I, I, P],
+    "deer_head_final": [P, I, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, I, I, P, F, I, P],
     "deer_ctl_begin_step": [P, P, I, P],
     "deer_preprocess_frames": [P, I, I, I, I, P, P, P, P, P, P],
     "deer_preprocess_scratch_bytes": [I, I, I, I],

@@ -90,6 +90,25 @@ __device__ __forceinline__ float dot8(const uint4 w, const float* x) {
   return a;
 }
 
+// Weight rows are bf16 (product arithmetic) or f32 (precision = 1, csrc/precise.hip): eight consecutive weights as a register bundle
+template <typename WT> struct W8;
+template <> struct W8<bf16_t> {
+  typedef uint4 reg;
+  static __device__ __forceinline__ reg zero() { return uint4{0, 0, 0, 0}; }
+  static __device__ __forceinline__ reg load(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ reg load_stream(const bf16_t* p) { return ld_stream16(p); }
+  static __device__ __forceinline__ float dot(const reg& w, const float* x) { return dot8(w, x); }
+};
+template <> struct W8<float> {
+  struct reg { float4 a, b; };
+  static __device__ __forceinline__ reg zero() { return reg{float4{0.f, 0.f, 0.f, 0.f}, float4{0.f, 0.f, 0.f, 0.f}}; }
+  static __device__ __forceinline__ reg load(const float* p) { return reg{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)}; }
+  static __device__ __forceinline__ reg load_stream(const float* p) { return load(p); }
+  static __device__ __forceinline__ float dot(const reg& w, const float* x) {
+    return w.a.x * x[0] + w.a.y * x[1] + w.a.z * x[2] + w.a.w * x[3] + w.b.x * x[4] + w.b.y * x[5] + w.b.z * x[6] + w.b.w * x[7];
+  }
+};
+
 // LayerNorm of src[0..n) into dst (LDS), optional ReLU; all threads of the block participate.
 __device__ __forceinline__ void block_ln(const float* __restrict__ src, float* dst, int n, const float* __restrict__ w,
                                          const float* __restrict__ b, float eps, bool relu, float* red) {
@@ -231,10 +250,11 @@ extern "C" int deer_head_pool(const float* feats, float* pooled, int T, int d, i
 // wave -> hidden unit j: rows j, H+j, 2H+j, 3H+j of [W_ih | W_hh]; c' = s(f) c + s(i) tanh(g); h' = s(o) tanh(c').
 // x_src: X_POOL_*: feats [B][T_stride rows][in_dim] (env b at x_src + b*x_bstride), pooled over the first T rows;
 //        X_LN / X_RAW: [B][in_dim] (previous layer's h of each env, x_bstride = in_dim).  State tensors are [B][H].
+template <typename WT>
 __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __restrict__ x_src, long x_bstride, int x_mode, int T,
                                                               int in_dim, const float* __restrict__ ln_w,
-                                                              const float* __restrict__ ln_b, const bf16_t* __restrict__ w_ih,
-                                                              const bf16_t* __restrict__ w_hh, const float* __restrict__ b_ih,
+                                                              const float* __restrict__ ln_b, const WT* __restrict__ w_ih,
+                                                              const WT* __restrict__ w_hh, const float* __restrict__ b_ih,
                                                               const float* __restrict__ b_hh, const float* __restrict__ h_prev,
                                                               const float* __restrict__ c_prev, float* __restrict__ h_out,
                                                               float* __restrict__ c_out, int H, int B_all, int b0, int B, float eps,
@@ -253,20 +273,20 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
   // issued BEFORE the activations are staged (pool / LayerNorm / copy into LDS), so the HBM round trip overlaps the staging and
   // there is one exposed memory latency per launch instead of one per k-step.
   constexpr int LSTM_PF = 4;
-  uint4 wi[LSTM_PF][4], wh[2][4];
+  typename W8<WT>::reg wi[LSTM_PF][4], wh[2][4];
 #pragma unroll
   for (int u = 0; u < LSTM_PF; ++u) {
     const int k = u * 512 + lane * 8;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      wi[u][q] = k < in_dim ? ld_stream16(w_ih + ((long)q * H + jr) * in_dim + k) : uint4{0, 0, 0, 0};
+      wi[u][q] = k < in_dim ? W8<WT>::load_stream(w_ih + ((long)q * H + jr) * in_dim + k) : W8<WT>::zero();
   }
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int k = u * 512 + lane * 8;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      wh[u][q] = k < H ? ld_stream16(w_hh + ((long)q * H + jr) * H + k) : uint4{0, 0, 0, 0};
+      wh[u][q] = k < H ? W8<WT>::load_stream(w_hh + ((long)q * H + jr) * H + k) : W8<WT>::zero();
   }
   if (x_mode == X_LN || x_mode == X_RAW) {
     rows_to_lds(x_src, x_bstride, xs, in_dim, B, x_mode == X_LN, ln_w, ln_b, eps, false);
@@ -303,19 +323,19 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
       for (int b = 0; b < HB_MAX; ++b)
         if (b < B) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q][b] += dot8(wi[u][q], xs + b * in_dim + k);
+          for (int q = 0; q < 4; ++q) acc[q][b] += W8<WT>::dot(wi[u][q], xs + b * in_dim + k);
         }
     }
   }
   for (int k = LSTM_PF * 512 + lane * 8; k < in_dim; k += 512) {
-    uint4 w[4];
+    typename W8<WT>::reg w[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const uint4*>(w_ih + ((long)q * H + j) * in_dim + k);
+    for (int q = 0; q < 4; ++q) w[q] = W8<WT>::load(w_ih + ((long)q * H + j) * in_dim + k);
 #pragma unroll
     for (int b = 0; b < HB_MAX; ++b)
       if (b < B) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q][b] += dot8(w[q], xs + b * in_dim + k);
+        for (int q = 0; q < 4; ++q) acc[q][b] += W8<WT>::dot(w[q], xs + b * in_dim + k);
       }
   }
 #pragma unroll
@@ -326,19 +346,19 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
       for (int b = 0; b < HB_MAX; ++b)
         if (b < B) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q][b] += dot8(wh[u][q], hs + b * H + k);
+          for (int q = 0; q < 4; ++q) acc[q][b] += W8<WT>::dot(wh[u][q], hs + b * H + k);
         }
     }
   }
   for (int k = 2 * 512 + lane * 8; k < H; k += 512) {
-    uint4 w[4];
+    typename W8<WT>::reg w[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const uint4*>(w_hh + ((long)q * H + j) * H + k);
+    for (int q = 0; q < 4; ++q) w[q] = W8<WT>::load(w_hh + ((long)q * H + j) * H + k);
 #pragma unroll
     for (int b = 0; b < HB_MAX; ++b)
       if (b < B) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q][b] += dot8(w[q], hs + b * H + k);
+        for (int q = 0; q < 4; ++q) acc[q][b] += W8<WT>::dot(w[q], hs + b * H + k);
       }
   }
   // wave totals land in every lane; lane b then does environment b's gate arithmetic (B transcendental chains in parallel)
@@ -364,7 +384,7 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
 extern "C" int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w,
                                     const float* ln_b, const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh,
                                     const float* h_prev, const float* c_prev, float* h_out, float* c_out, int H, int B, float eps,
-                                    const int* ctl, int kind, int layer, void* stream) {
+                                    const int* ctl, int kind, int layer, int w_is_f32, void* stream) {
   if (in_dim <= 0 || (in_dim & 7) || H <= 0 || (H & 7) || x_mode < 0 || x_mode > 3 || (x_mode == X_LN && (ln_w == nullptr || in_dim > 2048)) ||
       ((x_mode == X_LN || x_mode == X_RAW) && (x_bstride & 3)) ||
       ((x_mode == X_POOL_MAX || x_mode == X_POOL_AVG) && T <= 0) || B <= 0 || B > HB_MAX)
@@ -376,7 +396,9 @@ extern "C" int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mo
   if (nb_max < 1) return DEER_ERR_SHAPE;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&head_lstm_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&head_lstm_layer_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            150 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&head_lstm_layer_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             150 * 1024) != hipSuccess)
       return DEER_ERR_LAUNCH;
     attr_set = true;
@@ -385,9 +407,14 @@ extern "C" int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mo
   for (int b0 = 0; b0 < B; b0 += nb_even) {
     const int nb = B - b0 < nb_even ? B - b0 : nb_even;
     const int smem = nb * per_env + 64;
-    hipLaunchKernelGGL(head_lstm_layer_kernel, dim3((H + 3) / 4), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), x_src,
-                       x_bstride, x_mode, T, in_dim, ln_w, ln_b, reinterpret_cast<const bf16_t*>(w_ih),
-                       reinterpret_cast<const bf16_t*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, b0, nb, eps, ctl, kind, layer);
+    if (w_is_f32)
+      hipLaunchKernelGGL(head_lstm_layer_kernel<float>, dim3((H + 3) / 4), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), x_src,
+                         x_bstride, x_mode, T, in_dim, ln_w, ln_b, reinterpret_cast<const float*>(w_ih),
+                         reinterpret_cast<const float*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, b0, nb, eps, ctl, kind, layer);
+    else
+      hipLaunchKernelGGL(head_lstm_layer_kernel<bf16_t>, dim3((H + 3) / 4), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), x_src,
+                         x_bstride, x_mode, T, in_dim, ln_w, ln_b, reinterpret_cast<const bf16_t*>(w_ih),
+                         reinterpret_cast<const bf16_t*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, b0, nb, eps, ctl, kind, layer);
   }
   DEER_LAUNCH_CHECK();
   return DEER_OK;
@@ -397,11 +424,12 @@ extern "C" int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mo
 // src: [B][src_stride]; pro: PRO_LN   x = LN(src_b[0..in))  (shared: LSTM output LayerNorm, action_head.py:55-56)
 //      PRO_RAW x = src_b[0..in) (plain nn.LSTM); PRO_GROUP_LN_RELU x_g = relu(LN_g(src_b[g*in..])) (Linear -> LN -> ReLU,
 //      action_head.py:97-103); PRO_GROUP_RELU x_g = relu(src_b[g*in..]).   dst: [B][2*out_dim].
+template <typename WT>
 __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ src, int src_stride, int in_dim, int pro,
                                                       const float* __restrict__ lnw0, const float* __restrict__ lnb0,
                                                       const float* __restrict__ lnw1, const float* __restrict__ lnb1,
-                                                      const bf16_t* __restrict__ W0, const float* __restrict__ b0,
-                                                      const bf16_t* __restrict__ W1, const float* __restrict__ b1, int out_dim,
+                                                      const WT* __restrict__ W0, const float* __restrict__ b0,
+                                                      const WT* __restrict__ W1, const float* __restrict__ b1, int out_dim,
                                                       float* __restrict__ dst, int B, float eps, const int* ctl, int kind,
                                                       int layer) {
   if (head_skip(ctl, kind, layer, B)) return;
@@ -409,18 +437,18 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
   float* xs = lds;                     // [B][in_dim]
   const int grp = blockIdx.y;
   const bool grouped = (pro == PRO_GROUP_LN_RELU || pro == PRO_GROUP_RELU);
-  const bf16_t* W = grp ? W1 : W0;
+  const WT* W = grp ? W1 : W0;
   const float* bb = grp ? b1 : b0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = (blockIdx.x * 4 + wave) * 2;
   const bool live = n0 < out_dim, two = (n0 + 1 < out_dim);
   // weights of the first two k-steps are requested before the LayerNorm staging (one exposed HBM latency per launch)
-  uint4 pw0[2], pw1[2];
+  typename W8<WT>::reg pw0[2], pw1[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int k = u * 512 + lane * 8;
-    pw0[u] = (live && k < in_dim) ? ld_stream16(W + (long)n0 * in_dim + k) : uint4{0, 0, 0, 0};
-    pw1[u] = (two && k < in_dim) ? ld_stream16(W + (long)(n0 + 1) * in_dim + k) : uint4{0, 0, 0, 0};
+    pw0[u] = (live && k < in_dim) ? W8<WT>::load_stream(W + (long)n0 * in_dim + k) : W8<WT>::zero();
+    pw1[u] = (two && k < in_dim) ? W8<WT>::load_stream(W + (long)(n0 + 1) * in_dim + k) : W8<WT>::zero();
   }
   {
     const float* s0 = src + (grouped ? (long)grp * in_dim : 0);
@@ -441,19 +469,19 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
 #pragma unroll
       for (int b = 0; b < HB_MAX; ++b)
         if (b < B) {
-          a0[b] += dot8(pw0[u], xs + b * in_dim + k);
-          a1[b] += dot8(pw1[u], xs + b * in_dim + k);
+          a0[b] += W8<WT>::dot(pw0[u], xs + b * in_dim + k);
+          a1[b] += W8<WT>::dot(pw1[u], xs + b * in_dim + k);
         }
     }
   }
   for (int k = 2 * 512 + lane * 8; k < in_dim; k += 512) {
-    const uint4 w0 = *reinterpret_cast<const uint4*>(W + (long)n0 * in_dim + k);
-    const uint4 w1 = two ? *reinterpret_cast<const uint4*>(W + (long)(n0 + 1) * in_dim + k) : uint4{0, 0, 0, 0};
+    const typename W8<WT>::reg w0 = W8<WT>::load(W + (long)n0 * in_dim + k);
+    const typename W8<WT>::reg w1 = two ? W8<WT>::load(W + (long)(n0 + 1) * in_dim + k) : W8<WT>::zero();
 #pragma unroll
     for (int b = 0; b < HB_MAX; ++b)
       if (b < B) {
-        a0[b] += dot8(w0, xs + b * in_dim + k);
-        a1[b] += dot8(w1, xs + b * in_dim + k);
+        a0[b] += W8<WT>::dot(w0, xs + b * in_dim + k);
+        a1[b] += W8<WT>::dot(w1, xs + b * in_dim + k);
       }
   }
 #pragma unroll
@@ -469,16 +497,21 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
 
 extern "C" int deer_head_fc(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0,
                             const float* lnw1, const float* lnb1, const void* W0, const float* b0, const void* W1, const float* b1,
-                            int out_dim, float* dst, int B, float eps, const int* ctl, int kind, int layer, void* stream) {
+                            int out_dim, float* dst, int B, float eps, const int* ctl, int kind, int layer, int w_is_f32, void* stream) {
   if (in_dim <= 0 || (in_dim & 7) || out_dim <= 0 || pro < 0 || pro > 3 || B <= 0 || B > HB_MAX || (src_stride & 3) ||
       ((pro == PRO_LN || pro == PRO_GROUP_LN_RELU) && in_dim > 2048))
     return DEER_ERR_SHAPE;
   const int smem = (B * in_dim + 16) * (int)sizeof(float);
   if (smem > 64 * 1024) return DEER_ERR_SHAPE;
   dim3 grid((out_dim + 7) / 8, 2);
-  hipLaunchKernelGGL(head_fc_kernel, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), src, src_stride, in_dim, pro, lnw0,
-                     lnb0, lnw1, lnb1, reinterpret_cast<const bf16_t*>(W0), b0, reinterpret_cast<const bf16_t*>(W1), b1, out_dim, dst,
-                     B, eps, ctl, kind, layer);
+  if (w_is_f32)
+    hipLaunchKernelGGL(head_fc_kernel<float>, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), src, src_stride, in_dim, pro, lnw0,
+                       lnb0, lnw1, lnb1, reinterpret_cast<const float*>(W0), b0, reinterpret_cast<const float*>(W1), b1, out_dim, dst,
+                       B, eps, ctl, kind, layer);
+  else
+    hipLaunchKernelGGL(head_fc_kernel<bf16_t>, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), src, src_stride, in_dim, pro, lnw0,
+                       lnb0, lnw1, lnb1, reinterpret_cast<const bf16_t*>(W0), b0, reinterpret_cast<const bf16_t*>(W1), b1, out_dim, dst,
+                       B, eps, ctl, kind, layer);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
@@ -486,11 +519,12 @@ extern "C" int deer_head_fc(const float* src, int src_stride, int in_dim, int pr
 // ---- output Linear (6 tanh + 1 sigmoid) + exit gate, per environment ----------------------------------------------
 // One workgroup per environment.  src: [B][src_stride] (the last hidden Linear's output, [2][in_dim] per env).
 // ctl: env b at ctl + b*CTL_WORDS.  State tensors h/c: [L][B][H] (LH = L, sH = H).  action_dbg: [B][8] or NULL.
+template <typename WT>
 __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict__ src, int src_stride, int in_dim, int pro,
                                                          const float* __restrict__ lnw0, const float* __restrict__ lnb0,
                                                          const float* __restrict__ lnw1, const float* __restrict__ lnb1,
-                                                         const bf16_t* __restrict__ Wa, const float* __restrict__ ba,
-                                                         const bf16_t* __restrict__ Wg, const float* __restrict__ bg, int* ctl0,
+                                                         const WT* __restrict__ Wa, const float* __restrict__ ba,
+                                                         const WT* __restrict__ Wg, const float* __restrict__ bg, int* ctl0,
                                                          int kind, int layer, int slot, const float* __restrict__ thresholds,
                                                          int force, int thr_type, int leq, const float* __restrict__ h_tmp,
                                                          const float* __restrict__ c_tmp, float* __restrict__ h_state,
@@ -515,12 +549,12 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bf16_t* Wrow = (wave < 6) ? Wa + (long)wave * in_dim : Wg;
-  uint4 pw[2];                        // first two k-steps of this wave's output row, requested before the LayerNorm staging
+  const WT* Wrow = (wave < 6) ? Wa + (long)wave * in_dim : Wg;
+  typename W8<WT>::reg pw[2];                        // first two k-steps of this wave's output row, requested before the LayerNorm staging
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int k = u * 512 + lane * 8;
-    pw[u] = (wave < 7 && k < in_dim) ? *reinterpret_cast<const uint4*>(Wrow + k) : uint4{0, 0, 0, 0};
+    pw[u] = (wave < 7 && k < in_dim) ? W8<WT>::load(Wrow + k) : W8<WT>::zero();
   }
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xa = lds;                    // actions-head input [in_dim]
@@ -552,9 +586,9 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int k = u * 512 + lane * 8;
-      if (k < in_dim) a += dot8(pw[u], x + k);
+      if (k < in_dim) a += W8<WT>::dot(pw[u], x + k);
     }
-    for (int k = 2 * 512 + lane * 8; k < in_dim; k += 512) a += dot8(*reinterpret_cast<const uint4*>(Wrow + k), x + k);
+    for (int k = 2 * 512 + lane * 8; k < in_dim; k += 512) a += W8<WT>::dot(W8<WT>::load(Wrow + k), x + k);
     a = wave_sum(a);
     if (lane == 0) outv[wave] = a + ((wave < 6) ? ba[wave] : bg[0]);
   }
@@ -646,14 +680,19 @@ extern "C" int deer_head_final(const float* src, int src_stride, int in_dim, int
                                const float* lnw1, const float* lnb1, const void* Wa, const float* ba, const void* Wg, const float* bg,
                                int* ctl, int kind, int layer, int slot, const float* thresholds, int force, int thr_type, int leq,
                                const float* h_tmp, const float* c_tmp, float* h_state, float* c_state, int L, int H, int B,
-                               float* action_dbg, float eps, void* stream) {
+                               float* action_dbg, float eps, int w_is_f32, void* stream) {
   if (in_dim <= 0 || (in_dim & 7) || pro < 0 || pro > 3 || kind < 0 || kind > 2 || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
   if (kind == KIND_CHECK && (thresholds == nullptr || slot < 0 || ctl == nullptr)) return DEER_ERR_SHAPE;
   const int smem = (2 * in_dim + 16 + 8 + 4) * (int)sizeof(float);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(head_final_kernel, dim3(B), dim3(512), smem, st, src, src_stride, in_dim, pro, lnw0, lnb0, lnw1, lnb1,
-                     reinterpret_cast<const bf16_t*>(Wa), ba, reinterpret_cast<const bf16_t*>(Wg), bg, ctl, kind, layer, slot,
-                     thresholds, force, thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps);
+  if (w_is_f32)
+    hipLaunchKernelGGL(head_final_kernel<float>, dim3(B), dim3(512), smem, st, src, src_stride, in_dim, pro, lnw0, lnb0, lnw1, lnb1,
+                       reinterpret_cast<const float*>(Wa), ba, reinterpret_cast<const float*>(Wg), bg, ctl, kind, layer, slot,
+                       thresholds, force, thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps);
+  else
+    hipLaunchKernelGGL(head_final_kernel<bf16_t>, dim3(B), dim3(512), smem, st, src, src_stride, in_dim, pro, lnw0, lnb0, lnw1, lnb1,
+                       reinterpret_cast<const bf16_t*>(Wa), ba, reinterpret_cast<const bf16_t*>(Wg), bg, ctl, kind, layer, slot,
+                       thresholds, force, thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

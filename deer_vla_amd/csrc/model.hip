@@ -47,7 +47,8 @@ __global__ void ingest_rows_kernel(const SrcT* __restrict__ src, void* __restric
 }
 
 // row-major W[N,K] (f32 or bf16) -> MFMA-fragment order Wp[N/16][K/32][64 lanes][8] bf16 (the layout deer_gemm_skinny streams)
-template <typename SrcT>
+// LO: the second plane of the fp32 arithmetic, bf16(w - bf16(w)) - together with the hi plane ~16 mantissa bits of every weight
+template <typename SrcT, bool LO = false>
 __global__ void ingest_pack_kernel(const SrcT* __restrict__ W, bf16_t* __restrict__ Wp, int N, int K) {
   const long total = (long)(N >> 4) * (K >> 5) * 64;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -58,8 +59,14 @@ __global__ void ingest_pack_kernel(const SrcT* __restrict__ W, bf16_t* __restric
     const int n = tile * 16 + (lane & 15), k = kt * 32 + (lane >> 4) * 8;
     uint32_t o[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      o[e] = pack2bf(ld_as_f32<SrcT>(W, (long)n * K + k + 2 * e), ld_as_f32<SrcT>(W, (long)n * K + k + 2 * e + 1));
+    for (int e = 0; e < 4; ++e) {
+      float a = ld_as_f32<SrcT>(W, (long)n * K + k + 2 * e), b = ld_as_f32<SrcT>(W, (long)n * K + k + 2 * e + 1);
+      if (LO) {
+        a -= bf2f(f2bf(a));
+        b -= bf2f(f2bf(b));
+      }
+      o[e] = pack2bf(a, b);
+    }
     *reinterpret_cast<uint4*>(Wp + idx * 8) = uint4{o[0], o[1], o[2], o[3]};
   }
 }
@@ -151,6 +158,7 @@ struct deer_model {
   std::unordered_map<std::string, std::pair<size_t, size_t>> ws_named;
   VisionWS vws;
   PreciseWS hp{};
+  std::unordered_map<size_t, size_t> pack_lo;   // arena offset of a packed weight -> offset of its lo plane (precision = 1)
   std::vector<VisionWS> chains;
   size_t img, vis_x, vis_x_f32, kv_all, ids, key_mask, text_time, x, xn, ao, slab_a, slab_b, qkv_ws, hidden, h_state, c_state, h_tmp,
       c_tmp, h_shadow, c_shadow, pooled, ctl, step_info, thresholds, action_dbg;
@@ -227,6 +235,10 @@ size_t add_slot(deer_model* m, const std::string& name, int kind, long rows, int
   const size_t esz = kind == SK_F32 ? 4 : 2;
   const size_t off = existing != SIZE_MAX ? existing : m->al.add((size_t)rows * pitch * esz);
   Slot s{kind, rows, cols, dst_cols, pitch, {off, SIZE_MAX}, 0, required, false};
+  if (kind == SK_PACK && m->c.precision) {   // fp32 arithmetic: lo plane of the packed weight, streamed by a second skinny launch
+    s.dst[1] = m->al.add((size_t)rows * pitch * 2);
+    m->pack_lo[off] = s.dst[1];
+  }
   m->slots[name] = s;
   m->slot_order.push_back(name);
   return off;
@@ -237,7 +249,10 @@ void build_arena(deer_model* m) {
   const int W = m->W;
   const std::string v = "vision_encoder.visual.";
   const int kk = 3 * c.patch_size * c.patch_size;
-  m->conv = add_slot(m, v + "conv1.weight", SK_BF16, W, kk, true, m->kpad);
+  // GEMM operands of the vision tower / Perceiver / x-attn K|V projection: bf16 for the product arithmetic, f32 for the fp32 one
+  const int GK = c.precision ? SK_F32 : SK_BF16;
+  const size_t we = c.precision ? 4 : 2;
+  m->conv = add_slot(m, v + "conv1.weight", GK, W, kk, true, m->kpad);
   m->cls = add_slot(m, v + "class_embedding", SK_F32, 1, W);
   m->pos = add_slot(m, v + "positional_embedding", SK_F32, m->tok, W);
   m->ln_pre_w = add_slot(m, v + "ln_pre.weight", SK_F32, 1, W);
@@ -248,15 +263,15 @@ void build_arena(deer_model* m) {
     VitLayerW& L = m->vit[l];
     L.ln1w = add_slot(m, p + "ln_1.weight", SK_F32, 1, W);
     L.ln1b = add_slot(m, p + "ln_1.bias", SK_F32, 1, W);
-    L.wqkv = add_slot(m, p + "attn.in_proj_weight", SK_BF16, 3 * W, W);
+    L.wqkv = add_slot(m, p + "attn.in_proj_weight", GK, 3 * W, W);
     L.bqkv = add_slot(m, p + "attn.in_proj_bias", SK_F32, 1, 3 * W);
-    L.wo = add_slot(m, p + "attn.out_proj.weight", SK_BF16, W, W);
+    L.wo = add_slot(m, p + "attn.out_proj.weight", GK, W, W);
     L.bo = add_slot(m, p + "attn.out_proj.bias", SK_F32, 1, W);
     L.ln2w = add_slot(m, p + "ln_2.weight", SK_F32, 1, W);
     L.ln2b = add_slot(m, p + "ln_2.bias", SK_F32, 1, W);
-    L.wfc = add_slot(m, p + "mlp.c_fc.weight", SK_BF16, c.vit_mlp, W);
+    L.wfc = add_slot(m, p + "mlp.c_fc.weight", GK, c.vit_mlp, W);
     L.bfc = add_slot(m, p + "mlp.c_fc.bias", SK_F32, 1, c.vit_mlp);
-    L.wpr = add_slot(m, p + "mlp.c_proj.weight", SK_BF16, W, c.vit_mlp);
+    L.wpr = add_slot(m, p + "mlp.c_proj.weight", GK, W, c.vit_mlp);
     L.bpr = add_slot(m, p + "mlp.c_proj.bias", SK_F32, 1, W);
   }
   // ---- Perceiver: the media tokens are the same in every layer, so norm_media / to_kv of ALL layers are stacked (applied up
@@ -267,7 +282,7 @@ void build_arena(deer_model* m) {
   m->perc_normb = add_slot(m, "perceiver.norm.bias", SK_F32, 1, W);
   m->perc_nm_w = m->al.add((size_t)Lp * W * 4);
   m->perc_nm_b = m->al.add((size_t)Lp * W * 4);
-  m->perc_wkv_all = m->al.add((size_t)Lp * 2 * inner * W * 2);
+  m->perc_wkv_all = m->al.add((size_t)Lp * 2 * inner * W * we);
   m->perc.resize(Lp);
   for (int l = 0; l < Lp; ++l) {
     const std::string a = "perceiver.layers." + std::to_string(l) + ".0.", f = "perceiver.layers." + std::to_string(l) + ".1.";
@@ -276,24 +291,26 @@ void build_arena(deer_model* m) {
     add_slot(m, a + "norm_media.bias", SK_F32, 1, W, true, -1, m->perc_nm_b + (size_t)l * W * 4);
     L.nlw = add_slot(m, a + "norm_latents.weight", SK_F32, 1, W);
     L.nlb = add_slot(m, a + "norm_latents.bias", SK_F32, 1, W);
-    L.wqkv = m->al.add((size_t)3 * inner * W * 2);
-    add_slot(m, a + "to_q.weight", SK_BF16, inner, W, true, -1, L.wqkv);
-    add_slot(m, a + "to_kv.weight", SK_BF16, 2 * inner, W, true, -1, L.wqkv + (size_t)inner * W * 2);
-    m->slots[a + "to_kv.weight"].dst[1] = m->perc_wkv_all + (size_t)l * 2 * inner * W * 2;
+    L.wqkv = m->al.add((size_t)3 * inner * W * we);
+    add_slot(m, a + "to_q.weight", GK, inner, W, true, -1, L.wqkv);
+    add_slot(m, a + "to_kv.weight", GK, 2 * inner, W, true, -1, L.wqkv + (size_t)inner * W * we);
+    m->slots[a + "to_kv.weight"].dst[1] = m->perc_wkv_all + (size_t)l * 2 * inner * W * we;
     m->slots[a + "to_kv.weight"].dst2_pitch = W;
-    L.wo = add_slot(m, a + "to_out.weight", SK_BF16, W, inner);
+    L.wo = add_slot(m, a + "to_out.weight", GK, W, inner);
     L.fnw = add_slot(m, f + "0.weight", SK_F32, 1, W);
     L.fnb = add_slot(m, f + "0.bias", SK_F32, 1, W);
-    L.w1 = add_slot(m, f + "1.weight", SK_BF16, (long)c.perc_ff_mult * W, W);
-    L.w2 = add_slot(m, f + "3.weight", SK_BF16, W, c.perc_ff_mult * W);
+    L.w1 = add_slot(m, f + "1.weight", GK, (long)c.perc_ff_mult * W, W);
+    L.w2 = add_slot(m, f + "3.weight", GK, W, c.perc_ff_mult * W);
   }
   // ---- LLM: projections pre-packed in MFMA-fragment order; to_kv of all x-attn layers concatenated (media is layer-invariant)
   const int d = m->d, xin = m->xinner;
-  m->wte = add_slot(m, "lang_encoder.transformer.wte.weight", SK_BF16, c.vocab_size, d);
+  m->wte = add_slot(m, "lang_encoder.transformer.wte.weight", c.precision ? SK_F32 : SK_BF16, c.vocab_size, d);
   m->n_xattn = 0;
   for (int n = 0; n < c.n_layers; ++n)
     if ((n + 1) % c.cross_attn_every_n_layers == 0) ++m->n_xattn;
-  m->wkv_all = m->n_xattn ? m->al.add((size_t)m->n_xattn * 2 * xin * W * 2) : SIZE_MAX;
+  const int GKx = c.precision ? SK_F32 : SK_BF16;
+  const size_t wex = c.precision ? 4 : 2;
+  m->wkv_all = m->n_xattn ? m->al.add((size_t)m->n_xattn * 2 * xin * W * wex) : SIZE_MAX;
   m->llm.resize(c.n_layers);
   int kv_index = 0;
   const char* ln1 = c.mpt7b_names ? "norm_1" : "ln_1";
@@ -310,7 +327,7 @@ void build_arena(deer_model* m) {
       X.nw = add_slot(m, x + "attn.norm.weight", SK_F32, 1, d);
       X.nb = add_slot(m, x + "attn.norm.bias", SK_F32, 1, d);
       X.wq = add_slot(m, x + "attn.to_q.weight", SK_PACK, xin, d);
-      add_slot(m, x + "attn.to_kv.weight", SK_BF16, 2 * xin, W, true, -1, m->wkv_all + (size_t)kv_index * 2 * xin * W * 2);
+      add_slot(m, x + "attn.to_kv.weight", GKx, 2 * xin, W, true, -1, m->wkv_all + (size_t)kv_index * 2 * xin * W * wex);
       X.kv_index = kv_index++;
       X.wo = add_slot(m, x + "attn.to_out.weight", SK_PACK, d, xin);
       X.ag = add_slot(m, x + "attn_gate", SK_F32, 1, 1);
@@ -339,6 +356,7 @@ void build_arena(deer_model* m) {
   }
   // ---- action head (DeterministicDecoder, action_head.py:408-497): LN-LSTM = [LSTM, LN, Dropout] x L under rnn.layers.{3l, 3l+1}
   const std::string p = "extra_exit.";
+  const int HK = c.precision ? SK_F32 : SK_BF16;      // head weights: bf16, or f32 for the fp32 arithmetic
   const int H = m->H;
   m->lstm.resize(m->Lh);
   int in_f = d;
@@ -347,8 +365,8 @@ void build_arena(deer_model* m) {
     if (c.lstm_layernorm) { r = p + "rnn.layers." + std::to_string(3 * l) + "."; sfx = "_l0"; }
     else { r = p + "rnn."; sfx = "_l" + std::to_string(l); }
     LstmW& Lw = m->lstm[l];
-    Lw.wih = add_slot(m, r + "weight_ih" + sfx, SK_BF16, 4L * H, in_f);
-    Lw.whh = add_slot(m, r + "weight_hh" + sfx, SK_BF16, 4L * H, H);
+    Lw.wih = add_slot(m, r + "weight_ih" + sfx, HK, 4L * H, in_f);
+    Lw.whh = add_slot(m, r + "weight_hh" + sfx, HK, 4L * H, H);
     Lw.bih = add_slot(m, r + "bias_ih" + sfx, SK_F32, 1, 4 * H);
     Lw.bhh = add_slot(m, r + "bias_hh" + sfx, SK_F32, 1, 4 * H);
     Lw.lnw = Lw.lnb = SIZE_MAX;
@@ -366,7 +384,7 @@ void build_arena(deer_model* m) {
     for (int i = 0; i < m->n_fc; ++i) {
       const std::string li = p + heads[g] + ".mlp." + std::to_string(1 + 4 * i) + ".";
       const std::string ni = p + heads[g] + ".mlp." + std::to_string(2 + 4 * i) + ".";
-      m->fc[i].w[g] = add_slot(m, li + "weight", SK_BF16, m->fc_dims[i], cur);
+      m->fc[i].w[g] = add_slot(m, li + "weight", HK, m->fc_dims[i], cur);
       m->fc[i].b[g] = add_slot(m, li + "bias", SK_F32, 1, m->fc_dims[i]);
       m->fc[i].lnw[g] = m->fc[i].lnb[g] = SIZE_MAX;
       if (c.mlp_layernorm) {
@@ -377,7 +395,7 @@ void build_arena(deer_model* m) {
     }
     const std::string lo = p + heads[g] + ".mlp." + std::to_string(1 + 4 * m->n_fc) + ".";
     const int n_out = g == 0 ? 6 : 1;
-    (g == 0 ? m->wa : m->wg) = add_slot(m, lo + "weight", SK_BF16, n_out, cur);
+    (g == 0 ? m->wa : m->wg) = add_slot(m, lo + "weight", HK, n_out, cur);
     (g == 0 ? m->ba : m->bg) = add_slot(m, lo + "bias", SK_F32, 1, n_out);
   }
 }
@@ -475,8 +493,9 @@ void build_workspace(deer_model* m) {
   m->ao = named(m, "ao", (size_t)T * std::max(d, m->xinner) * 4);
   const long max_n = std::max(std::max((long)c.mlp_ratio * d, (long)c.xattn_ff_mult * d), 3L * d);
   const int mpad = 16 * ((T + 15) / 16);
-  m->slab_a_elems = (size_t)kMaxSplit * mpad * d;
-  m->slab_b_elems = (size_t)16 * mpad * max_n;
+  const int planes = c.precision ? 2 : 1;
+  m->slab_a_elems = (size_t)planes * kMaxSplit * mpad * d;
+  m->slab_b_elems = (size_t)planes * 16 * mpad * max_n;
   m->slab_a = named(m, "slab_a", m->slab_a_elems * 4);
   m->slab_b = named(m, "slab_b", m->slab_b_elems * 4);
   m->qkv_ws = named(m, "qkv_ws", (size_t)T * 3 * d * 4);
@@ -526,7 +545,7 @@ int ln_rows(deer_model* m, const float* x, const float* gamma, const float* beta
 
 const void* step_images(const deer_model* m) { return m->img_override ? m->img_override : m->Wk<void>(m->img); }
 
-int gemmf(deer_model* m, const float* A, long lda, const void* Wt, const float* bias, float* C, long ldc, long M, long N, long K, int epi, void* st);
+int gemmf(deer_model* m, const float* A, long lda, const float* Wt, const float* bias, float* C, long ldc, long M, long N, long K, int epi, void* st);
 
 int patch_embed(deer_model* m, const VisionWS& ws, void* st) {
   const deer_config& c = m->c;
@@ -538,7 +557,7 @@ int patch_embed(deer_model* m, const VisionWS& ws, void* st) {
       Bracket b(m, "deer_vit_im2col", 0, 0, st);
       DEER_TRY(deer_vit_im2col_f32(reinterpret_cast<const float*>(img), ws.n, c.image_size, c.patch_size, m->Wk<float>(m->hp.im2col), m->kpad, st));
     }
-    DEER_TRY(gemmf(m, m->Wk<float>(m->hp.im2col), m->kpad, m->A<void>(m->conv), nullptr, m->Wk<float>(ws.patch_out), W, (long)ws.n * P, W, m->kpad, 0, st));
+    DEER_TRY(gemmf(m, m->Wk<float>(m->hp.im2col), m->kpad, m->A<float>(m->conv), nullptr, m->Wk<float>(ws.patch_out), W, (long)ws.n * P, W, m->kpad, 0, st));
   } else {
     {
       Bracket b(m, "deer_vit_im2col", 0, 0, st);
@@ -642,8 +661,8 @@ int vit_blocks(deer_model* m, const VisionWS& ws, int lo, int hi, void* st) {
 
 
 // ---- fp32-activation arithmetic of the vision tower (deer_config.precision = 1, csrc/precise.hip) --------------------------
-int gemmf(deer_model* m, const float* A, long lda, const void* Wt, const float* bias, float* C, long ldc, long M, long N, long K, int epi, void* st) {
-  Bracket b(m, "deer_gemm_f32_nt", 2.0 * M * N * K, 4.0 * M * K + 2.0 * N * K + 4.0 * M * N, st);
+int gemmf(deer_model* m, const float* A, long lda, const float* Wt, const float* bias, float* C, long ldc, long M, long N, long K, int epi, void* st) {
+  Bracket b(m, "deer_gemm_f32_nt", 2.0 * M * N * K, 4.0 * M * K + 4.0 * N * K + 4.0 * M * N, st);
   return deer_gemm_f32_nt(A, (int)lda, Wt, (int)K, bias, C, (int)ldc, (int)M, (int)N, (int)K, epi, st);
 }
 
@@ -664,16 +683,16 @@ int vit_blocks_f32(deer_model* m, const VisionWS& ws, int lo, int hi, void* st) 
   for (int li = lo; li < hi; ++li) {
     const VitLayerW& L = m->vit[li];
     if (li == 0) DEER_TRY(ln_rows_f32(m, vx, m->A<float>(L.ln1w), m->A<float>(L.ln1b), xn, R, W, st));
-    DEER_TRY(gemmf(m, xn, W, m->A<void>(L.wqkv), m->A<float>(L.bqkv), qkv, 3 * W, R, 3 * W, W, 0, st));
+    DEER_TRY(gemmf(m, xn, W, m->A<float>(L.wqkv), m->A<float>(L.bqkv), qkv, 3 * W, R, 3 * W, W, 0, st));
     {
       Bracket b(m, "deer_attn_f32", 4.0 * N * H * tok * tok * 64, 0, st);
       DEER_TRY(deer_attn_f32(qkv, qkv + W, qkv + 2 * W, nullptr, nullptr, ao, N, H, tok, tok, 0, 3 * W, 3 * W, 0, W, (long)tok * 3 * W, (long)tok * 3 * W, 0,
                              (long)tok * W, 0.125f, st));
     }
-    DEER_TRY(gemmf(m, ao, W, m->A<void>(L.wo), m->A<float>(L.bo), vx, W, R, W, W, 3, st));                       // x += attn(ln_1(x))
+    DEER_TRY(gemmf(m, ao, W, m->A<float>(L.wo), m->A<float>(L.bo), vx, W, R, W, W, 3, st));                       // x += attn(ln_1(x))
     DEER_TRY(ln_rows_f32(m, vx, m->A<float>(L.ln2w), m->A<float>(L.ln2b), xn, R, W, st));
-    DEER_TRY(gemmf(m, xn, W, m->A<void>(L.wfc), m->A<float>(L.bfc), h, c.vit_mlp, R, c.vit_mlp, W, 1, st));      // QuickGELU
-    DEER_TRY(gemmf(m, h, c.vit_mlp, m->A<void>(L.wpr), m->A<float>(L.bpr), vx, W, R, W, c.vit_mlp, 3, st));      // x += mlp(ln_2(x))
+    DEER_TRY(gemmf(m, xn, W, m->A<float>(L.wfc), m->A<float>(L.bfc), h, c.vit_mlp, R, c.vit_mlp, W, 1, st));      // QuickGELU
+    DEER_TRY(gemmf(m, h, c.vit_mlp, m->A<float>(L.wpr), m->A<float>(L.bpr), vx, W, R, W, c.vit_mlp, 3, st));      // x += mlp(ln_2(x))
     if (li + 1 < c.vit_layers) {
       const VitLayerW& nx = m->vit[li + 1];
       DEER_TRY(ln_rows_f32(m, vx, m->A<float>(nx.ln1w), m->A<float>(nx.ln1b), xn, R, W, st));
@@ -708,18 +727,18 @@ int perceiver_f32(deer_model* m, const VisionWS& ws, void* st) {
       DEER_TRY(deer_layernorm_rows(tokens, W, tok_bstride, P, N, m->A<float>(m->perc_nm_w) + (size_t)li * W, m->A<float>(m->perc_nm_b) + (size_t)li * W,
                                    nullptr, mln, W, (long)P * W, W, kEps, st));
     }
-    DEER_TRY(gemmf(m, mln, W, m->A<char>(m->perc_wkv_all) + (size_t)li * 2 * inner * W * 2, nullptr, mkv, 2 * inner, NP, 2 * inner, W, 0, st));
+    DEER_TRY(gemmf(m, mln, W, m->A<float>(m->perc_wkv_all) + (size_t)li * 2 * inner * W, nullptr, mkv, 2 * inner, NP, 2 * inner, W, 0, st));
     DEER_TRY(ln_rows_f32(m, lat, m->A<float>(L.nlw), m->A<float>(L.nlb), latln, NL, W, st));
-    DEER_TRY(gemmf(m, latln, W, m->A<void>(L.wqkv), nullptr, pqkv, 3 * inner, NL, 3 * inner, W, 0, st));
+    DEER_TRY(gemmf(m, latln, W, m->A<float>(L.wqkv), nullptr, pqkv, 3 * inner, NL, 3 * inner, W, 0, st));
     {
       Bracket b(m, "deer_attn_f32", 4.0 * N * c.perc_heads * nl * (P + nl) * 64, 0, st);
       DEER_TRY(deer_attn_f32(pqkv, mkv, mkv + inner, pqkv + inner, pqkv + 2 * inner, pao, N, c.perc_heads, nl, P, nl, 3 * inner, 2 * inner, 3 * inner, inner,
                              (long)nl * 3 * inner, (long)P * 2 * inner, (long)nl * 3 * inner, (long)nl * inner, scale, st));
     }
-    DEER_TRY(gemmf(m, pao, inner, m->A<void>(L.wo), nullptr, lat, W, NL, W, inner, 3, st));
+    DEER_TRY(gemmf(m, pao, inner, m->A<float>(L.wo), nullptr, lat, W, NL, W, inner, 3, st));
     DEER_TRY(ln_rows_f32(m, lat, m->A<float>(L.fnw), m->A<float>(L.fnb), pln, NL, W, st));
-    DEER_TRY(gemmf(m, pln, W, m->A<void>(L.w1), nullptr, ph, ffw, NL, ffw, W, 2, st));
-    DEER_TRY(gemmf(m, ph, ffw, m->A<void>(L.w2), nullptr, lat, W, NL, W, ffw, 3, st));
+    DEER_TRY(gemmf(m, pln, W, m->A<float>(L.w1), nullptr, ph, ffw, NL, ffw, W, 2, st));
+    DEER_TRY(gemmf(m, ph, ffw, m->A<float>(L.w2), nullptr, lat, W, NL, W, ffw, 3, st));
   }
   // closing perceiver.norm -> media tokens: f32 (this arithmetic) and bf16 (kept current for readers of "vis_x")
   Bracket b(m, "deer_layernorm_rows", 8.0 * NL * W, 10.0 * NL * W, st);
@@ -730,7 +749,7 @@ int perceiver_f32(deer_model* m, const VisionWS& ws, void* st) {
 int media_kv_f32(deer_model* m, void* st) {
   if (!m->n_xattn) return DEER_OK;
   if (m->media_override != nullptr) return DEER_ERR_SHAPE;      // a bf16 media tensor cannot feed the f32 arithmetic: use the model's own
-  return gemmf(m, m->Wk<float>(m->vis_x_f32), m->W, m->A<void>(m->wkv_all), nullptr, m->Wk<float>(m->hp.kv_all), (long)m->n_xattn * 2 * m->xinner,
+  return gemmf(m, m->Wk<float>(m->vis_x_f32), m->W, m->A<float>(m->wkv_all), nullptr, m->Wk<float>(m->hp.kv_all), (long)m->n_xattn * 2 * m->xinner,
                (long)m->N * m->nl, (long)m->n_xattn * 2 * m->xinner, m->W, 0, st);
 }
 
@@ -749,11 +768,21 @@ int skinny(deer_model* m, const void* Wp, long N, long K, int R, float* out_slab
            int a_mode, const int* ctl, void* st, int* S_out, long* stride_out) {
   const int S = deer_skinny_splitk(R, (int)N, (int)K);
   const int mpad = 16 * ((R + 15) / 16);
-  if ((size_t)S * mpad * N > out_elems) return DEER_ERR_SHAPE;
-  Bracket b(m, "deer_gemm_skinny", 2.0 * R * N * K, 2.0 * N * K, st);    // algorithmic bytes = the bf16 weights, once
-  *S_out = S;
+  const int planes = m->c.precision ? 2 : 1;
+  if ((size_t)planes * S * mpad * N > out_elems) return DEER_ERR_SHAPE;
+  *S_out = planes * S;
   *stride_out = (long)mpad * N;
-  return deer_gemm_skinny(A, lda, a_slab, s_in, (long)mpad * K, a_mode, Wp, out_slab, R, (int)N, (int)K, S, ctl, st);
+  {
+    Bracket b(m, "deer_gemm_skinny", 2.0 * R * N * K, 2.0 * N * K, st);    // algorithmic bytes = the bf16 weights, once
+    DEER_TRY(deer_gemm_skinny(A, lda, a_slab, s_in, (long)mpad * K, a_mode, Wp, out_slab, R, (int)N, (int)K, S, ctl, st));
+  }
+  if (planes == 2) {   // fp32 arithmetic: W = hi + lo (two bf16 planes); the lo plane's products go into S more slabs of the same consumer
+    auto it = m->pack_lo.find((size_t)(reinterpret_cast<const char*>(Wp) - m->arena));
+    if (it == m->pack_lo.end()) return DEER_ERR_SHAPE;
+    Bracket b(m, "deer_gemm_skinny", 2.0 * R * N * K, 2.0 * N * K, st);
+    DEER_TRY(deer_gemm_skinny(A, lda, a_slab, s_in, (long)mpad * K, a_mode, m->A<void>(it->second), out_slab + (size_t)S * mpad * N, R, (int)N, (int)K, S, ctl, st));
+  }
+  return DEER_OK;
 }
 
 int resadd(deer_model* m, int R, const Pending* p, const float* gamma, const float* beta, float* x_copy, const int* ctl, void* st) {
@@ -765,7 +794,7 @@ int resadd(deer_model* m, int R, const Pending* p, const float* gamma, const flo
 // the residual branch a layer leaves un-applied when it is not finalized: the down-projection slabs (shape-determined)
 Pending pending_of_down(const deer_model* m, int R) {
   const long K = (long)m->c.mlp_ratio * m->d;
-  const int S = deer_skinny_splitk(R, m->d, (int)K);
+  const int S = deer_skinny_splitk(R, m->d, (int)K) * (m->c.precision ? 2 : 1);
   return Pending{m->Wk<float>(m->slab_a), S, (long)(16 * ((R + 15) / 16)) * m->d, nullptr};
 }
 
@@ -891,7 +920,7 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
     }
     Bracket b(m, "deer_head_lstm_layer", 0, 2.0 * 4 * H * (in_dim + H), st);
     DEER_TRY(deer_head_lstm_layer(src, bstride, mode, T, in_dim, lnw, lnb, m->A<void>(Lw.wih), m->A<void>(Lw.whh), m->A<float>(Lw.bih), m->A<float>(Lw.bhh),
-                                  h_prev + l * lst, c_prev + l * lst, h_tmp + l * lst, c_tmp + l * lst, H, B, kEps, ctl, kind, layer, st));
+                                  h_prev + l * lst, c_prev + l * lst, h_tmp + l * lst, c_tmp + l * lst, H, B, kEps, ctl, kind, layer, c.precision, st));
   }
   const float* src = h_tmp + (m->Lh - 1) * lst;
   int in_dim = H, sstride = H, pro = DEER_PRO_RAW;
@@ -904,7 +933,7 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
     {
       Bracket b(m, "deer_head_fc", 0, 0, st);
       DEER_TRY(deer_head_fc(src, sstride, in_dim, pro, ln[0], ln[1], ln[2], ln[3], m->A<void>(F.w[0]), m->A<float>(F.b[0]), m->A<void>(F.w[1]),
-                            m->A<float>(F.b[1]), dim, z, B, kEps, ctl, kind, layer, st));
+                            m->A<float>(F.b[1]), dim, z, B, kEps, ctl, kind, layer, c.precision, st));
     }
     src = z; in_dim = dim; sstride = 2 * dim;
     if (c.mlp_layernorm) { pro = DEER_PRO_GROUP_LN_RELU; ln[0] = m->A<float>(F.lnw[0]); ln[1] = m->A<float>(F.lnb[0]); ln[2] = m->A<float>(F.lnw[1]); ln[3] = m->A<float>(F.lnb[1]); }
@@ -915,7 +944,7 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
   return deer_head_final(src, sstride, in_dim, pro, ln[0], ln[1], ln[2], ln[3], m->A<void>(m->wa), m->A<float>(m->ba), m->A<void>(m->wg), m->A<float>(m->bg),
                          no_ctl_final ? nullptr : m->Wk<int>(m->ctl), kind, layer, slot, thr, force ? 1 : 0, m->thr_type, m->leq, h_tmp, c_tmp,
                          m->Wk<float>(shadow ? m->h_shadow : m->h_state), m->Wk<float>(shadow ? m->c_shadow : m->c_state), m->Lh, H, B,
-                         m->Wk<float>(m->action_dbg), kEps, st);
+                         m->Wk<float>(m->action_dbg), kEps, c.precision, st);
 }
 
 struct PlanRow { int need_pseudo, is_exit, slot; };
@@ -938,6 +967,8 @@ std::vector<PlanRow> dynamic_plan(const deer_model* m) {
 int embed(deer_model* m, int T, void* st) {
   Bracket b(m, "deer_embed_tokens", 0, 0, st);
   const long long* ids = m->ids_override ? m->ids_override : m->Wk<long long>(m->ids);
+  if (m->c.precision)
+    return deer_embed_tokens_f32(ids, m->A<float>(m->wte), m->Wk<float>(m->x), m->Wk<int>(m->text_time), T, m->B, m->d, m->c.vocab_size, m->c.media_token_id, st);
   return deer_embed_tokens(ids, m->A<void>(m->wte), m->Wk<float>(m->x), m->Wk<int>(m->text_time), T, m->B, m->d, m->c.vocab_size, m->c.media_token_id, st);
 }
 
@@ -1066,6 +1097,10 @@ int deer_model_load_tensor(deer_model* m, const char* name, const void* src, int
     const int pb = (int)std::min<long>((tot + 255) / 256, 4096);
     if (src_is_bf16) hipLaunchKernelGGL(ingest_pack_kernel<bf16_t>, dim3(pb), dim3(256), 0, st, (const bf16_t*)src, m->A<bf16_t>(s.dst[0]), (int)s.rows, s.cols);
     else hipLaunchKernelGGL(ingest_pack_kernel<float>, dim3(pb), dim3(256), 0, st, (const float*)src, m->A<bf16_t>(s.dst[0]), (int)s.rows, s.cols);
+    if (s.dst[1] != SIZE_MAX) {
+      if (src_is_bf16) hipLaunchKernelGGL((ingest_pack_kernel<bf16_t, true>), dim3(pb), dim3(256), 0, st, (const bf16_t*)src, m->A<bf16_t>(s.dst[1]), (int)s.rows, s.cols);
+      else hipLaunchKernelGGL((ingest_pack_kernel<float, true>), dim3(pb), dim3(256), 0, st, (const float*)src, m->A<bf16_t>(s.dst[1]), (int)s.rows, s.cols);
+    }
   } else {
     for (int k = 0; k < 2; ++k) {
       if (s.dst[k] == SIZE_MAX) continue;

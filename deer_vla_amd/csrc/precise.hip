@@ -1,17 +1,16 @@
-// fp32-ACTIVATION arithmetic for the vision tower and the gated cross-attention (deer_config.precision = 1).
+// fp32 arithmetic for the vision tower and the gated cross-attention (deer_config.precision = 1).
 //
 // The default path rounds activations to bf16 wherever they enter an MFMA in the ViT, the Perceiver, the media K/V projection
 // and the x-attn core (1.2-1.6e-3 on the action against the fp32 oracle, half of it from the vision tower, half
 // from the bf16 media tokens / K/V / x-attn operands).  This file is the second arithmetic north_star's "1e-3 fp32" clause asks
 // for: every activation stays fp32 from the image to the action -
 //   * deer_gemm_f32_nt   C[M,N] f32 (op)= A[M,K] f32 * W[N,K]^T + bias with the exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of
-//                        the bf16 rate); the weights are the arena's bf16 tensors, converted on the way into LDS (a bf16 value
-//                        is an f32 value), so the products are exact and the accumulation is fp32;
+//                        the bf16 rate); in this arithmetic the arena keeps the weights of these GEMMs in f32;
 //   * deer_attn_f32      softmax(q k^T * scale) v, head_dim 64, keys in one or two segments (Perceiver: [media ; latents]),
 //                        all fp32 VALU, K then V of a head staged in LDS;
 //   * deer_xattn_f32     the gated x-attn core (media-time mask, helpers.py:192-232) with fp32 K/V.
-// The LLM trunk already multiplies fp32 activations as bf16 hi + lo pairs, the MPT attention, the head and the exit gate are
-// fp32.  Throughput is not the point of this mode (ViT-L at ~1/10 of the bf16 path); parity is.
+// The LLM trunk multiplies fp32 activations as bf16 hi + lo pairs with hi + lo weight planes (model.hip::skinny), the embedding table and
+// the head's weights are f32 in this mode, the MPT attention, the LSTM state and the exit gate are fp32 anyway.  Throughput is not the point of this mode (ViT-L at ~1/10 of the bf16 path); parity is.
 #include "common.h"
 
 enum { PE_F32 = 0, PE_QGELU = 1, PE_GELU = 2, PE_RESADD = 3 };
@@ -19,7 +18,7 @@ enum { PE_F32 = 0, PE_QGELU = 1, PE_GELU = 2, PE_RESADD = 3 };
 #define PG_BK 32
 #define PG_PITCH 36          // floats per LDS row: 32 + 4 (keeps float4 alignment; (row*36 + g) mod 64 is conflict-free for 16 rows x 4 k)
 
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
                                                        const float* __restrict__ bias, float* __restrict__ C, int ldc, int M, int N,
                                                        int K, int epi) {
   __shared__ __attribute__((aligned(16))) float As[2][64][PG_PITCH];
@@ -35,34 +34,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float4 ra[2];
-  uint4 rw;
+  float4 ra[2], rw[2];
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int id = tid + i * 256, row = id >> 3, seg = id & 7;
-      const int m = m0 + row, k = k0 + seg * 4;
-      ra[i] = (m < M && k < K) ? *reinterpret_cast<const float4*>(A + (long)m * lda + k) : float4{0.f, 0.f, 0.f, 0.f};
+      const int k = k0 + seg * 4;
+      ra[i] = (m0 + row < M && k < K) ? *reinterpret_cast<const float4*>(A + (long)(m0 + row) * lda + k) : float4{0.f, 0.f, 0.f, 0.f};
+      rw[i] = (n0 + row < N && k < K) ? *reinterpret_cast<const float4*>(W + (long)(n0 + row) * ldw + k) : float4{0.f, 0.f, 0.f, 0.f};
     }
-    const int row = tid >> 2, seg = tid & 3;
-    const int n = n0 + row, k = k0 + seg * 8;
-    rw = (n < N && k < K) ? *reinterpret_cast<const uint4*>(W + (long)n * ldw + k) : uint4{0, 0, 0, 0};
   };
   auto swrite = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int id = tid + i * 256, row = id >> 3, seg = id & 7;
       *reinterpret_cast<float4*>(&As[buf][row][seg * 4]) = ra[i];
+      *reinterpret_cast<float4*>(&Ws[buf][row][seg * 4]) = rw[i];
     }
-    const int row = tid >> 2, seg = tid & 3;
-    const uint32_t u[4] = {rw.x, rw.y, rw.z, rw.w};
-    float4 lo, hi;
-    lo.x = __uint_as_float(u[0] << 16); lo.y = __uint_as_float(u[0] & 0xffff0000u);
-    lo.z = __uint_as_float(u[1] << 16); lo.w = __uint_as_float(u[1] & 0xffff0000u);
-    hi.x = __uint_as_float(u[2] << 16); hi.y = __uint_as_float(u[2] & 0xffff0000u);
-    hi.z = __uint_as_float(u[3] << 16); hi.w = __uint_as_float(u[3] & 0xffff0000u);
-    *reinterpret_cast<float4*>(&Ws[buf][row][seg * 8]) = lo;
-    *reinterpret_cast<float4*>(&Ws[buf][row][seg * 8 + 4]) = hi;
   };
 
   const int nk = (K + PG_BK - 1) / PG_BK;
@@ -114,15 +102,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   }
 }
 
-// A f32 [M,K] (lda), W bf16 [N,K] (ldw, nn.Linear layout), bias f32[N] or NULL, C f32 [M,N] (ldc).
-// epi: 0 store, 1 QuickGELU, 2 exact GELU, 3 C += (A W^T + bias).  K % 8 == 0, N % 4 == 0.
-extern "C" int deer_gemm_f32_nt(const float* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
+// A f32 [M,K] (lda), W f32 [N,K] (ldw, nn.Linear layout), bias f32[N] or NULL, C f32 [M,N] (ldc).
+// epi: 0 store, 1 QuickGELU, 2 exact GELU, 3 C += (A W^T + bias).  K % 4 == 0, N % 4 == 0.
+extern "C" int deer_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
                                 int epi, void* stream) {
-  if (A == nullptr || W == nullptr || C == nullptr || M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 3) || (lda & 3) || (ldw & 7) || (ldc & 3) ||
+  if (A == nullptr || W == nullptr || C == nullptr || M <= 0 || N <= 0 || K <= 0 || (K & 3) || (N & 3) || (lda & 3) || (ldw & 3) || (ldc & 3) ||
       epi < 0 || epi > 3)
     return DEER_ERR_SHAPE;
   dim3 grid((N + 63) / 64, (M + 63) / 64);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A, lda, reinterpret_cast<const bf16_t*>(W), ldw,
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A, lda, W, ldw,
                      bias, C, ldc, M, N, K, epi);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
@@ -344,6 +332,30 @@ extern "C" int deer_vit_im2col_f32(const float* img, int N, int S, int patch, fl
   const long total = (long)N * gw * gw * Kpad;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(im2col_f32_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), img, N, S, patch, gw, out, Kpad);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// ---- token embedding from an f32 table (deer_embed_tokens keeps bf16) + media bookkeeping ---------------------------------
+__global__ __launch_bounds__(256) void embed_tokens_f32_kernel(const long long* __restrict__ ids, const float* __restrict__ wte, float* __restrict__ x,
+                                                               int* __restrict__ text_time, int T, int d, int vocab, int media_id) {
+  const int row = blockIdx.x, t = row % T, e0 = row - t;   // rows are [env][T]; the media count restarts per environment
+  long long id = ids[row];
+  if (id < 0) id = 0;
+  if (id >= vocab) id = vocab - 1;
+  for (int i = threadIdx.x; i < d; i += 256) x[(long)row * d + i] = wte[id * d + i];
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int j = 0; j <= t; ++j) c += (ids[e0 + j] == media_id) ? 1 : 0;
+    text_time[row] = c;
+  }
+}
+
+extern "C" int deer_embed_tokens_f32(const long long* ids, const float* wte, float* x, int* text_time, int T, int batch, int d, int vocab,
+                                     int media_id, void* stream) {
+  if (T <= 0 || batch <= 0 || d <= 0 || vocab <= 0) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(embed_tokens_f32_kernel, dim3(T * batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ids, wte, x, text_time, T, d,
+                     vocab, media_id);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

@@ -176,7 +176,7 @@ class DeerEngine:
         self.thresholds = v("thresholds", torch.float32)
         self.thresholds.fill_(1e8)
         self.action_dbg = v("action_dbg", torch.float32).view(B, 8)
-        self.wte = self._buf("lang_encoder.transformer.wte.weight", 0).view(torch.bfloat16).view(cfg.vocab_size, d)
+        self.wte = self._buf("lang_encoder.transformer.wte.weight", 0).view(torch.float32 if self.precision == "fp32" else torch.bfloat16).view(cfg.vocab_size, d)
         self.ctl_host = torch.zeros(B * abi.CTL_WORDS, dtype=torch.int32).pin_memory()
         self._ctl_host_np = self.ctl_host.numpy()
         self.step_info_host = torch.zeros(8, 4, dtype=torch.int32).pin_memory()   # ring: an async upload may still be pending

@@ -154,11 +154,13 @@ int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_stride, int d_
                         const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws,
                         void* out, int out_is_f32, int ldo, int T, int batch, const int* ctl, void* stream);
 
+/* (deer_head_*: w_is_f32 = 1 when the weight pointers are f32 - the fp32 arithmetic keeps the head's weights in f32) */
+
 /* ---- fp32-activation arithmetic (csrc/precise.hip; deer_config.precision = 1): the second arithmetic of the path, for
- * north_star's "1e-3 fp32" clause.  Activations stay f32 end to end; the weights are the arena's bf16 tensors (exact in f32). */
+ * north_star's "1e-3 fp32" clause.  Activations AND weights stay f32 end to end (the arena keeps f32 / hi+lo copies in this mode). */
 /* every nn.Linear / conv of the ViT, the Perceiver and the media K/V projection: C f32 [M,N] (op)= A f32 [M,K] * W[N,K]^T + bias with
- * the exact-f32 MFMA.  epi: 0 store, 1 QuickGELU, 2 exact GELU, 3 C += (residual add).  K % 8 == 0, N % 4 == 0. */
-int deer_gemm_f32_nt(const float* A, int lda, const void* W_bf16, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
+ * the exact-f32 MFMA.  epi: 0 store, 1 QuickGELU, 2 exact GELU, 3 C += (residual add).  K % 4 == 0, N % 4 == 0. */
+int deer_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
                      int epi, void* stream);
 /* open_clip MHA core / PerceiverAttention core (helpers.py:47-73) in fp32: q [batch][q_len][ldq] (head h at column h*64), keys and
  * values in one or two segments ([batch][kv_s][ld_s], pointers at the K / V column offset), out f32 [batch][q_len][ldo].
@@ -171,6 +173,9 @@ int deer_attn_f32(const float* Q, const float* K1, const float* V1, const float*
 int deer_xattn_f32(const float* qslab, int s_in, long slab_stride, int ldqs, const float* kv, int ldkv, int inner, const int* text_time,
                    int n_per_media, float* out, int ldo, int T, int n_kv, int heads, int batch, float scale, const int* ctl, void* stream);
 
+/* deer_embed_tokens with an f32 table */
+int deer_embed_tokens_f32(const long long* ids, const float* wte, float* x, int* text_time, int T, int batch, int d, int vocab,
+                          int media_id, void* stream);
 /* im2col of the camera frames in f32 (deer_vit_im2col keeps bf16): out f32 [N*P, Kpad] */
 int deer_vit_im2col_f32(const float* img, int N, int S, int patch, float* out, int Kpad, void* stream);
 
@@ -208,15 +213,15 @@ int deer_head_pool(const float* feats, float* pooled, int T, int d, int avg, int
 int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w, const float* ln_b,
                          const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh, const float* h_prev,
                          const float* c_prev, float* h_out, float* c_out, int H, int B, float eps, const int* ctl, int kind,
-                         int layer, void* stream);
+                         int layer, int w_is_f32, void* stream);
 int deer_head_fc(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0, const float* lnw1,
                  const float* lnb1, const void* W0, const float* b0, const void* W1, const float* b1, int out_dim, float* dst,
-                 int B, float eps, const int* ctl, int kind, int layer, void* stream);
+                 int B, float eps, const int* ctl, int kind, int layer, int w_is_f32, void* stream);
 int deer_head_final(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0, const float* lnw1,
                     const float* lnb1, const void* Wa, const float* ba, const void* Wg, const float* bg, int* ctl, int kind,
                     int layer, int slot, const float* thresholds, int force, int thr_type, int leq, const float* h_tmp,
                     const float* c_tmp, float* h_state, float* c_state, int L, int H, int B, float* action_dbg, float eps,
-                    void* stream);
+                    int w_is_f32, void* stream);
 /* ExitController.set_timestep (eval_utils.py:662-663) + per-step reset.  step_info: device int32[4] = {hold, step sequence
  * number, host mirror pointer lo, hi} or NULL (no stage hold, no mirror). */
 int deer_ctl_begin_step(int* ctl, const int* step_info, int B, void* stream);

@@ -35,8 +35,9 @@ typedef struct deer_config {
   int n_envs;               /* environments evaluated per control step (1..8) */
   int max_text_len;         /* longest instruction (tokens); n_envs * T must be <= 128 rows */
   int n_chains;             /* independent vision chains of the two-stream schedule (0 = default 2) */
-  int precision;            /* 0: bf16 MFMA operands in the vision tower / x-attn (the product path); 1: fp32 activations everywhere
-                             * (csrc/precise.hip; single-stream schedule; ~1/10 of the vision tower's throughput) */
+  int precision;            /* 0: bf16 MFMA operands in the vision tower / x-attn (the product path); 1: fp32 arithmetic -
+                             * f32 activations and f32 (or bf16 hi + lo) weight copies everywhere (csrc/precise.hip; single-stream schedule;
+                             * ~1/10 of the vision tower's throughput, 1.8x the arena) */
 } deer_config;
 
 typedef struct deer_model deer_model;

@@ -569,7 +569,7 @@ def test_head_lstm_layer_env_batch(lib, B, in_dim, ln):
     mode = 3 if ln else 0                                  # X_LN / X_RAW
     abi.check(lib.deer_head_lstm_layer(abi.ptr(x), in_dim, mode, 1, in_dim, abi.ptr(lw) if ln else None, abi.ptr(lb) if ln else None,
                                        abi.ptr(wih), abi.ptr(whh), abi.ptr(bih), abi.ptr(bhh), abi.ptr(h0), abi.ptr(c0), abi.ptr(h1),
-                                       abi.ptr(c1), H, B, 1e-5, None, 2, 0, st()), "lstm")
+                                       abi.ptr(c1), H, B, 1e-5, None, 2, 0, 0, st()), "lstm")
     torch.cuda.synchronize()
     xin = torch.nn.functional.layer_norm(x, (in_dim,), lw, lb, 1e-5) if ln else x
     gates = xin @ wih.float().t() + bih + h0 @ whh.float().t() + bhh
@@ -582,9 +582,9 @@ def test_head_lstm_layer_env_batch(lib, B, in_dim, ln):
 # ------------------------------------------------------------------------------------------ fp32-activation arithmetic (precise.hip)
 @pytest.mark.parametrize("M,N,K,epi", [(257, 1024, 1024, 0), (514, 4096, 1024, 1), (128, 1024, 4096, 2), (70, 132, 72, 0), (514, 1024, 1024, 3)])
 def test_gemm_f32_exact_products(lib, M, N, K, epi):
-    """f32 activations x bf16 weights with the exact-f32 MFMA: differs from torch fp32 math by summation order only (1e-6)."""
+    """f32 x f32 with the exact-f32 MFMA: differs from torch fp64 math by fp32 rounding of the accumulation only (1e-6)."""
     A = dev(rnd(M, K, seed=1))
-    W = dev(rnd(N, K, seed=2, scale=K ** -0.5), torch.bfloat16)
+    W = dev(rnd(N, K, seed=2, scale=K ** -0.5))
     bias = dev(rnd(N, seed=3, scale=0.1))
     C0 = dev(rnd(M, N, seed=4))
     C = C0.clone()

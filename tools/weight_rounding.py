@@ -1,3 +1,5 @@
+"""What the arena's bf16 weight rounding costs against a reference that keeps f32 weights (full-size 3B, synthetic N(0, 0.02^2) weights,
+static exit at the last layer): the bf16 arithmetic vs the fp32 arithmetic (f32 / hi+lo weight copies).  usage: weight_rounding.py"""
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
 import torch
@@ -7,7 +9,7 @@ from deer_vla_amd.engine import DeerEngine
 from oracle import deer_oracle as orc
 torch.set_num_threads(32)
 cfg = deer_3b(max_layer=12)
-sd = syn.make_synthetic_state(cfg, 0, std="0.02", bf16_round=False)      # genuine f32 weights: the engine rounds GEMM operands to bf16
+sd = syn.make_synthetic_state(cfg, 0, std="0.02", bf16_round=False)      # genuine f32 weights: the bf16 arithmetic rounds GEMM operands, the fp32 one keeps them
 for prec in ("fp32", "bf16"):
     eng = DeerEngine(cfg, sd, precision=prec)
     eng.configure_exit(cfg.exit_ids(), 12, 1)
@@ -22,5 +24,5 @@ for prec in ("fp32", "bf16"):
         r = eng.step(rgb, grip, ids, mask, exit_id=11)
         a_e = torch.cat([r["pose"], torch.tensor([r["gripper"]])])
         worst = max(worst, float((a_e - a_o).abs().max()))
-    print(prec, "engine (weights rounded to bf16) vs oracle on the UNROUNDED f32 weights: worst action err %.2e" % worst)
+    print(prec, "arithmetic vs the oracle on UNROUNDED f32 weights: worst action err %.2e" % worst)
     del eng
