@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
                     help="bf16: the product arithmetic (BASELINE's dtype). fp32: the fp32-activation parity arithmetic (csrc/precise.hip) - "
                          "a separate, slower line for DESIGN.md, never the headline")
+    ap.add_argument("--no-two-groups", action="store_true", help="skip the leg with several env batches in flight per GPU")
+    ap.add_argument("--batched-groups", type=int, default=4,
+                    help="env batches of --batched-envs environments in flight per GPU in the `batched_groups` leg (own stream and host thread each)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--full-depth-only", type=int, default=0, metavar="K",
@@ -206,6 +209,59 @@ def window_leg(eng, cfg, frames, ids, reps):
     return {"window_size": W, "frames_per_group": G, "rows": {"vit": 514 * G, "trunk": int(G * ids1.shape[1])}, "reps": reps, **out, "roofline": r,
             "note": "frames of a window are batch rows of the env-batch engine (same kernels, same arena); value generation = "
                     "ActionValueNet(mode='generate') with the windows' time steps replayed through the LSTM head"}
+
+
+def two_groups_leg(cfg, rb, B, steps, burn_in, local_rank, stagger=True, G=4):
+    """G env batches of B environments per GPU, in flight together: one engine each over the SAME weight arena, each on its own
+    stream, driven by its own host thread (the native step driver releases the GIL).  While one batch is in its MFMA-bound vision
+    tower the other is in its HBM-bound trunk, so the GPU interleaves complementary work.  Same thresholds, dynamic exits, the
+    host reads every batch's actions after every step - 2B environments per GPU advance, each at its own pace."""
+    import threading
+    from deer_vla_amd import synthetic as syn
+    from deer_vla_amd.engine import DeerEngine
+    e1 = rb["eng"]
+    engs = [e1] + [DeerEngine(cfg, None, device=e1.dev, n_envs=B, weights_from=e1) for _ in range(G - 1)]
+    ids = rb["ids"]
+    pools = [rb["frames"]]
+    for g in range(1, G):
+        engs[g].configure_exit(e1.exit_ids, e1._max_layer_arg, 1)
+        engs[g].set_thresholds(rb["thr"])
+        per = []
+        for s in range(len(rb["frames"])):
+            pe = [syn.synthetic_step_inputs(cfg, s, rank=1000 * g + e, text_seed=7 + e) for e in range(B)]
+            per.append((torch.stack([p[0] for p in pe]).to(e1.dev, torch.bfloat16), torch.stack([p[1] for p in pe]).to(e1.dev, torch.bfloat16)))
+        pools.append(per)
+    streams = [torch.cuda.Stream(device=e1.dev) for _ in range(G)]
+
+    def episode_steps(g, lo, hi, acc, delay=0.0):
+        eng, pool = engs[g], pools[g]
+        if delay:
+            time.sleep(delay)                             # start half a step apart: vision of one batch beside the trunk of the other
+        with torch.cuda.stream(streams[g]):
+            for i in range(lo, hi):
+                if i % EP_LEN == 0:
+                    eng.reset()
+                    eng.cur_step = 0
+                r = eng.step(pool[i % len(pool)][0], pool[i % len(pool)][1], ids, None)
+                acc[g] += sum(x["exit_layer"] + 1 for x in r)
+    for g in range(G):                                    # graph capture and burn-in one engine at a time (capture is process-global)
+        episode_steps(g, 0, burn_in, [0] * G)
+    torch.cuda.synchronize()
+    acc = [0] * G
+    half = rb["t_max"] / max(steps, 1) / G if stagger else 0.0
+    th = [threading.Thread(target=episode_steps, args=(g, burn_in, burn_in + steps, acc, g * half)) for g in range(G)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = G * B * steps
+    return {"envs_per_gpu": G * B, "groups": G, "value": round(n / dt, 2), "unit": "action-steps/s", "steps_per_group": steps,
+            "ms_per_env_step": round(1e3 * dt / n, 4), "avg_exit_layer": round(sum(acc) / n, 3),
+            "note": "env batches in flight together over one weight arena, each on its own stream / host thread (the native step driver "
+                    "releases the GIL): one batch's vision tower (MFMA-bound) overlaps another's trunk (HBM-bound)"}
 
 
 def lib_hash():
@@ -398,7 +454,7 @@ def run_workload(args, cfg, sd_dev, B, rank, world, local_rank, dist, max_layer,
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)         # one tiny RCCL all-reduce: the only exchange of the path
         stats[0] = tmax[0]
     t_max, exits, n_steps = float(stats[0]), float(stats[1]), float(stats[2])
-    return dict(eng=eng, ctl=ctl, frames=frames, ids=ids, T=T, t_max=t_max, value=n_steps / t_max, avg_exit=exits / n_steps,
+    return dict(eng=eng, ctl=ctl, frames=frames, ids=ids, T=T, t_max=t_max, value=n_steps / t_max, avg_exit=exits / n_steps, thr=thr,
                 hist=hist, setup_s=setup_s)
 
 
@@ -551,6 +607,8 @@ def main():
                           "avg_exit_layer": round(rb["avg_exit"], 3),
                           "note": "all environments of a rank advance in lock step through the same graph pieces; same kernels, "
                                   "same thresholds solver, per-environment exit decisions on the device"}
+        if rank == 0 and world == 1 and args.precision == "bf16" and not args.no_two_groups:
+            out["batched_groups"] = two_groups_leg(cfg, rb, args.batched_envs, nb, 60, local_rank, G=args.batched_groups)
         if args.window_reps > 0 and rank == 0 and world == 1 and rb.get("eng") is not None:
             out["window"] = window_leg(rb["eng"], cfg, rb["frames"], rb["ids"], args.window_reps)
         rb["eng"] = None

@@ -26,6 +26,17 @@ import numpy as np
 import torch
 
 from . import _abi as abi
+
+_CAPTURE_LOCK = __import__("threading").RLock()
+
+
+@contextmanager
+def _capture(graph):
+    """HIP-graph capture that tolerates OTHER host threads driving their own engines meanwhile (several env batches per GPU,
+    rollout.evaluate_policy_batched(groups=...)): thread-local error mode, one capture at a time."""
+    with _CAPTURE_LOCK:
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            yield
 from ._abi import config_to_c  # noqa: F401  (re-exported: tests / tools import it from here)
 from .config import DeerConfig
 from .synthetic import mlp_layer_indices
@@ -451,7 +462,7 @@ class DeerEngine:
                 self._enqueue_step(T, use_mask, exit_id, shadow)  # eager warm-up (sets kernel attributes) - a real step
                 torch.cuda.current_stream().synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):                         # capture does not execute kernels
+                with _capture(g):                         # capture does not execute kernels
                     self._enqueue_step(T, use_mask, exit_id, shadow)
                 self._graphs[key] = g
             else:
@@ -478,7 +489,7 @@ class DeerEngine:
         if C is None:
             def cap(fn):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _capture(g):
                     fn()
                 return g
             C = {"chain_head": [cap(lambda c=c: self._enqueue_chain(c, "head")) for c in range(self.n_chains)],
@@ -526,7 +537,7 @@ class DeerEngine:
             main_st.synchronize()
             self._vision_chain_graphs()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _capture(g):
                 self._enqueue_media_kv()
                 self.enqueue_llm_static(T, use_mask, exit_id)
             self._graphs[key] = g
@@ -571,7 +582,7 @@ class DeerEngine:
                 keep.append(e)
 
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _capture(g):
                 cap = torch.cuda.current_stream()
                 fork(cap, side)
                 with torch.cuda.stream(side):
@@ -653,14 +664,14 @@ class DeerEngine:
             self._vision_chain_graphs()
             for i, need_pseudo, is_exit, _ in plan:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _capture(g):
                     if i == 0:
                         self._enqueue_media_kv()
                     self.enqueue_dynamic_main(T, use_mask, i)
                 P["main"].append(g)
                 if need_pseudo or is_exit:
                     gh = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gh):
+                    with _capture(gh):
                         self.enqueue_dynamic_heads(T, i, use_mask=use_mask)
                     P["head"][i] = gh
                     P["ev"][i] = torch.cuda.Event()

@@ -180,6 +180,17 @@ class MPTFlamingo(nn.Module):
             self.lm_head = self.extra_exit
         return self._engine
 
+    def sibling(self) -> "MPTFlamingo":
+        """A second model over the SAME device weights (own workspace, LSTM state, exit controller): a further env batch that can be
+        stepped concurrently with this one from another host thread / stream (rollout.evaluate_policy_batched(groups=...))."""
+        other = MPTFlamingo(self.cfg, None, window_size=self.window_size, use_gripper=self.use_gripper, fusion_mode=self.fusion_mode,
+                            device=self._device, n_envs=self.n_envs, precision=self.precision)
+        other._sd = self._sd
+        other._engine = DeerEngine(self.cfg, None, device=self._device, n_envs=self.n_envs, precision=self.precision, weights_from=self.engine)
+        other.extra_exit = DeterministicDecoder(other._engine, self.window_size)
+        other.lm_head = other.extra_exit
+        return other
+
     def state_dict(self, *a, **k):
         return dict(self._sd)
 

@@ -129,3 +129,36 @@ def test_env_batch_per_rank_evaluation_matches_sequential_bookkeeping():
     assert a["n_steps"] == b["n_steps"] == 11 * 4 and b["n_steps_all"] == 44 and b["envs_per_rank"] == 3
     assert a["chain_sr"] == b["chain_sr"] and sum(b["exit_hist"]) == 44
     assert all(b["exit_hist"][i] == 0 for i in range(cfg.n_layers) if i not in cfg.exit_ids())
+
+
+@pytest.mark.gpu
+def test_two_env_batches_in_flight_give_the_same_bookkeeping():
+    """evaluate_policy_batched(groups=...): a second env batch (MPTFlamingo.sibling(): same device weights, own state) runs in its
+    own host thread / stream and draws chains from the same queue - chain and step bookkeeping must equal the one-batch run."""
+    from deer_vla_amd import synthetic as syn
+    from deer_vla_amd.config import deer_tiny
+    from deer_vla_amd.factory import create_model_and_transforms
+    from deer_vla_amd.value_net import ActionValueNet, ExitController
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
+    ann = {"a": ["open the drawer"], "b": ["turn on the light bulb now"], "c": ["push the block left"]}
+    seqs = [(None, ["a", "b", "c"]), (None, ["b", "a"]), (None, ["c"]), (None, ["a", "c", "b"]), (None, ["c", "b"]), (None, ["b"]), (None, ["a", "a"])]
+    B = 2
+    model, proc, tok = create_model_and_transforms("ViT-L-14", "openai", "", "", window_size=12, use_gripper=True, fusion_mode="post",
+                                                   llm_name="mpt_dolly_3b", state_dict=sd, cfg=cfg, n_envs=B)
+    ok = ro.steps_task_checker(4)
+
+    def wrapper(m):
+        vn = ActionValueNet(m.get_all_exit_idx(), None, cfg.exit_interval, 12, "L2")
+        ctl = ExitController(vn, m.get_all_exit_idx(), max_layer=cfg.early_exit_layer + 1)
+        ctl._set_threshold_value([0.02] * (ctl.real_num_exit - 1) + [1e5])
+        return ro.BatchedModelWrapper(m, tok, proc, torch.float32, exit_controller=ctl)
+
+    one = ro.evaluate_policy_batched(wrapper(model), [ro.SyntheticEnv(seed=2 + b) for b in range(B)], seqs, ann, ok, ep_len=6)
+    second = model.sibling()
+    assert second.engine.arena.data_ptr() == model.engine.arena.data_ptr()           # the same device weights
+    two = ro.evaluate_policy_batched(wrapper(model), [ro.SyntheticEnv(seed=2 + b) for b in range(B)], seqs, ann, ok, ep_len=6,
+                                     groups=[(wrapper(second), [ro.SyntheticEnv(seed=20 + b) for b in range(B)])])
+    assert one["n_chains"] == two["n_chains"] == 7 and one["avg_seq_len"] == two["avg_seq_len"]
+    assert one["n_steps"] == two["n_steps"] == two["n_steps_all"] == 14 * 4 and two["envs_per_rank"] == 2 * B
+    assert one["chain_sr"] == two["chain_sr"] and sum(two["exit_hist"]) == 14 * 4
