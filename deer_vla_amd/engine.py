@@ -27,14 +27,68 @@ import torch
 
 from . import _abi as abi
 
-_CAPTURE_LOCK = __import__("threading").RLock()
+import threading
+
+
+class _StepGate:
+    """Several env batches per GPU are stepped from several host threads (rollout.evaluate_policy_batched(groups=...)).  Steps of
+    different engines run side by side (shared hold); a HIP-graph CAPTURE waits until no other thread is inside a step and keeps
+    new steps out while it lasts (exclusive hold) - captures are rare (first use of an instruction length) and short."""
+
+    def __init__(self):
+        self.cv = threading.Condition()
+        self.readers, self.writer = 0, False
+        self.local = threading.local()
+
+    @contextmanager
+    def step(self):
+        if getattr(self.local, "depth", 0):                      # nested (a step that calls another engine method): already inside
+            self.local.depth += 1
+            try:
+                yield
+            finally:
+                self.local.depth -= 1
+            return
+        with self.cv:
+            while self.writer:
+                self.cv.wait()
+            self.readers += 1
+        self.local.depth = 1
+        try:
+            yield
+        finally:
+            self.local.depth = 0
+            with self.cv:
+                self.readers -= 1
+                self.cv.notify_all()
+
+    @contextmanager
+    def exclusive(self):
+        inside = bool(getattr(self.local, "depth", 0))
+        with self.cv:
+            if inside:
+                self.readers -= 1                                # give up this thread's own shared hold while it waits
+            while self.writer or self.readers > 0:
+                self.cv.wait()
+            self.writer = True
+        try:
+            yield
+        finally:
+            with self.cv:
+                self.writer = False
+                if inside:
+                    self.readers += 1
+                self.cv.notify_all()
+
+
+_GATE = _StepGate()
 
 
 @contextmanager
 def _capture(graph):
-    """HIP-graph capture that tolerates OTHER host threads driving their own engines meanwhile (several env batches per GPU,
-    rollout.evaluate_policy_batched(groups=...)): thread-local error mode, one capture at a time."""
-    with _CAPTURE_LOCK:
+    """HIP-graph capture while no other host thread is inside an engine step (see _StepGate); thread-local error mode so that other
+    threads' allocations / copies outside a step do not invalidate it."""
+    with _GATE.exclusive():
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             yield
 from ._abi import config_to_c  # noqa: F401  (re-exported: tests / tools import it from here)
@@ -422,6 +476,10 @@ class DeerEngine:
 
     def step(self, rgb, gripper, ids, mask=None, exit_id: Optional[int] = None, use_graph: bool = True, sync: bool = True,
              shadow: bool = False):
+        with _GATE.step():
+            return self._step_impl(rgb, gripper, ids, mask, exit_id, use_graph, sync, shadow)
+
+    def _step_impl(self, rgb, gripper, ids, mask, exit_id, use_graph, sync, shadow):
         """One control step of all n_envs environments.  Returns (when sync) dict(pose (6,), gripper prob, gripper_logit,
         exit_layer, deltas) for n_envs == 1, else a list of such dicts (one per environment).
         shadow=True (calibration): every exit is evaluated and its delta recorded, the LSTM state / action are
