@@ -211,11 +211,12 @@ def load_checkpoint_files(deer_ckpt: str, openflamingo_ckpt: Optional[str] = Non
 
 def build_model_from_checkpoint(deer_ckpt: str, openflamingo_ckpt: Optional[str] = None, clip_state: Optional[str] = None,
                                 mpt_state: Optional[str] = None, max_layer: Optional[int] = None, device="cuda", strict: bool = True,
-                                trunk: Optional[DeerConfig] = None):
-    """-> (MPTFlamingo, info) ready for ``forward`` / ``ModelWrapper``; raises when tensors are missing (strict)."""
+                                trunk: Optional[DeerConfig] = None, precision: str = "bf16", n_envs: int = 1):
+    """-> (MPTFlamingo, info) ready for ``forward`` / ``ModelWrapper``; raises when tensors are missing (strict).  precision="fp32" keeps
+    the checkpoint's f32 weights (f32 / hi+lo copies on the device) - the arithmetic of a reference run at ``--precision fp32``."""
     from .flamingo_mpt import MPTFlamingo
     cfg, sd, info = load_checkpoint_files(deer_ckpt, openflamingo_ckpt, clip_state, mpt_state, max_layer, trunk)
     if strict and info["missing"]:
         raise RuntimeError(f"{len(info['missing'])} tensors missing after loading all checkpoint files, e.g. {info['missing'][:4]}")
-    model = MPTFlamingo(cfg, sd, window_size=info["name_args"]["window_size"], device=device)
+    model = MPTFlamingo(cfg, sd, window_size=info["name_args"]["window_size"], device=device, precision=precision, n_envs=n_envs)
     return model, info

@@ -133,3 +133,23 @@ def test_factory_precision_fp32_matches_the_references_own_forward():
         assert float((o.hidden_states[-1].cpu() - ref_h).abs().max() / ref_h.abs().max()) < 1e-4
     print(f"\n[fp32 precision vs reference forward goldens] worst |logit - reference| {worst:.2e}")
     assert worst < FP32_ACTION_TOL
+
+
+def test_fp32_precision_env_batch_matches_independent_oracle_runs():
+    """two environments per step in the fp32 arithmetic: each must match its own single-environment oracle run within 1e-3"""
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=False)
+    B = 2
+    eng = DeerEngine(cfg, sd, precision="fp32", n_envs=B)
+    eng.configure_exit(cfg.exit_ids(), 12, 1)
+    per = [syn.synthetic_step_inputs(cfg, 2, rank=e, text_seed=7 + e) for e in range(B)]
+    rgb = torch.stack([p[0] for p in per])
+    grip = torch.stack([p[1] for p in per])
+    ids = torch.cat([p[2] for p in per])
+    e = cfg.exit_ids()[-1]
+    eng.reset()
+    out = eng.step(rgb, grip, ids, None, exit_id=e)
+    for b in range(B):
+        a_o, _, _ = oracle_step(sd, cfg, per[b][0], per[b][1], per[b][2], per[b][3], e)
+        a_e = torch.cat([out[b]["pose"], torch.tensor([out[b]["gripper"]])])
+        assert float((a_e - a_o).abs().max()) < FP32_ACTION_TOL
