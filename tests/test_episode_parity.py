@@ -34,14 +34,14 @@ def _dump_report():
             json.dump(REPORT, fh, indent=1)
 
 
-def replay_episode(z, tag, n_steps=None, n_envs=1):
+def replay_episode(z, tag, n_steps=None, n_envs=1, precision="bf16"):
     cfg = DeerConfig(**json.loads(bytes(z[tag + "_cfg_json"]).decode()))
     max_layer = int(z[tag + "_max_layer"])
     thr = [float(t) for t in z[tag + "_thr"]]
     ref_exit, ref_act, margin = z[tag + "_exit"], z[tag + "_action"], z[tag + "_margin"]
     n = int(z["n_steps"]) if n_steps is None else min(n_steps, int(z["n_steps"]))
     sd = syn.make_synthetic_state(cfg, int(z["seed"]), std="0.02", bf16_round=True)
-    eng = DeerEngine(cfg, sd)
+    eng = DeerEngine(cfg, sd, precision=precision)
     eng.configure_exit(cfg.exit_ids(), max_layer, 1)
     eng.set_thresholds(thr)
     eng.reset()
@@ -67,9 +67,9 @@ def replay_episode(z, tag, n_steps=None, n_envs=1):
     rep = dict(steps=n, thresholds=thr, exit_hist={int(k): v for k, v in sorted(hist.items())},
                knife_edge_steps=int((margin[:n] <= BAND).sum()), knife_edge_flips=flips, mismatches_outside_band=outside,
                worst_action_err=worst, worst_action_err_step=worst_at, band=BAND)
-    REPORT[tag] = rep
+    REPORT[tag if precision == "bf16" else tag + "_" + precision] = rep
     _dump_report()
-    print(f"\n[{tag}] {n} steps, exits {rep['exit_hist']}, knife-edge steps {rep['knife_edge_steps']} "
+    print(f"\n[{tag} {precision}] {n} steps, exits {rep['exit_hist']}, knife-edge steps {rep['knife_edge_steps']} "
           f"(engine decided differently on {len(flips)}), mismatches outside the band {len(outside)}, "
           f"worst |action - oracle| {worst:.2e} at step {worst_at}")
     return rep
@@ -87,3 +87,12 @@ def test_full_size_360_step_episode_matches_oracle_trace(golden, tag):
     assert rep["worst_action_err"] < ACTION_TOL, rep
     assert not rep["mismatches_outside_band"], rep["mismatches_outside_band"]
     assert len(rep["exit_hist"]) > 1 or tag == "s08", rep["exit_hist"]
+
+
+@pytest.mark.parametrize("tag", ["b08", "b10", "s08"])
+def test_fp32_arithmetic_reproduces_the_360_step_exit_sequence_exactly(golden, tag):
+    """SURVEY 8(d) parity gate, literally: with precision="fp32" the exit_layer sequence is IDENTICAL to the fp32 oracle's over the
+    whole 360-step episode - no margin rule, no re-alignment - and the actions stay within 1e-3."""
+    rep = replay_episode(golden, tag, precision="fp32")
+    assert not rep["mismatches_outside_band"] and not rep["knife_edge_flips"], (rep["mismatches_outside_band"], rep["knife_edge_flips"])
+    assert rep["worst_action_err"] < 1e-3, rep["worst_action_err"]
