@@ -233,7 +233,15 @@ def two_groups_leg(cfg, rb, B, steps, burn_in, local_rank, stagger=True, G=4):
         pools.append(per)
     streams = [torch.cuda.Stream(device=e1.dev) for _ in range(G)]
 
+    failures = []
+
     def episode_steps(g, lo, hi, acc, delay=0.0):
+        try:
+            _episode_steps(g, lo, hi, acc, delay)
+        except Exception as e:                             # a worker thread must not die silently: the leg reports it
+            failures.append(e)
+
+    def _episode_steps(g, lo, hi, acc, delay=0.0):
         eng, pool = engs[g], pools[g]
         if delay:
             time.sleep(delay)                             # start half a step apart: vision of one batch beside the trunk of the other
@@ -257,6 +265,8 @@ def two_groups_leg(cfg, rb, B, steps, burn_in, local_rank, stagger=True, G=4):
         t.join()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if failures:
+        raise failures[0]
     n = G * B * steps
     return {"envs_per_gpu": G * B, "groups": G, "value": round(n / dt, 2), "unit": "action-steps/s", "steps_per_group": steps,
             "ms_per_env_step": round(1e3 * dt / n, 4), "avg_exit_layer": round(sum(acc) / n, 3),
@@ -608,9 +618,15 @@ def main():
                           "note": "all environments of a rank advance in lock step through the same graph pieces; same kernels, "
                                   "same thresholds solver, per-environment exit decisions on the device"}
         if rank == 0 and world == 1 and args.precision == "bf16" and not args.no_two_groups:
-            out["batched_groups"] = two_groups_leg(cfg, rb, args.batched_envs, nb, 60, local_rank, G=args.batched_groups)
+            try:                                           # auxiliary single-rank leg: its failure must not cost the bench line
+                out["batched_groups"] = two_groups_leg(cfg, rb, args.batched_envs, nb, 60, local_rank, G=args.batched_groups)
+            except Exception as e:
+                out["batched_groups"] = {"error": f"{type(e).__name__}: {e}"}
         if args.window_reps > 0 and rank == 0 and world == 1 and rb.get("eng") is not None:
-            out["window"] = window_leg(rb["eng"], cfg, rb["frames"], rb["ids"], args.window_reps)
+            try:
+                out["window"] = window_leg(rb["eng"], cfg, rb["frames"], rb["ids"], args.window_reps)
+            except Exception as e:
+                out["window"] = {"error": f"{type(e).__name__}: {e}"}
         rb["eng"] = None
     if rank == 0:
         if not (args.no_cpu_baseline or world > 1):
