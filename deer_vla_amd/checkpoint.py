@@ -164,9 +164,9 @@ def assemble_state_dict(cfg: DeerConfig, sources: Iterable[Tuple[str, Dict[str, 
                     n = min(shape[0], v.shape[0])
                     t[:n] = v[:n]
                     v = t
-                elif v.numel() == int(torch.tensor(shape).prod()):
-                    v = v.reshape(shape)                                     # e.g. class_embedding (W,) vs (1, W)
-                else:
+                elif tuple(d for d in v.shape if d != 1) == tuple(d for d in shape if d != 1):
+                    v = v.reshape(shape)                                     # singleton dims only: class_embedding (W,) vs (1, W), gates () vs (1,)
+                else:                                                        # same numel, other layout (e.g. (in, out) vs (out, in)): never reshaped silently
                     raise RuntimeError(f"size mismatch for {k} ({tag}): {tuple(v.shape)} vs {shape}")
             sd[ck] = v.detach()
             origin[ck] = tag
@@ -180,7 +180,13 @@ def _torch_load(path: str):
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
         return load_file(path)
-    return torch.load(path, map_location="cpu", weights_only=False)
+    try:                                                                     # checkpoints hold tensors and plain Python values only
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:
+        if os.environ.get("DEER_UNSAFE_PICKLE") == "1":                      # explicit opt-in: full unpickling executes code from the file
+            return torch.load(path, map_location="cpu", weights_only=False)
+        raise RuntimeError(f"{path}: not loadable with weights_only=True ({type(e).__name__}: {e}); if the file is trusted, set "
+                           "DEER_UNSAFE_PICKLE=1 to allow full unpickling") from e
 
 
 def load_checkpoint_files(deer_ckpt: str, openflamingo_ckpt: Optional[str] = None, clip_state: Optional[str] = None,

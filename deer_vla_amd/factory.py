@@ -71,7 +71,8 @@ class GpuImageProcessor:
         import ctypes
         self._mean = (ctypes.c_float * 3)(*CLIP_MEAN)
         self._std = (ctypes.c_float * 3)(*CLIP_STD)
-        self._tmp = None
+        import threading
+        self._tls = threading.local()      # scratch per host thread: env batches stepped from several threads / streams share a processor
 
     def __call__(self, frames, out_f32: bool = False) -> torch.Tensor:
         import ctypes
@@ -83,12 +84,13 @@ class GpuImageProcessor:
         x = x.to(self.dev, non_blocking=True).contiguous()
         N, H, W, _ = x.shape
         need = self.lib.deer_preprocess_scratch_bytes(N, H, W, self.size)
-        if self._tmp is None or self._tmp.numel() < need:
-            self._tmp = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        tmp = getattr(self._tls, "tmp", None)
+        if tmp is None or tmp.numel() < need:
+            tmp = self._tls.tmp = torch.empty(need, dtype=torch.uint8, device=self.dev)
         out = torch.empty(N, 3, self.size, self.size, dtype=torch.float32 if out_f32 else torch.bfloat16, device=self.dev)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         abi = self._abi
-        abi.check(self.lib.deer_preprocess_frames(abi.ptr(x), N, H, W, self.size, self._mean, self._std, abi.ptr(self._tmp),
+        abi.check(self.lib.deer_preprocess_frames(abi.ptr(x), N, H, W, self.size, self._mean, self._std, abi.ptr(tmp),
                                                   None if out_f32 else abi.ptr(out), abi.ptr(out) if out_f32 else None, st), "deer_preprocess_frames")
         return out
 
@@ -152,6 +154,35 @@ def create_model_and_transforms(clip_vision_encoder_path: str = "ViT-L-14", clip
         raise NotImplementedError("LLaMA-based BCFlamingo is out of scope (SURVEY §2 row 12)")
     if decoder_type != "lstm" or head_type != "deterministic":
         raise NotImplementedError("only the LSTM DeterministicDecoder head is used by DeeR checkpoints (SURVEY §2 row 5)")
+    # Keywords that change the ARITHMETIC of the reference model and are not built here fail loudly (they used to be
+    # accepted and ignored, while checkpoint.py parses them from checkpoint names, eval_calvin.py:355-421).  Keywords that only
+    # steer training (freeze_embed, train_params, unfreeze_vit, freeze_sampler, debug) or that the reference's MPTFlamingo itself
+    # accepts and never reads (no_image_patch, global_latent: flamingo_mpt.py:55-56 are their only occurrences) stay accepted.
+    unsupported = {
+        "multi_step_action": (multi_step_action, 1, "the head emits out_features * multi_step_action values (action_head.py:436-470)"),
+        "last_action": (bool(last_action), False, "action_head.py concatenates the previous action to the head input"),
+        "fwd_pred": (bool(fwd_pred), False, "forward-prediction heads (flamingo_mpt.py:53-54)"),
+        "fwd_pred_hand": (bool(fwd_pred_hand), False, "forward-prediction heads (flamingo_mpt.py:53-54)"),
+        "residual": (bool(residual), False, "changes init_flamingo's gated x-attn (flamingo_mpt.py:111-121)"),
+        "pad_length": (pad_length, -1, "the harness asserts pad_length == -1 for multi-exit nets (eval_utils.py:300)"),
+        "refresh": (refresh, -1, "refresh_window re-runs the LSTM over the stored window (action_head.py:561-586)"),
+        "return_feature": (bool(return_feature), False, "feature outputs of the head are a training-side hook"),
+        "layerwise_exit_eval": (bool(flamingo_kwargs.get("layerwise_exit_eval", False)), False,
+                                "per-exit heads lm_exits[i] instead of extra_exit (flamingo_mpt.py:443-461)"),
+        "use_hist": (bool(flamingo_kwargs.get("use_hist", False)), False, "history frames (flamingo_mpt.py:372-373)"),
+        "use_diff": (bool(flamingo_kwargs.get("use_diff", False)), False, "diffusion head (SURVEY §2 row 12)"),
+        "share_exit": (bool(flamingo_kwargs.get("share_exit", False)), False, "shared exit heads are a training-time layout"),
+    }
+    for name, (got, want, why) in unsupported.items():
+        if got != want:
+            raise NotImplementedError(f"create_model_and_transforms({name}={got!r}) is not implemented by deer_vla_amd: {why}")
+    for name, got in (("use_state", use_state), ("sep_resampler", sep_resampler)):
+        if got and not getattr(DeerConfig, "supports_" + name, False):
+            raise NotImplementedError(f"create_model_and_transforms({name}=True) is not implemented by deer_vla_amd")
+    if hidden_size is not None and hidden_size != 1024:
+        raise NotImplementedError("hidden_size is a GPTDecoder keyword (flamingo_mpt.py:179); the LSTM head is 1024 wide")
+    if not flamingo_kwargs.get("multi_exit", True):
+        raise NotImplementedError("multi_exit=False builds no extra_exit head (flamingo_mpt.py:239-259)")
     early_exit_layer = flamingo_kwargs.get("early_exit_layer", -1)
     if cfg is None:
         base = deer_9b if llm_name == "mpt_9b" else deer_3b

@@ -136,6 +136,8 @@ class MPTFlamingo(nn.Module):
     def __init__(self, cfg: DeerConfig, state_dict: Optional[Dict[str, torch.Tensor]] = None, window_size: int = 12,
                  use_gripper: bool = True, fusion_mode: str = "post", device="cuda", n_envs: int = 1, precision: str = "bf16", **unused):
         super().__init__()
+        if unused:
+            raise TypeError(f"MPTFlamingo: keywords {sorted(unused)} are not implemented by deer_vla_amd (they would be silently ignored)")
         if not use_gripper or fusion_mode != "post":
             raise NotImplementedError("released DeeR checkpoints use use_gripper=True, fusion_mode='post' (flamingo_mpt.py:380-381)")
         self.cfg = cfg

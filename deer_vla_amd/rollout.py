@@ -353,6 +353,11 @@ class BatchedModelWrapper:
         self.text_process_fn = functools.partial(preprocess_text_calvin, tokenizer=tokenizer)
         self.image_process_fn = functools.partial(preprocess_image, image_processor=image_processor)
         self.exit_controller, self.exit_id = exit_controller, exit_id
+        ctl = getattr(exit_controller, "module", exit_controller)
+        if ctl is not None and getattr(ctl, "steps_per_stage", 1) != 1:
+            # the slots of an env batch are at different steps of their sub-tasks, the hold state (value_net.py:285-286) is one word
+            # per batch on the device: the reference's per-rollout `set_timestep(step)` has no batched equivalent
+            raise NotImplementedError("env batches need an ExitController with steps_per_stage == 1")
         self.replan = m.replan
         self.current_exit_layers = [-1] * self.B
         self._goals: List[Optional[str]] = [None] * self.B
@@ -363,15 +368,38 @@ class BatchedModelWrapper:
         """start of a sub-task in slot b (eval_utils.py:252-277 for that environment only)"""
         self.model.module.engine.reset_env(b)
 
+    def check_instructions(self, goals):
+        """Every instruction of an env batch is right-padded to the longest one and n_envs * T rows must fit the trunk GEMM's 128
+        rows (engine.max_T = 128 // n_envs, 16 tokens at 8 environments; the reference allows 32, data.py:905-919).  Raises before
+        a run starts instead of asserting in the middle of it."""
+        max_T = self.model.module.engine.max_T
+        ids, mask = self.text_process_fn(list(goals))
+        worst = int(mask.sum(dim=1).max())
+        if worst > max_T:
+            bad = goals[int(mask.sum(dim=1).argmax())]
+            raise ValueError(f"instruction {bad!r} tokenizes to {worst} tokens; an env batch of {self.B} takes at most {max_T} "
+                             f"(n_envs * T <= 128 trunk rows): build the model with n_envs <= {128 // worst}")
+
+    def _frames(self, obs_list, key):
+        """processed frames of all slots; an idle slot gets a blank frame of the SAME device / dtype as the live ones (a CPU fp32 blank
+        cannot be stacked with the CUDA bf16 output of GpuImageProcessor: ADVICE r2)"""
+        live = [self.image_process_fn([o["rgb_obs"][key]])[0] if o is not None else None for o in obs_list]
+        ref = next((x for x in live if x is not None), None)
+        if ref is None:
+            S = self.model.module.cfg.image_size
+            ref = torch.zeros(3, S, S)
+        if self._blank is None or self._blank.device != ref.device or self._blank.dtype != ref.dtype:
+            self._blank = torch.zeros_like(ref)
+        return torch.stack([x if x is not None else self._blank for x in live])
+
     def step(self, obs_list, goals):
-        S = self.model.module.cfg.image_size
-        if self._blank is None:
-            self._blank = torch.zeros(3, S, S)
-        rgb = torch.stack([self.image_process_fn([o["rgb_obs"]["rgb_static"]])[0] if o is not None else self._blank for o in obs_list])
-        grip = torch.stack([self.image_process_fn([o["rgb_obs"]["rgb_gripper"]])[0] if o is not None else self._blank for o in obs_list])
+        rgb = self._frames(obs_list, "rgb_static")
+        grip = self._frames(obs_list, "rgb_gripper")
         goals = [g if g is not None else "idle" for g in goals]
         if goals != self._goals:                                   # instructions change only between sub-tasks
             ids, mask = self.text_process_fn(goals)
+            if ids.shape[1] > self.model.module.engine.max_T:
+                self.check_instructions(goals)
             self._text = (ids.cuda(), mask.cuda())
             self._goals = list(goals)
         ids, mask = self._text
@@ -416,7 +444,8 @@ def evaluate_policy_batched(model: BatchedModelWrapper, envs: Sequence, eval_seq
 
         def start_subtask(b):
             st = slot[b]
-            envs[b].reset() if st["k"] == 0 else None             # chain start: environment reset (initial state is the simulator's)
+            if st["k"] == 0:                                       # chain start: the chain's own initial condition (eval_utils.py:587-588)
+                envs[b].reset() if st["init"] is None else envs[b].reset(**st["init"])
             model.reset_env(b)
             st["step"], st["exits"], st["start"] = 0, [], envs[b].get_info()
             st["goal"] = pick_annotation(annotations, st["chain"][st["k"]], st["k"], base + st["seq_i"])
@@ -427,8 +456,8 @@ def evaluate_policy_batched(model: BatchedModelWrapper, envs: Sequence, eval_seq
             if item is None:
                 slot[b] = None
                 return
-            i, (_, chain) = item
-            slot[b] = dict(seq_i=i, chain=list(chain), k=0, n_ok=0)
+            i, (initial_state, chain) = item
+            slot[b] = dict(seq_i=i, chain=list(chain), k=0, n_ok=0, init=initial_state)
             start_subtask(b)
 
         for b in range(B):
@@ -467,6 +496,11 @@ def evaluate_policy_batched(model: BatchedModelWrapper, envs: Sequence, eval_seq
             n_steps_box[0] += n_local
 
     members = [(model, envs)] + list(groups)
+    # every instruction this rank will see must fit the env batch's rows: fail before the run, not in the middle of it
+    all_goals = sorted({pick_annotation(annotations, sub, k, base + i) for i, (_, chain) in enumerate(mine) for k, sub in enumerate(chain)})
+    if all_goals:
+        for mw, _ in members:
+            mw.check_instructions(all_goals)
     t0 = time.perf_counter()
     if len(members) == 1:
         worker(model, envs)

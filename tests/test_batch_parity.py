@@ -1,0 +1,149 @@
+"""Full-size parity of the paths the env-batch throughput figures are quoted on:
+
+(a) ``n_envs=8`` DYNAMIC episode at 3B size (DeeR-B max_layer=12, exit_ratio 0.8 thresholds) - every environment against its OWN
+    committed fp32-oracle trace (tests/golden/episode_batch8.npz, made by tests/golden/make_batch_goldens.py: 8 independent
+    single-environment oracle runs, inputs ``rank=e, text_seed=7+e`` as bench.py::run_workload / eval_utils.py:523-527 feed them).
+    Gate as tests/test_episode_parity.py: actions within 1e-2 at every env-step; exit layer identical wherever the oracle's decision
+    is not knife-edge (margin > 1e-2); a flipped knife-edge env-step is re-aligned on the oracle's exit (that environment's LSTM state
+    is taken from a static replay of the step at the oracle's exit layer), so every later env-step stays a like-for-like comparison.
+(b) two sibling engines (one weight arena, two workspaces / streams / host threads - the ``batched_groups`` bench leg and
+    ``evaluate_policy_batched(groups=...)``) stepped CONCURRENTLY give bit-identical results to each engine stepped alone."""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from deer_vla_amd import synthetic as syn  # noqa: E402
+from deer_vla_amd.config import DeerConfig  # noqa: E402
+from deer_vla_amd.engine import DeerEngine  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "episode_batch8.npz")
+ACTION_TOL = 1e-2
+BAND = 1e-2
+
+
+@pytest.fixture(scope="module")
+def setup():
+    assert os.path.exists(GOLD), "tests/golden/episode_batch8.npz missing (run tests/golden/make_batch_goldens.py)"
+    z = np.load(GOLD)
+    cfg = DeerConfig(**json.loads(bytes(z["cfg_json"]).decode()))
+    sd = syn.make_synthetic_state(cfg, int(z["seed"]), std="0.02", bf16_round=True)
+    B = int(z["n_envs"])
+    eng = DeerEngine(cfg, sd, n_envs=B)
+    return z, cfg, eng, B
+
+
+def batch_inputs(cfg, B, s, dev, step_offset=0):
+    per_env = [syn.synthetic_step_inputs(cfg, s + step_offset, rank=e, text_seed=7 + e) for e in range(B)]
+    rgb = torch.stack([p[0] for p in per_env]).to(dev, torch.bfloat16)
+    grip = torch.stack([p[1] for p in per_env]).to(dev, torch.bfloat16)
+    ids = torch.cat([p[2] for p in per_env]).to(dev)
+    return rgb, grip, ids
+
+
+def test_eight_environment_dynamic_episode_matches_each_environments_oracle_trace(setup):
+    z, cfg, eng, B = setup
+    n = int(z["n_steps"])
+    thr = [float(t) for t in z["thr"]]
+    ref_exit, ref_act, margin = z["exit"], z["action"], z["margin"]
+    eng.configure_exit(cfg.exit_ids(), int(z["max_layer"]), 1)
+    eng.set_thresholds(thr)
+    eng.reset()
+    flips, outside, worst, compared = [], [], 0.0, 0
+    hist = {}
+    ids_keep = None
+    for s in range(n):
+        rgb, grip, ids = batch_inputs(cfg, B, s, eng.dev)
+        ids_keep = ids if ids_keep is None else ids_keep          # one instruction tensor for the whole episode (upload once)
+        h0, c0 = eng.h_state.clone(), eng.c_state.clone()
+        out = eng.step(rgb, grip, ids_keep, None)
+        wrong = [e for e in range(B) if out[e]["exit_layer"] != int(ref_exit[e, s])]
+        for e in wrong:
+            rec = dict(env=e, step=s, engine=out[e]["exit_layer"], oracle=int(ref_exit[e, s]), margin=float(margin[e, s]))
+            (flips if margin[e, s] <= BAND else outside).append(rec)
+        if wrong:                                                  # re-align the flipped environments on the oracle's trajectory
+            torch.cuda.synchronize()
+            h_dyn, c_dyn = eng.h_state.clone(), eng.c_state.clone()
+            for e in wrong:
+                eng.h_state.copy_(h0)
+                eng.c_state.copy_(c0)
+                rep = eng.step(rgb, grip, ids_keep, None, exit_id=int(ref_exit[e, s]))
+                torch.cuda.synchronize()
+                h_dyn[:, e], c_dyn[:, e] = eng.h_state[:, e], eng.c_state[:, e]
+                out[e] = rep[e]
+            eng.h_state.copy_(h_dyn)
+            eng.c_state.copy_(c_dyn)
+        for e in range(B):
+            err = max(float((out[e]["pose"] - torch.from_numpy(ref_act[e, s, :6])).abs().max()), abs(out[e]["gripper"] - float(ref_act[e, s, 6])))
+            worst = max(worst, err)
+            compared += 1
+            hist[out[e]["exit_layer"]] = hist.get(out[e]["exit_layer"], 0) + 1
+    knife = int((margin[:, :n] <= BAND).sum())
+    rep = dict(env_steps=compared, exit_hist={int(k): v for k, v in sorted(hist.items())}, knife_edge_env_steps=knife,
+               knife_edge_flips=flips, mismatches_outside_band=outside, worst_action_err=worst)
+    out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "batch_parity_report.json"), "w") as fh:
+            json.dump(rep, fh, indent=1)
+    print(f"\n[env batch of {B}, {n} steps, full size] {compared} env-steps, exits {rep['exit_hist']}, knife-edge env-steps {knife} "
+          f"(engine decided differently on {len(flips)}), outside the band {len(outside)}, worst |action - oracle| {worst:.2e}")
+    assert compared == B * n
+    assert not outside, outside
+    assert worst < ACTION_TOL, worst
+    assert len(hist) > 2, hist                                      # the environments really exit at different layers
+
+
+def test_two_sibling_engines_stepped_concurrently_equal_each_engine_alone(setup):
+    z, cfg, eng, B = setup
+    thr = [float(t) for t in z["thr"]]
+    sib = DeerEngine(cfg, None, n_envs=B, weights_from=eng)
+    assert sib.arena.data_ptr() == eng.arena.data_ptr()
+    engines, offsets, n = [eng, sib], [0, 100], 16
+    for e in engines:
+        e.configure_exit(cfg.exit_ids(), int(z["max_layer"]), 1)
+        e.set_thresholds(thr)
+    inputs = [[batch_inputs(cfg, B, s, eng.dev, off) for s in range(n)] for off in offsets]
+
+    def episode(e, frames, out):
+        e.reset()
+        ids = frames[0][2]
+        for rgb, grip, _ in frames:
+            r = e.step(rgb, grip, ids, None)
+            out.append([(x["exit_layer"], x["pose"].clone(), x["gripper"]) for x in r])
+
+    alone = [[], []]
+    for k in range(2):
+        episode(engines[k], inputs[k], alone[k])
+    torch.cuda.synchronize()
+    together, errors = [[], []], []
+
+    def run(k, stream):
+        try:
+            with torch.cuda.stream(stream):
+                episode(engines[k], inputs[k], together[k])
+        except Exception as ex:                                     # surfaced below
+            errors.append(ex)
+
+    threads = [threading.Thread(target=run, args=(k, torch.cuda.Stream())) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    n_exits = set()
+    for k in range(2):
+        assert len(together[k]) == n
+        for s in range(n):
+            for e in range(B):
+                a, b = alone[k][s][e], together[k][s][e]
+                assert a[0] == b[0], (k, s, e, a[0], b[0])
+                assert torch.equal(a[1], b[1]) and a[2] == b[2], (k, s, e)
+                n_exits.add(a[0])
+    assert len(n_exits) > 1

@@ -110,13 +110,91 @@ def test_skinny_respects_exit_flag(lib):
 
 
 def test_abi_rejects_bad_shapes(lib):
-    assert lib.deer_gemm_skinny(None, 0, None, 0, 0, 0, None, None, 70, 64, 64, 1, None, st()) == 1      # M > 64
+    # every operand valid except the property under test (the old "M > 64" line passed because A was NULL)
+    A = torch.zeros(130, 64, device="cuda", dtype=torch.bfloat16)
+    Wp = torch.zeros(64, 64, device="cuda", dtype=torch.bfloat16)
+    part = torch.zeros(1, 144, 64, device="cuda")
+    ok = lambda M, N, K, S: lib.deer_gemm_skinny(abi.ptr(A), 64, None, 0, 0, abi.A_BF16, abi.ptr(Wp), abi.ptr(part), M, N, K, S, None, st())
+    assert ok(128, 64, 64, 1) == 0                                                                        # 128 rows = 8 envs x 16 tokens: the cap
+    assert ok(129, 64, 64, 1) == 1                                                                        # M > 128
+    assert ok(4, 60, 64, 1) == 1                                                                          # N % 16
+    assert ok(4, 64, 48, 1) == 1                                                                          # K % 32
+    assert ok(4, 64, 64, 4) == 1                                                                          # K % (splitk * 32)
+    assert lib.deer_gemm_skinny(None, 0, None, 0, 0, 0, None, None, 4, 64, 64, 1, None, st()) == 1        # A == NULL
+    torch.cuda.synchronize()
     assert lib.deer_gemm_skinny(None, 0, None, 0, 0, 0, None, None, 4, 60, 64, 1, None, st()) == 1       # N % 16
     assert lib.deer_gemm_bf16_nt(None, 8, 0, None, 8, None, None, 8, 0, 4, 16, 12, 1, 0, None, 0, None, st()) == 1   # K % 8
     assert lib.deer_attn_mfma_hd64(None, None, None, None, 1, 1, 4, 400, 64, 64, 64, 64, 0, 0, 0, 0, 1.0, st()) == 1  # kv_len
 
 
+@pytest.mark.parametrize("M", [70, 96, 112, 128])
+@pytest.mark.parametrize("N,K,mode", [(6144, 2048, "f32"), (2048, 2048, "f32"), (8192, 2048, "f32"), (2048, 8192, "slabs_gelu"),
+                                      (16384, 4096, "f32"), (4096, 16384, "slabs_gelu")])
+def test_gemm_skinny_env_batch_rows_trunk_shapes(lib, M, N, K, mode):
+    """The row tiles an env batch of 5-8 environments uses (MT = 5..8: 70-128 rows) on every projection shape of the MPT-1B / MPT-7B
+    trunk, in the two activation modes the spine feeds them with (f32 rows as bf16 hi+lo; GELU of the up-projection's slabs), against
+    fp64 torch math on the same bf16 weights."""
+    W = dev(rnd(N, K, seed=52, scale=K ** -0.5), torch.bfloat16)
+    Wp = torch.empty_like(W)
+    abi.check(lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), N, K, st()), "pack")
+    S = lib.deer_skinny_splitk(M, N, K)
+    mpad = abi.skinny_mpad(M)
+    part = torch.full((S, mpad, N), float("nan"), device="cuda")
+    if mode == "f32":
+        A = dev(rnd(M, K, seed=51))
+        abi.check(lib.deer_gemm_skinny(abi.ptr(A), K, None, 0, 0, abi.A_F32, abi.ptr(Wp), abi.ptr(part), M, N, K, S, None, st()), "skinny")
+        a = A.double()
+    else:
+        s_in = 3
+        slab = dev(rnd(s_in, mpad, K, seed=53))
+        abi.check(lib.deer_gemm_skinny(None, 0, abi.ptr(slab), s_in, mpad * K, abi.A_SLABS_GELU, abi.ptr(Wp), abi.ptr(part), M, N, K, S, None,
+                                       st()), "skinny")
+        a = torch.nn.functional.gelu(slab.sum(0)[:M]).double()
+    torch.cuda.synchronize()
+    ref = (a @ W.double().t()).float()
+    assert torch.isfinite(part).all()
+    assert rel_err(part.sum(0)[:M], ref) < 3e-5
+    if mpad > M:
+        assert float(part[:, M:].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------- tiled GEMM
+@pytest.mark.parametrize("tile", [17, 39, 45, 0])
+@pytest.mark.parametrize("M", [2056, 3084, 4112])
+@pytest.mark.parametrize("N,K,epi", [(3072, 1024, "bf16"), (4096, 1024, "qgelu"), (1024, 1024, "f32"), (1024, 4096, "f32")])
+def test_gemm_tiled_big_m_tiles(lib, tile, M, N, K, epi):
+    """The tiles `gemm_dispatch` auto-selects for an env batch / calibration window (M = 257 x 8 / 12 / 16 frames: 17 = 128x128 / 16
+    waves, 39 = 192x128, 45 = 128x192) on the four ViT-L projection shapes, called directly AND through the selector (tile 0), against
+    fp32 torch math; the ragged last row block (M % 128 = 8, 12, 16) and every epilogue the tower uses."""
+    A = dev(rnd(M, K, seed=61), torch.bfloat16)
+    W = dev(rnd(N, K, seed=62, scale=K ** -0.5), torch.bfloat16)
+    bias = dev(rnd(N, seed=63, scale=0.1))
+    ref = A.float() @ W.float().t() + bias
+    e = {"bf16": abi.EPI_BF16, "qgelu": abi.EPI_QGELU_BF16, "f32": abi.EPI_F32}[epi]
+    C = torch.full((M + 8, N), float("nan"), device="cuda", dtype=torch.float32 if epi == "f32" else torch.bfloat16)
+    abi.check(lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(W), K, abi.ptr(bias), abi.ptr(C), N, 0, M, N, K, 1, e, None, tile, None, st()), "gemm")
+    torch.cuda.synchronize()
+    assert torch.isnan(C[M:].float()).all()                                  # nothing written past row M
+    if epi == "f32":
+        assert rel_err(C[:M], ref) < 2e-5
+    elif epi == "bf16":
+        assert rel_err(C[:M].float(), ref) < 4e-3
+    else:
+        assert rel_err(C[:M].float(), ref * torch.sigmoid(1.702 * ref)) < 4e-3
+
+
+@pytest.mark.parametrize("M", [2056, 4112])
+def test_gemm_tiled_big_m_splitk_halves(lib, M):
+    """c_proj of an env batch runs as two K halves from 2048 rows (model.hip::pick_split): slab[0] + slab[1] == the full product."""
+    N, K = 1024, 4096
+    A = dev(rnd(M, K, seed=64), torch.bfloat16)
+    W = dev(rnd(N, K, seed=65, scale=K ** -0.5), torch.bfloat16)
+    slab = torch.zeros(2, M, N, device="cuda")
+    abi.check(lib.deer_gemm_bf16_nt_splitk(abi.ptr(A), K, abi.ptr(W), K, abi.ptr(slab), M, N, K, 2, 0, None, st()), "splitk")
+    torch.cuda.synchronize()
+    assert rel_err(slab.sum(0), A.float() @ W.float().t()) < 2e-5
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 0])
 @pytest.mark.parametrize("M,N,K", [(514, 3072, 1024), (514, 1024, 4096), (128, 1024, 512), (37, 128, 640), (640, 1024, 1024)])
 def test_gemm_tiled_epilogues(lib, tile, M, N, K):

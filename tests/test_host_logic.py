@@ -122,3 +122,19 @@ def test_factory_surface_and_state_dict_contract_on_cpu():
     if not torch.cuda.is_available():
         with pytest.raises(_abi.DeerHipError):
             model(torch.zeros(1, 1, 1, 3, 56, 56), ids, t["attention_mask"], vision_gripper=torch.zeros(1, 1, 1, 3, 56, 56), exit_id=1)
+
+
+def test_factory_fails_loudly_on_keywords_it_does_not_implement():
+    """keywords of the reference factory (factory.py:53-91) that change the model's arithmetic and are not built
+    here raise before anything is constructed (no GPU needed) instead of being accepted and ignored; keywords the reference's
+    MPTFlamingo never reads (no_image_patch, global_latent: flamingo_mpt.py:55-56 only) and training-only ones stay accepted."""
+    import pytest
+    from deer_vla_amd.factory import create_model_and_transforms
+    base = dict(clip_vision_encoder_path="ViT-L-14", clip_vision_encoder_pretrained="openai", lang_encoder_path="", tokenizer_path="",
+                use_gripper=True, fusion_mode="post", llm_name="mpt_dolly_3b", device="cpu")
+    for kw in (dict(multi_step_action=3), dict(last_action=True), dict(fwd_pred=True), dict(fwd_pred_hand=True), dict(residual=True),
+               dict(pad_length=12), dict(refresh=2), dict(return_feature=True), dict(layerwise_exit_eval=True), dict(use_hist=True),
+               dict(use_diff=True), dict(share_exit=True), dict(hidden_size=512), dict(multi_exit=False), dict(decoder_type="gpt"),
+               dict(head_type="diffusion"), dict(llm_name="llama_9b"), dict(clip_vision_encoder_path="ViT-B-32")):
+        with pytest.raises(NotImplementedError):
+            create_model_and_transforms(**{**base, **kw})

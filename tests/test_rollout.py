@@ -162,3 +162,79 @@ def test_two_env_batches_in_flight_give_the_same_bookkeeping():
     assert one["n_chains"] == two["n_chains"] == 7 and one["avg_seq_len"] == two["avg_seq_len"]
     assert one["n_steps"] == two["n_steps"] == two["n_steps_all"] == 14 * 4 and two["envs_per_rank"] == 2 * B
     assert one["chain_sr"] == two["chain_sr"] and sum(two["exit_hist"]) == 14 * 4
+
+
+class _SpeedEnv(ro.SyntheticEnv):
+    """an environment whose reset state changes the outcome: reset(speed=k) makes every step count k towards the task oracle"""
+
+    def __init__(self, seed=0):
+        super().__init__(seed)
+        self.speed = 1
+
+    def reset(self, speed=1, **kwargs):
+        super().reset()
+        self.speed = speed
+
+    def step(self, action):
+        obs, r, d, _ = super().step(action)
+        self.t += self.speed - 1
+        return self.get_obs(), r, d, self.get_info()
+
+
+@pytest.mark.gpu
+def test_env_batch_resets_every_chain_to_its_initial_state():
+    """the env-batch evaluator used to drop each chain's initial_state (bare ``env.reset()``); the reference resets the
+    environment to the chain's initial condition (eval_utils.py:587-588).  With an environment whose reset state decides how many
+    steps a sub-task takes, the batched run must give the step counts of the one-environment harness."""
+    from deer_vla_amd import synthetic as syn
+    from deer_vla_amd.config import deer_tiny
+    from deer_vla_amd.factory import create_model_and_transforms
+    from deer_vla_amd.value_net import ActionValueNet, ExitController
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
+    ann = {"a": ["open the drawer"], "b": ["turn on the light bulb now"]}
+    seqs = [({"speed": 2}, ["a", "b"]), (None, ["b", "a"]), ({"speed": 4}, ["a"]), ({"speed": 2}, ["b", "b", "a"])]
+    ok = ro.steps_task_checker(4)
+    outs = []
+    for B in (1, 2):
+        model, proc, tok = create_model_and_transforms("ViT-L-14", "openai", "", "", window_size=12, use_gripper=True, fusion_mode="post",
+                                                       llm_name="mpt_dolly_3b", state_dict=sd, cfg=cfg, n_envs=B)
+        vn = ActionValueNet(model.get_all_exit_idx(), None, cfg.exit_interval, 12, "L2")
+        ctl = ExitController(vn, model.get_all_exit_idx(), max_layer=cfg.early_exit_layer + 1)
+        ctl._set_threshold_value([0.02] * (ctl.real_num_exit - 1) + [1e5])
+        if B == 1:
+            w = ro.ModelWrapper(model, tok, proc, torch.float32, early_exit=True, exit_controller=ctl)
+            outs.append(ro.evaluate_policy_ddp(w, _SpeedEnv(2), seqs, ann, ok, ep_len=6))
+        else:
+            w = ro.BatchedModelWrapper(model, tok, proc, torch.float32, exit_controller=ctl)
+            outs.append(ro.evaluate_policy_batched(w, [_SpeedEnv(2 + b) for b in range(B)], seqs, ann, ok, ep_len=6))
+    a, b = outs
+    want = 2 * 2 + 2 * 4 + 1 + 3 * 2                 # steps per sub-task: ceil(4 / speed)
+    assert a["n_steps"] == want and b["n_steps"] == want, (a["n_steps"], b["n_steps"], want)
+    assert a["avg_seq_len"] == b["avg_seq_len"] == 8 / 4
+
+
+@pytest.mark.gpu
+def test_env_batch_rejects_instructions_that_do_not_fit_before_the_run_starts():
+    """8 environments x T tokens must fit the trunk's 128 rows (T <= 16); an enriched annotation of 14+ words tokenizes
+    longer.  The evaluator validates every instruction up front with a clear error instead of asserting mid-run; a controller with
+    steps_per_stage > 1 is refused at construction."""
+    from deer_vla_amd import synthetic as syn
+    from deer_vla_amd.config import deer_tiny
+    from deer_vla_amd.factory import create_model_and_transforms
+    from deer_vla_amd.value_net import ActionValueNet, ExitController
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
+    model, proc, tok = create_model_and_transforms("ViT-L-14", "openai", "", "", window_size=12, use_gripper=True, fusion_mode="post",
+                                                   llm_name="mpt_dolly_3b", state_dict=sd, cfg=cfg, n_envs=8)
+    vn = ActionValueNet(model.get_all_exit_idx(), None, cfg.exit_interval, 12, "L2")
+    ctl = ExitController(vn, model.get_all_exit_idx(), max_layer=cfg.early_exit_layer + 1)
+    ctl._set_threshold_value([0.02] * (ctl.real_num_exit - 1) + [1e5])
+    w = ro.BatchedModelWrapper(model, tok, proc, torch.float32, exit_controller=ctl)
+    long = "go towards the red block lying on the table and then carefully lift it up high"
+    ann = {"a": ["open the drawer"], "b": [long]}
+    with pytest.raises(ValueError, match="n_envs"):
+        ro.evaluate_policy_batched(w, [ro.SyntheticEnv(seed=b) for b in range(8)], [(None, ["a", "b"])], ann, ro.steps_task_checker(2), ep_len=3)
+    ctl3 = ExitController(vn, model.get_all_exit_idx(), steps_per_stage=3, max_layer=cfg.early_exit_layer + 1)
+    with pytest.raises(NotImplementedError):
+        ro.BatchedModelWrapper(model, tok, proc, torch.float32, exit_controller=ctl3)
