@@ -24,6 +24,9 @@ SIGNATURES = {
     "deer_gemm_bf16_nt_splitk": [P, I, P, I, P, I, I, I, I, I, P, P],
     "deer_gemm_skinny": [P, I, P, I, L, I, P, P, I, I, I, I, P, P],
     "deer_skinny_splitk": [I, I, I],
+    "deer_gemm_skinny_hl": [P, P, I, P, P, I, I, I, I, P, P],
+    "deer_skinny_hl_splitk": [I, I, I],
+    "deer_slab_gelu_split": [P, I, L, I, P, P, I, I, P, P],
     "deer_pack_weight_mfma16": [P, P, I, I, P],
     "deer_attn_mfma_hd64": [P, P, P, P, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
     "deer_attn_mfma_hd64_2seg": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
@@ -31,9 +34,11 @@ SIGNATURES = {
     "deer_xattn_fused": [P, I, P, P, I, I, P, I, I, P, P, L, I, I, I, F, P, P],
     "deer_xattn_small": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, I, I, F, P, P],
     "deer_mpt_attn_small": [P, I, L, I, I, P, P, F, P, F, P, P, I, I, I, I, P, P],
+    "deer_mpt_attn_small_hl": [P, I, L, I, I, P, P, F, P, F, P, P, P, I, I, I, P, P],
     "deer_layernorm_rows": [P, L, L, I, I, P, P, P, P, L, L, I, F, P],
     "deer_layernorm_rows_multi": [P, L, L, I, I, P, P, I, L, P, L, L, L, I, F, P],
     "deer_resadd_ln": [P, P, I, L, P, P, P, P, P, P, P, I, I, F, P, P],
+    "deer_resadd_ln_split": [P, P, I, L, P, P, P, P, P, P, P, P, I, I, F, P, P],
     "deer_vit_im2col": [P, I, I, I, I, P, I, P],
     "deer_vit_embed_lnpre": [P, P, P, P, P, P, I, I, I, F, P],
     "deer_embed_tokens_f32": [P, P, P, P, I, I, I, I, I, P],

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
                                                              const unsigned char* __restrict__ key_mask,
                                                              float alibi_slope_base, int n_heads,
                                                              void* __restrict__ out, int out_is_f32, int ldo, int T,
-                                                             const int* ctl) {
+                                                             const int* ctl, bf16_t* __restrict__ out_lo) {
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ __attribute__((aligned(16))) float qs[MA_MAXT][128 + 4];
   __shared__ __attribute__((aligned(16))) float ks[MA_MAXT][128 + 4];
@@ -430,6 +430,7 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
   if (key_mask != nullptr) key_mask += blockIdx.y * T;
   out = out_is_f32 ? (void*)(reinterpret_cast<float*>(out) + (long)blockIdx.y * T * ldo)
                    : (void*)(reinterpret_cast<bf16_t*>(out) + (long)blockIdx.y * T * ldo);
+  if (out_lo != nullptr) out_lo += (long)blockIdx.y * T * ldo;
   const int hd4 = hd >> 2;
   for (int idx = tid; idx < T * hd4; idx += 256) {
     const int t = idx / hd4, d = (idx - t * hd4) * 4;
@@ -468,7 +469,11 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
     float a = 0.f;
     for (int j = 0; j <= t; ++j) a += sim[t][j] * vs[j][d];
     if (out_is_f32) reinterpret_cast<float*>(out)[(long)t * ldo + h * hd + d] = a;
-    else reinterpret_cast<bf16_t*>(out)[(long)t * ldo + h * hd + d] = f2bf(a);
+    else {
+      const bf16_t hi = f2bf(a);
+      reinterpret_cast<bf16_t*>(out)[(long)t * ldo + h * hd + d] = hi;
+      if (out_lo != nullptr) out_lo[(long)t * ldo + h * hd + d] = f2bf(a - bf2f(hi));    // second plane: a = hi + lo
+    }
   }
 }
 
@@ -486,7 +491,26 @@ extern "C" int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_str
   hipLaunchKernelGGL(qkv_reduce_ln_kernel, dim3(T * batch, 3), dim3(256), 0, st, qkvslab, s_in, slab_stride, d_model, q_ln_w, k_ln_w,
                      eps, qkv_ws, ctl);
   hipLaunchKernelGGL(mpt_attn_small_kernel, dim3(n_heads, batch), dim3(256), 0, st, qkv_ws, d_model, hd, key_mask, alibi_bias_max,
-                     n_heads, out, out_is_f32, ldo, T, ctl);
+                     n_heads, out, out_is_f32, ldo, T, ctl, static_cast<bf16_t*>(nullptr));
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// the same op with the output as two bf16 planes hi / lo [batch*T, ldo] (activation operand of deer_gemm_skinny_hl)
+extern "C" int deer_mpt_attn_small_hl(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads,
+                                      const float* q_ln_w, const float* k_ln_w, float eps, const unsigned char* key_mask,
+                                      float alibi_bias_max, float* qkv_ws, void* out_hi, void* out_lo, int ldo, int T, int batch,
+                                      const int* ctl, void* stream) {
+  const int hd = d_model / n_heads;
+  if (T <= 0 || T > MA_MAXT || hd > 128 || (hd & 3) || hd * n_heads != d_model || s_in <= 0 || (d_model & 3) || d_model > 4096 ||
+      qkv_ws == nullptr || batch <= 0 || out_hi == nullptr || out_lo == nullptr)
+    return DEER_ERR_SHAPE;
+  if ((q_ln_w == nullptr) != (k_ln_w == nullptr)) return DEER_ERR_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(qkv_reduce_ln_kernel, dim3(T * batch, 3), dim3(256), 0, st, qkvslab, s_in, slab_stride, d_model, q_ln_w, k_ln_w,
+                     eps, qkv_ws, ctl);
+  hipLaunchKernelGGL(mpt_attn_small_kernel, dim3(n_heads, batch), dim3(256), 0, st, qkv_ws, d_model, hd, key_mask, alibi_bias_max,
+                     n_heads, out_hi, 0, ldo, T, ctl, reinterpret_cast<bf16_t*>(out_lo));
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

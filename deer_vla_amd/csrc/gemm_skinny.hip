@@ -19,6 +19,7 @@
 //    in-kernel cross-workgroup hand-off: deterministic, and a kernel boundary (~1.5 us) is cheaper than
 //    a grid barrier on this chip (MI355X_MICROARCH price list).
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -153,6 +154,213 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
 #pragma unroll
   for (int j = 0; j < MT; ++j)
     *reinterpret_cast<float4*>(dst + (long)(j * 16 + c) * N) = float4{acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Env-batch variant (49..128 rows: 4-8 environments x 14 tokens): at these row counts the GEMM is no longer a pure weight
+// stream - per 1 KiB weight fragment a wave issues 2*MT MFMAs and reads 2*MT activation fragments, so MFMA time (3.0 us for
+// 8192x2048), LDS-read time (3.0 us) and HBM time (5.6 us) are the same order, and the kernel above loses to its own
+// serialisation (measured r03: 5 us per 128-column chunk = load -> cvt -> ds_write -> barrier -> ds_read -> MFMA with nothing
+// overlapped; 21.9 us for 33.5 MB) and to its slabs (S = 8 f32 slabs of 128 x 8192 = the weight bytes again, written in a burst
+// at the end, then re-read - summed, GELU'ed and split - by EVERY column group of the consumer).
+// Here
+//  * the activation arrives PRE-SPLIT as two bf16 planes hi = bf16(a), lo = bf16(a - hi) (written by the producing kernel:
+//    deer_resadd_ln_split / deer_mpt_attn_small_hl / deer_slab_gelu_split), so staging is a pure copy and runs on the LDS-DMA
+//    path (global_load_lds_dwordx4) into a ring of D stages of 64 K-columns, exactly like csrc/gemm_tiled.hip: counted
+//    s_waitcnt vmcnt + ONE raw s_barrier per stage, XOR-swizzled 128-byte rows (conflict-free ds_read_b128 fragment reads);
+//  * the packed weight fragments ride the same ring (one 1 KiB DMA per fragment: all loads of a wave are LDS-DMA, so the
+//    in-order vmcnt accounting stays exact; the fragment is read back lane-linear, conflict-free);
+//  * a workgroup is 8 waves = 128 columns and walks a K range of K/S columns: S = 256 * 128 / N slabs instead of 256 * 256 / N
+//    (4 instead of 8 for the 8192-wide up-projections, 16 instead of 32 for the down-projections).
+// Algorithmic bytes per launch = 2*N*K (weights once); L2->LDS activation traffic = (N/128) * 128 rows * K * 4 B.
+static inline int skinny_mt(int M);
+typedef __attribute__((address_space(1))) const void sk_gptr_t;
+typedef __attribute__((address_space(3))) void sk_lptr_t;
+
+template <int N_>
+__device__ __forceinline__ void sk_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+template <int MT, int D>
+__global__ __launch_bounds__(512) void gemm_skinny_hl_kernel(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo, int lda,
+                                                            const bf16_t* __restrict__ Wp, float* __restrict__ part, int M, int N,
+                                                            int K, int KR, const int* ctl, int flags) {
+  DEER_RETURN_IF_EXITED(ctl);
+  constexpr int MTL = (MT + 1) & ~1;                  // row tiles LOADED per plane (even: every wave issues the same number of DMAs)
+  constexpr int MPAD = MT * 16;
+  constexpr int A_CH = 4 * MTL;                       // 1 KiB chunks (8 rows x 128 B) of [hi plane ; lo plane] per stage
+  constexpr int CH = A_CH + 16;                       // + 8 column tiles x 2 K-tiles of packed weight fragments
+  constexpr int CPW = CH / 8;                         // chunks per wave per stage
+  static_assert(CH % 8 == 0, "static vmcnt");
+  constexpr int A_BYTES = A_CH * 1024;
+  constexpr int STAGE = CH * 1024;
+  static_assert((D - 2) * CPW <= 63, "vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int ks = blockIdx.y, k_begin = ks * KR;
+  const int nk = KR >> 6;                             // stages of 64 K-columns
+  const int ktiles = K >> 5;
+  const int tile_raw = blockIdx.x * 8 + wave;
+  const bool tile_ok = tile_raw * 16 < N;
+
+  // per-wave DMA sources: chunk q = wave + i*8
+  const bf16_t* src[CPW];
+  int kstep[CPW];                                     // elements to advance per stage (64 for A rows, 2 fragments for W)
+  const int lr = lane >> 3, ls = ((lane & 7) ^ lr) * 8;
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int q = wave + i * 8;                       // wave-uniform
+    if (q < A_CH) {
+      const int plane = q / (2 * MTL), r8 = q - plane * 2 * MTL;
+      const int row = min(r8 * 8 + lr, M - 1);        // rows >= M repeat the last row (their outputs are zeroed in the epilogue)
+      src[i] = (plane ? Alo : Ahi) + (long)row * lda + k_begin + ls;
+      kstep[i] = 64;
+      if (flags & 1) { src[i] = (plane ? Alo : Ahi) + ((long)(k_begin >> 6) * 128 + row) * 64 + ls; kstep[i] = 128 * 64; }   // experiment: K-blocked planes
+    } else {
+      const int w = q - A_CH, ct = w >> 1, kt = w & 1;
+      const int t16 = blockIdx.x * 8 + ct;
+      const int tile = (t16 * 16 < N) ? t16 : 0;      // ragged N: stream tile 0, never stored
+      src[i] = Wp + (((long)tile * ktiles + (k_begin >> 5) + kt) * 64 + lane) * 8;
+      kstep[i] = 2 * 64 * 8;
+      if (flags & 2) { src[i] = Wp + ((((long)(k_begin >> 5) + kt) * (N >> 4) + tile) * 64 + lane) * 8; kstep[i] = 2 * (N >> 4) * 512; }   // experiment: kt-major weights
+    }
+  }
+  const int dbg = flags >> 4;
+  auto issue = [&](int t) {
+    const int tt = min(t, nk - 1);
+    unsigned char* st = smem_raw + (t % D) * STAGE;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const bool is_a = (wave + i * 8) < A_CH;
+      if ((dbg == 1 && is_a) || (dbg == 2 && !is_a)) continue;          // ablation (tools/bench_skinny_hl.py); vmcnt over-waits then
+      __builtin_amdgcn_global_load_lds((sk_gptr_t*)(src[i] + (long)tt * kstep[i]), (sk_lptr_t*)(st + (wave + i * 8) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int a_row = c * 128;
+  const int sw0 = ((0 * 4 + g) ^ (c & 7)) << 4, sw1 = ((1 * 4 + g) ^ (c & 7)) << 4;
+  const int w_off = A_BYTES + wave * 2048 + lane * 16;
+
+  const int nk_run = (dbg == 5) ? 0 : nk;             // ablation: epilogue only
+  if (dbg != 5) {
+#pragma unroll
+    for (int t = 0; t < D - 1; ++t) issue(t);
+  }
+  for (int kt = 0; kt < nk_run; ++kt) {
+    sk_wait_vmcnt<(D - 2) * CPW>();                   // this wave's part of stage kt has landed
+    __builtin_amdgcn_s_barrier();                     // ... everybody's; and everybody finished reading stage kt-1 (refilled now)
+    issue(kt + D - 1);
+    const unsigned char* st = smem_raw + (kt % D) * STAGE;
+    if (dbg == 3) continue;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int sw = kk ? sw1 : sw0;
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(st + w_off + kk * 1024);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(st + a_row + j * 2048 + sw);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(st + a_row + (MTL * 16 + j * 16) * 128 + sw);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, ah, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, al, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  sk_wait_vmcnt<0>();                                 // clamped tail loads must not land in LDS after the workgroup is gone
+  if (!tile_ok) return;
+  if (dbg == 4) { if (acc[0][0] == 123.456f) part[0] = 1.f; return; }      // ablation: no epilogue stores
+  float* dst = part + ((long)ks * MPAD) * N + tile_raw * 16 + g * 4;
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int row = j * 16 + c;
+    const float4 v = row < M ? float4{acc[j][0], acc[j][1], acc[j][2], acc[j][3]} : float4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<float4*>(dst + (long)row * N) = v;
+  }
+}
+
+// split-K of the env-batch kernel: 128-column workgroups, ~256 of them, K range per workgroup >= 256 columns (4 ring stages)
+extern "C" int deer_skinny_hl_splitk(int M, int N, int K) {
+  (void)M;
+  const int groups = (N + 127) / 128;
+  int s = 1;
+  while (groups * s * 2 <= 288 && (K / (s * 2)) >= 256 && (K % (s * 2 * 64)) == 0) s *= 2;
+  return s;
+}
+
+extern "C" int deer_gemm_skinny_hl(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K,
+                                   int splitk, const int* ctl, void* stream) {
+  if (M <= 0 || M > 128 || N <= 0 || (N & 15) || K <= 0 || (K & 63) || splitk <= 0 || (K % (splitk * 64)) != 0 || (lda & 7))
+    return DEER_ERR_SHAPE;
+  if (Ahi == nullptr || Alo == nullptr || Wp == nullptr || part == nullptr) return DEER_ERR_SHAPE;
+  const int KR = K / splitk;
+  const int mt = skinny_mt(M);
+  const char* fe = getenv("DEER_SKHL_FLAGS");          // experiments only (tools/bench_skinny_hl.py)
+  const int flags = fe ? atoi(fe) : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((N + 127) / 128, splitk);
+  const bf16_t* ah = reinterpret_cast<const bf16_t*>(Ahi);
+  const bf16_t* al = reinterpret_cast<const bf16_t*>(Alo);
+  const bf16_t* wp = reinterpret_cast<const bf16_t*>(Wp);
+#define DEER_SKHL_CASE(MT_, D_)                                                                                              \
+  case MT_: {                                                                                                                \
+    constexpr int smem = D_ * (4 * ((MT_ + 1) & ~1) + 16) * 1024;                                                            \
+    static_assert(smem <= 160 * 1024, "LDS");                                                                                \
+    static bool attr_set = false;                                                                                            \
+    auto kern = &gemm_skinny_hl_kernel<MT_, D_>;                                                                             \
+    if (!attr_set) {                                                                                                         \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=     \
+          hipSuccess) return DEER_ERR_LAUNCH;                                                                                \
+      attr_set = true;                                                                                                       \
+    }                                                                                                                        \
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, ah, al, lda, wp, part, M, N, K, KR, ctl, flags);                     \
+  } break
+  switch (mt) {
+    DEER_SKHL_CASE(1, 4);
+    DEER_SKHL_CASE(2, 4);
+    DEER_SKHL_CASE(3, 4);
+    DEER_SKHL_CASE(4, 4);
+    DEER_SKHL_CASE(5, 3);
+    DEER_SKHL_CASE(6, 3);
+    DEER_SKHL_CASE(7, 3);
+    DEER_SKHL_CASE(8, 3);
+    default: return DEER_ERR_SHAPE;
+  }
+#undef DEER_SKHL_CASE
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// ---- producer of the env-batch kernel's activation for the down-projections: GELU(sum of the up-projection's slabs) as
+// bf16 hi / lo planes [rows][C].  One pass over the slabs (the kernel above re-did this sum + GELU + split in EVERY column group
+// of the consumer: 8x for the 2048-wide down-projections).
+__global__ __launch_bounds__(256) void slab_gelu_split_kernel(const float* __restrict__ slab, int s_in, long stride, int gelu,
+                                                              bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long total4,
+                                                              const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    float4 s = slab_sum4(slab + i * 4, s_in, stride);
+    if (gelu) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
+    const uint32_t h01 = pack2bf(s.x, s.y), h23 = pack2bf(s.z, s.w);
+    *reinterpret_cast<uint2*>(hi + i * 4) = uint2{h01, h23};
+    *reinterpret_cast<uint2*>(lo + i * 4) =
+        uint2{pack2bf(s.x - __uint_as_float(h01 << 16), s.y - __uint_as_float(h01 & 0xffff0000u)),
+              pack2bf(s.z - __uint_as_float(h23 << 16), s.w - __uint_as_float(h23 & 0xffff0000u))};
+  }
+}
+
+extern "C" int deer_slab_gelu_split(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows,
+                                    int C, const int* ctl, void* stream) {
+  if (slab == nullptr || s_in <= 0 || out_hi == nullptr || out_lo == nullptr || rows <= 0 || C <= 0 || (C & 3)) return DEER_ERR_SHAPE;
+  const long total4 = (long)rows * C / 4;
+  const int blocks = (int)std::min<long>((total4 + 255) / 256, 2048);
+  hipLaunchKernelGGL(slab_gelu_split_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slab, s_in, slab_stride,
+                     gelu, reinterpret_cast<bf16_t*>(out_hi), reinterpret_cast<bf16_t*>(out_lo), total4, ctl);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
 }
 
 // ---- weight packing: row-major W[N,K] bf16 -> Wp[N/16][K/32][64][8] (done once at load time) ----

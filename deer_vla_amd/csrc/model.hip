@@ -24,6 +24,12 @@ constexpr float kEps = 1e-5f;
 constexpr int kVitHeadLayers = 3;   // ViT blocks in the first piece of a vision chain (short graph: the GPU idles until it is submitted)
 constexpr int kMaxRows = 128;       // LLM rows (n_envs * T) the skinny GEMM takes
 constexpr int kMaxSplit = 32;
+// LLM rows from which the trunk projections run on deer_gemm_skinny_hl (pre-split hi/lo activation planes, LDS-DMA ring, 128-column
+// workgroups): 4+ environments.  Below, the weight-streaming deer_gemm_skinny (f32 activation split in the kernel) is HBM-bound and faster.
+int hl_min_rows() {
+  static const int v = [] { const char* e = getenv("DEER_SKINNY_HL_MIN"); return e ? atoi(e) : 48; }();
+  return v;
+}
 
 // ---- weight ingestion kernels -------------------------------------------------------------------------------------------
 template <typename SrcT>
@@ -162,6 +168,8 @@ struct deer_model {
   std::vector<VisionWS> chains;
   size_t img, vis_x, vis_x_f32, kv_all, ids, key_mask, text_time, x, xn, ao, slab_a, slab_b, qkv_ws, hidden, h_state, c_state, h_tmp,
       c_tmp, h_shadow, c_shadow, pooled, ctl, step_info, thresholds, action_dbg;
+  size_t xn_hl, ao_hl, h_hl;        // bf16 hi / lo planes of the trunk activations (env batches > kHlMinRows rows: deer_gemm_skinny_hl)
+  long hl_plane_d, hl_plane_h;      // elements per plane: rows * d, rows * max_n
   size_t slab_a_elems, slab_b_elems;
   size_t z_fc[3];
   char* arena = nullptr;
@@ -499,6 +507,11 @@ void build_workspace(deer_model* m) {
   m->slab_a = named(m, "slab_a", m->slab_a_elems * 4);
   m->slab_b = named(m, "slab_b", m->slab_b_elems * 4);
   m->qkv_ws = named(m, "qkv_ws", (size_t)T * 3 * d * 4);
+  m->hl_plane_d = (long)T * std::max(d, m->xinner);
+  m->hl_plane_h = (long)T * max_n;
+  m->xn_hl = m->wl.add((size_t)2 * m->hl_plane_d * 2);
+  m->ao_hl = m->wl.add((size_t)2 * m->hl_plane_d * 2);
+  m->h_hl = m->wl.add((size_t)2 * m->hl_plane_h * 2);
   m->hidden = named(m, "hidden", (size_t)c.n_layers * T * d * 4);
   const size_t st = (size_t)m->Lh * B * m->H * 4;
   m->h_state = named(m, "h_state", st);
@@ -785,6 +798,42 @@ int skinny(deer_model* m, const void* Wp, long N, long K, int R, float* out_slab
   return DEER_OK;
 }
 
+bool use_hl(const deer_model* m, int R) { return !m->c.precision && R > hl_min_rows(); }
+
+// the MPT block of a layer runs on the hi/lo-plane kernels (every K of its four projections is d or mlp_ratio*d)
+bool block_hl(const deer_model* m, int R) { return use_hl(m, R) && (m->d & 63) == 0 && (((long)m->c.mlp_ratio * m->d) & 63) == 0; }
+
+int trunk_splitk(const deer_model* m, int R, long N, long K) {
+  return block_hl(m, R) ? deer_skinny_hl_splitk(R, (int)N, (int)K) : deer_skinny_splitk(R, (int)N, (int)K);
+}
+
+// env-batch form: activation as bf16 hi / lo planes
+int skinny_hl(deer_model* m, const void* Wp, long N, long K, int R, float* out_slab, size_t out_elems, const bf16_t* hi, const bf16_t* lo, int lda,
+              const int* ctl, void* st, int* S_out, long* stride_out) {
+  const int S = deer_skinny_hl_splitk(R, (int)N, (int)K);
+  const int mpad = 16 * ((R + 15) / 16);
+  if ((size_t)S * mpad * N > out_elems) return DEER_ERR_SHAPE;
+  *S_out = S;
+  *stride_out = (long)mpad * N;
+  Bracket b(m, "deer_gemm_skinny_hl", 2.0 * R * N * K, 2.0 * N * K, st);    // algorithmic bytes = the bf16 weights, once
+  return deer_gemm_skinny_hl(hi, lo, lda, Wp, out_slab, R, (int)N, (int)K, S, ctl, st);
+}
+
+// GELU(sum of the up-projection's slabs) -> hi / lo planes [R][C] (the activation of the down-projection)
+int gelu_split(deer_model* m, const float* slab, int S, long stride, int R, long C, const int* ctl, void* st) {
+  Bracket b(m, "deer_slab_gelu_split", 0, 4.0 * S * R * C + 4.0 * R * C, st);
+  bf16_t* h = m->Wk<bf16_t>(m->h_hl);
+  return deer_slab_gelu_split(slab, S, stride, 1, h, h + m->hl_plane_h, R, (int)C, ctl, st);
+}
+
+// resadd with the LayerNorm output as hi / lo planes in xn_hl (rows x d)
+int resadd_split(deer_model* m, int R, const Pending* p, const float* gamma, const float* beta, float* x_copy, const int* ctl, void* st) {
+  Bracket b(m, "deer_resadd_ln", 0, 4.0 * R * m->d * ((p ? p->S : 0) + 3), st);
+  bf16_t* h = m->Wk<bf16_t>(m->xn_hl);
+  return deer_resadd_ln_split(m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma, beta, h,
+                              h + m->hl_plane_d, nullptr, x_copy, R, m->d, kEps, ctl, st);
+}
+
 int resadd(deer_model* m, int R, const Pending* p, const float* gamma, const float* beta, float* x_copy, const int* ctl, void* st) {
   Bracket b(m, "deer_resadd_ln", 0, 4.0 * R * m->d * ((p ? p->S : 0) + 3), st);
   return deer_resadd_ln(m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma, beta, nullptr,
@@ -794,7 +843,7 @@ int resadd(deer_model* m, int R, const Pending* p, const float* gamma, const flo
 // the residual branch a layer leaves un-applied when it is not finalized: the down-projection slabs (shape-determined)
 Pending pending_of_down(const deer_model* m, int R) {
   const long K = (long)m->c.mlp_ratio * m->d;
-  const int S = deer_skinny_splitk(R, m->d, (int)K) * (m->c.precision ? 2 : 1);
+  const int S = trunk_splitk(m, R, m->d, K) * (m->c.precision ? 2 : 1);
   return Pending{m->Wk<float>(m->slab_a), S, (long)(16 * ((R + 15) / 16)) * m->d, nullptr};
 }
 
@@ -809,6 +858,10 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
   float* slab_b = m->Wk<float>(m->slab_b);
   float* xn = m->Wk<float>(m->xn);
   float* ao = m->Wk<float>(m->ao);
+  const bool hl = block_hl(m, R);                          // env batch of 4+ environments: activations as bf16 hi / lo planes
+  const bf16_t* xh = m->Wk<bf16_t>(m->xn_hl);
+  const bf16_t* hh = m->Wk<bf16_t>(m->h_hl);
+  bf16_t* aoh = m->Wk<bf16_t>(m->ao_hl);
   Pending pend{}, *pp = nullptr;
   // a layer that was not finalized leaves its last residual branch to this layer's first row op, which then ALSO writes the
   // completed x out as hidden_states[i-1] (no extra launch): every hidden state up to the exit layer is real
@@ -855,28 +908,52 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
       DEER_TRY(skinny(m, m->A<void>(X.wo), d, xin, R, slab_a, m->slab_a_elems, ao, xin, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
     }
     pend = Pending{slab_a, S, stride, m->A<float>(X.ag)};
-    DEER_TRY(resadd(m, R, &pend, m->A<float>(X.fnw), m->A<float>(X.fnb), nullptr, ctl, st));
-    DEER_TRY(skinny(m, m->A<void>(X.w1), (long)c.xattn_ff_mult * d, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
-    DEER_TRY(skinny(m, m->A<void>(X.w2), d, (long)c.xattn_ff_mult * d, R, slab_a, m->slab_a_elems, nullptr, 0, slab_b, S, DEER_A_SLABS_GELU, ctl, st, &S,
-                    &stride));
+    const long xff = (long)c.xattn_ff_mult * d;
+    if (hl && (xff & 63) == 0) {
+      DEER_TRY(resadd_split(m, R, &pend, m->A<float>(X.fnw), m->A<float>(X.fnb), nullptr, ctl, st));
+      DEER_TRY(skinny_hl(m, m->A<void>(X.w1), xff, d, R, slab_b, m->slab_b_elems, xh, xh + m->hl_plane_d, d, ctl, st, &S, &stride));
+      DEER_TRY(gelu_split(m, slab_b, S, stride, R, xff, ctl, st));
+      DEER_TRY(skinny_hl(m, m->A<void>(X.w2), d, xff, R, slab_a, m->slab_a_elems, hh, hh + m->hl_plane_h, (int)xff, ctl, st, &S, &stride));
+    } else {
+      DEER_TRY(resadd(m, R, &pend, m->A<float>(X.fnw), m->A<float>(X.fnb), nullptr, ctl, st));
+      DEER_TRY(skinny(m, m->A<void>(X.w1), xff, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
+      DEER_TRY(skinny(m, m->A<void>(X.w2), d, xff, R, slab_a, m->slab_a_elems, nullptr, 0, slab_b, S, DEER_A_SLABS_GELU, ctl, st, &S, &stride));
+    }
     pend = Pending{slab_a, S, stride, m->A<float>(X.fg)};
     pp = &pend;
   }
   const float* ln1b = m->loaded(L.ln1b_name) ? m->A<float>(L.ln1b) : nullptr;
   const float* ln2b = m->loaded(L.ln2b_name) ? m->A<float>(L.ln2b) : nullptr;
-  DEER_TRY(resadd(m, R, pp, m->A<float>(L.ln1w), ln1b, prev_hidden, ctl, st));
-  DEER_TRY(skinny(m, m->A<void>(L.wqkv), 3L * d, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
-  {
-    Bracket b(m, "deer_mpt_attn_small", 0, 0, st);
-    const unsigned char* km = m->mask_override ? m->mask_override : m->Wk<unsigned char>(m->key_mask);
-    DEER_TRY(deer_mpt_attn_small(slab_b, S, stride, d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
-                                 (float)c.alibi_bias_max, m->Wk<float>(m->qkv_ws), ao, 1, d, T, B, ctl, st));
+  const unsigned char* km = m->mask_override ? m->mask_override : m->Wk<unsigned char>(m->key_mask);
+  const long ffw = (long)c.mlp_ratio * d;
+  if (hl) {
+    DEER_TRY(resadd_split(m, R, pp, m->A<float>(L.ln1w), ln1b, prev_hidden, ctl, st));
+    DEER_TRY(skinny_hl(m, m->A<void>(L.wqkv), 3L * d, d, R, slab_b, m->slab_b_elems, xh, xh + m->hl_plane_d, d, ctl, st, &S, &stride));
+    {
+      Bracket b(m, "deer_mpt_attn_small", 0, 0, st);
+      DEER_TRY(deer_mpt_attn_small_hl(slab_b, S, stride, d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
+                                      (float)c.alibi_bias_max, m->Wk<float>(m->qkv_ws), aoh, aoh + m->hl_plane_d, d, T, B, ctl, st));
+    }
+    DEER_TRY(skinny_hl(m, m->A<void>(L.wo), d, d, R, slab_a, m->slab_a_elems, aoh, aoh + m->hl_plane_d, d, ctl, st, &S, &stride));
+    pend = Pending{slab_a, S, stride, nullptr};
+    DEER_TRY(resadd_split(m, R, &pend, m->A<float>(L.ln2w), ln2b, nullptr, ctl, st));
+    DEER_TRY(skinny_hl(m, m->A<void>(L.wup), ffw, d, R, slab_b, m->slab_b_elems, xh, xh + m->hl_plane_d, d, ctl, st, &S, &stride));
+    DEER_TRY(gelu_split(m, slab_b, S, stride, R, ffw, ctl, st));
+    DEER_TRY(skinny_hl(m, m->A<void>(L.wdown), d, ffw, R, slab_a, m->slab_a_elems, hh, hh + m->hl_plane_h, (int)ffw, ctl, st, &S, &stride));
+  } else {
+    DEER_TRY(resadd(m, R, pp, m->A<float>(L.ln1w), ln1b, prev_hidden, ctl, st));
+    DEER_TRY(skinny(m, m->A<void>(L.wqkv), 3L * d, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
+    {
+      Bracket b(m, "deer_mpt_attn_small", 0, 0, st);
+      DEER_TRY(deer_mpt_attn_small(slab_b, S, stride, d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
+                                   (float)c.alibi_bias_max, m->Wk<float>(m->qkv_ws), ao, 1, d, T, B, ctl, st));
+    }
+    DEER_TRY(skinny(m, m->A<void>(L.wo), d, d, R, slab_a, m->slab_a_elems, ao, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
+    pend = Pending{slab_a, S, stride, nullptr};
+    DEER_TRY(resadd(m, R, &pend, m->A<float>(L.ln2w), ln2b, nullptr, ctl, st));
+    DEER_TRY(skinny(m, m->A<void>(L.wup), ffw, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
+    DEER_TRY(skinny(m, m->A<void>(L.wdown), d, ffw, R, slab_a, m->slab_a_elems, nullptr, 0, slab_b, S, DEER_A_SLABS_GELU, ctl, st, &S, &stride));
   }
-  DEER_TRY(skinny(m, m->A<void>(L.wo), d, d, R, slab_a, m->slab_a_elems, ao, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
-  pend = Pending{slab_a, S, stride, nullptr};
-  DEER_TRY(resadd(m, R, &pend, m->A<float>(L.ln2w), ln2b, nullptr, ctl, st));
-  DEER_TRY(skinny(m, m->A<void>(L.wup), (long)c.mlp_ratio * d, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
-  DEER_TRY(skinny(m, m->A<void>(L.wdown), d, (long)c.mlp_ratio * d, R, slab_a, m->slab_a_elems, nullptr, 0, slab_b, S, DEER_A_SLABS_GELU, ctl, st, &S, &stride));
   if (finalize) {   // hidden_states[i] = output of layer i (mosaic_gpt_3b.py:424-427)
     pend = Pending{slab_a, S, stride, nullptr};
     const size_t rows_cap = std::min(B * c.max_text_len, kMaxRows);

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         bf16_t* __restrict__ out_bf, float* __restrict__ out_f32,
                                                         float* __restrict__ x_copy, int d, float eps, const int* ctl,
-                                                        const float* __restrict__ bias) {
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out_lo) {
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ float red[16];
   const int r = blockIdx.x;
@@ -155,8 +155,14 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
         const float4 bb = *reinterpret_cast<const float4*>(beta + (long)i4 * 4);
         y.x += bb.x; y.y += bb.y; y.z += bb.z; y.w += bb.w;
       }
-      if (out_bf != nullptr)
-        *reinterpret_cast<uint2*>(out_bf + (long)r * d + (long)i4 * 4) = uint2{pack2bf(y.x, y.y), pack2bf(y.z, y.w)};
+      if (out_bf != nullptr) {
+        const uint32_t h01 = pack2bf(y.x, y.y), h23 = pack2bf(y.z, y.w);
+        *reinterpret_cast<uint2*>(out_bf + (long)r * d + (long)i4 * 4) = uint2{h01, h23};
+        if (out_lo != nullptr)      // second bf16 plane: y = hi + lo to ~16 mantissa bits (activation operand of deer_gemm_skinny_hl)
+          *reinterpret_cast<uint2*>(out_lo + (long)r * d + (long)i4 * 4) =
+              uint2{pack2bf(y.x - __uint_as_float(h01 << 16), y.y - __uint_as_float(h01 & 0xffff0000u)),
+                    pack2bf(y.z - __uint_as_float(h23 << 16), y.w - __uint_as_float(h23 & 0xffff0000u))};
+      }
       if (out_f32 != nullptr) *reinterpret_cast<float4*>(out_f32 + (long)r * d + (long)i4 * 4) = y;
     }
   }
@@ -169,7 +175,21 @@ extern "C" int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_s
       (gamma != nullptr && out_bf16 == nullptr && out_f32 == nullptr))
     return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(resadd_ln_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in,
-                     slab_stride, gate, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl, bias);
+                     slab_stride, gate, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl, bias,
+                     static_cast<bf16_t*>(nullptr));
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// deer_resadd_ln with the LayerNorm output ALSO as two bf16 planes hi = bf16(y), lo = bf16(y - hi) (the pre-split activation operand
+// of deer_gemm_skinny_hl); out_f32 optional (deer_xattn_fused reads it).
+extern "C" int deer_resadd_ln_split(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
+                                    const float* gamma, const float* beta, void* out_hi, void* out_lo, float* out_f32, float* x_copy,
+                                    int T, int d, float eps, const int* ctl, void* stream) {
+  if (T <= 0 || d <= 0 || (d & 3) || d > 4096 || (slab != nullptr && s_in <= 0) || gamma == nullptr || out_hi == nullptr || out_lo == nullptr)
+    return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(resadd_ln_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
+                     gamma, beta, reinterpret_cast<bf16_t*>(out_hi), out_f32, x_copy, d, eps, ctl, bias, reinterpret_cast<bf16_t*>(out_lo));
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

@@ -111,6 +111,20 @@ int deer_gemm_bf16_nt_splitk(const void* A, int lda, const void* W, int ldw, flo
 int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int s_in, long slab_stride_in, int a_mode, const void* Wp,
                      float* part, int M, int N, int K, int splitk, const int* ctl, void* stream);
 int deer_skinny_splitk(int M, int N, int K);                       /* host helper: suggested split-K */
+/* The same Linears for an ENV BATCH of 4-8 environments (49..128 rows), where MFMA time, LDS-read time and the weight stream are
+ * the same order: the activation arrives pre-split as two bf16 planes A_hi = bf16(a), A_lo = bf16(a - A_hi), each [>= M rows, lda]
+ * (written by deer_resadd_ln_split / deer_mpt_attn_small_hl / deer_slab_gelu_split), and is staged - together with the packed
+ * weight fragments - by LDS-DMA into a ring (counted vmcnt + one raw barrier per 64 K-columns).  128-column workgroups:
+ * splitk = deer_skinny_hl_splitk(M, N, K) slabs, half as many as deer_gemm_skinny.  K % (64 * splitk) == 0.  part[ks][Mpad][N];
+ * rows M..Mpad-1 are written as zeros. */
+int deer_gemm_skinny_hl(const void* A_hi, const void* A_lo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
+                        const int* ctl, void* stream);
+int deer_skinny_hl_splitk(int M, int N, int K);
+/* hi / lo planes [rows, C] of act(sum_s slab[s]) (act = exact GELU when gelu != 0): the activation of the down-projections
+ * (GELU between mlp_up / mlp_down of the MPT block and ff.1 / ff.3 of the gated x-attn block, helpers.py:15-22), computed ONCE
+ * instead of once per column group of the consumer. */
+int deer_slab_gelu_split(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows, int C,
+                         const int* ctl, void* stream);
 int deer_pack_weight_mfma16(const void* W, void* Wp, int N, int K, void* stream);  /* [N,K] -> [N/16][K/32][64][8] */
 
 /* ---- attention ----------------------------------------------------------------------------------------------
@@ -153,6 +167,10 @@ int deer_xattn_small(const float* qslab, int s_in, long slab_stride, int ldqs, c
 int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w,
                         const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws,
                         void* out, int out_is_f32, int ldo, int T, int batch, const int* ctl, void* stream);
+/* the same op, output as two bf16 planes hi = bf16(o), lo = bf16(o - hi), each [batch*T, ldo] (operand of deer_gemm_skinny_hl) */
+int deer_mpt_attn_small_hl(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w,
+                           const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws,
+                           void* out_hi, void* out_lo, int ldo, int T, int batch, const int* ctl, void* stream);
 
 /* (deer_head_*: w_is_f32 = 1 when the weight pointers are f32 - the fp32 arithmetic keeps the head's weights in f32) */
 
@@ -195,6 +213,11 @@ int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_stride, cons
                    const float* gamma,
                    const float* beta, void* out_bf16, float* out_f32, float* x_copy, int T, int d, float eps, const int* ctl,
                    void* stream);
+/* deer_resadd_ln with the LayerNorm output ALSO as two bf16 planes hi = bf16(y), lo = bf16(y - hi) (operand of deer_gemm_skinny_hl);
+ * out_f32 optional. */
+int deer_resadd_ln_split(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
+                         const float* gamma, const float* beta, void* out_hi, void* out_lo, float* out_f32, float* x_copy, int T,
+                         int d, float eps, const int* ctl, void* stream);
 /* ViT patch embedding (open_clip conv1 + class/positional embedding + ln_pre) */
 int deer_vit_im2col(const void* img, int img_is_bf16, int N, int S, int patch, void* out_bf16, int Kpad, void* stream);
 int deer_vit_embed_lnpre(const float* patch, const float* cls, const float* pos, const float* ln_w, const float* ln_b,

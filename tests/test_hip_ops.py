@@ -158,6 +158,76 @@ def test_gemm_skinny_env_batch_rows_trunk_shapes(lib, M, N, K, mode):
         assert float(part[:, M:].abs().max()) == 0.0
 
 
+def _split_hl(a):
+    hi = a.to(torch.bfloat16)
+    lo = (a - hi.float()).to(torch.bfloat16)
+    return hi.contiguous(), lo.contiguous()
+
+
+@pytest.mark.parametrize("M", [1, 14, 33, 50, 56, 70, 84, 96, 112, 128])
+@pytest.mark.parametrize("N,K", [(6144, 2048), (2048, 2048), (8192, 2048), (2048, 8192), (16384, 4096), (4096, 16384), (512, 2048), (80, 128), (2048, 512)])
+def test_gemm_skinny_hl_env_batch_kernel(lib, M, N, K):
+    """deer_gemm_skinny_hl (LDS-DMA ring, pre-split hi/lo activation planes, 128-column workgroups) on every trunk projection shape
+    of MPT-1B / MPT-7B (+ ragged N, short K) against fp64 torch math on the same bf16 weights; bit-reproducible; padded rows zero."""
+    a = dev(rnd(M, K, seed=81))
+    hi, lo = _split_hl(a)
+    W = dev(rnd(N, K, seed=82, scale=K ** -0.5), torch.bfloat16)
+    Wp = torch.empty_like(W)
+    abi.check(lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), N, K, st()), "pack")
+    S = lib.deer_skinny_hl_splitk(M, N, K)
+    assert S >= 1 and K % (S * 64) == 0
+    mpad = abi.skinny_mpad(M)
+    outs = []
+    for _ in range(2):
+        part = torch.full((S, mpad, N), float("nan"), device="cuda")
+        abi.check(lib.deer_gemm_skinny_hl(abi.ptr(hi), abi.ptr(lo), K, abi.ptr(Wp), abi.ptr(part), M, N, K, S, None, st()), "skinny_hl")
+        torch.cuda.synchronize()
+        outs.append(part)
+    part = outs[0]
+    assert torch.isfinite(part).all()
+    ref = (a.double() @ W.double().t()).float()
+    assert rel_err(part.sum(0)[:M], ref) < 3e-5
+    assert torch.equal(outs[0], outs[1])
+    if mpad > M:
+        assert float(part[:, M:].abs().max()) == 0.0
+
+
+def test_skinny_hl_producers_and_exit_flag(lib):
+    """deer_slab_gelu_split == split(gelu(sum slabs)); deer_resadd_ln_split's planes == split of its own f32 LayerNorm output;
+    deer_gemm_skinny_hl returns at entry once ALL_EXITED is set."""
+    rows, C, s_in = 112, 8192, 4
+    slab = dev(rnd(s_in, 112, C, seed=83))
+    hi = torch.zeros(rows, C, device="cuda", dtype=torch.bfloat16)
+    lo = torch.zeros_like(hi)
+    abi.check(lib.deer_slab_gelu_split(abi.ptr(slab), s_in, 112 * C, 1, abi.ptr(hi), abi.ptr(lo), rows, C, None, st()), "gelu_split")
+    torch.cuda.synchronize()
+    a = torch.nn.functional.gelu(slab.sum(0))
+    rh, rl = _split_hl(a)
+    assert float(((hi.float() + lo.float()) - a).abs().max()) < 1e-4 * float(a.abs().max())
+    assert (hi != rh).float().mean() < 1e-3 and rel_err(lo.float(), rl.float()) < 2e-2     # erf ulps may flip a rounding
+    d, T = 2048, 112
+    x = dev(rnd(T, d, seed=84))
+    g, b = dev(1 + 0.1 * rnd(d, seed=85)), dev(0.1 * rnd(d, seed=86))
+    y32 = torch.zeros(T, d, device="cuda")
+    yh = torch.zeros(T, d, device="cuda", dtype=torch.bfloat16)
+    yl = torch.zeros_like(yh)
+    abi.check(lib.deer_resadd_ln_split(abi.ptr(x), None, 0, 0, None, None, abi.ptr(g), abi.ptr(b), abi.ptr(yh), abi.ptr(yl), abi.ptr(y32), None,
+                                       T, d, 1e-5, None, st()), "resadd_ln_split")
+    torch.cuda.synchronize()
+    rh, rl = _split_hl(y32)
+    assert torch.equal(yh, rh) and torch.equal(yl, rl)
+    assert rel_err(y32, torch.nn.functional.layer_norm(x, (d,), g, b, 1e-5)) < 1e-5
+    ctl = torch.zeros(abi.CTL_WORDS, dtype=torch.int32, device="cuda")
+    ctl[abi.CTL_ALL_EXITED] = 1
+    W = dev(rnd(128, d, seed=87), torch.bfloat16)
+    Wp = torch.empty_like(W)
+    abi.check(lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), 128, d, st()), "pack")
+    part = torch.full((1, 112, 128), 7.0, device="cuda")
+    abi.check(lib.deer_gemm_skinny_hl(abi.ptr(yh), abi.ptr(yl), d, abi.ptr(Wp), abi.ptr(part), T, 128, d, 1, abi.ptr(ctl), st()), "skinny_hl")
+    torch.cuda.synchronize()
+    assert float(part.min()) == 7.0
+
+
 # ------------------------------------------------------------------------------------------- tiled GEMM
 @pytest.mark.parametrize("tile", [17, 39, 45, 0])
 @pytest.mark.parametrize("M", [2056, 3084, 4112])
