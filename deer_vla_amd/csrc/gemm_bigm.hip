@@ -1,0 +1,346 @@
+// Big-M bf16 MFMA GEMMs of the vision tower for env batches / calibration windows (M = 257 x 8..16 frames):
+//
+//   C[M,N] = epi( A[M,K] (bf16, row-major) * W[N,K]^T (bf16, nn.Linear layout) + bias[N] )
+//
+// What round 3 measured about these shapes (tools/fill_bench.hip, the ring-depth sweep of deer_gemm_skinny_hl, an 8-wave
+// 256x256 kernel on the guide's 8-phase schedule - two staggered wave rows, counted vmcnt once per K-tile - that reached only
+// 26 GB/s of tile fill per CU = 40 us per 256x256x1024 tile and was removed again):
+//  * the operand stream of a GEMM tile (rows of A shared by a tile row, rows of W shared by a tile column, all CUs in step) enters a
+//    CU's LDS at 33-38 GB/s however it is asked for: ring depth 2..5 gives the same time (rate-bound, not latency-bound), 16 issuing
+//    waves are ~25 % better than 8, hipBLASLt's own kernels sit at the same per-CU rate (its 29.8 us for 4112x3072x1024 = 35 GB/s per CU
+//    with 256x256 tiles);
+//  * so the levers are FLOP per staged byte (256-row x 256-column tiles: 128 FLOP/B against 64 for the 128x128 kernels of
+//    gemm_tiled.hip) and not wasting CUs on ragged tiles: M = 257 n is never a multiple of a power-of-two tile, and a ragged tile of
+//    8-16 valid rows costs 3/4 of a full one (the DMA instruction count, not the bytes, is what a CU pays for).
+// Two kernels, both the ring structure of gemm_tiled.hip with 32-column K-steps (so that 256-row tiles still leave room for a ring):
+//  * gemm_ring32_kernel: BM x BN in {256x256, 128x128}, 16 waves as 4 x 4;
+//  * gemm_ring272_kernel: ONE IMAGE PER ROW TILE - 257 valid rows computed as 17 MFMA row tiles (272 rows; the 15 extra rows are
+//    the next image's first rows, computed and dropped): M = 257 n tiles exactly into n row tiles, 16 x 16 = 256 workgroups for the
+//    c_fc GEMM of 16 frames (one round on 256 CUs instead of 272 tiles), 16 x 12 for in_proj.
+#include "common.h"
+#include <type_traits>
+
+enum { P8_EPI_BF16 = 0, P8_EPI_F32 = 1, P8_EPI_QGELU_BF16 = 2, P8_EPI_GELU_BF16 = 3, P8_EPI_RESADD_F32 = 4 };
+
+typedef __attribute__((address_space(1))) const void p8_gptr_t;
+typedef __attribute__((address_space(3))) void p8_lptr_t;
+
+template <int N_>
+__device__ __forceinline__ void p8_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// ring32: the ring structure of gemm_tiled.hip with 32-column K-steps, so that a 256x256 tile (128 FLOP per staged byte, twice
+// the 128x128 kernels) still has 3-4 stages IN FLIGHT inside 160 KB of LDS (5 x 32 KB).  Measured r03 (tools/fill_bench, the depth
+// sweep of deer_gemm_skinny_hl, the 8-phase kernel above): on these streams a CU's LDS-DMA path sustains 26-38 GB/s with 8 waves
+// issuing and is rate-bound, not latency-bound (ring depth 2..5 gives the same time) - the two levers are waves issuing (16 here:
+// 44-51 -> 64-72 GB/s per CU in the microbenchmark) and FLOP per staged byte.
+//  * 16 waves as 4 x 4, wave tile (BM/4) x (BN/4) (64x64: 4x4 MFMA tiles, 64 accumulator VGPRs, 8 ds_read_b128 per 16 MFMAs);
+//  * LDS rows of 64 bytes: the 16-byte slot of a row is XOR-swizzled with f((row >> 2) & 3), f = {0, 2, 3, 1}, which makes every
+//    16-lane group of a ds_read_b128 fragment read hit 16 distinct 16-byte bank units (rows c = 0..15 of a tile, slot g);
+//  * one counted vmcnt + ONE raw s_barrier per K-step, every wave issues exactly CPW DMAs per step.
+template <int BM, int BN, int D>
+__global__ __launch_bounds__(1024) void gemm_ring32_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
+                                                            const bf16_t* __restrict__ W, int ldw, long strideW,
+                                                            const float* __restrict__ bias, void* __restrict__ Cv, int ldc,
+                                                            long strideC, int M, int N, int K, int epi,
+                                                            const float* __restrict__ gate, const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
+  constexpr int TM = BM / 64, TN = BN / 64;                 // MFMA tiles per wave (4 x 4 waves)
+  constexpr int CH = (BM + BN) / 16;                        // 1 KiB DMA chunks (16 rows x 64 B) per stage
+  constexpr int CPW = CH / 16;
+  static_assert(CH % 16 == 0, "every wave issues the same number of DMAs");
+  constexpr int STAGE = (BM + BN) * 64;
+  static_assert(D * STAGE <= 160 * 1024 && (D - 2) * CPW <= 63, "LDS / vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int c = lane & 15, g = lane >> 4;
+
+  // tile order: full row tiles first, ragged ones last in every XCD's dispatch order (thin tiles spread over the XCDs, dispatched after the full ones)
+  constexpr int BMS = BM == 256 ? 8 : 7;
+  static_assert(BM == 256 || BM == 128, "row tile");
+  const int tiles_n = (N + BN - 1) / BN;
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int nfull = (M >> BMS) * tiles_n;
+  const int xcd = bid & 7, idx = bid >> 3;
+  int tile;
+  {
+    const int fq = nfull >> 3, fr = nfull & 7;
+    const int fcount = fq + (xcd < fr ? 1 : 0), fstart = xcd * fq + min(xcd, fr);
+    if (idx < fcount) tile = fstart + idx;
+    else {
+      const int bq = nb >> 3, br = nb & 7;
+      tile = nfull + (xcd * bq + min(xcd, br) - fstart) + (idx - fcount);
+    }
+  }
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  A += (long)blockIdx.z * strideA;
+  W += (long)blockIdx.z * strideW;
+
+  // DMA chunk q = wave + i*16: rows 16q .. 16q+15 of [A tile ; W tile]; lane: row 16q + (lane >> 2), source slot (lane & 3) ^ f
+  const int lr = lane >> 2;
+  const int fsw = (0x1320 >> (((lr >> 2) & 3) * 4)) & 3;    // f = {0, 2, 3, 1} for (row >> 2) & 3 = 0..3
+  const int ls = ((lane & 3) ^ fsw) * 8;
+  const bf16_t* sp[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int row = (wave + i * 16) * 16 + lr;              // wave-uniform side: A chunk or W chunk
+    sp[i] = (row < BM) ? A + (long)min(m0 + row, M - 1) * lda + ls : W + (long)min(n0 + row - BM, N - 1) * ldw + ls;
+  }
+  const int nk = K >> 5;
+  auto issue = [&](int t) {
+    const int k0 = min(t, nk - 1) << 5;
+    unsigned char* st = smem + (t % D) * STAGE;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i)
+      __builtin_amdgcn_global_load_lds((p8_gptr_t*)(sp[i] + k0), (p8_lptr_t*)(st + (wave + i * 16) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment of MFMA tile t: row t*16 + c, slot g: byte = row * 64 + ((g ^ f((row >> 2) & 3)) << 4); (row >> 2) & 3 == (c >> 2) & 3
+  const int fr_sw = (g ^ ((0x1320 >> (((c >> 2) & 3) * 4)) & 3)) << 4;
+  const int a_off = (wm * (BM / 4) + c) * 64 + fr_sw;
+  const int w_off = (BM + wn * (BN / 4) + c) * 64 + fr_sw;
+  // valid MFMA row tiles of this wave (ragged last row tile)
+  const int mv = max(0, min(TM, (M - (m0 + wm * (BM / 4)) + 15) >> 4));
+
+#pragma unroll
+  for (int t = 0; t < D - 1; ++t) issue(t);
+  for (int kt = 0; kt < nk; ++kt) {
+    p8_wait_vmcnt<(D - 2) * CPW>();             // this wave's part of stage kt has landed
+    __builtin_amdgcn_s_barrier();               // ... everybody's; and everybody finished reading stage kt-1 (refilled now)
+    issue(kt + D - 1);
+    const unsigned char* st = smem + (kt % D) * STAGE;
+    bf16x8 af[TM], wf[TN];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) af[j] = *reinterpret_cast<const bf16x8*>(st + a_off + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + w_off + i * 16 * 64);
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+      if (j < mv) {                              // wave-uniform: a ragged last row tile computes only the MFMA tiles that hold a valid row
+#pragma unroll
+        for (int i = 0; i < TN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+      }
+  }
+  p8_wait_vmcnt<0>();
+
+  const float gs = (epi == P8_EPI_RESADD_F32 && gate != nullptr) ? tanhf(*gate) : 1.f;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = n0 + wn * (BN / 4) + i * 16 + g * 4;
+    if (n >= N) continue;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (bias != nullptr) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+      b0 = bv.x; b1 = bv.y; b2 = bv.z; b3 = bv.w;
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm * (BM / 4) + j * 16 + c;
+      if (m >= M) continue;
+      float v0 = acc[i][j][0] + b0, v1 = acc[i][j][1] + b1, v2 = acc[i][j][2] + b2, v3 = acc[i][j][3] + b3;
+      const long off = (long)blockIdx.z * strideC + (long)m * ldc + n;
+      if (epi == P8_EPI_RESADD_F32) {
+        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + off);
+        float4 r = *p;
+        r.x += gs * v0; r.y += gs * v1; r.z += gs * v2; r.w += gs * v3;
+        *p = r;
+      } else if (epi == P8_EPI_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + off) = float4{v0, v1, v2, v3};
+      } else {
+        if (epi == P8_EPI_QGELU_BF16) {
+          v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3);
+        } else if (epi == P8_EPI_GELU_BF16) {
+          v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + off) = uint2{pack2bf(v0, v1), pack2bf(v2, v3)};
+      }
+    }
+  }
+}
+
+// One image per row tile: `tile_rows` (257) valid rows per tile, computed as 17 MFMA row tiles; BN = 256 columns; 16 waves as 4 x 4 with
+// row tiles 5 | 4 | 4 | 4 per wave row (one wave of every row on each SIMD) and 64 columns per wave column.  A stage is 17 A chunks (16
+// rows x 64 B) + 16 W chunks: wave w issues A chunk w and W chunk w, wave 0 also A chunk 16 - its loop is instantiated with its own
+// counted vmcnt (3 DMAs per stage instead of 2).
+template <int D>
+__global__ __launch_bounds__(1024) void gemm_ring272_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
+                                                             const bf16_t* __restrict__ W, int ldw, long strideW,
+                                                             const float* __restrict__ bias, void* __restrict__ Cv, int ldc,
+                                                             long strideC, int M, int N, int K, int epi, int tile_rows,
+                                                             const float* __restrict__ gate, const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
+  constexpr int TN = 4, TMX = 5;
+  constexpr int A_BYTES = 17 * 1024, STAGE = 33 * 1024;
+  static_assert(D * STAGE <= 160 * 1024 && (D - 2) * 3 <= 63, "LDS / vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int c = lane & 15, g = lane >> 4;
+  const int t0 = wm == 0 ? 0 : 1 + 4 * wm;                   // first MFMA row tile of this wave: 0, 5, 9, 13
+  const int tm = wm == 0 ? 5 : 4;
+
+  // contiguous run of tiles (column index fastest) per XCD: the workgroups of an XCD share few A row tiles in its L2
+  const int tiles_n = N >> 8;
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int xq = nb >> 3, xr = nb & 7, xcd = bid & 7;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  const int m0 = (tile / tiles_n) * tile_rows, n0 = (tile % tiles_n) << 8;
+  const int rows_valid = min(tile_rows, M - m0);
+  A += (long)blockIdx.z * strideA;
+  W += (long)blockIdx.z * strideW;
+
+  const int lr = lane >> 2;
+  const int ls = ((lane & 3) ^ ((0x1320 >> (((lr >> 2) & 3) * 4)) & 3)) * 8;
+  const bf16_t* spa = A + (long)min(m0 + wave * 16 + lr, M - 1) * lda + ls;
+  const bf16_t* spw = W + (long)min(n0 + wave * 16 + lr, N - 1) * ldw + ls;
+  const bf16_t* spx = A + (long)min(m0 + 256 + lr, M - 1) * lda + ls;      // A chunk 16 (wave 0 only)
+  const int nk = K >> 5;
+
+  f32x4 acc[TN][TMX];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TMX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr_sw = (g ^ ((0x1320 >> (((c >> 2) & 3) * 4)) & 3)) << 4;
+  const int a_off = (t0 * 16 + c) * 64 + fr_sw;
+  const int w_off = A_BYTES + (wn * 64 + c) * 64 + fr_sw;
+
+  auto run = [&](auto cpw_tag) {
+    constexpr int CPW = decltype(cpw_tag)::value;
+    auto issue = [&](int t) {
+      const int k0 = min(t, nk - 1) << 5;
+      unsigned char* st = smem + (t % D) * STAGE;
+      __builtin_amdgcn_global_load_lds((p8_gptr_t*)(spa + k0), (p8_lptr_t*)(st + wave * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((p8_gptr_t*)(spw + k0), (p8_lptr_t*)(st + A_BYTES + wave * 1024), 16, 0, 0);
+      if (CPW == 3) __builtin_amdgcn_global_load_lds((p8_gptr_t*)(spx + k0), (p8_lptr_t*)(st + 16 * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < D - 1; ++t) issue(t);
+    for (int kt = 0; kt < nk; ++kt) {
+      p8_wait_vmcnt<(D - 2) * CPW>();
+      __builtin_amdgcn_s_barrier();
+      issue(kt + D - 1);
+      const unsigned char* st = smem + (kt % D) * STAGE;
+      bf16x8 af[TMX];
+#pragma unroll
+      for (int j = 0; j < TMX; ++j)
+        if (j < tm) af[j] = *reinterpret_cast<const bf16x8*>(st + a_off + j * 16 * 64);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(st + w_off + i * 16 * 64);
+#pragma unroll
+        for (int j = 0; j < TMX; ++j)
+          if (j < tm) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    p8_wait_vmcnt<0>();
+  };
+  if (wave == 0) run(std::integral_constant<int, 3>{});
+  else run(std::integral_constant<int, 2>{});
+
+  const float gs = (epi == P8_EPI_RESADD_F32 && gate != nullptr) ? tanhf(*gate) : 1.f;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = n0 + wn * 64 + i * 16 + g * 4;
+    if (n >= N) continue;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (bias != nullptr) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+      b0 = bv.x; b1 = bv.y; b2 = bv.z; b3 = bv.w;
+    }
+#pragma unroll
+    for (int j = 0; j < TMX; ++j) {
+      const int r = (t0 + j) * 16 + c;                      // row inside the tile: rows >= rows_valid belong to the next tile / nobody
+      if (j >= tm || r >= rows_valid) continue;
+      const int m = m0 + r;
+      float v0 = acc[i][j][0] + b0, v1 = acc[i][j][1] + b1, v2 = acc[i][j][2] + b2, v3 = acc[i][j][3] + b3;
+      const long off = (long)blockIdx.z * strideC + (long)m * ldc + n;
+      if (epi == P8_EPI_RESADD_F32) {
+        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + off);
+        float4 rr = *p;
+        rr.x += gs * v0; rr.y += gs * v1; rr.z += gs * v2; rr.w += gs * v3;
+        *p = rr;
+      } else if (epi == P8_EPI_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + off) = float4{v0, v1, v2, v3};
+      } else {
+        if (epi == P8_EPI_QGELU_BF16) {
+          v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3);
+        } else if (epi == P8_EPI_GELU_BF16) {
+          v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + off) = uint2{pack2bf(v0, v1), pack2bf(v2, v3)};
+      }
+    }
+  }
+}
+
+template <int D>
+static int launch_ring272(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
+                          int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl,
+                          hipStream_t st) {
+  if ((N & 255) || (K & 31) || M <= 0 || batch <= 0) return DEER_ERR_SHAPE;
+  const int tile_rows = (M % 257 == 0) ? 257 : 272;         // M = 257 n (n camera frames): one frame per row tile
+  constexpr int smem_bytes = D * 33 * 1024;
+  static bool attr_set = false;
+  auto kern = &gemm_ring272_kernel<D>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
+      return DEER_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int tiles = ((M + tile_rows - 1) / tile_rows) * (N >> 8);
+  hipLaunchKernelGGL(kern, dim3(tiles, 1, batch), dim3(1024), smem_bytes, st, A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N,
+                     K, epi, tile_rows, gate, ctl);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+template <int BM, int BN, int D>
+static int launch_ring32(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
+                         int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl,
+                         hipStream_t st) {
+  if ((N & 15) || (K & 31) || M <= 0 || batch <= 0) return DEER_ERR_SHAPE;
+  constexpr int smem_bytes = D * (BM + BN) * 64;
+  static bool attr_set = false;
+  auto kern = &gemm_ring32_kernel<BM, BN, D>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
+      return DEER_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles, 1, batch), dim3(1024), smem_bytes, st, A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N,
+                     K, epi, gate, ctl);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// variant: 0 = 256x256 / 5 stages (160 KB), 1 = 256x256 / 4 stages, 2 = 128x128 / 8 stages (128 KB), 3 = 256x256 / 2 stages,
+//          4 = 256x256 / 3 stages, 5 = 128x128 / 5 stages (80 KB: two workgroups per CU), 6 / 7 = 257(272)x256 / 3 / 4 stages
+int deer_launch_gemm_ring32(int variant, const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias,
+                            void* C, int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl,
+                            hipStream_t st) {
+#define P8_ARGS A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, batch, epi, gate, ctl, st
+  switch (variant) {
+    case 0: return launch_ring32<256, 256, 5>(P8_ARGS);
+    case 1: return launch_ring32<256, 256, 4>(P8_ARGS);
+    case 2: return launch_ring32<128, 128, 8>(P8_ARGS);
+    case 3: return launch_ring32<256, 256, 2>(P8_ARGS);
+    case 4: return launch_ring32<256, 256, 3>(P8_ARGS);
+    case 5: return launch_ring32<128, 128, 5>(P8_ARGS);
+    case 6: return launch_ring272<3>(P8_ARGS);              // one camera frame (257 rows) per row tile, 99 KB ring
+    case 7: return launch_ring272<4>(P8_ARGS);              // the same, 132 KB ring
+    default: return DEER_ERR_SHAPE;
+  }
+#undef P8_ARGS
+}

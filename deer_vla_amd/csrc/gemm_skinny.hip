@@ -318,6 +318,23 @@ extern "C" int deer_gemm_skinny_hl(const void* Ahi, const void* Alo, int lda, co
     }                                                                                                                        \
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, ah, al, lda, wp, part, M, N, K, KR, ctl, flags);                     \
   } break
+  if (mt == 4 && (flags >> 8)) {                        // experiment: ring depth sweep at 4 row tiles (32 KB stages)
+    const int dsel = flags >> 8;
+#define DEER_SKHL_DEPTH(D_)                                                                                                  \
+    if (dsel == D_) {                                                                                                        \
+      constexpr int smem = D_ * (4 * 4 + 16) * 1024;                                                                         \
+      auto kern = &gemm_skinny_hl_kernel<4, D_>;                                                                             \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=     \
+          hipSuccess) return DEER_ERR_LAUNCH;                                                                                \
+      hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, ah, al, lda, wp, part, M, N, K, KR, ctl, flags & 255);             \
+      DEER_LAUNCH_CHECK();                                                                                                   \
+      return DEER_OK;                                                                                                        \
+    }
+    DEER_SKHL_DEPTH(2)
+    DEER_SKHL_DEPTH(3)
+    DEER_SKHL_DEPTH(5)
+#undef DEER_SKHL_DEPTH
+  }
   switch (mt) {
     DEER_SKHL_CASE(1, 4);
     DEER_SKHL_CASE(2, 4);

@@ -371,6 +371,11 @@ static int launch_tiled(const bf16_t* A, int lda, long strideA, const bf16_t* W,
   return DEER_OK;
 }
 
+// csrc/gemm_bigm.hip
+int deer_launch_gemm_ring32(int variant, const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias,
+                            void* C, int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl,
+                            hipStream_t st);
+
 // tile: 0 = auto; simple register-staged kernels (any K % 8 == 0): 1 = 64x64, 2 = 64x128, 3 = 128x128;
 //       LDS-ring DMA kernels (K % 64 == 0): 4 = 64x64 / 8 waves / 4 stages, 5 = 128x64 / 8 waves / 3 stages,
 //       6 = 64x64 / 16 waves / 6 stages, 7 = 128x128 / 16 waves / 3 stages, 8 = 64x128 / 8 waves / 3 stages,
@@ -457,6 +462,8 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     case 43: return launch_ring<128, 192, 2, 4, 2>(DEER_ARGS);       // 8 waves (64x48), 80 KB
     case 45: return launch_ring<128, 192, 4, 2, 2>(DEER_ARGS);       // 8 waves (32x96), 80 KB
     case 46: return launch_ring<96, 128, 2, 2, 3>(DEER_ARGS);        // 4 waves (48x64), 84 KB
+    case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58:            // 16 waves, 32-column K-steps, deep ring (csrc/gemm_bigm.hip)
+      return deer_launch_gemm_ring32(tile - 51, DEER_ARGS);
     case 26: return launch_ring<64, 64, 2, 4, 4, 0, 1, 1>(DEER_ARGS);    // register-pipelined K loop (fragments of k+1 read under the MFMAs of k)
     case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)
     case 34: return launch_ring<64, 64, 2, 4, 4, 2>(DEER_ARGS);
