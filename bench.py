@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--no-two-groups", action="store_true", help="skip the leg with several env batches in flight per GPU")
     ap.add_argument("--batched-groups", type=int, default=4,
                     help="env batches of --batched-envs environments in flight per GPU in the `batched_groups` leg (own stream and host thread each)")
+    ap.add_argument("--surface-steps", type=int, default=200,
+                    help="steps of the `surface` leg (ModelWrapper.step on raw uint8 frames, GPU preprocessing, numpy action); 0 disables")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--full-depth-only", type=int, default=0, metavar="K",
@@ -76,11 +78,12 @@ def parse():
 # kernel class (C-ABI entry point) -> which roofline bounds it
 SAME_KERNEL = {"deer_gemm_bf16_nt_splitk": "deer_gemm_bf16_nt", "deer_gemm_bf16_nt_wbatch": "deer_gemm_bf16_nt",
                "deer_attn_mfma_hd64_2seg": "deer_attn_mfma_hd64", "deer_layernorm_rows_multi": "deer_layernorm_rows"}
-KERNEL_BOUND = {"deer_gemm_bf16_nt": "mfma", "deer_attn_mfma_hd64": "mfma", "deer_gemm_skinny": "hbm", "deer_gemm_f32_nt": "mfma"}
+KERNEL_BOUND = {"deer_gemm_bf16_nt": "mfma", "deer_attn_mfma_hd64": "mfma", "deer_gemm_skinny": "hbm", "deer_gemm_skinny_hl": "hbm",
+                "deer_gemm_f32_nt": "mfma"}
 MFMA_PEAK_BY_CLASS = {"deer_gemm_f32_nt": 157.3}      # exact-f32 MFMA (v_mfma_f32_16x16x4_f32): 1/16 of the bf16 rate (MI355X_MICROARCH.md)
 
 
-def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
+def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6, traffic_key=None):
     """In-situ per-kernel timing with HIP events (on the launch stream) over full control steps of the SAME workload:
     every launch of every kernel class is bracketed by two events while the step runs eagerly behind a spin kernel
     (so the host is ahead of the GPU and brackets contain no host launch gaps).  The static full-depth schedule
@@ -159,7 +162,7 @@ def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6):
         achieved, peak, unit = d["flops"] / d["us"] / 1e6, MFMA_PEAK_BY_CLASS.get(dom, MFMA_PEAK_TF), "TFLOP/s"
     else:
         achieved, peak, unit = d["bytes"] / d["us"] / 1e3, HBM_PEAK_GBS, "GB/s"
-    traffic, traffic_src = pmc_traffic(dom)
+    traffic, traffic_src = pmc_traffic(dom, traffic_key)
     return {"kernel": dom, "bound": KERNEL_BOUND[dom], "achieved": round(achieved, 2), "peak": peak, "unit": unit,
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)",
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]),
@@ -204,7 +207,7 @@ def window_leg(eng, cfg, frames, ids, reps):
             for p in range(4)]
     ids_g = ids1.expand(G, -1).contiguous()
     w.configure_exit(eng.exit_ids, eng._max_layer_arg, 1)
-    r = measure_roofline(w, cfg, pool, ids_g)
+    r = measure_roofline(w, cfg, pool, ids_g, traffic_key=None)      # no PMC pass at the window's row counts: traffic null
     r.pop("schedule_note", None)
     return {"window_size": W, "frames_per_group": G, "rows": {"vit": 514 * G, "trunk": int(G * ids1.shape[1])}, "reps": reps, **out, "roofline": r,
             "note": "frames of a window are batch rows of the env-batch engine (same kernels, same arena); value generation = "
@@ -274,6 +277,101 @@ def two_groups_leg(cfg, rb, B, steps, burn_in, local_rank, stagger=True, G=4):
                     "releases the GIL): one batch's vision tower (MFMA-bound) overlaps another's trunk (HBM-bound)"}
 
 
+def surface_leg(cfg, eng, thr, frames, ids, steps, warmup=20):
+    """Steps/s through the DROP-IN SURFACE (a step = one ``ModelWrapper.step``, eval_utils.py:279-480): raw uint8 camera
+    frames (200x200 static, 84x84 gripper) -> GPU preprocessing (csrc/preprocess.hip) -> ``MPTFlamingo.forward`` with the native exit
+    controller -> float16 numpy action on the host, beside ``DeerEngine.step`` on the SAME frames preprocessed once (what `value` times).
+    The model object shares this engine's weight arena."""
+    import numpy as np
+    from deer_vla_amd import rollout as ro
+    from deer_vla_amd.action_head import DeterministicDecoder
+    from deer_vla_amd.engine import DeerEngine
+    from deer_vla_amd.factory import GpuImageProcessor, SyntheticTokenizer
+    from deer_vla_amd.flamingo_mpt import MPTFlamingo
+    from deer_vla_amd.value_net import ActionValueNet, ExitController
+    model = MPTFlamingo(cfg, None, window_size=cfg.window_size)
+    model._engine = DeerEngine(cfg, None, device=eng.dev, n_envs=1, weights_from=eng)
+    model.extra_exit = DeterministicDecoder(model._engine, cfg.window_size)
+    model.lm_head = model.extra_exit
+    vn = ActionValueNet(model.get_all_exit_idx(), None, cfg.exit_interval, cfg.window_size, "L2")
+    ctl = ExitController(vn, model.get_all_exit_idx(), max_layer=eng._max_layer_arg)
+    ctl._set_threshold_value(list(thr))
+    proc = GpuImageProcessor(cfg.image_size, device=eng.dev)
+    w = ro.ModelWrapper(model, SyntheticTokenizer(cfg), proc, torch.bfloat16, early_exit=True, exit_controller=ctl)
+    rng = np.random.default_rng(5)
+    obs = [{"rgb_obs": {"rgb_static": rng.integers(0, 255, (200, 200, 3), dtype=np.uint8),
+                        "rgb_gripper": rng.integers(0, 255, (84, 84, 3), dtype=np.uint8)}, "robot_obs": np.zeros(15, np.float32)} for _ in range(16)]
+    goal = "lift the red block from the sliding cabinet"
+    n = warmup + steps
+
+    def run_surface():
+        w.reset()
+        exits = 0
+        for i in range(n):
+            if i == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            ctl.set_timestep(i)
+            a = w.step(obs[i % len(obs)], goal)
+            if i >= warmup:
+                exits += w.current_exit_layer + 1
+        torch.cuda.synchronize()
+        assert a.shape == (7,) or a.shape == (1, 7)
+        return steps / (time.perf_counter() - t0), exits / steps
+
+    def run_engine():
+        e = model.engine
+        pre = [(proc(o["rgb_obs"]["rgb_static"]), proc(o["rgb_obs"]["rgb_gripper"])) for o in obs]      # preprocessed once, resident in HBM
+        ids_t, _ = ro.preprocess_text_calvin([goal], SyntheticTokenizer(cfg))
+        ids_t = ids_t.to(e.dev)
+        e.configure_exit(ctl.exit_id_list, eng._max_layer_arg, 1)
+        e.set_thresholds(list(thr))
+        e.reset()
+        e.cur_step = 0
+        exits = 0
+        for i in range(n):
+            if i == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            r = e.step(pre[i % len(pre)][0], pre[i % len(pre)][1], ids_t, None)
+            if i >= warmup:
+                exits += r["exit_layer"] + 1
+        torch.cuda.synchronize()
+        return steps / (time.perf_counter() - t0), exits / steps
+
+    def run_forward():
+        """MPTFlamingo.forward alone (native controller, host_outputs) on the frames preprocessed once"""
+        pre = [(proc(o["rgb_obs"]["rgb_static"]).unsqueeze(1).unsqueeze(1), proc(o["rgb_obs"]["rgb_gripper"]).unsqueeze(1).unsqueeze(1)) for o in obs]
+        ids_t, mask_t = ro.preprocess_text_calvin([goal], SyntheticTokenizer(cfg))
+        ids_t, mask_t = ids_t.to(eng.dev), mask_t.to(eng.dev)
+        model.clear_all_exit_memory()
+        exits = 0
+        for i in range(n):
+            if i == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            ctl.set_timestep(i)
+            o = model(vision_x=pre[i % len(pre)][0], lang_x=ids_t, attention_mask=mask_t, vision_gripper=pre[i % len(pre)][1],
+                      dynamic_early_exit=True, exit_controller=ctl)
+            if i >= warmup:
+                exits += o.exit_layer + 1
+        torch.cuda.synchronize()
+        return steps / (time.perf_counter() - t0), exits / steps
+
+    run_surface()                                                  # captures the graphs
+    v_s, x_s = run_surface()
+    v_f, x_f = run_forward()
+    v_e, x_e = run_engine()
+    return {"value": round(v_s, 2), "unit": "action-steps/s", "steps": steps, "avg_exit_layer": round(x_s, 3),
+            "forward_same_frames": {"value": round(v_f, 2), "avg_exit_layer": round(x_f, 3)},
+            "engine_step_same_frames": {"value": round(v_e, 2), "avg_exit_layer": round(x_e, 3)},
+            "forward_over_engine": round(v_f / v_e, 4), "surface_over_engine": round(v_s / v_e, 4),
+            "note": "ModelWrapper.step: raw uint8 frames -> deer_preprocess_frames (2 launches per camera) -> MPTFlamingo.forward "
+                    "(native ExitController, host_outputs) -> float16 numpy action; forward_same_frames = MPTFlamingo.forward alone and "
+                    "engine_step_same_frames = DeerEngine.step (the path `value` times) on the same frames preprocessed once; the "
+                    "surface's extra time is the per-step preprocessing (~60 us: two uploads + four launches) and the wrapper's host code"}
+
+
 def lib_hash():
     """sha256 (first 16 hex) of the HIP library the numbers were measured with"""
     import hashlib
@@ -282,23 +380,28 @@ def lib_hash():
         return hashlib.sha256(fh.read()).hexdigest()[:16]
 
 
-def pmc_traffic(kernel_class):
+def pmc_traffic(kernel_class, workload_key):
     """HBM-side bytes per launch of a kernel class from the committed rocprofv3 --pmc summary (FETCH_SIZE and WRITE_SIZE
-    are collected in separate passes by tools/profile_bench.sh over full-depth steps of this same workload; bench.py
-    cannot run PMC passes on itself).  The summary is stamped with the hash of the kernel SOURCES it was collected on
-    (csrc/*.hip, common.h): a stale stamp is reported, and the figure is then withheld (None)."""
+    are collected in separate passes by tools/profile_bench.sh over full-depth steps; bench.py cannot run PMC passes on
+    itself).  The summary is keyed by WORKLOAD ("<workload>/envs<B>": the launches of a class move different bytes at
+    another model size or row count) - a workload without its own pass gets None, never another shape's
+    figure - and stamped with the hash of the kernel SOURCES it was collected on (csrc/*.hip, common.h): a stale stamp
+    is reported, and the figure is then withheld (None)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
+    if not os.path.exists(path) or workload_key is None:
         return None, None
     with open(path) as fh:
         t = json.load(fh)
-    c = t.get("classes", {}).get(kernel_class)
+    wl = t.get("workloads", {}).get(workload_key)
+    if not wl:
+        return None, "no PMC pass of workload %s in profiles/pmc_traffic.json" % workload_key
+    c = wl.get("classes", {}).get(kernel_class)
     if not c:
         return None, None
-    stamp, now = t.get("kernel_source_hash"), kernel_source_hash()
+    stamp, now = wl.get("kernel_source_hash"), kernel_source_hash()
     if stamp != now:
         return None, "profiles/pmc_traffic.json is STALE (collected on kernel sources %s, now %s): re-run tools/profile_bench.sh" % (stamp, now)
-    return c["hbm_bytes_per_launch"], "profiles/pmc_traffic.json (%s)" % t.get("note", "")
+    return c["hbm_bytes_per_launch"], "profiles/pmc_traffic.json[%s] (%s)" % (workload_key, t.get("note", ""))
 
 
 def kernel_source_hash():
@@ -536,13 +639,18 @@ def main():
                                     "realised": [round(res["hist"][e] / tot_, 3) for e in xs_],
                                     "target_avg_layers": round(sum((e + 1) * p for e, p in zip(xs_, pk_)) / sum(pk_), 2)}
     if world > 1:   # lets the driver verify that RCCL really saw N ranks on N distinct devices
-        info = torch.tensor([rank, local_rank, torch.cuda.current_device()], dtype=torch.int64,
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        uuid = str(getattr(props, "uuid", "")) or str(getattr(props, "pci_bus_id", ""))
+        ub = uuid.encode()[:40].ljust(40, b" ")
+        info = torch.tensor([rank, local_rank, torch.cuda.current_device()] + list(ub), dtype=torch.int64,
                             device=eng.dev if dist.get_backend() == "nccl" else "cpu")
         allinfo = [torch.zeros_like(info) for _ in range(world)]
         dist.all_gather(allinfo, info)
         out["rccl_world"] = dist.get_world_size()
-        out["backend"] = dist.get_backend()
-        out["ranks"] = [{"rank": int(t[0]), "local_rank": int(t[1]), "device": int(t[2])} for t in allinfo]
+        out["backend"] = dist.get_backend()                  # the OBSERVED backend of the process group the reductions ran on
+        out["ranks"] = [{"rank": int(t[0]), "local_rank": int(t[1]), "device": int(t[2]),
+                         "device_uuid": bytes(int(x) for x in t[3:]).decode(errors="replace").strip()} for t in allinfo]
+        out["distinct_devices"] = len({r["device_uuid"] or r["device"] for r in out["ranks"]})
     # step latency at a KNOWN depth: static exit at every exit layer (median of --latency-reps steps, action read on the host)
     if args.latency_reps > 0 and B == 1 and rank == 0:
         frames_, ids_l = res["frames"], res["ids"]
@@ -597,12 +705,24 @@ def main():
         st = torch.tensor([dt], dtype=torch.float64, device=eng.dev)
         if dist is not None:
             dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        out["value_at_target_depth"] = {
+            "value": round(world * len(sched) / float(st[0]), 2), "unit": "action-steps/s",
+            "avg_exit_layer": round(sum(e + 1 for e in sched) / len(sched), 3),
+            "target_avg_layers": round(float(torch.tensor([e + 1 for e in exits], dtype=torch.float64) @ (pk / pk.sum())), 2),
+            "note": "the figure to compare run to run: the scripted exit schedule below (exit ids drawn from the calibration target "
+                    "p_k ~ exit_ratio^k, E[layers] = 5.74 at 0.8) - `value`'s depth is whatever its timed window of the synthetic "
+                    "episode holds (`avg_exit_layer`, `exit_distribution`)"}
         out["scripted"] = {"value": round(world * len(sched) / float(st[0]), 2), "unit": "action-steps/s", "steps": len(sched),
                            "avg_exit_layer": round(sum(e + 1 for e in sched) / len(sched), 3),
                            "note": "static exit_id per step drawn from p_k ~ exit_ratio^k (seed 99); two-chain vision + one trunk "
                                    "graph per exit id, host reads the action after every step"}
+    if rank == 0 and world == 1 and B == 1 and args.surface_steps > 0 and args.precision == "bf16":
+        try:                                               # auxiliary single-rank leg: its failure must not cost the bench line
+            out["surface"] = surface_leg(cfg, eng, res["thr"], res["frames"], res["ids"], args.surface_steps)
+        except Exception as e:
+            out["surface"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and not args.no_roofline:
-        out["roofline"] = measure_roofline(eng, cfg, res["frames"], res["ids"])
+        out["roofline"] = measure_roofline(eng, cfg, res["frames"], res["ids"], traffic_key="%s/envs%d" % (args.workload, B))
     # ---- the same workload with one ENV BATCH per rank (north_star: "one env batch per rank"): every weight byte and
     #      every kernel boundary is shared by the environments of the batch.  Reported beside `value`, never as it. ----
     if args.batched_envs > 1 and B == 1:

@@ -49,6 +49,8 @@ SIGNATURES = {
     "deer_embed_tokens": [P, P, P, P, I, I, I, I, I, P],
     "deer_broadcast_rows": [P, P, L, I, P],
     "deer_head_pool": [P, P, I, I, I, I, P, P, I, I, P],
+    "deer_head_state_embed": [P, P, P, P, P, P, P, I, I, I, P],
+    "deer_head_pool_state": [P, P, I, I, I, I, P, P, P, I, I, P],
     "deer_head_lstm_layer": [P, L, I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, P, I, I, I, P],
     "deer_head_fc": [P, I, I, I, P, P, P, P, P, P, P, P, I, P, I, F, P, I, I, I, P],
     "deer_head_final": [P, I, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, I, I, P, F, I, P],
@@ -77,6 +79,7 @@ SIGNATURES = {
     "deer_begin_step": [P, P, P],
     "deer_vision": [P, I, I, I, P],
     "deer_media_kv": [P, P],
+    "deer_head_state": [P, P],
     "deer_llm_embed": [P, I, P],
     "deer_llm_layer": [P, I, I, I, I, I, I, P],
     "deer_head_eval": [P, I, I, I, I, I, I, I, I, P, I, P],
@@ -122,7 +125,7 @@ class DeerConfigC(ctypes.Structure):
         "cross_attn_every_n_layers", "xattn_heads", "xattn_dim_head", "xattn_ff_mult", "media_token_id",
         "mpt7b_names", "exit_interval",
         "head_hidden", "lstm_num_layers", "lstm_layernorm", "mlp_layernorm", "mlp_num_hidden_layers", "pooling_avg",
-        "n_envs", "max_text_len", "n_chains", "precision")]
+        "n_envs", "max_text_len", "n_chains", "precision", "use_state", "sep_resampler")]
 
 
 PRECISIONS = {"bf16": 0, "fp32": 1}
@@ -145,6 +148,8 @@ def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0, precisio
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
     c.precision = PRECISIONS[precision]
+    c.use_state = 1 if getattr(cfg, "use_state", False) else 0
+    c.sep_resampler = 1 if getattr(cfg, "sep_resampler", False) else 0
     return c
 
 

@@ -96,7 +96,8 @@ def config_from_args(name_args: Dict, ckpt_args: Dict, trunk: Optional[DeerConfi
     kw = dict(exit_interval=ckpt_args["exit_interval"], lstm_layernorm=bool(ckpt_args["lstm_layernorm"]),
               mlp_layernorm=bool(ckpt_args["mlp_layernorm"]), lstm_num_layers=ckpt_args["lstm_num_layers"],
               mlp_num_hidden_layers=ckpt_args["mlp_num_hidden_layers"], pooling=ckpt_args["pooling"],
-              window_size=name_args["window_size"])
+              window_size=name_args["window_size"],
+              use_state=bool(name_args.get("use_state", False)), sep_resampler=bool(name_args.get("sep_resampler", False)))
     ee = min(ckpt_args["early_exit_layer"], ckpt_args["max_layer"])
     if trunk is not None:
         from dataclasses import replace

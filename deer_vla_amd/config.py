@@ -54,6 +54,12 @@ class DeerConfig:
     mlp_num_hidden_layers: int = 2
     pooling: str = "max"
     window_size: int = 12
+    # ---- variants the reference parses from checkpoint names (eval_calvin.py:355-377); off in the released DeeR checkpoints --------
+    use_state: bool = False         # DeterministicDecoder adds an embedding of the robot state to the pooled feature (action_head.py:524-536)
+    sep_resampler: bool = False     # the gripper camera has its own PerceiverResampler weights (flamingo_mpt.py:132-134,656-659)
+
+    supports_use_state = True       # read by factory.create_model_and_transforms (keywords without this marker raise)
+    supports_sep_resampler = True
 
     # ------------------------------------------------------------------ derived
     @property

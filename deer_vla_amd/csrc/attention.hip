@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
                                                         float scale, int q_slabs, long q_slab_stride,
                                                         const int* __restrict__ text_time, int n_per_media, int out_is_f32,
                                                         const int* ctl, const bf16_t* __restrict__ K2,
-                                                        const bf16_t* __restrict__ V2, int kv1, int ld2, long bstride2) {
+                                                        const bf16_t* __restrict__ V2, int kv1, int ld2, long bstride2, int qtpw) {
   DEER_RETURN_IF_EXITED(ctl);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int kvpad = (kv_len + 31) & ~31;
@@ -50,29 +50,37 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
   const bf16_t* Kb2 = K2 != nullptr ? K2 + b * bstride2 + h * AM_HD : nullptr;
   const bf16_t* Vb2 = V2 != nullptr ? V2 + b * bstride2 + h * AM_HD : nullptr;
 
-  const int q0 = blockIdx.x * (16 * NWAVE) + wave * 16;
+  // qtpw query tiles per wave (wave w: tiles w, w + NWAVE, ...): with qtpw = ceil(q tiles / NWAVE) ONE workgroup serves a whole
+  // (head, image) and the head's K/V are staged once instead of once per 64-128 queries (env batches: 16 frames x 16 heads = 256
+  // workgroups of 8 waves; r03: 23.5 -> see profiles/r03_*classes_env_batch_8*)
+  int q0 = blockIdx.x * (16 * NWAVE * qtpw) + wave * 16;
 
   // Q fragments first (MFMA "B" operand: B[k = d][n = query]; rows >= q_len are zero): their global-load latency
   // overlaps the K/V staging below instead of following the barrier
   bf16x8 qf[2];
+  int tt_q = 1, klo = 0, khi = 0;
+  auto load_q = [&]() {
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    uint4 v = uint4{0, 0, 0, 0};
-    if (q0 + c < q_len) {
-      if (XATTN) {                                           // f32 split-K partials -> sum -> bf16
-        const float* qp = reinterpret_cast<const float*>(Qv) + b * q_bstride + h * AM_HD + (long)(q0 + c) * ldq + ks * 32 + g * 8;
-        const float4 a0 = slab_sum4(qp, q_slabs, q_slab_stride), a1 = slab_sum4(qp + 4, q_slabs, q_slab_stride);
-        v = uint4{pack2bf(a0.x, a0.y), pack2bf(a0.z, a0.w), pack2bf(a1.x, a1.y), pack2bf(a1.z, a1.w)};
-      } else {
-        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(Qv) + b * q_bstride + h * AM_HD +
-                                            (long)(q0 + c) * ldq + ks * 32 + g * 8);
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 v = uint4{0, 0, 0, 0};
+      if (q0 + c < q_len) {
+        if (XATTN) {                                           // f32 split-K partials -> sum -> bf16
+          const float* qp = reinterpret_cast<const float*>(Qv) + b * q_bstride + h * AM_HD + (long)(q0 + c) * ldq + ks * 32 + g * 8;
+          const float4 a0 = slab_sum4(qp, q_slabs, q_slab_stride), a1 = slab_sum4(qp + 4, q_slabs, q_slab_stride);
+          v = uint4{pack2bf(a0.x, a0.y), pack2bf(a0.z, a0.w), pack2bf(a1.x, a1.y), pack2bf(a1.z, a1.w)};
+        } else {
+          v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(Qv) + b * q_bstride + h * AM_HD +
+                                              (long)(q0 + c) * ldq + ks * 32 + g * 8);
+        }
       }
+      qf[ks] = __builtin_bit_cast(bf16x8, v);
     }
-    qf[ks] = __builtin_bit_cast(bf16x8, v);
-  }
-  // media-time mask (x-attn only): key j is visible iff text_time[q] == j / n_per_media + 1, i.e. j in [klo, khi)
-  const int tt_q = (XATTN && q0 + c < q_len) ? text_time[b * q_len + q0 + c] : 1;
-  const int klo = (tt_q - 1) * n_per_media, khi = tt_q * n_per_media;
+    // media-time mask (x-attn only): key j is visible iff text_time[q] == j / n_per_media + 1, i.e. j in [klo, khi)
+    tt_q = (XATTN && q0 + c < q_len) ? text_time[b * q_len + q0 + c] : 1;
+    klo = (tt_q - 1) * n_per_media;
+    khi = tt_q * n_per_media;
+  };
+  load_q();
 
   // ---- stage K (row-major) and V (transposed) for this head; rows >= kv_len are zero ----
   // two key rows per thread: K rows are copied as they are, V is transposed with 32-bit LDS stores that carry the
@@ -103,8 +111,10 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
   }
   __syncthreads();
 
-  if (q0 >= q_len) return;
   const int nt = kvpad >> 4;
+  for (int it = 0; it < qtpw; ++it, q0 += 16 * NWAVE) {
+  if (q0 >= q_len) break;
+  if (it > 0) load_q();
 
   // ---- S^T tiles: s[t][r] = S[q = c][key = t*16 + g*4 + r] ----
   f32x4 s[AM_MAXT];
@@ -189,6 +199,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
             uint2{pack2bf(o[dt][0] * inv, o[dt][1] * inv), pack2bf(o[dt][2] * inv, o[dt][3] * inv)};
     }
   }
+  }   // query tiles of this wave
 }
 
 static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O, int batch, int heads, int q_len, int kv_len,
@@ -223,9 +234,15 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
   // queries and is pulled by twice as many waves (the per-CU fill rate grows with the number of waves issuing loads)
   static const bool wide_ok = [] { const char* e = getenv("DEER_ATTN_WIDE"); return e == nullptr || e[0] != '0'; }();
   const bool wide = wide_ok && q_slabs == 0 && q_len > 64;
-  dim3 grid((q_len + (wide ? 127 : 63)) / (wide ? 128 : 64), heads, batch);
+  // env batches (>= 128 (head, image) pairs: the chip is full with ONE workgroup per pair): every wave walks several query tiles
+  // and the head's K/V are staged once; at one environment (16-32 pairs) the queries stay spread over more workgroups
+  static const bool loop_ok = [] { const char* e = getenv("DEER_ATTN_LOOP"); return e == nullptr || e[0] != '0'; }();
+  const int per_wg = wide ? 128 : 64;
+  int qtpw = 1;
+  if (loop_ok && wide && (long)heads * batch >= 128) qtpw = (q_len + per_wg - 1) / per_wg;
+  dim3 grid((q_len + per_wg * qtpw - 1) / (per_wg * qtpw), heads, batch);
 #define DEER_ATTN_ARGS Q, kp, vp, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride, scale, q_slabs, \
-                       q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2
+                       q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2, qtpw
   if (q_slabs > 0)
     hipLaunchKernelGGL((attn_mfma_kernel<true, 4>), grid, dim3(256), smem, st, DEER_ATTN_ARGS);
   else if (wide)

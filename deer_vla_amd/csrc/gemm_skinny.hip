@@ -173,6 +173,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
 //  * a workgroup is 8 waves = 128 columns and walks a K range of K/S columns: S = 256 * 128 / N slabs instead of 256 * 256 / N
 //    (4 instead of 8 for the 8192-wide up-projections, 16 instead of 32 for the down-projections).
 // Algorithmic bytes per launch = 2*N*K (weights once); L2->LDS activation traffic = (N/128) * 128 rows * K * 4 B.
+// Measured r03 at 112 rows, 8192x2048 (profiles/r03_b_skinny_hl_*.txt; ablations by temporary kernel flags, since removed): 17.7 us
+// against 22.6; epilogue (S = 4 slabs, 14.7 MB of stores) 3.5 us; the K loop 1.5 us per 48 KB stage whatever the ring depth
+// (2..5 stages: rate-bound at ~35 GB/s of LDS-DMA fill per CU, not latency-bound), with either operand's DMAs removed still
+// 1.1 us per stage, with the MFMAs / fragment reads removed 1.2 us; K-blocked activation planes or kt-major packed weights
+// (channel spreading) change nothing.  S = 2 (fewer slabs, 16 stages) and S = 8 (more workgroups than CUs) both lose.
 static inline int skinny_mt(int M);
 typedef __attribute__((address_space(1))) const void sk_gptr_t;
 typedef __attribute__((address_space(3))) void sk_lptr_t;
@@ -185,7 +190,7 @@ __device__ __forceinline__ void sk_wait_vmcnt() {
 template <int MT, int D>
 __global__ __launch_bounds__(512) void gemm_skinny_hl_kernel(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo, int lda,
                                                             const bf16_t* __restrict__ Wp, float* __restrict__ part, int M, int N,
-                                                            int K, int KR, const int* ctl, int flags) {
+                                                            int K, int KR, const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
   constexpr int MTL = (MT + 1) & ~1;                  // row tiles LOADED per plane (even: every wave issues the same number of DMAs)
   constexpr int MPAD = MT * 16;
@@ -217,26 +222,20 @@ __global__ __launch_bounds__(512) void gemm_skinny_hl_kernel(const bf16_t* __res
       const int row = min(r8 * 8 + lr, M - 1);        // rows >= M repeat the last row (their outputs are zeroed in the epilogue)
       src[i] = (plane ? Alo : Ahi) + (long)row * lda + k_begin + ls;
       kstep[i] = 64;
-      if (flags & 1) { src[i] = (plane ? Alo : Ahi) + ((long)(k_begin >> 6) * 128 + row) * 64 + ls; kstep[i] = 128 * 64; }   // experiment: K-blocked planes
     } else {
       const int w = q - A_CH, ct = w >> 1, kt = w & 1;
       const int t16 = blockIdx.x * 8 + ct;
       const int tile = (t16 * 16 < N) ? t16 : 0;      // ragged N: stream tile 0, never stored
       src[i] = Wp + (((long)tile * ktiles + (k_begin >> 5) + kt) * 64 + lane) * 8;
       kstep[i] = 2 * 64 * 8;
-      if (flags & 2) { src[i] = Wp + ((((long)(k_begin >> 5) + kt) * (N >> 4) + tile) * 64 + lane) * 8; kstep[i] = 2 * (N >> 4) * 512; }   // experiment: kt-major weights
     }
   }
-  const int dbg = flags >> 4;
   auto issue = [&](int t) {
     const int tt = min(t, nk - 1);
     unsigned char* st = smem_raw + (t % D) * STAGE;
 #pragma unroll
-    for (int i = 0; i < CPW; ++i) {
-      const bool is_a = (wave + i * 8) < A_CH;
-      if ((dbg == 1 && is_a) || (dbg == 2 && !is_a)) continue;          // ablation (tools/bench_skinny_hl.py); vmcnt over-waits then
+    for (int i = 0; i < CPW; ++i)
       __builtin_amdgcn_global_load_lds((sk_gptr_t*)(src[i] + (long)tt * kstep[i]), (sk_lptr_t*)(st + (wave + i * 8) * 1024), 16, 0, 0);
-    }
   };
 
   f32x4 acc[MT];
@@ -246,17 +245,13 @@ __global__ __launch_bounds__(512) void gemm_skinny_hl_kernel(const bf16_t* __res
   const int sw0 = ((0 * 4 + g) ^ (c & 7)) << 4, sw1 = ((1 * 4 + g) ^ (c & 7)) << 4;
   const int w_off = A_BYTES + wave * 2048 + lane * 16;
 
-  const int nk_run = (dbg == 5) ? 0 : nk;             // ablation: epilogue only
-  if (dbg != 5) {
 #pragma unroll
-    for (int t = 0; t < D - 1; ++t) issue(t);
-  }
-  for (int kt = 0; kt < nk_run; ++kt) {
+  for (int t = 0; t < D - 1; ++t) issue(t);
+  for (int kt = 0; kt < nk; ++kt) {
     sk_wait_vmcnt<(D - 2) * CPW>();                   // this wave's part of stage kt has landed
     __builtin_amdgcn_s_barrier();                     // ... everybody's; and everybody finished reading stage kt-1 (refilled now)
     issue(kt + D - 1);
     const unsigned char* st = smem_raw + (kt % D) * STAGE;
-    if (dbg == 3) continue;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int sw = kk ? sw1 : sw0;
@@ -272,7 +267,6 @@ __global__ __launch_bounds__(512) void gemm_skinny_hl_kernel(const bf16_t* __res
   }
   sk_wait_vmcnt<0>();                                 // clamped tail loads must not land in LDS after the workgroup is gone
   if (!tile_ok) return;
-  if (dbg == 4) { if (acc[0][0] == 123.456f) part[0] = 1.f; return; }      // ablation: no epilogue stores
   float* dst = part + ((long)ks * MPAD) * N + tile_raw * 16 + g * 4;
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
@@ -298,8 +292,6 @@ extern "C" int deer_gemm_skinny_hl(const void* Ahi, const void* Alo, int lda, co
   if (Ahi == nullptr || Alo == nullptr || Wp == nullptr || part == nullptr) return DEER_ERR_SHAPE;
   const int KR = K / splitk;
   const int mt = skinny_mt(M);
-  const char* fe = getenv("DEER_SKHL_FLAGS");          // experiments only (tools/bench_skinny_hl.py)
-  const int flags = fe ? atoi(fe) : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((N + 127) / 128, splitk);
   const bf16_t* ah = reinterpret_cast<const bf16_t*>(Ahi);
@@ -316,25 +308,8 @@ extern "C" int deer_gemm_skinny_hl(const void* Ahi, const void* Alo, int lda, co
           hipSuccess) return DEER_ERR_LAUNCH;                                                                                \
       attr_set = true;                                                                                                       \
     }                                                                                                                        \
-    hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, ah, al, lda, wp, part, M, N, K, KR, ctl, flags);                     \
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, ah, al, lda, wp, part, M, N, K, KR, ctl);                            \
   } break
-  if (mt == 4 && (flags >> 8)) {                        // experiment: ring depth sweep at 4 row tiles (32 KB stages)
-    const int dsel = flags >> 8;
-#define DEER_SKHL_DEPTH(D_)                                                                                                  \
-    if (dsel == D_) {                                                                                                        \
-      constexpr int smem = D_ * (4 * 4 + 16) * 1024;                                                                         \
-      auto kern = &gemm_skinny_hl_kernel<4, D_>;                                                                             \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=     \
-          hipSuccess) return DEER_ERR_LAUNCH;                                                                                \
-      hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, ah, al, lda, wp, part, M, N, K, KR, ctl, flags & 255);             \
-      DEER_LAUNCH_CHECK();                                                                                                   \
-      return DEER_OK;                                                                                                        \
-    }
-    DEER_SKHL_DEPTH(2)
-    DEER_SKHL_DEPTH(3)
-    DEER_SKHL_DEPTH(5)
-#undef DEER_SKHL_DEPTH
-  }
   switch (mt) {
     DEER_SKHL_CASE(1, 4);
     DEER_SKHL_CASE(2, 4);

@@ -219,7 +219,7 @@ __device__ __forceinline__ void rows_to_lds(const float* __restrict__ src, long 
 // rows, so they are left out of the pool (max: skipped; avg: divided by the number of valid tokens).
 __global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict__ feats, float* __restrict__ pooled, int T, int d,
                                                         int avg, int B, const unsigned char* __restrict__ key_mask,
-                                                        const int* ctl, int kind, int layer) {
+                                                        const int* ctl, int kind, int layer, const float* __restrict__ add) {
   if (head_skip(ctl, kind, layer, B)) return;
   const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   if (i >= d) return;
@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict_
     ++n;
   }
   if (avg) a /= (float)max(n, 1);
+  if (add != nullptr) a += add[(long)b * d + i];          // use_state: the embedded robot state (action_head.py:536)
   pooled[(long)b * d + i] = a;
 }
 
@@ -241,7 +242,63 @@ extern "C" int deer_head_pool(const float* feats, float* pooled, int T, int d, i
                               const int* ctl, int kind, int layer, void* stream) {
   if (T <= 0 || d <= 0 || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(head_pool_kernel, dim3((d + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), feats, pooled, T, d,
-                     avg, B, key_mask, ctl, kind, layer);
+                     avg, B, key_mask, ctl, kind, layer, static_cast<const float*>(nullptr));
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// deer_head_pool with the robot-state embedding added to the pooled feature (DeterministicDecoder(use_state=True), action_head.py:524-536)
+extern "C" int deer_head_pool_state(const float* feats, float* pooled, int T, int d, int avg, int B, const unsigned char* key_mask,
+                                    const float* state_emb, const int* ctl, int kind, int layer, void* stream) {
+  if (T <= 0 || d <= 0 || B <= 0 || B > HB_MAX || state_emb == nullptr) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(head_pool_kernel, dim3((d + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), feats, pooled, T, d,
+                     avg, B, key_mask, ctl, kind, layer, state_emb);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// ---- robot-state embedding of DeterministicDecoder(use_state=True) (action_head.py:443-453,524-536) ------------------------------
+// state [B][8] f32 = (arm pose robot_obs[:6], gripper opening robot_obs[-1] in {-1, +1}, pad);
+// u = [relu(W_arm arm + b_arm) ; relu(E_grip[((g + 1) / 2) truncated])] (2d); out[b] = W_state u + b_state (d).  One environment per
+// blockIdx.y, 16 output rows per workgroup; u is rebuilt per workgroup in LDS (6 MACs per element).
+template <typename WT>
+__global__ __launch_bounds__(256) void head_state_embed_kernel(const float* __restrict__ state, const float* __restrict__ w_arm,
+                                                               const float* __restrict__ b_arm, const float* __restrict__ e_grip,
+                                                               const WT* __restrict__ w_state, const float* __restrict__ b_state,
+                                                               float* __restrict__ out, int d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // u[2d]
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* st = state + b * 8;
+  const int gi = min(1, max(0, (int)((st[6] + 1.0f) * 0.5f)));     // .long() truncates
+  for (int i = threadIdx.x; i < d; i += 256) {
+    float a = b_arm[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a += w_arm[i * 6 + k] * st[k];
+    lds[i] = fmaxf(a, 0.f);
+    lds[d + i] = fmaxf(e_grip[(long)gi * d + i], 0.f);
+  }
+  __syncthreads();
+  for (int r = 0; r < 4; ++r) {
+    const int n = blockIdx.x * 16 + wave * 4 + r;
+    if (n >= d) break;
+    float a = 0.f;
+    for (int k = lane * 8; k < 2 * d; k += 512) a += W8<WT>::dot(W8<WT>::load(w_state + (long)n * 2 * d + k), lds + k);
+    a = wave_sum(a);
+    if (lane == 0) out[(long)b * d + n] = a + b_state[n];
+  }
+}
+
+extern "C" int deer_head_state_embed(const float* state, const float* w_arm, const float* b_arm, const float* e_grip, const void* w_state,
+                                     const float* b_state, float* out, int d, int B, int w_is_f32, void* stream) {
+  if (d <= 0 || (d & 3) || B <= 0 || B > HB_MAX || 2 * d * 4 > 64 * 1024) return DEER_ERR_SHAPE;
+  dim3 grid((d + 15) / 16, B);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (w_is_f32)
+    hipLaunchKernelGGL(head_state_embed_kernel<float>, grid, dim3(256), 2 * d * 4, st, state, w_arm, b_arm, e_grip,
+                       reinterpret_cast<const float*>(w_state), b_state, out, d);
+  else
+    hipLaunchKernelGGL(head_state_embed_kernel<bf16_t>, grid, dim3(256), 2 * d * 4, st, state, w_arm, b_arm, e_grip,
+                       reinterpret_cast<const bf16_t*>(w_state), b_state, out, d);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

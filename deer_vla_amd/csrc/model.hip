@@ -102,6 +102,8 @@ struct Layout {
 
 struct VitLayerW { size_t ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr; };
 struct PercLayerW { size_t nlw, nlb, wqkv, wo, fnw, fnb, w1, w2; };
+// one PerceiverResampler weight set ("perceiver." for both cameras, or + "perceiver_gripper." when sep_resampler)
+struct PercSet { size_t latents, normw, normb, nm_w, nm_b, wkv_all; std::vector<PercLayerW> L; };
 struct XattnW { size_t nw, nb, wq, wo, ag, fg, fnw, fnb, w1, w2; int kv_index; };
 struct LlmLayerW {
   bool has_xa;
@@ -123,6 +125,8 @@ struct VisionWS {
   size_t im2col, patch_out, vx, v_ln, v_qkv, v_ao, v_h, v_slab, p_lat, p_mln, p_mkv, p_latln, p_qkv, p_ao, p_ln, p_h;
   size_t vis_x, vis_x_f32;                    // row ranges of the step's media-token buffers
   int vit_split[2], perc_split[2];
+  int cam = 0;                                // Perceiver weight set of this chain's frames (sep_resampler: 1 = gripper camera)
+  size_t out_bf = SIZE_MAX, out_f32 = SIZE_MAX;   // sep_resampler: contiguous media tokens of the chain, scattered into the env-major buffers
 };
 
 int pick_split(long M, long N, long K, int target_blocks = 320, int max_split = 8) {
@@ -152,8 +156,9 @@ struct deer_model {
   std::vector<std::string> slot_order;
   size_t conv, cls, pos, ln_pre_w, ln_pre_b;
   std::vector<VitLayerW> vit;
-  size_t latents, perc_normw, perc_normb, perc_nm_w, perc_nm_b, perc_wkv_all;
-  std::vector<PercLayerW> perc;
+  PercSet ps[2];                    // [camera]; ps[1] is only built with sep_resampler
+  size_t w_arm = SIZE_MAX, b_arm = SIZE_MAX, e_grip = SIZE_MAX, w_state = SIZE_MAX, b_state = SIZE_MAX;   // use_state head weights
+  size_t state_in = SIZE_MAX, state_emb = SIZE_MAX;
   size_t wte, wkv_all;
   std::vector<LlmLayerW> llm;
   std::vector<LstmW> lstm;
@@ -285,30 +290,34 @@ void build_arena(deer_model* m) {
   // ---- Perceiver: the media tokens are the same in every layer, so norm_media / to_kv of ALL layers are stacked (applied up
   // front by one LayerNorm pass + one batched GEMM); the latents are projected to q | k | v by [to_q ; to_kv] in one GEMM
   const int inner = m->p_inner, Lp = m->Lp;
-  m->latents = add_slot(m, "perceiver.latents", SK_F32, m->nl, W);
-  m->perc_normw = add_slot(m, "perceiver.norm.weight", SK_F32, 1, W);
-  m->perc_normb = add_slot(m, "perceiver.norm.bias", SK_F32, 1, W);
-  m->perc_nm_w = m->al.add((size_t)Lp * W * 4);
-  m->perc_nm_b = m->al.add((size_t)Lp * W * 4);
-  m->perc_wkv_all = m->al.add((size_t)Lp * 2 * inner * W * we);
-  m->perc.resize(Lp);
-  for (int l = 0; l < Lp; ++l) {
-    const std::string a = "perceiver.layers." + std::to_string(l) + ".0.", f = "perceiver.layers." + std::to_string(l) + ".1.";
-    PercLayerW& L = m->perc[l];
-    add_slot(m, a + "norm_media.weight", SK_F32, 1, W, true, -1, m->perc_nm_w + (size_t)l * W * 4);
-    add_slot(m, a + "norm_media.bias", SK_F32, 1, W, true, -1, m->perc_nm_b + (size_t)l * W * 4);
-    L.nlw = add_slot(m, a + "norm_latents.weight", SK_F32, 1, W);
-    L.nlb = add_slot(m, a + "norm_latents.bias", SK_F32, 1, W);
-    L.wqkv = m->al.add((size_t)3 * inner * W * we);
-    add_slot(m, a + "to_q.weight", GK, inner, W, true, -1, L.wqkv);
-    add_slot(m, a + "to_kv.weight", GK, 2 * inner, W, true, -1, L.wqkv + (size_t)inner * W * we);
-    m->slots[a + "to_kv.weight"].dst[1] = m->perc_wkv_all + (size_t)l * 2 * inner * W * we;
-    m->slots[a + "to_kv.weight"].dst2_pitch = W;
-    L.wo = add_slot(m, a + "to_out.weight", GK, W, inner);
-    L.fnw = add_slot(m, f + "0.weight", SK_F32, 1, W);
-    L.fnb = add_slot(m, f + "0.bias", SK_F32, 1, W);
-    L.w1 = add_slot(m, f + "1.weight", GK, (long)c.perc_ff_mult * W, W);
-    L.w2 = add_slot(m, f + "3.weight", GK, W, c.perc_ff_mult * W);
+  for (int cam = 0; cam < (c.sep_resampler ? 2 : 1); ++cam) {
+    const std::string pp = cam == 0 ? "perceiver." : "perceiver_gripper.";      // flamingo_mpt.py:132-134
+    PercSet& S = m->ps[cam];
+    S.latents = add_slot(m, pp + "latents", SK_F32, m->nl, W);
+    S.normw = add_slot(m, pp + "norm.weight", SK_F32, 1, W);
+    S.normb = add_slot(m, pp + "norm.bias", SK_F32, 1, W);
+    S.nm_w = m->al.add((size_t)Lp * W * 4);
+    S.nm_b = m->al.add((size_t)Lp * W * 4);
+    S.wkv_all = m->al.add((size_t)Lp * 2 * inner * W * we);
+    S.L.resize(Lp);
+    for (int l = 0; l < Lp; ++l) {
+      const std::string a = pp + "layers." + std::to_string(l) + ".0.", f = pp + "layers." + std::to_string(l) + ".1.";
+      PercLayerW& L = S.L[l];
+      add_slot(m, a + "norm_media.weight", SK_F32, 1, W, true, -1, S.nm_w + (size_t)l * W * 4);
+      add_slot(m, a + "norm_media.bias", SK_F32, 1, W, true, -1, S.nm_b + (size_t)l * W * 4);
+      L.nlw = add_slot(m, a + "norm_latents.weight", SK_F32, 1, W);
+      L.nlb = add_slot(m, a + "norm_latents.bias", SK_F32, 1, W);
+      L.wqkv = m->al.add((size_t)3 * inner * W * we);
+      add_slot(m, a + "to_q.weight", GK, inner, W, true, -1, L.wqkv);
+      add_slot(m, a + "to_kv.weight", GK, 2 * inner, W, true, -1, L.wqkv + (size_t)inner * W * we);
+      m->slots[a + "to_kv.weight"].dst[1] = S.wkv_all + (size_t)l * 2 * inner * W * we;
+      m->slots[a + "to_kv.weight"].dst2_pitch = W;
+      L.wo = add_slot(m, a + "to_out.weight", GK, W, inner);
+      L.fnw = add_slot(m, f + "0.weight", SK_F32, 1, W);
+      L.fnb = add_slot(m, f + "0.bias", SK_F32, 1, W);
+      L.w1 = add_slot(m, f + "1.weight", GK, (long)c.perc_ff_mult * W, W);
+      L.w2 = add_slot(m, f + "3.weight", GK, W, c.perc_ff_mult * W);
+    }
   }
   // ---- LLM: projections pre-packed in MFMA-fragment order; to_kv of all x-attn layers concatenated (media is layer-invariant)
   const int d = m->d, xin = m->xinner;
@@ -366,6 +375,13 @@ void build_arena(deer_model* m) {
   const std::string p = "extra_exit.";
   const int HK = c.precision ? SK_F32 : SK_BF16;      // head weights: bf16, or f32 for the fp32 arithmetic
   const int H = m->H;
+  if (c.use_state) {                                   // action_head.py:443-453
+    m->w_arm = add_slot(m, p + "embed_arm_state.0.weight", SK_F32, d, 6);
+    m->b_arm = add_slot(m, p + "embed_arm_state.0.bias", SK_F32, 1, d);
+    m->e_grip = add_slot(m, p + "embed_gripper_state.0.weight", SK_F32, 2, d);
+    m->w_state = add_slot(m, p + "embed_state.weight", HK, d, 2 * d);
+    m->b_state = add_slot(m, p + "embed_state.bias", SK_F32, 1, d);
+  }
   m->lstm.resize(m->Lh);
   int in_f = d;
   for (int l = 0; l < m->Lh; ++l) {
@@ -468,12 +484,19 @@ void build_workspace(deer_model* m) {
   int n_ch = c.n_chains > 0 ? c.n_chains : 2;
   if (const char* e = getenv("DEER_CHAINS")) n_ch = atoi(e);
   n_ch = std::max(1, std::min(N, n_ch));
+  if (c.sep_resampler) n_ch = 2;                       // camera-major frames: chain 0 = every env's rgb frame, chain 1 = the gripper frames
   const int per = (N + n_ch - 1) / n_ch;
   for (int ch = 0; ch < n_ch; ++ch) {
     const int lo = ch * per, hi = std::min(N, (ch + 1) * per);
     if (hi <= lo) break;
     m->chains.emplace_back();
-    build_vision_ws(m, m->chains.back(), hi - lo, lo, &m->vws);
+    VisionWS& cw = m->chains.back();
+    build_vision_ws(m, cw, hi - lo, lo, &m->vws);
+    if (c.sep_resampler) {
+      cw.cam = ch;
+      cw.out_bf = m->wl.add((size_t)(hi - lo) * nl * W * 2);
+      cw.out_f32 = m->wl.add((size_t)(hi - lo) * nl * W * 4);
+    }
   }
   m->kv_all = named(m, "kv_all", (size_t)N * nl * std::max(m->n_xattn, 1) * 2 * m->xinner * 2);
   if (c.precision) {   // f32 twins of the vision tower's activations and of the x-attn K/V (csrc/precise.hip)
@@ -522,6 +545,10 @@ void build_workspace(deer_model* m) {
   m->c_shadow = named(m, "c_shadow", st);
   for (int i = 0; i < m->n_fc; ++i) m->z_fc[i] = m->wl.add((size_t)B * 2 * m->fc_dims[i] * 4);
   m->pooled = named(m, "pooled", (size_t)B * d * 4);
+  if (c.use_state) {
+    m->state_in = named(m, "state_in", (size_t)B * 8 * 4);
+    m->state_emb = named(m, "state_emb", (size_t)B * d * 4);
+  }
   m->ctl = named(m, "ctl", (size_t)B * CTL_WORDS * 4);
   m->step_info = named(m, "step_info", 16);
   m->thresholds = named(m, "thresholds", 16 * 4);
@@ -588,8 +615,25 @@ int patch_embed(deer_model* m, const VisionWS& ws, void* st) {
   return ln_rows(m, m->Wk<float>(ws.vx), m->A<float>(m->vit[0].ln1w), m->A<float>(m->vit[0].ln1b), m->Wk<void>(ws.v_ln), R, W, st);
 }
 
+// sep_resampler: the chain's media tokens land in a contiguous staging buffer and are scattered into the env-major media buffers
+// (env b: [rgb latents ; gripper latents], flamingo_mpt.py:661)
+int scatter_media(deer_model* m, const VisionWS& ws, void* st) {
+  if (ws.out_bf == SIZE_MAX) return DEER_OK;
+  const size_t row_bf = (size_t)m->nl * m->W * 2, row_f = (size_t)m->nl * m->W * 4;
+  const int b0 = ws.first - ws.cam * m->B;              // first environment of this chain (camera-major frame order)
+  hipStream_t s = (hipStream_t)st;
+  if (hipMemcpy2DAsync(m->Wk<char>(m->vis_x) + ((size_t)b0 * 2 + ws.cam) * row_bf, 2 * row_bf, m->Wk<char>(ws.out_bf), row_bf, row_bf, ws.n,
+                       hipMemcpyDeviceToDevice, s) != hipSuccess) return DEER_ERR_LAUNCH;
+  if (hipMemcpy2DAsync(m->Wk<char>(m->vis_x_f32) + ((size_t)b0 * 2 + ws.cam) * row_f, 2 * row_f, m->Wk<char>(ws.out_f32), row_f, row_f, ws.n,
+                       hipMemcpyDeviceToDevice, s) != hipSuccess) return DEER_ERR_LAUNCH;
+  return DEER_OK;
+}
+
 int perceiver(deer_model* m, const VisionWS& ws, void* st) {
   const deer_config& c = m->c;
+  const PercSet& PS = m->ps[ws.cam];
+  void* out_bf = ws.out_bf != SIZE_MAX ? m->Wk<void>(ws.out_bf) : m->Wk<void>(ws.vis_x);
+  float* out_f32 = ws.out_f32 != SIZE_MAX ? m->Wk<float>(ws.out_f32) : m->Wk<float>(ws.vis_x_f32);
   const int P = m->P, W = m->W, tok = m->tok, nl = m->nl, inner = m->p_inner, Lp = m->Lp, N = ws.n;
   // Media side once for all layers: one LayerNorm pass with every layer's norm_media affine, one batched GEMM with every layer's
   // to_kv.  Per layer only the 64 latents move: q|k|v projection, attention over [media K/V ; latent K/V] (two segments,
@@ -597,26 +641,26 @@ int perceiver(deer_model* m, const VisionWS& ws, void* st) {
   // applies the NEXT LayerNorm.
   {
     Bracket b(m, "deer_broadcast_rows", 0, 0, st);
-    DEER_TRY(deer_broadcast_rows(m->A<float>(m->latents), m->Wk<float>(ws.p_lat), (long)nl * W, N, st));
+    DEER_TRY(deer_broadcast_rows(m->A<float>(PS.latents), m->Wk<float>(ws.p_lat), (long)nl * W, N, st));
   }
   const float* tokens = m->tokens_override ? m->tokens_override + (size_t)ws.first * P * W : m->Wk<float>(ws.vx) + W;   // skip the cls row
   const long tok_bstride = m->tokens_override ? (long)P * W : (long)tok * W;
   {
     Bracket b(m, "deer_layernorm_rows", 8.0 * N * P * W, (4.0 + 2.0 * Lp) * N * P * W, st);
-    DEER_TRY(deer_layernorm_rows_multi(tokens, W, tok_bstride, P, N, m->A<float>(m->perc_nm_w), m->A<float>(m->perc_nm_b), Lp, W,
+    DEER_TRY(deer_layernorm_rows_multi(tokens, W, tok_bstride, P, N, m->A<float>(PS.nm_w), m->A<float>(PS.nm_b), Lp, W,
                                        m->Wk<void>(ws.p_mln), (long)N * P * W, W, (long)P * W, W, kEps, st));
   }
   {
     Bracket b(m, "deer_gemm_bf16_nt", 2.0 * Lp * N * P * 2 * inner * W, 2.0 * Lp * ((double)N * P * W + 2.0 * inner * W + (double)N * P * 2 * inner), st);
-    DEER_TRY(deer_gemm_bf16_nt_wbatch(m->Wk<void>(ws.p_mln), W, (long)N * P * W, m->A<void>(m->perc_wkv_all), W, 2L * inner * W, nullptr,
+    DEER_TRY(deer_gemm_bf16_nt_wbatch(m->Wk<void>(ws.p_mln), W, (long)N * P * W, m->A<void>(PS.wkv_all), W, 2L * inner * W, nullptr,
                                       m->Wk<void>(ws.p_mkv), 2 * inner, (long)N * P * 2 * inner, N * P, 2 * inner, W, Lp, DEER_EPI_BF16, 0,
                                       nullptr, st));
   }
-  DEER_TRY(ln_rows(m, m->Wk<float>(ws.p_lat), m->A<float>(m->perc[0].nlw), m->A<float>(m->perc[0].nlb), m->Wk<void>(ws.p_latln), (long)N * nl, W, st));
+  DEER_TRY(ln_rows(m, m->Wk<float>(ws.p_lat), m->A<float>(PS.L[0].nlw), m->A<float>(PS.L[0].nlb), m->Wk<void>(ws.p_latln), (long)N * nl, W, st));
   const int Pa = ws.perc_split[0], Pf = ws.perc_split[1];
   char* qkv = m->Wk<char>(ws.p_qkv);
   for (int li = 0; li < Lp; ++li) {
-    const PercLayerW& L = m->perc[li];
+    const PercLayerW& L = PS.L[li];
     DEER_TRY(gemm(m, m->Wk<void>(ws.p_latln), m->A<void>(L.wqkv), qkv, (long)N * nl, 3 * inner, W, DEER_EPI_BF16, nullptr, st));
     const char* mkv = m->Wk<char>(ws.p_mkv) + (size_t)li * N * P * 2 * inner * 2;
     {
@@ -631,15 +675,15 @@ int perceiver(deer_model* m, const VisionWS& ws, void* st) {
     DEER_TRY(gemm(m, m->Wk<void>(ws.p_ln), m->A<void>(L.w1), m->Wk<void>(ws.p_h), (long)N * nl, (long)c.perc_ff_mult * W, W, DEER_EPI_GELU_BF16, nullptr, st));
     DEER_TRY(gemm_splitk(m, m->Wk<void>(ws.p_h), m->A<void>(L.w2), m->Wk<float>(ws.v_slab), (long)N * nl, W, (long)c.perc_ff_mult * W, Pf, st));
     if (li + 1 < Lp) {
-      const PercLayerW& nx = m->perc[li + 1];
+      const PercLayerW& nx = PS.L[li + 1];
       DEER_TRY(vresadd(m, m->Wk<float>(ws.p_lat), m->Wk<float>(ws.v_slab), Pf, (long)N * nl, W, nullptr, m->A<float>(nx.nlw), m->A<float>(nx.nlb),
                        m->Wk<void>(ws.p_latln), nullptr, st));
     } else {   // closing perceiver.norm -> media tokens (bf16 for the K/V GEMM, f32 kept)
-      DEER_TRY(vresadd(m, m->Wk<float>(ws.p_lat), m->Wk<float>(ws.v_slab), Pf, (long)N * nl, W, nullptr, m->A<float>(m->perc_normw),
-                       m->A<float>(m->perc_normb), m->Wk<void>(ws.vis_x), m->Wk<float>(ws.vis_x_f32), st));
+      DEER_TRY(vresadd(m, m->Wk<float>(ws.p_lat), m->Wk<float>(ws.v_slab), Pf, (long)N * nl, W, nullptr, m->A<float>(PS.normw),
+                       m->A<float>(PS.normb), out_bf, out_f32, st));
     }
   }
-  return DEER_OK;
+  return scatter_media(m, ws, st);
 }
 
 int vit_blocks(deer_model* m, const VisionWS& ws, int lo, int hi, void* st) {
@@ -716,11 +760,14 @@ int vit_blocks_f32(deer_model* m, const VisionWS& ws, int lo, int hi, void* st) 
 
 int perceiver_f32(deer_model* m, const VisionWS& ws, void* st) {
   const deer_config& c = m->c;
+  const PercSet& PS = m->ps[ws.cam];
+  void* out_bf = ws.out_bf != SIZE_MAX ? m->Wk<void>(ws.out_bf) : m->Wk<void>(ws.vis_x);
+  float* out_f32 = ws.out_f32 != SIZE_MAX ? m->Wk<float>(ws.out_f32) : m->Wk<float>(ws.vis_x_f32);
   const int P = m->P, W = m->W, tok = m->tok, nl = m->nl, inner = m->p_inner, Lp = m->Lp, N = ws.n;
   const long NL = (long)N * nl, NP = (long)N * P, ffw = (long)c.perc_ff_mult * W;
   {
     Bracket b(m, "deer_broadcast_rows", 0, 0, st);
-    DEER_TRY(deer_broadcast_rows(m->A<float>(m->latents), m->Wk<float>(ws.p_lat), (long)nl * W, N, st));
+    DEER_TRY(deer_broadcast_rows(m->A<float>(PS.latents), m->Wk<float>(ws.p_lat), (long)nl * W, N, st));
   }
   const float* tokens = m->tokens_override ? m->tokens_override + (size_t)ws.first * P * W : m->Wk<float>(ws.vx) + W;   // skip the cls row
   const long tok_bstride = m->tokens_override ? (long)P * W : (long)tok * W;
@@ -734,13 +781,13 @@ int perceiver_f32(deer_model* m, const VisionWS& ws, void* st) {
   float* ph = m->Wk<float>(m->hp.ph);
   const float scale = 1.0f / sqrtf((float)c.perc_dim_head);
   for (int li = 0; li < Lp; ++li) {
-    const PercLayerW& L = m->perc[li];
+    const PercLayerW& L = PS.L[li];
     {   // norm_media of this layer on the (layer-invariant) media tokens, then its to_kv (helpers.py:47-56)
       Bracket b(m, "deer_layernorm_rows", 8.0 * NP * W, 8.0 * NP * W, st);
-      DEER_TRY(deer_layernorm_rows(tokens, W, tok_bstride, P, N, m->A<float>(m->perc_nm_w) + (size_t)li * W, m->A<float>(m->perc_nm_b) + (size_t)li * W,
+      DEER_TRY(deer_layernorm_rows(tokens, W, tok_bstride, P, N, m->A<float>(PS.nm_w) + (size_t)li * W, m->A<float>(PS.nm_b) + (size_t)li * W,
                                    nullptr, mln, W, (long)P * W, W, kEps, st));
     }
-    DEER_TRY(gemmf(m, mln, W, m->A<float>(m->perc_wkv_all) + (size_t)li * 2 * inner * W, nullptr, mkv, 2 * inner, NP, 2 * inner, W, 0, st));
+    DEER_TRY(gemmf(m, mln, W, m->A<float>(PS.wkv_all) + (size_t)li * 2 * inner * W, nullptr, mkv, 2 * inner, NP, 2 * inner, W, 0, st));
     DEER_TRY(ln_rows_f32(m, lat, m->A<float>(L.nlw), m->A<float>(L.nlb), latln, NL, W, st));
     DEER_TRY(gemmf(m, latln, W, m->A<float>(L.wqkv), nullptr, pqkv, 3 * inner, NL, 3 * inner, W, 0, st));
     {
@@ -754,9 +801,11 @@ int perceiver_f32(deer_model* m, const VisionWS& ws, void* st) {
     DEER_TRY(gemmf(m, ph, ffw, m->A<float>(L.w2), nullptr, lat, W, NL, W, ffw, 3, st));
   }
   // closing perceiver.norm -> media tokens: f32 (this arithmetic) and bf16 (kept current for readers of "vis_x")
-  Bracket b(m, "deer_layernorm_rows", 8.0 * NL * W, 10.0 * NL * W, st);
-  return deer_layernorm_rows(lat, W, 0, (int)NL, 1, m->A<float>(m->perc_normw), m->A<float>(m->perc_normb), m->Wk<void>(ws.vis_x), m->Wk<float>(ws.vis_x_f32),
-                             W, 0, W, kEps, st);
+  {
+    Bracket b(m, "deer_layernorm_rows", 8.0 * NL * W, 10.0 * NL * W, st);
+    DEER_TRY(deer_layernorm_rows(lat, W, 0, (int)NL, 1, m->A<float>(PS.normw), m->A<float>(PS.normb), out_bf, out_f32, W, 0, W, kEps, st));
+  }
+  return scatter_media(m, ws, st);
 }
 
 int media_kv_f32(deer_model* m, void* st) {
@@ -976,7 +1025,8 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
   float* pooled = m->Wk<float>(m->pooled);
   {
     Bracket b(m, "deer_head_pool", 0, 0, st);
-    DEER_TRY(deer_head_pool(feats, pooled, T, d, c.pooling_avg, B, km, ctl, kind, layer, st));
+    if (c.use_state) DEER_TRY(deer_head_pool_state(feats, pooled, T, d, c.pooling_avg, B, km, m->Wk<float>(m->state_emb), ctl, kind, layer, st));
+    else DEER_TRY(deer_head_pool(feats, pooled, T, d, c.pooling_avg, B, km, ctl, kind, layer, st));
   }
   float* h_tmp = m->Wk<float>(m->h_tmp);
   float* c_tmp = m->Wk<float>(m->c_tmp);
@@ -1050,6 +1100,7 @@ int embed(deer_model* m, int T, void* st) {
 }
 
 int llm_dynamic(deer_model* m, int T, bool use_mask, bool shadow, void* st) {
+  if (m->c.use_state) return DEER_ERR_SHAPE;            // the reference's dynamic exit raises with use_state (value_net.py:122-129)
   const std::vector<PlanRow> plan = dynamic_plan(m);
   bool pending = false;
   DEER_TRY(embed(m, T, st));
@@ -1067,7 +1118,16 @@ int llm_dynamic(deer_model* m, int T, bool use_mask, bool shadow, void* st) {
   return DEER_OK;
 }
 
+// DeterministicDecoder(use_state=True): the embedding of this step's robot state ("state_in"), once per step
+int state_embed(deer_model* m, void* st) {
+  if (!m->c.use_state) return DEER_OK;
+  Bracket b(m, "deer_head_state_embed", 0, 0, st);
+  return deer_head_state_embed(m->Wk<float>(m->state_in), m->A<float>(m->w_arm), m->A<float>(m->b_arm), m->A<float>(m->e_grip), m->A<void>(m->w_state),
+                               m->A<float>(m->b_state), m->Wk<float>(m->state_emb), m->d, m->B, m->c.precision, st);
+}
+
 int llm_static(deer_model* m, int T, bool use_mask, int exit_id, void* st) {
+  DEER_TRY(state_embed(m, st));
   DEER_TRY(embed(m, T, st));
   for (int i = 0; i <= exit_id; ++i) DEER_TRY(llm_layer(m, i, T, use_mask, false, true, false, st));
   return head_eval(m, exit_id, T, DEER_KIND_COMMIT, -1, false, false, false, false, nullptr, use_mask && m->B > 1, st);
@@ -1275,10 +1335,16 @@ int deer_begin_step(deer_model* m, const int* step_info, void* stream) {
 
 int deer_vision(deer_model* m, int chain, int part, int with_kv, void* stream) {
   if (m->ws == nullptr || part < 0 || part > 2 || chain >= (int)m->chains.size()) return DEER_ERR_SHAPE;
+  if (chain < 0 && m->c.sep_resampler) {                // the batched pass would mix the cameras: run the two camera chains in turn
+    for (const VisionWS& cw : m->chains) DEER_TRY(vision(m, cw, part, false, stream));
+    return (with_kv && part != 1) ? media_kv(m, stream) : DEER_OK;
+  }
   return vision(m, chain < 0 ? m->vws : m->chains[chain], part, with_kv != 0, stream);
 }
 
 int deer_media_kv(deer_model* m, void* stream) { return m->ws ? media_kv(m, stream) : DEER_ERR_SHAPE; }
+
+int deer_head_state(deer_model* m, void* stream) { return m->ws ? state_embed(m, stream) : DEER_ERR_SHAPE; }
 
 int deer_llm_embed(deer_model* m, int T, void* stream) {
   if (m->ws == nullptr || T <= 0 || T > m->c.max_text_len || m->B * T > kMaxRows) return DEER_ERR_SHAPE;
@@ -1299,7 +1365,12 @@ int deer_head_eval(deer_model* m, int layer, int T, int kind, int slot, int forc
 int deer_step_enqueue(deer_model* m, int T, int use_mask, int exit_id, int shadow, const int* step_info, void* stream) {
   if (m->ws == nullptr || T <= 0 || T > m->c.max_text_len || m->B * T > kMaxRows || exit_id >= m->c.n_layers) return DEER_ERR_SHAPE;
   DEER_TRY(deer_begin_step(m, step_info, stream));
-  DEER_TRY(vision(m, m->vws, 0, true, stream));
+  if (m->c.sep_resampler) {                             // one chain per camera (own Perceiver weights), same stream
+    for (const VisionWS& cw : m->chains) DEER_TRY(vision(m, cw, 0, false, stream));
+    DEER_TRY(media_kv(m, stream));
+  } else {
+    DEER_TRY(vision(m, m->vws, 0, true, stream));
+  }
   return exit_id < 0 ? llm_dynamic(m, T, use_mask != 0, shadow != 0, stream) : llm_static(m, T, use_mask != 0, exit_id, stream);
 }
 
@@ -1324,7 +1395,13 @@ int deer_vit_l14_encode(deer_model* m, const void* images_bf16, int n_images, fl
 int deer_perceiver_resample(deer_model* m, const float* tokens, int n_images, void* media_bf16_out, float* media_f32_out, void* stream) {
   if (m->ws == nullptr || n_images != m->N) return DEER_ERR_SHAPE;
   m->tokens_override = tokens;
-  const int rc = m->c.precision ? perceiver_f32(m, m->vws, stream) : perceiver(m, m->vws, stream);
+  int rc = DEER_OK;
+  if (m->c.sep_resampler) {                             // frames camera-major: one pass per camera with its own weight set
+    for (const VisionWS& cw : m->chains)
+      if (rc == DEER_OK) rc = m->c.precision ? perceiver_f32(m, cw, stream) : perceiver(m, cw, stream);
+  } else {
+    rc = m->c.precision ? perceiver_f32(m, m->vws, stream) : perceiver(m, m->vws, stream);
+  }
   m->tokens_override = nullptr;
   if (rc != DEER_OK) return rc;
   const size_t n = (size_t)m->N * m->nl * m->W;

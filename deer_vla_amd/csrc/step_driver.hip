@@ -15,6 +15,7 @@
 #include "../../include/deer_hip.h"
 #include "../../include/deer_model.h"
 #include <chrono>
+#include <sched.h>
 #include <cstring>
 #include <vector>
 
@@ -118,6 +119,11 @@ extern "C" int deer_step_plan_run(deer_step_plan* p, int hold, int seq, void* ma
     std::chrono::steady_clock::time_point dead;
     bool armed = false;
     while (load_acquire(mirror + HOSTM_DONE) != seq && load_acquire(mirror + HOSTM_PROGRESS) < want) {
+      // one poller per engine (four per GPU in the batched_groups leg, 32 on an 8-GPU node): `pause` keeps the spin off the
+      // sibling hyperthread's issue slots and the memory pipeline; a wait longer than ~100 us (the vision tower: ~2 ms before the
+      // first verdict) also yields the core to a runnable launch thread (sched_yield returns at once when there is none)
+      __builtin_ia32_pause();
+      if (spins > 4096u) sched_yield();
       if ((++spins & 0xFFFFFu) == 0) {
         const auto now = std::chrono::steady_clock::now();
         if (!armed) { dead = now + std::chrono::seconds(20); armed = true; }

@@ -236,6 +236,8 @@ class DeerEngine:
         for n in ("h_state", "c_state", "h_tmp", "c_tmp", "h_shadow", "c_shadow"):   # LSTM state: [layer][env][H]
             setattr(self, n, v(n, torch.float32).view(Lh, B, H))
         self.pooled = v("pooled", torch.float32).view(B, d)
+        if getattr(cfg, "use_state", False):              # robot state of the step: (arm pose robot_obs[:6], gripper opening robot_obs[-1], pad)
+            self.state_in = v("state_in", torch.float32).view(B, 8)
         self.ctl = v("ctl", torch.int32)                                   # one control block per environment
         self.hold_dev = v("step_info", torch.int32)                        # step_info: {hold, seq, host mirror ptr lo, hi}
         self.thresholds = v("thresholds", torch.float32)
@@ -397,6 +399,8 @@ class DeerEngine:
 
     def enqueue_llm_static(self, T, use_mask, exit_id):
         """exit_id given (flamingo_mpt.py:402-411,446-461): run layers 0..exit_id, committing head call."""
+        if getattr(self.cfg, "use_state", False):
+            abi.check(self.lib.deer_head_state(self._h, _cur_stream()), "deer_head_state")
         self.enqueue_embed(T)
         for i in range(exit_id + 1):
             self.enqueue_llm_layer(i, T, None, use_mask, finalize=True, ctl=False)
@@ -454,8 +458,12 @@ class DeerEngine:
         S, B = self.cfg.image_size, self.B
         iv = getattr(self, "_img_views", None)
         if iv is None:
-            img = self.img.view(B, 2, 3, S, S)
-            iv = self._img_views = (img[:, 0], img[:, 1])
+            if getattr(self.cfg, "sep_resampler", False):     # camera-major frames: every vision chain holds ONE camera (own Perceiver weights)
+                img = self.img.view(2, B, 3, S, S)
+                iv = self._img_views = (img[0], img[1])
+            else:
+                img = self.img.view(B, 2, 3, S, S)
+                iv = self._img_views = (img[:, 0], img[:, 1])
         iv[0].copy_(rgb.view(B, 3, S, S) if rgb.is_contiguous() else rgb.reshape(B, 3, S, S), non_blocking=True)
         iv[1].copy_(gripper.view(B, 3, S, S) if gripper.is_contiguous() else gripper.reshape(B, 3, S, S), non_blocking=True)
         ids = ids.reshape(B, -1)
@@ -469,13 +477,34 @@ class DeerEngine:
             self._ids_keep = ids                              # keeps data_ptr from being recycled under the tag
         use_mask = False
         if mask is not None:
-            m = mask.reshape(B, T).to(torch.uint8)
-            use_mask = bool((m == 0).any())
-            self.key_mask[:B * T].copy_(m.reshape(-1), non_blocking=True)
+            # like the instruction, the mask only changes between sub-tasks: the "any padding?" question costs a device round trip
+            # (bool() of a device tensor), so it is asked once per mask tensor
+            mtag = (mask.data_ptr(), mask._version, B * T)
+            if mtag != getattr(self, "_mask_tag", None):
+                m = mask.reshape(B, T).to(torch.uint8)
+                self._mask_any_pad = bool((m == 0).any())
+                self.key_mask[:B * T].copy_(m.reshape(-1), non_blocking=True)
+                self._mask_tag, self._mask_keep = mtag, mask
+            use_mask = self._mask_any_pad
+        else:
+            self._mask_tag = None
         return T, use_mask
 
     def step(self, rgb, gripper, ids, mask=None, exit_id: Optional[int] = None, use_graph: bool = True, sync: bool = True,
-             shadow: bool = False):
+             shadow: bool = False, state: Optional[torch.Tensor] = None):
+        """state: robot_obs of every environment, (B, ..., 15) (eval_utils.py:324-332) - read only by a ``use_state`` model, whose
+        head embeds (robot_obs[:6], robot_obs[-1]) into the pooled feature (action_head.py:524-536)."""
+        if getattr(self.cfg, "use_state", False):
+            if exit_id is None:
+                raise NotImplementedError("use_state has no dynamic exit: the reference's ActionValueNet calls the head without a state "
+                                          "tensor and raises TypeError (value_net.py:122-129); pass a static exit_id")
+            if state is None:
+                raise ValueError("a use_state model needs the robot state of the step (state=robot_obs, (B, 15))")
+            st = state.reshape(self.B, -1).to(torch.float32)
+            packed = torch.zeros(self.B, 8, dtype=torch.float32)
+            packed[:, :6] = st[:, :6].cpu()
+            packed[:, 6] = st[:, -1].cpu()
+            self.state_in.copy_(packed, non_blocking=False)
         with _GATE.step():
             return self._step_impl(rgb, gripper, ids, mask, exit_id, use_graph, sync, shadow)
 

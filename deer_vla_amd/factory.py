@@ -199,6 +199,8 @@ def create_model_and_transforms(clip_vision_encoder_path: str = "ViT-L-14", clip
         cfg.lstm_num_layers = flamingo_kwargs.get("lstm_num_layers", 4)
         cfg.pooling = pooling
         cfg.window_size = window_size
+    cfg.use_state = bool(use_state) or cfg.use_state                 # action_head.py:524-536 / flamingo_mpt.py:132-134 variants
+    cfg.sep_resampler = bool(sep_resampler) or cfg.sep_resampler
     synthetic = state_dict is None
     if synthetic:
         state_dict = syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True)

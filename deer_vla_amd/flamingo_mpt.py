@@ -41,6 +41,29 @@ class CausalLMOutputWithPast:
     exit_layer: Optional[int] = None
 
 
+class _LazyHidden:
+    """``hidden_states`` of a step as a tuple-like object that copies the layer outputs off the engine's buffers on FIRST access (valid
+    until the next step overwrites them): ``len`` is the reference's exit_layer + 1 (flamingo_mpt.py:458)."""
+
+    def __init__(self, engine, exit_layer, T):
+        self._e, self._n, self._T, self._t = engine, exit_layer + 1, T, None
+
+    def _materialise(self):
+        if self._t is None:
+            hs = self._e.hidden[: self._n, : self._T].clone()
+            self._t = tuple(hs[i].unsqueeze(0) for i in range(self._n))
+        return self._t
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+
 class _Cfg:
     def __init__(self, n_layers, d_model):
         self.n_layers, self.d_model = n_layers, d_model
@@ -149,14 +172,18 @@ class MPTFlamingo(nn.Module):
         # attributes read by the CALVIN harness through `.module` (eval_utils.py:192-247,300-331,456,480)
         self.window_size = window_size
         self.use_gripper, self.fusion_mode = use_gripper, fusion_mode
-        self.use_state, self.sep_lm_head, self.tcp_rel = False, True, False
+        self.use_state, self.sep_lm_head, self.tcp_rel = bool(getattr(cfg, "use_state", False)), True, False
         self.replan, self.refresh, self.pad_length, self.act_step = -1, -1, -1, 1
         self.decoder_type, self.head_type = "lstm", "deterministic"
-        self.use_diff, self.use_hist, self.sep_resampler = False, False, False
+        self.use_diff, self.use_hist, self.sep_resampler = False, False, bool(getattr(cfg, "sep_resampler", False))
         self.eoc_token_id, self.media_token_id = cfg.eoc_token_id, cfg.media_token_id
         self.vis_dim, self.lang_dim = cfg.vit_width, cfg.d_model
         self.early_exit_layer = cfg.early_exit_layer
         self.layerwise_exit_eval = False
+        # host_outputs=True (set by rollout.ModelWrapper, which only reads the action and the exit layer): ``forward`` returns the action
+        # as CPU tensors taken from the step's pinned verdict block and ``hidden_states`` as a lazy tuple that is copied off the engine's
+        # buffers on first access - no device clone, no extra device read per step.  Default False: eager device tensors like the reference.
+        self.host_outputs = False
         self.llm_inference_time = -1.0
         self.lm_exits = {i: None for i in range(cfg.exit_interval - 1, cfg.early_exit_layer, cfg.exit_interval)}
         self.lang_encoder = LangEncoder(self)
@@ -287,6 +314,7 @@ class MPTFlamingo(nn.Module):
         T = ids.numel()
         e.ids[:T].copy_(ids)
         e._ids_tag = None                 # the engine's "same instruction tensor as last step" shortcut no longer holds
+        e._mask_tag = None
         e._shadow_on = False              # ctl is zeroed below (shadow flag included)
         use_mask = False
         if attention_mask is not None:
@@ -376,6 +404,8 @@ class MPTFlamingo(nn.Module):
         if vision_x.ndim != 6 or vision_x.shape[1] != 1:
             raise NotImplementedError("vision_x must be (B, 1, 1, 3, S, S)")
         assert vision_x.shape[2] == 1, "Only single frame supported"
+        if self.use_state and exit_id is None and not (dynamic_early_exit and exit_controller is not None):
+            raise NotImplementedError("window-mode calibration with use_state is not implemented")
         if exit_id is None and not (dynamic_early_exit and exit_controller is not None):
             # the all-exits branch (flamingo_mpt.py:463-517): inference-side use = window-mode calibration (value_net.py:375-385)
             if not (only_extra_exit and return_in_feat):
@@ -384,6 +414,9 @@ class MPTFlamingo(nn.Module):
             return self._forward_window(vision_x, lang_x, attention_mask, vision_gripper, with_gripper_logits)
         if vision_x.shape[0] != 1:
             raise NotImplementedError("step mode takes one frame pair (B=1); batches of frames go through the window-mode call")
+        if self.use_state and exit_id is None:
+            # the reference itself fails here: ActionValueNet.forward calls exit_head(feats[i]) without state_tensor (value_net.py:122-129)
+            raise NotImplementedError("use_state + dynamic_early_exit: the reference raises TypeError (value_net.py:122-129); use a static exit_id")
         e, cfg = self.engine, self.cfg
         ctl = getattr(exit_controller, "module", exit_controller)
         native = isinstance(ctl, ExitController)
@@ -396,7 +429,7 @@ class MPTFlamingo(nn.Module):
         if exit_id is not None or native:
             if native and exit_id is None:
                 self._sync_controller(ctl)
-            r = e.step(vision_x, vision_gripper, lang_x, attention_mask, exit_id=exit_id)
+            r = e.step(vision_x, vision_gripper, lang_x, attention_mask, exit_id=exit_id, state=state_tensor if self.use_state else None)
             exit_layer = r["exit_layer"]
             if native and exit_id is None:
                 ctl.cur_exit_id = int(e.ctl_host[abi.CTL_CUR_EXIT_ID])
@@ -417,14 +450,19 @@ class MPTFlamingo(nn.Module):
             self.llm_inference_time = st["llm_and_exit_checks"] / 1e3 if st else self.forward_time
             self.vision_time = st["vision"] / 1e3 if st else float("nan")
         T = lang_x.reshape(-1).numel()
-        if exit_id is not None or native:
-            a = e.ctl.view(torch.float32)[abi.CTL_OUT_ACTION: abi.CTL_OUT_ACTION + 8].clone()
+        fast = self.host_outputs and (exit_id is not None or native)
+        if fast:
+            a = torch.cat([r["pose"], torch.tensor([r["gripper"], r["gripper_logit"]], dtype=torch.float32)])   # from the pinned verdict block
+            hidden = _LazyHidden(e, exit_layer, T)
         else:
-            a = e.action_dbg[0].clone()
-        # every layer's output up to the exit is real (the spine writes hidden[i] of a non-exit layer with the first row op
-        # of layer i+1); ONE copy, so that the tuple survives the next step overwriting the engine's buffers
-        hs = e.hidden[: exit_layer + 1, :T].clone()
-        hidden = tuple(hs[i].unsqueeze(0) for i in range(exit_layer + 1))
+            if exit_id is not None or native:
+                a = e.ctl.view(torch.float32)[abi.CTL_OUT_ACTION: abi.CTL_OUT_ACTION + 8].clone()
+            else:
+                a = e.action_dbg[0].clone()
+            # every layer's output up to the exit is real (the spine writes hidden[i] of a non-exit layer with the first row op
+            # of layer i+1); ONE copy, so that the tuple survives the next step overwriting the engine's buffers
+            hs = e.hidden[: exit_layer + 1, :T].clone()
+            hidden = tuple(hs[i].unsqueeze(0) for i in range(exit_layer + 1))
         assert len(hidden) == exit_layer + 1                                                # flamingo_mpt.py:458
         pose, grip = a[:6].view(1, 1, 6), a[6:7].view(1, 1, 1)
         logits = (pose, (grip, a[7:8].view(1, 1, 1))) if with_gripper_logits else (pose, grip)

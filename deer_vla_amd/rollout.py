@@ -36,6 +36,8 @@ def preprocess_image(sample, image_processor) -> torch.Tensor:
     """data.py:898-902: stack of processed frames, (n, 3, S, S).  A processor with ``on_device`` (factory.GpuImageProcessor) takes the
     raw uint8 frames of the whole list in one call and returns device tensors."""
     if getattr(image_processor, "on_device", False):
+        if len(sample) == 1:                                       # the per-step case: no host-side copy of the frame
+            return image_processor(np.asarray(sample[0])[None])
         return image_processor(np.stack([np.asarray(s) for s in sample]))
     return torch.cat([image_processor(s).unsqueeze(0) for s in sample], dim=0)
 
@@ -124,6 +126,8 @@ class ModelWrapper:
         if m.act_step != 1:
             raise NotImplementedError("multi-step action heads are not part of DeeR's released configuration")
         self.model = model
+        if hasattr(m, "host_outputs"):
+            m.host_outputs = True                                   # this wrapper reads only the action and the exit layer
         self.replan = m.replan
         self.decoder_type = m.decoder_type
         self.cast_type = cast_dtype
@@ -170,12 +174,15 @@ class ModelWrapper:
         gripper = None
         if m.use_gripper:
             gripper = self.image_process_fn([obs["rgb_obs"]["rgb_gripper"]]).unsqueeze(1).unsqueeze(1).to(dtype=self.cast_type)
+        state = None
+        if m.use_state or m.sep_lm_head:                            # eval_utils.py:324-332: robot_obs (15,) -> (1, 1, 1, 15) f32
+            state = torch.from_numpy(np.stack([obs["robot_obs"]])).unsqueeze(1).unsqueeze(1).to(torch.float32)
         with torch.no_grad():
             image_x = image_x.cuda(non_blocking=True)
             gripper = gripper.cuda(non_blocking=True) if gripper is not None else None
             self.img_queue.append(image_x)
             self.gripper_queue.append(gripper)
-            out = self.model(vision_x=image_x, lang_x=text_x, attention_mask=mask, vision_gripper=gripper, state_tensor=None,
+            out = self.model(vision_x=image_x, lang_x=text_x, attention_mask=mask, vision_gripper=gripper, state_tensor=state,
                              return_feature=True, deterministic=True, exit_id=self.exit_id,
                              dynamic_early_exit=self.dynamic_early_exit, exit_controller=self.exit_controller)
             if hasattr(out, "exit_layer"):

@@ -64,23 +64,25 @@ def param_shapes(cfg: DeerConfig) -> "OrderedDict[str, Tuple[tuple, str]]":
         P[b + "mlp.c_proj.bias"] = ((W,), BIAS)
 
     inner = cfg.perc_heads * cfg.perc_dim_head
-    P["perceiver.latents"] = ((cfg.perc_latents, W), LATENT)
-    for l in range(cfg.perc_depth):
-        a = f"perceiver.layers.{l}.0."
-        P[a + "norm_media.weight"] = ((W,), LN_W)
-        P[a + "norm_media.bias"] = ((W,), LN_B)
-        P[a + "norm_latents.weight"] = ((W,), LN_W)
-        P[a + "norm_latents.bias"] = ((W,), LN_B)
-        P[a + "to_q.weight"] = ((inner, W), LINEAR)
-        P[a + "to_kv.weight"] = ((2 * inner, W), LINEAR)
-        P[a + "to_out.weight"] = ((W, inner), LINEAR)
-        f = f"perceiver.layers.{l}.1."
-        P[f + "0.weight"] = ((W,), LN_W)
-        P[f + "0.bias"] = ((W,), LN_B)
-        P[f + "1.weight"] = ((cfg.perc_ff_mult * W, W), LINEAR)
-        P[f + "3.weight"] = ((W, cfg.perc_ff_mult * W), LINEAR)
-    P["perceiver.norm.weight"] = ((W,), LN_W)
-    P["perceiver.norm.bias"] = ((W,), LN_B)
+    # sep_resampler: a second PerceiverResampler for the gripper camera (flamingo_mpt.py:132-134: ``perceiver_gripper``)
+    for pp in (["perceiver.", "perceiver_gripper."] if cfg.sep_resampler else ["perceiver."]):
+        P[pp + "latents"] = ((cfg.perc_latents, W), LATENT)
+        for l in range(cfg.perc_depth):
+            a = f"{pp}layers.{l}.0."
+            P[a + "norm_media.weight"] = ((W,), LN_W)
+            P[a + "norm_media.bias"] = ((W,), LN_B)
+            P[a + "norm_latents.weight"] = ((W,), LN_W)
+            P[a + "norm_latents.bias"] = ((W,), LN_B)
+            P[a + "to_q.weight"] = ((inner, W), LINEAR)
+            P[a + "to_kv.weight"] = ((2 * inner, W), LINEAR)
+            P[a + "to_out.weight"] = ((W, inner), LINEAR)
+            f = f"{pp}layers.{l}.1."
+            P[f + "0.weight"] = ((W,), LN_W)
+            P[f + "0.bias"] = ((W,), LN_B)
+            P[f + "1.weight"] = ((cfg.perc_ff_mult * W, W), LINEAR)
+            P[f + "3.weight"] = ((W, cfg.perc_ff_mult * W), LINEAR)
+        P[pp + "norm.weight"] = ((W,), LN_W)
+        P[pp + "norm.bias"] = ((W,), LN_B)
 
     d = cfg.d_model
     xin = cfg.xattn_heads * cfg.xattn_dim_head
@@ -129,6 +131,12 @@ def head_param_shapes(cfg: DeerConfig, prefix: str) -> "OrderedDict[str, Tuple[t
     P: "OrderedDict[str, Tuple[tuple, str]]" = OrderedDict()
     H = cfg.head_hidden
     in_f = cfg.d_model
+    if cfg.use_state:                                    # action_head.py:443-453: state embedding added to the pooled feature
+        P[prefix + "embed_arm_state.0.weight"] = ((in_f, 6), LINEAR)
+        P[prefix + "embed_arm_state.0.bias"] = ((in_f,), BIAS)
+        P[prefix + "embed_gripper_state.0.weight"] = ((2, in_f), EMBED)
+        P[prefix + "embed_state.weight"] = ((in_f, 2 * in_f), LINEAR)
+        P[prefix + "embed_state.bias"] = ((in_f,), BIAS)
     for l in range(cfg.lstm_num_layers):
         if cfg.lstm_layernorm:
             r = f"{prefix}rnn.layers.{3 * l}."            # LSTM at 0,3,6,9; LN at 1,4,7,10

@@ -231,7 +231,14 @@ int deer_broadcast_rows(const float* src, float* dst, long n, int batch, void* s
  * All three evaluate a BATCH of B <= 8 independent environments per launch (weights read once): features [B][T][d],
  * LSTM state tensors [L][B][H], control blocks ctl + b*DEER_CTL_WORDS, exit decision per environment. */
 int deer_head_pool(const float* feats, float* pooled, int T, int d, int avg, int B, const unsigned char* key_mask, const int* ctl,
-                   int kind, int layer, void* stream);   /* AdaptiveMax/AvgPool1d over the text tokens (action_head.py:480-483,
+                   int kind, int layer, void* stream);
+/* DeterministicDecoder(use_state=True) (action_head.py:443-453,524-536): deer_head_state_embed computes, per environment, the embedding
+ * W_state [relu(W_arm arm + b_arm) ; relu(E_grip[(g + 1) / 2])] + b_state of the robot state (state [B][8] f32: arm pose robot_obs[:6],
+ * gripper opening robot_obs[-1], pad); deer_head_pool_state is deer_head_pool with that embedding added to the pooled feature. */
+int deer_head_state_embed(const float* state, const float* w_arm, const float* b_arm, const float* e_grip, const void* w_state,
+                          const float* b_state, float* out, int d, int B, int w_is_f32, void* stream);
+int deer_head_pool_state(const float* feats, float* pooled, int T, int d, int avg, int B, const unsigned char* key_mask,
+                         const float* state_emb, const int* ctl, int kind, int layer, void* stream);   /* AdaptiveMax/AvgPool1d over the text tokens (action_head.py:480-483,
                    519-520); key_mask (uint8 [B][T], 0 = right-padding of an env batch, data.py:905-919) or NULL */
 int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w, const float* ln_b,
                          const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh, const float* h_prev,

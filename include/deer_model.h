@@ -38,6 +38,12 @@ typedef struct deer_config {
   int precision;            /* 0: bf16 MFMA operands in the vision tower / x-attn (the product path); 1: fp32 arithmetic -
                              * f32 activations and f32 (or bf16 hi + lo) weight copies everywhere (csrc/precise.hip; single-stream schedule;
                              * ~1/10 of the vision tower's throughput, 1.8x the arena) */
+  int use_state;            /* DeterministicDecoder(use_state=True), action_head.py:524-536: the embedded robot state (workspace buffer
+                             * "state_in", [n_envs][8] f32) is added to the pooled feature.  Static exit_id only: the reference's dynamic
+                             * exit raises with it (value_net.py:122-129 calls the head without a state tensor). */
+  int sep_resampler;        /* flamingo_mpt.py:132-134,656-659: the gripper camera has its own PerceiverResampler ("perceiver_gripper.*").
+                             * The camera frames are then ordered camera-major ([rgb of every env ; gripper of every env]) and every vision
+                             * chain holds the frames of ONE camera. */
 } deer_config;
 
 typedef struct deer_model deer_model;
@@ -96,6 +102,8 @@ int deer_begin_step(deer_model* m, const int* step_info, void* stream);
  * part: 0 whole tower, 1 patch embedding + first blocks, 2 the rest + Perceiver; media_kv: also project K|V of every x-attn layer */
 int deer_vision(deer_model* m, int chain, int part, int media_kv, void* stream);
 int deer_media_kv(deer_model* m, void* stream);
+/* use_state models: the embedding of this step's robot state (workspace "state_in") for the head evaluations of the step; no-op otherwise */
+int deer_head_state(deer_model* m, void* stream);
 int deer_llm_embed(deer_model* m, int T, void* stream);
 /* pending_in: the previous layer left its last residual branch un-applied (it was not finalized); finalize: write hidden[i] */
 int deer_llm_layer(deer_model* m, int layer, int T, int use_mask, int pending_in, int finalize, int use_ctl, void* stream);

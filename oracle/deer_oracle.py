@@ -309,6 +309,15 @@ class OracleHead:
             input_feature = (input_feature.amax(dim=1) if cfg.pooling == "max"
                              else input_feature.mean(dim=1))
         input_feature = input_feature.reshape(-1, cur_ws, input_feature.shape[1])
+        if getattr(cfg, "use_state", False):                                # action_head.py:524-536
+            p = self.prefix
+            arm = torch.relu(_lin(state_tensor[..., :6], self.sd[p + "embed_arm_state.0.weight"]) + self.sd[p + "embed_arm_state.0.bias"])
+            arm = arm.view(-1, self.window_size, arm.shape[-1])
+            gidx = ((state_tensor[..., -1] + 1.0) / 2).long()
+            grp = torch.relu(self.sd[p + "embed_gripper_state.0.weight"][gidx])
+            grp = grp.view(-1, self.window_size, grp.shape[-1])
+            emb = _lin(torch.cat((arm, grp), dim=2), self.sd[p + "embed_state.weight"]) + self.sd[p + "embed_state.bias"]
+            input_feature = input_feature + emb
         if input_feature.shape[1] == 1:                                     # step mode (:548)
             self.history_memory.append(input_feature)
             x, h_n = head_rnn_step(self.sd, cfg, self.prefix, input_feature[:, 0], self.hidden_state)
@@ -550,7 +559,8 @@ class OracleDeer:
             return t.reshape(b, T, Fr, t.shape[1], t.shape[2])
 
         rgb = perceiver_resampler(self.sd, cfg, enc(vision_x))
-        grip = perceiver_resampler(self.sd, cfg, enc(vision_gripper))
+        grip = perceiver_resampler(self.sd, cfg, enc(vision_gripper),       # :656-659: own weights when sep_resampler
+                                   "perceiver_gripper." if getattr(cfg, "sep_resampler", False) else "perceiver.")
         return torch.cat([rgb, grip], dim=2)                                # :661  (b,T,2n,D)
 
     def forward(self, vision_x, lang_x, attention_mask=None, vision_gripper=None, state_tensor=None,

@@ -166,7 +166,7 @@ def gen_flamingo_layer():
 def build_ref_head(cfg, sd, prefix="extra_exit."):
     m = DeterministicDecoder(cfg.d_model, cfg.window_size, 0.0, 0.0, "layerwise", cfg.mlp_layernorm,
                              cfg.lstm_layernorm, cfg.mlp_num_hidden_layers, hidden_size=cfg.head_hidden,
-                             lstm_num_layers=cfg.lstm_num_layers, pooling=cfg.pooling).eval()
+                             lstm_num_layers=cfg.lstm_num_layers, pooling=cfg.pooling, use_state=cfg.use_state).eval()
     load_strict(m, sub_state(sd, prefix))
     return m
 
@@ -201,6 +201,121 @@ def gen_head(name, **kw):
     save(name, cfg, seed, feats=feats, upd=np.asarray(upd), pose=torch.stack(poses), grip=torch.stack(grips),
          h=torch.stack(hs), c=torch.stack(cs), wfeat=wfeat, wpose=wa, wgrip=wg, wpose_last=wa_last,
          wgrip_last=wg_last, wgrip_logits=wgl)
+
+
+def gen_head_state(name="head_state.npz"):
+    """DeterministicDecoder(use_state=True) (action_head.py:443-453,524-536): the robot state - arm pose robot_obs[:6] and the
+    gripper opening robot_obs[-1] in {-1, +1} (eval_utils.py:324-332 hands over all 15 values) - is embedded and ADDED to the pooled
+    feature; step mode with LSTM carry."""
+    cfg, seed = small_cfg(use_state=True), 4
+    sd = syn.make_synthetic_state(cfg, seed)
+    m = build_ref_head(cfg, sd)
+    m.window_size = 1
+    T, n = 7, 6
+    feats = seeded("head.feats", (n, 1, T, cfg.d_model))
+    state = seeded("head.state", (n, 1, 1, 1, 15))
+    state[..., -1] = torch.tensor([1.0, -1.0, -1.0, 1.0, 1.0, -1.0]).view(n, 1, 1, 1)
+    upd = [False, True, True, False, True, True]
+    poses, grips = [], []
+    for t in range(n):
+        a, g = m(feats[t], state_tensor=state[t], update_hidden_state=upd[t])
+        poses.append(a)
+        grips.append(g)
+    save(name, cfg, seed, feats=feats, state=state, upd=np.asarray(upd), pose=torch.stack(poses), grip=torch.stack(grips))
+
+
+def gen_deer_forward_variant(name, use_state=False, sep_resampler=False):
+    """The reference's own MPTFlamingo.forward with ``use_state`` / ``sep_resampler`` (flamingo_mpt.py:132-136,656-659; the state
+    reaches ONLY the action head on the post-fusion path: ``_encode_multi_vision_post_fusion`` is called without it, :381).  Static
+    exits; with sep_resampler also a dynamic episode (with use_state the reference's ``ActionValueNet`` calls the head without a
+    state tensor, value_net.py:122-129, and raises - dynamic exit does not exist for that variant)."""
+    _dist_init()
+    cfg, seed = llm_cfg(use_state=use_state, sep_resampler=sep_resampler), 7
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
+    lm, mod = build_ref_lang_encoder(cfg, sd)
+    extend_instance(lm, FlamingoLMMixin)
+    lm.set_decoder_layers_attr_name("transformer.blocks")
+    venc_mod = nn.Module()
+    venc_mod.visual = _OracleVisual(cfg, sd)
+    model = MPTFlamingo(venc_mod, lm, cfg.eoc_token_id, cfg.media_token_id, vis_dim=cfg.vit_width,
+                        cross_attn_every_n_layers=cfg.cross_attn_every_n_layers, window_size=cfg.window_size,
+                        use_gripper=True, fusion_mode="post", llm="mpt_dolly_3b", pooling="max", use_state=use_state,
+                        sep_resampler=sep_resampler, early_exit_layer=cfg.early_exit_layer, multi_exit=False,
+                        exit_interval=cfg.exit_interval, mlp_layernorm=True, lstm_layernorm=True, mlp_num_hidden_layers=2,
+                        lstm_num_layers=4).eval()
+    sd_model = {k: v for k, v in sd.items() if not k.startswith("vision_encoder.")}
+    ref_keys = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    for k, v in sd_model.items():
+        assert k in ref_keys and ref_keys[k] == tuple(v.shape), (k, tuple(v.shape), ref_keys.get(k))
+    missing, unexpected = model.load_state_dict(sd_model, strict=False)
+    assert not unexpected, unexpected
+    if sep_resampler:
+        assert not any(k.startswith("perceiver_gripper.") for k in missing), missing
+    if use_state:                                            # state_fc (a media token on other fusion paths) is never applied here
+        assert all(not k.startswith("extra_exit.embed") for k in missing), missing
+    T, S, n_steps = 8, cfg.image_size, 6
+    ids = torch.tensor([[cfg.media_token_id, 5, 17, 3, 42, 8, cfg.eoc_token_id, 0]])
+    mask = torch.ones(1, T, dtype=torch.bool)
+    rgb = seeded("deer.rgb", (n_steps, 1, 1, 1, 3, S, S))
+    grip = seeded("deer.grip", (n_steps, 1, 1, 1, 3, S, S))
+    state = seeded("deer.state", (n_steps, 1, 1, 1, 15))
+    state[..., -1] = torch.tensor([1.0, -1.0, 1.0, 1.0, -1.0, -1.0]).view(n_steps, 1, 1, 1)
+    model.set_all_exit_window_size(1)
+    outs = {}
+    for eid in (3, 4):                                       # static exits, LSTM carried over the steps
+        model.clear_all_exit_memory()
+        ps, gs = [], []
+        for s_ in range(n_steps):
+            o = model(vision_x=rgb[s_], lang_x=ids, attention_mask=mask, vision_gripper=grip[s_], state_tensor=state[s_],
+                      return_feature=True, deterministic=True, exit_id=eid, dynamic_early_exit=False, exit_controller=None)
+            ps.append(o.logits[0])
+            gs.append(o.logits[1])
+        outs[f"static{eid}_pose"], outs[f"static{eid}_grip"] = torch.stack(ps), torch.stack(gs)
+    outs["vis_x"] = lm._get_decoder_layers()[0].vis_x
+    if not use_state:
+        exit_ids = model.get_all_exit_idx()
+        model.clear_all_exit_memory()
+        vn = _RecVN(exit_list=exit_ids, exit_head=model.extra_exit, interval=cfg.exit_interval, window_size=cfg.window_size,
+                    threshold_type="L2")
+        ctl = ExitController(vn, exit_id_list=exit_ids, steps_per_stage=1, leq=True, exit_dist="exp", max_layer=12)
+        real = len([x for x in exit_ids if x <= ctl.max_layer])
+        ctl._set_threshold_value([-1.0] * real)
+        for s_ in range(n_steps):
+            ctl.set_timestep(s_)
+            model(vision_x=rgb[s_], lang_x=ids, attention_mask=mask, vision_gripper=grip[s_], state_tensor=state[s_], return_feature=True,
+                  deterministic=True, exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
+        thr = [gap_threshold([v for (i, v) in vn.rec if i == e], 0.2, 0.8) for e in exit_ids[:real]]
+        thr[-1] = 1e5
+        model.clear_all_exit_memory()
+        vn.reset_actions()
+        vn.rec = []
+        ctl._set_threshold_value(thr)
+        ex, ps, gs = [], [], []
+        for s_ in range(n_steps):
+            ctl.set_timestep(s_)
+            o = model(vision_x=rgb[s_], lang_x=ids, attention_mask=mask, vision_gripper=grip[s_], state_tensor=state[s_], return_feature=True,
+                      deterministic=True, exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
+            ex.append(o.exit_layer)
+            ps.append(o.logits[0])
+            gs.append(o.logits[1])
+        print(f"  {name} dyn: exits={ex}")
+        outs.update(dyn_thr=np.asarray(thr), dyn_exit=np.asarray(ex), dyn_pose=torch.stack(ps), dyn_grip=torch.stack(gs), dyn_max_layer=12,
+                    dyn_rec_layer=np.asarray([i for i, _ in vn.rec]), dyn_rec_delta=np.asarray([v for _, v in vn.rec]))
+    else:                                                    # pin the reference's behaviour: dynamic exit + use_state raises
+        vn = ActionValueNet(exit_list=model.get_all_exit_idx(), exit_head=model.extra_exit, interval=cfg.exit_interval,
+                            window_size=cfg.window_size, threshold_type="L2")
+        ctl = ExitController(vn, exit_id_list=model.get_all_exit_idx(), steps_per_stage=1, leq=True, exit_dist="exp", max_layer=12)
+        ctl._set_threshold_value([1e5] * len([x for x in model.get_all_exit_idx() if x <= ctl.max_layer]))
+        model.clear_all_exit_memory()
+        ctl.set_timestep(0)
+        try:
+            model(vision_x=rgb[0], lang_x=ids, attention_mask=mask, vision_gripper=grip[0], state_tensor=state[0], return_feature=True,
+                  deterministic=True, exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
+            outs["dynamic_raises"] = np.asarray(0)
+        except TypeError as e:
+            outs["dynamic_raises"] = np.asarray(1)
+            print(f"  {name}: the reference's dynamic exit with use_state raises {type(e).__name__}: {e}")
+    save(name, cfg, seed, ids=ids, mask=mask, rgb=rgb, grip=grip, state=state, bf16_round=1, **outs)
 
 
 def _dist_init():
@@ -716,6 +831,7 @@ if __name__ == "__main__":
     gen_head("head_ln.npz")
     gen_head("head_plain.npz", lstm_layernorm=False, mlp_layernorm=False)
     gen_head("head_avg3.npz", pooling="avg", mlp_num_hidden_layers=3)
+    gen_head_state()
     gen_controller("controller_b12.npz", n_layers=12, max_layer=12, steps_per_stage=1)
     gen_controller("controller_s4.npz", n_layers=5, max_layer=4, steps_per_stage=1)
     gen_controller("controller_sps3.npz", n_layers=12, max_layer=12, steps_per_stage=3)
@@ -725,5 +841,7 @@ if __name__ == "__main__":
     gen_mosaic_loop()
     gen_mpt9b_loop()
     gen_deer_forward()
+    gen_deer_forward_variant("deer_forward_state.npz", use_state=True)
+    gen_deer_forward_variant("deer_forward_sep.npz", sep_resampler=True)
     gen_hf_mpt_block()
     gen_hf_clip()

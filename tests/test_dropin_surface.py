@@ -110,3 +110,74 @@ def test_eval_time_hook_reports_per_stage_gpu_times():
         o = model(vision_x=rgb.cuda(), lang_x=ids.cuda(), attention_mask=mask.cuda(), vision_gripper=grip.cuda(), exit_id=3, eval_time=True)
     assert o.exit_layer == 3
     assert 0.0 < model.llm_inference_time < model.forward_time and 0.0 < model.vision_time < model.forward_time
+
+
+@pytest.mark.parametrize("name,precision", [("deer_forward_state.npz", "bf16"), ("deer_forward_sep.npz", "bf16"),
+                                            ("deer_forward_state.npz", "fp32"), ("deer_forward_sep.npz", "fp32")])
+def test_use_state_and_sep_resampler_variants_match_reference_forward(name, precision):
+    """the two variants the reference parses from checkpoint names (eval_calvin.py:355-377) through the factory's own
+    keywords - ``use_state`` (robot-state embedding in the action head, action_head.py:524-536; static exits only: the reference's
+    dynamic exit raises with it, and so does this surface) and ``sep_resampler`` (own PerceiverResampler for the gripper camera,
+    flamingo_mpt.py:132-134,656-659) - against the golden outputs of the reference's own MPTFlamingo.forward."""
+    cfg, seed, g = load(name)
+    tol = TOL if precision == "bf16" else 1e-3
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
+    model, _, _ = factory.create_model_and_transforms(
+        "ViT-L-14", "openai", "", "", cross_attn_every_n_layers=1, window_size=12, use_gripper=True, fusion_mode="post",
+        llm_name="mpt_dolly_3b", state_dict=sd, cfg=cfg, use_state=cfg.use_state, sep_resampler=cfg.sep_resampler, precision=precision)
+    assert model.use_state == cfg.use_state and model.sep_resampler == cfg.sep_resampler
+    ids, mask = g["ids"].long().cuda(), g["mask"].cuda()
+    n = g["rgb"].shape[0]
+    for eid in (3, 4):
+        model.clear_all_exit_memory()
+        for s in range(n):
+            o = model(vision_x=g["rgb"][s].cuda(), lang_x=ids, attention_mask=mask, vision_gripper=g["grip"][s].cuda(),
+                      state_tensor=g["state"][s].cuda(), return_feature=True, deterministic=True, exit_id=eid)
+            assert float((o.logits[0].cpu() - g[f"static{eid}_pose"][s]).abs().max()) < tol, (eid, s)
+            assert float((o.logits[1].cpu() - g[f"static{eid}_grip"][s]).abs().max()) < tol, (eid, s)
+    ref_vis = g["vis_x"].reshape(-1, cfg.vit_width)
+    vis = model.engine.vis_x_f32.cpu()
+    assert float((vis - ref_vis).abs().max() / ref_vis.abs().max()) < (2e-2 if precision == "bf16" else 1e-4)
+    vn = ActionValueNet(model.get_all_exit_idx(), model.extra_exit, cfg.exit_interval, cfg.window_size, "L2")
+    if cfg.use_state:
+        assert int(g["dynamic_raises"]) == 1                      # the reference raises TypeError here (fixture)
+        ctl = ExitController(vn, model.get_all_exit_idx(), steps_per_stage=1, max_layer=12)
+        ctl._set_threshold_value([1e5] * ctl.real_num_exit)
+        with pytest.raises(NotImplementedError):
+            model(vision_x=g["rgb"][0].cuda(), lang_x=ids, attention_mask=mask, vision_gripper=g["grip"][0].cuda(),
+                  state_tensor=g["state"][0].cuda(), exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
+        return
+    model.clear_all_exit_memory()
+    ctl = ExitController(vn, model.get_all_exit_idx(), steps_per_stage=1, leq=True, exit_dist="exp", max_layer=int(g["dyn_max_layer"]))
+    ctl._set_threshold_value([float(t) for t in g["dyn_thr"]])
+    for s in range(n):
+        ctl.module.set_timestep(s)
+        o = model(vision_x=g["rgb"][s].cuda(), lang_x=ids, attention_mask=mask, vision_gripper=g["grip"][s].cuda(),
+                  return_feature=True, deterministic=True, exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
+        assert o.exit_layer == int(g["dyn_exit"][s]), s
+        assert float((o.logits[0].cpu() - g["dyn_pose"][s]).abs().max()) < tol
+        assert float((o.logits[1].cpu() - g["dyn_grip"][s]).abs().max()) < tol
+
+
+def test_sep_resampler_env_batch_matches_single_environment_runs():
+    """sep_resampler with an env batch: frames are ordered camera-major inside the engine (one vision chain per camera, own Perceiver
+    weights) and the media tokens are scattered back env-major - every environment must equal its own one-environment run bit for bit
+    on the media tokens and within rounding on the action."""
+    from deer_vla_amd.config import deer_tiny
+    from deer_vla_amd.engine import DeerEngine
+    cfg = deer_tiny(sep_resampler=True)
+    sd = syn.make_synthetic_state(cfg, 5, bf16_round=True)
+    B = 3
+    one = DeerEngine(cfg, sd, n_envs=1)
+    bat = DeerEngine(cfg, sd, n_envs=B)
+    inp = [syn.synthetic_step_inputs(cfg, 0, rank=e, text_len=11, text_seed=7) for e in range(B)]
+    rgb = torch.stack([p[0] for p in inp]).cuda()
+    grip = torch.stack([p[1] for p in inp]).cuda()
+    ids = torch.cat([p[2] for p in inp]).cuda()
+    rb = bat.step(rgb, grip, ids, None, exit_id=3)
+    vis_b = bat.vis_x_f32.clone().view(B, 2 * cfg.perc_latents, cfg.vit_width)
+    for e in range(B):
+        one.reset()
+        r1 = one.step(inp[e][0].cuda(), inp[e][1].cuda(), inp[e][2].cuda(), None, exit_id=3)
+        assert torch.equal(one.vis_x_f32.view(2 * cfg.perc_latents, cfg.vit_width), vis_b[e]), e
+        assert float((r1["pose"] - rb[e]["pose"]).abs().max()) < 1e-3

@@ -254,3 +254,50 @@ def test_postprocess_action():
     assert a.shape == (7,) and float(a[-1]) == 1.0
     a = orc.postprocess_action(pose, torch.tensor([[[0.2]]]))
     assert float(a[-1]) == -1.0
+
+
+def test_action_head_with_robot_state_matches_reference():
+    """DeterministicDecoder(use_state=True) (action_head.py:443-453,524-536): the embedded robot state is added to the pooled feature."""
+    cfg, seed, g = load("head_state.npz")
+    assert cfg.use_state
+    sd = state(cfg, seed)
+    head = orc.OracleHead(sd, cfg)
+    head.window_size = 1
+    for t in range(g["feats"].shape[0]):
+        a, gr = head(g["feats"][t], state_tensor=g["state"][t], update_hidden_state=bool(g["upd"][t]))
+        close(a, g["pose"][t])
+        close(gr, g["grip"][t])
+
+
+@pytest.mark.parametrize("name", ["deer_forward_state.npz", "deer_forward_sep.npz"])
+def test_forward_variants_match_reference_mptflamingo(name):
+    """``use_state`` (state embedding in the action head; static exits only - the reference's dynamic exit raises TypeError with it,
+    value_net.py:122-129, recorded in the fixture) and ``sep_resampler`` (own Perceiver weights for the gripper camera,
+    flamingo_mpt.py:132-134,656-659), against the reference's own MPTFlamingo.forward."""
+    cfg, seed, g = load(name)
+    from deer_vla_amd import synthetic as syn
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=bool(int(g["bf16_round"])))
+    model = orc.OracleDeer(sd, cfg)
+    model.set_all_exit_window_size(1)
+    ids, mask, rgb, grip, st = g["ids"].long(), g["mask"].bool(), g["rgb"], g["grip"], g["state"]
+    close(model.encode_vision(rgb[-1], grip[-1]), g["vis_x"], atol=1e-5)
+    for eid in (3, 4):
+        model.clear_all_exit_memory()
+        for s in range(rgb.shape[0]):
+            o = model.forward(rgb[s], ids, mask, grip[s], state_tensor=st[s], exit_id=eid)
+            close(o["logits"][0], g[f"static{eid}_pose"][s], atol=1e-5)
+            close(o["logits"][1], g[f"static{eid}_grip"][s], atol=1e-5)
+    if cfg.use_state:
+        assert int(g["dynamic_raises"]) == 1
+        return
+    model.clear_all_exit_memory()
+    exit_ids = cfg.exit_ids()
+    vn = orc.OracleValueNet(exit_ids, model.extra_exit, cfg.exit_interval, cfg.window_size, "L2")
+    ctl = orc.OracleExitController(vn, exit_ids, steps_per_stage=1, max_layer=int(g["dyn_max_layer"]))
+    ctl._set_threshold_value([float(t) for t in g["dyn_thr"]])
+    for s in range(rgb.shape[0]):
+        ctl.set_timestep(s)
+        o = model.forward(rgb[s], ids, mask, grip[s], dynamic_early_exit=True, exit_controller=ctl)
+        assert o["exit_layer"] == int(g["dyn_exit"][s]), s
+        close(o["logits"][0], g["dyn_pose"][s], atol=1e-5)
+        close(o["logits"][1], g["dyn_grip"][s], atol=1e-5)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel mean of rocprofv3 --pmc counters from its CSV output (counter_collection.csv).
 usage: pmc_summary.py <dir-or-csv> [out.txt]
-       pmc_summary.py --traffic <fetch-dir> <write-dir> <out.json>    (per-class HBM bytes per launch for bench.py)   (FETCH_SIZE/WRITE_SIZE are reported in KiB by rocprofv3; gfx950 FETCH_SIZE
+       pmc_summary.py --traffic <out.json> <workload key> <fetch-dir> <write-dir> [...]    (per-class HBM bytes per launch, per workload, for bench.py)   (FETCH_SIZE/WRITE_SIZE are reported in KiB by rocprofv3; gfx950 FETCH_SIZE
 under-reports wide coalesced reads by 2x - see /opt/skills/guides/MI355X_MICROARCH.md 'HBM' - the x2 column applies it)"""
 import csv
 import glob
@@ -10,7 +10,8 @@ import sys
 from collections import defaultdict
 
 
-CLASS_OF = (("gemm_tiled", "deer_gemm_bf16_nt"), ("gemm_skinny", "deer_gemm_skinny"), ("attn_mfma_kernel<false>", "deer_attn_mfma_hd64"),
+CLASS_OF = (("gemm_tiled", "deer_gemm_bf16_nt"), ("gemm_ring", "deer_gemm_bf16_nt"), ("gemm_skinny_hl", "deer_gemm_skinny_hl"),
+            ("gemm_skinny", "deer_gemm_skinny"), ("slab_gelu_split", "deer_slab_gelu_split"), ("attn_mfma_kernel<false>", "deer_attn_mfma_hd64"),
             ("attn_mfma_kernel<true>", "deer_xattn_mfma"), ("resadd_ln", "deer_resadd_ln"), ("ln_rows", "deer_layernorm_rows"),
             ("head_lstm", "deer_head_lstm_layer"))
 
@@ -31,21 +32,26 @@ def per_class(src):
     return agg
 
 
-def traffic(fetch_dir, write_dir, out):
+def traffic(out, triples):
+    """triples: [workload key, fetch dir, write dir, ...] -> {"workloads": {key: {"kernel_source_hash", "classes": {...}}}}"""
     import json
-    f, w = per_class(fetch_dir), per_class(write_dir)
-    classes = {}
-    for cls in f:
-        fk = f[cls][0] / max(f[cls][1], 1)                     # KiB per dispatch as reported
-        wk = w[cls][0] / max(w[cls][1], 1) if cls in w else 0.0
-        classes[cls] = {"fetch_kib_reported": round(fk, 1), "write_kib_reported": round(wk, 1), "dispatches": f[cls][1],
-                        "hbm_bytes_per_launch": int(round((2.0 * fk + wk) * 1024))}
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench                                          # the stamp bench.py checks: hash of the kernel sources profiled
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, full-depth steps; FETCH_SIZE x2 (gfx950 "
-                       "128-B requests tallied at 64 B), WRITE_SIZE as reported", "kernel_source_hash": bench.kernel_source_hash(),
-               "classes": classes}, open(out, "w"), indent=1)
-    print(json.dumps(classes, indent=1))
+    stamp = bench.kernel_source_hash()
+    wls = {}
+    for i in range(0, len(triples), 3):
+        key, fetch_dir, write_dir = triples[i:i + 3]
+        f, w = per_class(fetch_dir), per_class(write_dir)
+        classes = {}
+        for cls in f:
+            fk = f[cls][0] / max(f[cls][1], 1)                     # KiB per dispatch as reported
+            wk = w[cls][0] / max(w[cls][1], 1) if cls in w else 0.0
+            classes[cls] = {"fetch_kib_reported": round(fk, 1), "write_kib_reported": round(wk, 1), "dispatches": f[cls][1],
+                            "hbm_bytes_per_launch": int(round((2.0 * fk + wk) * 1024))}
+        wls[key] = {"kernel_source_hash": stamp, "classes": classes}
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, full-depth steps of the named workload; FETCH_SIZE x2 "
+                       "(gfx950 128-B requests tallied at 64 B), WRITE_SIZE as reported", "workloads": wls}, open(out, "w"), indent=1)
+    print(json.dumps(wls, indent=1))
 
 
 def mfma(src, out):
@@ -77,7 +83,7 @@ def mfma(src, out):
 
 def main():
     if sys.argv[1] == "--traffic":
-        return traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+        return traffic(sys.argv[2], sys.argv[3:])
     if sys.argv[1] == "--mfma":
         return mfma(sys.argv[2], sys.argv[3])
     src = sys.argv[1]
