@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
                                                         float scale, int q_slabs, long q_slab_stride,
                                                         const int* __restrict__ text_time, int n_per_media, int out_is_f32,
                                                         const int* ctl, const bf16_t* __restrict__ K2,
-                                                        const bf16_t* __restrict__ V2, int kv1, int ld2, long bstride2, int qtpw) {
+                                                        const bf16_t* __restrict__ V2, int kv1, int ld2, long bstride2, int tpw) {
   DEER_RETURN_IF_EXITED(ctl);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int kvpad = (kv_len + 31) & ~31;
@@ -50,10 +50,10 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
   const bf16_t* Kb2 = K2 != nullptr ? K2 + b * bstride2 + h * AM_HD : nullptr;
   const bf16_t* Vb2 = V2 != nullptr ? V2 + b * bstride2 + h * AM_HD : nullptr;
 
-  // qtpw query tiles per wave (wave w: tiles w, w + NWAVE, ...): with qtpw = ceil(q tiles / NWAVE) ONE workgroup serves a whole
-  // (head, image) and the head's K/V are staged once instead of once per 64-128 queries (env batches: 16 frames x 16 heads = 256
-  // workgroups of 8 waves; r03: 23.5 -> see profiles/r03_*classes_env_batch_8*)
-  int q0 = blockIdx.x * (16 * NWAVE * qtpw) + wave * 16;
+  // A workgroup serves tpw 16-query tiles of one (head, image); wave w takes tiles w, w + NWAVE, ...  tpw = NWAVE is one tile per
+  // wave; env batches (>= 128 (head, image) pairs fill the chip anyway) use tpw = 9 for the ViT's 17 tiles: two workgroups per pair
+  // instead of three (one of which held a single query row), so the head's K/V are staged twice instead of three times
+  int q0 = (blockIdx.x * tpw + wave) * 16;
 
   // Q fragments first (MFMA "B" operand: B[k = d][n = query]; rows >= q_len are zero): their global-load latency
   // overlaps the K/V staging below instead of following the barrier
@@ -112,9 +112,9 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
   __syncthreads();
 
   const int nt = kvpad >> 4;
-  for (int it = 0; it < qtpw; ++it, q0 += 16 * NWAVE) {
+  for (int ti = wave; ti < tpw; ti += NWAVE, q0 += 16 * NWAVE) {
   if (q0 >= q_len) break;
-  if (it > 0) load_q();
+  if (ti >= NWAVE) load_q();
 
   // ---- S^T tiles: s[t][r] = S[q = c][key = t*16 + g*4 + r] ----
   f32x4 s[AM_MAXT];
@@ -237,12 +237,15 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
   // env batches (>= 128 (head, image) pairs: the chip is full with ONE workgroup per pair): every wave walks several query tiles
   // and the head's K/V are staged once; at one environment (16-32 pairs) the queries stay spread over more workgroups
   static const bool loop_ok = [] { const char* e = getenv("DEER_ATTN_LOOP"); return e == nullptr || e[0] != '0'; }();
-  const int per_wg = wide ? 128 : 64;
-  int qtpw = 1;
-  if (loop_ok && wide && (long)heads * batch >= 128) qtpw = (q_len + per_wg - 1) / per_wg;
-  dim3 grid((q_len + per_wg * qtpw - 1) / (per_wg * qtpw), heads, batch);
+  const int nwave = wide ? 8 : 4, tiles = (q_len + 15) / 16;
+  int tpw = nwave;
+  if (loop_ok && wide && (long)heads * batch >= 128) {
+    const int n_wg = (tiles + nwave) / (nwave + 1);          // at most one extra tile for a workgroup's first wave(s)
+    tpw = (tiles + n_wg - 1) / n_wg;
+  }
+  dim3 grid((tiles + tpw - 1) / tpw, heads, batch);
 #define DEER_ATTN_ARGS Q, kp, vp, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride, scale, q_slabs, \
-                       q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2, qtpw
+                       q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2, tpw
   if (q_slabs > 0)
     hipLaunchKernelGGL((attn_mfma_kernel<true, 4>), grid, dim3(256), smem, st, DEER_ATTN_ARGS);
   else if (wide)
