@@ -26,7 +26,7 @@
 // Optional extras (gated x-attn inside the LLM, helpers.py:192-232): Q given as f32 split-K partial slabs
 // (q_slabs > 0: Q points to f32, reduced while loading), keys masked by media time (text_time[q] == key/n_per_media + 1,
 // rows with text_time == 0 zeroed), f32 output, early-exit control block.
-template <bool XATTN, int NWAVE>
+template <bool XATTN, int NWAVE, bool LOOP = false>
 __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __restrict__ Qv, const bf16_t* __restrict__ Kp,
                                                         const bf16_t* __restrict__ V, void* __restrict__ Ov,
                                                         int q_len, int kv_len, int ldq, int ldk, int ldv, int ldo,
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
   // A workgroup serves tpw 16-query tiles of one (head, image); wave w takes tiles w, w + NWAVE, ...  tpw = NWAVE is one tile per
   // wave; env batches (>= 128 (head, image) pairs fill the chip anyway) use tpw = 9 for the ViT's 17 tiles: two workgroups per pair
   // instead of three (one of which held a single query row), so the head's K/V are staged twice instead of three times
-  int q0 = (blockIdx.x * tpw + wave) * 16;
+  // (LOOP = false keeps the single-tile form: the loop costs SGPR spills, seen as +12 % on the one-environment launches)
+  int q0 = (blockIdx.x * (LOOP ? tpw : NWAVE) + wave) * 16;
 
   // Q fragments first (MFMA "B" operand: B[k = d][n = query]; rows >= q_len are zero): their global-load latency
   // overlaps the K/V staging below instead of following the barrier
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
   __syncthreads();
 
   const int nt = kvpad >> 4;
-  for (int ti = wave; ti < tpw; ti += NWAVE, q0 += 16 * NWAVE) {
+  for (int ti = wave; ti < (LOOP ? tpw : NWAVE); ti += NWAVE, q0 += 16 * NWAVE) {
   if (q0 >= q_len) break;
-  if (ti >= NWAVE) load_q();
+  if (LOOP && ti >= NWAVE) load_q();
 
   // ---- S^T tiles: s[t][r] = S[q = c][key = t*16 + g*4 + r] ----
   f32x4 s[AM_MAXT];
@@ -222,6 +223,8 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
                             max_smem) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             max_smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            max_smem) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             max_smem) != hipSuccess)
       return DEER_ERR_LAUNCH;
@@ -248,6 +251,8 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
                        q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2, tpw
   if (q_slabs > 0)
     hipLaunchKernelGGL((attn_mfma_kernel<true, 4>), grid, dim3(256), smem, st, DEER_ATTN_ARGS);
+  else if (wide && tpw != nwave)
+    hipLaunchKernelGGL((attn_mfma_kernel<false, 8, true>), grid, dim3(512), smem, st, DEER_ATTN_ARGS);
   else if (wide)
     hipLaunchKernelGGL((attn_mfma_kernel<false, 8>), grid, dim3(512), smem, st, DEER_ATTN_ARGS);
   else

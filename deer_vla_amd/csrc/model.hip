@@ -24,10 +24,12 @@ constexpr float kEps = 1e-5f;
 constexpr int kVitHeadLayers = 3;   // ViT blocks in the first piece of a vision chain (short graph: the GPU idles until it is submitted)
 constexpr int kMaxRows = 128;       // LLM rows (n_envs * T) the skinny GEMM takes
 constexpr int kMaxSplit = 32;
-// LLM rows from which the trunk projections run on deer_gemm_skinny_hl (pre-split hi/lo activation planes, LDS-DMA ring, 128-column
-// workgroups): 4+ environments.  Below, the weight-streaming deer_gemm_skinny (f32 activation split in the kernel) is HBM-bound and faster.
+// LLM rows ABOVE which the trunk projections run on deer_gemm_skinny_hl (pre-split hi/lo activation planes, LDS-DMA ring, 128-column
+// workgroups, GELU/slab reduction once per layer).  Default 0 = always (r03, full-depth step as one graph: 3.79 -> 3.59 ms at one
+// environment, 4.84 -> 4.39 at two, 5.56 -> 4.94 at three, 8.90 -> 8.01 at eight); DEER_SKINNY_HL_MIN=128 selects deer_gemm_skinny
+// (f32 activation split inside the kernel) everywhere.  The fp32 arithmetic (two weight planes) always uses deer_gemm_skinny.
 int hl_min_rows() {
-  static const int v = [] { const char* e = getenv("DEER_SKINNY_HL_MIN"); return e ? atoi(e) : 48; }();
+  static const int v = [] { const char* e = getenv("DEER_SKINNY_HL_MIN"); return e ? atoi(e) : 0; }();
   return v;
 }
 
