@@ -40,7 +40,26 @@ __device__ __forceinline__ void p8_wait_vmcnt() {
 //  * LDS rows of 64 bytes: the 16-byte slot of a row is XOR-swizzled with f((row >> 2) & 3), f = {0, 2, 3, 1}, which makes every
 //    16-lane group of a ds_read_b128 fragment read hit 16 distinct 16-byte bank units (rows c = 0..15 of a tile, slot g);
 //  * one counted vmcnt + ONE raw s_barrier per K-step, every wave issues exactly CPW DMAs per step.
-template <int BM, int BN, int D>
+// a raw workgroup barrier that neither the IR optimiser nor the machine scheduler moves LDS reads / DMAs / MFMAs across
+#define BIGM_SYNC()                             \
+  do {                                          \
+    asm volatile("" ::: "memory");              \
+    __builtin_amdgcn_sched_barrier(0);          \
+    __builtin_amdgcn_s_barrier();               \
+    __builtin_amdgcn_sched_barrier(0);          \
+    asm volatile("" ::: "memory");              \
+  } while (0)
+
+// STAG: the 16 waves run as TWO GROUPS of 8 (one wave row pair each; two waves of either group on every SIMD), group 1 one barrier
+// behind group 0, and a K-step has two barriers (fragment reads + DMA issue | MFMAs): while one group issues its 16 MFMAs the other
+// reads its fragments and issues its DMAs.  With ONE barrier per K-step every wave leaves the barrier in the same phase - 16 waves
+// read fragments (LDS busy, matrix pipe idle), then 16 waves issue MFMAs (matrix pipe busy, LDS idle): 512 + 1024 cycles per step
+// measured as ~2000 (ring32, 31 us per 256x256x1024 tile) although the same DMA pattern alone runs at 92 GB/s per CU = 11.4 us per
+// tile (tools/fill_share.hip).  Hazards (interval = time between two barrier events; group 0 reads stage k in interval 2k and issues
+// its MFMAs in 2k+1, group 1 one interval later): a slot read in interval Y may be refilled from Y+2 on - READ(k) refills the slot of
+// stage k-2 with stage k+D-2; a wave's counted vmcnt in READ(k) retires stage k+1, which group 0 reads from interval 2k+2 on (after
+// the barrier that follows group 1's wait).
+template <int BM, int BN, int D, bool STAG = false>
 __global__ __launch_bounds__(1024) void gemm_ring32_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
                                                             const bf16_t* __restrict__ W, int ldw, long strideW,
                                                             const float* __restrict__ bias, void* __restrict__ Cv, int ldc,
@@ -111,6 +130,37 @@ __global__ __launch_bounds__(1024) void gemm_ring32_kernel(const bf16_t* __restr
   // valid MFMA row tiles of this wave (ragged last row tile)
   const int mv = max(0, min(TM, (M - (m0 + wm * (BM / 4)) + 15) >> 4));
 
+  if constexpr (STAG) {
+    static_assert(D >= 4, "staggered groups: stage k+1 must be resident while stage k is consumed and stage k-1 still read");
+    constexpr int AHEAD = D - 2;
+    const int grp = wave >> 3;
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) issue(t);
+    p8_wait_vmcnt<(AHEAD - 1) * CPW>();         // stage 0 landed
+    BIGM_SYNC();
+    if (grp == 1) BIGM_SYNC();                  // group 1 runs one barrier behind group 0
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned char* st = smem + (kt % D) * STAGE;
+      bf16x8 af[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) af[j] = *reinterpret_cast<const bf16x8*>(st + a_off + j * 16 * 64);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + w_off + i * 16 * 64);
+      issue(kt + AHEAD);                        // into the slot of stage kt-2
+      p8_wait_vmcnt<(AHEAD - 1) * CPW>();       // stage kt+1 landed (this wave's part)
+      BIGM_SYNC();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        if (j < mv) {
+#pragma unroll
+          for (int i = 0; i < TN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+      BIGM_SYNC();
+    }
+    if (grp == 0) BIGM_SYNC();
+  } else {
 #pragma unroll
   for (int t = 0; t < D - 1; ++t) issue(t);
   for (int kt = 0; kt < nk; ++kt) {
@@ -129,6 +179,7 @@ __global__ __launch_bounds__(1024) void gemm_ring32_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < TN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
       }
+  }
   }
   p8_wait_vmcnt<0>();
 
@@ -305,14 +356,14 @@ static int launch_ring272(const bf16_t* A, int lda, long strideA, const bf16_t* 
   return DEER_OK;
 }
 
-template <int BM, int BN, int D>
+template <int BM, int BN, int D, bool STAG = false>
 static int launch_ring32(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
                          int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl,
                          hipStream_t st) {
   if ((N & 15) || (K & 31) || M <= 0 || batch <= 0) return DEER_ERR_SHAPE;
   constexpr int smem_bytes = D * (BM + BN) * 64;
   static bool attr_set = false;
-  auto kern = &gemm_ring32_kernel<BM, BN, D>;
+  auto kern = &gemm_ring32_kernel<BM, BN, D, STAG>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
       return DEER_ERR_LAUNCH;
@@ -338,6 +389,10 @@ int deer_launch_gemm_ring32(int variant, const bf16_t* A, int lda, long strideA,
     case 3: return launch_ring32<256, 256, 2>(P8_ARGS);
     case 4: return launch_ring32<256, 256, 3>(P8_ARGS);
     case 5: return launch_ring32<128, 128, 5>(P8_ARGS);
+    case 8: return launch_ring32<256, 256, 5, true>(P8_ARGS);   // staggered wave groups, two barriers per K-step
+    case 9: return launch_ring32<128, 128, 5, true>(P8_ARGS);
+    case 10: return launch_ring32<256, 256, 4, true>(P8_ARGS);
+    case 11: return launch_ring32<128, 128, 8, true>(P8_ARGS);
     case 6: return launch_ring272<3>(P8_ARGS);              // one camera frame (257 rows) per row tile, 99 KB ring
     case 7: return launch_ring272<4>(P8_ARGS);              // the same, 132 KB ring
     default: return DEER_ERR_SHAPE;

@@ -402,7 +402,13 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
       // 192x128 / 128x192 tiles (8 waves, 48x64 wave tiles: 14 fragment reads per 24 MFMAs instead of 8 per 8) is made on the
       // number of half-rounds each needs on the 256 CUs; a 192-row/column tile costs ~1.35x a 128x128 one (tools/bench_vendor_gemm.py)
       tile = big_tile;
-      if (big_sel) {
+      // 256x256 tiles (16 waves in two staggered groups, 32-column K-steps, csrc/gemm_bigm.hip) when they fill the chip in exactly ONE
+      // round - ViT in_proj at 16 frames: 17 x 12 = 204 workgroups, 36.4 us against 41.1 (r03, profiles/r03_c_bigm_gemm_4112_stag.txt);
+      // with more tiles than CUs the second round costs more than the larger tile returns (c_fc at 16 frames: 272 tiles, 55 vs 45 us)
+      static const bool sel256 = [] { const char* e = getenv("DEER_GEMM_256"); return e == nullptr || e[0] != '0'; }();
+      const long n256 = nblk(256, 256);
+      if (sel256 && big_sel && (N & 255) == 0 && (K & 31) == 0 && n256 >= 192 && n256 <= 256) tile = 61;
+      else if (big_sel) {
         auto cost = [&](int bm, int bn, float rel) { return (float)((nblk(bm, bn) + 255) / 256) * rel; };
         float best = cost(128, 128, 1.0f);
         if (cost(192, 128, 1.35f) < best) { best = cost(192, 128, 1.35f); tile = 39; }
@@ -462,7 +468,7 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     case 43: return launch_ring<128, 192, 2, 4, 2>(DEER_ARGS);       // 8 waves (64x48), 80 KB
     case 45: return launch_ring<128, 192, 4, 2, 2>(DEER_ARGS);       // 8 waves (32x96), 80 KB
     case 46: return launch_ring<96, 128, 2, 2, 3>(DEER_ARGS);        // 4 waves (48x64), 84 KB
-    case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58:            // 16 waves, 32-column K-steps, deep ring (csrc/gemm_bigm.hip)
+    case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59: case 60: case 61: case 62:            // 16 waves, 32-column K-steps, deep ring (csrc/gemm_bigm.hip)
       return deer_launch_gemm_ring32(tile - 51, DEER_ARGS);
     case 26: return launch_ring<64, 64, 2, 4, 4, 0, 1, 1>(DEER_ARGS);    // register-pipelined K loop (fragments of k+1 read under the MFMAs of k)
     case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)
