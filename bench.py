@@ -405,9 +405,11 @@ def pmc_traffic(kernel_class, workload_key):
 
 
 def kernel_source_hash():
-    """hash of the DEVICE code sources: csrc/*.h and every csrc/*.hip that defines a kernel (host-only files, e.g. the native step
-    driver, do not change what a PMC pass measures)"""
+    """hash of the DEVICE code: csrc/*.h and every csrc/*.hip that defines a kernel (host-only files, e.g. the native step driver, do
+    not change what a PMC pass measures), with `//` comments and blank lines stripped - rewording a comment does not make a profile
+    stale, changing an instruction does"""
     import hashlib
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "deer_vla_amd", "csrc")
     for f in sorted(os.listdir(d)):
@@ -415,7 +417,12 @@ def kernel_source_hash():
             with open(os.path.join(d, f), "rb") as fh:
                 src = fh.read()
             if f.endswith(".h") or b"__global__" in src:
-                h.update(src)
+                code = []
+                for line in src.decode("utf-8", "replace").splitlines():
+                    line = re.sub(r"//.*$", "", line).rstrip()
+                    if line.strip():
+                        code.append(line)
+                h.update(f.encode() + b"\n" + "\n".join(code).encode())
     return h.hexdigest()[:16]
 
 

@@ -2,16 +2,14 @@
 //
 //   C[M,N] = epi( A[M,K] (bf16, row-major) * W[N,K]^T (bf16, nn.Linear layout) + bias[N] )
 //
-// What round 3 measured about these shapes (tools/fill_bench.hip, the ring-depth sweep of deer_gemm_skinny_hl, an 8-wave
-// 256x256 kernel on the guide's 8-phase schedule - two staggered wave rows, counted vmcnt once per K-tile - that reached only
-// 26 GB/s of tile fill per CU = 40 us per 256x256x1024 tile and was removed again):
-//  * the operand stream of a GEMM tile (rows of A shared by a tile row, rows of W shared by a tile column, all CUs in step) enters a
-//    CU's LDS at 33-38 GB/s however it is asked for: ring depth 2..5 gives the same time (rate-bound, not latency-bound), 16 issuing
-//    waves are ~25 % better than 8, hipBLASLt's own kernels sit at the same per-CU rate (its 29.8 us for 4112x3072x1024 = 35 GB/s per CU
-//    with 256x256 tiles);
-//  * so the levers are FLOP per staged byte (256-row x 256-column tiles: 128 FLOP/B against 64 for the 128x128 kernels of
-//    gemm_tiled.hip) and not wasting CUs on ragged tiles: M = 257 n is never a multiple of a power-of-two tile, and a ragged tile of
-//    8-16 valid rows costs 3/4 of a full one (the DMA instruction count, not the bytes, is what a CU pays for).
+// What round 3 measured about these shapes (tools/fill_share.hip, tools/bench_vendor_gemm.py; an 8-wave 256x256 kernel on
+// the guide's 8-phase schedule was also written, measured at 40 us per 256x256x1024 tile and removed again):
+//  * a 256x256x1024 tile takes 30-32 us in these kernels for ring depth 2..5 and with or without the staggered two-barrier schedule
+//    (~46 % of the matrix pipe inside a tile; the guide's best plain-HIP GEMM sits at 53-60 %); the LDS-DMA path is NOT what it waits
+//    for - DMAs alone move 92 GB/s per CU on a GEMM-like shared stream (11.4 us per tile pass);
+//  * what separates the shapes is tile quantisation on 256 CUs: M = 257 n is never a multiple of a power-of-two tile (a ragged tile of
+//    8-16 valid rows costs 3/4 of a full one), in_proj at 16 frames is 204 256x256 tiles (one round), c_fc 272 (two rounds);
+//    hipBLASLt's 29-32 us on in_proj is ONE 256x256 tile time plus a shorter prologue / epilogue.
 // Two kernels, both the ring structure of gemm_tiled.hip with 32-column K-steps (so that 256-row tiles still leave room for a ring):
 //  * gemm_ring32_kernel: BM x BN in {256x256, 128x128}, 16 waves as 4 x 4;
 //  * gemm_ring272_kernel: ONE IMAGE PER ROW TILE - 257 valid rows computed as 17 MFMA row tiles (272 rows; the 15 extra rows are
@@ -32,10 +30,7 @@ __device__ __forceinline__ void p8_wait_vmcnt() {
 
 // ------------------------------------------------------------------------------------------------------------------------
 // ring32: the ring structure of gemm_tiled.hip with 32-column K-steps, so that a 256x256 tile (128 FLOP per staged byte, twice
-// the 128x128 kernels) still has 3-4 stages IN FLIGHT inside 160 KB of LDS (5 x 32 KB).  Measured r03 (tools/fill_bench, the depth
-// sweep of deer_gemm_skinny_hl, the 8-phase kernel above): on these streams a CU's LDS-DMA path sustains 26-38 GB/s with 8 waves
-// issuing and is rate-bound, not latency-bound (ring depth 2..5 gives the same time) - the two levers are waves issuing (16 here:
-// 44-51 -> 64-72 GB/s per CU in the microbenchmark) and FLOP per staged byte.
+// the 128x128 kernels) still has 3-4 stages IN FLIGHT inside 160 KB of LDS (5 x 32 KB).
 //  * 16 waves as 4 x 4, wave tile (BM/4) x (BN/4) (64x64: 4x4 MFMA tiles, 64 accumulator VGPRs, 8 ds_read_b128 per 16 MFMAs);
 //  * LDS rows of 64 bytes: the 16-byte slot of a row is XOR-swizzled with f((row >> 2) & 3), f = {0, 2, 3, 1}, which makes every
 //    16-lane group of a ds_read_b128 fragment read hit 16 distinct 16-byte bank units (rows c = 0..15 of a tile, slot g);
