@@ -113,6 +113,11 @@ __device__ __forceinline__ float4 slab_sum4(const float* __restrict__ p, int s_i
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
+// the bf16-output GEMM epilogues: v_exp_f32 + v_rcp_f32 (1 ulp each, the result is rounded to bf16) instead of the IEEE division
+// sequence - in a one-round 257 x 256 tile the activation of 68 outputs per lane is serial time at the end of the launch
+__device__ __forceinline__ float quick_gelu_bf(float x) {
+  return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669596f * x));   // 1.702 * log2(e)
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // Kernels on the early-exit path return at entry once the exit flag is set (device-side

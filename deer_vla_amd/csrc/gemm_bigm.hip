@@ -10,11 +10,17 @@
 //  * what separates the shapes is tile quantisation on 256 CUs: M = 257 n is never a multiple of a power-of-two tile (a ragged tile of
 //    8-16 valid rows costs 3/4 of a full one), in_proj at 16 frames is 204 256x256 tiles (one round), c_fc 272 (two rounds);
 //    hipBLASLt's 29-32 us on in_proj is ONE 256x256 tile time plus a shorter prologue / epilogue.
-// Two kernels, both the ring structure of gemm_tiled.hip with 32-column K-steps (so that 256-row tiles still leave room for a ring):
+//  * a launch has ~8 us that do not scale with K (K sweep): the epilogue was store-ISSUE bound (a lane holds 4 columns
+//    of one row: a wave store touches 16 rows x 32 bytes) and the activation of 68 outputs per lane is serial time at the end of a
+//    one-round launch - the frame kernel stages bf16 results through LDS and stores whole lines, and uses quick_gelu_bf.
+// Three kernels, all the ring structure of gemm_tiled.hip with 32-column K-steps (so that 256-row tiles still leave room for a ring):
 //  * gemm_ring32_kernel: BM x BN in {256x256, 128x128}, 16 waves as 4 x 4;
 //  * gemm_ring272_kernel: ONE IMAGE PER ROW TILE - 257 valid rows computed as 17 MFMA row tiles (272 rows; the 15 extra rows are
 //    the next image's first rows, computed and dropped): M = 257 n tiles exactly into n row tiles, 16 x 16 = 256 workgroups for the
-//    c_fc GEMM of 16 frames (one round on 256 CUs instead of 272 tiles), 16 x 12 for in_proj.
+//    c_fc GEMM of 16 frames (one round on 256 CUs instead of 272 tiles), 16 x 12 for in_proj; wave row 0 carries the 17th row tile
+//    (5 | 4 | 4 | 4) - kept as the measured baseline of
+//  * gemm_frame_kernel: the same row tile with the 17th MFMA row tile dealt out one 16 x 16 tile per wave (auto-selected by
+//    gemm_dispatch when frames x N / BN is one round of 192-256 workgroups).
 #include "common.h"
 #include <type_traits>
 
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(1024) void gemm_ring32_kernel(const bf16_t* __restr
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + off) = float4{v0, v1, v2, v3};
       } else {
         if (epi == P8_EPI_QGELU_BF16) {
-          v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3);
+          v0 = quick_gelu_bf(v0); v1 = quick_gelu_bf(v1); v2 = quick_gelu_bf(v2); v3 = quick_gelu_bf(v3);
         } else if (epi == P8_EPI_GELU_BF16) {
           v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
         }
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(1024) void gemm_ring272_kernel(const bf16_t* __rest
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + off) = float4{v0, v1, v2, v3};
       } else {
         if (epi == P8_EPI_QGELU_BF16) {
-          v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3);
+          v0 = quick_gelu_bf(v0); v1 = quick_gelu_bf(v1); v2 = quick_gelu_bf(v2); v3 = quick_gelu_bf(v3);
         } else if (epi == P8_EPI_GELU_BF16) {
           v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
         }
@@ -347,6 +353,174 @@ static int launch_ring272(const bf16_t* A, int lda, long strideA, const bf16_t* 
   const int tiles = ((M + tile_rows - 1) / tile_rows) * (N >> 8);
   hipLaunchKernelGGL(kern, dim3(tiles, 1, batch), dim3(1024), smem_bytes, st, A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N,
                      K, epi, tile_rows, gate, ctl);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// One camera frame per row tile, BALANCED: the 16 waves (or 8) are 4 wave rows x WN wave columns, every wave owns 4 x TN MFMA tiles of
+// the frame's first 256 rows and the 17th row tile (the frame's 257th row) is dealt out one 16x16 tile per wave - wave (wm, wn) takes
+// column tile wm of its own column group, whose W fragment it already holds - so a K-step is 4*TN + 1 MFMAs on every wave with wm < TN
+// instead of wave row 0 carrying 5*TN (ring272 above: +25 % on the critical path for +6 % work).  BN = 16 * WN * TN columns per
+// workgroup: 16 frames x N / BN is exactly 256 workgroups for in_proj (BN = 192), c_fc (BN = 256) and the N = 1024 projections (BN = 64
+// or BN = 128 with two K halves) - one round on the 256 CUs where M = 257 n never tiles into powers of two.
+// A stage is 17 A chunks + BN / 16 W chunks of 1 KiB (16 rows x 64 B, the swizzle of ring32); chunk q = wave + i * NW; the first N_HI
+// waves issue CPW DMAs per stage, the others CPW - 1 - each group runs the loop instantiated with its own counted vmcnt.
+template <int WN, int TN, int D>
+__global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
+                                                               const bf16_t* __restrict__ W, int ldw, long strideW,
+                                                               const float* __restrict__ bias, void* __restrict__ Cv, int ldc,
+                                                               long strideC, int M, int N, int K, int epi, int tile_rows,
+                                                               const float* __restrict__ gate, const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
+  constexpr int NW = 4 * WN, BN = 16 * WN * TN, CH = 17 + BN / 16, STAGE = CH * 1024;
+  constexpr int CPW = (CH + NW - 1) / NW, N_HI = CH - (CPW - 1) * NW;
+  static_assert(TN >= 1 && TN <= 4 && (WN == 2 || WN == 4), "wave grid");
+  static_assert(D * STAGE <= 160 * 1024 && (D - 2) * CPW <= 63, "LDS / vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int c = lane & 15, g = lane >> 4;
+
+  // contiguous run of tiles (column index fastest) per XCD: the workgroups of an XCD share few frames in its L2
+  const int tiles_n = N / BN;
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int xq = nb >> 3, xr = nb & 7, xcd = bid & 7;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  const int m0 = (tile / tiles_n) * tile_rows, n0 = (tile % tiles_n) * BN;
+  const int rows_valid = min(tile_rows, M - m0);
+  A += (long)blockIdx.z * strideA;
+  W += (long)blockIdx.z * strideW;
+
+  const int lr = lane >> 2;
+  const int ls = ((lane & 3) ^ ((0x1320 >> (((lr >> 2) & 3) * 4)) & 3)) * 8;
+  const bf16_t* sp[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int q = min(wave + i * NW, CH - 1);                 // wave-uniform: an A chunk or a W chunk
+    sp[i] = (q < 17) ? A + (long)min(m0 + q * 16 + lr, M - 1) * lda + ls : W + (long)min(n0 + (q - 17) * 16 + lr, N - 1) * ldw + ls;
+  }
+  const int nk = K >> 5;
+
+  f32x4 acc[TN][4], accx = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr_sw = (g ^ ((0x1320 >> (((c >> 2) & 3) * 4)) & 3)) << 4;
+  const int a_off = (wm * 64 + c) * 64 + fr_sw;
+  const int x_off = (256 + c) * 64 + fr_sw;
+  const int w_off = 17 * 1024 + (wn * TN * 16 + c) * 64 + fr_sw;
+  const bool has_x = wm < TN;
+
+  auto run = [&](auto cpw_tag) {
+    constexpr int CPWL = decltype(cpw_tag)::value;
+    auto issue = [&](int t) {
+      const int k0 = min(t, nk - 1) << 5;
+      unsigned char* st = smem + (t % D) * STAGE;
+#pragma unroll
+      for (int i = 0; i < CPWL; ++i)
+        __builtin_amdgcn_global_load_lds((p8_gptr_t*)(sp[i] + k0), (p8_lptr_t*)(st + (wave + i * NW) * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < D - 1; ++t) issue(t);
+    for (int kt = 0; kt < nk; ++kt) {
+      p8_wait_vmcnt<(D - 2) * CPWL>();
+      __builtin_amdgcn_s_barrier();
+      issue(kt + D - 1);
+      const unsigned char* st = smem + (kt % D) * STAGE;
+      bf16x8 af[4], wf[TN], afx;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const bf16x8*>(st + a_off + j * 1024);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + w_off + i * 1024);
+      if (has_x) afx = *reinterpret_cast<const bf16x8*>(st + x_off);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < TN; ++e)
+        if (wm == e) accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[e], afx, accx, 0, 0, 0);
+    }
+    p8_wait_vmcnt<0>();
+  };
+  if (wave < N_HI) run(std::integral_constant<int, CPW>{});
+  else run(std::integral_constant<int, CPW - 1>{});
+
+  const float gs = (epi == P8_EPI_RESADD_F32 && gate != nullptr) ? tanhf(*gate) : 1.f;
+  const bool to_bf16 = epi == P8_EPI_BF16 || epi == P8_EPI_QGELU_BF16 || epi == P8_EPI_GELU_BF16;
+  // bf16 outputs leave through LDS: the accumulator layout gives a lane 4 columns of ONE row (8 bytes; a wave store touches 16 rows,
+  // 32 bytes each - the epilogue of the direct form is store-ISSUE bound, ~5 us of a 40 us launch); staged, a lane stores 16 bytes
+  // of a row and a wave 1 KiB of whole 128-byte lines, half as many instructions.  Row pitch BN*2 + 16 bytes: the ds_write_b64 of a
+  // 16 x 16 tile (rows c, 8-byte slot g) and the ds_read_b128 rows are both conflict-free.
+  constexpr int CPITCH = BN * 2 + 16;
+  static_assert(272 * CPITCH <= 160 * 1024, "C staging tile");
+  auto store = [&](int r, int n, const f32x4& a) {            // row r of the frame, columns n0 + n .. n0 + n + 3
+    float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3];
+    if (bias != nullptr) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + n);
+      v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+    }
+    if (to_bf16) {
+      if (epi == P8_EPI_QGELU_BF16) {
+        v0 = quick_gelu_bf(v0); v1 = quick_gelu_bf(v1); v2 = quick_gelu_bf(v2); v3 = quick_gelu_bf(v3);
+      } else if (epi == P8_EPI_GELU_BF16) {
+        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+      }
+      *reinterpret_cast<uint2*>(smem + r * CPITCH + n * 2) = uint2{pack2bf(v0, v1), pack2bf(v2, v3)};
+      return;
+    }
+    if (r >= rows_valid) return;
+    const long off = (long)blockIdx.z * strideC + (long)(m0 + r) * ldc + n0 + n;
+    if (epi == P8_EPI_RESADD_F32) {
+      float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + off);
+      float4 rr = *p;
+      rr.x += gs * v0; rr.y += gs * v1; rr.z += gs * v2; rr.w += gs * v3;
+      *p = rr;
+    } else {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + off) = float4{v0, v1, v2, v3};
+    }
+  };
+  if (to_bf16) BIGM_SYNC();                                   // every wave has read its last fragments: the ring becomes the C tile
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = (wn * TN + i) * 16 + g * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) store(wm * 64 + j * 16 + c, n, acc[i][j]);
+  }
+  if (has_x) store(256 + c, (wn * TN + wm) * 16 + g * 4, accx);
+  if (to_bf16) {
+    BIGM_SYNC();
+    constexpr int PPR = BN / 8;                               // 16-byte pieces per row
+    const int pieces = rows_valid * PPR;
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv) + (long)blockIdx.z * strideC + (long)m0 * ldc + n0;
+    for (int p = tid; p < pieces; p += NW * 64) {
+      const int r = p / PPR, cp = p - r * PPR;
+      *reinterpret_cast<uint4*>(Cb + (long)r * ldc + cp * 8) = *reinterpret_cast<const uint4*>(smem + r * CPITCH + cp * 16);
+    }
+  }
+}
+
+template <int WN, int TN, int D>
+static int launch_frame(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
+                        int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl,
+                        hipStream_t st) {
+  constexpr int BN = 16 * WN * TN;
+  if ((N % BN) || (K & 31) || M <= 0 || batch <= 0) return DEER_ERR_SHAPE;
+  const int tile_rows = (M % 257 == 0) ? 257 : 256;         // M = 257 n (n camera frames): one frame per row tile
+  constexpr int ring_bytes = D * (17 + BN / 16) * 1024, c_bytes = 272 * (BN * 2 + 16);
+  constexpr int smem_bytes = ring_bytes > c_bytes ? ring_bytes : c_bytes;   // the ring, then the staged bf16 C tile
+  static bool attr_set = false;
+  auto kern = &gemm_frame_kernel<WN, TN, D>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
+      return DEER_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int tiles = ((M + tile_rows - 1) / tile_rows) * (N / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles, 1, batch), dim3(WN * 256), smem_bytes, st, A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M,
+                     N, K, epi, tile_rows, gate, ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
@@ -390,6 +564,15 @@ int deer_launch_gemm_ring32(int variant, const bf16_t* A, int lda, long strideA,
     case 11: return launch_ring32<128, 128, 8, true>(P8_ARGS);
     case 6: return launch_ring272<3>(P8_ARGS);              // one camera frame (257 rows) per row tile, 99 KB ring
     case 7: return launch_ring272<4>(P8_ARGS);              // the same, 132 KB ring
+    case 12: return launch_frame<4, 4, 4>(P8_ARGS);         // frame tiles, balanced 17th row tile: 257 x 256, 16 waves, 132 KB
+    case 13: return launch_frame<4, 3, 4>(P8_ARGS);         // 257 x 192, 16 waves, 116 KB
+    case 14: return launch_frame<4, 3, 5>(P8_ARGS);         // 257 x 192, 145 KB ring
+    case 15: return launch_frame<2, 4, 3>(P8_ARGS);         // 257 x 128, 8 waves, 75 KB: two workgroups per CU
+    case 16: return launch_frame<4, 2, 4>(P8_ARGS);         // 257 x 128, 16 waves, 100 KB
+    case 17: return launch_frame<4, 1, 4>(P8_ARGS);         // 257 x 64, 16 waves, 84 KB
+    case 18: return launch_frame<2, 2, 3>(P8_ARGS);         // 257 x 64, 8 waves, 63 KB: two workgroups per CU
+    case 19: return launch_frame<4, 4, 3>(P8_ARGS);         // 257 x 256, 99 KB
+    case 20: return launch_frame<2, 4, 4>(P8_ARGS);         // 257 x 128, 8 waves, 100 KB
     default: return DEER_ERR_SHAPE;
   }
 #undef P8_ARGS

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restric
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + off) = float4{v0, v1, v2, v3};
       } else {
         if (epi == EPI_QGELU_BF16) {
-          v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3);
+          v0 = quick_gelu_bf(v0); v1 = quick_gelu_bf(v1); v2 = quick_gelu_bf(v2); v3 = quick_gelu_bf(v3);
         } else if (epi == EPI_GELU_BF16) {
           v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
         }
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + off) = float4{v0, v1, v2, v3};
       } else {
         if (epi == EPI_QGELU_BF16) {
-          v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3);
+          v0 = quick_gelu_bf(v0); v1 = quick_gelu_bf(v1); v2 = quick_gelu_bf(v2); v3 = quick_gelu_bf(v3);
         } else if (epi == EPI_GELU_BF16) {
           v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
         }
@@ -388,7 +388,7 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool ring_ok = (K % GT_BK) == 0;
   if (!ring_ok && tile >= 4) return DEER_ERR_SHAPE;
-  if (tile < 0 || tile > 63) return DEER_ERR_SHAPE;
+  if (tile < 0 || tile > 79) return DEER_ERR_SHAPE;
   static const int big_tile = [] { const char* e = getenv("DEER_GEMM_BIG"); return e ? atoi(e) : 17; }();   // 17: 16 waves 32x32 (best in situ, tools/graph_time.py); 28: 8 waves 32x64 (+5 % in the microbenchmark only)
   static const bool big_sel = [] { const char* e = getenv("DEER_GEMM_SEL"); return e == nullptr || e[0] != '0'; }();
   static const bool u2_ok = [] { const char* e = getenv("DEER_GEMM_U2"); return e == nullptr || e[0] != '0'; }();
@@ -407,7 +407,18 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
       // with more tiles than CUs the second round costs more than the larger tile returns (c_fc at 16 frames: 272 tiles, 55 vs 45 us)
       static const bool sel256 = [] { const char* e = getenv("DEER_GEMM_256"); return e == nullptr || e[0] != '0'; }();
       const long n256 = nblk(256, 256);
-      if (sel256 && big_sel && (N & 255) == 0 && (K & 31) == 0 && n256 >= 192 && n256 <= 256) tile = 61;
+      // frame tiles (one camera frame = 257 rows per row tile, the 17th MFMA row tile dealt out over the waves; bf16 results leave
+      // through LDS as whole lines): M = 257 n tiles EXACTLY - 16 frames x 3072 / 192 = 16 frames x 4096 / 256 = 256 workgroups, one
+      // round.  in_proj at 16 frames 38.0-39.4 -> 32.1-33.1 us, c_fc 43.3-44.7 -> 39.9 (hipBLASLt on the same box 30.3-30.7 / 43.6-44.7);
+      // at 12 frames (192 workgroups) 31.9 -> 28.8 and 37.0 -> 34.1 (profiles/r03_k_frame_tiles_*.txt)
+      const long frames = (M % 257 == 0) ? M / 257 : 0;
+      auto one_round = [&](int bn) { return frames > 0 && (N % bn) == 0 && frames * (N / bn) * batch >= 192 && frames * (N / bn) * batch <= 256; };
+      if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16) && one_round(192)) tile = 64;
+      else if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16) && one_round(256)) tile = 63;
+      // ... and the K halves of c_proj (f32 slabs, N = 1024) as 257 x 128 tiles: 16 frames x 8 x 2 = 256 workgroups, 49.8 -> 43.1 us
+      else if (sel256 && big_sel && (K & 31) == 0 && epi == EPI_F32 && one_round(128)) tile = 67;
+      else if (sel256 && big_sel && (N & 255) == 0 && (K & 31) == 0 && n256 >= 192 && n256 <= 256) tile = 61;
+      else if (big_sel && N <= 1024 && batch == 1) tile = 17;   // out_proj at 16 frames: 264 128x128 tiles sit two per CU (17.5 us; 192-row tiles 19.9)
       else if (big_sel) {
         auto cost = [&](int bm, int bn, float rel) { return (float)((nblk(bm, bn) + 255) / 256) * rel; };
         float best = cost(128, 128, 1.0f);
@@ -469,6 +480,7 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     case 45: return launch_ring<128, 192, 4, 2, 2>(DEER_ARGS);       // 8 waves (32x96), 80 KB
     case 46: return launch_ring<96, 128, 2, 2, 3>(DEER_ARGS);        // 4 waves (48x64), 84 KB
     case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59: case 60: case 61: case 62:            // 16 waves, 32-column K-steps, deep ring (csrc/gemm_bigm.hip)
+    case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71:                                     // one camera frame per row tile, balanced (csrc/gemm_bigm.hip)
       return deer_launch_gemm_ring32(tile - 51, DEER_ARGS);
     case 26: return launch_ring<64, 64, 2, 4, 4, 0, 1, 1>(DEER_ARGS);    // register-pipelined K loop (fragments of k+1 read under the MFMAs of k)
     case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)

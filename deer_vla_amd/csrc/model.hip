@@ -483,7 +483,10 @@ void build_workspace(deer_model* m) {
   m->vis_x_f32 = named(m, "vis_x_f32", (size_t)N * nl * W * 4);
   build_vision_ws(m, m->vws, N, 0, nullptr);
   m->ws_named["vx"] = {m->vws.vx, (size_t)N * (m->P + 1) * W * 4};
-  int n_ch = c.n_chains > 0 ? c.n_chains : 2;
+  // two chains of camera frames on two streams hide each other's launch boundaries while a kernel cannot fill the chip by itself
+  // (1-7 environments); from 16 frames on every GEMM of ONE chain is a full round of frame tiles (gemm_bigm.hip: 16 x 16 = 256
+  // workgroups) - measured at 8 environments: batched 945 -> 950, four batches in flight 1102 -> 1172 steps/s
+  int n_ch = c.n_chains > 0 ? c.n_chains : (N >= 16 ? 1 : 2);
   if (const char* e = getenv("DEER_CHAINS")) n_ch = atoi(e);
   n_ch = std::max(1, std::min(N, n_ch));
   if (c.sep_resampler) n_ch = 2;                       // camera-major frames: chain 0 = every env's rgb frame, chain 1 = the gripper frames

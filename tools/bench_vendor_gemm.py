@@ -16,6 +16,7 @@ TILES = tuple(int(t) for t in sys.argv[2].split(",")) if len(sys.argv) > 2 else 
 SHAPES = [("vit qkv", 514, 3072, 1024), ("vit out", 514, 1024, 1024), ("vit fc1", 514, 4096, 1024), ("vit fc2", 514, 1024, 4096),
           ("perc kv", 512, 1024, 1024), ("perc ff1", 128, 4096, 1024), ("perc ff2", 128, 1024, 4096), ("media kv", 128, 12288, 1024)]
 NCOPY = 24
+EPI = int(os.environ.get("EPI", abi.EPI_BF16))     # 2 = bias + QuickGELU (the c_fc epilogue)
 
 
 def timed(fn):
@@ -42,6 +43,8 @@ for name, M, N, K in SHAPES:
     Ws = [torch.randn(N, K, device="cuda").bfloat16() * K ** -0.5 for _ in range(NCOPY)]
     C = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
     flops = 2.0 * M * N * K
+    bias_t = torch.randn(N, device="cuda")
+    bias = abi.ptr(bias_t) if EPI != abi.EPI_BF16 else None
 
     def vendor():
         for w in Ws:
@@ -53,13 +56,24 @@ for name, M, N, K in SHAPES:
     for tile in TILES:
         def ours():
             for w in Ws:
-                lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(w), K, None, abi.ptr(C), N, 0, M, N, K, 1, abi.EPI_BF16, None, tile,
+                lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(w), K, bias, abi.ptr(C), N, 0, M, N, K, 1, EPI, None, tile,
                                       None, st())
-        rc = lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(Ws[0]), K, None, abi.ptr(C), N, 0, M, N, K, 1, abi.EPI_BF16, None, tile,
+        rc = lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(Ws[0]), K, bias, abi.ptr(C), N, 0, M, N, K, 1, EPI, None, tile,
                                    None, st())
         if rc != 0:
             line += f" t{tile}: n/a |"
             continue
         o = timed(ours)
         line += f" deer t{tile} {o:6.1f} us {flops / o / 1e6:6.0f} TF/s |"
+    if os.environ.get("SPLITK"):                      # the projections that close a residual branch run through the split-K entry (f32 slabs)
+        S = int(os.environ["SPLITK"]) if K >= 4096 else 1
+        slab = torch.zeros(S, M, N, device="cuda")
+        for tile in TILES:
+            def ours_sk():
+                for w in Ws:
+                    lib.deer_gemm_bf16_nt_splitk(abi.ptr(A), K, abi.ptr(w), K, abi.ptr(slab), M, N, K, S, tile, None, st())
+            if lib.deer_gemm_bf16_nt_splitk(abi.ptr(A), K, abi.ptr(Ws[0]), K, abi.ptr(slab), M, N, K, S, tile, None, st()) != 0:
+                continue
+            o = timed(ours_sk)
+            line += f" slabs{S} t{tile} {o:6.1f} |"
     print(line, flush=True)
