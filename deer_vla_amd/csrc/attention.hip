@@ -86,33 +86,19 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
   // ---- stage K (row-major) and V (transposed) for this head; rows >= kv_len are zero ----
   // two key rows per thread: K rows are copied as they are, V is transposed with 32-bit LDS stores that carry the
   // same d of two adjacent keys (half the store instructions of a per-element transpose)
-  // every global load of the staging is issued before the first LDS store (the loop is unrolled to the largest head: 160 key pairs x 8
-  // segments over the workgroup's threads) - one round trip to L2 instead of one per loop iteration
-  constexpr int NTHR = 64 * NWAVE, STG_IT = (AM_MAXT * 8 * 8 + NTHR - 1) / NTHR;
-  uint4 sk0[STG_IT], sk1[STG_IT], sv0[STG_IT], sv1[STG_IT];
-  const int n_items = (kvpad >> 1) * 8;
-#pragma unroll
-  for (int it = 0; it < STG_IT; ++it) {
-    const int idx = tid + it * NTHR;
+  for (int idx = tid; idx < (kvpad >> 1) * 8; idx += 64 * NWAVE) {
     const int row = (idx >> 3) * 2, seg = idx & 7;
-    sk0[it] = sk1[it] = sv0[it] = sv1[it] = uint4{0, 0, 0, 0};
-    if (idx < n_items && row < kv_len) {
+    uint4 k0 = uint4{0, 0, 0, 0}, k1 = k0, v0 = k0, v1 = k0;
+    if (row < kv_len) {
       const bool s2 = row >= kv1;
-      sk0[it] = *reinterpret_cast<const uint4*>((s2 ? Kb2 + (long)(row - kv1) * ld2 : Kb + (long)row * ldk) + seg * 8);
-      sv0[it] = *reinterpret_cast<const uint4*>((s2 ? Vb2 + (long)(row - kv1) * ld2 : Vb + (long)row * ldv) + seg * 8);
+      k0 = *reinterpret_cast<const uint4*>((s2 ? Kb2 + (long)(row - kv1) * ld2 : Kb + (long)row * ldk) + seg * 8);
+      v0 = *reinterpret_cast<const uint4*>((s2 ? Vb2 + (long)(row - kv1) * ld2 : Vb + (long)row * ldv) + seg * 8);
     }
-    if (idx < n_items && row + 1 < kv_len) {
+    if (row + 1 < kv_len) {
       const bool s2 = row + 1 >= kv1;
-      sk1[it] = *reinterpret_cast<const uint4*>((s2 ? Kb2 + (long)(row + 1 - kv1) * ld2 : Kb + (long)(row + 1) * ldk) + seg * 8);
-      sv1[it] = *reinterpret_cast<const uint4*>((s2 ? Vb2 + (long)(row + 1 - kv1) * ld2 : Vb + (long)(row + 1) * ldv) + seg * 8);
+      k1 = *reinterpret_cast<const uint4*>((s2 ? Kb2 + (long)(row + 1 - kv1) * ld2 : Kb + (long)(row + 1) * ldk) + seg * 8);
+      v1 = *reinterpret_cast<const uint4*>((s2 ? Vb2 + (long)(row + 1 - kv1) * ld2 : Vb + (long)(row + 1) * ldv) + seg * 8);
     }
-  }
-#pragma unroll
-  for (int it = 0; it < STG_IT; ++it) {
-    const int idx = tid + it * NTHR;
-    if (idx >= n_items) break;
-    const int row = (idx >> 3) * 2, seg = idx & 7;
-    const uint4 k0 = sk0[it], k1 = sk1[it], v0 = sv0[it], v1 = sv1[it];
     *reinterpret_cast<uint4*>(Ks + row * AM_KPITCH + seg * 8) = k0;
     *reinterpret_cast<uint4*>(Ks + (row + 1) * AM_KPITCH + seg * 8) = k1;
     const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bq[4] = {v1.x, v1.y, v1.z, v1.w};
