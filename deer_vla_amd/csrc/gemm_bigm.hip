@@ -365,16 +365,19 @@ static int launch_ring272(const bf16_t* A, int lda, long strideA, const bf16_t* 
 // or BN = 128 with two K halves) - one round on the 256 CUs where M = 257 n never tiles into powers of two.
 // A stage is 17 A chunks + BN / 16 W chunks of 1 KiB (16 rows x 64 B, the swizzle of ring32); chunk q = wave + i * NW; the first N_HI
 // waves issue CPW DMAs per stage, the others CPW - 1 - each group runs the loop instantiated with its own counted vmcnt.
-template <int WN, int TN, int D>
+// TM = MFMA row tiles per wave: 4 = a whole frame per workgroup (16 + 1 row tiles); 2 = HALF a frame (8 + 1 row tiles: rows 0..128 of the
+// frame, the 129th being the dealt-out row tile, or rows 129..256 with no extra tile) - 32 half frames x 1024 / 128 = 256 workgroups for
+// the N = 1024 projections of 16 frames without splitting K.
+template <int TM, int WN, int TN, int D>
 __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
                                                                const bf16_t* __restrict__ W, int ldw, long strideW,
                                                                const float* __restrict__ bias, void* __restrict__ Cv, int ldc,
                                                                long strideC, int M, int N, int K, int epi, int tile_rows,
                                                                const float* __restrict__ gate, const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
-  constexpr int NW = 4 * WN, BN = 16 * WN * TN, CH = 17 + BN / 16, STAGE = CH * 1024;
+  constexpr int NW = 4 * WN, BN = 16 * WN * TN, RT = 4 * TM, CH = RT + 1 + BN / 16, STAGE = CH * 1024;
   constexpr int CPW = (CH + NW - 1) / NW, N_HI = CH - (CPW - 1) * NW;
-  static_assert(TN >= 1 && TN <= 4 && (WN == 2 || WN == 4), "wave grid");
+  static_assert(TN >= 1 && TN <= 4 && (WN == 2 || WN == 4) && (TM == 2 || TM == 4), "wave grid");
   static_assert(D * STAGE <= 160 * 1024 && (D - 2) * CPW <= 63, "LDS / vmcnt field");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -387,8 +390,12 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
   const int nb = gridDim.x, bid = blockIdx.x;
   const int xq = nb >> 3, xr = nb & 7, xcd = bid & 7;
   const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-  const int m0 = (tile / tiles_n) * tile_rows, n0 = (tile % tiles_n) * BN;
-  const int rows_valid = min(tile_rows, M - m0);
+  const int rt = tile / tiles_n, n0 = (tile % tiles_n) * BN;
+  int m0, rows_here;
+  if (TM == 4) { m0 = rt * tile_rows; rows_here = tile_rows; }
+  else if (tile_rows == 257) { m0 = (rt >> 1) * 257 + (rt & 1) * 129; rows_here = (rt & 1) ? 128 : 129; }   // half frames
+  else { m0 = rt * 128; rows_here = 128; }
+  const int rows_valid = min(rows_here, M - m0);
   A += (long)blockIdx.z * strideA;
   W += (long)blockIdx.z * strideW;
 
@@ -398,20 +405,20 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
 #pragma unroll
   for (int i = 0; i < CPW; ++i) {
     const int q = min(wave + i * NW, CH - 1);                 // wave-uniform: an A chunk or a W chunk
-    sp[i] = (q < 17) ? A + (long)min(m0 + q * 16 + lr, M - 1) * lda + ls : W + (long)min(n0 + (q - 17) * 16 + lr, N - 1) * ldw + ls;
+    sp[i] = (q < RT + 1) ? A + (long)min(m0 + q * 16 + lr, M - 1) * lda + ls : W + (long)min(n0 + (q - RT - 1) * 16 + lr, N - 1) * ldw + ls;
   }
   const int nk = K >> 5;
 
-  f32x4 acc[TN][4], accx = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[TN][TM], accx = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fr_sw = (g ^ ((0x1320 >> (((c >> 2) & 3) * 4)) & 3)) << 4;
-  const int a_off = (wm * 64 + c) * 64 + fr_sw;
-  const int x_off = (256 + c) * 64 + fr_sw;
-  const int w_off = 17 * 1024 + (wn * TN * 16 + c) * 64 + fr_sw;
-  const bool has_x = wm < TN;
+  const int a_off = (wm * TM * 16 + c) * 64 + fr_sw;
+  const int x_off = (RT * 16 + c) * 64 + fr_sw;
+  const int w_off = (RT + 1) * 1024 + (wn * TN * 16 + c) * 64 + fr_sw;
+  const bool has_x = wm < TN && rows_valid > RT * 16;         // the dealt-out row tile holds a valid row (not in the second half of a frame)
 
   auto run = [&](auto cpw_tag) {
     constexpr int CPWL = decltype(cpw_tag)::value;
@@ -429,19 +436,19 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
       __builtin_amdgcn_s_barrier();
       issue(kt + D - 1);
       const unsigned char* st = smem + (kt % D) * STAGE;
-      bf16x8 af[4], wf[TN], afx;
+      bf16x8 af[TM], wf[TN], afx;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const bf16x8*>(st + a_off + j * 1024);
+      for (int j = 0; j < TM; ++j) af[j] = *reinterpret_cast<const bf16x8*>(st + a_off + j * 1024);
 #pragma unroll
       for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + w_off + i * 1024);
       if (has_x) afx = *reinterpret_cast<const bf16x8*>(st + x_off);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int e = 0; e < TN; ++e)
-        if (wm == e) accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[e], afx, accx, 0, 0, 0);
+        if (has_x && wm == e) accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[e], afx, accx, 0, 0, 0);
     }
     p8_wait_vmcnt<0>();
   };
@@ -454,8 +461,12 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
   // 32 bytes each - the epilogue of the direct form is store-ISSUE bound, ~5 us of a 40 us launch); staged, a lane stores 16 bytes
   // of a row and a wave 1 KiB of whole 128-byte lines, half as many instructions.  Row pitch BN*2 + 16 bytes: the ds_write_b64 of a
   // 16 x 16 tile (rows c, 8-byte slot g) and the ds_read_b128 rows are both conflict-free.
-  constexpr int CPITCH = BN * 2 + 16;
-  static_assert(272 * CPITCH <= 160 * 1024, "C staging tile");
+  constexpr int CPITCH = BN * 2 + 16, FPITCH = BN * 4 + 16;
+  static_assert((RT + 1) * 16 * CPITCH <= 160 * 1024, "C staging tile");
+  // f32 slabs take the same route when the tile fits (BN <= 128: 272 x 528 B = 140 KB): ds_write_b128 of a 16 x 16 tile and the row
+  // reads are conflict-free at this pitch; a wave then stores two whole 512-byte rows instead of 16 rows x 64 bytes
+  constexpr bool F32_STAGE = (RT + 1) * 16 * FPITCH <= 160 * 1024;
+  const bool f32_staged = F32_STAGE && epi == P8_EPI_F32;
   auto store = [&](int r, int n, const f32x4& a) {            // row r of the frame, columns n0 + n .. n0 + n + 3
     float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3];
     if (bias != nullptr) {
@@ -471,6 +482,10 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
       *reinterpret_cast<uint2*>(smem + r * CPITCH + n * 2) = uint2{pack2bf(v0, v1), pack2bf(v2, v3)};
       return;
     }
+    if (f32_staged) {
+      *reinterpret_cast<float4*>(smem + r * FPITCH + n * 4) = float4{v0, v1, v2, v3};
+      return;
+    }
     if (r >= rows_valid) return;
     const long off = (long)blockIdx.z * strideC + (long)(m0 + r) * ldc + n0 + n;
     if (epi == P8_EPI_RESADD_F32) {
@@ -482,16 +497,17 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + off) = float4{v0, v1, v2, v3};
     }
   };
-  if (to_bf16) BIGM_SYNC();                                   // every wave has read its last fragments: the ring becomes the C tile
+  const bool staged = to_bf16 || f32_staged;
+  if (staged) BIGM_SYNC();                                    // every wave has read its last fragments: the ring becomes the C tile
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     const int n = (wn * TN + i) * 16 + g * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) store(wm * 64 + j * 16 + c, n, acc[i][j]);
+    for (int j = 0; j < TM; ++j) store((wm * TM + j) * 16 + c, n, acc[i][j]);
   }
-  if (has_x) store(256 + c, (wn * TN + wm) * 16 + g * 4, accx);
+  if (has_x) store(RT * 16 + c, (wn * TN + wm) * 16 + g * 4, accx);
+  if (staged) BIGM_SYNC();
   if (to_bf16) {
-    BIGM_SYNC();
     constexpr int PPR = BN / 8;                               // 16-byte pieces per row
     const int pieces = rows_valid * PPR;
     bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv) + (long)blockIdx.z * strideC + (long)m0 * ldc + n0;
@@ -499,26 +515,37 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
       const int r = p / PPR, cp = p - r * PPR;
       *reinterpret_cast<uint4*>(Cb + (long)r * ldc + cp * 8) = *reinterpret_cast<const uint4*>(smem + r * CPITCH + cp * 16);
     }
+  } else if (f32_staged) {
+    constexpr int PPR = BN / 4;
+    const int pieces = rows_valid * PPR;
+    float* Cf = reinterpret_cast<float*>(Cv) + (long)blockIdx.z * strideC + (long)m0 * ldc + n0;
+    for (int p = tid; p < pieces; p += NW * 64) {
+      const int r = p / PPR, cp = p - r * PPR;
+      *reinterpret_cast<uint4*>(Cf + (long)r * ldc + cp * 4) = *reinterpret_cast<const uint4*>(smem + r * FPITCH + cp * 16);
+    }
   }
 }
 
-template <int WN, int TN, int D>
+template <int TM, int WN, int TN, int D>
 static int launch_frame(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
                         int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl,
                         hipStream_t st) {
   constexpr int BN = 16 * WN * TN;
   if ((N % BN) || (K & 31) || M <= 0 || batch <= 0) return DEER_ERR_SHAPE;
   const int tile_rows = (M % 257 == 0) ? 257 : 256;         // M = 257 n (n camera frames): one frame per row tile
-  constexpr int ring_bytes = D * (17 + BN / 16) * 1024, c_bytes = 272 * (BN * 2 + 16);
-  constexpr int smem_bytes = ring_bytes > c_bytes ? ring_bytes : c_bytes;   // the ring, then the staged bf16 C tile
+  constexpr int ring_bytes = D * (4 * TM + 1 + BN / 16) * 1024, c_bytes = (4 * TM + 1) * 16 * (BN * 2 + 16);
+  constexpr int f_bytes = (4 * TM + 1) * 16 * (BN * 4 + 16) <= 160 * 1024 ? (4 * TM + 1) * 16 * (BN * 4 + 16) : 0;
+  constexpr int rc_bytes = ring_bytes > c_bytes ? ring_bytes : c_bytes;
+  constexpr int smem_bytes = rc_bytes > f_bytes ? rc_bytes : f_bytes;   // the ring, then the staged C tile (bf16, or f32 where it fits)
   static bool attr_set = false;
-  auto kern = &gemm_frame_kernel<WN, TN, D>;
+  auto kern = &gemm_frame_kernel<TM, WN, TN, D>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
       return DEER_ERR_LAUNCH;
     attr_set = true;
   }
-  const int tiles = ((M + tile_rows - 1) / tile_rows) * (N / BN);
+  const int row_tiles = TM == 4 ? (M + tile_rows - 1) / tile_rows : (tile_rows == 257 ? 2 * (M / 257) : (M + 127) / 128);
+  const int tiles = row_tiles * (N / BN);
   hipLaunchKernelGGL(kern, dim3(tiles, 1, batch), dim3(WN * 256), smem_bytes, st, A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M,
                      N, K, epi, tile_rows, gate, ctl);
   DEER_LAUNCH_CHECK();
@@ -564,15 +591,19 @@ int deer_launch_gemm_ring32(int variant, const bf16_t* A, int lda, long strideA,
     case 11: return launch_ring32<128, 128, 8, true>(P8_ARGS);
     case 6: return launch_ring272<3>(P8_ARGS);              // one camera frame (257 rows) per row tile, 99 KB ring
     case 7: return launch_ring272<4>(P8_ARGS);              // the same, 132 KB ring
-    case 12: return launch_frame<4, 4, 4>(P8_ARGS);         // frame tiles, balanced 17th row tile: 257 x 256, 16 waves, 132 KB
-    case 13: return launch_frame<4, 3, 4>(P8_ARGS);         // 257 x 192, 16 waves, 116 KB
-    case 14: return launch_frame<4, 3, 5>(P8_ARGS);         // 257 x 192, 145 KB ring
-    case 15: return launch_frame<2, 4, 3>(P8_ARGS);         // 257 x 128, 8 waves, 75 KB: two workgroups per CU
-    case 16: return launch_frame<4, 2, 4>(P8_ARGS);         // 257 x 128, 16 waves, 100 KB
-    case 17: return launch_frame<4, 1, 4>(P8_ARGS);         // 257 x 64, 16 waves, 84 KB
-    case 18: return launch_frame<2, 2, 3>(P8_ARGS);         // 257 x 64, 8 waves, 63 KB: two workgroups per CU
-    case 19: return launch_frame<4, 4, 3>(P8_ARGS);         // 257 x 256, 99 KB
-    case 20: return launch_frame<2, 4, 4>(P8_ARGS);         // 257 x 128, 8 waves, 100 KB
+    case 12: return launch_frame<4, 4, 4, 4>(P8_ARGS);         // frame tiles, balanced 17th row tile: 257 x 256, 16 waves, 132 KB
+    case 13: return launch_frame<4, 4, 3, 4>(P8_ARGS);         // 257 x 192, 16 waves, 116 KB
+    case 14: return launch_frame<4, 4, 3, 5>(P8_ARGS);         // 257 x 192, 145 KB ring
+    case 15: return launch_frame<4, 2, 4, 3>(P8_ARGS);         // 257 x 128, 8 waves, 75 KB: two workgroups per CU
+    case 16: return launch_frame<4, 4, 2, 4>(P8_ARGS);         // 257 x 128, 16 waves, 100 KB
+    case 17: return launch_frame<4, 4, 1, 4>(P8_ARGS);         // 257 x 64, 16 waves, 84 KB
+    case 18: return launch_frame<4, 2, 2, 3>(P8_ARGS);         // 257 x 64, 8 waves, 63 KB: two workgroups per CU
+    case 19: return launch_frame<4, 4, 4, 3>(P8_ARGS);         // 257 x 256, 99 KB
+    case 20: return launch_frame<4, 2, 4, 4>(P8_ARGS);         // 257 x 128, 8 waves, 100 KB
+    // HALF frames (measured, not auto-selected: out_proj at 16 frames 18.0 us against 17.3 for the 128x128 ring; c_proj without the K split
+    // 50-55 us against 42.8 for the 257 x 128 tiles of the two K halves):
+    case 21: return launch_frame<2, 4, 2, 5>(P8_ARGS);      // 129 | 128 x 128, 16 waves (32 x 32 wave tiles), 85 KB
+    case 22: return launch_frame<2, 2, 4, 4>(P8_ARGS);      // 129 | 128 x 128, 8 waves (32 x 64 wave tiles), 68 KB
     default: return DEER_ERR_SHAPE;
   }
 #undef P8_ARGS

@@ -481,6 +481,7 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     case 46: return launch_ring<96, 128, 2, 2, 3>(DEER_ARGS);        // 4 waves (48x64), 84 KB
     case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59: case 60: case 61: case 62:            // 16 waves, 32-column K-steps, deep ring (csrc/gemm_bigm.hip)
     case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71:                                     // one camera frame per row tile, balanced (csrc/gemm_bigm.hip)
+    case 72: case 73:                                                                                                    // half a frame per row tile
       return deer_launch_gemm_ring32(tile - 51, DEER_ARGS);
     case 26: return launch_ring<64, 64, 2, 4, 4, 0, 1, 1>(DEER_ARGS);    // register-pipelined K loop (fragments of k+1 read under the MFMAs of k)
     case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)

@@ -229,7 +229,7 @@ def test_skinny_hl_producers_and_exit_flag(lib):
 
 
 # ------------------------------------------------------------------------------------------- tiled GEMM
-@pytest.mark.parametrize("tile", [17, 39, 45, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 0])
+@pytest.mark.parametrize("tile", [17, 39, 45, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 0])
 @pytest.mark.parametrize("M", [2056, 3084, 4112, 4096, 300])
 @pytest.mark.parametrize("N,K,epi", [(3072, 1024, "bf16"), (4096, 1024, "qgelu"), (1024, 1024, "f32"), (1024, 4096, "f32")])
 def test_gemm_tiled_big_m_tiles(lib, tile, M, N, K, epi):
