@@ -159,9 +159,7 @@ class DeerEngine:
         # the exit still launches and returns at entry (see _step_one_graph; measured slower: 242 vs 352 steps/s at one
         # environment, 778 vs 862 at eight)
         self._one_graph = os.environ.get("DEER_ONE_GRAPH") == "1"
-        # the side stream carries the head evaluations (the exit verdict the host is waiting for) next to the speculative trunk layer on the
-        # caller's stream: DEER_SIDE_PRIO=1 asks for a high-priority HIP stream
-        self._side_stream = torch.cuda.Stream(device=self.dev, priority=-1 if os.environ.get("DEER_SIDE_PRIO", "0") == "1" else 0)
+        self._side_stream = torch.cuda.Stream(device=self.dev)
         self._plans = []                                                   # native step plans (own HIP events): freed with the graphs
         self._native_step = os.environ.get("DEER_NATIVE_STEP", "1") == "1"   # 0: the Python submission / polling loop (debugging)
         self._extra_streams: List[torch.cuda.Stream] = []
