@@ -1,3 +1,4 @@
+"""One-line summary + the top kernel classes of a bench.py JSON line (stdin or file).  usage: show_bench.py [bench.json]"""
 import json,sys
 d=json.loads(open(sys.argv[1]).read() if len(sys.argv)>1 else sys.stdin.read())
 r=d["roofline"]
