@@ -385,12 +385,36 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
   const int wm = wave / WN, wn = wave % WN;
   const int c = lane & 15, g = lane >> 4;
 
-  // contiguous run of tiles (column index fastest) per XCD: the workgroups of an XCD share few frames in its L2
+  // workgroup b runs on XCD b % 8: every XCD gets a BLOCK of (row tiles / gr) x (column tiles / gc) tiles, gr x gc = 8 chosen so that
+  // the rows of A plus the rows of W its L2 has to fetch are fewest (16 frames x 16 column tiles: 4 x 8 tiles per XCD = 12 operand
+  // panels instead of the 2 x 16 = 18 of a contiguous run; PMC: 110 MB of L2 misses per c_fc launch against 17 MB of operands)
   const int tiles_n = N / BN;
   const int nb = gridDim.x, bid = blockIdx.x;
-  const int xq = nb >> 3, xr = nb & 7, xcd = bid & 7;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-  const int rt = tile / tiles_n, n0 = (tile % tiles_n) * BN;
+  const int rows_n = nb / tiles_n;
+  int rt, ct;
+  {
+    int gr = 0, gc = 0;
+    long best = 1L << 60;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r_ = 1 << e, c_ = 8 >> e;
+      if (rows_n % r_ == 0 && tiles_n % c_ == 0) {
+        const long cost = (long)(rows_n / r_) * tile_rows + (long)(tiles_n / c_) * BN;
+        if (cost < best) { best = cost; gr = r_; gc = c_; }
+      }
+    }
+    if (gr != 0) {
+      const int xcd = bid & 7, idx = bid >> 3, bc = tiles_n / gc, br = rows_n / gr;
+      rt = (xcd / gc) * br + idx / bc;
+      ct = (xcd % gc) * bc + idx % bc;
+    } else {                                                  // contiguous run of tiles (column index fastest) per XCD
+      const int xq = nb >> 3, xr = nb & 7, xcd = bid & 7;
+      const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+      rt = tile / tiles_n;
+      ct = tile % tiles_n;
+    }
+  }
+  const int n0 = ct * BN;
   int m0, rows_here;
   if (TM == 4) { m0 = rt * tile_rows; rows_here = tile_rows; }
   else if (tile_rows == 257) { m0 = (rt >> 1) * 257 + (rt & 1) * 129; rows_here = (rt & 1) ? 128 : 129; }   // half frames

@@ -18,7 +18,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gemm_tiled" in r["Kernel_Name"]:
+        if "gemm_" in r["Kernel_Name"]:
             a = agg[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for k, (t, n) in sorted(agg.items()):
     print(f"{k:40s} {t / n:16.1f}  (per dispatch, {n} dispatches)")
