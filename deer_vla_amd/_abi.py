@@ -100,6 +100,7 @@ _RESTYPE = {"deer_hip_arch": c_char_p, "deer_model_arena_bytes": c_long, "deer_m
 CTL_EXIT_FLAG, CTL_EXIT_LAYER, CTL_CUR_EXIT_ID, CTL_HOLD, CTL_N_EVALS, CTL_SHADOW, CTL_COMMITTED, CTL_ALL_EXITED = 0, 1, 2, 3, 4, 5, 6, 7
 CTL_PREV_ACTION, CTL_OUT_ACTION, CTL_DELTAS, CTL_WORDS = 8, 16, 24, 64
 CTL_N_EXITED, CTL_SEQ, CTL_HOST_PTR, CTL_EVALS_DONE = 40, 41, 42, 44
+CTL_PREV_REAL, CTL_ENS_ACTION = 45, 48
 HOSTM_PROGRESS, HOSTM_DONE = 0, 1
 EPI_BF16, EPI_F32, EPI_QGELU_BF16, EPI_GELU_BF16, EPI_RESADD_F32 = 0, 1, 2, 3, 4
 A_BF16, A_SLABS_GELU, A_SLABS, A_F32 = 0, 1, 2, 3

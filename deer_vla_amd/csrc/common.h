@@ -32,6 +32,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CTL_SEQ 41          // (block 0 only) sequence number of the current control step (from step_info)
 #define CTL_HOST_PTR 42     // (block 0 only) 2 words: host-visible mirror (pinned, system-coherent) or 0 - see head.hip
 #define CTL_EVALS_DONE 44   // (block 0 only) environments that finished the current exit check
+#define CTL_PREV_REAL 45    // 1 when CTL_PREV_ACTION is the action of an exit check of THIS step (0: the pseudo action of the first check)
+#define CTL_ENS_ACTION 48   // float[8]: value_net.get_ensemble_action() - mean of the last two exit-check actions of this step (pose6, gripper prob, count)
 // host mirror layout (int32 words): [0] = seq*64 + number of exit checks completed in this step ("progress"),
 // [1] = seq once every environment has exited ("done"), [64*(1+b) .. +64) = copy of environment b's control block at its exit
 #define HOSTM_PROGRESS 0

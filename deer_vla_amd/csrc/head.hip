@@ -665,6 +665,7 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
       const bool hold = ctl0[CTL_HOLD] != 0;
       if (kind == KIND_PSEUDO) {
         for (int i = 0; i < 8; ++i) prev[i] = cur[i];
+        ctl[CTL_PREV_REAL] = 0;                         // not a member of action_list (value_net.py:120-123)
       } else if (kind == KIND_CHECK && !hold) {
         float delta;                                    // value_net.py:105-117
         if (thr_type == THR_COSINE) {
@@ -684,6 +685,13 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
           delta = (thr_type == THR_L2) ? sqrtf(acc / 6.f) : (thr_type == THR_MEAN ? acc / 6.f : acc);
         }
         if (slot >= 0 && slot < 16) deltas[slot] = delta;
+        {                                               // get_ensemble_action(): mean over action_list[-2:] of this step (value_net.py:92-95)
+          float* ens = reinterpret_cast<float*>(ctl + CTL_ENS_ACTION);
+          const bool two = ctl[CTL_PREV_REAL] != 0;
+          for (int i = 0; i < 7; ++i) ens[i] = two ? 0.5f * (prev[i] + cur[i]) : cur[i];
+          ens[7] = two ? 2.f : 1.f;
+          ctl[CTL_PREV_REAL] = 1;
+        }
         for (int i = 0; i < 8; ++i) prev[i] = cur[i];   // action_list.append(action)
         const bool below = delta <= thresholds[slot];
         if ((below == (leq != 0)) || force) {           // value_net.py:293
@@ -765,6 +773,7 @@ __global__ void ctl_begin_step_kernel(int* ctl0, const int* hold_src, int B) {
     ctl[CTL_EXIT_LAYER] = -1;
     ctl[CTL_N_EVALS] = 0;
     ctl[CTL_COMMITTED] = 0;
+    ctl[CTL_PREV_REAL] = 0;                             // reset_actions() after every step of the ensembling harness (eval_utils.py:461)
     if (b == 0) {
       ctl[CTL_HOLD] = (hold_src != nullptr) ? hold_src[0] : 0;
       ctl[CTL_SEQ] = (hold_src != nullptr) ? hold_src[1] : 0;

@@ -964,8 +964,10 @@ class DeerEngine:
             if int(c[abi.CTL_EXIT_LAYER]) < 0:
                 raise abi.DeerHipError(f"environment {b}: the step ended without an exit verdict (no exit check was forced)")
             a = f[abi.CTL_OUT_ACTION: abi.CTL_OUT_ACTION + 8].copy()
+            en = f[abi.CTL_ENS_ACTION: abi.CTL_ENS_ACTION + 8].copy()   # ActionValueNet.get_ensemble_action (dynamic steps only)
             out.append(dict(exit_layer=int(c[abi.CTL_EXIT_LAYER]), n_evals=int(c[abi.CTL_N_EVALS]),
                             pose=torch.from_numpy(a[:6]), gripper=float(a[6]), gripper_logit=float(a[7]),
+                            ens_pose=torch.from_numpy(en[:6]), ens_gripper=float(en[6]), ens_count=int(en[7]),
                             deltas=torch.from_numpy(f[abi.CTL_DELTAS: abi.CTL_DELTAS + 16].copy())))
         return out[0] if self.B == 1 else out
 

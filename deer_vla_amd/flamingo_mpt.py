@@ -433,6 +433,8 @@ class MPTFlamingo(nn.Module):
             exit_layer = r["exit_layer"]
             if native and exit_id is None:
                 ctl.cur_exit_id = int(e.ctl_host[abi.CTL_CUR_EXIT_ID])
+                if ctl.value_net is not None:                        # ActionValueNet.get_ensemble_action (eval_utils.py:460)
+                    ctl.value_net._ensemble = (r["ens_pose"], r["ens_gripper"], r["ens_count"])
         else:
             # foreign controller: the reference's host loop on our kernels
             T, use_mask = e.load_inputs(vision_x, vision_gripper, lang_x, attention_mask)

@@ -117,8 +117,10 @@ class ModelWrapper:
         m = model.module
         if use_diff or m.head_type == "diffusion":
             raise NotImplementedError("diffusion head: not on the DeeR path (SURVEY §8, out of scope)")
-        if use_action_ensemble:
-            raise NotImplementedError("action ensembling over exits: not on the DeeR path")
+        if use_action_ensemble and not (early_exit and exit_controller is not None
+                                        and getattr(getattr(exit_controller, "module", exit_controller), "value_net", None) is not None):
+            raise ValueError("use_action_ensemble needs the dynamic exit: the ensemble is ActionValueNet.get_ensemble_action() "
+                             "(eval_utils.py:457-461)")
         if m.pad_length != -1:                                     # eval_utils.py:204
             raise AssertionError("Padding for multi-exit net is not implemented. It requires store feature_cache for each exit separately.")
         if m.fusion_mode in ("two_way", "vit_concat"):
@@ -141,7 +143,7 @@ class ModelWrapper:
         self.dynamic_early_exit = early_exit
         self.exit_controller = exit_controller
         self.multi_execution = multi_execution
-        self.use_action_ensemble = False
+        self.use_action_ensemble = bool(use_action_ensemble)
         self.current_exit_layer = exit_id if isinstance(exit_id, int) else -1
         self._text_cache: Tuple[Optional[str], Optional[torch.Tensor], Optional[torch.Tensor]] = (None, None, None)
         self.reset()
@@ -188,7 +190,13 @@ class ModelWrapper:
             if hasattr(out, "exit_layer"):
                 self.current_exit_layer = out.exit_layer
             # eval_utils.py:454-462: [pose6, gripper > 0.5] of the last time step, gripper scaled to -1 / +1
-            action = torch.concat((out.logits[0], (out.logits[1] > 0.5).to(out.logits[0].dtype)), dim=2).squeeze(0)[-1]
+            if not self.use_action_ensemble:
+                action = torch.concat((out.logits[0], (out.logits[1] > 0.5).to(out.logits[0].dtype)), dim=2).squeeze(0)[-1]
+            else:                                                   # mean of the last two exits' actions of this step
+                vn = self.exit_controller.module.value_net
+                pose, grip = vn.get_ensemble_action()
+                vn.reset_actions()
+                action = torch.concat((pose, (grip > 0.5).to(pose.dtype)), dim=2).squeeze(0)[-1]
             action[-1] = (action[-1] - 0.5) * 2
             action = torch.stack([action] * self.multi_execution, dim=0)
             action = action.cpu().detach().to(dtype=torch.float16).numpy()

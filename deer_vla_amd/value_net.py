@@ -69,7 +69,19 @@ class ActionValueNet:
         self.history_memory: list = []
 
     def reset_actions(self):
+        """value_net.py:82-83.  The per-step action list lives on the device (control block: CTL_PREV_ACTION / CTL_PREV_REAL); the
+        harness calls this after reading the ensemble of a step (eval_utils.py:460-461)."""
         self.action_list = []
+        self._ensemble = None
+
+    def get_ensemble_action(self):
+        """value_net.py:92-95: mean over ``action_list[-2:]`` - the actions of the last two exit checks of the current step (the
+        pseudo action the first check is compared with is not a member, value_net.py:120-130).  Computed by the exit check on the
+        device (``head_final``: CTL_ENS_ACTION) and handed over by ``MPTFlamingo.forward`` with the step's verdict; returns
+        (pose (1, 1, 6), gripper probability (1, 1, 1)) like the reference's head outputs."""
+        ens = getattr(self, "_ensemble", None)
+        assert ens is not None and ens[2] > 0, "no exit check ran since the last reset_actions() (value_net.py:93)"
+        return ens[0].view(1, 1, 6), torch.tensor([ens[1]], dtype=torch.float32).view(1, 1, 1)
 
 
 class ExitController:

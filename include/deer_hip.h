@@ -44,6 +44,9 @@ extern "C" {
 #define DEER_CTL_SEQ 41        /* block 0: sequence number of the current control step (from step_info) */
 #define DEER_CTL_HOST_PTR 42   /* block 0, 2 words: pinned host mirror the verdicts are published to, or 0 */
 #define DEER_CTL_EVALS_DONE 44 /* block 0: environments that finished the current exit check */
+#define DEER_CTL_PREV_REAL 45  /* PREV_ACTION is an exit-check action of this step (member of value_net.action_list), not the pseudo action */
+#define DEER_CTL_ENS_ACTION 48 /* float[8]: ActionValueNet.get_ensemble_action (value_net.py:92-95): mean of the last two exit-check actions
+                                * of this step - pose[6], gripper prob, number of actions averaged (1 or 2) */
 /* host mirror (int32 words, pinned + system-coherent): [0] = seq*64 + exit checks completed this step, [1] = seq once every
  * environment exited, [64*(1+b), +64) = environment b's control block at its exit.  Lets the host stop enqueueing the
  * remaining graph segments of a step without the device ever waiting for the host. */

@@ -745,16 +745,26 @@ def gen_deer_forward():
         vn.reset_actions()
         vn.rec = []
         ctl._set_threshold_value(thr)
-        ex, ps, gs, hid = [], [], [], []
+        ex, ps, gs, hid, eps_, egs, ecn = [], [], [], [], [], [], []
         for s in range(n_steps):
             ctl.set_timestep(s)
+            vn.reset_actions()                           # the ensembling harness resets after every step (eval_utils.py:460-461);
+                                                         # the exit decisions do not depend on it (action_list[-1] is only read
+                                                         # after a check of the same step appended to it)
             o = model(vision_x=rgb[s], lang_x=ids, attention_mask=mask, vision_gripper=grip[s], state_tensor=state,
                       return_feature=True, deterministic=True, exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
             ex.append(o.exit_layer)
             ps.append(o.logits[0])
             gs.append(o.logits[1])
             hid.append(o.hidden_states[o.exit_layer])
-        print(f"  deer_forward {tag}: exits={ex}")
+            ep, eg = vn.get_ensemble_action()            # value_net.py:92-95: mean over action_list[-2:]
+            eps_.append(ep)
+            egs.append(eg)
+            ecn.append(min(len(vn.action_list), 2))
+        print(f"  deer_forward {tag}: exits={ex} ensemble over {ecn} actions")
+        outs[tag + "_ens_pose"] = torch.stack(eps_)
+        outs[tag + "_ens_grip"] = torch.stack(egs)
+        outs[tag + "_ens_count"] = np.asarray(ecn)
         outs[tag + "_thr"] = np.asarray(thr)
         outs[tag + "_exit"] = np.asarray(ex)
         outs[tag + "_pose"] = torch.stack(ps)

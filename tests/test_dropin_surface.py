@@ -59,6 +59,16 @@ def test_native_controller_matches_reference_dynamic_exit(setup, tag):
         assert float((o.logits[0].cpu() - g[tag + "_pose"][s]).abs().max()) < TOL
         assert float((o.logits[1].cpu() - g[tag + "_grip"][s]).abs().max()) < TOL
         assert ctl.cur_exit_id == o.exit_layer
+        # ActionValueNet.get_ensemble_action (value_net.py:92-95; eval_utils.py:457-461): mean of the last two exit-check actions of
+        # the step, computed by the exit check on the device - against the reference's own output
+        ep, eg = vn.get_ensemble_action()
+        assert ep.shape == (1, 1, 6) and eg.shape == (1, 1, 1)
+        assert vn._ensemble[2] == int(g[tag + "_ens_count"][s]), (tag, s)
+        assert float((ep - g[tag + "_ens_pose"][s]).abs().max()) < TOL
+        assert float((eg - g[tag + "_ens_grip"][s]).abs().max()) < TOL
+        vn.reset_actions()
+        with pytest.raises(AssertionError):                        # value_net.py:93
+            vn.get_ensemble_action()
 
 
 def test_foreign_controller_protocol(setup):

@@ -224,11 +224,16 @@ def test_full_forward_matches_reference_mptflamingo():
         ctl._set_threshold_value([float(t) for t in g[tag + "_thr"]])
         for s in range(rgb.shape[0]):
             ctl.set_timestep(s)
+            vn.reset_actions()                                      # the ensembling harness (eval_utils.py:460-461)
             o = model.forward(rgb[s], ids, mask, grip[s], dynamic_early_exit=True, exit_controller=ctl)
             assert o["exit_layer"] == int(g[tag + "_exit"][s]), (tag, s)
             close(o["hidden_states"][o["exit_layer"]], g[tag + "_hidden"][s], atol=2e-5)
             close(o["logits"][0], g[tag + "_pose"][s], atol=1e-5)
             close(o["logits"][1], g[tag + "_grip"][s], atol=1e-5)
+            ep, eg = vn.get_ensemble_action()                       # value_net.py:92-95 (reference output in the fixture)
+            assert min(len(vn.action_list), 2) == int(g[tag + "_ens_count"][s])
+            close(ep, g[tag + "_ens_pose"][s], atol=1e-5)
+            close(eg, g[tag + "_ens_grip"][s], atol=1e-5)
 
 
 def test_mpt_block_matches_hf_port():

@@ -82,6 +82,44 @@ def test_model_wrapper_step_protocol(harness):
 
 
 @pytest.mark.gpu
+def test_model_wrapper_action_ensemble_over_the_last_two_exits(harness):
+    """``use_action_ensemble`` (eval_utils.py:457-461): the executed action is the mean of the last two exit-check actions of the step
+    (``ActionValueNet.get_ensemble_action``), the gripper decided on the mean probability; the list is reset after every step.  The
+    wrapper's output is compared with the engine's own per-exit actions (the device-side ensemble against the reference is pinned in
+    tests/test_dropin_surface.py), and the same frames without ensembling exit at the same layers."""
+    cfg, model, image_processor, tokenizer, ctl = harness
+    with pytest.raises(ValueError):                                   # the ensemble lives in the exit controller's value net
+        ro.ModelWrapper(model, tokenizer, image_processor, torch.float32, exit_id=1, early_exit=False, use_action_ensemble=True)
+    plain = ro.ModelWrapper(model, tokenizer, image_processor, torch.float32, early_exit=True, exit_controller=ctl)
+    ens = ro.ModelWrapper(model, tokenizer, image_processor, torch.float32, early_exit=True, exit_controller=ctl, use_action_ensemble=True)
+    frames = []
+    env = ro.SyntheticEnv(seed=3)
+    obs = env.get_obs()
+    for t in range(6):
+        frames.append(obs)
+        obs, _, _, _ = env.step(np.zeros(7, dtype=np.float16))
+    runs = {}
+    for name, w in (("plain", plain), ("ens", ens)):
+        w.reset()
+        rec = []
+        for t, ob in enumerate(frames):
+            ctl.module.set_timestep(t)
+            a = w.step(ob, "push the red block")
+            r = model.engine.read_result()
+            rec.append((a[0].astype(np.float32), w.current_exit_layer, r["pose"].numpy(), r["gripper"], r["ens_pose"].numpy(), r["ens_gripper"],
+                        r["ens_count"], r["n_evals"]))
+        runs[name] = rec
+    two = 0
+    for (ap, lp, pose, gprob, _, _, _, _), (ae, le, _, _, epose, egrip, ecount, n_evals) in zip(runs["plain"], runs["ens"]):
+        assert lp == le                                                # the exit decision does not depend on the ensembling
+        assert np.allclose(ap[:6], pose.astype(np.float16).astype(np.float32)) and ap[6] == (1.0 if gprob > 0.5 else -1.0)
+        assert np.allclose(ae[:6], epose.astype(np.float16).astype(np.float32)) and ae[6] == (1.0 if egrip > 0.5 else -1.0)
+        assert ecount == min(2, n_evals - 1)                          # head evaluations of the step = pseudo action + the exit checks
+        two += ecount == 2
+    assert two > 0                                                     # some step exited at a later check: a real two-action mean
+
+
+@pytest.mark.gpu
 def test_chain_evaluation_and_metrics(harness):
     cfg, model, image_processor, tokenizer, ctl = harness
     w = ro.ModelWrapper(model, tokenizer, image_processor, torch.float32, early_exit=True, exit_controller=ctl)
