@@ -339,10 +339,10 @@ class MPTFlamingo(nn.Module):
                     break
         return CausalLMOutputWithPast(logits=[1.0], hidden_states=hidden, exit_layer=b)
 
-    def step_env_batch(self, vision_x, lang_x, attention_mask, vision_gripper, exit_controller=None, exit_id=None):
+    def step_env_batch(self, vision_x, lang_x, attention_mask, vision_gripper, exit_controller=None, exit_id=None, ensemble=False):
         """One control step of ALL n_envs environments (north_star: one env batch per rank): vision_x / vision_gripper
         (n_envs, ..., 3, S, S), lang_x / attention_mask (n_envs, T) right-padded.  Returns (pose (n_envs, 6), gripper prob (n_envs,),
-        exit layers list).  Every environment exits at its own layer on the device; LSTM state per environment."""
+        exit layers list); ``ensemble``: the mean of every environment's last two exit-check actions instead (eval_utils.py:457-461).  Every environment exits at its own layer on the device; LSTM state per environment."""
         e = self.engine
         ctl = getattr(exit_controller, "module", exit_controller)
         if exit_id is None:
@@ -350,7 +350,8 @@ class MPTFlamingo(nn.Module):
             self._sync_controller(ctl)
         r = e.step(vision_x, vision_gripper, lang_x, attention_mask, exit_id=exit_id)
         r = r if isinstance(r, list) else [r]
-        return torch.stack([x["pose"] for x in r]), torch.tensor([x["gripper"] for x in r]), [x["exit_layer"] for x in r]
+        pk, gk = ("ens_pose", "ens_gripper") if ensemble else ("pose", "gripper")    # ensemble: get_ensemble_action per environment
+        return torch.stack([x[pk] for x in r]), torch.tensor([x[gk] for x in r]), [x["exit_layer"] for x in r]
 
     def _forward_window(self, vision_x, lang_x, attention_mask, vision_gripper, with_gripper_logits=False, generator=None):
         """Window mode (flamingo_mpt.py:463-517 as ``generate_action_values`` calls it, value_net.py:375-385): the batch rows are

@@ -360,9 +360,12 @@ class BatchedModelWrapper:
     control step of the engine; every environment has its own instruction, LSTM history and exit layer.  ``step`` takes the
     observations / goals of all slots (None for an idle slot) and returns one (7,) float16 action per slot."""
 
-    def __init__(self, model, tokenizer, image_processor, cast_dtype, exit_controller=None, exit_id=None):
+    def __init__(self, model, tokenizer, image_processor, cast_dtype, exit_controller=None, exit_id=None, use_action_ensemble=False):
         m = model.module
         assert m.n_envs > 1, "build the model with n_envs > 1 (create_model_and_transforms(..., n_envs=B))"
+        if use_action_ensemble and (exit_controller is None or exit_id is not None):
+            raise ValueError("use_action_ensemble needs the dynamic exit (eval_utils.py:457-461)")
+        self.use_action_ensemble = bool(use_action_ensemble)
         self.model, self.B = model, m.n_envs
         self.cast_type = cast_dtype
         self.text_process_fn = functools.partial(preprocess_text_calvin, tokenizer=tokenizer)
@@ -421,7 +424,8 @@ class BatchedModelWrapper:
         with torch.no_grad():
             pose, g, exits = self.model.module.step_env_batch(rgb.to(self.cast_type).cuda(non_blocking=True), ids, mask,
                                                               grip.to(self.cast_type).cuda(non_blocking=True),
-                                                              exit_controller=self.exit_controller, exit_id=self.exit_id)
+                                                              exit_controller=self.exit_controller, exit_id=self.exit_id,
+                                                              ensemble=self.use_action_ensemble)
         self.current_exit_layers = exits
         act = torch.cat([pose, ((g > 0.5).to(pose.dtype).unsqueeze(1) - 0.5) * 2], dim=1)      # eval_utils.py:454-464
         return act.to(torch.float16).numpy()

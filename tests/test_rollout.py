@@ -120,6 +120,54 @@ def test_model_wrapper_action_ensemble_over_the_last_two_exits(harness):
 
 
 @pytest.mark.gpu
+def test_env_batch_action_ensemble_equals_single_environment_wrappers():
+    """``BatchedModelWrapper(use_action_ensemble=True)``: every slot's action equals what a single-environment ensembling wrapper
+    returns for the same frames (the device forms the mean per environment)."""
+    from deer_vla_amd.factory import create_model_and_transforms
+    from deer_vla_amd.value_net import ExitController, ActionValueNet
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, seed=5, std="fanin")
+    B, n = 3, 5
+
+    def build(n_envs):
+        model, proc, tok = create_model_and_transforms("ViT-L-14", "openai", "", "", cross_attn_every_n_layers=1, window_size=12, use_gripper=True,
+                                                       fusion_mode="post", llm_name="mpt_dolly_3b", state_dict=sd, cfg=cfg, n_envs=n_envs)
+        vn = ActionValueNet(model.get_all_exit_idx(), model.extra_exit, cfg.exit_interval, 12, "L2")
+        ctl = ExitController(vn, model.get_all_exit_idx(), steps_per_stage=1, leq=True, max_layer=cfg.early_exit_layer + 1)
+        ctl._set_threshold_value([0.02] * (ctl.real_num_exit - 1) + [1e5])
+        return model, proc, tok, ctl
+    frames = []
+    for e in range(B):
+        env = ro.SyntheticEnv(seed=10 + e)
+        obs, fl = env.get_obs(), []
+        for t in range(n):
+            fl.append(obs)
+            obs, _, _, _ = env.step(np.zeros(7, dtype=np.float16))
+        frames.append(fl)
+    goals = ["lift the blue block"] * B
+    model1, proc, tok, ctl1 = build(1)
+    single = []
+    for e in range(B):
+        w = ro.ModelWrapper(model1, tok, proc, torch.float32, early_exit=True, exit_controller=ctl1, use_action_ensemble=True)
+        w.reset()
+        acts = []
+        for t in range(n):
+            ctl1.module.set_timestep(t)
+            acts.append((w.step(frames[e][t], goals[e])[0].copy(), w.current_exit_layer))
+        single.append(acts)
+    modelB, procB, tokB, ctlB = build(B)
+    wb = ro.BatchedModelWrapper(modelB, tokB, procB, torch.float32, exit_controller=ctlB, use_action_ensemble=True)
+    for e in range(B):
+        wb.reset_env(e)
+    for t in range(n):
+        a = wb.step([frames[e][t] for e in range(B)], goals)
+        for e in range(B):
+            assert wb.current_exit_layers[e] == single[e][t][1], (t, e)
+            got, want = np.asarray(a[e], dtype=np.float32).reshape(-1), single[e][t][0].astype(np.float32)
+            assert np.abs(got[:6] - want[:6]).max() < 2e-3 and got[6] == want[6], (t, e, got, want)
+
+
+@pytest.mark.gpu
 def test_chain_evaluation_and_metrics(harness):
     cfg, model, image_processor, tokenizer, ctl = harness
     w = ro.ModelWrapper(model, tokenizer, image_processor, torch.float32, early_exit=True, exit_controller=ctl)
