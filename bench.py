@@ -346,15 +346,19 @@ def surface_leg(cfg, eng, thr, frames, ids, steps, warmup=20):
         ids_t, mask_t = ids_t.to(eng.dev), mask_t.to(eng.dev)
         model.clear_all_exit_memory()
         exits = 0
-        for i in range(n):
-            if i == warmup:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-            ctl.set_timestep(i)
-            o = model(vision_x=pre[i % len(pre)][0], lang_x=ids_t, attention_mask=mask_t, vision_gripper=pre[i % len(pre)][1],
-                      dynamic_early_exit=True, exit_controller=ctl)
-            if i >= warmup:
-                exits += o.exit_layer + 1
+        model.host_outputs = True                                  # what ModelWrapper.step asks for on its own calls
+        try:
+            for i in range(n):
+                if i == warmup:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                ctl.set_timestep(i)
+                o = model(vision_x=pre[i % len(pre)][0], lang_x=ids_t, attention_mask=mask_t, vision_gripper=pre[i % len(pre)][1],
+                          dynamic_early_exit=True, exit_controller=ctl)
+                if i >= warmup:
+                    exits += o.exit_layer + 1
+        finally:
+            model.host_outputs = False
         torch.cuda.synchronize()
         return steps / (time.perf_counter() - t0), exits / steps
 

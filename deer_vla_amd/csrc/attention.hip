@@ -216,7 +216,7 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
   const bf16_t* v2 = reinterpret_cast<const bf16_t*>(V2);
   const int kvpad = (kv_len + 31) & ~31;
   const int smem = (kvpad * AM_KPITCH + AM_HD * (kvpad + 8)) * (int)sizeof(bf16_t);
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   constexpr int max_smem = (AM_MAXT * 16 * AM_KPITCH + AM_HD * (AM_MAXT * 16 + 8)) * 2;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,

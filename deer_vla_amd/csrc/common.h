@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>   // launch wrappers are called from several host threads (env batches in flight): their one-time attribute flags are atomics
 
 typedef uint16_t bf16_t;  // bf16 storage type in HBM / LDS
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -343,7 +343,7 @@ static int launch_ring272(const bf16_t* A, int lda, long strideA, const bf16_t* 
   if ((N & 255) || (K & 31) || M <= 0 || batch <= 0) return DEER_ERR_SHAPE;
   const int tile_rows = (M % 257 == 0) ? 257 : 272;         // M = 257 n (n camera frames): one frame per row tile
   constexpr int smem_bytes = D * 33 * 1024;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   auto kern = &gemm_ring272_kernel<D>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
@@ -561,7 +561,7 @@ static int launch_frame(const bf16_t* A, int lda, long strideA, const bf16_t* W,
   constexpr int f_bytes = (4 * TM + 1) * 16 * (BN * 4 + 16) <= 160 * 1024 ? (4 * TM + 1) * 16 * (BN * 4 + 16) : 0;
   constexpr int rc_bytes = ring_bytes > c_bytes ? ring_bytes : c_bytes;
   constexpr int smem_bytes = rc_bytes > f_bytes ? rc_bytes : f_bytes;   // the ring, then the staged C tile (bf16, or f32 where it fits)
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   auto kern = &gemm_frame_kernel<TM, WN, TN, D>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
@@ -582,7 +582,7 @@ static int launch_ring32(const bf16_t* A, int lda, long strideA, const bf16_t* W
                          hipStream_t st) {
   if ((N & 15) || (K & 31) || M <= 0 || batch <= 0) return DEER_ERR_SHAPE;
   constexpr int smem_bytes = D * (BM + BN) * 64;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   auto kern = &gemm_ring32_kernel<BM, BN, D, STAG>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)

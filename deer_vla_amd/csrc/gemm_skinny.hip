@@ -301,7 +301,7 @@ extern "C" int deer_gemm_skinny_hl(const void* Ahi, const void* Alo, int lda, co
   case MT_: {                                                                                                                \
     constexpr int smem = D_ * (4 * ((MT_ + 1) & ~1) + 16) * 1024;                                                            \
     static_assert(smem <= 160 * 1024, "LDS");                                                                                \
-    static bool attr_set = false;                                                                                            \
+    static std::atomic<bool> attr_set{false};                                                                                            \
     auto kern = &gemm_skinny_hl_kernel<MT_, D_>;                                                                             \
     if (!attr_set) {                                                                                                         \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=     \
@@ -416,7 +416,7 @@ extern "C" int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int 
   const bf16_t* wp = reinterpret_cast<const bf16_t*>(Wp);
 #define DEER_SK_LAUNCH(MT_, SP_, NW_, WU_)                                                                                     \
   do {                                                                                                                         \
-    static bool attr_set = false;                                                                                              \
+    static std::atomic<bool> attr_set{false};                                                                                              \
     auto kern = &gemm_skinny_kernel<MT_, SP_, NW_, WU_>;                                                                       \
     if (!attr_set) {                                                                                                           \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) !=  \

@@ -338,7 +338,7 @@ static int launch_ring(const bf16_t* A, int lda, long strideA, const bf16_t* W, 
                        const int* ctl, hipStream_t st) {
   constexpr int smem = D * (BM + BN) * 128;
   static_assert(smem <= 160 * 1024, "LDS");
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (PIPE && ((K / GT_BK) & 1)) return DEER_ERR_SHAPE;   // pipelined loop is unrolled by two K-steps
   auto kern = &gemm_tiled_ring_kernel<BM, BN, WM, WN, D, DBG, U, PIPE>;
   if (!attr_set) {
@@ -358,7 +358,7 @@ static int launch_tiled(const bf16_t* A, int lda, long strideA, const bf16_t* W,
                         int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate,
                         const int* ctl, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * GT_PITCH * (int)sizeof(bf16_t);
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   auto kern = &gemm_tiled_kernel<BM, BN>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)

@@ -451,7 +451,7 @@ extern "C" int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mo
   const int per_env = (in_dim + H) * (int)sizeof(float);
   const int nb_max = (150 * 1024 - 64) / per_env;
   if (nb_max < 1) return DEER_ERR_SHAPE;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&head_lstm_layer_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             150 * 1024) != hipSuccess ||
@@ -774,6 +774,10 @@ __global__ void ctl_begin_step_kernel(int* ctl0, const int* hold_src, int B) {
     ctl[CTL_N_EVALS] = 0;
     ctl[CTL_COMMITTED] = 0;
     ctl[CTL_PREV_REAL] = 0;                             // reset_actions() after every step of the ensembling harness (eval_utils.py:461)
+    // ... which also empties action_list: a step in which no exit check runs (hold steps, steps_per_stage > 1) has NO ensemble action -
+    // count 0 makes get_ensemble_action() assert like the reference's `assert len(self.action_list) > 0` (value_net.py:93) instead of
+    // handing back the previous step's mean
+    ctl[CTL_ENS_ACTION + 7] = 0;
     if (b == 0) {
       ctl[CTL_HOLD] = (hold_src != nullptr) ? hold_src[0] : 0;
       ctl[CTL_SEQ] = (hold_src != nullptr) ? hold_src[1] : 0;

@@ -209,7 +209,7 @@ extern "C" int deer_attn_f32(const float* Q, const float* K1, const float* V1, c
     return DEER_ERR_SHAPE;
   const int kv = kv1 + kv2;
   const int smem = (kv * 65 + PA_QB * 64 + PA_QB * kv) * (int)sizeof(float);
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
       return DEER_ERR_LAUNCH;
@@ -295,7 +295,7 @@ extern "C" int deer_xattn_f32(const float* qslab, int s_in, long slab_stride, in
   if (T <= 0 || T > PX_MAXT || n_kv <= 0 || n_kv > PX_MAXKV || s_in <= 0 || n_per_media <= 0 || batch <= 0 || (ldkv & 3) || (ldqs & 3))
     return DEER_ERR_SHAPE;
   const int smem = (PX_MAXT * 65 + PX_MAXT * (PX_MAXKV + 1) + PX_MAXKV * 65 + PX_MAXKV * 64) * (int)sizeof(float);
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return DEER_ERR_LAUNCH;

@@ -267,7 +267,7 @@ extern "C" int deer_xattn_fused(const float* xn, int d, const void* Wq_p, const 
   dim3 grid(heads * NS, batch);
 #define DEER_XF_LAUNCH(MT_)                                                                                                     \
   do {                                                                                                                          \
-    static bool attr_set = false;                                                                                               \
+    static std::atomic<bool> attr_set{false};                                                                                               \
     auto kern = &xattn_fused_kernel<MT_>;                                                                                       \
     if (!attr_set) {                                                                                                            \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) !=  \

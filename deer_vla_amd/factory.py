@@ -14,6 +14,7 @@ network, no checkpoints), so
 """
 from __future__ import annotations
 
+import dataclasses
 import os
 import zlib
 from typing import Optional
@@ -166,7 +167,6 @@ def create_model_and_transforms(clip_vision_encoder_path: str = "ViT-L-14", clip
         "residual": (bool(residual), False, "changes init_flamingo's gated x-attn (flamingo_mpt.py:111-121)"),
         "pad_length": (pad_length, -1, "the harness asserts pad_length == -1 for multi-exit nets (eval_utils.py:300)"),
         "refresh": (refresh, -1, "refresh_window re-runs the LSTM over the stored window (action_head.py:561-586)"),
-        "return_feature": (bool(return_feature), False, "feature outputs of the head are a training-side hook"),
         "layerwise_exit_eval": (bool(flamingo_kwargs.get("layerwise_exit_eval", False)), False,
                                 "per-exit heads lm_exits[i] instead of extra_exit (flamingo_mpt.py:443-461)"),
         "use_hist": (bool(flamingo_kwargs.get("use_hist", False)), False, "history frames (flamingo_mpt.py:372-373)"),
@@ -179,10 +179,14 @@ def create_model_and_transforms(clip_vision_encoder_path: str = "ViT-L-14", clip
     for name, got in (("use_state", use_state), ("sep_resampler", sep_resampler)):
         if got and not getattr(DeerConfig, "supports_" + name, False):
             raise NotImplementedError(f"create_model_and_transforms({name}=True) is not implemented by deer_vla_amd")
-    if hidden_size is not None and hidden_size != 1024:
-        raise NotImplementedError("hidden_size is a GPTDecoder keyword (flamingo_mpt.py:179); the LSTM head is 1024 wide")
-    if not flamingo_kwargs.get("multi_exit", True):
-        raise NotImplementedError("multi_exit=False builds no extra_exit head (flamingo_mpt.py:239-259)")
+    # Accepted as no-ops, exactly as the reference treats them on this path (eval_calvin.py:491-540 passes all three on every run):
+    #  * return_feature (hard-coded True at eval_calvin.py:516): a constructor default that DeterministicDecoder.forward overwrites with
+    #    its own argument on every call (action_head.py:499-511; MPTFlamingo.forward passes return_feature=False by default);
+    #  * hidden_size (argparse default 768, eval_calvin.py:314,521): read only by GPTDecoder (flamingo_mpt.py:179,229); with
+    #    decoder_type == "lstm" (enforced above) nothing reads it - the LSTM head is 1024 wide (action_head.py:428);
+    #  * multi_exit=False (eval_calvin.py:530 whenever layerwise_exit_eval == 0): only makes lm_exits an nn.Identity; extra_exit, the one
+    #    head used at inference, is built either way (flamingo_mpt.py:236-259).
+    del return_feature, hidden_size
     early_exit_layer = flamingo_kwargs.get("early_exit_layer", -1)
     if cfg is None:
         base = deer_9b if llm_name == "mpt_9b" else deer_3b
@@ -199,8 +203,8 @@ def create_model_and_transforms(clip_vision_encoder_path: str = "ViT-L-14", clip
         cfg.lstm_num_layers = flamingo_kwargs.get("lstm_num_layers", 4)
         cfg.pooling = pooling
         cfg.window_size = window_size
-    cfg.use_state = bool(use_state) or cfg.use_state                 # action_head.py:524-536 / flamingo_mpt.py:132-134 variants
-    cfg.sep_resampler = bool(sep_resampler) or cfg.sep_resampler
+    # action_head.py:524-536 / flamingo_mpt.py:132-134 variants; a caller-supplied cfg is never mutated
+    cfg = dataclasses.replace(cfg, use_state=bool(use_state) or cfg.use_state, sep_resampler=bool(sep_resampler) or cfg.sep_resampler)
     synthetic = state_dict is None
     if synthetic:
         state_dict = syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True)

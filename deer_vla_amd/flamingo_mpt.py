@@ -47,9 +47,13 @@ class _LazyHidden:
 
     def __init__(self, engine, exit_layer, T):
         self._e, self._n, self._T, self._t = engine, exit_layer + 1, T, None
+        self._seq = engine._seq                     # the step these buffers belong to
 
     def _materialise(self):
         if self._t is None:
+            if self._e._seq != self._seq:           # a later step has overwritten the engine's buffers: never hand out its data
+                raise RuntimeError("hidden_states of a host_outputs step were first read after a later control step; read them before "
+                                   "the next step or call the model with host_outputs=False (eager device copies)")
             hs = self._e.hidden[: self._n, : self._T].clone()
             self._t = tuple(hs[i].unsqueeze(0) for i in range(self._n))
         return self._t

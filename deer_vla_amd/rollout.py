@@ -128,8 +128,9 @@ class ModelWrapper:
         if m.act_step != 1:
             raise NotImplementedError("multi-step action heads are not part of DeeR's released configuration")
         self.model = model
-        if hasattr(m, "host_outputs"):
-            m.host_outputs = True                                   # this wrapper reads only the action and the exit layer
+        # this wrapper reads only the action and the exit layer: its OWN forward calls ask for host outputs (step()); the flag is
+        # restored after every call, so other callers of the shared model keep eager device tensors
+        self._host_outputs = hasattr(m, "host_outputs")
         self.replan = m.replan
         self.decoder_type = m.decoder_type
         self.cast_type = cast_dtype
@@ -184,9 +185,16 @@ class ModelWrapper:
             gripper = gripper.cuda(non_blocking=True) if gripper is not None else None
             self.img_queue.append(image_x)
             self.gripper_queue.append(gripper)
-            out = self.model(vision_x=image_x, lang_x=text_x, attention_mask=mask, vision_gripper=gripper, state_tensor=state,
-                             return_feature=True, deterministic=True, exit_id=self.exit_id,
-                             dynamic_early_exit=self.dynamic_early_exit, exit_controller=self.exit_controller)
+            prev_ho = getattr(m, "host_outputs", False)
+            if self._host_outputs:
+                m.host_outputs = True
+            try:
+                out = self.model(vision_x=image_x, lang_x=text_x, attention_mask=mask, vision_gripper=gripper, state_tensor=state,
+                                 return_feature=True, deterministic=True, exit_id=self.exit_id,
+                                 dynamic_early_exit=self.dynamic_early_exit, exit_controller=self.exit_controller)
+            finally:
+                if self._host_outputs:
+                    m.host_outputs = prev_ho
             if hasattr(out, "exit_layer"):
                 self.current_exit_layer = out.exit_layer
             # eval_utils.py:454-462: [pose6, gripper > 0.5] of the last time step, gripper scaled to -1 / +1

@@ -80,8 +80,43 @@ class ActionValueNet:
         device (``head_final``: CTL_ENS_ACTION) and handed over by ``MPTFlamingo.forward`` with the step's verdict; returns
         (pose (1, 1, 6), gripper probability (1, 1, 1)) like the reference's head outputs."""
         ens = getattr(self, "_ensemble", None)
+        if ens is None and self.action_list:       # slow path (the controller was CALLED, see forward): the reference's own formula
+            actions, grippers = zip(*self.action_list[-2:])
+            return torch.stack(actions, dim=0).mean(0), torch.stack(grippers, dim=0).mean(0)
         assert ens is not None and ens[2] > 0, "no exit check ran since the last reset_actions() (value_net.py:93)"
         return ens[0].view(1, 1, 6), torch.tensor([ens[1]], dtype=torch.float32).view(1, 1, 1)
+
+    def _delta(self, a1: torch.Tensor, a2: torch.Tensor) -> torch.Tensor:
+        """``get_delta`` (value_net.py:105-117)."""
+        delta = torch.abs(a1 - a2)
+        if self.threshold_type == "mean":
+            return delta.mean(-1)
+        if self.threshold_type == "L2":
+            return delta.pow(2).mean(-1).pow(0.5)
+        if self.threshold_type == "max":
+            return delta.max(-1)[0]
+        if self.threshold_type == "cosine":
+            return 1 - torch.nn.functional.cosine_similarity(a1, a2, dim=-1, eps=1e-5)
+        raise NotImplementedError(self.threshold_type)
+
+    def forward(self, feats, i=None, mode="infer", rand_layer_feat=None):
+        """``ActionValueNet.forward(mode='infer')`` (value_net.py:120-133) on the HOST: the slow path a caller takes when it invokes
+        the controller like the reference's LLM loop does (mosaic_gpt_3b.py:438-439) instead of handing it to ``MPTFlamingo.forward``
+        (where the same criterion runs on the device).  ``feats``: tuple of hidden states (1, T, d), ``exit_head``: the model's
+        ``extra_exit`` handle - every call is one head evaluation on the engine + one synchronisation."""
+        if mode != "infer":
+            raise NotImplementedError("mode='generate' runs through generate_action_values / DeerEngine.generate_values")
+        assert i > 0, "the first layer similarity is not implemented yet"
+        if i - self.interval < 0:                   # no action before the first exit: pseudo action from the previous layer's feature
+            prev_action = self.exit_head(feats[i - 1], update_hidden_state=False)
+        else:
+            prev_action = self.action_list[-1]
+        action = self.exit_head(feats[i], update_hidden_state=False)
+        self.action_list.append(action)
+        self._ensemble = None
+        return self._delta(action[0], prev_action[0])
+
+    __call__ = forward
 
 
 class ExitController:
@@ -128,6 +163,28 @@ class ExitController:
 
     def set_timestep(self, t):
         self.cur_step = t
+
+    @torch.no_grad()
+    def forward(self, x, i):
+        """``ExitController.forward`` (value_net.py:277-297), the reference's protocol ``ctl(all_hidden_states, b_idx) -> bool`` as
+        the LLM loop calls it (mosaic_gpt_3b.py:438-439).  Host-side slow path: ``MPTFlamingo.forward`` never comes here with a
+        native controller (it configures the device-side gate instead); a foreign LLM loop, ``lang_encoder(...)`` called directly
+        with this controller, and the tests do."""
+        assert self.thresholds is not None, "Please set thresholds before calling forward"
+        assert isinstance(i, int), "index muast be integer"
+        if i not in self.exit_id_list:
+            return False
+        if self.cur_step % self.steps_per_stage != 0:            # still in a stage: reuse the previous exit id
+            return i >= self.cur_exit_id
+        if not isinstance(self.value_net, ActionValueNet):
+            raise NotImplementedError
+        value = self.value_net(x, i)
+        if bool(value <= self.thresholds[i]) is self.leq or i >= self.max_layer:   # both true or both false
+            self.cur_exit_id = i
+            return True
+        return False
+
+    __call__ = forward
 
     def threshold_list(self) -> List[float]:
         return [self.thresholds[e] for e in self.exit_id_list[: self.real_num_exit]]

@@ -95,6 +95,34 @@ def test_foreign_controller_protocol(setup):
         assert float((o.logits[0].cpu() - g[tag + "_pose"][s]).abs().max()) < TOL
 
 
+def test_native_controller_called_through_the_llm_loop(setup):
+    """the NATIVE controller invoked with the reference protocol - ``lang_encoder(ids, mask, exit_controller=ctl)``
+    runs the reference's host loop (mosaic_gpt_3b.py:397-443), which calls ``ctl(all_hidden_states, b_idx)`` after every layer; the
+    controller's ``forward`` (value_net.py:277-297) then evaluates ``ActionValueNet.forward`` -> ``extra_exit(feats[i],
+    update_hidden_state=False)`` on the engine's head kernels.  Exit layers and actions against the reference's own dynamic-exit
+    goldens, and identical to what the device-side gate decides for the same controller."""
+    cfg, g, model = setup
+    ids, mask = g["ids"].long().cuda(), g["mask"].cuda()
+    tag = "dyn"
+    model.clear_all_exit_memory()
+    e = model.engine
+    vn = ActionValueNet(model.get_all_exit_idx(), model.extra_exit, cfg.exit_interval, 1, "L2")
+    ctl = ExitController(vn, model.get_all_exit_idx(), steps_per_stage=1, leq=True, exit_dist="exp", max_layer=int(g[tag + "_max_layer"]))
+    ctl._set_threshold_value([float(t) for t in g[tag + "_thr"]])
+    for s in range(g["rgb"].shape[0]):
+        ctl.set_timestep(s)
+        e.load_inputs(g["rgb"][s].cuda(), g["grip"][s].cuda(), ids, mask)
+        e.enqueue_vision()
+        out = model.lang_encoder(ids, mask, exit_controller=ctl)
+        assert out.exit_layer == int(g[tag + "_exit"][s]) == ctl.cur_exit_id, s
+        assert len(out.hidden_states) == out.exit_layer + 1
+        pose, grip = model.extra_exit(out.hidden_states[out.exit_layer], update_hidden_state=True)      # flamingo_mpt.py:459
+        assert float((pose.cpu() - g[tag + "_pose"][s]).abs().max()) < TOL
+        ep, eg = vn.get_ensemble_action()                      # host-side action list of the slow path (value_net.py:92-95)
+        assert float((ep.cpu() - g[tag + "_ens_pose"][s]).abs().max()) < TOL
+        vn.reset_actions()
+
+
 def test_forward_argument_errors(setup):
     cfg, g, model = setup
     ids, mask = g["ids"].long().cuda(), g["mask"].cuda()
