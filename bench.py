@@ -54,9 +54,14 @@ def parse():
                     help="untimed steps from the episode start before warm-up: the timed window then sits mid-episode (LSTM in "
                          "steady state) whatever --steps is")
     ap.add_argument("--latency-reps", type=int, default=15, help="static-exit steps timed per exit for `latency_ms_by_exit` (0 disables)")
+    ap.add_argument("--on-policy-steps", type=int, default=200,
+                    help="timed steps of the `on_policy` leg (the real exit criterion with the calibrated thresholds, mid-episode); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
-    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the CPU leg; 0 = pick the fastest of a measured sweep over 32 / 64 / 128 (capped at the host's cores)")
+    ap.add_argument("--cpu-full-protocol", action="store_true",
+                    help="CPU leg with BASELINE.md section 3's full 20 warm-up + 100 timed steps (minutes) instead of the bounded sample")
     ap.add_argument("--window-reps", type=int, default=10,
                     help="window-mode (threshold calibration) leg: windows of cfg.window_size frame pairs timed as batch rows (0 = skip)")
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
@@ -430,31 +435,65 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(cfg, sd, ctl, budget_s, threads, rank):
+def target_schedule(n_exits, exit_ratio, n, seed=99):
+    """Exit SLOTS (indices into the thresholded exits + the forced one) of n steps at the calibration target p_k ~ exit_ratio^k
+    (value_net.py:216-217,238), STRATIFIED: slot k appears round(n * p_k) times (largest remainders), in a seeded shuffle - so the mix,
+    and with it the average depth, is the target's for every n (20 steps: 5/4/4/3/2/2 -> 5.9 layers vs E = 5.74) instead of whatever n
+    independent draws happen to give."""
+    pk = [float(exit_ratio) ** k for k in range(1, n_exits + 1)]
+    tot = sum(pk)
+    want = [n * p / tot for p in pk]
+    cnt = [int(w) for w in want]
+    for k in sorted(range(n_exits), key=lambda k: -(want[k] - cnt[k]))[: n - sum(cnt)]:
+        cnt[k] += 1
+    slots = [k for k in range(n_exits) for _ in range(cnt[k])]
+    perm = torch.randperm(len(slots), generator=torch.Generator().manual_seed(seed)).tolist()
+    return [slots[i] for i in perm]
+
+
+def forced_thresholds(slot, real):
+    """thresholds that make the exit check of `slot` the first one to fire: the checks before it run and decline (delta > -1), this
+    one accepts (delta <= 1e8) - the dynamic path does all of its work, the verdict is scripted"""
+    return [-1.0] * slot + [1e8] * (real - slot)
+
+
+def cpu_baseline(cfg, sd, ctl, slots, budget_s, threads, rank, full_protocol=False):
     """The CPU oracle (oracle/deer_oracle.py = pure-PyTorch fp32 restatement of the reference forward, pinned against
-    the reference's own modules) timed on this box's host cores on a bounded sample of the same workload (same synthetic
-    inputs, weights, thresholds).  Protocol of BASELINE.md §3 with two documented deviations (see `deviation`)."""
+    the reference's own modules) timed on this box's host cores on a bounded sample of the SAME workload: same synthetic inputs and
+    weights, the same dynamic-exit protocol, and the same scripted exit mix as the GPU leg (`slots`: stratified to the calibration
+    target, so the CPU figure is MEASURED at the GPU leg's depth).  Thread count: the fastest of a measured sweep (BASELINE.md
+    section 3 says "all host cores"; with all 256 logical cores PyTorch's intra-op pool oversubscribes - the sweep is in the JSON)."""
     from deer_vla_amd import synthetic as syn
     from oracle import deer_oracle as orc
-    cores = max(1, min(threads, os.cpu_count() or 1))
-    torch.set_num_threads(cores)
     model = orc.OracleDeer(sd, cfg)
     model.set_all_exit_window_size(1)
     vn = orc.OracleValueNet(ctl.exit_id_list, model.extra_exit, cfg.exit_interval, 1, "L2")
     oc = orc.OracleExitController(vn, ctl.exit_id_list, steps_per_stage=1, max_layer=ctl.max_layer + 1)
-    oc._set_threshold_value(ctl.threshold_list())
-    exits = []
+    real = ctl.real_num_exit
+
+    def one(s, slot):
+        rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, s, rank=rank)
+        oc._set_threshold_value(forced_thresholds(slot, real))
+        oc.set_timestep(s)
+        o = model.forward(rgb, ids, mask, grip, dynamic_early_exit=True, exit_controller=oc)
+        return o["exit_layer"]
+
+    ncpu = os.cpu_count() or 1
+    sweep = {}
     with torch.no_grad():
-        def one(s):
-            rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, s, rank=rank)
-            oc.set_timestep(s)
-            o = model.forward(rgb, ids, mask, grip, dynamic_early_exit=True, exit_controller=oc)
-            return o["exit_layer"]
-        t0 = time.perf_counter()
-        one(0)                                             # warm-up (thread pools, allocator); also sizes the sample
-        one(1)
-        warm = (time.perf_counter() - t0) / 2
-        # per-stage milliseconds (BASELINE.md §3): vision tower, one LLM layer (x-attn + block), one head evaluation
+        cands = [threads] if threads > 0 else sorted({min(c, ncpu) for c in (32, 64, 128)})
+        mid = real // 2
+        for c in cands:
+            torch.set_num_threads(c)
+            one(0, mid)                                        # warm-up of this pool size
+            t0 = time.perf_counter()
+            one(1, mid)
+            one(2, mid)
+            sweep[c] = round(2 / (time.perf_counter() - t0), 4)
+        cores = max(sweep, key=sweep.get)
+        torch.set_num_threads(cores)
+        warm = 1.0 / sweep[cores]
+        # per-stage milliseconds (BASELINE.md section 3): vision tower, one LLM layer (x-attn + block), one head evaluation
         rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, 2, rank=rank)
         t0 = time.perf_counter()
         vis = model.encode_vision(rgb, grip)
@@ -466,21 +505,28 @@ def cpu_baseline(cfg, sd, ctl, budget_s, threads, rank):
         model.extra_exit(hid[0], update_hidden_state=False)
         t_head = time.perf_counter() - t0
         model.clear_all_exit_memory()
-        n_steps = int(max(2, min(100, budget_s / max(warm, 1e-3))))
+        n_warm, n_steps = (20, 100) if full_protocol else (2, int(max(6, min(100, budget_s / max(warm, 1e-3)))))
+        sched = target_schedule(real, _EXIT_RATIO[0], n_steps, seed=99)
+        for s in range(n_warm):
+            one(s, sched[s % len(sched)])
+        exits = []
         t0 = time.perf_counter()
         for s in range(n_steps):
-            exits.append(one(s) + 1)
+            exits.append(one(n_warm + s, sched[s]) + 1)
         dt = time.perf_counter() - t0
     return {"value": round(n_steps / dt, 4), "unit": "action-steps/s", "cores": cores, "kind": "port",
-            "host_logical_cores": os.cpu_count(),
+            "host_logical_cores": ncpu, "thread_sweep_steps_per_s": {str(k): v for k, v in sweep.items()},
             "per_stage_ms": {"vision_tower_2xViT_2xPerceiver": round(1e3 * t_vis, 1), "llm_layer": round(1e3 * t_layer, 2),
                              "head_evaluation": round(1e3 * t_head, 2)},
             "avg_exit_layer": round(sum(exits) / len(exits), 2),
-            "sample": f"2 warm-up + {n_steps} timed control steps of the same workload (fp32 oracle, torch.set_num_threads({cores}) on a "
-                      f"{os.cpu_count()}-logical-core host), {dt:.1f} s",
-            "deviation": "BASELINE.md §3 asks for 20+100 steps on all cores: the sample is bounded to ~%.0f s of CPU work (task contract) "
-                         "and uses %d threads - with all %s logical cores PyTorch's intra-op pool oversubscribes (measured 0.005 "
-                         "steps/s in round 1)" % (budget_s, cores, os.cpu_count())}
+            "sample": f"{n_warm} warm-up + {n_steps} timed control steps of the same workload at the GPU leg's scripted exit mix (fp32 oracle, "
+                      f"dynamic-exit protocol, torch.set_num_threads({cores}) on a {ncpu}-logical-core host), {dt:.1f} s",
+            "protocol": "BASELINE.md section 3 (20 + 100 steps)" if full_protocol else
+                        "bounded sample (task contract: ~10-30 s of CPU work); --cpu-full-protocol runs BASELINE.md section 3's 20 + 100 "
+                        "steps (profiles/ holds one such run per round)"}
+
+
+_EXIT_RATIO = [0.8]     # set by main() from --exit-ratio (read by cpu_baseline's schedule)
 
 
 def run_workload(args, cfg, sd_dev, B, rank, world, local_rank, dist, max_layer, timed_steps, warmup):
@@ -548,30 +594,72 @@ def run_workload(args, cfg, sd_dev, B, rank, world, local_rank, dist, max_layer,
     thr = ctl.threshold_list()
     eng.set_thresholds(thr)
 
-    # ---- timed region ----
-    # the episode starts `burn_in` steps BEFORE the warm-up, so the timed window sits mid-episode (LSTM history in steady
-    # state) and its depth statistics do not depend on --steps / --warmup (20 timed steps right after a reset
-    # averaged exit layer 9.8, 300 steps 4.45)
-    for i in range(args.burn_in + warmup):
-        run_step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    exit_sum, hist = 0, [0] * cfg.n_layers
-    for i in range(args.burn_in + warmup, args.burn_in + warmup + timed_steps):
-        r = run_step(i)
-        for re in (r if B > 1 else [r]):
-            exit_sum += re["exit_layer"] + 1
-            hist[re["exit_layer"]] += 1
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    real_n = ctl.real_num_exit
 
-    stats = torch.tensor([elapsed, float(exit_sum), float(timed_steps * B)], dtype=torch.float64, device=dev)
+    def timed(n_steps, pre, slots=None):
+        """`pre` untimed + `n_steps` timed control steps (contract: barrier + synchronize on both sides); slots: scripted verdicts
+        (one exit slot per step, thresholds forced on the device before the step) or None = the calibrated thresholds (on-policy)."""
+        thr_rows = None
+        if slots is not None:
+            thr_rows = torch.full((real_n, 16), 1e8, dtype=torch.float32)
+            for k in range(real_n):
+                thr_rows[k, :real_n] = torch.tensor(forced_thresholds(k, real_n))
+            thr_rows = thr_rows.to(dev)
+        else:
+            eng.set_thresholds(thr)
+
+        def one(i):
+            if thr_rows is not None:
+                eng.set_thresholds_device(thr_rows[slots[i % len(slots)]])
+            return run_step(i)
+        for i in range(pre):
+            one(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        exit_sum, hist = 0, [0] * cfg.n_layers
+        for i in range(pre, pre + n_steps):
+            r = one(i)
+            for re in (r if B > 1 else [r]):
+                exit_sum += re["exit_layer"] + 1
+                hist[re["exit_layer"]] += 1
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, exit_sum, hist
+
+    # ---- on-policy leg (secondary): the REAL criterion with the calibrated thresholds, mid-episode (burn-in first: 20 steps right after
+    # a reset averaged exit layer 9.8, 300 steps 4.45 in round 1).  Its depth is whatever the synthetic episode's own deltas give - with
+    # random weights they are not the calibration deltas - which is why it is not the headline (VERDICT r3 #5: 318 <-> 357 <-> 387
+    # steps/s between runs of the same code with the 4th digit of a threshold).
+    on_policy = None
+    n_on = args.on_policy_steps if B == 1 else timed_steps
+    if n_on > 0:
+        dt, xs, hist = timed(n_on, args.burn_in + warmup)
+        on_policy = {"value": round(world * n_on * B / dt, 2), "unit": "action-steps/s", "steps": n_on, "avg_exit_layer": round(xs / (n_on * B), 3),
+                     "exit_hist": hist, "thresholds": [round(x, 6) for x in thr],
+                     "note": "dynamic exits decided by the calibrated thresholds on the synthetic episode's own deltas (this rank's "
+                             "replica x world; not barrier-timed across ranks)"}
+    if B > 1:
+        # env batches: every environment exits at its own layer by the real criterion (thresholds are shared by the batch, so a
+        # scripted verdict would make all environments leave together) - this leg IS the on-policy one
+        elapsed, exit_sum, hist = dt, xs, hist
+        n_timed = n_on
+    else:
+        # ---- the timed region of `value`: `timed_steps` steps of the DYNAMIC pipeline (pseudo action, every exit check up to the exit,
+        # device-side verdict, host-fed graph pieces) with the verdicts scripted to the calibration target mix, stratified - the depth
+        # of the timed window is the target's whatever --steps is
+        slots = target_schedule(real_n, args.exit_ratio, timed_steps, seed=99)
+        eng.reset()
+        eng.cur_step = 0
+        elapsed, exit_sum, hist = timed(timed_steps, warmup, slots)
+        eng.set_thresholds(thr)
+        n_timed = timed_steps
+
+    stats = torch.tensor([elapsed, float(exit_sum), float(n_timed * B)], dtype=torch.float64, device=dev)
     if dist is not None:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -579,7 +667,7 @@ def run_workload(args, cfg, sd_dev, B, rank, world, local_rank, dist, max_layer,
         stats[0] = tmax[0]
     t_max, exits, n_steps = float(stats[0]), float(stats[1]), float(stats[2])
     return dict(eng=eng, ctl=ctl, frames=frames, ids=ids, T=T, t_max=t_max, value=n_steps / t_max, avg_exit=exits / n_steps, thr=thr,
-                hist=hist, setup_s=setup_s)
+                hist=hist, setup_s=setup_s, on_policy=on_policy, n_timed=n_timed)
 
 
 def main():
@@ -612,6 +700,7 @@ def main():
         cfg = deer_3b(max_layer=max_layer)
     sd = syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True)
     B = args.envs_per_gpu
+    _EXIT_RATIO[0] = args.exit_ratio
     res = run_workload(args, cfg, sd, B, rank, world, local_rank, dist, max_layer, args.steps, args.warmup)
     if res is None:
         print(json.dumps({"full_depth_steps": args.full_depth_only}))
@@ -624,23 +713,29 @@ def main():
         "metric": "action-steps/sec (whole job) + avg exit-layer, %s max_layer=%d, synthetic CALVIN-D-shaped inputs"
                   % ("MPT-7B" if args.workload == "deer_9b" else "MPT-1B", max_layer),
         "value": round(value, 2), "unit": "action-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1e3 * t_max / res["n_timed"], 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32 activations, bf16-representable weights", "data": "synthetic",
         "avg_exit_layer": round(res["avg_exit"], 3),
         "config": {"workload": "%s DeeR-%s max_layer=%d exit_ratio=%.2f, step mode, %d env(s)/GPU per control "
                                "step, 2x224x224 frames + %d text tokens per env, LSTM history carried over %d-step episodes"
                                % ("OpenFlamingo-9B/MPT-7B" if args.workload == "deer_9b" else "OpenFlamingo-3B/MPT-1B",
                                   "B" if max_layer == 12 else "S", max_layer, args.exit_ratio, B, T, EP_LEN),
-                   "envs_per_gpu": B, "ms_per_env_step": round(1e3 * t_max / (args.steps * B), 4),
+                   "avg_exit_layer": round(res["avg_exit"], 3),
+                   "exit_schedule": ("dynamic pipeline (pseudo action + every exit check up to the exit, device-side verdict), verdicts "
+                                     "scripted to the calibration target p_k ~ %.2f^k, stratified over the timed steps (depth-stable for "
+                                     "every --steps); the real criterion on the synthetic episode is the `on_policy` object" % args.exit_ratio)
+                                    if B == 1 else "real criterion, calibrated thresholds, every environment exits at its own layer",
+                   "envs_per_gpu": B, "ms_per_env_step": round(1e3 * t_max / (res["n_timed"] * B), 4),
                    "exit_hist": res["hist"] if world == 1 else None, "per_gpu_steps_per_s": round(value / world, 2),
                    "graph": not args.no_graph, "weights_gb": round(eng.weight_bytes() / 1e9, 3),
                    "thresholds": [round(x, 6) for x in ctl.threshold_list()], "setup_s": round(res["setup_s"], 1),
                    "calibration": "reference protocol, deterministic: %d shadow steps, LSTM history on a seeded random exit layer per "
                                   "step, thresholds from solve_thresholds(exit_ratio=%.2f) (value_net.py:203-260)" % (args.calib_steps, args.exit_ratio),
-                   "timed_window": "episode steps %d..%d of %d-step episodes (burn-in %d + warm-up %d untimed steps first)"
-                                   % (args.burn_in + args.warmup, args.burn_in + args.warmup + args.steps - 1, EP_LEN, args.burn_in, args.warmup)},
+                   "timed_window": "%d warm-up steps, then %d timed steps of %d-step episodes" % (args.warmup, res["n_timed"], EP_LEN)},
         "lib_sha256_16": lib_hash(), "kernel_source_hash": kernel_source_hash(),
     }
+    if res.get("on_policy") is not None and B == 1:
+        out["on_policy"] = res["on_policy"]
     # realised vs target exit distribution (p_k ~ exit_ratio^k over the thresholded exits + the forced one)
     if world == 1:
         xs_ = [e for e in cfg.exit_ids() if e <= eng.ctl_max_layer]
@@ -691,13 +786,15 @@ def main():
                              "mfma_frac": round(gflop * value / world / 1e3 / MFMA_PEAK_TF, 4),
                              "GB/s": round(gbyte * value / world, 1), "hbm_frac": round(gbyte * value / world / HBM_PEAK_GBS, 4),
                              "note": "per GPU; weights counted once per step (bf16), SURVEY.md 8(d)"}
-    # scripted exit schedule: static exit ids drawn (seed 99) from p_k ~ exit_ratio^k, independent of the
-    # synthetic model's own (chaotic) delta statistics - a throughput figure that is comparable at a KNOWN average depth
+    # the same target mix with STATIC exit ids (no pseudo action, no exit checks: one committing head call per step) - beside `value`
+    # it prices the exit checks of the dynamic pipeline
+    if B == 1:
+        out["value_at_target_depth"] = {"value": out["value"], "unit": "action-steps/s", "avg_exit_layer": out["avg_exit_layer"],
+                                        "note": "= `value` since round 4: the timed region itself runs the target mix (kept for run-to-run "
+                                                "comparison with rounds 1-3, where it was the static-exit schedule now under `scripted`)"}
     if args.scripted_steps > 0 and B == 1 and max_layer == 12:
         exits = [e for e in cfg.exit_ids() if e <= eng.ctl_max_layer]
-        pk = torch.tensor([args.exit_ratio ** k for k in range(1, len(exits) + 1)], dtype=torch.float64)
-        draw = torch.multinomial(pk / pk.sum(), args.scripted_steps, replacement=True, generator=torch.Generator().manual_seed(99))
-        sched = [exits[int(i)] for i in draw]
+        sched = [exits[k] for k in target_schedule(len(exits), args.exit_ratio, args.scripted_steps, seed=99)]
         frames, ids_ = res["frames"], res["ids"]
         eng.reset()
         for e in exits:                                           # capture one graph per exit id
@@ -716,17 +813,10 @@ def main():
         st = torch.tensor([dt], dtype=torch.float64, device=eng.dev)
         if dist is not None:
             dist.all_reduce(st, op=dist.ReduceOp.MAX)
-        out["value_at_target_depth"] = {
-            "value": round(world * len(sched) / float(st[0]), 2), "unit": "action-steps/s",
-            "avg_exit_layer": round(sum(e + 1 for e in sched) / len(sched), 3),
-            "target_avg_layers": round(float(torch.tensor([e + 1 for e in exits], dtype=torch.float64) @ (pk / pk.sum())), 2),
-            "note": "the figure to compare run to run: the scripted exit schedule below (exit ids drawn from the calibration target "
-                    "p_k ~ exit_ratio^k, E[layers] = 5.74 at 0.8) - `value`'s depth is whatever its timed window of the synthetic "
-                    "episode holds (`avg_exit_layer`, `exit_distribution`)"}
         out["scripted"] = {"value": round(world * len(sched) / float(st[0]), 2), "unit": "action-steps/s", "steps": len(sched),
                            "avg_exit_layer": round(sum(e + 1 for e in sched) / len(sched), 3),
-                           "note": "static exit_id per step drawn from p_k ~ exit_ratio^k (seed 99); two-chain vision + one trunk "
-                                   "graph per exit id, host reads the action after every step"}
+                           "note": "static exit_id per step at the stratified target mix; two-chain vision + one trunk graph per exit "
+                                   "id, no exit checks, host reads the action after every step"}
     if rank == 0 and world == 1 and B == 1 and args.surface_steps > 0 and args.precision == "bf16":
         try:                                               # auxiliary single-rank leg: its failure must not cost the bench line
             out["surface"] = surface_leg(cfg, eng, res["thr"], res["frames"], res["ids"], args.surface_steps)
@@ -743,7 +833,7 @@ def main():
         nb = max(args.steps // 3, 20)
         rb = run_workload(args, cfg, sd, args.batched_envs, rank, world, local_rank, dist, max_layer, nb, max(args.warmup // 3, 5))
         out["batched"] = {"envs_per_gpu": args.batched_envs, "value": round(rb["value"], 2), "unit": "action-steps/s",
-                          "steps": nb, "ms_per_step": round(1e3 * rb["t_max"] / nb, 4),
+                          "steps": nb, "ms_per_step": round(1e3 * rb["t_max"] / nb, 4), "exit_hist": rb["hist"],
                           "ms_per_env_step": round(1e3 * rb["t_max"] / (nb * args.batched_envs), 4),
                           "avg_exit_layer": round(rb["avg_exit"], 3),
                           "note": "all environments of a rank advance in lock step through the same graph pieces; same kernels, "
@@ -761,19 +851,7 @@ def main():
         rb["eng"] = None
     if rank == 0:
         if not (args.no_cpu_baseline or world > 1):
-            cb = cpu_baseline(cfg, sd, ctl, args.cpu_budget_s, args.cpu_threads, rank)
-            # the CPU sample starts at the episode start (deep exits while the LSTM warms up), the GPU window sits mid-episode:
-            # a like-for-like figure at the GPU run's realised depth, from the CPU per-stage times
-            ps = cb["per_stage_ms"]
-            xs2 = [e for e in cfg.exit_ids() if e <= eng_ctl_max]
-            tot = max(sum(res["hist"]), 1)
-            e_layers = sum((l + 1) * h for l, h in enumerate(res["hist"])) / tot
-            e_heads = 2.0 + sum((xs2.index(l) + 1) * h for l, h in enumerate(res["hist"]) if h and l in xs2) / tot
-            ms = ps["vision_tower_2xViT_2xPerceiver"] + e_layers * ps["llm_layer"] + e_heads * ps["head_evaluation"]
-            cb["at_matched_depth"] = {"value": round(1e3 / ms, 4), "unit": "action-steps/s", "avg_layers": round(e_layers, 2),
-                                      "head_evaluations": round(e_heads, 2),
-                                      "note": "from per_stage_ms at the exit histogram of the timed GPU window (the CPU sample itself "
-                                              "covers the first steps of an episode, where exits are deep)"}
+            cb = cpu_baseline(cfg, sd, ctl, None, args.cpu_budget_s, args.cpu_threads, rank, full_protocol=args.cpu_full_protocol)
             out["cpu_baseline"] = cb
         print(json.dumps(out))
     if dist is not None:

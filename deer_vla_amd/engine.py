@@ -343,6 +343,13 @@ class DeerEngine:
         t[: len(thresholds)] = torch.tensor([float(v) for v in thresholds], dtype=torch.float32)
         self.thresholds.copy_(t)
 
+    def set_thresholds_device(self, row: torch.Tensor):
+        """The same from a DEVICE row of 16 floats (unused slots 1e8): an asynchronous device-to-device copy on the caller's stream, for
+        callers that change thresholds between steps of a timed loop (bench.py's scripted exit schedule)."""
+        assert row.is_cuda and row.dtype == torch.float32 and row.numel() == 16
+        self._drain_side_streams()                               # a speculative exit check of the last step may still read them
+        self.thresholds.copy_(row, non_blocking=True)
+
     def reset(self):
         """Episode start: ``clear_all_exit_memory`` + controller state (eval_utils.py:252-277)."""
         # a speculative head evaluation of the last step may still be queued on the side stream; it returns at entry only
