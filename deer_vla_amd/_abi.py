@@ -35,8 +35,9 @@ SIGNATURES = {
     "deer_xattn_small": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, I, I, F, P, P],
     "deer_mpt_attn_small": [P, I, L, I, I, P, P, F, P, F, P, P, I, I, I, I, P, P],
     "deer_mpt_attn_small_hl": [P, I, L, I, I, P, P, F, P, F, P, P, P, I, I, I, P, P],
-    "deer_trunk_ln_gemm": [P, P, I, L, P, P, P, P, P, F, P, I, I, I, P, P, P, I, P, I, P, P],
-    "deer_trunk_gemm": [P, P, P, I, P, I, I, I, I, P, L, P, P, I, P, P],
+    "deer_trunk_wide_gemm": [P, P, P, I, I, I, P, P, P, I, P, I, P, P],
+    "deer_resadd_ln_packed": [P, P, I, L, P, P, P, P, P, P, P, P, I, I, F, P, P],
+    "deer_xattn_fused_packed": [P, P, I, P, P, I, I, P, I, I, P, P, L, I, I, F, P, P],
     "deer_trunk_mpt_attn": [P, P, I, I, P, P, F, P, F, P, P, I, I, P, P],
     "deer_layernorm_rows": [P, L, L, I, I, P, P, P, P, L, L, I, F, P],
     "deer_layernorm_rows_multi": [P, L, L, I, I, P, P, I, L, P, L, L, L, I, F, P],

@@ -175,7 +175,7 @@ struct deer_model {
   std::vector<VisionWS> chains;
   size_t img, vis_x, vis_x_f32, kv_all, ids, key_mask, text_time, x, xn, ao, slab_a, slab_b, qkv_ws, hidden, h_state, c_state, h_tmp,
       c_tmp, h_shadow, c_shadow, pooled, ctl, step_info, thresholds, action_dbg;
-  size_t x2, ln_stats;              // one-environment trunk (csrc/trunk_r16.hip): second residual-stream buffer, q/k LayerNorm moments
+  size_t ln_stats;                  // one-environment trunk (csrc/trunk_r16.hip): q/k LayerNorm moments per 32-column group
   size_t xn_hl, ao_hl, h_hl;        // bf16 hi / lo planes of the trunk activations (env batches > kHlMinRows rows: deer_gemm_skinny_hl)
   long hl_plane_d, hl_plane_h;      // elements per plane: rows * d, rows * max_n
   size_t slab_a_elems, slab_b_elems;
@@ -541,7 +541,6 @@ void build_workspace(deer_model* m) {
   m->xn_hl = m->wl.add((size_t)2 * m->hl_plane_d * 2);
   m->ao_hl = m->wl.add((size_t)2 * m->hl_plane_d * 2);
   m->h_hl = m->wl.add((size_t)2 * m->hl_plane_h * 2);
-  m->x2 = m->wl.add((size_t)T * d * 4);
   m->ln_stats = m->wl.add((size_t)(3 * d / 32 + 1) * 16 * 2 * 4);
   m->hidden = named(m, "hidden", (size_t)c.n_layers * T * d * 4);
   const size_t st = (size_t)m->Lh * B * m->H * 4;
@@ -898,88 +897,97 @@ int resadd(deer_model* m, int R, const Pending* p, const float* gamma, const flo
 }
 
 // the residual branch a layer leaves un-applied when it is not finalized: the down-projection slabs (shape-determined)
-bool r16_ok(const deer_model* m, int T);
 Pending pending_of_down(const deer_model* m, int R) {
-  if (r16_ok(m, R)) return Pending{m->Wk<float>(m->slab_a), 2, 16L * m->d, nullptr};
   const long K = (long)m->c.mlp_ratio * m->d;
   const int S = trunk_splitk(m, R, m->d, K) * (m->c.precision ? 2 : 1);
   return Pending{m->Wk<float>(m->slab_a), S, (long)(16 * ((R + 15) / 16)) * m->d, nullptr};
 }
 
-// One environment, <= 16 text rows: the nine-launch layer of csrc/trunk_r16.hip (row operations inside the GEMMs).  DEER_TRUNK_R16=0
-// selects the fifteen-launch form below (the env-batch / long-instruction / 9B path).
+// One environment, <= 16 text rows: the twelve-launch layer (csrc/trunk_r16.hip) - the wide projections reduce their K split inside
+// the workgroup and leave final results (GELU planes / q|k|v + LayerNorm moments), so the two deer_slab_gelu_split passes and the
+// slab-reducing q/k LayerNorm launch of the fifteen-launch form below disappear; LayerNorm outputs travel as fragment-ordered bf16
+// planes (coalesced operand reads).  DEER_TRUNK_R16=0 selects the form below (env batches, long instructions, 9B).
 bool r16_ok(const deer_model* m, int T) {
   static const bool on = [] { const char* e = getenv("DEER_TRUNK_R16"); return e == nullptr || e[0] != '0'; }();
   const deer_config& c = m->c;
-  const long ffw = (long)c.mlp_ratio * m->d, xff = (long)c.xattn_ff_mult * m->d;
-  return on && !c.precision && m->B == 1 && T <= 16 && (m->d == 2048 || m->d == 256) && c.cross_attn_every_n_layers == 1 && c.xattn_heads * 64 == m->xinner &&
-         (m->xinner == 256 || m->xinner == 512 || m->xinner == 2048 || m->xinner == 4096) && (m->xinner & 31) == 0 && (ffw == 4L * m->d) && (xff == 4L * m->d) &&
-         m->d / c.n_heads <= 128 && ((m->d / c.n_heads) & 3) == 0 && 2 * m->nl <= 128;
+  return on && !c.precision && m->B == 1 && T <= 16 && (m->d == 2048 || m->d == 256) && block_hl(m, T) && (((long)c.xattn_ff_mult * m->d) & 63) == 0 &&
+         (m->d & 127) == 0 && m->d / c.n_heads <= 128 && ((m->d / c.n_heads) & 3) == 0;
 }
 
-int ln_gemm(deer_model* m, const float* x, const float* slab, int s_in, long stride, const float* gate, float* x_out, float* x_copy, const float* gamma,
-            const float* beta, const void* Wp, long N, int epi, float* out_f32, bf16_t* out_hi, bf16_t* out_lo, long ldo, int T, const int* ctl, void* st) {
-  Bracket b(m, "deer_trunk_ln_gemm", 2.0 * T * N * m->d, 2.0 * N * m->d, st);        // algorithmic bytes = the bf16 weights, once
-  return deer_trunk_ln_gemm(x, slab, s_in, stride, gate, x_out, x_copy, gamma, beta, kEps, Wp, (int)N, m->d, epi, out_f32, out_hi, out_lo, (int)ldo,
-                            m->Wk<float>(m->ln_stats), T, ctl, st);
+int resadd_packed(deer_model* m, int R, const Pending* p, const float* gamma, const float* beta, float* x_copy, const int* ctl, void* st) {
+  Bracket b(m, "deer_resadd_ln", 0, 4.0 * R * m->d * ((p ? p->S : 0) + 3), st);
+  bf16_t* h = m->Wk<bf16_t>(m->xn_hl);
+  return deer_resadd_ln_packed(m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma, beta, h,
+                               h + m->hl_plane_d, nullptr, x_copy, R, m->d, kEps, ctl, st);
 }
 
-int tgemm(deer_model* m, const bf16_t* a_hi, const bf16_t* a_lo, const float* a_f32, long lda, const void* Wp, long N, long K, int splitk, bool inplace,
-          float* out, long stride, const float* gate, int T, const int* ctl, void* st) {
-  Bracket b(m, "deer_trunk_gemm", 2.0 * T * N * K, 2.0 * N * K, st);
-  return deer_trunk_gemm(a_hi, a_lo, a_f32, (int)lda, Wp, (int)N, (int)K, splitk, inplace ? 1 : 0, out, stride, gate, nullptr, T, ctl, st);
+int wide_gemm(deer_model* m, const void* Wp, long N, int epi, float* out_f32, bf16_t* out_hi, bf16_t* out_lo, long ldo, int T, const int* ctl, void* st) {
+  Bracket b(m, "deer_trunk_wide_gemm", 2.0 * T * N * m->d, 2.0 * N * m->d, st);      // algorithmic bytes = the bf16 weights, once
+  const bf16_t* h = m->Wk<bf16_t>(m->xn_hl);
+  return deer_trunk_wide_gemm(h, h + m->hl_plane_d, Wp, (int)N, m->d, epi, out_f32, out_hi, out_lo, (int)ldo, m->Wk<float>(m->ln_stats), T, ctl, st);
 }
-
-int resadd(deer_model* m, int R, const Pending* p, const float* gamma, const float* beta, float* x_copy, const int* ctl, void* st);
 
 int llm_layer_r16(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool finalize, bool use_ctl, void* st) {
   const deer_config& c = m->c;
   const LlmLayerW& L = m->llm[i];
-  const XattnW& X = L.xa;
   const int d = m->d, xin = m->xinner;
   const int* ctl = use_ctl ? m->Wk<int>(m->ctl) : nullptr;
-  float* xa = m->Wk<float>(m->x);
-  float* xb = m->Wk<float>(m->x2);
   float* slab_a = m->Wk<float>(m->slab_a);
-  float* slab_b = m->Wk<float>(m->slab_b);
-  float* ao = m->Wk<float>(m->ao);
   float* qkv = m->Wk<float>(m->qkv_ws);
+  const bf16_t* xh = m->Wk<bf16_t>(m->xn_hl);
   bf16_t* hh = m->Wk<bf16_t>(m->h_hl);
   bf16_t* hl = hh + m->hl_plane_h;
   bf16_t* aoh = m->Wk<bf16_t>(m->ao_hl);
   bf16_t* aol = aoh + m->hl_plane_d;
-  const long sstride = 16L * d, ffw = 4L * d;
+  const long ffw = (long)c.mlp_ratio * d;
   const size_t rows_cap = std::min(m->B * c.max_text_len, kMaxRows);
-  float* prev_hidden = pending_in ? m->Wk<float>(m->hidden) + (size_t)(i - 1) * rows_cap * d : nullptr;
-  const int n_media = 2 * m->nl;
-  // ---- gated x-attn (helpers.py:260-279): q = LN(x) Wq^T [the pending mlp_down branch of layer i-1 is folded in; x -> second buffer]
-  DEER_TRY(ln_gemm(m, xa, pending_in ? slab_a : nullptr, pending_in ? 2 : 0, sstride, nullptr, xb, prev_hidden, m->A<float>(X.nw), m->A<float>(X.nb),
-                   m->A<void>(X.wq), xin, 0, slab_b, nullptr, nullptr, xin, T, ctl, st));
-  {
-    Bracket b(m, "deer_xattn_mfma", 0, 0, st);
-    const char* kv = m->Wk<char>(m->kv_all) + (size_t)X.kv_index * 2 * xin * 2;
-    DEER_TRY(deer_xattn_mfma(slab_b, 1, 0, xin, kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, ao, 1, xin, T, n_media, c.xattn_heads, 1,
-                             1.0f / sqrtf((float)c.xattn_dim_head), ctl, st));
+  Pending pend{}, *pp = nullptr;
+  float* prev_hidden = nullptr;
+  if (pending_in) {
+    pend = pending_of_down(m, T);
+    pp = &pend;
+    prev_hidden = m->Wk<float>(m->hidden) + (size_t)(i - 1) * rows_cap * d;
   }
-  DEER_TRY(tgemm(m, nullptr, nullptr, ao, xin, m->A<void>(X.wo), d, xin, 1, true, xb, 0, m->A<float>(X.ag), T, ctl, st));      // x += tanh(attn_gate) * to_out(.)
-  DEER_TRY(ln_gemm(m, xb, nullptr, 0, 0, nullptr, nullptr, nullptr, m->A<float>(X.fnw), m->A<float>(X.fnb), m->A<void>(X.w1), ffw, 1, nullptr, hh, hl, ffw, T, ctl, st));
-  DEER_TRY(tgemm(m, hh, hl, nullptr, ffw, m->A<void>(X.w2), d, ffw, 2, false, slab_b, sstride, nullptr, T, ctl, st));
-  // ---- MPT block: q|k|v = LN1(x + tanh(ff_gate) * ff) Wqkv^T; x -> first buffer
+  int S;
+  long stride;
+  if (L.has_xa) {   // gated x-attn (helpers.py:260-279)
+    const XattnW& X = L.xa;
+    DEER_TRY(resadd_packed(m, T, pp, m->A<float>(X.nw), m->A<float>(X.nb), prev_hidden, ctl, st));
+    prev_hidden = nullptr;
+    const int n_media = 2 * m->nl;
+    const char* kv = m->Wk<char>(m->kv_all) + (size_t)X.kv_index * 2 * xin * 2;
+    if ((size_t)c.xattn_heads * 16 * d > m->slab_a_elems) return DEER_ERR_SHAPE;
+    {
+      Bracket b(m, "deer_xattn_fused", 2.0 * T * d * xin * 2, 2.0 * 2 * xin * d, st);
+      DEER_TRY(deer_xattn_fused_packed(xh, xh + m->hl_plane_d, d, m->A<void>(X.wq), kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, n_media,
+                                       m->A<void>(X.wo), slab_a, 16L * d, T, c.xattn_heads, 1.0f / sqrtf((float)c.xattn_dim_head), ctl, st));
+    }
+    pend = Pending{slab_a, c.xattn_heads, 16L * d, m->A<float>(X.ag)};
+    const long xff = (long)c.xattn_ff_mult * d;
+    DEER_TRY(resadd_packed(m, T, &pend, m->A<float>(X.fnw), m->A<float>(X.fnb), nullptr, ctl, st));
+    DEER_TRY(wide_gemm(m, m->A<void>(X.w1), xff, 1, nullptr, hh, hl, xff, T, ctl, st));                       // GELU(ff.1(.)) as hi / lo planes
+    DEER_TRY(skinny_hl(m, m->A<void>(X.w2), d, xff, T, slab_a, m->slab_a_elems, hh, hl, (int)xff, ctl, st, &S, &stride));
+    pend = Pending{slab_a, S, stride, m->A<float>(X.fg)};
+    pp = &pend;
+  }
+  // MPT block
   const float* ln1b = m->loaded(L.ln1b_name) ? m->A<float>(L.ln1b) : nullptr;
   const float* ln2b = m->loaded(L.ln2b_name) ? m->A<float>(L.ln2b) : nullptr;
-  DEER_TRY(ln_gemm(m, xb, slab_b, 2, sstride, m->A<float>(X.fg), xa, nullptr, m->A<float>(L.ln1w), ln1b, m->A<void>(L.wqkv), 3L * d, c.attn_qk_ln ? 2 : 0, qkv,
-                   nullptr, nullptr, 3L * d, T, ctl, st));
+  DEER_TRY(resadd_packed(m, T, pp, m->A<float>(L.ln1w), ln1b, prev_hidden, ctl, st));
+  DEER_TRY(wide_gemm(m, m->A<void>(L.wqkv), 3L * d, c.attn_qk_ln ? 2 : 0, qkv, nullptr, nullptr, 3L * d, T, ctl, st));   // final q|k|v (+ LayerNorm moments)
   {
     Bracket b(m, "deer_trunk_mpt_attn", 0, 0, st);
     const unsigned char* km = m->mask_override ? m->mask_override : m->Wk<unsigned char>(m->key_mask);
     DEER_TRY(deer_trunk_mpt_attn(qkv, m->Wk<float>(m->ln_stats), d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
                                  (float)c.alibi_bias_max, aoh, aol, d, T, ctl, st));
   }
-  DEER_TRY(tgemm(m, aoh, aol, nullptr, d, m->A<void>(L.wo), d, d, 1, true, xa, 0, nullptr, T, ctl, st));                      // x += out_proj(.)
-  DEER_TRY(ln_gemm(m, xa, nullptr, 0, 0, nullptr, nullptr, nullptr, m->A<float>(L.ln2w), ln2b, m->A<void>(L.wup), ffw, 1, nullptr, hh, hl, ffw, T, ctl, st));
-  DEER_TRY(tgemm(m, hh, hl, nullptr, ffw, m->A<void>(L.wdown), d, ffw, 2, false, slab_a, sstride, nullptr, T, ctl, st));
+  DEER_TRY(skinny_hl(m, m->A<void>(L.wo), d, d, T, slab_a, m->slab_a_elems, aoh, aol, d, ctl, st, &S, &stride));
+  pend = Pending{slab_a, S, stride, nullptr};
+  DEER_TRY(resadd_packed(m, T, &pend, m->A<float>(L.ln2w), ln2b, nullptr, ctl, st));
+  DEER_TRY(wide_gemm(m, m->A<void>(L.wup), ffw, 1, nullptr, hh, hl, ffw, T, ctl, st));                         // GELU(mlp_up(.)) as hi / lo planes
+  DEER_TRY(skinny_hl(m, m->A<void>(L.wdown), d, ffw, T, slab_a, m->slab_a_elems, hh, hl, (int)ffw, ctl, st, &S, &stride));
   if (finalize) {   // hidden_states[i] = output of layer i (mosaic_gpt_3b.py:424-427)
-    Pending pend{slab_a, 2, sstride, nullptr};
+    pend = Pending{slab_a, S, stride, nullptr};
     DEER_TRY(resadd(m, T, &pend, nullptr, nullptr, m->Wk<float>(m->hidden) + (size_t)i * rows_cap * d, ctl, st));
   }
   return DEER_OK;

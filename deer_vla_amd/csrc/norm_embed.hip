@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         bf16_t* __restrict__ out_bf, float* __restrict__ out_f32,
                                                         float* __restrict__ x_copy, int d, float eps, const int* ctl,
-                                                        const float* __restrict__ bias, bf16_t* __restrict__ out_lo) {
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out_lo, int packed = 0) {
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ float red[16];
   const int r = blockIdx.x;
@@ -157,9 +157,13 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
       }
       if (out_bf != nullptr) {
         const uint32_t h01 = pack2bf(y.x, y.y), h23 = pack2bf(y.z, y.w);
-        *reinterpret_cast<uint2*>(out_bf + (long)r * d + (long)i4 * 4) = uint2{h01, h23};
+        // packed: MFMA-fragment order [k-tile][lane = 16 * (k % 32 / 8) + row][8] - the <= 16 rows of one environment read back as ONE
+        // contiguous 1 KiB per k-tile and plane (deer_trunk_wide_gemm, deer_xattn_fused_packed)
+        const int col = i4 * 4;
+        const long o = packed ? (((long)(col >> 5) * 64 + ((col & 31) >> 3) * 16 + r) * 8 + (col & 7)) : ((long)r * d + col);
+        *reinterpret_cast<uint2*>(out_bf + o) = uint2{h01, h23};
         if (out_lo != nullptr)      // second bf16 plane: y = hi + lo to ~16 mantissa bits (activation operand of deer_gemm_skinny_hl)
-          *reinterpret_cast<uint2*>(out_lo + (long)r * d + (long)i4 * 4) =
+          *reinterpret_cast<uint2*>(out_lo + o) =
               uint2{pack2bf(y.x - __uint_as_float(h01 << 16), y.y - __uint_as_float(h01 & 0xffff0000u)),
                     pack2bf(y.z - __uint_as_float(h23 << 16), y.w - __uint_as_float(h23 & 0xffff0000u))};
       }
@@ -190,6 +194,18 @@ extern "C" int deer_resadd_ln_split(float* x, const float* slab, int s_in, long 
     return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(resadd_ln_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
                      gamma, beta, reinterpret_cast<bf16_t*>(out_hi), out_f32, x_copy, d, eps, ctl, bias, reinterpret_cast<bf16_t*>(out_lo));
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// the same with the two planes in MFMA-fragment order [d/32][64][8] (T <= 16 rows: lane = 16 * (k % 32 / 8) + row); d % 32 == 0
+extern "C" int deer_resadd_ln_packed(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
+                                     const float* gamma, const float* beta, void* out_hi, void* out_lo, float* out_f32, float* x_copy,
+                                     int T, int d, float eps, const int* ctl, void* stream) {
+  if (T <= 0 || T > 16 || d <= 0 || (d & 31) || d > 4096 || (slab != nullptr && s_in <= 0) || gamma == nullptr || out_hi == nullptr || out_lo == nullptr)
+    return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(resadd_ln_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
+                     gamma, beta, reinterpret_cast<bf16_t*>(out_hi), out_f32, x_copy, d, eps, ctl, bias, reinterpret_cast<bf16_t*>(out_lo), 1);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

@@ -20,13 +20,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define XF_KP 72           // K rows: 64 + 8 bf16
 #define XF_MAXKV 128
 
-template <int MT>
+// PACKED (one environment, <= 16 rows): the activation arrives as bf16 hi / lo planes in MFMA-fragment order (xn = hi plane, xlo = lo
+// plane; deer_resadd_ln_packed) - one coalesced 1 KiB read per k-tile and plane instead of 16 rows x 16 B per lane
+template <int MT, bool PACKED = false>
 __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __restrict__ xn, int d, const bf16_t* __restrict__ Wq_p,
                                                                 const bf16_t* __restrict__ kv, int ldkv, int inner,
                                                                 const int* __restrict__ text_time, int n_per_media, int n_kv,
                                                                 const bf16_t* __restrict__ Wo_p, float* __restrict__ out, long slab_stride,
-                                                                int T, int heads, int NS, float scale, const int* ctl) {
+                                                                int T, int heads, int NS, float scale, const int* ctl,
+                                                                const bf16_t* __restrict__ xlo = nullptr) {
   DEER_RETURN_IF_EXITED(ctl);
+  static_assert(!PACKED || MT == 1, "packed planes hold one 16-row tile");
   constexpr int MPAD = MT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);                                   // [NW][MPAD][64] f32 partial q
@@ -76,11 +80,17 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
   for (int kt0 = wave; kt0 < ktiles; kt0 += 4 * XF_NW) {
     u32x4 w[4][4];
     float4 a[4][MT][2];
+    bf16x8 ph[4], pl[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {                               // 16 weight fragments + the activation pieces in flight
       const int kt = min(kt0 + u * XF_NW, ktiles - 1);
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4) w[u][t4] = __builtin_nontemporal_load(wq + ((long)t4 * ktiles + kt) * 64);
+      if (PACKED) {
+        ph[u] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(xn) + ((long)kt * 64 + lane) * 8);
+        pl[u] = *reinterpret_cast<const bf16x8*>(xlo + ((long)kt * 64 + lane) * 8);
+        continue;
+      }
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int row = j * 16 + c;
@@ -95,6 +105,15 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
       if (kt0 + u * XF_NW < ktiles) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
+          if (PACKED) {
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+              const bf16x8 wf = __builtin_bit_cast(bf16x8, w[u][t4]);
+              acc[t4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, ph[u], acc[t4][j], 0, 0, 0);
+              acc[t4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pl[u], acc[t4][j], 0, 0, 0);
+            }
+            continue;
+          }
           const float4 x0 = a[u][j][0], x1 = a[u][j][1];
           const uint32_t h0 = pack2bf(x0.x, x0.y), h1 = pack2bf(x0.z, x0.w), h2 = pack2bf(x1.x, x1.y), h3 = pack2bf(x1.z, x1.w);
           const uint4 hi = uint4{h0, h1, h2, h3};
@@ -247,9 +266,28 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
 // xn: f32 [batch*T, d] = LN(x) of the block's attention branch; Wq_p / Wo_p: to_q [inner, d] and to_out [d, inner] in the packed
 // layout of deer_pack_weight_mfma16; kv: bf16 [batch*n_kv, ldkv] (k of head h at column h*64, v at inner + h*64); out: f32
 // [heads][slab_stride] with slab_stride >= batch*T*d - slab h holds head h's contribution to all rows.  T <= 32, n_kv <= 128.
+static int launch_xattn_fused(const float* xn, const void* x_lo_packed, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
+                              int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch, float scale,
+                              const int* ctl, void* stream);
+
 extern "C" int deer_xattn_fused(const float* xn, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
                                 int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch,
                                 float scale, const int* ctl, void* stream) {
+  return launch_xattn_fused(xn, nullptr, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T, heads, batch, scale, ctl, stream);
+}
+
+// the same for ONE environment of <= 16 rows with LN(x) as bf16 hi / lo planes in MFMA-fragment order (deer_resadd_ln_packed)
+extern "C" int deer_xattn_fused_packed(const void* x_hi, const void* x_lo, int d, const void* Wq_p, const void* kv, int ldkv, int inner,
+                                       const int* text_time, int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T,
+                                       int heads, float scale, const int* ctl, void* stream) {
+  if (x_lo == nullptr || T > 16) return DEER_ERR_SHAPE;
+  return launch_xattn_fused(reinterpret_cast<const float*>(x_hi), x_lo, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T,
+                            heads, 1, scale, ctl, stream);
+}
+
+static int launch_xattn_fused(const float* xn, const void* x_lo_packed, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
+                              int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch, float scale,
+                              const int* ctl, void* stream) {
   if (xn == nullptr || Wq_p == nullptr || kv == nullptr || Wo_p == nullptr || out == nullptr || text_time == nullptr) return DEER_ERR_SHAPE;
   if (T <= 0 || T > 32 || n_kv <= 0 || n_kv > XF_MAXKV || heads <= 0 || inner != heads * XF_HD || (d & 127) || (ldkv & 7) || batch <= 0 ||
       n_per_media <= 0 || slab_stride < (long)batch * T * d)
@@ -265,10 +303,10 @@ extern "C" int deer_xattn_fused(const float* xn, int d, const void* Wq_p, const 
   const int smem = XF_NW * mpad * XF_HD * 4 + (mpad * XF_KP + XF_MAXKV * XF_KP + XF_HD * (XF_MAXKV + 8) + 2 * mpad * XF_KP) * 2;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(heads * NS, batch);
-#define DEER_XF_LAUNCH(MT_)                                                                                                     \
+#define DEER_XF_LAUNCH(MT_, PK_)                                                                                                \
   do {                                                                                                                          \
     static std::atomic<bool> attr_set{false};                                                                                               \
-    auto kern = &xattn_fused_kernel<MT_>;                                                                                       \
+    auto kern = &xattn_fused_kernel<MT_, PK_>;                                                                                  \
     if (!attr_set) {                                                                                                            \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) !=  \
           hipSuccess) return DEER_ERR_LAUNCH;                                                                                   \
@@ -276,9 +314,12 @@ extern "C" int deer_xattn_fused(const float* xn, int d, const void* Wq_p, const 
     }                                                                                                                           \
     hipLaunchKernelGGL(kern, grid, dim3(64 * XF_NW), smem, st, xn, d, reinterpret_cast<const bf16_t*>(Wq_p),                   \
                        reinterpret_cast<const bf16_t*>(kv), ldkv, inner, text_time, n_per_media, n_kv,                          \
-                       reinterpret_cast<const bf16_t*>(Wo_p), out, slab_stride, T, heads, NS, scale, ctl);                       \
+                       reinterpret_cast<const bf16_t*>(Wo_p), out, slab_stride, T, heads, NS, scale, ctl,                        \
+                       reinterpret_cast<const bf16_t*>(x_lo_packed));                                                           \
   } while (0)
-  if (mt == 1) DEER_XF_LAUNCH(1); else DEER_XF_LAUNCH(2);
+  if (x_lo_packed != nullptr) DEER_XF_LAUNCH(1, true);
+  else if (mt == 1) DEER_XF_LAUNCH(1, false);
+  else DEER_XF_LAUNCH(2, false);
 #undef DEER_XF_LAUNCH
   DEER_LAUNCH_CHECK();
   return DEER_OK;

@@ -175,27 +175,30 @@ int deer_mpt_attn_small_hl(const float* qkvslab, int s_in, long slab_stride, int
                            const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws,
                            void* out_hi, void* out_lo, int ldo, int T, int batch, const int* ctl, void* stream);
 
-/* ---- the trunk at ONE environment, <= 16 text rows (csrc/trunk_r16.hip): the row operations of a layer ride inside its GEMMs ----
- * deer_trunk_ln_gemm: y = LN(x + tanh(*gate or 1) * sum_s slab[s]) W^T - the LayerNorm + Linear pairs of the layer (helpers.py:260-279:
- * attn.norm -> to_q, ff.0 -> ff.1; MPT block, SURVEY App. B.1: ln_1 -> Wqkv, ln_2 -> mlp_up) with the preceding gated residual update
- * (helpers.py:267-279, x + tanh(gate) * y) folded into the prologue.  x f32 [T, d] (d = 256 or 2048), slab f32 [s_in][slab_stride]
- * (rows of d), Wp = packed [N, d] (deer_pack_weight_mfma16), N % 32 == 0, T <= 16.  epi 0: out_f32 [T, ldo]; 1: exact GELU ->
- * bf16 hi / lo planes [T, ldo] (operand of the down-projection); 2: out_f32 + stats [N/32][16][2] = (mean, centred sum of squares) of
- * every row over each 32-column group (combined by deer_trunk_mpt_attn into the q / k LayerNorm over d_model).  x_out (!= x) / x_copy:
- * optional stores of the completed residual stream (hidden_states[i-1], mosaic_gpt_3b.py:424-427). */
-int deer_trunk_ln_gemm(const float* x, const float* slab, int s_in, long slab_stride, const float* gate, float* x_out, float* x_copy,
-                       const float* gamma, const float* beta, float eps, const void* Wp, int N, int d, int epi, float* out_f32, void* out_hi,
-                       void* out_lo, int ldo, float* stats, int T, const int* ctl, void* stream);
-/* deer_trunk_gemm: the d-wide bias-free Linears of the layer (to_out, ff.3, out_proj, mlp_down): A as bf16 hi / lo planes [T, lda] or
- * f32 [T, lda]; splitk == 1 && inplace: out = x [T, N], x += tanh(*gate or 1) * (A W^T) (the residual add of helpers.py:267 / the MPT
- * block), x_copy optional; else out = f32 slabs [splitk][slab_stride] (slab_stride >= 16 N; rows T..15 zero).  K % (256 splitk) == 0. */
-int deer_trunk_gemm(const void* a_hi, const void* a_lo, const float* a_f32, int lda, const void* Wp, int N, int K, int splitk, int inplace,
-                    float* out, long slab_stride, const float* gate, float* x_copy, int T, const int* ctl, void* stream);
+/* ---- the trunk at ONE environment, <= 16 text rows (csrc/trunk_r16.hip) ----
+ * deer_trunk_wide_gemm: the wide bias-free Linears of a layer (helpers.py:15-22 ff.1; MPT block, SURVEY App. B.1: Wqkv, mlp_up) with the K
+ * split INSIDE the workgroup, so the result leaves final.  a_hi / a_lo: the LayerNorm output as bf16 planes in MFMA-fragment order
+ * [K/32][64][8] (deer_resadd_ln_packed); Wp = packed [N, K] (deer_pack_weight_mfma16); N % 32 == 0, K = 256 or 2048, T <= 16.
+ * epi 0: out_f32 [T, ldo]; 1: exact GELU (helpers.py:19 / the MPT MLP) -> row-major bf16 hi / lo planes [T, ldo] (operand of
+ * deer_gemm_skinny_hl for ff.3 / mlp_down); 2: out_f32 + stats [N/32][16][2] = (mean, centred sum of squares) of every row over each
+ * 32-column group (combined by deer_trunk_mpt_attn into the q / k LayerNorm over d_model). */
+int deer_trunk_wide_gemm(const void* a_hi, const void* a_lo, const void* Wp, int N, int K, int epi, float* out_f32, void* out_hi, void* out_lo,
+                         int ldo, float* stats, int T, const int* ctl, void* stream);
 /* deer_trunk_mpt_attn: MPT attention core like deer_mpt_attn_small on FINAL f32 q|k|v [T, 3 d_model] (no slabs); the q / k LayerNorm over
- * d_model (attn_qk_ln, weights or NULL) from the 32-column moments `stats` of deer_trunk_ln_gemm(epi 2); out as bf16 hi / lo planes. */
+ * d_model (attn_qk_ln, weights or NULL) from the 32-column moments `stats` of deer_trunk_wide_gemm(epi 2); out as row-major bf16 hi / lo
+ * planes [T, ldo].  d_model % 256 == 0, T <= 16. */
 int deer_trunk_mpt_attn(const float* qkv, const float* stats, int d_model, int n_heads, const float* q_ln_w, const float* k_ln_w, float eps,
                         const unsigned char* key_mask, float alibi_bias_max, void* out_hi, void* out_lo, int ldo, int T, const int* ctl,
                         void* stream);
+/* deer_resadd_ln_split with the two planes in MFMA-fragment order [d/32][64 lanes][8], lane = 16 * (k % 32 / 8) + row (T <= 16): the operand
+ * of deer_trunk_wide_gemm / deer_xattn_fused_packed reads back as one contiguous 1 KiB per k-tile and plane. */
+int deer_resadd_ln_packed(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias, const float* gamma,
+                          const float* beta, void* out_hi, void* out_lo, float* out_f32, float* x_copy, int T, int d, float eps, const int* ctl,
+                          void* stream);
+/* deer_xattn_fused for ONE environment of <= 16 rows with LN(x) as fragment-ordered bf16 hi / lo planes (deer_resadd_ln_packed) */
+int deer_xattn_fused_packed(const void* x_hi, const void* x_lo, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
+                            int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, float scale,
+                            const int* ctl, void* stream);
 
 /* (deer_head_*: w_is_f32 = 1 when the weight pointers are f32 - the fp32 arithmetic keeps the head's weights in f32) */
 

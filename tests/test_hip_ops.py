@@ -788,3 +788,150 @@ def test_xattn_f32_matches_the_masked_cross_attention(lib):
     att = torch.softmax(sim, -1).masked_fill((tt == 0).view(batch, 1, T, 1), 0.0)
     ref = (att @ v).transpose(1, 2).reshape(batch, T, inner)
     assert rel_err(out, ref) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------ one-environment trunk (csrc/trunk_r16.hip)
+def _pack(lib, W):
+    Wp = torch.empty_like(W)
+    abi.check(lib.deer_pack_weight_mfma16(abi.ptr(W), abi.ptr(Wp), W.shape[0], W.shape[1], st()), "pack")
+    return Wp
+
+
+def _ln(x, g, b, eps=1e-5):
+    return torch.nn.functional.layer_norm(x.double(), (x.shape[-1],), g.double(), None if b is None else b.double(), eps)
+
+
+def _pack_planes(a):
+    """f32 [T <= 16, K] -> bf16 hi / lo planes in MFMA-fragment order [K/32][64][8], lane = 16 * (k % 32 / 8) + row (rows >= T zero)"""
+    T, K = a.shape
+    hi = a.to(torch.bfloat16)
+    lo = (a - hi.float()).to(torch.bfloat16)
+    out = []
+    for p in (hi, lo):
+        full = torch.zeros(16, K, dtype=torch.bfloat16, device=a.device)
+        full[:T] = p
+        out.append(full.view(16, K // 32, 4, 8).permute(1, 2, 0, 3).contiguous().view(-1))     # [kt][g][row][8]
+    return out[0], out[1], hi, lo
+
+
+@pytest.mark.parametrize("T", [1, 14, 16])
+@pytest.mark.parametrize("K,N", [(2048, 8192), (2048, 6144), (2048, 512), (256, 768), (256, 1024)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_trunk_wide_gemm(lib, T, K, N, epi):
+    """The wide Linears at <= 16 rows with the K split inside the workgroup (final results, no slabs): plain f32 / exact GELU -> bf16
+    hi + lo planes / f32 + 32-column moments, against fp64 torch math on the same bf16 operands (hi + lo).  3e-5 relative (fp32
+    accumulation order); GELU planes reproduce the f32 value to bf16^2; rows >= T are never written."""
+    A = dev(rnd(T, K, seed=3))
+    W = dev(rnd(N, K, seed=7, scale=K ** -0.5), torch.bfloat16)
+    Wp = _pack(lib, W)
+    ph, pl, hi, lo = _pack_planes(A)
+    out = torch.full((16, N), float("nan"), device="cuda")
+    oh = torch.zeros(16, N, device="cuda", dtype=torch.bfloat16)
+    ol = torch.zeros(16, N, device="cuda", dtype=torch.bfloat16)
+    stats = torch.full((N // 32, 16, 2), float("nan"), device="cuda")
+    abi.check(lib.deer_trunk_wide_gemm(abi.ptr(ph), abi.ptr(pl), abi.ptr(Wp), N, K, epi, abi.ptr(out), abi.ptr(oh), abi.ptr(ol), N, abi.ptr(stats), T, None,
+                                       st()), "trunk_wide_gemm")
+    torch.cuda.synchronize()
+    y = (hi.double() + lo.double()) @ W.double().t()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(y)
+        assert rel_err(oh[:T].double() + ol[:T].double(), ref) < 1e-4
+        assert float((oh[:T].float() - ref.float()).abs().max()) <= float(ref.abs().max()) * 2 ** -7       # hi = bf16(gelu)
+        assert T == 16 or (float(oh[T:].abs().max()) == 0.0 and float(ol[T:].abs().max()) == 0.0)
+    else:
+        assert rel_err(out[:T], y.float()) < 3e-5
+        assert torch.isnan(out[T:]).all()
+        if epi == 2:
+            yg = out[:T].double().view(T, N // 32, 32)
+            mu = yg.mean(-1)
+            m2 = ((yg - mu.unsqueeze(-1)) ** 2).sum(-1)
+            assert float((stats[:, :T, 0].double() - mu.t()).abs().max()) < 1e-5
+            assert rel_err(stats[:, :T, 1], m2.t().float()) < 1e-5
+
+
+@pytest.mark.parametrize("T", [1, 14, 16])
+@pytest.mark.parametrize("d", [256, 2048])
+def test_resadd_ln_packed_is_the_split_form_in_fragment_order(lib, T, d):
+    """deer_resadd_ln_packed = deer_resadd_ln_split with the planes permuted into MFMA-fragment order: bit-identical values."""
+    x0 = dev(rnd(T, d, seed=31))
+    slab = dev(rnd(3, 16, d, seed=32, scale=0.2))
+    gate = dev(torch.tensor([0.3]))
+    gamma, beta = dev(1.0 + 0.1 * rnd(d, seed=33)), dev(0.1 * rnd(d, seed=34))
+    outs = []
+    for packed in (False, True):
+        x = x0.clone()
+        hi = torch.zeros(16 * d, device="cuda", dtype=torch.bfloat16)
+        lo = torch.zeros(16 * d, device="cuda", dtype=torch.bfloat16)
+        fn = lib.deer_resadd_ln_packed if packed else lib.deer_resadd_ln_split
+        abi.check(fn(abi.ptr(x), abi.ptr(slab), 3, 16 * d, abi.ptr(gate), None, abi.ptr(gamma), abi.ptr(beta), abi.ptr(hi), abi.ptr(lo), None, None, T, d,
+                     1e-5, None, st()), "resadd")
+        torch.cuda.synchronize()
+        outs.append((x, hi, lo))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in (1, 2):
+        rm = outs[0][k].view(16, d)
+        pk = outs[1][k].view(d // 32, 4, 16, 8).permute(2, 0, 1, 3).reshape(16, d)
+        assert torch.equal(rm[:T], pk[:T])
+
+
+@pytest.mark.parametrize("T", [3, 14, 16])
+@pytest.mark.parametrize("d", [256, 2048])
+def test_xattn_fused_packed_matches_f32_operand_form(lib, T, d):
+    """deer_xattn_fused_packed (LN(x) as fragment-ordered bf16 hi / lo planes) against deer_xattn_fused on the f32 LN(x): the same
+    hi + lo values enter the same MFMAs in the same order -> bit-identical head slabs."""
+    heads, inner, n_kv = 8, 512, 128
+    xn = dev(rnd(T, d, seed=51))
+    Wq = _pack(lib, dev(rnd(inner, d, seed=52, scale=d ** -0.5), torch.bfloat16))
+    Wo = _pack(lib, dev(rnd(d, inner, seed=53, scale=inner ** -0.5), torch.bfloat16))
+    kv = dev(rnd(n_kv, 2 * inner, seed=54), torch.bfloat16)
+    tt = dev(torch.ones(T, dtype=torch.int32))
+    ph, pl, _, _ = _pack_planes(xn)
+    a = torch.full((heads, 16, d), float("nan"), device="cuda")
+    b = torch.full((heads, 16, d), float("nan"), device="cuda")
+    abi.check(lib.deer_xattn_fused(abi.ptr(xn), d, abi.ptr(Wq), abi.ptr(kv), 2 * inner, inner, abi.ptr(tt), 64, n_kv, abi.ptr(Wo), abi.ptr(a), 16 * d, T,
+                                   heads, 1, 0.125, None, st()), "xattn_fused")
+    abi.check(lib.deer_xattn_fused_packed(abi.ptr(ph), abi.ptr(pl), d, abi.ptr(Wq), abi.ptr(kv), 2 * inner, inner, abi.ptr(tt), 64, n_kv, abi.ptr(Wo),
+                                          abi.ptr(b), 16 * d, T, heads, 0.125, None, st()), "xattn_fused_packed")
+    torch.cuda.synchronize()
+    assert torch.isfinite(a[:, :T]).all() and torch.equal(a[:, :T], b[:, :T])
+
+
+@pytest.mark.parametrize("T", [1, 5, 14, 16])
+@pytest.mark.parametrize("d,heads", [(2048, 16), (256, 2)])
+@pytest.mark.parametrize("qk_ln,mask", [(True, False), (True, True), (False, False)])
+def test_trunk_mpt_attn(lib, T, d, heads, qk_ln, mask):
+    """MPT attention on final q|k|v with the q/k LayerNorm over d_model reconstructed from 32-column moments (Chan's combination) -
+    against fp64 torch math (LayerNorm over the full row, ALiBi slopes 2^(-8(h+1)/H), causal + key-padding mask)."""
+    qkv = dev(rnd(T, 3 * d, seed=21) * 1.5 + 0.3)
+    gq, gk = dev(1.0 + 0.1 * rnd(d, seed=22)), dev(1.0 + 0.1 * rnd(d, seed=23))
+    g32 = qkv.double().view(T, 3 * d // 32, 32)
+    mu = g32.mean(-1)
+    stats = torch.zeros(3 * d // 32, 16, 2, device="cuda")
+    stats[:, :T, 0] = mu.t().float()
+    stats[:, :T, 1] = ((g32 - mu.unsqueeze(-1)) ** 2).sum(-1).t().float()
+    km = torch.ones(T, dtype=torch.uint8)
+    if mask and T > 2:
+        km[T - 2:] = 0                                           # right padding
+    hi = torch.zeros(16, d, device="cuda", dtype=torch.bfloat16)
+    lo = torch.zeros(16, d, device="cuda", dtype=torch.bfloat16)
+    abi.check(lib.deer_trunk_mpt_attn(abi.ptr(qkv), abi.ptr(stats), d, heads, abi.ptr(gq) if qk_ln else None, abi.ptr(gk) if qk_ln else None, 1e-5,
+                                      abi.ptr(dev(km)) if mask else None, 8.0, abi.ptr(hi), abi.ptr(lo), d, T, None, st()), "trunk_mpt_attn")
+    torch.cuda.synchronize()
+    q, k, v = qkv.double()[:, :d], qkv.double()[:, d:2 * d], qkv.double()[:, 2 * d:]
+    if qk_ln:
+        q, k = _ln(q, gq, None), _ln(k, gk, None)
+    hd = d // heads
+    out = torch.zeros(T, d, dtype=torch.float64, device="cuda")
+    for h in range(heads):
+        s = q[:, h * hd:(h + 1) * hd] @ k[:, h * hd:(h + 1) * hd].t() / math.sqrt(hd)
+        slope = 2.0 ** (-8.0 * (h + 1) / heads)
+        s = s - (T - 1 - torch.arange(T, device="cuda", dtype=torch.float64)).unsqueeze(0) * slope
+        bad = torch.triu(torch.ones(T, T, dtype=torch.bool, device="cuda"), 1)
+        if mask:
+            bad = bad | (dev(km) == 0).unsqueeze(0)
+        s = s.masked_fill(bad, float("-inf"))
+        out[:, h * hd:(h + 1) * hd] = torch.softmax(s, -1) @ v[:, h * hd:(h + 1) * hd]
+    rows = [t for t in range(T) if not (mask and T > 2 and False)]
+    got = hi[:T].double() + lo[:T].double()
+    ok = torch.isfinite(out).all(dim=1)                          # a row whose every visible key is padding is NaN in both arms
+    assert rel_err(got[ok], out[ok].float()) < 2e-5
