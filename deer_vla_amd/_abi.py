@@ -26,6 +26,7 @@ SIGNATURES = {
     "deer_skinny_splitk": [I, I, I],
     "deer_gemm_skinny_hl": [P, P, I, P, P, I, I, I, I, P, P],
     "deer_skinny_hl_splitk": [I, I, I],
+    "deer_gemm_skinny_hl_rows": [P, P, I, P, P, I, I, I, I, I, P, P],
     "deer_slab_gelu_split": [P, I, L, I, P, P, I, I, P, P],
     "deer_pack_weight_mfma16": [P, P, I, I, P],
     "deer_attn_mfma_hd64": [P, P, P, P, I, I, I, I, I, I, I, I, L, L, L, L, F, P],

@@ -190,7 +190,7 @@ __device__ __forceinline__ void sk_wait_vmcnt() {
 template <int MT, int D>
 __global__ __launch_bounds__(512) void gemm_skinny_hl_kernel(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo, int lda,
                                                             const bf16_t* __restrict__ Wp, float* __restrict__ part, int M, int N,
-                                                            int K, int KR, const int* ctl) {
+                                                            int K, int KR, const int* ctl, int part_rows) {
   DEER_RETURN_IF_EXITED(ctl);
   constexpr int MTL = (MT + 1) & ~1;                  // row tiles LOADED per plane (even: every wave issues the same number of DMAs)
   constexpr int MPAD = MT * 16;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_hl_kernel(const bf16_t* __res
   }
   sk_wait_vmcnt<0>();                                 // clamped tail loads must not land in LDS after the workgroup is gone
   if (!tile_ok) return;
-  float* dst = part + ((long)ks * MPAD) * N + tile_raw * 16 + g * 4;
+  float* dst = part + ((long)ks * part_rows) * N + tile_raw * 16 + g * 4;      // slab ks: rows part_rows * ks .. (this launch's rows first)
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     const int row = j * 16 + c;
@@ -285,8 +285,31 @@ extern "C" int deer_skinny_hl_splitk(int M, int N, int K) {
   return s;
 }
 
+static int launch_skinny_hl(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk, const int* ctl,
+                            void* stream, int part_rows);
+
 extern "C" int deer_gemm_skinny_hl(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K,
                                    int splitk, const int* ctl, void* stream) {
+  return launch_skinny_hl(Ahi, Alo, lda, Wp, part, M, N, K, splitk, ctl, stream, 16 * ((M + 15) / 16));
+}
+
+// More than 128 rows (8 environments x 32-token instructions: data.py:905-919 pads to the longest of the batch, max_length = 32; or
+// more environments per engine): row blocks of <= 128 rows, one launch each, into slabs of `slab_rows` rows (>= 16 * ceil(M / 16)) -
+// part[ks][slab_rows][N].  The weights of the later blocks come from the Infinity Cache (33 MB per projection).
+extern "C" int deer_gemm_skinny_hl_rows(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
+                                        int slab_rows, const int* ctl, void* stream) {
+  if (M <= 0 || M > 512 || slab_rows < 16 * ((M + 15) / 16)) return DEER_ERR_SHAPE;
+  for (int r0 = 0; r0 < M; r0 += 128) {
+    const int mb = std::min(128, M - r0);
+    const int rc = launch_skinny_hl(reinterpret_cast<const bf16_t*>(Ahi) + (long)r0 * lda, reinterpret_cast<const bf16_t*>(Alo) + (long)r0 * lda, lda, Wp,
+                                    part + (long)r0 * N, mb, N, K, splitk, ctl, stream, slab_rows);
+    if (rc != DEER_OK) return rc;
+  }
+  return DEER_OK;
+}
+
+static int launch_skinny_hl(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk, const int* ctl,
+                            void* stream, int part_rows) {
   if (M <= 0 || M > 128 || N <= 0 || (N & 15) || K <= 0 || (K & 63) || splitk <= 0 || (K % (splitk * 64)) != 0 || (lda & 7))
     return DEER_ERR_SHAPE;
   if (Ahi == nullptr || Alo == nullptr || Wp == nullptr || part == nullptr) return DEER_ERR_SHAPE;
@@ -308,7 +331,7 @@ extern "C" int deer_gemm_skinny_hl(const void* Ahi, const void* Alo, int lda, co
           hipSuccess) return DEER_ERR_LAUNCH;                                                                                \
       attr_set = true;                                                                                                       \
     }                                                                                                                        \
-    hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, ah, al, lda, wp, part, M, N, K, KR, ctl);                            \
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, ah, al, lda, wp, part, M, N, K, KR, ctl, part_rows);                 \
   } break
   switch (mt) {
     DEER_SKHL_CASE(1, 4);

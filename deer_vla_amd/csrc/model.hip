@@ -22,7 +22,7 @@ namespace {
 
 constexpr float kEps = 1e-5f;
 constexpr int kVitHeadLayers = 3;   // ViT blocks in the first piece of a vision chain (short graph: the GPU idles until it is submitted)
-constexpr int kMaxRows = 128;       // LLM rows (n_envs * T) the skinny GEMM takes
+constexpr int kMaxRows = 256;       // LLM rows (n_envs * T): 8 environments x 32 tokens (data.py:905-919: max_length = 32); the trunk GEMM runs them in blocks of 128
 constexpr int kMaxSplit = 32;
 // LLM rows ABOVE which the trunk projections run on deer_gemm_skinny_hl (pre-split hi/lo activation planes, LDS-DMA ring, 128-column
 // workgroups, GELU/slab reduction once per layer).  Default 0 = always (r03, full-depth step as one graph: 3.79 -> 3.59 ms at one
@@ -835,6 +835,7 @@ struct Pending { const float* slab; int S; long stride; const float* gate; };
 
 int skinny(deer_model* m, const void* Wp, long N, long K, int R, float* out_slab, size_t out_elems, const void* A, int lda, const float* a_slab, int s_in,
            int a_mode, const int* ctl, void* st, int* S_out, long* stride_out) {
+  if (R > 128) return DEER_ERR_SHAPE;      // only the hi/lo-plane kernel runs row blocks (bf16 arithmetic, d % 64 == 0)
   const int S = deer_skinny_splitk(R, (int)N, (int)K);
   const int mpad = 16 * ((R + 15) / 16);
   const int planes = m->c.precision ? 2 : 1;
@@ -872,6 +873,7 @@ int skinny_hl(deer_model* m, const void* Wp, long N, long K, int R, float* out_s
   *S_out = S;
   *stride_out = (long)mpad * N;
   Bracket b(m, "deer_gemm_skinny_hl", 2.0 * R * N * K, 2.0 * N * K, st);    // algorithmic bytes = the bf16 weights, once
+  if (R > 128) return deer_gemm_skinny_hl_rows(hi, lo, lda, Wp, out_slab, R, (int)N, (int)K, S, mpad, ctl, st);
   return deer_gemm_skinny_hl(hi, lo, lda, Wp, out_slab, R, (int)N, (int)K, S, ctl, st);
 }
 

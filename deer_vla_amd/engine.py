@@ -130,8 +130,11 @@ class DeerEngine:
         assert 1 <= n_envs <= 8
         self.B = n_envs
         self.n_cams = 2 * n_envs                       # images per step: (rgb, gripper) of every environment
-        self.max_T = min(max_text_len, 128 // n_envs)  # the skinny GEMM takes n_envs * T <= 128 rows
-        assert self.max_T >= 14, "n_envs * T must fit 128 LLM rows"
+        # trunk rows n_envs * T: up to 256 in the bf16 arithmetic (8 environments x the reference's max_length = 32, data.py:905-919; the
+        # hi/lo-plane trunk GEMM runs them in blocks of 128), 128 in the fp32 arithmetic (one launch of deer_gemm_skinny)
+        self.MAX_ROWS = 256 if (precision == "bf16" and cfg.d_model % 64 == 0) else 128
+        self.max_T = min(max_text_len, self.MAX_ROWS // n_envs)
+        assert self.max_T >= 14, "n_envs * T must fit the trunk's LLM rows"
         self._thr_type = abi.THR_TYPES[threshold_type]
         self._leq = 1 if leq else 0
         self._h = ctypes.c_void_p()
@@ -218,7 +221,7 @@ class DeerEngine:
     def _make_views(self):
         cfg, B = self.cfg, self.B
         N, S, W, nl, d = self.n_cams, cfg.image_size, cfg.vit_width, cfg.perc_latents, cfg.d_model
-        rows = min(B * self.max_T, 128)
+        rows = min(B * self.max_T, self.MAX_ROWS)
         self.max_rows = rows
         v = lambda name, dt: self._buf(name).view(dt)
         self.img = v("img", torch.float32 if self.precision == "fp32" else torch.bfloat16).view(N, 3, S, S)   # static input buffer (camera frames)

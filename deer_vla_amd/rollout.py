@@ -395,16 +395,18 @@ class BatchedModelWrapper:
         self.model.module.engine.reset_env(b)
 
     def check_instructions(self, goals):
-        """Every instruction of an env batch is right-padded to the longest one and n_envs * T rows must fit the trunk GEMM's 128
-        rows (engine.max_T = 128 // n_envs, 16 tokens at 8 environments; the reference allows 32, data.py:905-919).  Raises before
-        a run starts instead of asserting in the middle of it."""
+        """Every instruction of an env batch is right-padded to the longest one and n_envs * T rows must fit the trunk's rows
+        (engine.max_T = engine.MAX_ROWS // n_envs: 256 rows in the bf16 arithmetic -> the reference's full max_length = 32 at 8
+        environments, data.py:905-919; 128 rows in the fp32 arithmetic).  Raises before a run starts instead of asserting in the middle of
+        it."""
         max_T = self.model.module.engine.max_T
         ids, mask = self.text_process_fn(list(goals))
         worst = int(mask.sum(dim=1).max())
         if worst > max_T:
             bad = goals[int(mask.sum(dim=1).argmax())]
+            rows = self.model.module.engine.MAX_ROWS
             raise ValueError(f"instruction {bad!r} tokenizes to {worst} tokens; an env batch of {self.B} takes at most {max_T} "
-                             f"(n_envs * T <= 128 trunk rows): build the model with n_envs <= {128 // worst}")
+                             f"(n_envs * T <= {rows} trunk rows): build the model with n_envs <= {rows // worst}")
 
     def _frames(self, obs_list, key):
         """processed frames of all slots; an idle slot gets a blank frame of the SAME device / dtype as the live ones (a CPU fp32 blank

@@ -123,6 +123,10 @@ int deer_skinny_splitk(int M, int N, int K);                       /* host helpe
 int deer_gemm_skinny_hl(const void* A_hi, const void* A_lo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
                         const int* ctl, void* stream);
 int deer_skinny_hl_splitk(int M, int N, int K);
+/* the same for up to 512 rows (8 environments x 32-token instructions, data.py:905-919): row blocks of <= 128 rows, one launch each,
+ * part[ks][slab_rows][N] with slab_rows >= 16 * ceil(M / 16) */
+int deer_gemm_skinny_hl_rows(const void* A_hi, const void* A_lo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
+                             int slab_rows, const int* ctl, void* stream);
 /* hi / lo planes [rows, C] of act(sum_s slab[s]) (act = exact GELU when gelu != 0): the activation of the down-projections
  * (GELU between mlp_up / mlp_down of the MPT block and ff.1 / ff.3 of the gated x-attn block, helpers.py:15-22), computed ONCE
  * instead of once per column group of the consumer. */

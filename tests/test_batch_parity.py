@@ -147,3 +147,32 @@ def test_two_sibling_engines_stepped_concurrently_equal_each_engine_alone(setup)
                 assert torch.equal(a[1], b[1]) and a[2] == b[2], (k, s, e)
                 n_exits.add(a[0])
     assert len(n_exits) > 1
+
+
+def test_full_size_env_batch_padded_to_32_tokens_matches_the_unpadded_batch(setup):
+    """VERDICT r3 item 3b at 3B size: the same 8 environments with their 14-token instructions right-padded to the reference's
+    max_length = 32 (256 trunk rows: two row blocks of the hi/lo-plane GEMM, two MFMA row tiles per environment in both attention
+    kernels, padded keys masked, pad rows out of the head's token pool) against the unpadded batch (112 rows - the path held against
+    the oracle above).  Padding changes nothing but a constant ALiBi shift per row: actions agree to 1e-4, exit layers exactly."""
+    z, cfg, eng, B = setup
+    eng.configure_exit(cfg.exit_ids(), int(z["max_layer"]), 1)
+    eng.set_thresholds([float(t) for t in z["thr"]])
+    rgb, grip, ids = batch_inputs(cfg, B, 3, eng.dev)
+    T = ids.shape[1]
+    ids32 = torch.full((B, 32), 1, dtype=ids.dtype, device=ids.device)
+    ids32[:, :T] = ids
+    mask = torch.zeros(B, 32, dtype=torch.bool, device=ids.device)
+    mask[:, :T] = True
+    for exit_id in (11, None):
+        outs = []
+        for i, m in ((ids, None), (ids32, mask)):
+            eng.reset()
+            r = None
+            for s in range(2):                                    # second step: LSTM carry included
+                rgb_s, grip_s, _ = batch_inputs(cfg, B, 3 + s, eng.dev)
+                r = eng.step(rgb_s, grip_s, i, m, exit_id=exit_id)
+            outs.append(r)
+        for e in range(B):
+            assert outs[0][e]["exit_layer"] == outs[1][e]["exit_layer"], (exit_id, e)
+            assert float((outs[0][e]["pose"] - outs[1][e]["pose"]).abs().max()) < 1e-4, (exit_id, e)
+            assert abs(outs[0][e]["gripper"] - outs[1][e]["gripper"]) < 1e-4

@@ -440,6 +440,22 @@ def test_batched_environments_with_different_instruction_lengths():
     assert compared >= 0.8 * B * n_steps, (compared, flips)
 
 
+def test_eight_environments_with_instructions_up_to_32_tokens():
+    """the reference pads an instruction batch to its longest member with max_length = 32 (data.py:905-919); 8
+    environments x 32 tokens = 256 trunk rows (two row blocks of the hi/lo-plane GEMM, two MFMA row tiles per environment in the x-attn
+    and MPT attention kernels).  Mixed lengths 9..32: every environment against its own UNPADDED single-environment oracle run."""
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
+    B, n_steps = 8, 6
+    lens = [32, 14, 20, 9, 27, 16, 31, 11]
+    eng = DeerEngine(cfg, sd, n_envs=B)
+    assert eng.max_T == 32 and eng.max_rows == 256
+    env_inputs = [[syn.synthetic_step_inputs(cfg, s, rank=e, text_len=lens[e], text_seed=7 + e) for s in range(n_steps)] for e in range(B)]
+    thr, _ = probe_thresholds(cfg, sd, env_inputs[0], 12, 1)
+    compared, flips, seen = run_env_batch_against_independent_oracles(cfg, sd, eng, env_inputs, thr, 1, n_steps, B)
+    assert compared >= 0.8 * B * n_steps, (compared, flips)
+
+
 def test_full_size_mpt1b_vitl14_steps_vs_oracle():
     """BASELINE config sizes (ViT-L/14 x2, Perceiver, MPT-1B d=2048 x12 layers, 4x1024 LSTM head): static exit
     and a short dynamic episode against the fp32 CPU oracle."""

@@ -301,26 +301,46 @@ def test_env_batch_resets_every_chain_to_its_initial_state():
 
 
 @pytest.mark.gpu
-def test_env_batch_rejects_instructions_that_do_not_fit_before_the_run_starts():
-    """8 environments x T tokens must fit the trunk's 128 rows (T <= 16); an enriched annotation of 14+ words tokenizes
-    longer.  The evaluator validates every instruction up front with a clear error instead of asserting mid-run; a controller with
-    steps_per_stage > 1 is refused at construction."""
+def test_env_batch_takes_the_references_long_instructions_and_rejects_what_does_not_fit():
+    """8 environments x the reference's max_length = 32 tokens (data.py:905-919) = 256 trunk rows fit the bf16 engine, so
+    NO instruction of the reference's evaluation annotations is refused at 8 environments per rank: every distinct instruction of
+    lang_annotation_cache.json (first line, as the harness feeds it: eval_utils.py:638-644) with more than 10 words (7.9 % of the file, up to
+    14 words = 17 tokens with "<image>", "<|endofchunk|>" and eos even at one token per word; tests/golden/long_instructions.json, made by
+    tests/golden/make_long_instructions.py) passes the up-front check, and a batch holding the longest ones rolls out.  What cannot fit
+    still fails BEFORE the run starts with a clear error: the fp32 arithmetic keeps 128 rows (16 tokens at 8
+    environments); a controller with steps_per_stage > 1 is refused at construction."""
+    import json
+    import os
     from deer_vla_amd import synthetic as syn
     from deer_vla_amd.config import deer_tiny
     from deer_vla_amd.factory import create_model_and_transforms
     from deer_vla_amd.value_net import ActionValueNet, ExitController
     cfg = deer_tiny()
     sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
-    model, proc, tok = create_model_and_transforms("ViT-L-14", "openai", "", "", window_size=12, use_gripper=True, fusion_mode="post",
-                                                   llm_name="mpt_dolly_3b", state_dict=sd, cfg=cfg, n_envs=8)
-    vn = ActionValueNet(model.get_all_exit_idx(), None, cfg.exit_interval, 12, "L2")
-    ctl = ExitController(vn, model.get_all_exit_idx(), max_layer=cfg.early_exit_layer + 1)
-    ctl._set_threshold_value([0.02] * (ctl.real_num_exit - 1) + [1e5])
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "long_instructions.json")))
+    longs = gold["long_instructions"]
+    assert len(longs) >= 100 and len(longs[0].split()) == 14 and abs(gold["share_over_10_words"] - 0.0794) < 1e-3
+
+    def build(precision):
+        model, proc, tok = create_model_and_transforms("ViT-L-14", "openai", "", "", window_size=12, use_gripper=True, fusion_mode="post",
+                                                       llm_name="mpt_dolly_3b", state_dict=sd, cfg=cfg, n_envs=8, precision=precision)
+        vn = ActionValueNet(model.get_all_exit_idx(), None, cfg.exit_interval, 12, "L2")
+        ctl = ExitController(vn, model.get_all_exit_idx(), max_layer=cfg.early_exit_layer + 1)
+        ctl._set_threshold_value([0.02] * (ctl.real_num_exit - 1) + [1e5])
+        return model, proc, tok, vn, ctl
+
+    model, proc, tok, vn, ctl = build("bf16")
     w = ro.BatchedModelWrapper(model, tok, proc, torch.float32, exit_controller=ctl)
-    long = "go towards the red block lying on the table and then carefully lift it up high"
-    ann = {"a": ["open the drawer"], "b": [long]}
-    with pytest.raises(ValueError, match="n_envs"):
-        ro.evaluate_policy_batched(w, [ro.SyntheticEnv(seed=b) for b in range(8)], [(None, ["a", "b"])], ann, ro.steps_task_checker(2), ep_len=3)
+    assert model.engine.max_T == 32
+    w.check_instructions(longs)                                    # every long instruction of the reference's file fits
+    ann = {"a": ["open the drawer"], "b": [longs[0]], "c": [longs[1]]}
+    out = ro.evaluate_policy_batched(w, [ro.SyntheticEnv(seed=b) for b in range(8)], [(None, ["a", "b"]), (None, ["c", "a"])] * 4, ann,
+                                     ro.steps_task_checker(2), ep_len=3)
+    assert out["n_chains"] == 8 and out["n_steps"] > 0
     ctl3 = ExitController(vn, model.get_all_exit_idx(), steps_per_stage=3, max_layer=cfg.early_exit_layer + 1)
     with pytest.raises(NotImplementedError):
         ro.BatchedModelWrapper(model, tok, proc, torch.float32, exit_controller=ctl3)
+    model32, proc32, tok32, _, ctl32 = build("fp32")
+    w32 = ro.BatchedModelWrapper(model32, tok32, proc32, torch.float32, exit_controller=ctl32)
+    with pytest.raises(ValueError, match="n_envs"):
+        ro.evaluate_policy_batched(w32, [ro.SyntheticEnv(seed=b) for b in range(8)], [(None, ["a", "b"])], ann, ro.steps_task_checker(2), ep_len=3)
