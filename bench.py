@@ -36,8 +36,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--workload", default="deer_b", choices=["deer_b", "deer_s", "deer_9b"],
-                    help="deer_b: MPT-1B max_layer=12 exit_ratio 0.8 (the metric's config); deer_s: max_layer=4")
+    ap.add_argument("--workload", default="deer_b", choices=["deer_b", "deer_s", "deer_9b", "tiny"],
+                    help="deer_b: MPT-1B max_layer=12 exit_ratio 0.8 (the metric's config); deer_s: max_layer=4; tiny: reduced dims - "
+                         "only for exercising the N>1 code path in tests (tests/test_distributed_cpu.py), never a result")
     ap.add_argument("--exit-ratio", type=float, default=0.8)
     ap.add_argument("--envs-per-gpu", type=int, default=1,
                     help="independent environments evaluated per control step on each GPU (one env batch per rank); "
@@ -659,7 +660,8 @@ def run_workload(args, cfg, sd_dev, B, rank, world, local_rank, dist, max_layer,
         eng.set_thresholds(thr)
         n_timed = timed_steps
 
-    stats = torch.tensor([elapsed, float(exit_sum), float(n_timed * B)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, float(exit_sum), float(n_timed * B)], dtype=torch.float64,
+                         device=dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
     if dist is not None:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -693,12 +695,16 @@ def main():
     from deer_vla_amd.config import deer_3b
 
     max_layer = 4 if args.workload == "deer_s" else 12
-    if args.workload == "deer_9b":                             # BASELINE configs[4]: OpenFlamingo-9B / MPT-7B trunk, max_layer 12
+    if args.workload == "tiny":
+        from deer_vla_amd.config import deer_tiny
+        cfg = deer_tiny()
+        max_layer = cfg.early_exit_layer + 1
+    elif args.workload == "deer_9b":                             # BASELINE configs[4]: OpenFlamingo-9B / MPT-7B trunk, max_layer 12
         from deer_vla_amd.config import deer_9b
         cfg = deer_9b(max_layer=max_layer)
     else:
         cfg = deer_3b(max_layer=max_layer)
-    sd = syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True)
+    sd = syn.make_synthetic_state(cfg, 0, bf16_round=True) if args.workload == "tiny" else syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True)
     B = args.envs_per_gpu
     _EXIT_RATIO[0] = args.exit_ratio
     res = run_workload(args, cfg, sd, B, rank, world, local_rank, dist, max_layer, args.steps, args.warmup)
@@ -711,7 +717,7 @@ def main():
 
     out = {
         "metric": "action-steps/sec (whole job) + avg exit-layer, %s max_layer=%d, synthetic CALVIN-D-shaped inputs"
-                  % ("MPT-7B" if args.workload == "deer_9b" else "MPT-1B", max_layer),
+                  % ("MPT-7B" if args.workload == "deer_9b" else ("REDUCED-DIMS TEST MODEL (not a result)" if args.workload == "tiny" else "MPT-1B"), max_layer),
         "value": round(value, 2), "unit": "action-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * t_max / res["n_timed"], 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32 activations, bf16-representable weights", "data": "synthetic",
@@ -780,7 +786,7 @@ def main():
     n_head = 2.0 + (sum((xs.index(l) + 1) * h for l, h in enumerate(res["hist"]) if h and l in xs) / n_steps_h if world == 1 else 2.0)
     gflop = 347.1 + 2.68 * e_avg + 0.082 * n_head
     gbyte = 0.814 + 0.174 * e_avg
-    if args.workload != "deer_9b":                             # the constants above are the 3B model's
+    if args.workload not in ("deer_9b", "tiny"):               # the constants above are the 3B model's
         out["whole_step"] = {"algorithmic_gflop_per_step": round(gflop, 1), "algorithmic_gb_per_step": round(gbyte, 3),
                              "TFLOP/s": round(gflop * value / world / 1e3, 1),
                              "mfma_frac": round(gflop * value / world / 1e3 / MFMA_PEAK_TF, 4),
@@ -810,7 +816,7 @@ def main():
         if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
-        st = torch.tensor([dt], dtype=torch.float64, device=eng.dev)
+        st = torch.tensor([dt], dtype=torch.float64, device=eng.dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
         if dist is not None:
             dist.all_reduce(st, op=dist.ReduceOp.MAX)
         out["scripted"] = {"value": round(world * len(sched) / float(st[0]), 2), "unit": "action-steps/s", "steps": len(sched),

@@ -113,6 +113,42 @@ def config_from_args(name_args: Dict, ckpt_args: Dict, trunk: Optional[DeerConfi
     return cfg
 
 
+def apply_hf_mpt_config(cfg: DeerConfig, hf_config) -> DeerConfig:
+    """The fields of the HF MPT repo's ``config.json`` that decide the block's ARITHMETIC, read from the file the reference loads the
+    model with (``AutoModelForCausalLM.from_pretrained(lang_encoder_path, trust_remote_code=True)``, factory.py:134-136; the repos are
+    un-vendored and un-pinned) instead of being assumed: both published layouts are understood - MosaicGPT
+    (mpt-1b-redpajama-200b[-dolly]: flat ``attn_qk_ln``, ``alibi_bias_max``, ``mlp_ratio``) and MPT (mpt-7b: ``attn_config.qk_ln``,
+    ``attn_config.alibi_bias_max``, ``expansion_ratio``).  ``hf_config``: path of the json file or the parsed dict.  Returns a new
+    DeerConfig; raises on anything this engine's MPT block does not implement (it would otherwise be silently ignored)."""
+    import dataclasses
+    import json
+    c = json.load(open(hf_config)) if isinstance(hf_config, (str, bytes)) or hasattr(hf_config, "__fspath__") else dict(hf_config)
+    ac = c.get("attn_config") or {}
+
+    def pick(flat, nested, default=None):
+        return c[flat] if flat in c else ac.get(nested, default)
+    unsupported = {
+        "alibi": (pick("alibi", "alibi", True), True, "positions come from ALiBi only (mosaic_gpt_3b.py:342-343: no learned wpe is added)"),
+        "clip_qkv": (pick("attn_clip_qkv", "clip_qkv"), None, "qkv clamping is not built"),
+        "softmax_scale": (pick("softmax_scale", "softmax_scale"), None, "the block scales by 1/sqrt(head_dim)"),
+        "prefix_lm": (bool(pick("prefix_lm", "prefix_lm", False)), False, "causal attention only"),
+        "attn_uses_sequence_id": (bool(pick("attn_uses_sequence_id", "attn_uses_sequence_id", False)), False, "no packed sequences on this path"),
+        "no_bias": (bool(c.get("no_bias", True)), True, "Linear biases are not ingested (the released MPT checkpoints are bias-free)"),
+    }
+    for name, (got, want, why) in unsupported.items():
+        if got != want:
+            raise NotImplementedError(f"HF MPT config: {name}={got!r} is not implemented by deer_vla_amd ({why})")
+    norm = c.get("norm_type", "low_precision_layernorm")
+    if norm not in ("low_precision_layernorm", "layernorm"):
+        raise NotImplementedError(f"HF MPT config: norm_type={norm!r} (only LayerNorm variants are built)")
+    upd = dict(d_model=int(c["d_model"]), n_heads=int(c["n_heads"]), n_layers_total=int(c["n_layers"]),
+               mlp_ratio=int(c["mlp_ratio"] if "mlp_ratio" in c else c.get("expansion_ratio", cfg.mlp_ratio)),
+               attn_qk_ln=bool(pick("attn_qk_ln", "qk_ln", False)), alibi_bias_max=int(pick("alibi_bias_max", "alibi_bias_max", 8)))
+    if upd["n_layers_total"] <= cfg.early_exit_layer:
+        raise ValueError(f"HF MPT config has {upd['n_layers_total']} layers, the DeeR checkpoint exits at layer {cfg.early_exit_layer}")
+    return dataclasses.replace(cfg, **upd)
+
+
 def canonical_key(k: str) -> str:
     """One reference state-dict key -> the canonical name the engine ingests (deer_vla_amd.synthetic.param_shapes):
     strip DDP's ``module.``; fold the two alias registrations (flamingo_lm.py:160-176) into the block-local names."""
@@ -191,14 +227,19 @@ def _torch_load(path: str):
 
 
 def load_checkpoint_files(deer_ckpt: str, openflamingo_ckpt: Optional[str] = None, clip_state: Optional[str] = None,
-                          mpt_state: Optional[str] = None, max_layer: Optional[int] = None, trunk: Optional[DeerConfig] = None):
+                          mpt_state: Optional[str] = None, max_layer: Optional[int] = None, trunk: Optional[DeerConfig] = None,
+                          mpt_config: Optional[str] = None):
     """Read the files the reference's eval reads and return (cfg, state_dict, info).  ``clip_state`` / ``mpt_state``: state dicts
     of the open_clip model and of the HF MPT model saved to disk (the reference obtains them through open_clip / transformers
-    at construction time, factory.py:109-136; neither package's hub access exists here)."""
+    at construction time, factory.py:109-136; neither package's hub access exists here).  ``mpt_config``: the HF repo's
+    ``config.json`` (``mpt_dict[llm_name]["lang_encoder_path"]/config.json``): when given, attn_qk_ln / alibi_bias_max / sizes are READ
+    from it (apply_hf_mpt_config) instead of taken from this package's defaults."""
     ck = _torch_load(deer_ckpt)
     name_args = args_from_checkpoint_name(deer_ckpt)
     ckpt_args = args_from_checkpoint_dict(ck if isinstance(ck, dict) else {}, name_args["llm_name"], max_layer)
     cfg = config_from_args(name_args, ckpt_args, trunk)
+    if mpt_config is not None:
+        cfg = apply_hf_mpt_config(cfg, mpt_config)
     sources = []
     if clip_state:
         sources.append(("open_clip", map_open_clip_keys(_torch_load(clip_state))))
@@ -218,11 +259,11 @@ def load_checkpoint_files(deer_ckpt: str, openflamingo_ckpt: Optional[str] = Non
 
 def build_model_from_checkpoint(deer_ckpt: str, openflamingo_ckpt: Optional[str] = None, clip_state: Optional[str] = None,
                                 mpt_state: Optional[str] = None, max_layer: Optional[int] = None, device="cuda", strict: bool = True,
-                                trunk: Optional[DeerConfig] = None, precision: str = "bf16", n_envs: int = 1):
+                                trunk: Optional[DeerConfig] = None, precision: str = "bf16", n_envs: int = 1, mpt_config: Optional[str] = None):
     """-> (MPTFlamingo, info) ready for ``forward`` / ``ModelWrapper``; raises when tensors are missing (strict).  precision="fp32" keeps
     the checkpoint's f32 weights (f32 / hi+lo copies on the device) - the arithmetic of a reference run at ``--precision fp32``."""
     from .flamingo_mpt import MPTFlamingo
-    cfg, sd, info = load_checkpoint_files(deer_ckpt, openflamingo_ckpt, clip_state, mpt_state, max_layer, trunk)
+    cfg, sd, info = load_checkpoint_files(deer_ckpt, openflamingo_ckpt, clip_state, mpt_state, max_layer, trunk, mpt_config)
     if strict and info["missing"]:
         raise RuntimeError(f"{len(info['missing'])} tensors missing after loading all checkpoint files, e.g. {info['missing'][:4]}")
     model = MPTFlamingo(cfg, sd, window_size=info["name_args"]["window_size"], device=device, precision=precision, n_envs=n_envs)

@@ -133,3 +133,52 @@ def test_engine_loaded_from_reference_format_files_reproduces_the_reference_forw
         assert o.exit_layer == int(g[tag + "_exit"])
         assert float((o.logits[0].cpu().reshape(-1) - g[tag + "_pose"].reshape(-1)).abs().max()) < 1e-2
         assert abs(float(o.logits[1]) - float(g[tag + "_grip"])) < 1e-2
+
+
+# config.json of the two HF MPT repos the reference loads (factory.py:13-26), IN THE PUBLISHED LAYOUTS, restated by hand: the repos are
+# un-vendored and un-pinned and there is no network here, so these literals are NOT pinned to the hub files - what the
+# test pins is that the loader READS the flags that decide the block's arithmetic from whatever file it is given instead of assuming them.
+MOSAIC_GPT_1B_CONFIG = {   # mosaicml/mpt-1b-redpajama-200b-dolly (MosaicGPT: flat keys)
+    "alibi": True, "alibi_bias_max": 8, "architectures": ["MosaicGPT"], "attn_clip_qkv": None, "attn_impl": "torch", "attn_pdrop": 0,
+    "attn_qk_ln": True, "attn_uses_sequence_id": False, "d_model": 2048, "emb_pdrop": 0, "embedding_fraction": 1.0,
+    "low_precision_layernorm": True, "max_seq_len": 2048, "mlp_ratio": 4, "model_type": "mosaic_gpt", "n_heads": 16, "n_layers": 24,
+    "no_bias": True, "prefix_lm": False, "resid_pdrop": 0, "softmax_scale": None, "tokenizer_name": "EleutherAI/gpt-neox-20b",
+    "vocab_size": 50432}
+MPT_7B_CONFIG = {          # mosaicml/mpt-7b (MPT: attn_config sub-dict)
+    "architectures": ["MPTForCausalLM"],
+    "attn_config": {"alibi": True, "alibi_bias_max": 8, "attn_impl": "torch", "attn_pdrop": 0, "attn_type": "multihead_attention",
+                    "attn_uses_sequence_id": False, "clip_qkv": None, "prefix_lm": False, "qk_ln": False, "softmax_scale": None},
+    "d_model": 4096, "emb_pdrop": 0, "expansion_ratio": 4, "learned_pos_emb": True, "max_seq_len": 2048, "model_type": "mpt", "n_heads": 32,
+    "n_layers": 32, "no_bias": True, "norm_type": "low_precision_layernorm", "resid_pdrop": 0, "vocab_size": 50432}
+
+
+def test_loader_reads_the_block_arithmetic_from_the_hf_config_json(tmp_path):
+    """``attn_qk_ln`` (LayerNorm over d_model on q and k - the one piece of the MPT block no independent
+    implementation in this container has) is read from the HF repo's config.json, in both published layouts, together with
+    alibi_bias_max and the sizes; features the engine's block does not implement raise instead of being ignored."""
+    from deer_vla_amd.config import deer_3b, deer_9b
+    base = deer_3b()
+    for flag in (True, False):
+        p = os.path.join(tmp_path, f"config_{flag}.json")
+        json.dump({**MOSAIC_GPT_1B_CONFIG, "attn_qk_ln": flag, "alibi_bias_max": 4 if not flag else 8}, open(p, "w"))
+        cfg = ck.apply_hf_mpt_config(base, p)
+        assert cfg.attn_qk_ln is flag and cfg.alibi_bias_max == (8 if flag else 4)
+        assert (cfg.d_model, cfg.n_heads, cfg.n_layers_total, cfg.mlp_ratio) == (2048, 16, 24, 4) and cfg.early_exit_layer == base.early_exit_layer
+    assert base.attn_qk_ln is True                                       # the caller's config is not mutated
+    c9 = ck.apply_hf_mpt_config(deer_9b(), MPT_7B_CONFIG)
+    assert c9.attn_qk_ln is False and (c9.d_model, c9.n_heads, c9.n_layers_total, c9.mlp_ratio) == (4096, 32, 32, 4)
+    assert ck.apply_hf_mpt_config(deer_9b(), {**MPT_7B_CONFIG, "attn_config": {**MPT_7B_CONFIG["attn_config"], "qk_ln": True}}).attn_qk_ln is True
+    for bad in ({"attn_clip_qkv": 6.0}, {"softmax_scale": 0.1}, {"prefix_lm": True}, {"no_bias": False}, {"alibi": False}):
+        with pytest.raises(NotImplementedError):
+            ck.apply_hf_mpt_config(base, {**MOSAIC_GPT_1B_CONFIG, **bad})
+    with pytest.raises(NotImplementedError):
+        ck.apply_hf_mpt_config(deer_9b(), {**MPT_7B_CONFIG, "norm_type": "rmsnorm"})
+    with pytest.raises(ValueError):
+        ck.apply_hf_mpt_config(base, {**MOSAIC_GPT_1B_CONFIG, "n_layers": 8})      # fewer layers than the DeeR checkpoint's exit layer
+    # through the file loader: the flag of the config file reaches the model config
+    meta, trunk, _, _, files = write_reference_format_files(tmp_path)
+    tiny_json = os.path.join(tmp_path, "tiny_config.json")
+    json.dump({**MOSAIC_GPT_1B_CONFIG, "d_model": trunk.d_model, "n_heads": trunk.n_heads, "n_layers": trunk.n_layers_total, "attn_qk_ln": not trunk.attn_qk_ln},
+              open(tiny_json, "w"))
+    cfg, _, _ = ck.load_checkpoint_files(files[0], files[1], files[2], files[3], trunk=trunk, mpt_config=tiny_json)
+    assert cfg.attn_qk_ln is (not trunk.attn_qk_ln)

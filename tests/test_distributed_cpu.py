@@ -127,3 +127,37 @@ def test_two_rank_nccl_collectives_accept_cpu_tensors():
         raise AssertionError(msg)
     for r, _, n_chains, avg_len, shp, g04, devtype in out:
         assert n_chains == 2 and abs(avg_len - 1.5) < 1e-12 and shp == (6, 8) and g04 == 100.0 and devtype == "cpu"
+
+
+@pytest.mark.gpu
+def test_bench_with_eight_ranks_through_torch_distributed_run():
+    """the driver's 8-GPU command line, ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py
+    --gpus 8``, end to end on whatever box this runs on: eight processes, eight model replicas, barrier-bracketed timed region, the packed
+    all-reduce, the per-rank device report (``ranks`` / ``distinct_devices``).  With fewer than 8 GPUs every rank uses device 0 and the
+    process group is gloo (DEER_BENCH_SINGLE_DEVICE / DEER_BENCH_BACKEND: RCCL refuses several ranks on one device); on an 8-GPU box
+    the same test runs one rank per GPU over RCCL.  Reduced-dims model (``--workload tiny``): this exercises the N = 8 code path
+    (rank slicing as eval_utils.py:523-527: 224 chains = 8 x 28), not performance."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    real = torch.cuda.device_count() >= 8
+    env = dict(os.environ)
+    if not real:
+        env.update(DEER_BENCH_SINGLE_DEVICE="1", DEER_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2", "--workload", "tiny", "--calib-steps", "24",
+           "--burn-in", "0", "--on-policy-steps", "0", "--scripted-steps", "0", "--latency-reps", "0", "--no-cpu-baseline", "--batched-envs", "0",
+           "--surface-steps", "0", "--no-roofline"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 8 and out["rccl_world"] == 8 and out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 6
+    assert out["backend"] == ("nccl" if real else "gloo")
+    assert sorted(r["rank"] for r in out["ranks"]) == list(range(8))
+    assert out["distinct_devices"] == (8 if real else 1)
+    assert abs(out["config"]["per_gpu_steps_per_s"] * 8 - out["value"]) < 0.05 * out["value"]
+    from deer_vla_amd import distributed as dd2
+    seqs = list(range(224))
+    assert [len(dd2.shard_sequences(seqs, r, 8)) for r in range(8)] == [28] * 8 and dd2.shard_sequences(seqs, 7, 8)[-1] == 223

@@ -245,6 +245,56 @@ def test_mpt_block_matches_hf_port():
     close(out, g["out"], atol=1e-5)
 
 
+def test_qk_layernorm_is_over_d_model_in_an_independent_formulation():
+    """``attn_qk_ln`` is the one piece of the MPT block without an independent implementation here (transformers'
+    MptBlock has none; the HF repo is un-vendored).  Its published semantics (MosaicGPT attention.py of mpt-1b-redpajama-200b:
+    ``self.q_ln = layernorm_class(self.d_model)``, applied to the whole query / key BEFORE the split into heads; later llm-foundry
+    versions call the per-head alternative ``qk_gn``) are restated here with torch's OWN modules - nn.Linear, nn.LayerNorm(d_model),
+    F.scaled_dot_product_attention with an additive ALiBi + causal mask - i.e. none of the oracle's helpers, and contrasted with the
+    per-head variant: the oracle's block agrees with the full-d formulation to 1e-5 and is far from the per-head one."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    cfg, seed, g = load("hf_mpt_block.npz")
+    import dataclasses
+    cfg = dataclasses.replace(cfg, attn_qk_ln=True)
+    sd = state(cfg, seed)
+    p = "lang_encoder.transformer.blocks.0.decoder_layer."
+    d, H = cfg.d_model, cfg.n_heads
+    gq, gk = 1.0 + 0.2 * torch.randn(d, generator=torch.Generator().manual_seed(5)), 1.0 + 0.2 * torch.randn(d, generator=torch.Generator().manual_seed(6))
+    sd[p + "attn.q_ln.weight"], sd[p + "attn.k_ln.weight"] = gq, gk
+    x = g["x"]
+    B, S, _ = x.shape
+    out = orc.mpt_block(sd, p, cfg, x, orc.mpt_attn_bias(cfg, S, None))
+
+    def block(per_head: bool):
+        ln1, ln2 = nn.LayerNorm(d, bias=False), nn.LayerNorm(d, bias=False)
+        wqkv, wo = nn.Linear(d, 3 * d, bias=False), nn.Linear(d, d, bias=False)
+        up, down = nn.Linear(d, cfg.mlp_ratio * d, bias=False), nn.Linear(cfg.mlp_ratio * d, d, bias=False)
+        names = ("norm_1", "norm_2", "ffn.up_proj", "ffn.down_proj") if cfg.llm_name == "mpt_9b" else ("ln_1", "ln_2", "mlp.mlp_up", "mlp.mlp_down")
+        with torch.no_grad():
+            ln1.weight.copy_(sd[p + names[0] + ".weight"]); ln2.weight.copy_(sd[p + names[1] + ".weight"])
+            wqkv.weight.copy_(sd[p + "attn.Wqkv.weight"]); wo.weight.copy_(sd[p + "attn.out_proj.weight"])
+            up.weight.copy_(sd[p + names[2] + ".weight"]); down.weight.copy_(sd[p + names[3] + ".weight"])
+            q, k, v = wqkv(ln1(x)).chunk(3, dim=-1)
+            if per_head:       # the ALTERNATIVE (normalise every head's 128 dims on its own): not what attn_qk_ln means
+                q = (F.layer_norm(q.view(B, S, H, d // H), (d // H,)) .reshape(B, S, d)) * gq
+                k = (F.layer_norm(k.view(B, S, H, d // H), (d // H,)).reshape(B, S, d)) * gk
+            else:              # attn_qk_ln: LayerNorm(d_model) on the whole query / key
+                qn, kn = nn.LayerNorm(d, bias=False), nn.LayerNorm(d, bias=False)
+                qn.weight.copy_(gq); kn.weight.copy_(gk)
+                q, k = qn(q), kn(k)
+            hd = d // H
+            slopes = torch.tensor([2.0 ** (-cfg.alibi_bias_max * (h + 1) / H) for h in range(H)])
+            bias = -(S - 1 - torch.arange(S)).view(1, 1, 1, S) * slopes.view(1, H, 1, 1)
+            mask = bias + torch.full((S, S), float("-inf")).triu(1)
+            o = F.scaled_dot_product_attention(q.view(B, S, H, hd).transpose(1, 2), k.view(B, S, H, hd).transpose(1, 2),
+                                               v.view(B, S, H, hd).transpose(1, 2), attn_mask=mask)
+            y = x + wo(o.transpose(1, 2).reshape(B, S, d))
+            return y + down(F.gelu(up(ln2(y))))
+    close(out, block(per_head=False), atol=1e-5)
+    assert float((out - block(per_head=True)).abs().max()) > 1e-2
+
+
 def test_vit_matches_hf_clip_port():
     """Un-vendored CLIP ViT arithmetic: cross-check against transformers' CLIPVisionModel (quick_gelu,
     patch tokens before post_layernorm)."""
