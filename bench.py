@@ -85,7 +85,7 @@ def parse():
 SAME_KERNEL = {"deer_gemm_bf16_nt_splitk": "deer_gemm_bf16_nt", "deer_gemm_bf16_nt_wbatch": "deer_gemm_bf16_nt",
                "deer_attn_mfma_hd64_2seg": "deer_attn_mfma_hd64", "deer_layernorm_rows_multi": "deer_layernorm_rows"}
 KERNEL_BOUND = {"deer_gemm_bf16_nt": "mfma", "deer_attn_mfma_hd64": "mfma", "deer_gemm_skinny": "hbm", "deer_gemm_skinny_hl": "hbm",
-                "deer_gemm_f32_nt": "mfma"}
+                "deer_trunk_wide_gemm": "hbm", "deer_gemm_f32_nt": "mfma"}
 MFMA_PEAK_BY_CLASS = {"deer_gemm_f32_nt": 157.3}      # exact-f32 MFMA (v_mfma_f32_16x16x4_f32): 1/16 of the bf16 rate (MI355X_MICROARCH.md)
 
 

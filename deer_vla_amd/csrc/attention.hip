@@ -393,8 +393,10 @@ extern "C" int deer_xattn_small(const float* qslab, int s_in, long slab_stride, 
 __global__ __launch_bounds__(256) void qkv_reduce_ln_kernel(const float* __restrict__ slab, int s_in, long slab_stride,
                                                             int d, const float* __restrict__ q_ln_w,
                                                             const float* __restrict__ k_ln_w, float eps,
-                                                            float* __restrict__ qkv, const int* ctl) {
+                                                            float* __restrict__ qkv, const int* ctl,
+                                                            const int* __restrict__ cmap = nullptr, int rows_per_env = 0) {
   DEER_RETURN_IF_EXITED(ctl);
+  if (cmap != nullptr && (int)blockIdx.x >= cmap[CMAP_N] * rows_per_env) return;      // rows of exited environments (compaction)
   __shared__ float red[16];
   const int t = blockIdx.x, part = blockIdx.y;
   const long base = (long)t * 3 * d + (long)part * d;
@@ -443,8 +445,12 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
                                                              const unsigned char* __restrict__ key_mask,
                                                              float alibi_slope_base, int n_heads,
                                                              void* __restrict__ out, int out_is_f32, int ldo, int T,
-                                                             const int* ctl, bf16_t* __restrict__ out_lo) {
+                                                             const int* ctl, bf16_t* __restrict__ out_lo,
+                                                             const int* __restrict__ cmap = nullptr) {
   DEER_RETURN_IF_EXITED(ctl);
+  // compaction: blockIdx.y is a SLOT; the key-padding mask is indexed by the slot's environment
+  if (cmap != nullptr && (int)blockIdx.y >= cmap[CMAP_N]) return;
+  const int env_of_slot = cmap != nullptr ? cmap[CMAP_SLOT_ENV + blockIdx.y] : (int)blockIdx.y;
   __shared__ __attribute__((aligned(16))) float qs[MA_MAXT][128 + 4];
   __shared__ __attribute__((aligned(16))) float ks[MA_MAXT][128 + 4];
   __shared__ __attribute__((aligned(16))) float vs[MA_MAXT][128 + 4];
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * d_model;
   qkv += (long)blockIdx.y * T * ld;                        // environment blockIdx.y
-  if (key_mask != nullptr) key_mask += blockIdx.y * T;
+  if (key_mask != nullptr) key_mask += env_of_slot * T;
   out = out_is_f32 ? (void*)(reinterpret_cast<float*>(out) + (long)blockIdx.y * T * ldo)
                    : (void*)(reinterpret_cast<bf16_t*>(out) + (long)blockIdx.y * T * ldo);
   if (out_lo != nullptr) out_lo += (long)blockIdx.y * T * ldo;
@@ -517,6 +523,24 @@ extern "C" int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_str
                      eps, qkv_ws, ctl);
   hipLaunchKernelGGL(mpt_attn_small_kernel, dim3(n_heads, batch), dim3(256), 0, st, qkv_ws, d_model, hd, key_mask, alibi_bias_max,
                      n_heads, out, out_is_f32, ldo, T, ctl, static_cast<bf16_t*>(nullptr));
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// deer_mpt_attn_small_hl for an env batch with compaction: slots of `cmap` (T rows each) instead of environments
+extern "C" int deer_mpt_attn_small_hl_active(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w,
+                                             const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws,
+                                             void* out_hi, void* out_lo, int ldo, int T, int batch, const int* ctl, const int* cmap, void* stream) {
+  const int hd = d_model / n_heads;
+  if (T <= 0 || T > MA_MAXT || hd > 128 || (hd & 3) || hd * n_heads != d_model || s_in <= 0 || (d_model & 3) || d_model > 4096 ||
+      qkv_ws == nullptr || batch <= 0 || out_hi == nullptr || out_lo == nullptr || cmap == nullptr)
+    return DEER_ERR_SHAPE;
+  if ((q_ln_w == nullptr) != (k_ln_w == nullptr)) return DEER_ERR_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(qkv_reduce_ln_kernel, dim3(T * batch, 3), dim3(256), 0, st, qkvslab, s_in, slab_stride, d_model, q_ln_w, k_ln_w,
+                     eps, qkv_ws, ctl, cmap, T);
+  hipLaunchKernelGGL(mpt_attn_small_kernel, dim3(n_heads, batch), dim3(256), 0, st, qkv_ws, d_model, hd, key_mask, alibi_bias_max,
+                     n_heads, out_hi, 0, ldo, T, ctl, reinterpret_cast<bf16_t*>(out_lo), cmap);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

@@ -41,6 +41,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define HOSTM_DONE 1
 #define CTL_WORDS 64
 
+// Row map of an env batch with COMPACTION of exited environments (round 4): the trunk keeps the rows of the still-active
+// environments packed at the front of its buffers ("slots"); int32 words: [0] = number of active slots, [1 + s] = environment of slot s,
+// [1 + HB + e] = slot of environment e (-1 once it has exited).  Two copies (parity) per model: a compaction writes the other one while
+// the exit check of the previous exit layer may still read the old one.  NULL map = identity, every environment active.
+#define CMAP_N 0
+#define CMAP_SLOT_ENV 1
+#define CMAP_ENV_SLOT 9
+#define CMAP_WORDS 32
+__device__ __forceinline__ int cmap_active(const int* cmap, int B) { return cmap != nullptr ? cmap[CMAP_N] : B; }
+__device__ __forceinline__ int cmap_env(const int* cmap, int slot) { return cmap != nullptr ? cmap[CMAP_SLOT_ENV + slot] : slot; }
+__device__ __forceinline__ int cmap_slot(const int* cmap, int env) { return cmap != nullptr ? cmap[CMAP_ENV_SLOT + env] : env; }
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even, NaN preserved (same as torch .to(bfloat16))

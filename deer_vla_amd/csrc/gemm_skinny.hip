@@ -188,10 +188,9 @@ __device__ __forceinline__ void sk_wait_vmcnt() {
 }
 
 template <int MT, int D>
-__global__ __launch_bounds__(512) void gemm_skinny_hl_kernel(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo, int lda,
-                                                            const bf16_t* __restrict__ Wp, float* __restrict__ part, int M, int N,
-                                                            int K, int KR, const int* ctl, int part_rows) {
-  DEER_RETURN_IF_EXITED(ctl);
+__device__ __forceinline__ void gemm_skinny_hl_body(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo, int lda,
+                                                    const bf16_t* __restrict__ Wp, float* __restrict__ part, int M, int N, int K, int KR,
+                                                    int part_rows) {
   constexpr int MTL = (MT + 1) & ~1;                  // row tiles LOADED per plane (even: every wave issues the same number of DMAs)
   constexpr int MPAD = MT * 16;
   constexpr int A_CH = 4 * MTL;                       // 1 KiB chunks (8 rows x 128 B) of [hi plane ; lo plane] per stage
@@ -276,6 +275,37 @@ __global__ __launch_bounds__(512) void gemm_skinny_hl_kernel(const bf16_t* __res
   }
 }
 
+template <int MT, int D>
+__global__ __launch_bounds__(512) void gemm_skinny_hl_kernel(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo, int lda,
+                                                            const bf16_t* __restrict__ Wp, float* __restrict__ part, int M, int N,
+                                                            int K, int KR, const int* ctl, int part_rows) {
+  DEER_RETURN_IF_EXITED(ctl);
+  gemm_skinny_hl_body<MT, D>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows);
+}
+
+// Env batch with COMPACTION of exited environments (common.h: CMAP_*): the number of valid rows is read from the device - the active
+// slots x rows_per_env, minus the rows of earlier row blocks - and the workgroup runs the body specialised for that many MFMA row tiles
+// (its own ring depth, DMA counts and waits: exactly the kernel a launch with that M would have run).  A launch costs what its ACTIVE rows
+// cost: 15.4 us at 112 rows, 6.9 us at 14 (r03).  Rows beyond the active ones are not written.
+__global__ __launch_bounds__(512) void gemm_skinny_hl_dyn_kernel(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo, int lda,
+                                                                const bf16_t* __restrict__ Wp, float* __restrict__ part, int M_max, int N,
+                                                                int K, int KR, const int* ctl, int part_rows, const int* __restrict__ cmap,
+                                                                int rows_per_env, int row0) {
+  DEER_RETURN_IF_EXITED(ctl);
+  const int M = min(M_max, cmap[CMAP_N] * rows_per_env - row0);
+  if (M <= 0) return;
+  switch ((M + 15) >> 4) {
+    case 1: gemm_skinny_hl_body<1, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
+    case 2: gemm_skinny_hl_body<2, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
+    case 3: gemm_skinny_hl_body<3, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
+    case 4: gemm_skinny_hl_body<4, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
+    case 5: gemm_skinny_hl_body<5, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
+    case 6: gemm_skinny_hl_body<6, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
+    case 7: gemm_skinny_hl_body<7, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
+    default: gemm_skinny_hl_body<8, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
+  }
+}
+
 // split-K of the env-batch kernel: 128-column workgroups, ~256 of them, K range per workgroup >= 256 columns (4 ring stages)
 extern "C" int deer_skinny_hl_splitk(int M, int N, int K) {
   (void)M;
@@ -305,6 +335,33 @@ extern "C" int deer_gemm_skinny_hl_rows(const void* Ahi, const void* Alo, int ld
                                     part + (long)r0 * N, mb, N, K, splitk, ctl, stream, slab_rows);
     if (rc != DEER_OK) return rc;
   }
+  return DEER_OK;
+}
+
+// deer_gemm_skinny_hl_rows for an env batch with compaction: M = the rows of ALL environments (the launch geometry), the valid rows are read
+// from `cmap` on the device (active slots x rows_per_env)
+extern "C" int deer_gemm_skinny_hl_active(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
+                                          int slab_rows, const int* ctl, const int* cmap, int rows_per_env, void* stream) {
+  if (M <= 0 || M > 512 || slab_rows < 16 * ((M + 15) / 16) || cmap == nullptr || rows_per_env <= 0 || N <= 0 || (N & 15) || K <= 0 || (K & 63) ||
+      splitk <= 0 || (K % (splitk * 64)) != 0 || (lda & 7) || Ahi == nullptr || Alo == nullptr || Wp == nullptr || part == nullptr)
+    return DEER_ERR_SHAPE;
+  constexpr int smem = 3 * (4 * 8 + 16) * 1024;               // the largest body (8 row tiles, 3 stages); the 4-stage bodies need 4 * (4 * 4 + 16) KB
+  static_assert(smem >= 4 * (4 * 4 + 16) * 1024 && smem <= 160 * 1024, "LDS");
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_hl_dyn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return DEER_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int KR = K / splitk;
+  dim3 grid((N + 127) / 128, splitk);
+  for (int r0 = 0; r0 < M; r0 += 128) {
+    const int mb = std::min(128, M - r0);
+    hipLaunchKernelGGL(gemm_skinny_hl_dyn_kernel, grid, dim3(512), smem, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16_t*>(Ahi) + (long)r0 * lda, reinterpret_cast<const bf16_t*>(Alo) + (long)r0 * lda, lda,
+                       reinterpret_cast<const bf16_t*>(Wp), part + (long)r0 * N, mb, N, K, KR, ctl, slab_rows, cmap, rows_per_env, r0);
+  }
+  DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
 
@@ -354,8 +411,9 @@ static int launch_skinny_hl(const void* Ahi, const void* Alo, int lda, const voi
 // of the consumer: 8x for the 2048-wide down-projections).
 __global__ __launch_bounds__(256) void slab_gelu_split_kernel(const float* __restrict__ slab, int s_in, long stride, int gelu,
                                                               bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long total4,
-                                                              const int* ctl) {
+                                                              const int* ctl, const int* __restrict__ cmap = nullptr, long per_env4 = 0) {
   DEER_RETURN_IF_EXITED(ctl);
+  if (cmap != nullptr) total4 = min(total4, (long)cmap[CMAP_N] * per_env4);      // active slots only (compaction)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
     float4 s = slab_sum4(slab + i * 4, s_in, stride);
     if (gelu) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
@@ -374,6 +432,19 @@ extern "C" int deer_slab_gelu_split(const float* slab, int s_in, long slab_strid
   const int blocks = (int)std::min<long>((total4 + 255) / 256, 2048);
   hipLaunchKernelGGL(slab_gelu_split_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slab, s_in, slab_stride,
                      gelu, reinterpret_cast<bf16_t*>(out_hi), reinterpret_cast<bf16_t*>(out_lo), total4, ctl);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// the same restricted to the active slots of an env batch with compaction (rows_per_env rows per slot)
+extern "C" int deer_slab_gelu_split_active(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows, int C,
+                                           const int* ctl, const int* cmap, int rows_per_env, void* stream) {
+  if (slab == nullptr || s_in <= 0 || out_hi == nullptr || out_lo == nullptr || rows <= 0 || C <= 0 || (C & 3) || cmap == nullptr || rows_per_env <= 0)
+    return DEER_ERR_SHAPE;
+  const long total4 = (long)rows * C / 4;
+  const int blocks = (int)std::min<long>((total4 + 255) / 256, 2048);
+  hipLaunchKernelGGL(slab_gelu_split_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slab, s_in, slab_stride,
+                     gelu, reinterpret_cast<bf16_t*>(out_hi), reinterpret_cast<bf16_t*>(out_lo), total4, ctl, cmap, (long)rows_per_env * C / 4);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

@@ -219,11 +219,19 @@ __device__ __forceinline__ void rows_to_lds(const float* __restrict__ src, long 
 // rows, so they are left out of the pool (max: skipped; avg: divided by the number of valid tokens).
 __global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict__ feats, float* __restrict__ pooled, int T, int d,
                                                         int avg, int B, const unsigned char* __restrict__ key_mask,
-                                                        const int* ctl, int kind, int layer, const float* __restrict__ add) {
+                                                        const int* ctl, int kind, int layer, const float* __restrict__ add,
+                                                        const int* __restrict__ cmap = nullptr) {
   if (head_skip(ctl, kind, layer, B)) return;
   const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   if (i >= d) return;
-  const float* x = feats + ((long)b * T) * d + i;
+  // compaction: the features of environment b live at its SLOT of the layer's row map; an environment that has left the trunk has no
+  // rows any more - its pooled feature is zero and the rest of the evaluation ignores it (head_final returns on its EXIT_FLAG)
+  const int slot = cmap != nullptr ? cmap[CMAP_ENV_SLOT + b] : b;
+  if (slot < 0) {
+    pooled[(long)b * d + i] = 0.f;
+    return;
+  }
+  const float* x = feats + ((long)slot * T) * d + i;
   const unsigned char* km = key_mask != nullptr ? key_mask + b * T : nullptr;
   float a = avg ? 0.f : -INFINITY;
   int n = 0;
@@ -243,6 +251,16 @@ extern "C" int deer_head_pool(const float* feats, float* pooled, int T, int d, i
   if (T <= 0 || d <= 0 || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(head_pool_kernel, dim3((d + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), feats, pooled, T, d,
                      avg, B, key_mask, ctl, kind, layer, static_cast<const float*>(nullptr));
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// deer_head_pool on the hidden state of a layer whose rows are packed by the row map `cmap` (env batch with compaction)
+extern "C" int deer_head_pool_active(const float* feats, float* pooled, int T, int d, int avg, int B, const unsigned char* key_mask,
+                                     const int* ctl, int kind, int layer, const int* cmap, void* stream) {
+  if (T <= 0 || d <= 0 || B <= 0 || B > HB_MAX || cmap == nullptr) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(head_pool_kernel, dim3((d + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), feats, pooled, T, d,
+                     avg, B, key_mask, ctl, kind, layer, static_cast<const float*>(nullptr), cmap);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
@@ -765,8 +783,16 @@ extern "C" int deer_head_final(const float* src, int src_stride, int in_dim, int
 // ---- per-step control-block reset (start of every control step) ----------------------------------------
 // step_info: device int32[4] written by the host before the step: {hold (1 iff cur_step % steps_per_stage != 0), step sequence
 // number, host mirror pointer lo, hi (0 = no mirror)}.
-__global__ void ctl_begin_step_kernel(int* ctl0, const int* hold_src, int B) {
+__global__ void ctl_begin_step_kernel(int* ctl0, const int* hold_src, int B, int* cmap) {
   const int b = blockIdx.x;
+  if (cmap != nullptr && b == 0 && threadIdx.x < 2) {      // both copies of the row map start as the identity: every environment active
+    int* cm = cmap + threadIdx.x * CMAP_WORDS;
+    cm[CMAP_N] = B;
+    for (int e = 0; e < HB_MAX; ++e) {
+      cm[CMAP_SLOT_ENV + e] = e;
+      cm[CMAP_ENV_SLOT + e] = e < B ? e : -1;
+    }
+  }
   int* ctl = ctl0 + b * CTL_WORDS;
   if (threadIdx.x == 0) {
     ctl[CTL_EXIT_FLAG] = 0;
@@ -793,7 +819,15 @@ __global__ void ctl_begin_step_kernel(int* ctl0, const int* hold_src, int B) {
 
 extern "C" int deer_ctl_begin_step(int* ctl, const int* hold_src, int B, void* stream) {
   if (ctl == nullptr || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
-  hipLaunchKernelGGL(ctl_begin_step_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ctl, hold_src, B);
+  hipLaunchKernelGGL(ctl_begin_step_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ctl, hold_src, B, static_cast<int*>(nullptr));
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// the same, also resetting the two copies of the row map (2 x CMAP_WORDS int32) of an env batch with compaction to the identity
+extern "C" int deer_ctl_begin_step_map(int* ctl, const int* hold_src, int B, int* cmap, void* stream) {
+  if (ctl == nullptr || B <= 0 || B > HB_MAX || cmap == nullptr) return DEER_ERR_SHAPE;
+  hipLaunchKernelGGL(ctl_begin_step_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ctl, hold_src, B, cmap);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

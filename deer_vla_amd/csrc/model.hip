@@ -175,6 +175,7 @@ struct deer_model {
   std::vector<VisionWS> chains;
   size_t img, vis_x, vis_x_f32, kv_all, ids, key_mask, text_time, x, xn, ao, slab_a, slab_b, qkv_ws, hidden, h_state, c_state, h_tmp,
       c_tmp, h_shadow, c_shadow, pooled, ctl, step_info, thresholds, action_dbg;
+  size_t x2, cmap;                  // env batch with compaction of exited environments: second residual-stream buffer, two row maps (common.h CMAP_*)
   size_t ln_stats;                  // one-environment trunk (csrc/trunk_r16.hip): q/k LayerNorm moments per 32-column group
   size_t xn_hl, ao_hl, h_hl;        // bf16 hi / lo planes of the trunk activations (env batches > kHlMinRows rows: deer_gemm_skinny_hl)
   long hl_plane_d, hl_plane_h;      // elements per plane: rows * d, rows * max_n
@@ -185,6 +186,7 @@ struct deer_model {
   // controller
   std::vector<int> exit_ids;
   int ctl_max_layer = 0, thr_type = 0, leq = 1;
+  bool compact = true;              // env batches: compaction of exited environments (DEER_COMPACT=0 / deer_model_set_compaction)
   // per-call overrides of the coarse operators
   const void* img_override = nullptr;
   const float* tokens_override = nullptr;
@@ -541,6 +543,8 @@ void build_workspace(deer_model* m) {
   m->xn_hl = m->wl.add((size_t)2 * m->hl_plane_d * 2);
   m->ao_hl = m->wl.add((size_t)2 * m->hl_plane_d * 2);
   m->h_hl = m->wl.add((size_t)2 * m->hl_plane_h * 2);
+  m->x2 = m->wl.add((size_t)T * d * 4);
+  m->cmap = named(m, "cmap", (size_t)2 * CMAP_WORDS * 4);
   m->ln_stats = m->wl.add((size_t)(3 * d / 32 + 1) * 16 * 2 * 4);
   m->hidden = named(m, "hidden", (size_t)c.n_layers * T * d * 4);
   const size_t st = (size_t)m->Lh * B * m->H * 4;
@@ -855,6 +859,31 @@ int skinny(deer_model* m, const void* Wp, long N, long K, int R, float* out_slab
   return DEER_OK;
 }
 
+// ---- env batch with COMPACTION of exited environments ("compact active rows after each exit layer") --------------------
+// The reference stops every environment at its own layer (mosaic_gpt_3b.py:438-443, one environment per process).  In an env batch the
+// rows of an environment that has exited leave the trunk: two layers after an exit check (the check of layer e runs beside layer e + 1;
+// its verdict is complete before layer e + 2 starts: the step driver waits for it) the first row operation of layer e + 2 GATHERS the
+// surviving environments' rows to the front of the other residual-stream buffer and publishes the new row map; every later kernel of the
+// layer works on the active slots only (the trunk GEMM runs the body compiled for that many row tiles).  Per-environment results are
+// bit-identical to the uncompacted batch: no arithmetic depends on a row's position.  DEER_COMPACT=0 disables it.
+struct RowCtx {
+  float* x = nullptr;             // residual stream of this layer
+  const int* cmap = nullptr;      // row map of this layer (nullptr: no compaction - all rows, identity)
+  const float* x_in = nullptr;    // gather source (first row operation of a compaction layer), else nullptr
+  const int* cmap_old = nullptr;
+  int T = 0;
+};
+
+bool block_hl(const deer_model* m, int R);
+bool compact_on(const deer_model* m) { return m->compact && m->B > 1 && !m->c.precision; }
+// ... on the hi/lo-plane path of BOTH halves of a layer (every K a multiple of 64)
+bool compact_active(const deer_model* m, int R) { return compact_on(m) && block_hl(m, R) && ((((long)m->c.xattn_ff_mult * m->d) & 63) == 0); }
+
+struct PlanRow { int need_pseudo, is_exit, slot; };
+std::vector<PlanRow> dynamic_plan(const deer_model* m);
+bool is_compaction_layer(const deer_model* m, int layer);
+int cmap_parity(const deer_model* m, int layer);
+
 bool use_hl(const deer_model* m, int R) { return !m->c.precision && R > hl_min_rows(); }
 
 // the MPT block of a layer runs on the hi/lo-plane kernels (every K of its four projections is d or mlp_ratio*d)
@@ -866,36 +895,48 @@ int trunk_splitk(const deer_model* m, int R, long N, long K) {
 
 // env-batch form: activation as bf16 hi / lo planes
 int skinny_hl(deer_model* m, const void* Wp, long N, long K, int R, float* out_slab, size_t out_elems, const bf16_t* hi, const bf16_t* lo, int lda,
-              const int* ctl, void* st, int* S_out, long* stride_out) {
+              const int* ctl, void* st, int* S_out, long* stride_out, const RowCtx* rc = nullptr) {
   const int S = deer_skinny_hl_splitk(R, (int)N, (int)K);
   const int mpad = 16 * ((R + 15) / 16);
   if ((size_t)S * mpad * N > out_elems) return DEER_ERR_SHAPE;
   *S_out = S;
   *stride_out = (long)mpad * N;
   Bracket b(m, "deer_gemm_skinny_hl", 2.0 * R * N * K, 2.0 * N * K, st);    // algorithmic bytes = the bf16 weights, once
+  if (rc != nullptr && rc->cmap != nullptr)
+    return deer_gemm_skinny_hl_active(hi, lo, lda, Wp, out_slab, R, (int)N, (int)K, S, mpad, ctl, rc->cmap, rc->T, st);
   if (R > 128) return deer_gemm_skinny_hl_rows(hi, lo, lda, Wp, out_slab, R, (int)N, (int)K, S, mpad, ctl, st);
   return deer_gemm_skinny_hl(hi, lo, lda, Wp, out_slab, R, (int)N, (int)K, S, ctl, st);
 }
 
 // GELU(sum of the up-projection's slabs) -> hi / lo planes [R][C] (the activation of the down-projection)
-int gelu_split(deer_model* m, const float* slab, int S, long stride, int R, long C, const int* ctl, void* st) {
+int gelu_split(deer_model* m, const float* slab, int S, long stride, int R, long C, const int* ctl, void* st, const RowCtx* rc = nullptr) {
   Bracket b(m, "deer_slab_gelu_split", 0, 4.0 * S * R * C + 4.0 * R * C, st);
   bf16_t* h = m->Wk<bf16_t>(m->h_hl);
+  if (rc != nullptr && rc->cmap != nullptr)
+    return deer_slab_gelu_split_active(slab, S, stride, 1, h, h + m->hl_plane_h, R, (int)C, ctl, rc->cmap, rc->T, st);
   return deer_slab_gelu_split(slab, S, stride, 1, h, h + m->hl_plane_h, R, (int)C, ctl, st);
 }
 
 // resadd with the LayerNorm output as hi / lo planes in xn_hl (rows x d)
-int resadd_split(deer_model* m, int R, const Pending* p, const float* gamma, const float* beta, float* x_copy, const int* ctl, void* st) {
+int resadd_split(deer_model* m, int R, const Pending* p, const float* gamma, const float* beta, float* x_copy, const int* ctl, void* st,
+                 const RowCtx* rc = nullptr) {
   Bracket b(m, "deer_resadd_ln", 0, 4.0 * R * m->d * ((p ? p->S : 0) + 3), st);
   bf16_t* h = m->Wk<bf16_t>(m->xn_hl);
-  return deer_resadd_ln_split(m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma, beta, h,
-                              h + m->hl_plane_d, nullptr, x_copy, R, m->d, kEps, ctl, st);
+  if (rc != nullptr && rc->cmap != nullptr)
+    return deer_resadd_ln_rows(rc->x, p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, gamma, beta, h, h + m->hl_plane_d,
+                               nullptr, x_copy, R, m->d, kEps, ctl, rc->cmap, rc->T, rc->x_in, rc->cmap_old, m->B, st);
+  return deer_resadd_ln_split(rc ? rc->x : m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma,
+                              beta, h, h + m->hl_plane_d, nullptr, x_copy, R, m->d, kEps, ctl, st);
 }
 
-int resadd(deer_model* m, int R, const Pending* p, const float* gamma, const float* beta, float* x_copy, const int* ctl, void* st) {
+int resadd(deer_model* m, int R, const Pending* p, const float* gamma, const float* beta, float* x_copy, const int* ctl, void* st,
+           const RowCtx* rc = nullptr) {
   Bracket b(m, "deer_resadd_ln", 0, 4.0 * R * m->d * ((p ? p->S : 0) + 3), st);
-  return deer_resadd_ln(m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma, beta, nullptr,
-                        gamma ? m->Wk<float>(m->xn) : nullptr, x_copy, R, m->d, kEps, ctl, st);
+  if (rc != nullptr && rc->cmap != nullptr)
+    return deer_resadd_ln_rows(rc->x, p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, gamma, beta, nullptr, nullptr,
+                               gamma ? m->Wk<float>(m->xn) : nullptr, x_copy, R, m->d, kEps, ctl, rc->cmap, rc->T, rc->x_in, rc->cmap_old, m->B, st);
+  return deer_resadd_ln(rc ? rc->x : m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma, beta,
+                        nullptr, gamma ? m->Wk<float>(m->xn) : nullptr, x_copy, R, m->d, kEps, ctl, st);
 }
 
 // the residual branch a layer leaves un-applied when it is not finalized: the down-projection slabs (shape-determined)
@@ -1011,6 +1052,29 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
   const bf16_t* xh = m->Wk<bf16_t>(m->xn_hl);
   const bf16_t* hh = m->Wk<bf16_t>(m->h_hl);
   bf16_t* aoh = m->Wk<bf16_t>(m->ao_hl);
+  // env batch with compaction of exited environments (hi/lo-plane path, dynamic steps): this layer's residual-stream buffer and row map;
+  // the first row operation of a compaction layer gathers the surviving rows from the previous layer's buffer / map
+  RowCtx rcx, *rc = nullptr;
+  bool gather = false;
+  if (use_ctl && compact_active(m, R)) {
+    int* maps = m->Wk<int>(m->cmap);
+    const int par = cmap_parity(m, i);
+    rcx.x = par ? m->Wk<float>(m->x2) : m->Wk<float>(m->x);
+    rcx.cmap = maps + par * CMAP_WORDS;
+    rcx.T = T;
+    rc = &rcx;
+    gather = is_compaction_layer(m, i);
+  }
+  auto first_row_op = [&](RowCtx& first) {                  // the context of the layer's first row operation
+    first = rcx;
+    if (gather) {
+      const int parp = cmap_parity(m, i - 1);
+      first.x_in = parp ? m->Wk<float>(m->x2) : m->Wk<float>(m->x);
+      first.cmap_old = m->Wk<int>(m->cmap) + parp * CMAP_WORDS;
+    }
+  };
+  RowCtx rfirst;
+  if (rc != nullptr) first_row_op(rfirst);
   Pending pend{}, *pp = nullptr;
   // a layer that was not finalized leaves its last residual branch to this layer's first row op, which then ALSO writes the
   // completed x out as hidden_states[i-1] (no extra launch): every hidden state up to the exit layer is real
@@ -1024,7 +1088,7 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
   long stride;
   if (L.has_xa) {
     const XattnW& X = L.xa;
-    DEER_TRY(resadd(m, R, pp, m->A<float>(X.nw), m->A<float>(X.nb), prev_hidden, ctl, st));
+    DEER_TRY(resadd(m, R, pp, m->A<float>(X.nw), m->A<float>(X.nb), prev_hidden, ctl, st, rc ? &rfirst : nullptr));
     prev_hidden = nullptr;
     static const bool fused = [] { const char* e = getenv("DEER_XATTN_FUSED"); return e == nullptr || e[0] != '0'; }();
     const int n_media = 2 * m->nl;
@@ -1043,8 +1107,12 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
       const int mpad = 16 * ((R + 15) / 16);
       if ((size_t)c.xattn_heads * mpad * d > m->slab_a_elems) return DEER_ERR_SHAPE;
       Bracket b(m, "deer_xattn_fused", 2.0 * R * d * xin * 2, 2.0 * 2 * xin * d, st);
-      DEER_TRY(deer_xattn_fused(xn, d, m->A<void>(X.wq), kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, n_media, m->A<void>(X.wo),
-                                slab_a, (long)mpad * d, T, c.xattn_heads, B, 1.0f / sqrtf((float)c.xattn_dim_head), ctl, st));
+      if (rc != nullptr)
+        DEER_TRY(deer_xattn_fused_active(xn, d, m->A<void>(X.wq), kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, n_media, m->A<void>(X.wo),
+                                         slab_a, (long)mpad * d, T, c.xattn_heads, B, 1.0f / sqrtf((float)c.xattn_dim_head), ctl, rc->cmap, st));
+      else
+        DEER_TRY(deer_xattn_fused(xn, d, m->A<void>(X.wq), kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, n_media, m->A<void>(X.wo),
+                                  slab_a, (long)mpad * d, T, c.xattn_heads, B, 1.0f / sqrtf((float)c.xattn_dim_head), ctl, st));
       S = c.xattn_heads;
       stride = (long)mpad * d;
     } else {
@@ -1059,10 +1127,10 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
     pend = Pending{slab_a, S, stride, m->A<float>(X.ag)};
     const long xff = (long)c.xattn_ff_mult * d;
     if (hl && (xff & 63) == 0) {
-      DEER_TRY(resadd_split(m, R, &pend, m->A<float>(X.fnw), m->A<float>(X.fnb), nullptr, ctl, st));
-      DEER_TRY(skinny_hl(m, m->A<void>(X.w1), xff, d, R, slab_b, m->slab_b_elems, xh, xh + m->hl_plane_d, d, ctl, st, &S, &stride));
-      DEER_TRY(gelu_split(m, slab_b, S, stride, R, xff, ctl, st));
-      DEER_TRY(skinny_hl(m, m->A<void>(X.w2), d, xff, R, slab_a, m->slab_a_elems, hh, hh + m->hl_plane_h, (int)xff, ctl, st, &S, &stride));
+      DEER_TRY(resadd_split(m, R, &pend, m->A<float>(X.fnw), m->A<float>(X.fnb), nullptr, ctl, st, rc));
+      DEER_TRY(skinny_hl(m, m->A<void>(X.w1), xff, d, R, slab_b, m->slab_b_elems, xh, xh + m->hl_plane_d, d, ctl, st, &S, &stride, rc));
+      DEER_TRY(gelu_split(m, slab_b, S, stride, R, xff, ctl, st, rc));
+      DEER_TRY(skinny_hl(m, m->A<void>(X.w2), d, xff, R, slab_a, m->slab_a_elems, hh, hh + m->hl_plane_h, (int)xff, ctl, st, &S, &stride, rc));
     } else {
       DEER_TRY(resadd(m, R, &pend, m->A<float>(X.fnw), m->A<float>(X.fnb), nullptr, ctl, st));
       DEER_TRY(skinny(m, m->A<void>(X.w1), xff, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
@@ -1076,19 +1144,24 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
   const unsigned char* km = m->mask_override ? m->mask_override : m->Wk<unsigned char>(m->key_mask);
   const long ffw = (long)c.mlp_ratio * d;
   if (hl) {
-    DEER_TRY(resadd_split(m, R, pp, m->A<float>(L.ln1w), ln1b, prev_hidden, ctl, st));
-    DEER_TRY(skinny_hl(m, m->A<void>(L.wqkv), 3L * d, d, R, slab_b, m->slab_b_elems, xh, xh + m->hl_plane_d, d, ctl, st, &S, &stride));
+    // (without an x-attn in this layer the ln_1 row operation is the layer's first one: it does the gathering)
+    DEER_TRY(resadd_split(m, R, pp, m->A<float>(L.ln1w), ln1b, prev_hidden, ctl, st, rc ? (L.has_xa ? rc : &rfirst) : nullptr));
+    DEER_TRY(skinny_hl(m, m->A<void>(L.wqkv), 3L * d, d, R, slab_b, m->slab_b_elems, xh, xh + m->hl_plane_d, d, ctl, st, &S, &stride, rc));
     {
       Bracket b(m, "deer_mpt_attn_small", 0, 0, st);
-      DEER_TRY(deer_mpt_attn_small_hl(slab_b, S, stride, d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
-                                      (float)c.alibi_bias_max, m->Wk<float>(m->qkv_ws), aoh, aoh + m->hl_plane_d, d, T, B, ctl, st));
+      if (rc != nullptr)
+        DEER_TRY(deer_mpt_attn_small_hl_active(slab_b, S, stride, d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
+                                               (float)c.alibi_bias_max, m->Wk<float>(m->qkv_ws), aoh, aoh + m->hl_plane_d, d, T, B, ctl, rc->cmap, st));
+      else
+        DEER_TRY(deer_mpt_attn_small_hl(slab_b, S, stride, d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
+                                        (float)c.alibi_bias_max, m->Wk<float>(m->qkv_ws), aoh, aoh + m->hl_plane_d, d, T, B, ctl, st));
     }
-    DEER_TRY(skinny_hl(m, m->A<void>(L.wo), d, d, R, slab_a, m->slab_a_elems, aoh, aoh + m->hl_plane_d, d, ctl, st, &S, &stride));
+    DEER_TRY(skinny_hl(m, m->A<void>(L.wo), d, d, R, slab_a, m->slab_a_elems, aoh, aoh + m->hl_plane_d, d, ctl, st, &S, &stride, rc));
     pend = Pending{slab_a, S, stride, nullptr};
-    DEER_TRY(resadd_split(m, R, &pend, m->A<float>(L.ln2w), ln2b, nullptr, ctl, st));
-    DEER_TRY(skinny_hl(m, m->A<void>(L.wup), ffw, d, R, slab_b, m->slab_b_elems, xh, xh + m->hl_plane_d, d, ctl, st, &S, &stride));
-    DEER_TRY(gelu_split(m, slab_b, S, stride, R, ffw, ctl, st));
-    DEER_TRY(skinny_hl(m, m->A<void>(L.wdown), d, ffw, R, slab_a, m->slab_a_elems, hh, hh + m->hl_plane_h, (int)ffw, ctl, st, &S, &stride));
+    DEER_TRY(resadd_split(m, R, &pend, m->A<float>(L.ln2w), ln2b, nullptr, ctl, st, rc));
+    DEER_TRY(skinny_hl(m, m->A<void>(L.wup), ffw, d, R, slab_b, m->slab_b_elems, xh, xh + m->hl_plane_d, d, ctl, st, &S, &stride, rc));
+    DEER_TRY(gelu_split(m, slab_b, S, stride, R, ffw, ctl, st, rc));
+    DEER_TRY(skinny_hl(m, m->A<void>(L.wdown), d, ffw, R, slab_a, m->slab_a_elems, hh, hh + m->hl_plane_h, (int)ffw, ctl, st, &S, &stride, rc));
   } else {
     DEER_TRY(resadd(m, R, pp, m->A<float>(L.ln1w), ln1b, prev_hidden, ctl, st));
     DEER_TRY(skinny(m, m->A<void>(L.wqkv), 3L * d, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
@@ -1106,7 +1179,7 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
   if (finalize) {   // hidden_states[i] = output of layer i (mosaic_gpt_3b.py:424-427)
     pend = Pending{slab_a, S, stride, nullptr};
     const size_t rows_cap = std::min(B * c.max_text_len, kMaxRows);
-    DEER_TRY(resadd(m, R, &pend, nullptr, nullptr, m->Wk<float>(m->hidden) + (size_t)i * rows_cap * d, ctl, st));
+    DEER_TRY(resadd(m, R, &pend, nullptr, nullptr, m->Wk<float>(m->hidden) + (size_t)i * rows_cap * d, ctl, st, rc));
   }
   return DEER_OK;
 }
@@ -1120,12 +1193,16 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
   const int H = m->H, d = m->d, B = m->B;
   const int* ctl = use_ctl ? m->Wk<int>(m->ctl) : nullptr;
   const size_t rows_cap = std::min(B * c.max_text_len, kMaxRows);
+  const bool feats_default = feats == nullptr;
   if (feats == nullptr) feats = m->Wk<float>(m->hidden) + (size_t)layer * rows_cap * d;     // [B*T, d]: env b owns rows b*T .. b*T+T-1
   const unsigned char* km = use_mask ? (m->mask_override ? m->mask_override : m->Wk<unsigned char>(m->key_mask)) : nullptr;
   float* pooled = m->Wk<float>(m->pooled);
   {
     Bracket b(m, "deer_head_pool", 0, 0, st);
+    // env batch with compaction: hidden_states[layer] is packed by that layer's row map
+    const bool cm = use_ctl && feats_default && compact_active(m, B * T);
     if (c.use_state) DEER_TRY(deer_head_pool_state(feats, pooled, T, d, c.pooling_avg, B, km, m->Wk<float>(m->state_emb), ctl, kind, layer, st));
+    else if (cm) DEER_TRY(deer_head_pool_active(feats, pooled, T, d, c.pooling_avg, B, km, ctl, kind, layer, m->Wk<int>(m->cmap) + cmap_parity(m, layer) * CMAP_WORDS, st));
     else DEER_TRY(deer_head_pool(feats, pooled, T, d, c.pooling_avg, B, km, ctl, kind, layer, st));
   }
   float* h_tmp = m->Wk<float>(m->h_tmp);
@@ -1174,8 +1251,6 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
                          m->Wk<float>(m->action_dbg), kEps, c.precision, st);
 }
 
-struct PlanRow { int need_pseudo, is_exit, slot; };
-
 // per layer of the dynamic step: (need_pseudo, is_exit, exit slot) - mosaic_gpt_3b.py:397-443, value_net.py:122-125
 std::vector<PlanRow> dynamic_plan(const deer_model* m) {
   std::vector<PlanRow> plan;
@@ -1189,6 +1264,20 @@ std::vector<PlanRow> dynamic_plan(const deer_model* m) {
     if (i >= m->ctl_max_layer) break;
   }
   return plan;
+}
+
+// compaction layers of the dynamic step: two layers after every exit check (its verdict is complete before that layer starts)
+bool is_compaction_layer(const deer_model* m, int layer) {
+  if (layer < 2) return false;
+  const std::vector<PlanRow> plan = dynamic_plan(m);
+  return layer < (int)plan.size() && plan[layer - 2].is_exit != 0;
+}
+
+int cmap_parity(const deer_model* m, int layer) {
+  const std::vector<PlanRow> plan = dynamic_plan(m);
+  int n = 0;
+  for (int l = 2; l <= layer && l < (int)plan.size(); ++l) n += plan[l - 2].is_exit ? 1 : 0;
+  return n & 1;
 }
 
 int embed(deer_model* m, int T, void* st) {
@@ -1284,7 +1373,14 @@ int deer_model_create(const deer_config* cfg, deer_model** out) {
   for (int i = c.exit_interval - 1; i < c.n_layers - 1; i += c.exit_interval) m->exit_ids.push_back(i);
   m->exit_ids.push_back(c.n_layers - 1);
   m->ctl_max_layer = m->exit_ids.back();
+  if (const char* e = getenv("DEER_COMPACT")) m->compact = e[0] != '0';
   *out = m;
+  return DEER_OK;
+}
+
+int deer_model_set_compaction(deer_model* m, int on) {
+  if (m == nullptr) return DEER_ERR_SHAPE;
+  m->compact = on != 0;          // takes effect for pieces enqueued / captured from now on
   return DEER_OK;
 }
 
@@ -1430,6 +1526,7 @@ int deer_dynamic_plan(const deer_model* m, int* need_pseudo, int* is_exit, int* 
 int deer_begin_step(deer_model* m, const int* step_info, void* stream) {
   if (m->ws == nullptr) return DEER_ERR_SHAPE;
   Bracket b(m, "deer_ctl_begin_step", 0, 0, stream);
+  if (compact_on(m)) return deer_ctl_begin_step_map(m->Wk<int>(m->ctl), step_info ? step_info : m->Wk<int>(m->step_info), m->B, m->Wk<int>(m->cmap), stream);
   return deer_ctl_begin_step(m->Wk<int>(m->ctl), step_info ? step_info : m->Wk<int>(m->step_info), m->B, stream);
 }
 

@@ -97,17 +97,72 @@ extern "C" int deer_layernorm_rows_multi(const float* x, long in_rstride, long i
 // ---- LLM row op: x += scale * sum_s slab[s] ; [copy x] ; [LN(x) -> bf16] ------------------------------
 // The consumer-side half of the skinny GEMM's split-K (launch-boundary reduce) fused with the gated
 // residual update (helpers.py:267-279: x + tanh(gate) * y; MPT block: x + y) and the following LayerNorm.
+// Env batches with compaction (common.h: CMAP_*): `rows_per_env` > 0 and `cmap` = the row map of this layer -> rows beyond the active
+// slots return at once.  GATHER (x_in != NULL): this launch is the first row operation of a compaction layer - workgroup r' owns
+// DESTINATION row r' of the new packing: the surviving slots of the old map `cmap_old` (environments whose EXIT_FLAG is still 0) are
+// counted in slot order, row r' reads x_in / the slabs at its SOURCE row, and x (a different buffer than x_in) receives the packed rows;
+// workgroup 0 publishes the new map into `cmap` (which the later kernels of the layer read).
+struct deer_rowmap {
+  const int* cmap;          // map of this layer (gather mode: WRITTEN by workgroup 0)
+  int rows_per_env;         // T (0 = no map)
+  const float* x_in;        // gather source (NULL = in place)
+  const int* cmap_old;      // map the source rows are packed by
+  const int* ctl0;          // control blocks (EXIT_FLAG per environment)
+  int B;
+};
+
 __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, const float* __restrict__ slab, int s_in,
                                                         long slab_stride, const float* __restrict__ gate,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         bf16_t* __restrict__ out_bf, float* __restrict__ out_f32,
                                                         float* __restrict__ x_copy, int d, float eps, const int* ctl,
-                                                        const float* __restrict__ bias, bf16_t* __restrict__ out_lo, int packed = 0) {
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out_lo, int packed = 0,
+                                                        deer_rowmap rm = deer_rowmap{nullptr, 0, nullptr, nullptr, nullptr, 0}) {
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ float red[16];
+  __shared__ int s_src;
   const int r = blockIdx.x;
+  int rs = r;                                              // source row (== r unless gathering)
+  if (rm.rows_per_env > 0) {
+    const int T = rm.rows_per_env;
+    if (rm.x_in != nullptr) {
+      if (threadIdx.x == 0) {
+        const int slot = r / T, t = r - slot * T;
+        const int n_old = rm.cmap_old[CMAP_N];
+        int kept = 0, src = -1;
+        for (int s = 0; s < n_old; ++s) {
+          const int e = rm.cmap_old[CMAP_SLOT_ENV + s];
+          if (((const volatile int*)rm.ctl0)[e * CTL_WORDS + CTL_EXIT_FLAG] != 0) continue;
+          if (kept == slot) src = s * T + t;
+          if (r == 0) {                                    // workgroup 0 publishes the new map
+            int* cm = const_cast<int*>(rm.cmap);
+            cm[CMAP_SLOT_ENV + kept] = e;
+            cm[CMAP_ENV_SLOT + e] = kept;
+          }
+          ++kept;
+        }
+        if (r == 0) {
+          int* cm = const_cast<int*>(rm.cmap);
+          cm[CMAP_N] = kept;
+          for (int s = 0; s < n_old; ++s) {
+            const int e = rm.cmap_old[CMAP_SLOT_ENV + s];
+            if (((const volatile int*)rm.ctl0)[e * CTL_WORDS + CTL_EXIT_FLAG] != 0) cm[CMAP_ENV_SLOT + e] = -1;
+          }
+          for (int e = 0; e < rm.B; ++e)
+            if (rm.cmap_old[CMAP_ENV_SLOT + e] < 0) cm[CMAP_ENV_SLOT + e] = -1;
+        }
+        s_src = src;
+      }
+      __syncthreads();
+      rs = s_src;
+      if (rs < 0) return;                                  // beyond the surviving slots
+    } else if (rm.cmap != nullptr && r >= rm.cmap[CMAP_N] * T) {
+      return;
+    }
+  }
   const int n4 = d >> 2;
   float* xr = x + (long)r * d;
+  const float* xs = (rm.x_in != nullptr ? rm.x_in : x) + (long)rs * d;
   float4 v[4];                                            // d <= 4096: the row stays in registers
   const float sc = (slab != nullptr && gate != nullptr) ? tanhf(*gate) : 1.f;
 #pragma unroll
@@ -117,17 +172,17 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
     if (i4 < n4) {
       float4 a = float4{0.f, 0.f, 0.f, 0.f};
       if (slab != nullptr) {
-        a = slab_sum4(slab + (long)r * d + (long)i4 * 4, s_in, slab_stride);
+        a = slab_sum4(slab + (long)rs * d + (long)i4 * 4, s_in, slab_stride);
         if (bias != nullptr) {
           const float4 t = *reinterpret_cast<const float4*>(bias + (long)i4 * 4);
           a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
         }
       }
-      float4 xv = *reinterpret_cast<const float4*>(xr + (long)i4 * 4);
+      float4 xv = *reinterpret_cast<const float4*>(xs + (long)i4 * 4);
       xv.x += sc * a.x; xv.y += sc * a.y; xv.z += sc * a.z; xv.w += sc * a.w;
       v[j] = xv;
-      if (slab != nullptr) *reinterpret_cast<float4*>(xr + (long)i4 * 4) = xv;
-      if (x_copy != nullptr) *reinterpret_cast<float4*>(x_copy + (long)r * d + (long)i4 * 4) = xv;
+      if (slab != nullptr || rm.x_in != nullptr) *reinterpret_cast<float4*>(xr + (long)i4 * 4) = xv;
+      if (x_copy != nullptr) *reinterpret_cast<float4*>(x_copy + (long)rs * d + (long)i4 * 4) = xv;
     }
   }
   if (gamma == nullptr) return;
@@ -194,6 +249,22 @@ extern "C" int deer_resadd_ln_split(float* x, const float* slab, int s_in, long 
     return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(resadd_ln_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
                      gamma, beta, reinterpret_cast<bf16_t*>(out_hi), out_f32, x_copy, d, eps, ctl, bias, reinterpret_cast<bf16_t*>(out_lo));
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// Env batches with compaction of exited environments: deer_resadd_ln / deer_resadd_ln_split (out_lo != NULL) restricted to the active slots
+// of `cmap` (rows_per_env rows per slot); x_in != NULL: the gathering first row operation of a compaction layer (see deer_rowmap above)
+extern "C" int deer_resadd_ln_rows(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* gamma, const float* beta,
+                                   void* out_bf16, void* out_lo, float* out_f32, float* x_copy, int T_rows, int d, float eps, const int* ctl,
+                                   const int* cmap, int rows_per_env, const float* x_in, const int* cmap_old, int B, void* stream) {
+  if (T_rows <= 0 || d <= 0 || (d & 3) || d > 4096 || (slab != nullptr && s_in <= 0) || (gamma != nullptr && out_bf16 == nullptr && out_f32 == nullptr) ||
+      cmap == nullptr || rows_per_env <= 0 || ctl == nullptr || B <= 0 || B > 8 || (x_in != nullptr && (cmap_old == nullptr || x_in == x)))
+    return DEER_ERR_SHAPE;
+  deer_rowmap rm{cmap, rows_per_env, x_in, cmap_old, ctl, B};
+  hipLaunchKernelGGL(resadd_ln_kernel, dim3(T_rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
+                     gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl, static_cast<const float*>(nullptr),
+                     reinterpret_cast<bf16_t*>(out_lo), 0, rm);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

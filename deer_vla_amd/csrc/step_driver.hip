@@ -24,7 +24,7 @@ struct deer_step_plan {
   std::vector<hipGraphExec_t> chain_head, chain_tail, main_g, head_g;   // head_g[i] == nullptr: no head evaluation after piece i
   std::vector<int> exits;                                             // piece index of exit check k
   hipEvent_t ev_in = nullptr;
-  std::vector<hipEvent_t> ev_join, ev_head;
+  std::vector<hipEvent_t> ev_join, ev_head, ev_head_done;
   int* step_info = nullptr;                                           // pinned: {hold, seq, mirror ptr lo, hi} read by ctl_begin_step
   int* mirror = nullptr;                                              // pinned: [0] progress, [1] done, then one ctl block per env
 };
@@ -62,9 +62,12 @@ extern "C" int deer_step_plan_create(int n_chains, void* const* chain_head, void
   bool ok = hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming) == hipSuccess;
   p->ev_join.resize(n_chains, nullptr);
   p->ev_head.resize(n_pieces, nullptr);
+  p->ev_head_done.resize(n_pieces, nullptr);
   for (int c = 1; c < n_chains && ok; ++c) ok = hipEventCreateWithFlags(&p->ev_join[c], hipEventDisableTiming) == hipSuccess;
   for (int i = 0; i < n_pieces && ok; ++i)
-    if (p->head_g[i] != nullptr) ok = hipEventCreateWithFlags(&p->ev_head[i], hipEventDisableTiming) == hipSuccess;
+    if (p->head_g[i] != nullptr)
+      ok = hipEventCreateWithFlags(&p->ev_head[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&p->ev_head_done[i], hipEventDisableTiming) == hipSuccess;
   if (!ok) { deer_step_plan_destroy(p); return DEER_ERR_LAUNCH; }
   *out = p;
   return DEER_OK;
@@ -75,6 +78,7 @@ extern "C" void deer_step_plan_destroy(deer_step_plan* p) {
   if (p->ev_in) (void)hipEventDestroy(p->ev_in);
   for (hipEvent_t e : p->ev_join) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->ev_head) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->ev_head_done) if (e) (void)hipEventDestroy(e);
   delete p;
 }
 
@@ -142,6 +146,10 @@ extern "C" int deer_step_plan_run(deer_step_plan* p, int hold, int seq, void* ma
       if (done) break;
     }
     if (done) break;
+    // env batches with compaction (csrc/model.hip): piece i gathers the rows of the environments still active after the exit check of
+    // layer i - 2.  With the default look-ahead the host has already SEEN that verdict (poll above); the stream dependency makes it
+    // hold for every look-ahead
+    if (p->n_envs > 1 && hs != ms && i >= 2 && p->ev_head_done[i - 2] != nullptr) SD_HIP(hipStreamWaitEvent(ms, p->ev_head_done[i - 2], 0));
     SD_HIP(hipGraphLaunch(p->main_g[i], ms));
     ++launched;
     if (p->head_g[i] != nullptr) {
@@ -150,6 +158,7 @@ extern "C" int deer_step_plan_run(deer_step_plan* p, int hold, int seq, void* ma
         SD_HIP(hipStreamWaitEvent(hs, p->ev_head[i], 0));
       }
       SD_HIP(hipGraphLaunch(p->head_g[i], hs));
+      if (p->n_envs > 1 && hs != ms) SD_HIP(hipEventRecord(p->ev_head_done[i], hs));
     }
   }
   if (!done) {

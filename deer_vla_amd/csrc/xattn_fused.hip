@@ -28,8 +28,11 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
                                                                 const int* __restrict__ text_time, int n_per_media, int n_kv,
                                                                 const bf16_t* __restrict__ Wo_p, float* __restrict__ out, long slab_stride,
                                                                 int T, int heads, int NS, float scale, const int* ctl,
-                                                                const bf16_t* __restrict__ xlo = nullptr) {
+                                                                const bf16_t* __restrict__ xlo = nullptr, const int* __restrict__ cmap = nullptr) {
   DEER_RETURN_IF_EXITED(ctl);
+  // compaction: blockIdx.y is a SLOT of the row map - activation / output rows by slot, media K/V and text_time by its environment
+  if (cmap != nullptr && (int)blockIdx.y >= cmap[CMAP_N]) return;
+  const int env = cmap != nullptr ? cmap[CMAP_SLOT_ENV + blockIdx.y] : (int)blockIdx.y;
   static_assert(!PACKED || MT == 1, "packed planes hold one 16-row tile");
   constexpr int MPAD = MT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
   const int c = lane & 15, g = lane >> 4;
   const int h = blockIdx.x / NS, cs = blockIdx.x - h * NS, b = blockIdx.y;
   const float* xb = xn + (long)b * T * d;
-  const bf16_t* kvb = kv + (long)b * n_kv * ldkv + h * XF_HD;
+  const bf16_t* kvb = kv + (long)env * n_kv * ldkv + h * XF_HD;
   const int ktiles = d >> 5;
 
   // ---- requests that do not depend on anything computed here: this wave's Wo fragments, the K/V tile of (env, head) ----
@@ -77,12 +80,15 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[t4][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const u32x4* wq = reinterpret_cast<const u32x4*>(Wq_p) + ((long)(4 * h) * ktiles) * 64 + lane;
-  for (int kt0 = wave; kt0 < ktiles; kt0 += 4 * XF_NW) {
-    u32x4 w[4][4];
-    float4 a[4][MT][2];
-    bf16x8 ph[4], pl[4];
+  // k-tiles per round: the packed form (one environment: the launch is a latency chain) keeps 8 k-tiles = 32 weight fragments + 16
+  // activation fragments of the wave in flight - d = 2048 in ONE round trip instead of two
+  constexpr int XU = PACKED ? 8 : 4;
+  for (int kt0 = wave; kt0 < ktiles; kt0 += XU * XF_NW) {
+    u32x4 w[XU][4];
+    float4 a[PACKED ? 1 : 4][MT][2];
+    bf16x8 ph[XU], pl[XU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {                               // 16 weight fragments + the activation pieces in flight
+    for (int u = 0; u < XU; ++u) {                              // the weight fragments + the activation pieces in flight
       const int kt = min(kt0 + u * XF_NW, ktiles - 1);
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4) w[u][t4] = __builtin_nontemporal_load(wq + ((long)t4 * ktiles + kt) * 64);
@@ -95,13 +101,13 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
       for (int j = 0; j < MT; ++j) {
         const int row = j * 16 + c;
         const float* p = xb + (long)min(row, T - 1) * d + kt * 32 + g * 8;
-        a[u][j][0] = *reinterpret_cast<const float4*>(p);
-        a[u][j][1] = *reinterpret_cast<const float4*>(p + 4);
-        if (row >= T) a[u][j][0] = a[u][j][1] = float4{0.f, 0.f, 0.f, 0.f};
+        a[PACKED ? 0 : u][j][0] = *reinterpret_cast<const float4*>(p);
+        a[PACKED ? 0 : u][j][1] = *reinterpret_cast<const float4*>(p + 4);
+        if (row >= T) a[PACKED ? 0 : u][j][0] = a[PACKED ? 0 : u][j][1] = float4{0.f, 0.f, 0.f, 0.f};
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < XU; ++u) {
       if (kt0 + u * XF_NW < ktiles) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
             }
             continue;
           }
-          const float4 x0 = a[u][j][0], x1 = a[u][j][1];
+          const float4 x0 = a[PACKED ? 0 : u][j][0], x1 = a[PACKED ? 0 : u][j][1];
           const uint32_t h0 = pack2bf(x0.x, x0.y), h1 = pack2bf(x0.z, x0.w), h2 = pack2bf(x1.x, x1.y), h3 = pack2bf(x1.z, x1.w);
           const uint4 hi = uint4{h0, h1, h2, h3};
           const uint4 lo = uint4{pack2bf(x0.x - __uint_as_float(h0 << 16), x0.y - __uint_as_float(h0 & 0xffff0000u)),
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
     bf16x8 qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qs + (q0 + c) * XF_KP + ks * 32 + g * 8);
-    const int tt_q = (q0 + c < T) ? text_time[b * T + q0 + c] : 1;
+    const int tt_q = (q0 + c < T) ? text_time[env * T + q0 + c] : 1;
     const int klo = (tt_q - 1) * n_per_media, khi = tt_q * n_per_media;
     constexpr int NT = XF_MAXKV / 16;
     f32x4 s[NT];
@@ -268,12 +274,20 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
 // [heads][slab_stride] with slab_stride >= batch*T*d - slab h holds head h's contribution to all rows.  T <= 32, n_kv <= 128.
 static int launch_xattn_fused(const float* xn, const void* x_lo_packed, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
                               int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch, float scale,
-                              const int* ctl, void* stream);
+                              const int* ctl, void* stream, const int* cmap = nullptr);
 
 extern "C" int deer_xattn_fused(const float* xn, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
                                 int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch,
                                 float scale, const int* ctl, void* stream) {
   return launch_xattn_fused(xn, nullptr, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T, heads, batch, scale, ctl, stream);
+}
+
+// deer_xattn_fused for an env batch with compaction: grid rows are SLOTS of `cmap`
+extern "C" int deer_xattn_fused_active(const float* xn, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
+                                       int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch,
+                                       float scale, const int* ctl, const int* cmap, void* stream) {
+  if (cmap == nullptr) return DEER_ERR_SHAPE;
+  return launch_xattn_fused(xn, nullptr, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T, heads, batch, scale, ctl, stream, cmap);
 }
 
 // the same for ONE environment of <= 16 rows with LN(x) as bf16 hi / lo planes in MFMA-fragment order (deer_resadd_ln_packed)
@@ -287,7 +301,7 @@ extern "C" int deer_xattn_fused_packed(const void* x_hi, const void* x_lo, int d
 
 static int launch_xattn_fused(const float* xn, const void* x_lo_packed, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
                               int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch, float scale,
-                              const int* ctl, void* stream) {
+                              const int* ctl, void* stream, const int* cmap) {
   if (xn == nullptr || Wq_p == nullptr || kv == nullptr || Wo_p == nullptr || out == nullptr || text_time == nullptr) return DEER_ERR_SHAPE;
   if (T <= 0 || T > 32 || n_kv <= 0 || n_kv > XF_MAXKV || heads <= 0 || inner != heads * XF_HD || (d & 127) || (ldkv & 7) || batch <= 0 ||
       n_per_media <= 0 || slab_stride < (long)batch * T * d)
@@ -315,7 +329,7 @@ static int launch_xattn_fused(const float* xn, const void* x_lo_packed, int d, c
     hipLaunchKernelGGL(kern, grid, dim3(64 * XF_NW), smem, st, xn, d, reinterpret_cast<const bf16_t*>(Wq_p),                   \
                        reinterpret_cast<const bf16_t*>(kv), ldkv, inner, text_time, n_per_media, n_kv,                          \
                        reinterpret_cast<const bf16_t*>(Wo_p), out, slab_stride, T, heads, NS, scale, ctl,                        \
-                       reinterpret_cast<const bf16_t*>(x_lo_packed));                                                           \
+                       reinterpret_cast<const bf16_t*>(x_lo_packed), cmap);                                                     \
   } while (0)
   if (x_lo_packed != nullptr) DEER_XF_LAUNCH(1, true);
   else if (mt == 1) DEER_XF_LAUNCH(1, false);

@@ -297,6 +297,14 @@ class DeerEngine:
                              f"reachable layer {min(self._max_layer_arg - 1, self.exit_ids[-1])} must be one of the exits (otherwise no "
                              "exit check is ever forced; the reference raises KeyError on thresholds[i] there)")
 
+    def set_compaction(self, on: bool):
+        """Env batches: compaction of the rows of exited environments in the trunk (csrc/model.hip; on by default, DEER_COMPACT=0 turns it
+        off at construction).  Per-environment results are bit-identical either way (tests/test_batch_parity.py)."""
+        abi.check(self.lib.deer_model_set_compaction(self._h, 1 if on else 0), "deer_model_set_compaction")
+        if self._graphs:
+            torch.cuda.synchronize(self.dev)
+        self._drop_graphs()
+
     def configure_exit(self, exit_ids: Sequence[int], max_layer: int, steps_per_stage: int = 1):
         """``ExitController.__init__`` (value_net.py:164-173): max_layer = min(max_layer-1, last exit)."""
         old = (self.exit_ids, self._max_layer_arg)
@@ -691,6 +699,8 @@ class DeerEngine:
                 fork(side, cap)
                 self._enqueue_media_kv()
                 for i, need_pseudo, is_exit, _ in plan:
+                    if self.B > 1 and i >= 2 and plan[i - 2][2]:
+                        fork(side, cap)                           # compaction layer: needs the verdict of the exit check of layer i - 2
                     self.enqueue_dynamic_main(T, use_mask, i)
                     if need_pseudo or is_exit:
                         fork(cap, side)
@@ -757,7 +767,7 @@ class DeerEngine:
             self.hold_dev.copy_(self.step_info_pinned, non_blocking=True)
             self._enqueue_step(T, use_mask, None)                 # eager warm-up of the whole step - a real step
             main_st.synchronize()
-            P = {"main": [], "head": {}, "ev": {}}
+            P = {"main": [], "head": {}, "ev": {}, "ev_done": {}}
             self._vision_chain_graphs()
             for i, need_pseudo, is_exit, _ in plan:
                 g = torch.cuda.CUDAGraph()
@@ -772,6 +782,7 @@ class DeerEngine:
                         self.enqueue_dynamic_heads(T, i, use_mask=use_mask)
                     P["head"][i] = gh
                     P["ev"][i] = torch.cuda.Event()
+                    P["ev_done"][i] = torch.cuda.Event()
             P["native"] = self._make_step_plan(P, plan)
             self._graphs[key] = P
             self.ctl_host.copy_(self.ctl, non_blocking=True)     # first call: verdict through the ordinary read-back
@@ -824,6 +835,8 @@ class DeerEngine:
                     break
             if done:
                 break
+            if self.B > 1 and side is not main_st and i >= 2 and (i - 2) in P["ev_done"]:
+                main_st.wait_event(P["ev_done"][i - 2])           # compaction layer: the verdict of check i - 2 is complete (see csrc/step_driver.hip)
             P["main"][i].replay()
             if self._trace is not None:
                 self._trace.append(("main%d" % i, self._mark(main_st), time.perf_counter()))
@@ -836,6 +849,8 @@ class DeerEngine:
                     side.wait_event(hev)
                     with torch.cuda.stream(side):
                         P["head"][i].replay()
+                    if self.B > 1:
+                        P["ev_done"][i].record(side)
                 if self._trace is not None:
                     self._trace.append(("head%d" % i, self._mark(side), time.perf_counter()))
         if not done:

@@ -204,6 +204,28 @@ int deer_xattn_fused_packed(const void* x_hi, const void* x_lo, int d, const voi
                             int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, float scale,
                             const int* ctl, void* stream);
 
+/* ---- env batch with COMPACTION of exited environments (the reference stops every environment at its own layer,
+ * mosaic_gpt_3b.py:438-443): the rows of the still-active environments stay packed at the front of the trunk's buffers.  Row map `cmap`
+ * (int32, CMAP_WORDS = 32 per copy): [0] = active slots, [1 + s] = environment of slot s, [9 + e] = slot of environment e or -1.  The
+ * *_active / *_rows entry points are the kernels above restricted to the active slots (rows_per_env rows each); per-environment inputs
+ * (media K/V, text_time, key mask, control blocks) stay in environment order and are reached through the map. ---- */
+int deer_resadd_ln_rows(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* gamma, const float* beta, void* out_bf16,
+                        void* out_lo, float* out_f32, float* x_copy, int T_rows, int d, float eps, const int* ctl, const int* cmap, int rows_per_env,
+                        const float* x_in, const int* cmap_old, int B, void* stream);   /* x_in != NULL: gather the surviving rows (first row op of a compaction layer), publish the new map into cmap */
+int deer_gemm_skinny_hl_active(const void* A_hi, const void* A_lo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk, int slab_rows,
+                               const int* ctl, const int* cmap, int rows_per_env, void* stream);
+int deer_slab_gelu_split_active(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows, int C, const int* ctl,
+                                const int* cmap, int rows_per_env, void* stream);
+int deer_mpt_attn_small_hl_active(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w, const float* k_ln_w,
+                                  float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws, void* out_hi, void* out_lo, int ldo, int T,
+                                  int batch, const int* ctl, const int* cmap, void* stream);
+int deer_xattn_fused_active(const float* xn, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time, int n_per_media, int n_kv,
+                            const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch, float scale, const int* ctl, const int* cmap,
+                            void* stream);
+int deer_head_pool_active(const float* feats, float* pooled, int T, int d, int avg, int B, const unsigned char* key_mask, const int* ctl, int kind,
+                          int layer, const int* cmap, void* stream);
+int deer_ctl_begin_step_map(int* ctl, const int* step_info, int B, int* cmap, void* stream);   /* deer_ctl_begin_step + both map copies := identity */
+
 /* (deer_head_*: w_is_f32 = 1 when the weight pointers are f32 - the fp32 arithmetic keeps the head's weights in f32) */
 
 /* ---- fp32-activation arithmetic (csrc/precise.hip; deer_config.precision = 1): the second arithmetic of the path, for

@@ -76,6 +76,10 @@ int deer_model_buffer(const deer_model* m, int which, const char* name, long* of
 
 /* ---- exit controller configuration (ExitController.__init__ / _set_threshold_value, value_net.py:164-183) ------- */
 /* host only.  max_layer as given to the reference's controller (the controller uses min(max_layer - 1, last exit)). */
+/* Env batches (n_envs > 1): compaction of the rows of exited environments in the trunk (csrc/model.hip).  On by default
+ * (DEER_COMPACT=0 at creation turns it off); changing it affects what is enqueued / captured afterwards.  Results per environment are
+ * bit-identical either way. */
+int deer_model_set_compaction(deer_model* m, int on);
 int deer_model_configure_exit(deer_model* m, const int* exit_ids, int n_exit, int max_layer, int thr_type, int leq);
 int deer_model_real_num_exit(const deer_model* m);
 

@@ -176,3 +176,29 @@ def test_full_size_env_batch_padded_to_32_tokens_matches_the_unpadded_batch(setu
             assert outs[0][e]["exit_layer"] == outs[1][e]["exit_layer"], (exit_id, e)
             assert float((outs[0][e]["pose"] - outs[1][e]["pose"]).abs().max()) < 1e-4, (exit_id, e)
             assert abs(outs[0][e]["gripper"] - outs[1][e]["gripper"]) < 1e-4
+
+
+def test_full_size_compaction_is_bit_identical_to_the_uncompacted_batch(setup):
+    """SURVEY 8(f).4 at 3B size: the 8-environment dynamic episode above runs WITH compaction of exited environments (the default); the
+    same episode on a sibling engine with compaction off must give bit-identical exit layers, actions and LSTM states."""
+    z, cfg, eng, B = setup
+    off = DeerEngine(cfg, None, n_envs=B, weights_from=eng)
+    off.set_compaction(False)
+    thr = [float(t) for t in z["thr"]]
+    for e_ in (eng, off):
+        e_.configure_exit(cfg.exit_ids(), int(z["max_layer"]), 1)
+        e_.set_thresholds(thr)
+        e_.reset()
+    layers = set()
+    ids_keep = None
+    for s in range(10):
+        rgb, grip, ids = batch_inputs(cfg, B, s, eng.dev)
+        ids_keep = ids if ids_keep is None else ids_keep
+        ra = eng.step(rgb, grip, ids_keep, None)
+        rb = off.step(rgb, grip, ids_keep, None)
+        for e in range(B):
+            assert ra[e]["exit_layer"] == rb[e]["exit_layer"] and torch.equal(ra[e]["pose"], rb[e]["pose"]) and ra[e]["gripper"] == rb[e]["gripper"], (s, e)
+            layers.add(ra[e]["exit_layer"])
+        torch.cuda.synchronize()
+        assert torch.equal(eng.h_state, off.h_state) and torch.equal(eng.c_state, off.c_state)
+    assert len(layers) > 2, layers

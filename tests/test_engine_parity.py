@@ -599,3 +599,48 @@ def test_window_mode_calibration_full_size_batched_vs_oracle(max_layer):
     vref = vn(feats, mode="generate", rand_layer_feat=torch.stack([ref[t, rl[t]] for t in range(W)]))
     assert vals.shape == vref.shape == (len(exit_ids), W - W // 2)
     assert float((vals - vref).abs().max()) < 5e-3, (vals, vref)
+
+
+@pytest.mark.parametrize("B,lens,use_graph", [(8, None, True), (8, None, False), (3, [14, 9, 11], True), (8, [32, 14, 20, 9, 27, 16, 31, 11], True), (2, None, True)])
+def test_compaction_of_exited_environments_is_bit_identical_to_the_uncompacted_batch(B, lens, use_graph):
+    """SURVEY 8(f).4 / VERDICT r3 item 3a: in an env batch the rows of an environment that has exited leave the trunk two layers after its
+    exit check (gathering first row operation + row map, csrc/model.hip).  No arithmetic depends on a row's position, so every
+    environment's exit layer, action, deltas and LSTM state must be BIT-identical to the same engine with compaction switched off -
+    over an episode in which the environments leave at different layers (thresholds spread so that every exit is used), with mixed
+    instruction lengths (padding masks follow the environment, not the slot), 256 trunk rows (two row blocks), graph pieces and eager
+    single-stream enqueueing."""
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
+    n_steps = 10
+    lens = lens or [11] * B
+    eng_on = DeerEngine(cfg, sd, n_envs=B)
+    eng_off = DeerEngine(cfg, None, n_envs=B, weights_from=eng_on)
+    eng_off.set_compaction(False)
+    env_inputs = [[syn.synthetic_step_inputs(cfg, s, rank=e, text_len=lens[e], text_seed=7 + e) for s in range(n_steps)] for e in range(B)]
+    thr, _ = probe_thresholds(cfg, sd, env_inputs[0], 12, 1)
+    T = max(lens)
+    ids = torch.full((B, T), 1, dtype=torch.long)
+    mask = torch.zeros(B, T, dtype=torch.bool)
+    for e in range(B):
+        ids[e, :lens[e]] = env_inputs[e][0][2].reshape(-1)
+        mask[e, :lens[e]] = True
+    ids, mask = ids.cuda(), mask.cuda()
+    seen = set()
+    for eng in (eng_on, eng_off):
+        eng.configure_exit(cfg.exit_ids(), 12, 1)
+        eng.set_thresholds(thr)
+        eng.reset()
+    for s in range(n_steps):
+        rgb = torch.stack([env_inputs[e][s][0] for e in range(B)]).cuda().bfloat16()
+        grip = torch.stack([env_inputs[e][s][1] for e in range(B)]).cuda().bfloat16()
+        ra = eng_on.step(rgb, grip, ids, mask if len(set(lens)) > 1 else None, use_graph=use_graph)
+        rb = eng_off.step(rgb, grip, ids, mask if len(set(lens)) > 1 else None, use_graph=use_graph)
+        for e in range(B):
+            assert ra[e]["exit_layer"] == rb[e]["exit_layer"], (s, e)
+            assert torch.equal(ra[e]["pose"], rb[e]["pose"]) and ra[e]["gripper"] == rb[e]["gripper"], (s, e)
+            da, db = ra[e]["deltas"], rb[e]["deltas"]
+            assert torch.equal(torch.nan_to_num(da, nan=-1.0), torch.nan_to_num(db, nan=-1.0)), (s, e)
+            seen.add(ra[e]["exit_layer"])
+        torch.cuda.synchronize()
+        assert torch.equal(eng_on.h_state, eng_off.h_state) and torch.equal(eng_on.c_state, eng_off.c_state), s
+    assert len(seen) > 1, seen                                    # environments really left at different layers
