@@ -104,6 +104,14 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 __device__ __forceinline__ float4 slab_sum4(const float* __restrict__ p, int s_in, long stride) {
   float4 a = float4{0.f, 0.f, 0.f, 0.f};
   int s = 0;
+  if (s_in == 16) {                                        // the down-projections' 16 slabs: all in flight together (summed in slab order)
+    float4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)u * stride);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    return a;
+  }
   for (; s + 8 <= s_in; s += 8) {
     float4 v[8];
 #pragma unroll

@@ -111,7 +111,10 @@ struct deer_rowmap {
   int B;
 };
 
-__global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, const float* __restrict__ slab, int s_in,
+// NT threads per row: 256, or 512 for the one-environment trunk (<= 16 rows: the launch is a latency chain - with 512 threads a thread
+// owns ONE float4 column of a 2048-wide row and all of its slab loads are in flight together, one L2 round trip instead of four)
+template <int NT>
+__global__ __launch_bounds__(NT) void resadd_ln_kernel(float* __restrict__ x, const float* __restrict__ slab, int s_in,
                                                         long slab_stride, const float* __restrict__ gate,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         bf16_t* __restrict__ out_bf, float* __restrict__ out_f32,
@@ -163,11 +166,12 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
   const int n4 = d >> 2;
   float* xr = x + (long)r * d;
   const float* xs = (rm.x_in != nullptr ? rm.x_in : x) + (long)rs * d;
-  float4 v[4];                                            // d <= 4096: the row stays in registers
+  constexpr int NV = 1024 / NT;                           // float4 per thread: d <= 4096
+  float4 v[NV];                                           // the row stays in registers
   const float sc = (slab != nullptr && gate != nullptr) ? tanhf(*gate) : 1.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int i4 = threadIdx.x + j * 256;
+  for (int j = 0; j < NV; ++j) {
+    const int i4 = threadIdx.x + j * NT;
     v[j] = float4{0.f, 0.f, 0.f, 0.f};
     if (i4 < n4) {
       float4 a = float4{0.f, 0.f, 0.f, 0.f};
@@ -188,19 +192,19 @@ __global__ __launch_bounds__(256) void resadd_ln_kernel(float* __restrict__ x, c
   if (gamma == nullptr) return;
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) s += v[j].x + v[j].y + v[j].z + v[j].w;
+  for (int j = 0; j < NV; ++j) s += v[j].x + v[j].y + v[j].z + v[j].w;
   const float mean = block_sum(s, red) / d;
   float var = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (threadIdx.x + j * 256 < n4) {
+  for (int j = 0; j < NV; ++j)
+    if (threadIdx.x + j * NT < n4) {
       const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, e = v[j].w - mean;
       var += a * a + b * b + c * c + e * e;
     }
   const float rstd = rsqrtf(block_sum(var, red) / d + eps);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int i4 = threadIdx.x + j * 256;
+  for (int j = 0; j < NV; ++j) {
+    const int i4 = threadIdx.x + j * NT;
     if (i4 < n4) {
       const float4 g = *reinterpret_cast<const float4*>(gamma + (long)i4 * 4);
       float4 y;
@@ -233,7 +237,7 @@ extern "C" int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_s
   if (T <= 0 || d <= 0 || (d & 3) || d > 4096 || (slab != nullptr && s_in <= 0) ||
       (gamma != nullptr && out_bf16 == nullptr && out_f32 == nullptr))
     return DEER_ERR_SHAPE;
-  hipLaunchKernelGGL(resadd_ln_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in,
+  hipLaunchKernelGGL(resadd_ln_kernel<256>, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in,
                      slab_stride, gate, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl, bias,
                      static_cast<bf16_t*>(nullptr));
   DEER_LAUNCH_CHECK();
@@ -247,7 +251,7 @@ extern "C" int deer_resadd_ln_split(float* x, const float* slab, int s_in, long 
                                     int T, int d, float eps, const int* ctl, void* stream) {
   if (T <= 0 || d <= 0 || (d & 3) || d > 4096 || (slab != nullptr && s_in <= 0) || gamma == nullptr || out_hi == nullptr || out_lo == nullptr)
     return DEER_ERR_SHAPE;
-  hipLaunchKernelGGL(resadd_ln_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
+  hipLaunchKernelGGL(resadd_ln_kernel<256>, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
                      gamma, beta, reinterpret_cast<bf16_t*>(out_hi), out_f32, x_copy, d, eps, ctl, bias, reinterpret_cast<bf16_t*>(out_lo));
   DEER_LAUNCH_CHECK();
   return DEER_OK;
@@ -262,7 +266,7 @@ extern "C" int deer_resadd_ln_rows(float* x, const float* slab, int s_in, long s
       cmap == nullptr || rows_per_env <= 0 || ctl == nullptr || B <= 0 || B > 8 || (x_in != nullptr && (cmap_old == nullptr || x_in == x)))
     return DEER_ERR_SHAPE;
   deer_rowmap rm{cmap, rows_per_env, x_in, cmap_old, ctl, B};
-  hipLaunchKernelGGL(resadd_ln_kernel, dim3(T_rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
+  hipLaunchKernelGGL(resadd_ln_kernel<256>, dim3(T_rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
                      gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl, static_cast<const float*>(nullptr),
                      reinterpret_cast<bf16_t*>(out_lo), 0, rm);
   DEER_LAUNCH_CHECK();
@@ -275,7 +279,7 @@ extern "C" int deer_resadd_ln_packed(float* x, const float* slab, int s_in, long
                                      int T, int d, float eps, const int* ctl, void* stream) {
   if (T <= 0 || T > 16 || d <= 0 || (d & 31) || d > 4096 || (slab != nullptr && s_in <= 0) || gamma == nullptr || out_hi == nullptr || out_lo == nullptr)
     return DEER_ERR_SHAPE;
-  hipLaunchKernelGGL(resadd_ln_kernel, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
+  hipLaunchKernelGGL(resadd_ln_kernel<512>, dim3(T), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
                      gamma, beta, reinterpret_cast<bf16_t*>(out_hi), out_f32, x_copy, d, eps, ctl, bias, reinterpret_cast<bf16_t*>(out_lo), 1);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
