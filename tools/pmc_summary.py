@@ -10,7 +10,8 @@ import sys
 from collections import defaultdict
 
 
-CLASS_OF = (("gemm_tiled", "deer_gemm_bf16_nt"), ("gemm_ring", "deer_gemm_bf16_nt"), ("gemm_skinny_hl", "deer_gemm_skinny_hl"),
+CLASS_OF = (("trunk_wide_gemm", "deer_trunk_wide_gemm"), ("trunk_mpt_attn", "deer_trunk_mpt_attn"), ("xattn_fused", "deer_xattn_fused"),
+            ("gemm_tiled", "deer_gemm_bf16_nt"), ("gemm_frame", "deer_gemm_bf16_nt"), ("gemm_ring", "deer_gemm_bf16_nt"), ("gemm_skinny_hl", "deer_gemm_skinny_hl"),
             ("gemm_skinny", "deer_gemm_skinny"), ("slab_gelu_split", "deer_slab_gelu_split"), ("attn_mfma_kernel<false>", "deer_attn_mfma_hd64"),
             ("attn_mfma_kernel<true>", "deer_xattn_mfma"), ("resadd_ln", "deer_resadd_ln"), ("ln_rows", "deer_layernorm_rows"),
             ("head_lstm", "deer_head_lstm_layer"))
