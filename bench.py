@@ -823,6 +823,8 @@ def main():
                            "avg_exit_layer": round(sum(e + 1 for e in sched) / len(sched), 3),
                            "note": "static exit_id per step at the stratified target mix; two-chain vision + one trunk graph per exit "
                                    "id, no exit checks, host reads the action after every step"}
+    if os.environ.get("DEER_PERSISTENT_LAYER") == "1":     # N1 experiment: never the default; say so on the line
+        out["experiment"] = {"persistent_layer": True, "barrier_error_word": eng.persistent_layer_error(), "first_timeout": eng.persistent_layer_error_detail()}
     if rank == 0 and world == 1 and B == 1 and args.surface_steps > 0 and args.precision == "bf16":
         try:                                               # auxiliary single-rank leg: its failure must not cost the bench line
             out["surface"] = surface_leg(cfg, eng, res["thr"], res["frames"], res["ids"], args.surface_steps)

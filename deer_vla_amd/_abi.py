@@ -47,6 +47,7 @@ SIGNATURES = {
     "deer_xattn_fused_active": [P, I, P, P, I, I, P, I, I, P, P, L, I, I, I, F, P, P, P],
     "deer_head_pool_active": [P, P, I, I, I, I, P, P, I, I, P, P],
     "deer_ctl_begin_step_map": [P, P, I, P, P],
+    "deer_trunk_layer_persistent": [P, P],
     "deer_layernorm_rows": [P, L, L, I, I, P, P, P, P, L, L, I, F, P],
     "deer_layernorm_rows_multi": [P, L, L, I, I, P, P, I, L, P, L, L, L, I, F, P],
     "deer_resadd_ln": [P, P, I, L, P, P, P, P, P, P, P, I, I, F, P, P],
@@ -86,6 +87,7 @@ SIGNATURES = {
     "deer_model_configure_exit": [P, P, I, I, I, I],
     "deer_model_real_num_exit": [P],
     "deer_model_set_compaction": [P, I],
+    "deer_model_set_persistent_layer": [P, I],
     "deer_vit_l14_encode": [P, P, I, P, P],
     "deer_perceiver_resample": [P, P, I, P, P, P],
     "deer_llm_early_exit": [P, P, P, I, P, I, I, P, P, P],

@@ -190,7 +190,7 @@ __device__ __forceinline__ void sk_wait_vmcnt() {
 template <int MT, int D>
 __device__ __forceinline__ void gemm_skinny_hl_body(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo, int lda,
                                                     const bf16_t* __restrict__ Wp, float* __restrict__ part, int M, int N, int K, int KR,
-                                                    int part_rows) {
+                                                    int part_rows, int bx, int by) {
   constexpr int MTL = (MT + 1) & ~1;                  // row tiles LOADED per plane (even: every wave issues the same number of DMAs)
   constexpr int MPAD = MT * 16;
   constexpr int A_CH = 4 * MTL;                       // 1 KiB chunks (8 rows x 128 B) of [hi plane ; lo plane] per stage
@@ -203,10 +203,10 @@ __device__ __forceinline__ void gemm_skinny_hl_body(const bf16_t* __restrict__ A
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int ks = blockIdx.y, k_begin = ks * KR;
+  const int ks = by, k_begin = ks * KR;
   const int nk = KR >> 6;                             // stages of 64 K-columns
   const int ktiles = K >> 5;
-  const int tile_raw = blockIdx.x * 8 + wave;
+  const int tile_raw = bx * 8 + wave;
   const bool tile_ok = tile_raw * 16 < N;
 
   // per-wave DMA sources: chunk q = wave + i*8
@@ -223,7 +223,7 @@ __device__ __forceinline__ void gemm_skinny_hl_body(const bf16_t* __restrict__ A
       kstep[i] = 64;
     } else {
       const int w = q - A_CH, ct = w >> 1, kt = w & 1;
-      const int t16 = blockIdx.x * 8 + ct;
+      const int t16 = bx * 8 + ct;
       const int tile = (t16 * 16 < N) ? t16 : 0;      // ragged N: stream tile 0, never stored
       src[i] = Wp + (((long)tile * ktiles + (k_begin >> 5) + kt) * 64 + lane) * 8;
       kstep[i] = 2 * 64 * 8;
@@ -280,9 +280,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_hl_kernel(const bf16_t* __res
                                                             const bf16_t* __restrict__ Wp, float* __restrict__ part, int M, int N,
                                                             int K, int KR, const int* ctl, int part_rows) {
   DEER_RETURN_IF_EXITED(ctl);
-  gemm_skinny_hl_body<MT, D>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows);
+  gemm_skinny_hl_body<MT, D>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y);
 }
 
+#ifndef DEER_BODIES_ONLY
 // Env batch with COMPACTION of exited environments (common.h: CMAP_*): the number of valid rows is read from the device - the active
 // slots x rows_per_env, minus the rows of earlier row blocks - and the workgroup runs the body specialised for that many MFMA row tiles
 // (its own ring depth, DMA counts and waits: exactly the kernel a launch with that M would have run).  A launch costs what its ACTIVE rows
@@ -295,14 +296,14 @@ __global__ __launch_bounds__(512) void gemm_skinny_hl_dyn_kernel(const bf16_t* _
   const int M = min(M_max, cmap[CMAP_N] * rows_per_env - row0);
   if (M <= 0) return;
   switch ((M + 15) >> 4) {
-    case 1: gemm_skinny_hl_body<1, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
-    case 2: gemm_skinny_hl_body<2, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
-    case 3: gemm_skinny_hl_body<3, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
-    case 4: gemm_skinny_hl_body<4, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
-    case 5: gemm_skinny_hl_body<5, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
-    case 6: gemm_skinny_hl_body<6, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
-    case 7: gemm_skinny_hl_body<7, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
-    default: gemm_skinny_hl_body<8, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows); break;
+    case 1: gemm_skinny_hl_body<1, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    case 2: gemm_skinny_hl_body<2, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    case 3: gemm_skinny_hl_body<3, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    case 4: gemm_skinny_hl_body<4, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    case 5: gemm_skinny_hl_body<5, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    case 6: gemm_skinny_hl_body<6, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    case 7: gemm_skinny_hl_body<7, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    default: gemm_skinny_hl_body<8, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
   }
 }
 
@@ -538,3 +539,4 @@ extern "C" int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int 
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
+#endif  // DEER_BODIES_ONLY

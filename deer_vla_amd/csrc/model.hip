@@ -176,6 +176,7 @@ struct deer_model {
   size_t img, vis_x, vis_x_f32, kv_all, ids, key_mask, text_time, x, xn, ao, slab_a, slab_b, qkv_ws, hidden, h_state, c_state, h_tmp,
       c_tmp, h_shadow, c_shadow, pooled, ctl, step_info, thresholds, action_dbg;
   size_t x2, cmap;                  // env batch with compaction of exited environments: second residual-stream buffer, two row maps (common.h CMAP_*)
+  size_t pl_state;                  // csrc/persistent_layer.hip (DEER_PERSISTENT_LAYER=1): 192 barrier words, then the error word
   size_t ln_stats;                  // one-environment trunk (csrc/trunk_r16.hip): q/k LayerNorm moments per 32-column group
   size_t xn_hl, ao_hl, h_hl;        // bf16 hi / lo planes of the trunk activations (env batches > kHlMinRows rows: deer_gemm_skinny_hl)
   long hl_plane_d, hl_plane_h;      // elements per plane: rows * d, rows * max_n
@@ -186,6 +187,7 @@ struct deer_model {
   // controller
   std::vector<int> exit_ids;
   int ctl_max_layer = 0, thr_type = 0, leq = 1;
+  bool persistent_layer = false;    // N1 experiment: one launch per trunk layer (DEER_PERSISTENT_LAYER=1 / deer_model_set_persistent_layer)
   bool compact = true;              // env batches: compaction of exited environments (DEER_COMPACT=0 / deer_model_set_compaction)
   // per-call overrides of the coarse operators
   const void* img_override = nullptr;
@@ -545,6 +547,7 @@ void build_workspace(deer_model* m) {
   m->h_hl = m->wl.add((size_t)2 * m->hl_plane_h * 2);
   m->x2 = m->wl.add((size_t)T * d * 4);
   m->cmap = named(m, "cmap", (size_t)2 * CMAP_WORDS * 4);
+  m->pl_state = named(m, "pl_state", (size_t)(16 * 12 + 16 + 64 * 64) * 4);     // persistent-layer experiment: barrier words + error word
   m->ln_stats = m->wl.add((size_t)(3 * d / 32 + 1) * 16 * 2 * 4);
   m->hidden = named(m, "hidden", (size_t)c.n_layers * T * d * 4);
   const size_t st = (size_t)m->Lh * B * m->H * 4;
@@ -993,6 +996,31 @@ int llm_layer_r16(deer_model* m, int i, int T, bool use_mask, bool pending_in, b
   }
   int S;
   long stride;
+  // N1 experiment (csrc/persistent_layer.hip): the whole layer as ONE persistent launch - same device functions, same order, bit-identical
+  // results, SLOWER; never the default (a persistent launch needs all of its workgroups resident: one engine per GPU)
+  if (m->persistent_layer && L.has_xa && c.xattn_ff_mult == 4 && c.mlp_ratio == 4) {
+    const XattnW& X = L.xa;
+    deer_trunk_layer_args a{};
+    a.T = T; a.d = d; a.xinner = xin; a.heads = c.xattn_heads; a.n_heads = c.n_heads; a.ffw = (int)ffw; a.n_kv = 2 * m->nl; a.n_per_media = 2 * m->nl;
+    a.ld_kv = m->n_xattn * 2 * xin; a.NS = ((d >> 4) + 31) / 32; a.pending_s = pending_in ? pend.S : 0; a.qk_ln = c.attn_qk_ln ? 1 : 0;
+    a.s_w2 = deer_skinny_hl_splitk(T, d, (int)ffw); a.s_wo = deer_skinny_hl_splitk(T, d, d); a.s_down = a.s_w2;
+    if (pending_in && (pend.S != a.s_down || pend.stride != 16L * d)) return DEER_ERR_SHAPE;
+    a.eps = kEps; a.xattn_scale = 1.0f / sqrtf((float)c.xattn_dim_head); a.alibi_bias_max = (float)c.alibi_bias_max;
+    a.x = m->Wk<float>(m->x); a.slab_a = slab_a; a.qkv = qkv; a.stats = m->Wk<float>(m->ln_stats); a.prev_hidden = prev_hidden;
+    a.hidden_out = finalize ? m->Wk<float>(m->hidden) + (size_t)i * rows_cap * d : nullptr;
+    a.xn_hi = const_cast<bf16_t*>(xh); a.xn_lo = const_cast<bf16_t*>(xh) + m->hl_plane_d; a.h_hi = hh; a.h_lo = hl; a.ao_hi = aoh; a.ao_lo = aol;
+    a.kv = m->Wk<char>(m->kv_all) + (size_t)X.kv_index * 2 * xin * 2; a.text_time = m->Wk<int>(m->text_time);
+    a.key_mask = use_mask ? (m->mask_override ? m->mask_override : m->Wk<unsigned char>(m->key_mask)) : nullptr;
+    a.x_nw = m->A<float>(X.nw); a.x_nb = m->A<float>(X.nb); a.x_ag = m->A<float>(X.ag); a.x_fnw = m->A<float>(X.fnw); a.x_fnb = m->A<float>(X.fnb);
+    a.x_fg = m->A<float>(X.fg); a.ln1w = m->A<float>(L.ln1w); a.ln1b = m->loaded(L.ln1b_name) ? m->A<float>(L.ln1b) : nullptr;
+    a.ln2w = m->A<float>(L.ln2w); a.ln2b = m->loaded(L.ln2b_name) ? m->A<float>(L.ln2b) : nullptr; a.qlnw = m->A<float>(L.qlnw); a.klnw = m->A<float>(L.klnw);
+    a.x_wq = m->A<void>(X.wq); a.x_wo = m->A<void>(X.wo); a.x_w1 = m->A<void>(X.w1); a.x_w2 = m->A<void>(X.w2);
+    a.wqkv = m->A<void>(L.wqkv); a.wo = m->A<void>(L.wo); a.wup = m->A<void>(L.wup); a.wdown = m->A<void>(L.wdown);
+    a.barrier = m->Wk<unsigned>(m->pl_state); a.error = m->Wk<int>(m->pl_state) + 16 * 12;
+    a.trace = i < 64 ? a.error + 16 + 64 * i : nullptr;   // per layer: who arrived last at every barrier, and when (tools/persistent_layer_check.py)
+    Bracket b(m, "deer_trunk_layer_persistent", 2.0 * T * (2.0 * d * xin + 8.0 * d * d + 12.0 * d * d), 2.0 * (2.0 * d * xin + 20.0 * d * d), st);
+    return deer_trunk_layer_persistent(&a, st);
+  }
   if (L.has_xa) {   // gated x-attn (helpers.py:260-279)
     const XattnW& X = L.xa;
     DEER_TRY(resadd_packed(m, T, pp, m->A<float>(X.nw), m->A<float>(X.nb), prev_hidden, ctl, st));
@@ -1374,7 +1402,14 @@ int deer_model_create(const deer_config* cfg, deer_model** out) {
   m->exit_ids.push_back(c.n_layers - 1);
   m->ctl_max_layer = m->exit_ids.back();
   if (const char* e = getenv("DEER_COMPACT")) m->compact = e[0] != '0';
+  if (const char* e = getenv("DEER_PERSISTENT_LAYER")) m->persistent_layer = e[0] == '1';
   *out = m;
+  return DEER_OK;
+}
+
+int deer_model_set_persistent_layer(deer_model* m, int on) {
+  if (m == nullptr) return DEER_ERR_SHAPE;
+  m->persistent_layer = on != 0;  // takes effect for pieces enqueued / captured from now on; one engine per GPU only (see csrc/persistent_layer.hip)
   return DEER_OK;
 }
 

@@ -1,0 +1,137 @@
+// The LLM row operation x += scale * sum_s slab[s] ; [copy x] ; [LayerNorm(x) -> bf16 planes / f32] as a device function of the ROW index
+// (csrc/norm_embed.hip launches it one workgroup per row; csrc/persistent_layer.hip runs it as a phase of one launch).
+#pragma once
+#include "common.h"
+
+// Env batches with compaction (common.h: CMAP_*): `rows_per_env` > 0 and `cmap` = the row map of this layer -> rows beyond the active
+// slots return at once.  GATHER (x_in != NULL): this launch is the first row operation of a compaction layer - workgroup r' owns
+// DESTINATION row r' of the new packing: the surviving slots of the old map `cmap_old` (environments whose EXIT_FLAG is still 0) are
+// counted in slot order, row r' reads x_in / the slabs at its SOURCE row, and x (a different buffer than x_in) receives the packed rows;
+// workgroup 0 publishes the new map into `cmap` (which the later kernels of the layer read).
+struct deer_rowmap {
+  const int* cmap;          // map of this layer (gather mode: WRITTEN by workgroup 0)
+  int rows_per_env;         // T (0 = no map)
+  const float* x_in;        // gather source (NULL = in place)
+  const int* cmap_old;      // map the source rows are packed by
+  const int* ctl0;          // control blocks (EXIT_FLAG per environment)
+  int B;
+};
+
+// NT threads per row: 256, or 512 for the one-environment trunk (<= 16 rows: the launch is a latency chain - with 512 threads a thread
+// owns ONE float4 column of a 2048-wide row and all of its slab loads are in flight together, one L2 round trip instead of four)
+template <int NT>
+__device__ __forceinline__ void resadd_ln_body(float* __restrict__ x, const float* __restrict__ slab, int s_in,
+                                                        long slab_stride, const float* __restrict__ gate,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        bf16_t* __restrict__ out_bf, float* __restrict__ out_f32,
+                                                        float* __restrict__ x_copy, int d, float eps, const int* ctl,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out_lo, int packed,
+                                                        deer_rowmap rm, int r) {
+  __shared__ float red[16];
+  __shared__ int s_src;
+  int rs = r;                                              // source row (== r unless gathering)
+  if (rm.rows_per_env > 0) {
+    const int T = rm.rows_per_env;
+    if (rm.x_in != nullptr) {
+      if (threadIdx.x == 0) {
+        const int slot = r / T, t = r - slot * T;
+        const int n_old = rm.cmap_old[CMAP_N];
+        int kept = 0, src = -1;
+        for (int s = 0; s < n_old; ++s) {
+          const int e = rm.cmap_old[CMAP_SLOT_ENV + s];
+          if (((const volatile int*)rm.ctl0)[e * CTL_WORDS + CTL_EXIT_FLAG] != 0) continue;
+          if (kept == slot) src = s * T + t;
+          if (r == 0) {                                    // workgroup 0 publishes the new map
+            int* cm = const_cast<int*>(rm.cmap);
+            cm[CMAP_SLOT_ENV + kept] = e;
+            cm[CMAP_ENV_SLOT + e] = kept;
+          }
+          ++kept;
+        }
+        if (r == 0) {
+          int* cm = const_cast<int*>(rm.cmap);
+          cm[CMAP_N] = kept;
+          for (int s = 0; s < n_old; ++s) {
+            const int e = rm.cmap_old[CMAP_SLOT_ENV + s];
+            if (((const volatile int*)rm.ctl0)[e * CTL_WORDS + CTL_EXIT_FLAG] != 0) cm[CMAP_ENV_SLOT + e] = -1;
+          }
+          for (int e = 0; e < rm.B; ++e)
+            if (rm.cmap_old[CMAP_ENV_SLOT + e] < 0) cm[CMAP_ENV_SLOT + e] = -1;
+        }
+        s_src = src;
+      }
+      __syncthreads();
+      rs = s_src;
+      if (rs < 0) return;                                  // beyond the surviving slots
+    } else if (rm.cmap != nullptr && r >= rm.cmap[CMAP_N] * T) {
+      return;
+    }
+  }
+  const int n4 = d >> 2;
+  float* xr = x + (long)r * d;
+  const float* xs = (rm.x_in != nullptr ? rm.x_in : x) + (long)rs * d;
+  constexpr int NV = 1024 / NT;                           // float4 per thread: d <= 4096
+  float4 v[NV];                                           // the row stays in registers
+  const float sc = (slab != nullptr && gate != nullptr) ? tanhf(*gate) : 1.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i4 = threadIdx.x + j * NT;
+    v[j] = float4{0.f, 0.f, 0.f, 0.f};
+    if (i4 < n4) {
+      float4 a = float4{0.f, 0.f, 0.f, 0.f};
+      if (slab != nullptr) {
+        a = slab_sum4(slab + (long)rs * d + (long)i4 * 4, s_in, slab_stride);
+        if (bias != nullptr) {
+          const float4 t = *reinterpret_cast<const float4*>(bias + (long)i4 * 4);
+          a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+      }
+      float4 xv = *reinterpret_cast<const float4*>(xs + (long)i4 * 4);
+      xv.x += sc * a.x; xv.y += sc * a.y; xv.z += sc * a.z; xv.w += sc * a.w;
+      v[j] = xv;
+      if (slab != nullptr || rm.x_in != nullptr) *reinterpret_cast<float4*>(xr + (long)i4 * 4) = xv;
+      if (x_copy != nullptr) *reinterpret_cast<float4*>(x_copy + (long)rs * d + (long)i4 * 4) = xv;
+    }
+  }
+  if (gamma == nullptr) return;
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) s += v[j].x + v[j].y + v[j].z + v[j].w;
+  const float mean = block_sum(s, red) / d;
+  float var = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    if (threadIdx.x + j * NT < n4) {
+      const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, e = v[j].w - mean;
+      var += a * a + b * b + c * c + e * e;
+    }
+  const float rstd = rsqrtf(block_sum(var, red) / d + eps);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i4 = threadIdx.x + j * NT;
+    if (i4 < n4) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + (long)i4 * 4);
+      float4 y;
+      y.x = (v[j].x - mean) * rstd * g.x; y.y = (v[j].y - mean) * rstd * g.y;
+      y.z = (v[j].z - mean) * rstd * g.z; y.w = (v[j].w - mean) * rstd * g.w;
+      if (beta != nullptr) {
+        const float4 bb = *reinterpret_cast<const float4*>(beta + (long)i4 * 4);
+        y.x += bb.x; y.y += bb.y; y.z += bb.z; y.w += bb.w;
+      }
+      if (out_bf != nullptr) {
+        const uint32_t h01 = pack2bf(y.x, y.y), h23 = pack2bf(y.z, y.w);
+        // packed: MFMA-fragment order [k-tile][lane = 16 * (k % 32 / 8) + row][8] - the <= 16 rows of one environment read back as ONE
+        // contiguous 1 KiB per k-tile and plane (deer_trunk_wide_gemm, deer_xattn_fused_packed)
+        const int col = i4 * 4;
+        const long o = packed ? (((long)(col >> 5) * 64 + ((col & 31) >> 3) * 16 + r) * 8 + (col & 7)) : ((long)r * d + col);
+        *reinterpret_cast<uint2*>(out_bf + o) = uint2{h01, h23};
+        if (out_lo != nullptr)      // second bf16 plane: y = hi + lo to ~16 mantissa bits (activation operand of deer_gemm_skinny_hl)
+          *reinterpret_cast<uint2*>(out_lo + o) =
+              uint2{pack2bf(y.x - __uint_as_float(h01 << 16), y.y - __uint_as_float(h01 & 0xffff0000u)),
+                    pack2bf(y.z - __uint_as_float(h23 << 16), y.w - __uint_as_float(h23 & 0xffff0000u))};
+      }
+      if (out_f32 != nullptr) *reinterpret_cast<float4*>(out_f32 + (long)r * d + (long)i4 * 4) = y;
+    }
+  }
+}
+

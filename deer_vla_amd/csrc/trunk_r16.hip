@@ -29,14 +29,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 enum { TR_EPI_F32 = 0, TR_EPI_GELU_PLANES = 1, TR_EPI_F32_STATS = 2 };
 
 // workgroup = 32 output columns (2 MFMA column tiles), 8 waves x KS k-tiles of 32 (K = 256 * KS)
+// (bodies are device functions taking the LOGICAL workgroup index: csrc/persistent_layer.hip runs them as phases of one launch)
 template <int KS, int EPI>
-__global__ __launch_bounds__(64 * TR_NW) void trunk_wide_gemm_kernel(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo,
-                                                                    const bf16_t* __restrict__ Wp, float* __restrict__ out_f32,
-                                                                    bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo,
-                                                                    float* __restrict__ stats, int T, const int* ctl) {
-  DEER_RETURN_IF_EXITED(ctl);
+__device__ __forceinline__ void trunk_wide_gemm_body(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo,
+                                                     const bf16_t* __restrict__ Wp, float* __restrict__ out_f32,
+                                                     bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo,
+                                                     float* __restrict__ stats, int T, int bx, float* opart /* LDS: TR_NW * 16 * TR_OPITCH floats */) {
   constexpr int KT = KS * TR_NW;
-  __shared__ __attribute__((aligned(16))) float opart[TR_NW * 16 * TR_OPITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int kt0 = wave * KS;                                   // this wave's k-tiles: kt0 .. kt0 + KS - 1
@@ -45,7 +44,7 @@ __global__ __launch_bounds__(64 * TR_NW) void trunk_wide_gemm_kernel(const bf16_
   u32x4 w[2][KS];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + ((long)(blockIdx.x * 2 + t) * KT + kt0) * 64 + lane;
+    const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + ((long)(bx * 2 + t) * KT + kt0) * 64 + lane;
 #pragma unroll
     for (int s = 0; s < KS; ++s) w[t][s] = __builtin_nontemporal_load(wp + s * 64);
   }
@@ -74,7 +73,7 @@ __global__ __launch_bounds__(64 * TR_NW) void trunk_wide_gemm_kernel(const bf16_
   float v = 0.f;
 #pragma unroll
   for (int wv = 0; wv < TR_NW; ++wv) v += opart[(wv * 16 + m) * TR_OPITCH + n];
-  const int col = blockIdx.x * 32 + n;
+  const int col = bx * 32 + n;
   if (EPI == TR_EPI_GELU_PLANES) {
     v = gelu_erf(v);
     const float vn = __shfl_down(v, 1, 64);
@@ -93,11 +92,22 @@ __global__ __launch_bounds__(64 * TR_NW) void trunk_wide_gemm_kernel(const bf16_
       float s2 = (v - mu) * (v - mu);
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
-      if (n == 0) *reinterpret_cast<float2*>(stats + ((long)blockIdx.x * 16 + m) * 2) = float2{mu, s2};
+      if (n == 0) *reinterpret_cast<float2*>(stats + ((long)bx * 16 + m) * 2) = float2{mu, s2};
     }
   }
 }
 
+template <int KS, int EPI>
+__global__ __launch_bounds__(64 * TR_NW) void trunk_wide_gemm_kernel(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo,
+                                                                    const bf16_t* __restrict__ Wp, float* __restrict__ out_f32,
+                                                                    bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo,
+                                                                    float* __restrict__ stats, int T, const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
+  __shared__ __attribute__((aligned(16))) float opart[TR_NW * 16 * TR_OPITCH];
+  trunk_wide_gemm_body<KS, EPI>(Ahi, Alo, Wp, out_f32, out_hi, out_lo, ldo, stats, T, blockIdx.x, opart);
+}
+
+#ifndef DEER_BODIES_ONLY
 // y = A W^T for the wide bias-free Linears at <= 16 rows.  a_hi / a_lo: the activation as bf16 planes in MFMA-fragment order
 // [K/32][64 lanes][8] (lane = 16 * (k % 32 / 8) + row; written by deer_resadd_ln_packed), Wp packed [N/16][K/32][64][8].
 // epi: 0 = out_f32 [T][ldo]; 1 = exact GELU -> ROW-MAJOR bf16 hi / lo planes [T][ldo]; 2 = out_f32 + stats [N/32][16][2] (mean, centred
@@ -128,6 +138,7 @@ extern "C" int deer_trunk_wide_gemm(const void* a_hi, const void* a_lo, const vo
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
+#endif  // DEER_BODIES_ONLY
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // deer_trunk_mpt_attn: MPT attention core on final f32 q|k|v [T][3d]: q/k LayerNorm over the FULL d_model from the
@@ -135,20 +146,22 @@ extern "C" int deer_trunk_wide_gemm(const void* a_hi, const void* a_lo, const vo
 // softmax(q k^T / sqrt(hd) + alibi + causal + key-pad) v -> bf16 hi / lo planes [T][ldo].  One workgroup per head.
 // ---------------------------------------------------------------------------------------------------------------------------
 #define TM_MAXT 16
-__global__ __launch_bounds__(256) void trunk_mpt_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ stats, int d_model, int hd,
-                                                             const float* __restrict__ q_ln_w, const float* __restrict__ k_ln_w, float eps,
-                                                             const unsigned char* __restrict__ key_mask, float alibi_slope_base, int n_heads,
-                                                             bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo, int T, const int* ctl) {
-  DEER_RETURN_IF_EXITED(ctl);
-  __shared__ __attribute__((aligned(16))) float qs[TM_MAXT][128 + 4];
-  __shared__ __attribute__((aligned(16))) float ks[TM_MAXT][128 + 4];
-  __shared__ __attribute__((aligned(16))) float vs[TM_MAXT][128 + 4];
-  __shared__ float sim[TM_MAXT][TM_MAXT + 1];
-  __shared__ float mom[2][TM_MAXT][2];                          // (mean, rstd) of the q row / k row over d_model
-  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define TM_LDS_FLOATS (3 * TM_MAXT * 132 + TM_MAXT * (TM_MAXT + 1) + 2 * TM_MAXT * 2)
+template <int NT>     // threads of the workgroup (256; 512 as a phase of the persistent layer)
+__device__ __forceinline__ void trunk_mpt_attn_body(const float* __restrict__ qkv, const float* __restrict__ stats, int d_model, int hd,
+                                                    const float* __restrict__ q_ln_w, const float* __restrict__ k_ln_w, float eps,
+                                                    const unsigned char* __restrict__ key_mask, float alibi_slope_base, int n_heads,
+                                                    bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo, int T, int h,
+                                                    float* lds /* TM_LDS_FLOATS floats, 16-byte aligned */) {
+  float (*qs)[128 + 4] = reinterpret_cast<float (*)[128 + 4]>(lds);
+  float (*ks)[128 + 4] = reinterpret_cast<float (*)[128 + 4]>(lds + TM_MAXT * 132);
+  float (*vs)[128 + 4] = reinterpret_cast<float (*)[128 + 4]>(lds + 2 * TM_MAXT * 132);
+  float (*sim)[TM_MAXT + 1] = reinterpret_cast<float (*)[TM_MAXT + 1]>(lds + 3 * TM_MAXT * 132);
+  float (*mom)[TM_MAXT][2] = reinterpret_cast<float (*)[TM_MAXT][2]>(lds + 3 * TM_MAXT * 132 + TM_MAXT * (TM_MAXT + 1));   // (mean, rstd) of the q / k row over d_model
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * d_model;
   const bool qk_ln = q_ln_w != nullptr;
-  if (qk_ln) {
+  if (qk_ln && tid < 256) {
     // 2 x 16 rows x G groups of 32 columns: thread (which, r, part) combines G/8 groups, the 8 parts of a row meet by xor-shuffles
     // (equal group sizes -> mean = average of the group means; M2 = sum of the group M2 + 32 * sum (group mean - mean)^2)
     const int which = tid >> 7, r = (tid >> 3) & 15, part = tid & 7;
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(256) void trunk_mpt_attn_kernel(const float* __rest
   }
   __syncthreads();
   const int hd4 = hd >> 2;
-  for (int idx = tid; idx < T * hd4; idx += 256) {
+  for (int idx = tid; idx < T * hd4; idx += NT) {
     const int t = idx / hd4, dd = (idx - t * hd4) * 4;
     const float* p = qkv + (long)t * ld + h * hd + dd;
     float4 q = *reinterpret_cast<const float4*>(p);
@@ -199,7 +212,7 @@ __global__ __launch_bounds__(256) void trunk_mpt_attn_kernel(const float* __rest
   __syncthreads();
   const float sc = rsqrtf((float)hd);
   const float slope = exp2f(-alibi_slope_base * (float)(h + 1) / (float)n_heads);
-  for (int idx = tid; idx < T * T; idx += 256) {
+  for (int idx = tid; idx < T * T; idx += NT) {
     const int i = idx / T, j = idx - i * T;
     float a = 0.f;
     if (j <= i)
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(256) void trunk_mpt_attn_kernel(const float* __rest
     sim[i][j] = a;
   }
   __syncthreads();
-  for (int i = wave; i < T; i += 4) {
+  for (int i = wave; i < T; i += NT / 64) {
     float v = (lane < T) ? sim[i][lane] : -INFINITY;
     const float mx = wave_max(v);
     const float p = (lane < T) ? expf(v - mx) : 0.f;
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(256) void trunk_mpt_attn_kernel(const float* __rest
     if (lane < T) sim[i][lane] = p / sum;
   }
   __syncthreads();
-  for (int idx = tid; idx < T * hd; idx += 256) {
+  for (int idx = tid; idx < T * hd; idx += NT) {
     const int t = idx / hd, dd = idx - t * hd;
     float a = 0.f;
     for (int j = 0; j <= t; ++j) a += sim[t][j] * vs[j][dd];
@@ -229,6 +242,16 @@ __global__ __launch_bounds__(256) void trunk_mpt_attn_kernel(const float* __rest
     out_hi[(long)t * ldo + h * hd + dd] = hi;
     out_lo[(long)t * ldo + h * hd + dd] = f2bf(a - bf2f(hi));
   }
+}
+
+#ifndef DEER_BODIES_ONLY
+__global__ __launch_bounds__(256) void trunk_mpt_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ stats, int d_model, int hd,
+                                                             const float* __restrict__ q_ln_w, const float* __restrict__ k_ln_w, float eps,
+                                                             const unsigned char* __restrict__ key_mask, float alibi_slope_base, int n_heads,
+                                                             bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo, int T, const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
+  __shared__ __attribute__((aligned(16))) float lds[TM_LDS_FLOATS];
+  trunk_mpt_attn_body<256>(qkv, stats, d_model, hd, q_ln_w, k_ln_w, eps, key_mask, alibi_slope_base, n_heads, out_hi, out_lo, ldo, T, blockIdx.x, lds);
 }
 
 extern "C" int deer_trunk_mpt_attn(const float* qkv, const float* stats, int d_model, int n_heads, const float* q_ln_w, const float* k_ln_w, float eps,
@@ -244,3 +267,4 @@ extern "C" int deer_trunk_mpt_attn(const float* qkv, const float* stats, int d_m
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
+#endif  // DEER_BODIES_ONLY

@@ -22,17 +22,16 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // PACKED (one environment, <= 16 rows): the activation arrives as bf16 hi / lo planes in MFMA-fragment order (xn = hi plane, xlo = lo
 // plane; deer_resadd_ln_packed) - one coalesced 1 KiB read per k-tile and plane instead of 16 rows x 16 B per lane
-template <int MT, bool PACKED = false>
-__global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __restrict__ xn, int d, const bf16_t* __restrict__ Wq_p,
+template <int MT, bool PACKED>
+__device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, int d, const bf16_t* __restrict__ Wq_p,
                                                                 const bf16_t* __restrict__ kv, int ldkv, int inner,
                                                                 const int* __restrict__ text_time, int n_per_media, int n_kv,
                                                                 const bf16_t* __restrict__ Wo_p, float* __restrict__ out, long slab_stride,
-                                                                int T, int heads, int NS, float scale, const int* ctl,
-                                                                const bf16_t* __restrict__ xlo = nullptr, const int* __restrict__ cmap = nullptr) {
-  DEER_RETURN_IF_EXITED(ctl);
-  // compaction: blockIdx.y is a SLOT of the row map - activation / output rows by slot, media K/V and text_time by its environment
-  if (cmap != nullptr && (int)blockIdx.y >= cmap[CMAP_N]) return;
-  const int env = cmap != nullptr ? cmap[CMAP_SLOT_ENV + blockIdx.y] : (int)blockIdx.y;
+                                                                int T, int heads, int NS, float scale,
+                                                                const bf16_t* __restrict__ xlo, const int* __restrict__ cmap, int bx, int by) {
+  // compaction: `by` is a SLOT of the row map - activation / output rows by slot, media K/V and text_time by its environment
+  if (cmap != nullptr && by >= cmap[CMAP_N]) return;
+  const int env = cmap != nullptr ? cmap[CMAP_SLOT_ENV + by] : by;
   static_assert(!PACKED || MT == 1, "packed planes hold one 16-row tile");
   constexpr int MPAD = MT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -46,7 +45,7 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int h = blockIdx.x / NS, cs = blockIdx.x - h * NS, b = blockIdx.y;
+  const int h = bx / NS, cs = bx - h * NS, b = by;
   const float* xb = xn + (long)b * T * d;
   const bf16_t* kvb = kv + (long)env * n_kv * ldkv + h * XF_HD;
   const int ktiles = d >> 5;
@@ -269,6 +268,19 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
   }
 }
 
+template <int MT, bool PACKED = false>
+__global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __restrict__ xn, int d, const bf16_t* __restrict__ Wq_p,
+                                                                const bf16_t* __restrict__ kv, int ldkv, int inner,
+                                                                const int* __restrict__ text_time, int n_per_media, int n_kv,
+                                                                const bf16_t* __restrict__ Wo_p, float* __restrict__ out, long slab_stride,
+                                                                int T, int heads, int NS, float scale, const int* ctl,
+                                                                const bf16_t* __restrict__ xlo = nullptr, const int* __restrict__ cmap = nullptr) {
+  DEER_RETURN_IF_EXITED(ctl);
+  xattn_fused_body<MT, PACKED>(xn, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T, heads, NS, scale, xlo, cmap,
+                               blockIdx.x, blockIdx.y);
+}
+
+#ifndef DEER_BODIES_ONLY
 // xn: f32 [batch*T, d] = LN(x) of the block's attention branch; Wq_p / Wo_p: to_q [inner, d] and to_out [d, inner] in the packed
 // layout of deer_pack_weight_mfma16; kv: bf16 [batch*n_kv, ldkv] (k of head h at column h*64, v at inner + h*64); out: f32
 // [heads][slab_stride] with slab_stride >= batch*T*d - slab h holds head h's contribution to all rows.  T <= 32, n_kv <= 128.
@@ -338,3 +350,4 @@ static int launch_xattn_fused(const float* xn, const void* x_lo_packed, int d, c
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
+#endif  // DEER_BODIES_ONLY

@@ -305,6 +305,30 @@ class DeerEngine:
             torch.cuda.synchronize(self.dev)
         self._drop_graphs()
 
+    def set_persistent_layer(self, on: bool):
+        """N1 experiment (csrc/persistent_layer.hip): one persistent launch per trunk layer of a one-environment step.  Bit-identical to
+        the twelve-launch layer and slower; needs ALL of its 256 workgroups resident, so only one engine per GPU may use it at a time."""
+        abi.check(self.lib.deer_model_set_persistent_layer(self._h, 1 if on else 0), "deer_model_set_persistent_layer")
+        torch.cuda.synchronize(self.dev)
+        self._drop_graphs()
+        self._buf("pl_state").view(torch.int32)[:16 * 12 + 16].zero_()   # barrier counters (cumulative over launches) + error words
+
+    def persistent_layer_error(self) -> int:
+        """barrier number that timed out in a persistent layer launch (0 = none)"""
+        return int(self._buf("pl_state").view(torch.int32)[16 * 12].item())
+
+    def persistent_layer_trace(self, clear: bool = False):
+        """int32 [64 layers][16 barriers][clock lo, clock hi (100 MHz), last workgroup to arrive, timeouts]; row 0 = entry of workgroup 0"""
+        t = self._buf("pl_state").view(torch.int32)[16 * 12 + 16:16 * 12 + 16 + 64 * 64].view(64, 16, 4)
+        out = t.cpu()
+        if clear:
+            t.zero_()
+        return out
+
+    def persistent_layer_error_detail(self):
+        """[epoch, workgroup, generation word, top counter, 8 group counters] recorded by the first barrier that timed out"""
+        return [int(v) for v in self._buf("pl_state").view(torch.int32)[16 * 12:16 * 12 + 12].tolist()]
+
     def configure_exit(self, exit_ids: Sequence[int], max_layer: int, steps_per_stage: int = 1):
         """``ExitController.__init__`` (value_net.py:164-173): max_layer = min(max_layer-1, last exit)."""
         old = (self.exit_ids, self._max_layer_arg)

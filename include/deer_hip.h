@@ -204,6 +204,30 @@ int deer_xattn_fused_packed(const void* x_hi, const void* x_lo, int d, const voi
                             int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, float scale,
                             const int* ctl, void* stream);
 
+/* N1 experiment (csrc/persistent_layer.hip): ONE gated x-attn + MPT decoder layer of the one-environment trunk (flamingo_lm.py:46-83) as ONE
+ * persistent launch of 256 workgroups - the twelve phases are the device functions of the kernels above, a device-wide barrier at every
+ * seam.  Bit-identical to the twelve-launch layer; slower; selected by DEER_PERSISTENT_LAYER=1 only.  All buffers as the
+ * spine lays them out: x f32 [T, d] (in / out), slab_a f32 (>= 16 slabs of [16, d]), qkv f32 [T, 3d], stats [3d/32][16][2], xn / h / ao
+ * planes (xn in MFMA-fragment order), kv bf16 media K|V of this layer, weights packed (deer_pack_weight_mfma16).  pending_s > 0: the previous
+ * layer's mlp_down slabs (in slab_a) are folded in first; hidden_out != NULL: x += this layer's mlp_down slabs and the result is copied out
+ * (hidden_states[i]); else they stay pending in slab_a (s_down slabs).  barrier: 192 uint32 (zero before the FIRST launch; cumulative after), error: int32, raised when a
+ * barrier times out. */
+typedef struct deer_trunk_layer_args {
+  int T, d, xinner, heads, n_heads, ffw, n_kv, n_per_media, ld_kv, NS, pending_s, qk_ln, s_w2, s_wo, s_down;
+  float eps, xattn_scale, alibi_bias_max;
+  float *x, *slab_a, *qkv, *stats, *prev_hidden, *hidden_out;
+  void *xn_hi, *xn_lo, *h_hi, *h_lo, *ao_hi, *ao_lo;
+  const void* kv;
+  const int* text_time;
+  const unsigned char* key_mask;
+  const float *x_nw, *x_nb, *x_ag, *x_fnw, *x_fnb, *x_fg, *ln1w, *ln1b, *ln2w, *ln2b, *qlnw, *klnw;
+  const void *x_wq, *x_wo, *x_w1, *x_w2, *wqkv, *wo, *wup, *wdown;
+  unsigned* barrier;
+  int* error;
+  int* trace;   /* NULL or 16 rows x 4 int32: row e = {clock lo, clock hi (100 MHz), workgroup} of the LAST arrival at barrier e, row 0 = entry of workgroup 0; [3] = timeouts at e */
+} deer_trunk_layer_args;
+int deer_trunk_layer_persistent(const deer_trunk_layer_args* a, void* stream);
+
 /* ---- env batch with COMPACTION of exited environments (the reference stops every environment at its own layer,
  * mosaic_gpt_3b.py:438-443): the rows of the still-active environments stay packed at the front of the trunk's buffers.  Row map `cmap`
  * (int32, CMAP_WORDS = 32 per copy): [0] = active slots, [1 + s] = environment of slot s, [9 + e] = slot of environment e or -1.  The

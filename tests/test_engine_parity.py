@@ -644,3 +644,39 @@ def test_compaction_of_exited_environments_is_bit_identical_to_the_uncompacted_b
         torch.cuda.synchronize()
         assert torch.equal(eng_on.h_state, eng_off.h_state) and torch.equal(eng_on.c_state, eng_off.c_state), s
     assert len(seen) > 1, seen                                    # environments really left at different layers
+
+
+@pytest.mark.parametrize("size", ["tiny", "3b"])
+def test_persistent_layer_launch_is_bit_identical_to_the_twelve_launch_layer(size):
+    """N1 experiment (csrc/persistent_layer.hip): every trunk layer of a one-environment step as ONE persistent launch - the same device
+    functions as the twelve kernels, a device-wide barrier at every seam.  Hidden states of every layer, actions and exit layers must be
+    BIT-identical to the default schedule (static full depth and a dynamic episode with LSTM carry), and no barrier may time out."""
+    cfg = deer_tiny() if size == "tiny" else deer_3b(max_layer=12)
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True) if size == "tiny" else syn.make_synthetic_state(cfg, 0, std="0.02", bf16_round=True)
+    ref = DeerEngine(cfg, sd)
+    per = DeerEngine(cfg, None, weights_from=ref)
+    per.set_persistent_layer(True)
+    inputs = make_inputs(cfg, 6)
+    last = cfg.n_layers - 1
+    for use_graph in (False, True):
+        for s, (rgb, grip, ids, mask) in enumerate(inputs[:3]):
+            outs = []
+            for eng in (ref, per):
+                eng.reset()
+                r = eng.step(rgb, grip, ids, mask, exit_id=last, use_graph=use_graph)
+                torch.cuda.synchronize()
+                outs.append((r, eng.hidden[:, :ids.shape[1]].clone()))
+            assert torch.equal(outs[0][1], outs[1][1]), (use_graph, s)
+            assert torch.equal(outs[0][0]["pose"], outs[1][0]["pose"]) and outs[0][0]["gripper"] == outs[1][0]["gripper"]
+    thr, _ = probe_thresholds(cfg, sd, inputs, 12, iters=1)
+    for eng in (ref, per):
+        eng.configure_exit(cfg.exit_ids(), 12, 1)
+        eng.set_thresholds(thr)
+        eng.reset()
+    per.set_persistent_layer(True)
+    for s, (rgb, grip, ids, mask) in enumerate(inputs):
+        ra, rb = ref.step(rgb, grip, ids, mask), per.step(rgb, grip, ids, mask)
+        assert ra["exit_layer"] == rb["exit_layer"] and torch.equal(ra["pose"], rb["pose"]) and ra["gripper"] == rb["gripper"], s
+    torch.cuda.synchronize()
+    assert torch.equal(ref.h_state, per.h_state)
+    assert per.persistent_layer_error() == 0
