@@ -1,4 +1,5 @@
-"""Wall-clock distribution of DeerEngine.step() (dynamic, pipelined) for a forced exit index."""
+"""Wall-clock distribution of DeerEngine.step() (dynamic, pipelined) for a forced exit index, next to the STATIC step that exits at the
+same layer (no exit checks; two-chain vision + one trunk graph) - the difference is what the exit checks of the dynamic pipeline cost."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,4 +26,14 @@ for exit_at in range(6):
         r = eng.step(rgb, grip, ids, None)
         ts.append(1e3 * (time.perf_counter() - t0))
     ts.sort()
-    print(f"exit index {exit_at} (layer {r['exit_layer']:2d}): min {ts[0]:.3f}  median {ts[len(ts)//2]:.3f}  p90 {ts[int(.9*len(ts))]:.3f}  max {ts[-1]:.3f} ms")
+    layer = r["exit_layer"]
+    for _ in range(3):
+        eng.step(rgb, grip, ids, None, exit_id=layer)
+    st = []
+    for _ in range(40):
+        t0 = time.perf_counter()
+        eng.step(rgb, grip, ids, None, exit_id=layer)
+        st.append(1e3 * (time.perf_counter() - t0))
+    st.sort()
+    print(f"exit index {exit_at} (layer {layer:2d}): dynamic min {ts[0]:.3f}  median {ts[len(ts)//2]:.3f}  p90 {ts[int(.9*len(ts))]:.3f}  max {ts[-1]:.3f} ms"
+          f"   static median {st[len(st)//2]:.3f} ms   dynamic - static {1e3 * (ts[len(ts)//2] - st[len(st)//2]):.0f} us")
