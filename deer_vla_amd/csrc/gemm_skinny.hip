@@ -192,7 +192,6 @@ __device__ __forceinline__ void gemm_skinny_hl_body(const bf16_t* __restrict__ A
                                                     const bf16_t* __restrict__ Wp, float* __restrict__ part, int M, int N, int K, int KR,
                                                     int part_rows, int bx, int by) {
   constexpr int MTL = (MT + 1) & ~1;                  // row tiles LOADED per plane (even: every wave issues the same number of DMAs)
-  constexpr int MPAD = MT * 16;
   constexpr int A_CH = 4 * MTL;                       // 1 KiB chunks (8 rows x 128 B) of [hi plane ; lo plane] per stage
   constexpr int CH = A_CH + 16;                       // + 8 column tiles x 2 K-tiles of packed weight fragments
   constexpr int CPW = CH / 8;                         // chunks per wave per stage
