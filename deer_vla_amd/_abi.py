@@ -51,6 +51,7 @@ SIGNATURES = {
     "deer_layernorm_rows": [P, L, L, I, I, P, P, P, P, L, L, I, F, P],
     "deer_layernorm_rows_multi": [P, L, L, I, I, P, P, I, L, P, L, L, L, I, F, P],
     "deer_resadd_ln": [P, P, I, L, P, P, P, P, P, P, P, I, I, F, P, P],
+    "deer_resadd_ln_multirow": [P, P, I, L, P, P, P, P, P, I, I, F, I, P],
     "deer_resadd_ln_split": [P, P, I, L, P, P, P, P, P, P, P, P, I, I, F, P, P],
     "deer_vit_im2col": [P, I, I, I, I, P, I, P],
     "deer_vit_embed_lnpre": [P, P, P, P, P, P, I, I, I, F, P],

@@ -2,6 +2,7 @@
 // ViT patch im2col and cls/pos/ln_pre embedding, token embedding, media-time bookkeeping.
 // All statistics are fp32 two-pass (mean, then biased variance), eps 1e-5, like torch.nn.LayerNorm.
 #include "common.h"
+#include <cstdlib>
 
 // ---- LayerNorm over rows: f32 in -> bf16 out (GEMM A operand) and/or f32 out -------------------------
 // Row r of batch b is read at  x + b*in_bstride + r*in_rstride  and written at  out + b*out_bstride + r*out_rstride
@@ -111,12 +112,113 @@ __global__ __launch_bounds__(NT) void resadd_ln_kernel(float* __restrict__ x, co
   resadd_ln_body<NT>(x, slab, s_in, slab_stride, gate, gamma, beta, out_bf, out_f32, x_copy, d, eps, ctl, bias, out_lo, packed, rm, blockIdx.x);
 }
 
+// ---- the same row op for the env-batch vision tower (thousands of 1024-wide rows): R rows per workgroup ----------------------------
+// One row per workgroup leaves a 4112-row launch at 3.5-4.1 TB/s: a workgroup's life is load -> two block reductions -> store, and only
+// its first third has bytes in flight.  With R rows per workgroup every thread requests its float4 of all R rows (x and every slab) before
+// the first use, the R rows' statistics go through ONE pair of block reductions (R values per wave, leading barrier before the scratch
+// is rewritten), and gamma / beta are read once.  Per row the arithmetic and its order are those of resadd_ln_body: results are
+// BIT-identical to the one-row kernel (tests/test_hip_ops.py).  d == 1024 exactly (a thread owns one float4 column).
+template <int R>
+__device__ __forceinline__ void block_sum_rows(float (&v)[R], float* red) {   // red: R x 16 floats
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = wave_sum(v[r]);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();                                         // the previous round's readers are done with `red`
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) red[r * 16 + w] = v[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[r * 16 + i];
+    v[r] = t;
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void resadd_ln_multirow_kernel(float* __restrict__ x, const float* __restrict__ slab, int s_in, long slab_stride,
+                                                                 const float* __restrict__ gate, const float* __restrict__ bias,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 bf16_t* __restrict__ out_bf, float eps, int rows) {
+  constexpr int D = 1024;
+  __shared__ float red[R * 16];
+  const int c = threadIdx.x * 4;
+  const int r0 = blockIdx.x * R;
+  long off[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) off[r] = (long)min(r0 + r, rows - 1) * D + c;   // a ragged last workgroup repeats the last row and does not store it
+  float4 a[R], v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) a[r] = slab != nullptr ? slab_sum4(slab + off[r], s_in, slab_stride) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = *reinterpret_cast<const float4*>(x + off[r]);
+  const float sc = (slab != nullptr && gate != nullptr) ? tanhf(*gate) : 1.f;
+  float4 bv = float4{0.f, 0.f, 0.f, 0.f};
+  if (slab != nullptr && bias != nullptr) bv = *reinterpret_cast<const float4*>(bias + c);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (slab != nullptr) {
+      if (bias != nullptr) { a[r].x += bv.x; a[r].y += bv.y; a[r].z += bv.z; a[r].w += bv.w; }
+      v[r].x += sc * a[r].x; v[r].y += sc * a[r].y; v[r].z += sc * a[r].z; v[r].w += sc * a[r].w;
+      if (r0 + r < rows) *reinterpret_cast<float4*>(x + off[r]) = v[r];
+    }
+  }
+  if (gamma == nullptr) return;
+  float s[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { s[r] = 0.f; s[r] += v[r].x + v[r].y + v[r].z + v[r].w; }
+  block_sum_rows<R>(s, red);
+  float mean[R], q[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    mean[r] = s[r] / D;
+    q[r] = 0.f;
+    q[r] += ln_sq4(v[r], mean[r]);
+  }
+  block_sum_rows<R>(q, red);
+  const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+  float4 bb = float4{0.f, 0.f, 0.f, 0.f};
+  if (beta != nullptr) bb = *reinterpret_cast<const float4*>(beta + c);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (r0 + r >= rows) break;
+    const float rstd = rsqrtf(q[r] / D + eps);
+    float4 y = ln_norm4(v[r], mean[r], rstd, g);
+    if (beta != nullptr) y = ln_add4(y, bb);
+    *reinterpret_cast<uint2*>(out_bf + off[r]) = uint2{pack2bf(y.x, y.y), pack2bf(y.z, y.w)};
+  }
+}
+
+// rows_per_wg: 2 or 4.  d must be 1024, out bf16; no control block (the vision tower runs before the first exit check).
+extern "C" int deer_resadd_ln_multirow(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
+                                       const float* gamma, const float* beta, void* out_bf16, int T, int d, float eps, int rows_per_wg,
+                                       void* stream) {
+  if (T <= 0 || d != 1024 || x == nullptr || (slab != nullptr && s_in <= 0) || (gamma != nullptr && out_bf16 == nullptr) ||
+      (rows_per_wg != 2 && rows_per_wg != 4))
+    return DEER_ERR_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (rows_per_wg == 2)
+    hipLaunchKernelGGL(resadd_ln_multirow_kernel<2>, dim3((T + 1) / 2), dim3(256), 0, st, x, slab, s_in, slab_stride, gate, bias, gamma, beta,
+                       reinterpret_cast<bf16_t*>(out_bf16), eps, T);
+  else
+    hipLaunchKernelGGL(resadd_ln_multirow_kernel<4>, dim3((T + 3) / 4), dim3(256), 0, st, x, slab, s_in, slab_stride, gate, bias, gamma, beta,
+                       reinterpret_cast<bf16_t*>(out_bf16), eps, T);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
 extern "C" int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_stride, const float* gate,
                               const float* bias, const float* gamma, const float* beta, void* out_bf16, float* out_f32, float* x_copy, int T,
                               int d, float eps, const int* ctl, void* stream) {
   if (T <= 0 || d <= 0 || (d & 3) || d > 4096 || (slab != nullptr && s_in <= 0) ||
       (gamma != nullptr && out_bf16 == nullptr && out_f32 == nullptr))
     return DEER_ERR_SHAPE;
+  // env-batch vision rows: several rows per workgroup (bit-identical per row; DEER_RESADD_ROWS=1 keeps the one-row kernel, 2 / 4 force R)
+  static const int rows_knob = [] { const char* e = getenv("DEER_RESADD_ROWS"); return e ? atoi(e) : 0; }();
+  if (d == 1024 && T >= 2048 && out_f32 == nullptr && x_copy == nullptr && ctl == nullptr && rows_knob != 1 && (slab != nullptr || gamma != nullptr))
+    return deer_resadd_ln_multirow(x, slab, s_in, slab_stride, gate, bias, gamma, beta, out_bf16, T, d, eps, rows_knob == 4 ? 4 : 2, stream);
   hipLaunchKernelGGL(resadd_ln_kernel<256>, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in,
                      slab_stride, gate, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl, bias,
                      static_cast<bf16_t*>(nullptr));

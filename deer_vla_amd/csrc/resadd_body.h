@@ -17,6 +17,26 @@ struct deer_rowmap {
   int B;
 };
 
+// LayerNorm arithmetic shared by every row kernel (one row per workgroup here, R rows per workgroup in norm_embed.hip): every product and
+// sum is rounded on its own (no fused multiply-add, whatever the caller's expression looks like after inlining), so that kernels with
+// different shapes give the same bits per row.
+__device__ __forceinline__ float ln_sq4(const float4 v, float mean) {
+#pragma clang fp contract(off)
+  const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
+  return a * a + b * b + c * c + e * e;
+}
+__device__ __forceinline__ float4 ln_norm4(const float4 v, float mean, float rstd, const float4 g) {
+#pragma clang fp contract(off)
+  float4 y;
+  y.x = (v.x - mean) * rstd * g.x; y.y = (v.y - mean) * rstd * g.y;
+  y.z = (v.z - mean) * rstd * g.z; y.w = (v.w - mean) * rstd * g.w;
+  return y;
+}
+__device__ __forceinline__ float4 ln_add4(const float4 y, const float4 b) {
+#pragma clang fp contract(off)
+  return float4{y.x + b.x, y.y + b.y, y.z + b.z, y.w + b.w};
+}
+
 // NT threads per row: 256, or 512 for the one-environment trunk (<= 16 rows: the launch is a latency chain - with 512 threads a thread
 // owns ONE float4 column of a 2048-wide row and all of its slab loads are in flight together, one L2 round trip instead of four)
 template <int NT>
@@ -101,23 +121,15 @@ __device__ __forceinline__ void resadd_ln_body(float* __restrict__ x, const floa
   float var = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j)
-    if (threadIdx.x + j * NT < n4) {
-      const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, e = v[j].w - mean;
-      var += a * a + b * b + c * c + e * e;
-    }
+    if (threadIdx.x + j * NT < n4) var += ln_sq4(v[j], mean);
   const float rstd = rsqrtf(block_sum(var, red) / d + eps);
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int i4 = threadIdx.x + j * NT;
     if (i4 < n4) {
       const float4 g = *reinterpret_cast<const float4*>(gamma + (long)i4 * 4);
-      float4 y;
-      y.x = (v[j].x - mean) * rstd * g.x; y.y = (v[j].y - mean) * rstd * g.y;
-      y.z = (v[j].z - mean) * rstd * g.z; y.w = (v[j].w - mean) * rstd * g.w;
-      if (beta != nullptr) {
-        const float4 bb = *reinterpret_cast<const float4*>(beta + (long)i4 * 4);
-        y.x += bb.x; y.y += bb.y; y.z += bb.z; y.w += bb.w;
-      }
+      float4 y = ln_norm4(v[j], mean, rstd, g);
+      if (beta != nullptr) y = ln_add4(y, *reinterpret_cast<const float4*>(beta + (long)i4 * 4));
       if (out_bf != nullptr) {
         const uint32_t h01 = pack2bf(y.x, y.y), h23 = pack2bf(y.z, y.w);
         // packed: MFMA-fragment order [k-tile][lane = 16 * (k % 32 / 8) + row][8] - the <= 16 rows of one environment read back as ONE

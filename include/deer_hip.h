@@ -228,6 +228,12 @@ typedef struct deer_trunk_layer_args {
 } deer_trunk_layer_args;
 int deer_trunk_layer_persistent(const deer_trunk_layer_args* a, void* stream);
 
+/* deer_resadd_ln for the env-batch vision tower (d == 1024, bf16 LayerNorm output, no control block): rows_per_wg = 2 or 4 rows per workgroup,
+ * all loads of all rows in flight before the first use, one pair of block reductions for the R rows.  Per row bit-identical to deer_resadd_ln,
+ * which selects it from 2048 rows on (open_clip ResidualAttentionBlock residual + ln_1 / ln_2 of the next op). */
+int deer_resadd_ln_multirow(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias, const float* gamma,
+                            const float* beta, void* out_bf16, int T, int d, float eps, int rows_per_wg, void* stream);
+
 /* ---- env batch with COMPACTION of exited environments (the reference stops every environment at its own layer,
  * mosaic_gpt_3b.py:438-443): the rows of the still-active environments stay packed at the front of the trunk's buffers.  Row map `cmap`
  * (int32, CMAP_WORDS = 32 per copy): [0] = active slots, [1 + s] = environment of slot s, [9 + e] = slot of environment e or -1.  The

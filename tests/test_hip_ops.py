@@ -485,6 +485,33 @@ def test_resadd_ln(lib):
     assert torch.equal(cp, x0)
 
 
+@pytest.mark.parametrize("T,s_in,R", [(4112, 2, 2), (4112, 1, 4), (2057, 2, 2), (2059, 1, 4), (5, 2, 4), (4112, 0, 2)])
+def test_resadd_ln_multirow_is_bit_identical_to_one_row_per_workgroup(lib, T, s_in, R):
+    """Env-batch vision rows (d = 1024): R rows per workgroup, every load of every row in flight before the first use, one pair of block
+    reductions for the R rows - x and LN(x) must equal the one-row kernel BIT for bit (ragged last workgroup, with / without slabs, gate)."""
+    d = 1024
+    x0 = dev(rnd(T, d, seed=31))
+    slab = dev(rnd(max(s_in, 1), T, d, seed=32))
+    bias, g, be = dev(rnd(d, seed=33)), dev(1 + 0.1 * rnd(d, seed=34)), dev(0.1 * rnd(d, seed=35))
+    gate = torch.tensor([0.7], device="cuda")
+    sp = abi.ptr(slab) if s_in else None
+    for gp in (None, abi.ptr(gate)):
+        xa, xb = x0.clone(), x0.clone()
+        oa, ob = (torch.zeros(T, d, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+        abi.check(lib.deer_resadd_ln_multirow(abi.ptr(xb), sp, s_in, T * d, gp, abi.ptr(bias), abi.ptr(g), abi.ptr(be), abi.ptr(ob), T, d, 1e-5, R, st()), "multirow")
+        if T < 2048:                                  # below the auto threshold deer_resadd_ln IS the one-row kernel
+            abi.check(lib.deer_resadd_ln(abi.ptr(xa), sp, s_in, T * d, gp, abi.ptr(bias), abi.ptr(g), abi.ptr(be), abi.ptr(oa), None, None, T, d, 1e-5, None, st()), "one row")
+        else:                                         # above it: the one-row kernel through its f32-output form (never routed to the multi-row kernel)
+            of = torch.zeros(T, d, device="cuda")
+            abi.check(lib.deer_resadd_ln(abi.ptr(xa), sp, s_in, T * d, gp, abi.ptr(bias), abi.ptr(g), abi.ptr(be), abi.ptr(oa), abi.ptr(of), None, T, d, 1e-5, None, st()),
+                      "one row")
+        torch.cuda.synchronize()
+        assert torch.equal(xa, xb) and torch.equal(oa, ob), (T, s_in, R)
+        ref = x0 + (math.tanh(0.7) if gp else 1.0) * (slab[:s_in].sum(0) + bias) if s_in else x0
+        assert float((xb - ref).abs().max()) < 1e-5
+        assert rel_err(ob.float(), torch.nn.functional.layer_norm(ref, (d,), g, be)) < 4e-3
+
+
 @pytest.mark.parametrize("M,N,K,S", [(514, 1024, 4096, 4), (514, 1024, 1024, 2), (128, 1024, 4096, 8), (33, 256, 512, 2),
                                      (70, 128, 48, 2)])
 def test_gemm_splitk_resadd_bias(lib, M, N, K, S):
