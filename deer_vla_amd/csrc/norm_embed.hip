@@ -166,6 +166,9 @@ __global__ __launch_bounds__(256) void resadd_ln_multirow_kernel(float* __restri
     }
   }
   if (gamma == nullptr) return;
+  const float4 g = *reinterpret_cast<const float4*>(gamma + c);          // requested before the reductions (see resadd_ln_body)
+  float4 bb = float4{0.f, 0.f, 0.f, 0.f};
+  if (beta != nullptr) bb = *reinterpret_cast<const float4*>(beta + c);
   float s[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) { s[r] = 0.f; s[r] += v[r].x + v[r].y + v[r].z + v[r].w; }
@@ -178,9 +181,6 @@ __global__ __launch_bounds__(256) void resadd_ln_multirow_kernel(float* __restri
     q[r] += ln_sq4(v[r], mean[r]);
   }
   block_sum_rows<R>(q, red);
-  const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-  float4 bb = float4{0.f, 0.f, 0.f, 0.f};
-  if (beta != nullptr) bb = *reinterpret_cast<const float4*>(beta + c);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (r0 + r >= rows) break;
