@@ -66,6 +66,8 @@ SIGNATURES = {
     "deer_head_state_embed": [P, P, P, P, P, P, P, I, I, I, P],
     "deer_head_pool_state": [P, P, I, I, I, I, P, P, P, I, I, P],
     "deer_head_lstm_layer": [P, L, I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, P, I, I, I, P],
+    "deer_head_lstm_hh": [P, P, I, P, P, I, I, I, P],
+    "deer_head_lstm_layer_pre": [P, L, I, I, I, P, P, P, P, P, P, P, P, I, I, F, P, I, I, I, P],
     "deer_head_fc": [P, I, I, I, P, P, P, P, P, P, P, P, I, P, I, F, P, I, I, I, P],
     "deer_head_final": [P, I, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, I, I, P, F, I, P],
     "deer_ctl_begin_step": [P, P, I, P],

@@ -333,11 +333,14 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
                                                               const float* __restrict__ b_hh, const float* __restrict__ h_prev,
                                                               const float* __restrict__ c_prev, float* __restrict__ h_out,
                                                               float* __restrict__ c_out, int H, int B_all, int b0, int B, float eps,
-                                                              const int* ctl, int kind, int layer) {
+                                                              const int* ctl, int kind, int layer, const float* __restrict__ ghh) {
   // environments b0 .. b0+B-1 of a batch of B_all (the launcher splits a batch whose activations do not fit the LDS)
   if (head_skip(ctl, kind, layer, B_all)) return;
+  // ghh != NULL: W_hh h_prev + b_hh of this layer was computed once for the whole control step (deer_head_lstm_hh: h_prev is the state
+  // the PREVIOUS step committed, the same for every exit check of a step) - [B_all][4H], gate-major; the launch then streams W_ih only
   x_src += (long)b0 * x_bstride;
-  h_prev += (long)b0 * H; c_prev += (long)b0 * H; h_out += (long)b0 * H; c_out += (long)b0 * H;
+  if (ghh != nullptr) ghh += (long)b0 * 4 * H; else h_prev += (long)b0 * H;
+  c_prev += (long)b0 * H; h_out += (long)b0 * H; c_out += (long)b0 * H;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;                    // [B][in_dim]
   float* hs = lds + B * in_dim;       // [B][H]
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
     const int k = u * 512 + lane * 8;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      wh[u][q] = k < H ? W8<WT>::load_stream(w_hh + ((long)q * H + jr) * H + k) : W8<WT>::zero();
+      wh[u][q] = (ghh == nullptr && k < H) ? W8<WT>::load_stream(w_hh + ((long)q * H + jr) * H + k) : W8<WT>::zero();
   }
   if (x_mode == X_LN || x_mode == X_RAW) {
     rows_to_lds(x_src, x_bstride, xs, in_dim, B, x_mode == X_LN, ln_w, ln_b, eps, false);
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
       }
     }
   }
-  block_copy_to_lds(h_prev, hs, B * H, false);
+  if (ghh == nullptr) block_copy_to_lds(h_prev, hs, B * H, false);
   __syncthreads();
 
   if (j >= H) return;
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
         for (int q = 0; q < 4; ++q) acc[q][b] += W8<WT>::dot(w[q], xs + b * in_dim + k);
       }
   }
+  if (ghh == nullptr) {
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int k = u * 512 + lane * 8;
@@ -436,6 +440,7 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
         for (int q = 0; q < 4; ++q) acc[q][b] += W8<WT>::dot(w[q], hs + b * H + k);
       }
   }
+  }
   // wave totals land in every lane; lane b then does environment b's gate arithmetic (B transcendental chains in parallel)
   float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
 #pragma unroll
@@ -446,20 +451,25 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
     }
   if (lane < B) {
     const int b = lane;
-    gi += b_ih[j] + b_hh[j];
-    gf += b_ih[H + j] + b_hh[H + j];
-    gg += b_ih[2 * H + j] + b_hh[2 * H + j];
-    go += b_ih[3 * H + j] + b_hh[3 * H + j];
+    if (ghh != nullptr) {
+      const float* gp = ghh + (long)b * 4 * H + j;
+      gi += b_ih[j] + gp[0]; gf += b_ih[H + j] + gp[H]; gg += b_ih[2 * H + j] + gp[2 * H]; go += b_ih[3 * H + j] + gp[3 * H];
+    } else {
+      gi += b_ih[j] + b_hh[j];
+      gf += b_ih[H + j] + b_hh[H + j];
+      gg += b_ih[2 * H + j] + b_hh[2 * H + j];
+      go += b_ih[3 * H + j] + b_hh[3 * H + j];
+    }
     const float c2 = sigmoidf_(gf) * c_prev[b * H + j] + sigmoidf_(gi) * tanhf(gg);
     c_out[b * H + j] = c2;
     h_out[b * H + j] = sigmoidf_(go) * tanhf(c2);
   }
 }
 
-extern "C" int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w,
-                                    const float* ln_b, const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh,
-                                    const float* h_prev, const float* c_prev, float* h_out, float* c_out, int H, int B, float eps,
-                                    const int* ctl, int kind, int layer, int w_is_f32, void* stream) {
+static int launch_head_lstm_layer(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w,
+                                  const float* ln_b, const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh,
+                                  const float* h_prev, const float* c_prev, float* h_out, float* c_out, int H, int B, float eps,
+                                  const int* ctl, int kind, int layer, int w_is_f32, void* stream, const float* ghh) {
   if (in_dim <= 0 || (in_dim & 7) || H <= 0 || (H & 7) || x_mode < 0 || x_mode > 3 || (x_mode == X_LN && (ln_w == nullptr || in_dim > 2048)) ||
       ((x_mode == X_LN || x_mode == X_RAW) && (x_bstride & 3)) ||
       ((x_mode == X_POOL_MAX || x_mode == X_POOL_AVG) && T <= 0) || B <= 0 || B > HB_MAX)
@@ -485,12 +495,111 @@ extern "C" int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mo
     if (w_is_f32)
       hipLaunchKernelGGL(head_lstm_layer_kernel<float>, dim3((H + 3) / 4), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), x_src,
                          x_bstride, x_mode, T, in_dim, ln_w, ln_b, reinterpret_cast<const float*>(w_ih),
-                         reinterpret_cast<const float*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, b0, nb, eps, ctl, kind, layer);
+                         reinterpret_cast<const float*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, b0, nb, eps, ctl, kind, layer, ghh);
     else
       hipLaunchKernelGGL(head_lstm_layer_kernel<bf16_t>, dim3((H + 3) / 4), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), x_src,
                          x_bstride, x_mode, T, in_dim, ln_w, ln_b, reinterpret_cast<const bf16_t*>(w_ih),
-                         reinterpret_cast<const bf16_t*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, b0, nb, eps, ctl, kind, layer);
+                         reinterpret_cast<const bf16_t*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, b0, nb, eps, ctl, kind, layer, ghh);
   }
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+extern "C" int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w,
+                                    const float* ln_b, const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh,
+                                    const float* h_prev, const float* c_prev, float* h_out, float* c_out, int H, int B, float eps,
+                                    const int* ctl, int kind, int layer, int w_is_f32, void* stream) {
+  if (w_hh == nullptr || b_hh == nullptr || h_prev == nullptr) return DEER_ERR_SHAPE;
+  return launch_head_lstm_layer(x_src, x_bstride, x_mode, T, in_dim, ln_w, ln_b, w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, eps, ctl, kind,
+                                layer, w_is_f32, stream, nullptr);
+}
+
+// The same LSTM layer with its recurrent half taken from `ghh` = W_hh h_prev + b_hh ([B][4H], deer_head_lstm_hh): every exit check of a
+// control step starts from the state the previous step committed, so that half is the same for all of them - the launch streams W_ih only
+// (16.8 + 3 x 8.4 MB per evaluation of the 4-layer head instead of 25.2 + 3 x 16.8).  Sums are grouped as (W_ih x + b_ih) + ghh.
+extern "C" int deer_head_lstm_layer_pre(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w, const float* ln_b,
+                                        const void* w_ih, const float* b_ih, const float* ghh, const float* c_prev, float* h_out, float* c_out, int H,
+                                        int B, float eps, const int* ctl, int kind, int layer, int w_is_f32, void* stream) {
+  if (ghh == nullptr) return DEER_ERR_SHAPE;
+  return launch_head_lstm_layer(x_src, x_bstride, x_mode, T, in_dim, ln_w, ln_b, w_ih, nullptr, b_ih, nullptr, nullptr, c_prev, h_out, c_out, H, B, eps, ctl,
+                                kind, layer, w_is_f32, stream, ghh);
+}
+
+// ghh[l][b][q*H + j] = W_hh^l[q*H + j, :] . h_state[l][b] + b_hh^l[q*H + j] for up to 8 LSTM layers in ONE launch (grid: H/4 x L; wave -> hidden
+// unit j of layer l, its four gate rows; h_state [L][B][H]).  Once per control step, before the first head evaluation.
+struct deer_lstm_hh_args { const void* w[8]; const float* b[8]; };
+template <typename WT>
+__global__ __launch_bounds__(256) void head_lstm_hh_kernel(deer_lstm_hh_args a, const float* __restrict__ h_state, float* __restrict__ ghh, int H, int B) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [B][H]
+  const int l = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + wave;
+  const int jr = j < H ? j : H - 1;
+  const WT* w_hh = reinterpret_cast<const WT*>(a.w[l]);
+  typename W8<WT>::reg wh[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = u * 512 + lane * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wh[u][q] = k < H ? W8<WT>::load_stream(w_hh + ((long)q * H + jr) * H + k) : W8<WT>::zero();
+  }
+  block_copy_to_lds(h_state + (long)l * B * H, lds, B * H, false);
+  __syncthreads();
+  if (j >= H) return;
+  float acc[4][HB_MAX];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b = 0; b < HB_MAX; ++b) acc[q][b] = 0.f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = u * 512 + lane * 8;
+    if (k < H) {
+#pragma unroll
+      for (int b = 0; b < HB_MAX; ++b)
+        if (b < B) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q][b] += W8<WT>::dot(wh[u][q], lds + b * H + k);
+        }
+    }
+  }
+  for (int k = 2 * 512 + lane * 8; k < H; k += 512) {
+    typename W8<WT>::reg w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = W8<WT>::load(w_hh + ((long)q * H + j) * H + k);
+#pragma unroll
+    for (int b = 0; b < HB_MAX; ++b)
+      if (b < B) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q][b] += W8<WT>::dot(w[q], lds + b * H + k);
+      }
+  }
+  const float* bh = a.b[l];
+  float* out = ghh + (long)l * B * 4 * H;
+#pragma unroll
+  for (int b = 0; b < HB_MAX; ++b)
+    if (b < B) {
+      const float t0 = wave_sum(acc[0][b]), t1 = wave_sum(acc[1][b]), t2 = wave_sum(acc[2][b]), t3 = wave_sum(acc[3][b]);
+      if (lane == 0) {
+        float* o = out + (long)b * 4 * H + j;
+        o[0] = t0 + bh[j]; o[H] = t1 + bh[H + j]; o[2 * H] = t2 + bh[2 * H + j]; o[3 * H] = t3 + bh[3 * H + j];
+      }
+    }
+}
+
+extern "C" int deer_head_lstm_hh(const void* const* w_hh, const float* const* b_hh, int L, const float* h_state, float* ghh, int H, int B, int w_is_f32,
+                                 void* stream) {
+  if (w_hh == nullptr || b_hh == nullptr || L <= 0 || L > 8 || h_state == nullptr || ghh == nullptr || H <= 0 || (H & 7) || B <= 0 || B > HB_MAX ||
+      (size_t)B * H * sizeof(float) > 64 * 1024)
+    return DEER_ERR_SHAPE;
+  deer_lstm_hh_args a{};
+  for (int l = 0; l < L; ++l) {
+    if (w_hh[l] == nullptr || b_hh[l] == nullptr) return DEER_ERR_SHAPE;
+    a.w[l] = w_hh[l]; a.b[l] = b_hh[l];
+  }
+  const int smem = B * H * (int)sizeof(float);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (w_is_f32) hipLaunchKernelGGL(head_lstm_hh_kernel<float>, dim3((H + 3) / 4, L), dim3(256), smem, st, a, h_state, ghh, H, B);
+  else hipLaunchKernelGGL(head_lstm_hh_kernel<bf16_t>, dim3((H + 3) / 4, L), dim3(256), smem, st, a, h_state, ghh, H, B);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

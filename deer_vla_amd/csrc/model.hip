@@ -188,6 +188,8 @@ struct deer_model {
   std::vector<int> exit_ids;
   int ctl_max_layer = 0, thr_type = 0, leq = 1;
   bool persistent_layer = false;    // N1 experiment: one launch per trunk layer (DEER_PERSISTENT_LAYER=1 / deer_model_set_persistent_layer)
+  size_t ghh = 0;
+  bool head_pre = true;             // recurrent half of the LSTM head once per control step (DEER_HEAD_PRE=0: every evaluation streams W_hh again)
   bool compact = true;              // env batches: compaction of exited environments (DEER_COMPACT=0 / deer_model_set_compaction)
   // per-call overrides of the coarse operators
   const void* img_override = nullptr;
@@ -556,6 +558,7 @@ void build_workspace(deer_model* m) {
   m->h_tmp = named(m, "h_tmp", st);
   m->c_tmp = named(m, "c_tmp", st);
   m->h_shadow = named(m, "h_shadow", st);
+  m->ghh = named(m, "lstm_ghh", 4 * st);                              // W_hh h_state + b_hh of every LSTM layer, once per control step (deer_begin_step)
   m->c_shadow = named(m, "c_shadow", st);
   for (int i = 0; i < m->n_fc; ++i) m->z_fc[i] = m->wl.add((size_t)B * 2 * m->fc_dims[i] * 4);
   m->pooled = named(m, "pooled", (size_t)B * d * 4);
@@ -1250,9 +1253,16 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
       if (c.lstm_layernorm) { mode = DEER_X_LN; lnw = m->A<float>(m->lstm[l - 1].lnw); lnb = m->A<float>(m->lstm[l - 1].lnb); }
       else mode = DEER_X_RAW;
     }
-    Bracket b(m, "deer_head_lstm_layer", 0, 2.0 * 4 * H * (in_dim + H), st);
-    DEER_TRY(deer_head_lstm_layer(src, bstride, mode, T, in_dim, lnw, lnb, m->A<void>(Lw.wih), m->A<void>(Lw.whh), m->A<float>(Lw.bih), m->A<float>(Lw.bhh),
-                                  h_prev + l * lst, c_prev + l * lst, h_tmp + l * lst, c_tmp + l * lst, H, B, kEps, ctl, kind, layer, c.precision, st));
+    // control steps (the features are this step's hidden states): the recurrent half comes from deer_begin_step's pre-pass; window mode
+    // (explicit features, the state moves from frame to frame inside one call) keeps the fused form
+    const bool pre = m->head_pre && m->Lh <= 8 && feats_default;
+    Bracket b(m, "deer_head_lstm_layer", 0, 2.0 * 4 * H * (in_dim + (pre ? 0 : H)), st);
+    if (pre)
+      DEER_TRY(deer_head_lstm_layer_pre(src, bstride, mode, T, in_dim, lnw, lnb, m->A<void>(Lw.wih), m->A<float>(Lw.bih), m->Wk<float>(m->ghh) + 4 * l * lst,
+                                        c_prev + l * lst, h_tmp + l * lst, c_tmp + l * lst, H, B, kEps, ctl, kind, layer, c.precision, st));
+    else
+      DEER_TRY(deer_head_lstm_layer(src, bstride, mode, T, in_dim, lnw, lnb, m->A<void>(Lw.wih), m->A<void>(Lw.whh), m->A<float>(Lw.bih), m->A<float>(Lw.bhh),
+                                    h_prev + l * lst, c_prev + l * lst, h_tmp + l * lst, c_tmp + l * lst, H, B, kEps, ctl, kind, layer, c.precision, st));
   }
   const float* src = h_tmp + (m->Lh - 1) * lst;
   int in_dim = H, sstride = H, pro = DEER_PRO_RAW;
@@ -1402,6 +1412,7 @@ int deer_model_create(const deer_config* cfg, deer_model** out) {
   m->exit_ids.push_back(c.n_layers - 1);
   m->ctl_max_layer = m->exit_ids.back();
   if (const char* e = getenv("DEER_COMPACT")) m->compact = e[0] != '0';
+  if (const char* e = getenv("DEER_HEAD_PRE")) m->head_pre = e[0] != '0';
   if (const char* e = getenv("DEER_PERSISTENT_LAYER")) m->persistent_layer = e[0] == '1';
   *out = m;
   return DEER_OK;
@@ -1560,6 +1571,15 @@ int deer_dynamic_plan(const deer_model* m, int* need_pseudo, int* is_exit, int* 
 // ---- pieces -------------------------------------------------------------------------------------------------------------
 int deer_begin_step(deer_model* m, const int* step_info, void* stream) {
   if (m->ws == nullptr) return DEER_ERR_SHAPE;
+  if (m->head_pre && m->Lh <= 8) {
+    // every head evaluation of this step starts from the LSTM state the previous step committed (action_head.py:560-575 with
+    // update_hidden_state=False until the committing call): its recurrent half W_hh h + b_hh is computed here, once, for all layers
+    Bracket b(m, "deer_head_lstm_hh", 0, 2.0 * m->Lh * 4 * m->H * m->H, stream);
+    const void* w[8];
+    const float* bb[8];
+    for (int l = 0; l < m->Lh; ++l) { w[l] = m->A<void>(m->lstm[l].whh); bb[l] = m->A<float>(m->lstm[l].bhh); }
+    DEER_TRY(deer_head_lstm_hh(w, bb, m->Lh, m->Wk<float>(m->h_state), m->Wk<float>(m->ghh), m->H, m->B, m->c.precision, stream));
+  }
   Bracket b(m, "deer_ctl_begin_step", 0, 0, stream);
   if (compact_on(m)) return deer_ctl_begin_step_map(m->Wk<int>(m->ctl), step_info ? step_info : m->Wk<int>(m->step_info), m->B, m->Wk<int>(m->cmap), stream);
   return deer_ctl_begin_step(m->Wk<int>(m->ctl), step_info ? step_info : m->Wk<int>(m->step_info), m->B, stream);

@@ -328,6 +328,15 @@ int deer_head_lstm_layer(const float* x_src, long x_bstride, int x_mode, int T, 
                          const void* w_ih, const void* w_hh, const float* b_ih, const float* b_hh, const float* h_prev,
                          const float* c_prev, float* h_out, float* c_out, int H, int B, float eps, const int* ctl, int kind,
                          int layer, int w_is_f32, void* stream);
+/* The recurrent half of all LSTM layers once per control step: ghh[l][b][q*H + j] = W_hh^l[q*H + j, :] . h_state[l][b] + b_hh^l (L <= 8 layers in
+ * one launch; h_state [L][B][H]).  Every head evaluation of a step (pseudo / exit checks / committing call) starts from the state the previous
+ * step committed (action_head.py:560-575, update_hidden_state=False until the committing call), so this half is common to all of them. */
+int deer_head_lstm_hh(const void* const* w_hh, const float* const* b_hh, int L, const float* h_state, float* ghh, int H, int B, int w_is_f32,
+                      void* stream);
+/* deer_head_lstm_layer with its recurrent half taken from ghh ([B][4H] of this layer): streams W_ih only. */
+int deer_head_lstm_layer_pre(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w, const float* ln_b,
+                             const void* w_ih, const float* b_ih, const float* ghh, const float* c_prev, float* h_out, float* c_out, int H, int B,
+                             float eps, const int* ctl, int kind, int layer, int w_is_f32, void* stream);
 int deer_head_fc(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0, const float* lnw1,
                  const float* lnb1, const void* W0, const float* b0, const void* W1, const float* b1, int out_dim, float* dst,
                  int B, float eps, const int* ctl, int kind, int layer, int w_is_f32, void* stream);

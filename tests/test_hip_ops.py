@@ -756,6 +756,42 @@ def test_head_lstm_layer_env_batch(lib, B, in_dim, ln):
     assert rel_err(c1, c_ref) < 1e-5 and rel_err(h1, h_ref) < 1e-5          # fp32 arithmetic on both sides: summation order only
 
 
+@pytest.mark.parametrize("B,L", [(1, 4), (8, 4), (3, 2)])
+def test_lstm_recurrent_half_once_per_step_equals_the_fused_layer(lib, B, L):
+    """deer_head_lstm_hh (W_hh h_prev + b_hh of every layer in one launch) + deer_head_lstm_layer_pre (streams W_ih only) against the fused
+    deer_head_lstm_layer and the torch arithmetic: every head evaluation of a control step starts from the state the previous step committed."""
+    H, in_dim = 1024, 2048
+    hs, cs = dev(rnd(L, B, H, seed=2, scale=0.5)), dev(rnd(L, B, H, seed=3, scale=0.5))
+    whh = [dev(rnd(4 * H, H, seed=50 + l, scale=H ** -0.5), torch.bfloat16) for l in range(L)]
+    bhh = [dev(rnd(4 * H, seed=60 + l, scale=0.1)) for l in range(L)]
+    ghh = torch.full((L, B, 4 * H), float("nan"), device="cuda")
+    wp = (ctypes.c_void_p * L)(*[w.data_ptr() for w in whh])
+    bp = (ctypes.c_void_p * L)(*[b.data_ptr() for b in bhh])
+    abi.check(lib.deer_head_lstm_hh(wp, bp, L, abi.ptr(hs), abi.ptr(ghh), H, B, 0, st()), "lstm_hh")
+    torch.cuda.synchronize()
+    for l in range(L):
+        assert rel_err(ghh[l], hs[l] @ whh[l].float().t() + bhh[l]) < 1e-5
+    x = dev(rnd(B, in_dim, seed=1))
+    wih = dev(rnd(4 * H, in_dim, seed=4, scale=in_dim ** -0.5), torch.bfloat16)
+    bih = dev(rnd(4 * H, seed=6, scale=0.1))
+    out = []
+    for pre in (False, True):
+        h1, c1 = (torch.full((B, H), float("nan"), device="cuda") for _ in range(2))
+        if pre:
+            abi.check(lib.deer_head_lstm_layer_pre(abi.ptr(x), in_dim, 0, 1, in_dim, None, None, abi.ptr(wih), abi.ptr(bih), abi.ptr(ghh[0]), abi.ptr(cs[0]),
+                                                   abi.ptr(h1), abi.ptr(c1), H, B, 1e-5, None, 2, 0, 0, st()), "lstm pre")
+        else:
+            abi.check(lib.deer_head_lstm_layer(abi.ptr(x), in_dim, 0, 1, in_dim, None, None, abi.ptr(wih), abi.ptr(whh[0]), abi.ptr(bih), abi.ptr(bhh[0]),
+                                               abi.ptr(hs[0]), abi.ptr(cs[0]), abi.ptr(h1), abi.ptr(c1), H, B, 1e-5, None, 2, 0, 0, st()), "lstm")
+        torch.cuda.synchronize()
+        out.append((h1, c1))
+    assert rel_err(out[1][0], out[0][0]) < 1e-6 and rel_err(out[1][1], out[0][1]) < 1e-6      # summation grouping only
+    gates = x @ wih.float().t() + bih + hs[0] @ whh[0].float().t() + bhh[0]
+    i, f, g, o = gates.chunk(4, dim=1)
+    c_ref = torch.sigmoid(f) * cs[0] + torch.sigmoid(i) * torch.tanh(g)
+    assert rel_err(out[1][1], c_ref) < 1e-5 and rel_err(out[1][0], torch.sigmoid(o) * torch.tanh(c_ref)) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------ fp32-activation arithmetic (precise.hip)
 @pytest.mark.parametrize("M,N,K,epi", [(257, 1024, 1024, 0), (514, 4096, 1024, 1), (128, 1024, 4096, 2), (70, 132, 72, 0), (514, 1024, 1024, 3)])
 def test_gemm_f32_exact_products(lib, M, N, K, epi):
