@@ -18,7 +18,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from deer_vla_amd import synthetic as syn  # noqa: E402
+from deer_vla_amd import synthetic as syn  # noqa: E402,F401
+from golden_util import full_size_state  # noqa: E402
 from deer_vla_amd.config import DeerConfig  # noqa: E402
 from deer_vla_amd.engine import DeerEngine  # noqa: E402
 
@@ -33,7 +34,7 @@ def setup():
     assert os.path.exists(GOLD), "tests/golden/episode_batch8.npz missing (run tests/golden/make_batch_goldens.py)"
     z = np.load(GOLD)
     cfg = DeerConfig(**json.loads(bytes(z["cfg_json"]).decode()))
-    sd = syn.make_synthetic_state(cfg, int(z["seed"]), std="0.02", bf16_round=True)
+    sd = full_size_state(cfg, int(z["seed"]), std="0.02", bf16_round=True)
     B = int(z["n_envs"])
     eng = DeerEngine(cfg, sd, n_envs=B)
     return z, cfg, eng, B

@@ -11,7 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from golden_util import load  # noqa: E402
+from golden_util import load, full_size_state  # noqa: E402
 from deer_vla_amd import synthetic as syn  # noqa: E402
 from deer_vla_amd.config import deer_tiny, deer_3b  # noqa: E402
 from deer_vla_amd.engine import DeerEngine  # noqa: E402
@@ -460,7 +460,7 @@ def test_full_size_mpt1b_vitl14_steps_vs_oracle():
     """BASELINE config sizes (ViT-L/14 x2, Perceiver, MPT-1B d=2048 x12 layers, 4x1024 LSTM head): static exit
     and a short dynamic episode against the fp32 CPU oracle."""
     cfg = deer_3b(max_layer=12)
-    sd = syn.make_synthetic_state(cfg, 0, std="0.02", bf16_round=True)
+    sd = full_size_state(cfg, 0, std="0.02", bf16_round=True)
     eng = DeerEngine(cfg, sd)
     inputs = make_inputs(cfg, 3)
     model = orc.OracleDeer(sd, cfg)
@@ -575,7 +575,7 @@ def test_window_mode_calibration_full_size_batched_vs_oracle(max_layer):
     calibration deltas (value_net.py:134-160) of one 12-step window against the fp32 oracle.  max_layer = 4 is BASELINE configs[1]
     (DeeR-S, "12-step history": 5 layers built, exit ids {1, 3, 4})."""
     cfg = deer_3b(max_layer=max_layer)
-    sd = syn.make_synthetic_state(cfg, 0, std="0.02", bf16_round=True)
+    sd = full_size_state(cfg, 0, std="0.02", bf16_round=True)
     eng = DeerEngine(cfg, sd)
     W = 12
     exit_ids = cfg.exit_ids()
@@ -652,7 +652,7 @@ def test_persistent_layer_launch_is_bit_identical_to_the_twelve_launch_layer(siz
     functions as the twelve kernels, a device-wide barrier at every seam.  Hidden states of every layer, actions and exit layers must be
     BIT-identical to the default schedule (static full depth and a dynamic episode with LSTM carry), and no barrier may time out."""
     cfg = deer_tiny() if size == "tiny" else deer_3b(max_layer=12)
-    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True) if size == "tiny" else syn.make_synthetic_state(cfg, 0, std="0.02", bf16_round=True)
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True) if size == "tiny" else full_size_state(cfg, 0, std="0.02", bf16_round=True)
     ref = DeerEngine(cfg, sd)
     per = DeerEngine(cfg, None, weights_from=ref)
     per.set_persistent_layer(True)

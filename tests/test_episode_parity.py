@@ -16,7 +16,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from deer_vla_amd import synthetic as syn  # noqa: E402
+from deer_vla_amd import synthetic as syn  # noqa: E402,F401
+from golden_util import full_size_state  # noqa: E402
 from deer_vla_amd.config import DeerConfig  # noqa: E402
 from deer_vla_amd.engine import DeerEngine  # noqa: E402
 
@@ -40,7 +41,7 @@ def replay_episode(z, tag, n_steps=None, n_envs=1, precision="bf16"):
     thr = [float(t) for t in z[tag + "_thr"]]
     ref_exit, ref_act, margin = z[tag + "_exit"], z[tag + "_action"], z[tag + "_margin"]
     n = int(z["n_steps"]) if n_steps is None else min(n_steps, int(z["n_steps"]))
-    sd = syn.make_synthetic_state(cfg, int(z["seed"]), std="0.02", bf16_round=True)
+    sd = full_size_state(cfg, int(z["seed"]), std="0.02", bf16_round=True)
     eng = DeerEngine(cfg, sd, precision=precision)
     eng.configure_exit(cfg.exit_ids(), max_layer, 1)
     eng.set_thresholds(thr)
