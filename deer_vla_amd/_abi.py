@@ -40,7 +40,7 @@ SIGNATURES = {
     "deer_resadd_ln_packed": [P, P, I, L, P, P, P, P, P, P, P, P, I, I, F, P, P],
     "deer_xattn_fused_packed": [P, P, I, P, P, I, I, P, I, I, P, P, L, I, I, F, P, P],
     "deer_trunk_mpt_attn": [P, P, I, I, P, P, F, P, F, P, P, I, I, P, P],
-    "deer_resadd_ln_rows": [P, P, I, L, P, P, P, P, P, P, P, I, I, F, P, P, I, P, P, I, P],
+    "deer_resadd_ln_rows": [P, P, I, L, P, P, P, P, P, P, P, I, I, F, P, P, I, P, P, I, I, P],
     "deer_gemm_skinny_hl_active": [P, P, I, P, P, I, I, I, I, I, P, P, I, P],
     "deer_slab_gelu_split_active": [P, I, L, I, P, P, I, I, P, P, I, P],
     "deer_mpt_attn_small_hl_active": [P, I, L, I, I, P, P, F, P, F, P, P, P, I, I, I, P, P, P],
@@ -90,6 +90,7 @@ SIGNATURES = {
     "deer_model_configure_exit": [P, P, I, I, I, I],
     "deer_model_real_num_exit": [P],
     "deer_model_set_compaction": [P, I],
+    "deer_model_head_state_changed": [P],
     "deer_model_set_persistent_layer": [P, I],
     "deer_vit_l14_encode": [P, P, I, P, P],
     "deer_perceiver_resample": [P, P, I, P, P, P],

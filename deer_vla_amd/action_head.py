@@ -45,6 +45,7 @@ class DeterministicDecoder:
         else:
             e.h_state.copy_(value[0].reshape(e.h_state.shape))
             e.c_state.copy_(value[1].reshape(e.c_state.shape))
+        e._head_state_changed()
 
     def clear_hidden_state(self) -> None:
         self.hidden_state = None
@@ -54,6 +55,7 @@ class DeterministicDecoder:
         e = self.engine
         e.h_state.copy_(self.tmp_hidden_state[0])
         e.c_state.copy_(self.tmp_hidden_state[1])
+        e._head_state_changed()
         self.tmp_hidden_state = None
 
     # ---- forward ---------------------------------------------------------------------------------------------
@@ -72,12 +74,14 @@ class DeterministicDecoder:
         if update_hidden_state:
             e.h_state.copy_(e.h_tmp)
             e.c_state.copy_(e.c_tmp)
+            e._head_state_changed()
         else:
             self.tmp_hidden_state = (e.h_tmp.clone(), e.c_tmp.clone())
         pose = a[:6].view(1, 1, 6)
         grip = a[6:7].view(1, 1, 1)
         if with_gripper_logits:
             return pose, (grip, a[7:8].view(1, 1, 1))
-        if return_feature:
-            return pose, grip, feats.amax(0, keepdim=True)
+        if return_feature:                                    # the pooled token feature (action_head.py:519-520: max or mean over the tokens)
+            pooled = feats.amax(0, keepdim=True) if e.cfg.pooling == "max" else feats.mean(0, keepdim=True)
+            return pose, grip, pooled
         return pose, grip

@@ -17,11 +17,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // Device-side control blocks shared by the LLM-layer kernels and the action-head kernels (int32 words; see
 // include/deer_hip.h for the ABI view).  One block of CTL_WORDS per environment of the batch, env b at ctl + b*CTL_WORDS;
-// HOLD, SHADOW and ALL_EXITED are batch-global and live in block 0.
+// SHADOW and ALL_EXITED are batch-global and live in block 0.
 #define CTL_EXIT_FLAG 0     // 1 once the exit criterion fired in this step -> later kernels return at entry
 #define CTL_EXIT_LAYER 1    // layer index the step exited at
 #define CTL_CUR_EXIT_ID 2   // ExitController.cur_exit_id (value_net.py:285-286,294)
-#define CTL_HOLD 3          // 1 when cur_step % steps_per_stage != 0 (reuse cur_exit_id)
+#define CTL_HOLD 3          // 1 when this environment's step % steps_per_stage != 0 (reuse cur_exit_id); per environment
 #define CTL_N_EVALS 4       // number of head evaluations executed this step (diagnostics)
 #define CTL_SHADOW 5        // calibration mode: evaluate EVERY exit, commit at the first that fires, never stop
 #define CTL_COMMITTED 6     // shadow mode: a commit already happened in this step

@@ -29,16 +29,20 @@ __device__ __forceinline__ bool head_skip(const int* ctl, int kind, int layer, i
   if (ctl == nullptr) return false;
   const volatile int* c = ctl;
   if (c[CTL_ALL_EXITED] != 0) return true;
-  if (c[CTL_HOLD] != 0) {
-    if (kind == KIND_PSEUDO) return true;
-    if (kind == KIND_CHECK) {
-      bool any = false;
-      for (int b = 0; b < B; ++b)
-        any = any || (c[b * CTL_WORDS + CTL_EXIT_FLAG] == 0 && layer >= c[b * CTL_WORDS + CTL_CUR_EXIT_ID]);
-      if (!any) return true;
-    }
+  if (kind == KIND_COMMIT) return false;
+  // HOLD is per environment (the slots of an env batch are at different steps of their sub-tasks): an environment that holds its stage
+  // needs no pseudo action and only the checks from its cur_exit_id on; the launch is skipped when NO environment needs it
+  bool any_hold = false;
+  for (int b = 0; b < B; ++b) any_hold = any_hold || c[b * CTL_WORDS + CTL_HOLD] != 0;
+  if (!any_hold) return false;
+  bool any = false;
+  for (int b = 0; b < B; ++b) {
+    const volatile int* cb = c + b * CTL_WORDS;
+    if (cb[CTL_EXIT_FLAG] != 0) continue;
+    if (cb[CTL_HOLD] == 0) any = true;
+    else if (kind == KIND_CHECK && layer >= cb[CTL_CUR_EXIT_ID]) any = true;
   }
-  return false;
+  return !any;
 }
 
 // ---- host-visible mirror ------------------------------------------------------------------------------------------------
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
   if (ctl != nullptr) {
     // this environment already exited in this step, or (stage hold) does not need this evaluation
     if (ctl[CTL_EXIT_FLAG] != 0 ||
-        (ctl0[CTL_HOLD] != 0 && (kind == KIND_PSEUDO || (kind == KIND_CHECK && layer < ctl[CTL_CUR_EXIT_ID])))) {
+        (ctl[CTL_HOLD] != 0 && (kind == KIND_PSEUDO || (kind == KIND_CHECK && layer < ctl[CTL_CUR_EXIT_ID])))) {
       if (kind == KIND_CHECK && threadIdx.x == 0) check_done(ctl0, slot, B);
       return;
     }
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
       float* prev = reinterpret_cast<float*>(ctl + CTL_PREV_ACTION);
       float* outa = reinterpret_cast<float*>(ctl + CTL_OUT_ACTION);
       float* deltas = reinterpret_cast<float*>(ctl + CTL_DELTAS);
-      const bool hold = ctl0[CTL_HOLD] != 0;
+      const bool hold = ctl[CTL_HOLD] != 0;
       if (kind == KIND_PSEUDO) {
         for (int i = 0; i < 8; ++i) prev[i] = cur[i];
         ctl[CTL_PREV_REAL] = 0;                         // not a member of action_list (value_net.py:120-123)
@@ -913,8 +917,10 @@ __global__ void ctl_begin_step_kernel(int* ctl0, const int* hold_src, int B, int
     // count 0 makes get_ensemble_action() assert like the reference's `assert len(self.action_list) > 0` (value_net.py:93) instead of
     // handing back the previous step's mean
     ctl[CTL_ENS_ACTION + 7] = 0;
+    // step_info[0] = hold MASK: bit b set iff environment b is inside a stage (its own step % steps_per_stage != 0, value_net.py:285-286);
+    // one environment: 0 / 1 as before
+    ctl[CTL_HOLD] = (hold_src != nullptr) ? ((hold_src[0] >> b) & 1) : 0;
     if (b == 0) {
-      ctl[CTL_HOLD] = (hold_src != nullptr) ? hold_src[0] : 0;
       ctl[CTL_SEQ] = (hold_src != nullptr) ? hold_src[1] : 0;
       ctl[CTL_HOST_PTR] = (hold_src != nullptr) ? hold_src[2] : 0;
       ctl[CTL_HOST_PTR + 1] = (hold_src != nullptr) ? hold_src[3] : 0;

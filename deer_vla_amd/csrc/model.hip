@@ -190,6 +190,7 @@ struct deer_model {
   bool persistent_layer = false;    // N1 experiment: one launch per trunk layer (DEER_PERSISTENT_LAYER=1 / deer_model_set_persistent_layer)
   size_t ghh = 0;
   bool head_pre = true;             // recurrent half of the LSTM head once per control step (DEER_HEAD_PRE=0: every evaluation streams W_hh again)
+  bool ghh_valid = false;           // the pre-pass result matches h_state: set by deer_begin_step, cleared by deer_model_head_state_changed
   bool compact = true;              // env batches: compaction of exited environments (DEER_COMPACT=0 / deer_model_set_compaction)
   // per-call overrides of the coarse operators
   const void* img_override = nullptr;
@@ -878,6 +879,7 @@ struct RowCtx {
   const float* x_in = nullptr;    // gather source (first row operation of a compaction layer), else nullptr
   const int* cmap_old = nullptr;
   int T = 0;
+  int drop_upto = -1;             // gather: environments that exited at a layer <= drop_upto leave (the verdicts ordered before this layer)
 };
 
 bool block_hl(const deer_model* m, int R);
@@ -930,7 +932,7 @@ int resadd_split(deer_model* m, int R, const Pending* p, const float* gamma, con
   bf16_t* h = m->Wk<bf16_t>(m->xn_hl);
   if (rc != nullptr && rc->cmap != nullptr)
     return deer_resadd_ln_rows(rc->x, p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, gamma, beta, h, h + m->hl_plane_d,
-                               nullptr, x_copy, R, m->d, kEps, ctl, rc->cmap, rc->T, rc->x_in, rc->cmap_old, m->B, st);
+                               nullptr, x_copy, R, m->d, kEps, ctl, rc->cmap, rc->T, rc->x_in, rc->cmap_old, m->B, rc->drop_upto, st);
   return deer_resadd_ln_split(rc ? rc->x : m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma,
                               beta, h, h + m->hl_plane_d, nullptr, x_copy, R, m->d, kEps, ctl, st);
 }
@@ -940,7 +942,7 @@ int resadd(deer_model* m, int R, const Pending* p, const float* gamma, const flo
   Bracket b(m, "deer_resadd_ln", 0, 4.0 * R * m->d * ((p ? p->S : 0) + 3), st);
   if (rc != nullptr && rc->cmap != nullptr)
     return deer_resadd_ln_rows(rc->x, p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, gamma, beta, nullptr, nullptr,
-                               gamma ? m->Wk<float>(m->xn) : nullptr, x_copy, R, m->d, kEps, ctl, rc->cmap, rc->T, rc->x_in, rc->cmap_old, m->B, st);
+                               gamma ? m->Wk<float>(m->xn) : nullptr, x_copy, R, m->d, kEps, ctl, rc->cmap, rc->T, rc->x_in, rc->cmap_old, m->B, rc->drop_upto, st);
   return deer_resadd_ln(rc ? rc->x : m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma, beta,
                         nullptr, gamma ? m->Wk<float>(m->xn) : nullptr, x_copy, R, m->d, kEps, ctl, st);
 }
@@ -1102,6 +1104,7 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
       const int parp = cmap_parity(m, i - 1);
       first.x_in = parp ? m->Wk<float>(m->x2) : m->Wk<float>(m->x);
       first.cmap_old = m->Wk<int>(m->cmap) + parp * CMAP_WORDS;
+      first.drop_upto = i - 2;
     }
   };
   RowCtx rfirst;
@@ -1255,7 +1258,9 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
     }
     // control steps (the features are this step's hidden states): the recurrent half comes from deer_begin_step's pre-pass; window mode
     // (explicit features, the state moves from frame to frame inside one call) keeps the fused form
-    const bool pre = m->head_pre && m->Lh <= 8 && feats_default;
+    // ... and so does an evaluation enqueued after the host changed h_state without a deer_begin_step in between (reset,
+    // reset_env, a manual commit - deer_model_head_state_changed): the pre-pass result would be stale
+    const bool pre = m->head_pre && m->Lh <= 8 && feats_default && m->ghh_valid;
     Bracket b(m, "deer_head_lstm_layer", 0, 2.0 * 4 * H * (in_dim + (pre ? 0 : H)), st);
     if (pre)
       DEER_TRY(deer_head_lstm_layer_pre(src, bstride, mode, T, in_dim, lnw, lnb, m->A<void>(Lw.wih), m->A<float>(Lw.bih), m->Wk<float>(m->ghh) + 4 * l * lst,
@@ -1424,6 +1429,13 @@ int deer_model_set_persistent_layer(deer_model* m, int on) {
   return DEER_OK;
 }
 
+// the host wrote h_state (episode reset, shadow copy, manual commit): head evaluations enqueued before the next deer_begin_step fall back
+// to the fused LSTM kernel, which reads h_state itself
+int deer_model_head_state_changed(deer_model* m) {
+  m->ghh_valid = false;
+  return DEER_OK;
+}
+
 int deer_model_set_compaction(deer_model* m, int on) {
   if (m == nullptr) return DEER_ERR_SHAPE;
   m->compact = on != 0;          // takes effect for pieces enqueued / captured from now on
@@ -1579,6 +1591,7 @@ int deer_begin_step(deer_model* m, const int* step_info, void* stream) {
     const float* bb[8];
     for (int l = 0; l < m->Lh; ++l) { w[l] = m->A<void>(m->lstm[l].whh); bb[l] = m->A<float>(m->lstm[l].bhh); }
     DEER_TRY(deer_head_lstm_hh(w, bb, m->Lh, m->Wk<float>(m->h_state), m->Wk<float>(m->ghh), m->H, m->B, m->c.precision, stream));
+    m->ghh_valid = true;
   }
   Bracket b(m, "deer_ctl_begin_step", 0, 0, stream);
   if (compact_on(m)) return deer_ctl_begin_step_map(m->Wk<int>(m->ctl), step_info ? step_info : m->Wk<int>(m->step_info), m->B, m->Wk<int>(m->cmap), stream);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NT) void resadd_ln_kernel(float* __restrict__ x, co
                                                        bf16_t* __restrict__ out_bf, float* __restrict__ out_f32,
                                                        float* __restrict__ x_copy, int d, float eps, const int* ctl,
                                                        const float* __restrict__ bias, bf16_t* __restrict__ out_lo, int packed = 0,
-                                                       deer_rowmap rm = deer_rowmap{nullptr, 0, nullptr, nullptr, nullptr, 0}) {
+                                                       deer_rowmap rm = deer_rowmap{nullptr, 0, nullptr, nullptr, nullptr, 0, 0}) {
   DEER_RETURN_IF_EXITED(ctl);
   resadd_ln_body<NT>(x, slab, s_in, slab_stride, gate, gamma, beta, out_bf, out_f32, x_copy, d, eps, ctl, bias, out_lo, packed, rm, blockIdx.x);
 }
@@ -243,11 +243,11 @@ extern "C" int deer_resadd_ln_split(float* x, const float* slab, int s_in, long 
 // of `cmap` (rows_per_env rows per slot); x_in != NULL: the gathering first row operation of a compaction layer (see deer_rowmap above)
 extern "C" int deer_resadd_ln_rows(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* gamma, const float* beta,
                                    void* out_bf16, void* out_lo, float* out_f32, float* x_copy, int T_rows, int d, float eps, const int* ctl,
-                                   const int* cmap, int rows_per_env, const float* x_in, const int* cmap_old, int B, void* stream) {
+                                   const int* cmap, int rows_per_env, const float* x_in, const int* cmap_old, int B, int drop_upto, void* stream) {
   if (T_rows <= 0 || d <= 0 || (d & 3) || d > 4096 || (slab != nullptr && s_in <= 0) || (gamma != nullptr && out_bf16 == nullptr && out_f32 == nullptr) ||
       cmap == nullptr || rows_per_env <= 0 || ctl == nullptr || B <= 0 || B > 8 || (x_in != nullptr && (cmap_old == nullptr || x_in == x)))
     return DEER_ERR_SHAPE;
-  deer_rowmap rm{cmap, rows_per_env, x_in, cmap_old, ctl, B};
+  deer_rowmap rm{cmap, rows_per_env, x_in, cmap_old, ctl, B, drop_upto};
   hipLaunchKernelGGL(resadd_ln_kernel<256>, dim3(T_rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
                      gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl, static_cast<const float*>(nullptr),
                      reinterpret_cast<bf16_t*>(out_lo), 0, rm);

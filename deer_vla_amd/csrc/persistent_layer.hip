@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512) void trunk_layer_persistent_kernel(deer_trunk_
   extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
   float* lds_f = reinterpret_cast<float*>(pl_smem);
   const int bid = blockIdx.x, T = a.T, d = a.d;
-  const deer_rowmap no_map{nullptr, 0, nullptr, nullptr, nullptr, 0};
+  const deer_rowmap no_map{nullptr, 0, nullptr, nullptr, nullptr, 0, 0};
   bf16_t* xh = reinterpret_cast<bf16_t*>(a.xn_hi);
   bf16_t* xl = reinterpret_cast<bf16_t*>(a.xn_lo);
   bf16_t* hh = reinterpret_cast<bf16_t*>(a.h_hi);

@@ -8,14 +8,27 @@
 // DESTINATION row r' of the new packing: the surviving slots of the old map `cmap_old` (environments whose EXIT_FLAG is still 0) are
 // counted in slot order, row r' reads x_in / the slabs at its SOURCE row, and x (a different buffer than x_in) receives the packed rows;
 // workgroup 0 publishes the new map into `cmap` (which the later kernels of the layer read).
+// Which environments leave is decided ONLY from verdicts the launch stream has ordered in front of this kernel: an
+// environment is dropped iff it exited at a layer <= `drop_upto` (= this layer - 2: the step driver makes the trunk wait for that check).
+// The check of layer - 1 may still be running beside this kernel and raise EXIT_FLAG while the workgroups read it (consecutive exit
+// layers, exit_interval = 1): head_final stores EXIT_LAYER (= layer - 1 > drop_upto) before EXIT_FLAG, so every workgroup sees either
+// "not exited" or "exited too late to drop" and all of them build the same packing; that environment leaves one compaction later.
 struct deer_rowmap {
   const int* cmap;          // map of this layer (gather mode: WRITTEN by workgroup 0)
   int rows_per_env;         // T (0 = no map)
   const float* x_in;        // gather source (NULL = in place)
   const int* cmap_old;      // map the source rows are packed by
-  const int* ctl0;          // control blocks (EXIT_FLAG per environment)
+  const int* ctl0;          // control blocks (EXIT_FLAG / EXIT_LAYER per environment)
   int B;
+  int drop_upto;            // gather mode: deepest exit layer whose environments leave the packing
 };
+
+__device__ __forceinline__ bool rowmap_dropped(const deer_rowmap& rm, int e) {
+  const volatile int* c = (const volatile int*)rm.ctl0 + e * CTL_WORDS;
+  if (c[CTL_EXIT_FLAG] == 0) return false;
+  const int el = c[CTL_EXIT_LAYER];
+  return el >= 0 && el <= rm.drop_upto;
+}
 
 // LayerNorm arithmetic shared by every row kernel (one row per workgroup here, R rows per workgroup in norm_embed.hip): every product and
 // sum is rounded on its own (no fused multiply-add, whatever the caller's expression looks like after inlining), so that kernels with
@@ -59,7 +72,7 @@ __device__ __forceinline__ void resadd_ln_body(float* __restrict__ x, const floa
         int kept = 0, src = -1;
         for (int s = 0; s < n_old; ++s) {
           const int e = rm.cmap_old[CMAP_SLOT_ENV + s];
-          if (((const volatile int*)rm.ctl0)[e * CTL_WORDS + CTL_EXIT_FLAG] != 0) continue;
+          if (rowmap_dropped(rm, e)) continue;
           if (kept == slot) src = s * T + t;
           if (r == 0) {                                    // workgroup 0 publishes the new map
             int* cm = const_cast<int*>(rm.cmap);
@@ -73,7 +86,7 @@ __device__ __forceinline__ void resadd_ln_body(float* __restrict__ x, const floa
           cm[CMAP_N] = kept;
           for (int s = 0; s < n_old; ++s) {
             const int e = rm.cmap_old[CMAP_SLOT_ENV + s];
-            if (((const volatile int*)rm.ctl0)[e * CTL_WORDS + CTL_EXIT_FLAG] != 0) cm[CMAP_ENV_SLOT + e] = -1;
+            if (rowmap_dropped(rm, e)) cm[CMAP_ENV_SLOT + e] = -1;
           }
           for (int e = 0; e < rm.B; ++e)
             if (rm.cmap_old[CMAP_ENV_SLOT + e] < 0) cm[CMAP_ENV_SLOT + e] = -1;

@@ -283,7 +283,9 @@ class DeerEngine:
                      feats: Optional[torch.Tensor] = None, shadow: bool = False, no_ctl_final: bool = False,
                      use_mask: bool = False):
         """One DeterministicDecoder evaluation on hidden_states[layer] (action_head.py:499-611) followed by the exit gate
-        (value_net.py:120-133,277-297).  kind: PSEUDO / CHECK / COMMIT (include/deer_hip.h)."""
+        (value_net.py:120-133,277-297).  kind: PSEUDO / CHECK / COMMIT (include/deer_hip.h).  With feats=None inside a control step the
+        LSTM's recurrent half comes from deer_begin_step's pre-pass; after a host write to h_state (_head_state_changed) the fused kernel
+        reads h_state itself."""
         abi.check(self.lib.deer_head_eval(self._h, layer, T, kind, slot, 1 if force else 0, 1 if use_ctl else 0, 1 if shadow else 0,
                                           1 if no_ctl_final else 0, abi.ptr(feats), 1 if use_mask else 0, _cur_stream()),
                   "deer_head_eval")
@@ -392,6 +394,7 @@ class DeerEngine:
         self._drain_side_streams()
         self.h_state.zero_()
         self.c_state.zero_()
+        self._head_state_changed()
         self.ctl.zero_()
         self._shadow_on = False
         self.cur_step = 0
@@ -402,12 +405,19 @@ class DeerEngine:
         self._drain_side_streams()
         self.h_state[:, b].zero_()
         self.c_state[:, b].zero_()
+        self._head_state_changed()
         W = abi.CTL_WORDS
         keep = self.ctl[:W].clone() if b == 0 else None            # block 0 also holds the batch-global words (shadow flag, host ptr)
         self.ctl[b * W:(b + 1) * W].zero_()
         if keep is not None:
             for k in (abi.CTL_SHADOW, abi.CTL_HOST_PTR, abi.CTL_HOST_PTR + 1):
                 self.ctl[k] = keep[k]
+
+    def _head_state_changed(self):
+        """The host wrote h_state: the recurrent half the last deer_begin_step computed from it (W_hh h + b_hh, read by the head
+        evaluations of a control step) is stale until the next step begins; piece calls in between (enqueue_head with feats=None) fall
+        back to the fused LSTM kernel (include/deer_model.h)."""
+        self.lib.deer_model_head_state_changed(self._h)
 
     def dynamic_plan(self):
         """Per layer of the dynamic step: (layer, need_pseudo, is_exit, exit slot).  mosaic_gpt_3b.py:397-443; computed by
@@ -533,9 +543,16 @@ class DeerEngine:
         return T, use_mask
 
     def step(self, rgb, gripper, ids, mask=None, exit_id: Optional[int] = None, use_graph: bool = True, sync: bool = True,
-             shadow: bool = False, state: Optional[torch.Tensor] = None):
+             shadow: bool = False, state: Optional[torch.Tensor] = None, env_steps: Optional[Sequence[int]] = None):
         """state: robot_obs of every environment, (B, ..., 15) (eval_utils.py:324-332) - read only by a ``use_state`` model, whose
-        head embeds (robot_obs[:6], robot_obs[-1]) into the pooled feature (action_head.py:524-536)."""
+        head embeds (robot_obs[:6], robot_obs[-1]) into the pooled feature (action_head.py:524-536).
+        env_steps: the step index of every environment inside ITS sub-task (what the reference hands to
+        ``ExitController.set_timestep`` per rollout, eval_utils.py:662-663): with ``steps_per_stage`` > 1 environment b re-uses its
+        previous exit while env_steps[b] % steps_per_stage != 0 (value_net.py:285-286).  Default: the engine's own step counter for
+        every environment."""
+        self._env_steps = None if env_steps is None else [int(v) for v in env_steps]
+        if self._env_steps is not None:
+            assert len(self._env_steps) == self.B, (len(self._env_steps), self.B)
         if getattr(self.cfg, "use_state", False):
             if exit_id is None:
                 raise NotImplementedError("use_state has no dynamic exit: the reference's ActionValueNet calls the head without a state "
@@ -564,7 +581,12 @@ class DeerEngine:
             self._shadow_on = bool(shadow)
         if exit_id is not None and exit_id < 0:
             exit_id += self.cfg.n_layers
-        hold = 1 if (exit_id is None and self.cur_step % self.steps_per_stage != 0) else 0
+        hold = 0                                                  # bit b: environment b is inside a stage (csrc/head.hip: CTL_HOLD per environment)
+        if exit_id is None and self.steps_per_stage != 1:
+            steps = getattr(self, "_env_steps", None) or [self.cur_step] * self.B
+            for b, t in enumerate(steps):
+                if t % self.steps_per_stage != 0:
+                    hold |= 1 << b
         seg_mode = self.segmented and use_graph and sync and exit_id is None and not shadow
         self._seq = (self._seq + 1) & 0xFFFFFF
         if self._seq == 0:                                        # wrap: stale mirror words would compare as "newer"
@@ -601,6 +623,7 @@ class DeerEngine:
         if shadow:
             self.h_state.copy_(self.h_shadow)
             self.c_state.copy_(self.c_shadow)
+            self._head_state_changed()
         self.ctl_host.copy_(self.ctl, non_blocking=True)
         self.cur_step += 1
         if not sync:
@@ -950,6 +973,7 @@ class DeerEngine:
         if commit:
             self.h_state.copy_(self.h_tmp)
             self.c_state.copy_(self.c_tmp)
+            self._head_state_changed()
         return self.action_dbg.clone()
 
     def generate_values(self, hidden: torch.Tensor, rand_layers, threshold_type: str = "L2", group: int = 8) -> torch.Tensor:

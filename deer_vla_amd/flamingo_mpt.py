@@ -343,16 +343,19 @@ class MPTFlamingo(nn.Module):
                     break
         return CausalLMOutputWithPast(logits=[1.0], hidden_states=hidden, exit_layer=b)
 
-    def step_env_batch(self, vision_x, lang_x, attention_mask, vision_gripper, exit_controller=None, exit_id=None, ensemble=False):
+    def step_env_batch(self, vision_x, lang_x, attention_mask, vision_gripper, exit_controller=None, exit_id=None, ensemble=False,
+                       env_steps=None):
         """One control step of ALL n_envs environments (north_star: one env batch per rank): vision_x / vision_gripper
         (n_envs, ..., 3, S, S), lang_x / attention_mask (n_envs, T) right-padded.  Returns (pose (n_envs, 6), gripper prob (n_envs,),
-        exit layers list); ``ensemble``: the mean of every environment's last two exit-check actions instead (eval_utils.py:457-461).  Every environment exits at its own layer on the device; LSTM state per environment."""
+        exit layers list); ``ensemble``: the mean of every environment's last two exit-check actions instead (eval_utils.py:457-461).  Every environment exits at its own layer on the device; LSTM state per environment.
+        ``env_steps``: every environment's step index inside its own sub-task - the per-rollout ``set_timestep(step)`` of the reference
+        (eval_utils.py:662-663) for a controller with ``steps_per_stage`` > 1 (value_net.py:285-286); default: the controller's cur_step."""
         e = self.engine
         ctl = getattr(exit_controller, "module", exit_controller)
         if exit_id is None:
             assert isinstance(ctl, ExitController), "env batches take the native controller (device-side exit gate)"
             self._sync_controller(ctl)
-        r = e.step(vision_x, vision_gripper, lang_x, attention_mask, exit_id=exit_id)
+        r = e.step(vision_x, vision_gripper, lang_x, attention_mask, exit_id=exit_id, env_steps=env_steps)
         r = r if isinstance(r, list) else [r]
         pk, gk = ("ens_pose", "ens_gripper") if ensemble else ("pose", "gripper")    # ensemble: get_ensemble_action per environment
         return torch.stack([x[pk] for x in r]), torch.tensor([x[gk] for x in r]), [x["exit_layer"] for x in r]

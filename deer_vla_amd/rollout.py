@@ -379,11 +379,9 @@ class BatchedModelWrapper:
         self.text_process_fn = functools.partial(preprocess_text_calvin, tokenizer=tokenizer)
         self.image_process_fn = functools.partial(preprocess_image, image_processor=image_processor)
         self.exit_controller, self.exit_id = exit_controller, exit_id
-        ctl = getattr(exit_controller, "module", exit_controller)
-        if ctl is not None and getattr(ctl, "steps_per_stage", 1) != 1:
-            # the slots of an env batch are at different steps of their sub-tasks, the hold state (value_net.py:285-286) is one word
-            # per batch on the device: the reference's per-rollout `set_timestep(step)` has no batched equivalent
-            raise NotImplementedError("env batches need an ExitController with steps_per_stage == 1")
+        # steps_per_stage > 1 (value_net.py:285-286, eval_calvin.py:340): the slots of an env batch are at different steps of their
+        # sub-tasks, so the stage hold is per environment on the device (csrc/head.hip: CTL_HOLD of every control block) and `step` takes
+        # every slot's own step index - the per-rollout `set_timestep(step)` of eval_utils.py:662-663
         self.replan = m.replan
         self.current_exit_layers = [-1] * self.B
         self._goals: List[Optional[str]] = [None] * self.B
@@ -420,7 +418,8 @@ class BatchedModelWrapper:
             self._blank = torch.zeros_like(ref)
         return torch.stack([x if x is not None else self._blank for x in live])
 
-    def step(self, obs_list, goals):
+    def step(self, obs_list, goals, env_steps=None):
+        """env_steps: step index of every slot inside its sub-task (idle slots: 0); only read by a controller with steps_per_stage > 1."""
         rgb = self._frames(obs_list, "rgb_static")
         grip = self._frames(obs_list, "rgb_gripper")
         goals = [g if g is not None else "idle" for g in goals]
@@ -435,7 +434,7 @@ class BatchedModelWrapper:
             pose, g, exits = self.model.module.step_env_batch(rgb.to(self.cast_type).cuda(non_blocking=True), ids, mask,
                                                               grip.to(self.cast_type).cuda(non_blocking=True),
                                                               exit_controller=self.exit_controller, exit_id=self.exit_id,
-                                                              ensemble=self.use_action_ensemble)
+                                                              ensemble=self.use_action_ensemble, env_steps=env_steps)
         self.current_exit_layers = exits
         act = torch.cat([pose, ((g > 0.5).to(pose.dtype).unsqueeze(1) - 0.5) * 2], dim=1)      # eval_utils.py:454-464
         return act.to(torch.float16).numpy()
@@ -492,10 +491,11 @@ def evaluate_policy_batched(model: BatchedModelWrapper, envs: Sequence, eval_seq
         for b in range(B):
             next_chain(b)
         while any(s is not None for s in slot):
-            if model.exit_controller is not None:                  # eval_utils.py:662-663; steps_per_stage == 1 on this path
+            if model.exit_controller is not None:                  # eval_utils.py:662-663: every slot's own step index goes with the step
                 model.exit_controller.module.set_timestep(0)
             obs = [envs[b].get_obs() if slot[b] is not None else None for b in range(B)]
-            acts = model.step(obs, [slot[b]["goal"] if slot[b] is not None else None for b in range(B)])
+            acts = model.step(obs, [slot[b]["goal"] if slot[b] is not None else None for b in range(B)],
+                              env_steps=[slot[b]["step"] if slot[b] is not None else 0 for b in range(B)])
             for b in range(B):
                 st = slot[b]
                 if st is None:

@@ -28,7 +28,7 @@ extern "C" {
 #define DEER_ERR_LAUNCH 2
 
 /* control block layout (32-bit words); one block per environment of the batch (env b at ctl + b*DEER_CTL_WORDS);
- * HOLD, SHADOW and ALL_EXITED are batch-global (block 0) */
+ * SHADOW and ALL_EXITED are batch-global (block 0); HOLD is per environment: deer_ctl_begin_step spreads bit b of step_info[0] into block b */
 #define DEER_CTL_EXIT_FLAG 0
 #define DEER_CTL_EXIT_LAYER 1
 #define DEER_CTL_CUR_EXIT_ID 2
@@ -241,7 +241,7 @@ int deer_resadd_ln_multirow(float* x, const float* slab, int s_in, long slab_str
  * (media K/V, text_time, key mask, control blocks) stay in environment order and are reached through the map. ---- */
 int deer_resadd_ln_rows(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* gamma, const float* beta, void* out_bf16,
                         void* out_lo, float* out_f32, float* x_copy, int T_rows, int d, float eps, const int* ctl, const int* cmap, int rows_per_env,
-                        const float* x_in, const int* cmap_old, int B, void* stream);   /* x_in != NULL: gather the surviving rows (first row op of a compaction layer), publish the new map into cmap */
+                        const float* x_in, const int* cmap_old, int B, int drop_upto, void* stream);   /* x_in != NULL: gather the surviving rows (first row op of a compaction layer: environments that exited at a layer <= drop_upto leave), publish the new map into cmap */
 int deer_gemm_skinny_hl_active(const void* A_hi, const void* A_lo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk, int slab_rows,
                                const int* ctl, const int* cmap, int rows_per_env, void* stream);
 int deer_slab_gelu_split_active(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows, int C, const int* ctl,

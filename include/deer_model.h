@@ -98,13 +98,18 @@ int deer_perceiver_resample(deer_model* m, const float* tokens, int n_images, vo
 /* ids: int64 [n_envs,T] device; key_mask: uint8 [n_envs,T] (0 = padding) or NULL; media_bf16: [n_envs*128, W] or NULL (workspace);
  * exit_id >= 0: static exit (flamingo_mpt.py:446-461), exit_id < 0: dynamic exit with the configured controller;
  * thresholds: device f32[16] or NULL (= the model's own "thresholds" buffer); step_info: device-visible int32[4]
- * {hold, sequence number, host mirror ptr lo, hi} or NULL.  Results: control blocks ("ctl": exit layer, action, deltas per
+ * {hold mask (bit b: environment b is inside a stage, its step % steps_per_stage != 0), sequence number, host mirror ptr lo, hi} or NULL.  Results: control blocks ("ctl": exit layer, action, deltas per
  * environment), hidden states ("hidden"), committed LSTM state ("h_state"/"c_state"). */
 int deer_llm_early_exit(deer_model* m, const long long* ids, const unsigned char* key_mask, int T, const void* media_bf16,
                         int exit_id, int shadow, const float* thresholds, const int* step_info, void* stream);
 
 /* ---- pieces (the same work in host-schedulable units; engine.py replays them as HIP-graph pieces) ------------------ */
+/* resets the control blocks AND computes the recurrent half (W_hh h + b_hh of every LSTM layer) of this step's head evaluations from the
+ * committed LSTM state.  deer_head_eval(feats = NULL) uses that pre-pass result while it is valid: call deer_model_head_state_changed()
+ * after writing h_state from the host (episode reset, manual commit) - evaluations enqueued before the next deer_begin_step then stream
+ * W_hh themselves (fused kernel, same result up to summation order). */
 int deer_begin_step(deer_model* m, const int* step_info, void* stream);
+int deer_model_head_state_changed(deer_model* m);
 /* chain: -1 = all camera frames batched on one stream, c >= 0 = chain c of the multi-stream schedule (its own workspace);
  * part: 0 whole tower, 1 patch embedding + first blocks, 2 the rest + Perceiver; media_kv: also project K|V of every x-attn layer */
 int deer_vision(deer_model* m, int chain, int part, int media_kv, void* stream);

@@ -347,8 +347,9 @@ def test_padding_mask_and_text_lengths(tiny):
         assert float((r["pose"] - ref["logits"][0].reshape(-1)).abs().max()) < ACTION_TOL
 
 
-def oracle_episode_margins(cfg, sd, inputs, thresholds, max_layer, steps_per_stage=1):
-    """oracle_episode + the relative margin |delta - thr| / thr of the tightest exit check the oracle evaluated at each step"""
+def oracle_episode_margins(cfg, sd, inputs, thresholds, max_layer, steps_per_stage=1, restart=None):
+    """oracle_episode + the relative margin |delta - thr| / thr of the tightest exit check the oracle evaluated at each step.
+    restart: step at which this environment begins a NEW sub-task (eval_utils.py:252-277 reset, its step index counts from 0 again)"""
     model = orc.OracleDeer(sd, cfg)
     model.set_all_exit_window_size(1)
     vn = RecVN(cfg.exit_ids(), model.extra_exit, cfg.exit_interval, 1, "L2")
@@ -358,7 +359,10 @@ def oracle_episode_margins(cfg, sd, inputs, thresholds, max_layer, steps_per_sta
     thr_by_exit = dict(zip(cfg.exit_ids(), thresholds))
     outs = []
     for s, (rgb, grip, ids, mask) in enumerate(inputs):
-        ctl.set_timestep(s)
+        if restart is not None and s == restart:
+            model.clear_all_exit_memory()
+            vn.reset_actions()
+        ctl.set_timestep(s if restart is None or s < restart else s - restart)
         n0 = len(vn.rec)
         o = model.forward(rgb, ids, mask, grip, dynamic_early_exit=True, exit_controller=ctl)
         m = [abs(v - thr_by_exit[i]) / thr_by_exit[i] for (i, v) in vn.rec[n0:] if thr_by_exit[i] < 1e4]
@@ -369,12 +373,12 @@ def oracle_episode_margins(cfg, sd, inputs, thresholds, max_layer, steps_per_sta
 BAND = 1e-2
 
 
-def run_env_batch_against_independent_oracles(cfg, sd, eng, env_inputs, thr, sps, n_steps, B):
+def run_env_batch_against_independent_oracles(cfg, sd, eng, env_inputs, thr, sps, n_steps, B, restarts=None):
     """Every environment of the batch must behave exactly like an independent single-environment oracle run.  Rule (the same
     as tests/test_episode_parity.py): exit layers are compared at every step whose oracle decision is not knife-edge (margin >
     1e-2); an environment whose knife-edge decision flips is reported and left out FROM THAT STEP ON (its LSTM history
     diverged; a batch cannot be re-aligned per environment).  Returns (#compared env-steps, flips, seen exit layers)."""
-    refs = [oracle_episode_margins(cfg, sd, env_inputs[e], thr, 12, sps) for e in range(B)]
+    refs = [oracle_episode_margins(cfg, sd, env_inputs[e], thr, 12, sps, None if restarts is None else restarts[e]) for e in range(B)]
     eng.configure_exit(cfg.exit_ids(), 12, sps)
     eng.set_thresholds(thr)
     eng.reset()
@@ -389,7 +393,13 @@ def run_env_batch_against_independent_oracles(cfg, sd, eng, env_inputs, thr, sps
         for e in range(B):                                         # right-pad to the longest instruction of the batch
             te = env_inputs[e][s][2].shape[1]
             ids[e, :te], mask[e, :te] = env_inputs[e][s][2][0], True
-        out = eng.step(rgb, grip, ids, mask, use_graph=(s >= 2))
+        env_steps = None
+        if restarts is not None:                                   # every environment's step index inside ITS sub-task
+            for e in range(B):
+                if restarts[e] is not None and s == restarts[e]:
+                    eng.reset_env(e)
+            env_steps = [s if restarts[e] is None or s < restarts[e] else s - restarts[e] for e in range(B)]
+        out = eng.step(rgb, grip, ids, mask, use_graph=(s >= 2), env_steps=env_steps)
         out = out if isinstance(out, list) else [out]
         assert len(out) == B
         for e in range(B):
@@ -421,6 +431,24 @@ def test_batched_environments_match_independent_oracle_runs(B, sps):
     env_inputs = [[syn.synthetic_step_inputs(cfg, s, rank=e, text_len=T, text_seed=7 + e) for s in range(n_steps)] for e in range(B)]
     thr, _ = probe_thresholds(cfg, sd, env_inputs[0], 12, sps)
     compared, flips, seen = run_env_batch_against_independent_oracles(cfg, sd, eng, env_inputs, thr, sps, n_steps, B)
+    assert compared >= 0.8 * B * n_steps, (compared, flips)
+    assert len(seen) > 1
+
+
+@pytest.mark.parametrize("B,sps,restarts", [(4, 3, [None, 4, 5, 7]), (3, 2, [None, 3, 6])])
+def test_env_batch_with_steps_per_stage_and_staggered_sub_tasks(B, sps, restarts):
+    """``steps_per_stage`` > 1 (value_net.py:285-286, eval_calvin.py:340) for ENV BATCHES: the slots of a batch are at different steps of
+    their sub-tasks (eval_utils.py:662-663 hands every rollout's own step to ``set_timestep``), so the stage hold is per environment on
+    the device (CTL_HOLD of every control block, bit b of the step info).  Here the environments restart their sub-tasks at different
+    batch steps - their hold phases drift apart - and each must still match an independent single-environment oracle run that sees the
+    same resets and step indices."""
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
+    eng = DeerEngine(cfg, sd, n_envs=B)
+    n_steps, T = 14, 11
+    env_inputs = [[syn.synthetic_step_inputs(cfg, s, rank=e, text_len=T, text_seed=7 + e) for s in range(n_steps)] for e in range(B)]
+    thr, _ = probe_thresholds(cfg, sd, env_inputs[0], 12, sps)
+    compared, flips, seen = run_env_batch_against_independent_oracles(cfg, sd, eng, env_inputs, thr, sps, n_steps, B, restarts)
     assert compared >= 0.8 * B * n_steps, (compared, flips)
     assert len(seen) > 1
 
@@ -601,23 +629,28 @@ def test_window_mode_calibration_full_size_batched_vs_oracle(max_layer):
     assert float((vals - vref).abs().max()) < 5e-3, (vals, vref)
 
 
-@pytest.mark.parametrize("B,lens,use_graph", [(8, None, True), (8, None, False), (3, [14, 9, 11], True), (8, [32, 14, 20, 9, 27, 16, 31, 11], True), (2, None, True)])
-def test_compaction_of_exited_environments_is_bit_identical_to_the_uncompacted_batch(B, lens, use_graph):
+@pytest.mark.parametrize("B,lens,use_graph,exits", [(8, None, True, None), (8, None, False, None), (3, [14, 9, 11], True, None),
+                                                   (8, [32, 14, 20, 9, 27, 16, 31, 11], True, None), (2, None, True, None),
+                                                   (8, None, True, [1, 2, 3, 4, 5]), (8, None, False, [1, 2, 3, 4, 5]), (4, [14, 9, 11, 20], True, [1, 2, 3, 4, 5])])
+def test_compaction_of_exited_environments_is_bit_identical_to_the_uncompacted_batch(B, lens, use_graph, exits):
     """SURVEY 8(f).4 / VERDICT r3 item 3a: in an env batch the rows of an environment that has exited leave the trunk two layers after its
     exit check (gathering first row operation + row map, csrc/model.hip).  No arithmetic depends on a row's position, so every
     environment's exit layer, action, deltas and LSTM state must be BIT-identical to the same engine with compaction switched off -
     over an episode in which the environments leave at different layers (thresholds spread so that every exit is used), with mixed
     instruction lengths (padding masks follow the environment, not the slot), 256 trunk rows (two row blocks), graph pieces and eager
-    single-stream enqueueing."""
+    single-stream enqueueing.  ``exits``: CONSECUTIVE exit layers - every layer from 2 on is then a compaction layer and
+    the exit check of layer i - 1 is still running on the side stream while layer i gathers: the gather may only drop environments whose
+    verdict the stream has ordered (exit layer <= i - 2, csrc/resadd_body.h), else workgroups could disagree about the packing."""
     cfg = deer_tiny()
     sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
-    n_steps = 10
+    n_steps = 10 if exits is None else 16
     lens = lens or [11] * B
     eng_on = DeerEngine(cfg, sd, n_envs=B)
     eng_off = DeerEngine(cfg, None, n_envs=B, weights_from=eng_on)
     eng_off.set_compaction(False)
     env_inputs = [[syn.synthetic_step_inputs(cfg, s, rank=e, text_len=lens[e], text_seed=7 + e) for s in range(n_steps)] for e in range(B)]
     thr, _ = probe_thresholds(cfg, sd, env_inputs[0], 12, 1)
+    exit_ids = cfg.exit_ids() if exits is None else exits
     T = max(lens)
     ids = torch.full((B, T), 1, dtype=torch.long)
     mask = torch.zeros(B, T, dtype=torch.bool)
@@ -626,8 +659,22 @@ def test_compaction_of_exited_environments_is_bit_identical_to_the_uncompacted_b
         mask[e, :lens[e]] = True
     ids, mask = ids.cuda(), mask.cuda()
     seen = set()
+    if exits is not None:
+        # thresholds of the denser exit list: the per-exit median of the deltas of a shadow episode (every exit evaluated, none taken) -
+        # about half of the environments that reach an exit leave there, so ADJACENT layers both see exits
+        eng_off.configure_exit(exit_ids, 12, 1)
+        eng_off.set_thresholds([1e-9] * (len(exit_ids) - 1) + [1e5])
+        eng_off.reset()
+        rec = [[] for _ in exit_ids]
+        for s in range(6):
+            rgb = torch.stack([env_inputs[e][s][0] for e in range(B)]).cuda().bfloat16()
+            grip = torch.stack([env_inputs[e][s][1] for e in range(B)]).cuda().bfloat16()
+            for r in eng_off.step(rgb, grip, ids, mask if len(set(lens)) > 1 else None, use_graph=False, shadow=True):
+                for k in range(len(exit_ids)):
+                    rec[k].append(float(r["deltas"][k]))
+        thr = [float(np.median(v)) for v in rec[:-1]] + [1e5]
     for eng in (eng_on, eng_off):
-        eng.configure_exit(cfg.exit_ids(), 12, 1)
+        eng.configure_exit(exit_ids, 12, 1)
         eng.set_thresholds(thr)
         eng.reset()
     for s in range(n_steps):
@@ -644,6 +691,8 @@ def test_compaction_of_exited_environments_is_bit_identical_to_the_uncompacted_b
         torch.cuda.synchronize()
         assert torch.equal(eng_on.h_state, eng_off.h_state) and torch.equal(eng_on.c_state, eng_off.c_state), s
     assert len(seen) > 1, seen                                    # environments really left at different layers
+    if exits is not None:                                         # ... and at ADJACENT layers (the case the gather's rule exists for)
+        assert any(l + 1 in seen for l in seen), seen
 
 
 @pytest.mark.parametrize("size", ["tiny", "3b"])

@@ -308,7 +308,7 @@ def test_env_batch_takes_the_references_long_instructions_and_rejects_what_does_
     14 words = 17 tokens with "<image>", "<|endofchunk|>" and eos even at one token per word; tests/golden/long_instructions.json, made by
     tests/golden/make_long_instructions.py) passes the up-front check, and a batch holding the longest ones rolls out.  What cannot fit
     still fails BEFORE the run starts with a clear error: the fp32 arithmetic keeps 128 rows (16 tokens at 8
-    environments); a controller with steps_per_stage > 1 is refused at construction."""
+    environments); a controller with steps_per_stage > 1 rolls out (per-environment stage hold; parity: tests/test_engine_parity.py)."""
     import json
     import os
     from deer_vla_amd import synthetic as syn
@@ -337,9 +337,13 @@ def test_env_batch_takes_the_references_long_instructions_and_rejects_what_does_
     out = ro.evaluate_policy_batched(w, [ro.SyntheticEnv(seed=b) for b in range(8)], [(None, ["a", "b"]), (None, ["c", "a"])] * 4, ann,
                                      ro.steps_task_checker(2), ep_len=3)
     assert out["n_chains"] == 8 and out["n_steps"] > 0
+    # steps_per_stage > 1 (eval_calvin.py:340): the hold is per environment on the device, the harness hands every slot's own step index
     ctl3 = ExitController(vn, model.get_all_exit_idx(), steps_per_stage=3, max_layer=cfg.early_exit_layer + 1)
-    with pytest.raises(NotImplementedError):
-        ro.BatchedModelWrapper(model, tok, proc, torch.float32, exit_controller=ctl3)
+    ctl3._set_threshold_value([0.02] * (ctl3.real_num_exit - 1) + [1e5])
+    w3 = ro.BatchedModelWrapper(model, tok, proc, torch.float32, exit_controller=ctl3)
+    out3 = ro.evaluate_policy_batched(w3, [ro.SyntheticEnv(seed=b) for b in range(8)], [(None, ["a", "b"]), (None, ["c", "a"])] * 4, ann,
+                                      ro.steps_task_checker(4), ep_len=5)
+    assert out3["n_chains"] == 8 and out3["n_steps"] > 0
     model32, proc32, tok32, _, ctl32 = build("fp32")
     w32 = ro.BatchedModelWrapper(model32, tok32, proc32, torch.float32, exit_controller=ctl32)
     with pytest.raises(ValueError, match="n_envs"):
