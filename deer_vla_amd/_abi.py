@@ -70,6 +70,7 @@ SIGNATURES = {
     "deer_head_lstm_layer_pre": [P, L, I, I, I, P, P, P, P, P, P, P, P, I, I, F, P, I, I, I, P],
     "deer_head_fc": [P, I, I, I, P, P, P, P, P, P, P, P, I, P, I, F, P, I, I, I, P],
     "deer_head_final": [P, I, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, I, I, P, F, I, P],
+    "deer_head_final_multi": [P, I, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, I, I, P, F, I, I, P, P],
     "deer_ctl_begin_step": [P, P, I, P],
     "deer_preprocess_frames": [P, I, I, I, I, P, P, P, P, P, P],
     "deer_preprocess_scratch_bytes": [I, I, I, I],
@@ -102,6 +103,8 @@ SIGNATURES = {
     "deer_llm_embed": [P, I, P],
     "deer_llm_layer": [P, I, I, I, I, I, I, P],
     "deer_head_eval": [P, I, I, I, I, I, I, I, I, P, I, P],
+    "deer_model_layerwise_head": [P, I],
+    "deer_head_eval_layerwise": [P, I, I, I, I, P],
     "deer_step_enqueue": [P, I, I, I, I, P, P],
     "deer_dynamic_plan": [P, P, P, P, I],
     "deer_model_n_chains": [P],
@@ -145,7 +148,7 @@ class DeerConfigC(ctypes.Structure):
         "cross_attn_every_n_layers", "xattn_heads", "xattn_dim_head", "xattn_ff_mult", "media_token_id",
         "mpt7b_names", "exit_interval",
         "head_hidden", "lstm_num_layers", "lstm_layernorm", "mlp_layernorm", "mlp_num_hidden_layers", "pooling_avg",
-        "n_envs", "max_text_len", "n_chains", "precision", "use_state", "sep_resampler")]
+        "n_envs", "max_text_len", "n_chains", "precision", "use_state", "sep_resampler", "multi_step_action", "layerwise_exit_eval")]
 
 
 PRECISIONS = {"bf16": 0, "fp32": 1}
@@ -170,6 +173,8 @@ def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0, precisio
     c.precision = PRECISIONS[precision]
     c.use_state = 1 if getattr(cfg, "use_state", False) else 0
     c.sep_resampler = 1 if getattr(cfg, "sep_resampler", False) else 0
+    c.multi_step_action = int(getattr(cfg, "multi_step_action", 1))
+    c.layerwise_exit_eval = 1 if getattr(cfg, "layerwise_exit_eval", False) else 0
     return c
 
 

@@ -77,10 +77,11 @@ class DeterministicDecoder:
             e._head_state_changed()
         else:
             self.tmp_hidden_state = (e.h_tmp.clone(), e.c_tmp.clone())
-        pose = a[:6].view(1, 1, 6)
-        grip = a[6:7].view(1, 1, 1)
+        A = e.A                                              # multi_step_action: 6 A pose + A gripper outputs (action_head.py:472-473)
+        pose = a[:6 * A].view(1, 1, 6 * A)
+        grip = a[6 * A:7 * A].view(1, 1, A)
         if with_gripper_logits:
-            return pose, (grip, a[7:8].view(1, 1, 1))
+            return pose, (grip, a[7 * A:8 * A].view(1, 1, A))
         if return_feature:                                    # the pooled token feature (action_head.py:519-520: max or mean over the tokens)
             pooled = feats.amax(0, keepdim=True) if e.cfg.pooling == "max" else feats.mean(0, keepdim=True)
             return pose, grip, pooled

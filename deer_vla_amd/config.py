@@ -57,9 +57,15 @@ class DeerConfig:
     # ---- variants the reference parses from checkpoint names (eval_calvin.py:355-377); off in the released DeeR checkpoints --------
     use_state: bool = False         # DeterministicDecoder adds an embedding of the robot state to the pooled feature (action_head.py:524-536)
     sep_resampler: bool = False     # the gripper camera has its own PerceiverResampler weights (flamingo_mpt.py:132-134,656-659)
+    # ---- harness ablations / checkpoint-name variants (round 5) ---------------------------------------------------------------------
+    multi_step_action: int = 1      # the heads emit 6 * A pose values and A gripper values per call (action_head.py:458,472-473; "Nstep" in a
+                                    # checkpoint name, eval_calvin.py:384-387); ModelWrapper executes the first multi_execution of them
+    layerwise_exit_eval: bool = False   # the action of exit layer k comes from that layer's OWN head lm_exits[k] / lm_head (flamingo_mpt.py:253-261,
+                                        # 450-457; eval_calvin.py:330,530,539) instead of extra_exit; the exit DECISION stays with extra_exit
 
     supports_use_state = True       # read by factory.create_model_and_transforms (keywords without this marker raise)
     supports_sep_resampler = True
+    MAX_MULTI_STEP = 8              # csrc/head.hip: 7 * A outputs per head evaluation, A <= 8
 
     # ------------------------------------------------------------------ derived
     @property
@@ -97,6 +103,13 @@ class DeerConfig:
         """``MPTFlamingo.get_all_exit_idx`` (flamingo_mpt.py:239-250,268-270)."""
         ids = list(range(self.exit_interval - 1, self.early_exit_layer, self.exit_interval))
         return ids + [self.n_layers - 1]
+
+    def layerwise_heads(self) -> List[tuple]:
+        """(state-dict prefix, exit layer) of the per-layer heads, in the order the reference registers them: ``lm_exit_modules.j`` is the
+        head of the j-th internal exit (``self.lm_exits`` is a plain dict, ``nn.ModuleList(self.lm_exits.values())`` carries the
+        parameters: flamingo_mpt.py:239-244), ``lm_head`` serves the last layer (:453-454)."""
+        ids = self.exit_ids()
+        return [(f"lm_exit_modules.{j}.", e) for j, e in enumerate(ids[:-1])] + [("lm_head.", ids[-1])]
 
     def has_xattn(self, layer_idx: int) -> bool:
         """flamingo_lm.py:176: x-attn on layers where (idx+1) % every_n == 0."""

@@ -203,6 +203,162 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
   }   // query tiles of this wave
 }
 
+// ------------------------------------------------------------------------------------------------
+// (1b) ViT self-attention, round 5 (csrc/attention.hip::attn_vit_kernel): the same arithmetic as attn_mfma_kernel<false, ...> - same
+// MFMAs in the same order, scores scaled, row maximum subtracted, exp, sum, P rounded to bf16, O scaled by 1 / sum - restructured
+// around what the counters said about the old kernel at 16 frames (profiles/r05_b_attn_pmc_before.txt: 24.0 us, MFMA busy 8 %, the
+// LDS busy 35 % of the launch with 56 % of those cycles in bank conflicts, 1 590 VALU instructions per wave):
+//  * V stays ROW-major in LDS ([key][72], plain 16-byte stores, conflict-free) and the P*V operand is fetched with the gfx950 transpose
+//    read ds_read_b64_tr_b16: a 16-lane group hands in the 16 eight-byte pieces of a [4 keys][16 d] block and lane c receives column c
+//    (tools/tr_probe.hip) - exactly the k-slot layout the old kernel built with an 8-way bank-conflicted transposing store
+//    (32-bit stores of one d of two keys: (8 * pitch / 2) % 32 == 0 puts the 8 segments of a row pair on ONE bank);
+//  * all K / V pieces of a thread (9 x 16 B) are requested before the first one is stored: one memory round trip instead of three;
+//  * softmax: the maximum is taken over the raw scores, exp2((s - max) * scale * log2 e) is one FMA + one v_exp per score, and only
+//    the last key tile is masked against kv_len (half the VALU work per score).
+// Results differ from the old kernel by the rounding of exp alone (exp2 of a fused product instead of __expf of a scaled
+// difference): both kernels are compared with an fp32 reference in tests/test_hip_ops.py; DEER_ATTN_VIT=0 selects the old kernel.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+template <int NWAVE, bool LOOP, int NT>     // NT = key tiles of 16 (kv_len <= 16 NT); PV runs (NT + 1) / 2 chunks of 32 keys
+__global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void attn_vit_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
+                                                              const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int q_len, int kv_len,
+                                                              int ldq, int ldk, int ldv, int ldo, long q_bstride, long k_bstride,
+                                                              long v_bstride, long o_bstride, float scale_log2e, int tpw) {
+  constexpr int KROWS = NT * 16, NCH = (NT + 1) / 2, VROWS = NCH * 32;
+  constexpr int NPIECE = (KROWS + VROWS) * 8, PER = (NPIECE + 64 * NWAVE - 1) / (64 * NWAVE);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);                  // [KROWS][72]
+  bf16_t* Vs = Ks + KROWS * AM_KPITCH;                               // [VROWS][72] row-major: read transposed
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* Kb = Kp + b * k_bstride + h * AM_HD;
+  const bf16_t* Vb = V + b * v_bstride + h * AM_HD;
+  int q0 = (blockIdx.x * (LOOP ? tpw : NWAVE) + wave) * 16;
+
+  // ---- every K / V piece of this thread in flight, then the Q fragments; rows >= kv_len are zero ----
+  uint4 piece[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int p = tid + i * 64 * NWAVE;
+    piece[i] = uint4{0, 0, 0, 0};
+    if (p < KROWS * 8) {
+      const int row = p >> 3, seg = p & 7;
+      if (row < kv_len) piece[i] = *reinterpret_cast<const uint4*>(Kb + (long)row * ldk + seg * 8);
+    } else if (p < NPIECE) {
+      const int row = (p - KROWS * 8) >> 3, seg = p & 7;
+      if (row < kv_len) piece[i] = *reinterpret_cast<const uint4*>(Vb + (long)row * ldv + seg * 8);
+    }
+  }
+  bf16x8 qf[2];
+  auto load_q = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 v = uint4{0, 0, 0, 0};
+      if (q0 + c < q_len) v = *reinterpret_cast<const uint4*>(Q + b * q_bstride + h * AM_HD + (long)(q0 + c) * ldq + ks * 32 + g * 8);
+      qf[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  };
+  load_q();
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int p = tid + i * 64 * NWAVE;
+    if (p < NPIECE) *reinterpret_cast<uint4*>(Ks + (p >> 3) * AM_KPITCH + (p & 7) * 8) = piece[i];   // Vs follows Ks: piece p -> row p >> 3 of [K ; V]
+  }
+  __syncthreads();
+
+  // transpose-read base of this lane: key g*4 + (c >> 2), d piece (c & 3) * 4 of a [4 keys][16 d] block
+  lds_s16x4_t* vt = (lds_s16x4_t*)(Vs + (g * 4 + (c >> 2)) * AM_KPITCH + (c & 3) * 4);      // generic -> LDS address space (C-style cast)
+#pragma nounroll
+  for (int ti = wave; ti < (LOOP ? tpw : NWAVE); ti += NWAVE, q0 += 16 * NWAVE) {
+    if (q0 >= q_len) break;
+    if (LOOP && ti >= NWAVE) load_q();
+    // the K fragments do not depend on the query tile: without this hipcc hoists all 34 of them out of the loop (136 VGPRs -> one
+    // workgroup per CU, or 460 bytes of scratch per lane under the two-workgroup register bound)
+    if (LOOP) asm volatile("" ::: "memory");
+    // ---- S^T tiles: s[t][r] = S[q = c][key = t*16 + g*4 + r] (unscaled) ----
+    f32x4 s[2 * NCH];
+#pragma unroll
+    for (int t = 0; t < 2 * NCH; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < NT) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c) * AM_KPITCH + ks * 32 + g * 8);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+        }
+      }
+    }
+    // keys beyond kv_len live in the last tile only (kv_len > 16 (NT - 1), checked by the launcher)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if ((NT - 1) * 16 + g * 4 + r >= kv_len) s[NT - 1][r] = -INFINITY;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) mx = fmaxf(fmaxf(fmaxf(mx, s[t][0]), fmaxf(s[t][1], s[t][2])), s[t][3]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mneg = -mx * scale_log2e;
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], scale_log2e, mneg));
+        s[t][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    // ---- O^T = V^T * P^T : k-slot (g, j<4) <-> key 32*ch + g*4 + j ; (g, j>=4) <-> key 32*ch + 16 + g*4 + (j-4) ----
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      uint4 pw;
+      pw.x = pack2bf(s[2 * ch][0], s[2 * ch][1]);
+      pw.y = pack2bf(s[2 * ch][2], s[2 * ch][3]);
+      pw.z = pack2bf(s[2 * ch + 1][0], s[2 * ch + 1][1]);      // tile NT (odd NT: beyond the keys) holds zeros
+      pw.w = pack2bf(s[2 * ch + 1][2], s[2 * ch + 1][3]);
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vt + ((ch * 32) * AM_KPITCH + dt * 16) / 4);
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vt + ((ch * 32 + 16) * AM_KPITCH + dt * 16) / 4);
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        const uint4 vw = uint4{l2.x, l2.y, h2.x, h2.y};
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[dt], 0, 0, 0);
+      }
+    }
+    if (q0 + c < q_len) {                                    // lane holds O[q = q0 + c][d = dt*16 + g*4 .. +3]
+      bf16_t* op = O + b * o_bstride + (long)(q0 + c) * ldo + h * AM_HD + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<uint2*>(op + dt * 16) = uint2{pack2bf(o[dt][0] * inv, o[dt][1] * inv), pack2bf(o[dt][2] * inv, o[dt][3] * inv)};
+    }
+  }
+}
+
+template <int NWAVE, bool LOOP, int NT>
+static int launch_attn_vit_nt(dim3 grid, hipStream_t st, const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, int q_len, int kv_len, int ldq,
+                              int ldk, int ldv, int ldo, long q_bstride, long k_bstride, long v_bstride, long o_bstride, float scale, int tpw) {
+  constexpr int smem = (NT * 16 + ((NT + 1) / 2) * 32) * AM_KPITCH * 2;
+  static std::atomic<bool> attr_set{false};
+  auto kern = &attn_vit_kernel<NWAVE, LOOP, NT>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return DEER_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NWAVE), smem, st, Q, K, V, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride,
+                     scale * 1.4426950408889634f, tpw);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
 static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O, int batch, int heads, int q_len, int kv_len,
                             int ldq, int ldk, int ldv, int ldo, long q_bstride, long k_bstride, long v_bstride, long o_bstride,
                             float scale, int q_slabs, long q_slab_stride, const int* text_time, int n_per_media, int out_is_f32,
@@ -247,6 +403,15 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
     tpw = (tiles + n_wg - 1) / n_wg;
   }
   dim3 grid((tiles + tpw - 1) / tpw, heads, batch);
+  // ViT-L/14 self-attention (bf16 q / k / v of one segment, bf16 output, 257 keys = 17 key tiles): attn_vit_kernel
+  static const bool vit_ok = [] { const char* e = getenv("DEER_ATTN_VIT"); return e == nullptr || e[0] != '0'; }();
+  if (vit_ok && wide && K2 == nullptr && text_time == nullptr && !out_is_f32 && ctl == nullptr && (kv_len + 15) / 16 == 17) {
+    const bf16_t* q = reinterpret_cast<const bf16_t*>(Q);
+    bf16_t* o = reinterpret_cast<bf16_t*>(O);
+#define DEER_VIT_ARGS grid, st, q, kp, vp, o, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride, scale, tpw
+    return tpw != nwave ? launch_attn_vit_nt<8, true, 17>(DEER_VIT_ARGS) : launch_attn_vit_nt<8, false, 17>(DEER_VIT_ARGS);
+#undef DEER_VIT_ARGS
+  }
 #define DEER_ATTN_ARGS Q, kp, vp, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride, scale, q_slabs, \
                        q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2, tpw
   if (q_slabs > 0)

@@ -717,7 +717,8 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
                                                          int force, int thr_type, int leq, const float* __restrict__ h_tmp,
                                                          const float* __restrict__ c_tmp, float* __restrict__ h_state,
                                                          float* __restrict__ c_state, int L, int H, int B,
-                                                         float* __restrict__ action_dbg, float eps) {
+                                                         float* __restrict__ action_dbg, float eps, int A,
+                                                         float* __restrict__ act_ext) {
   const int b = blockIdx.x;
   if (head_skip(ctl0, kind, layer, B)) {
     // Every workgroup of a CHECK launch reports exactly once, whatever path it takes: a check nobody needed (stage hold)
@@ -748,8 +749,8 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
   float* xa = lds;                    // actions-head input [in_dim]
   float* xg = lds + in_dim;           // gripper-head input [in_dim]
   float* red = xg + in_dim;           // [16]
-  float* outv = red + 16;             // [8]
-  int* flag = reinterpret_cast<int*>(outv + 8);
+  float* outv = red + 16;             // [64]: 7 A raw outputs (A = multi_step_action <= 8), then the A gripper logits
+  int* flag = reinterpret_cast<int*>(outv + 64);
   const bool grouped = (pro == PRO_GROUP_LN_RELU || pro == PRO_GROUP_RELU);
   const float* s0 = src + (long)b * src_stride;
   const float* s1 = s0 + (grouped ? in_dim : 0);
@@ -778,16 +779,112 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
     }
     for (int k = 2 * 512 + lane * 8; k < in_dim; k += 512) a += W8<WT>::dot(W8<WT>::load(Wrow + k), x + k);
     a = wave_sum(a);
-    if (lane == 0) outv[wave] = a + ((wave < 6) ? ba[wave] : bg[0]);
+    if (lane == 0 && A == 1) outv[wave] = a + ((wave < 6) ? ba[wave] : bg[0]);
+  }
+  if (A > 1) {
+    // multi_step_action (action_head.py:472-473): 6 A pose rows of Wa then A gripper rows of Wg; wave w takes rows w, w + 8, ...
+    for (int row = wave; row < 7 * A; row += 8) {
+      const bool pose_row = row < 6 * A;
+      const WT* wr = pose_row ? Wa + (long)row * in_dim : Wg + (long)(row - 6 * A) * in_dim;
+      const float* x = pose_row ? xa : xg;
+      float a = 0.f;
+      for (int k = lane * 8; k < in_dim; k += 512) a += W8<WT>::dot(W8<WT>::load(wr + k), x + k);
+      a = wave_sum(a);
+      if (lane == 0) outv[row] = a + (pose_row ? ba[row] : bg[row - 6 * A]);
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && A > 1) {
+    // ---- the same protocol as below over 7 A values; actions live in act_ext[b] = {previous | committed | ensemble}[64]; the first
+    // executed action ([pose 0..5, gripper 0, logit 0]) is mirrored into the control block's 8-float fields ----
+    const int NP = 6 * A, NA = 7 * A;
+    for (int i = 0; i < A; ++i) outv[NA + i] = outv[NP + i];                      // gripper logits
+    for (int i = 0; i < NP; ++i) outv[i] = tanhf(outv[i]);
+    for (int i = NP; i < NA; ++i) outv[i] = sigmoidf_(outv[i]);
+    if (action_dbg != nullptr)
+      for (int i = 0; i < 8 * A; ++i) action_dbg[b * 64 + i] = outv[i];
+    bool commit = false;
+    if (ctl != nullptr) {
+      float* prev = act_ext + (long)b * 256;
+      float* outa = prev + 64;
+      float* ens = prev + 128;
+      float* deltas = reinterpret_cast<float*>(ctl + CTL_DELTAS);
+      const bool hold = ctl[CTL_HOLD] != 0;
+      if (kind == KIND_PSEUDO) {
+        for (int i = 0; i < NA; ++i) prev[i] = outv[i];
+        ctl[CTL_PREV_REAL] = 0;
+      } else if (kind == KIND_CHECK && !hold) {
+        float delta;                                    // value_net.py:105-117 over all 6 A pose values
+        if (thr_type == THR_COSINE) {
+          float na = 0.f, nb = 0.f, ab = 0.f;
+          for (int i = 0; i < NP; ++i) { na += outv[i] * outv[i]; nb += prev[i] * prev[i]; }
+          na = fmaxf(sqrtf(na), 1e-5f); nb = fmaxf(sqrtf(nb), 1e-5f);
+          for (int i = 0; i < NP; ++i) ab += (outv[i] / na) * (prev[i] / nb);
+          delta = 1.f - ab;
+        } else {
+          float acc = 0.f;
+          for (int i = 0; i < NP; ++i) {
+            const float dd = fabsf(outv[i] - prev[i]);
+            if (thr_type == THR_L2) acc += dd * dd;
+            else if (thr_type == THR_MEAN) acc += dd;
+            else acc = fmaxf(acc, dd);
+          }
+          delta = (thr_type == THR_L2) ? sqrtf(acc / NP) : (thr_type == THR_MEAN ? acc / NP : acc);
+        }
+        if (slot >= 0 && slot < 16) deltas[slot] = delta;
+        const bool two = ctl[CTL_PREV_REAL] != 0;
+        for (int i = 0; i < NA; ++i) ens[i] = two ? 0.5f * (prev[i] + outv[i]) : outv[i];
+        reinterpret_cast<float*>(ctl + CTL_ENS_ACTION)[7] = two ? 2.f : 1.f;
+        ctl[CTL_PREV_REAL] = 1;
+        for (int i = 0; i < NA; ++i) prev[i] = outv[i];
+        const bool below = delta <= thresholds[slot];
+        if ((below == (leq != 0)) || force) {
+          ctl[CTL_CUR_EXIT_ID] = layer;
+          commit = true;
+        }
+      } else {
+        commit = true;
+      }
+      ctl[CTL_N_EVALS] += 1;
+      const bool shadow_on = ctl0[CTL_SHADOW] != 0;
+      if (commit && shadow_on) {
+        if (ctl[CTL_COMMITTED] != 0) commit = false;
+        else ctl[CTL_COMMITTED] = 1;
+      }
+      if (commit) {
+        float* o8 = reinterpret_cast<float*>(ctl + CTL_OUT_ACTION);
+        for (int i = 0; i < 8 * A; ++i) outa[i] = outv[i];
+        for (int i = 0; i < 6; ++i) o8[i] = outv[i];
+        o8[6] = outv[NP];
+        o8[7] = outv[NA];
+        ctl[CTL_EXIT_LAYER] = layer;
+        if (!shadow_on) {
+          ctl[CTL_EXIT_FLAG] = 1;
+          int* hm = host_mirror(ctl0);
+          if (hm != nullptr) {
+            for (int i = 0; i < CTL_WORDS; ++i) hm[CTL_WORDS * (1 + b) + i] = ctl[i];
+            float* hx = reinterpret_cast<float*>(hm + CTL_WORDS * (1 + B)) + (long)b * 128;   // mirror extension: committed | ensemble
+            for (int i = 0; i < 64; ++i) { hx[i] = outa[i]; hx[64 + i] = ens[i]; }
+          }
+          if (B == 1) {
+            ctl0[CTL_ALL_EXITED] = 1;
+          } else {
+            __threadfence_system();
+            if (atomicAdd(&ctl0[CTL_N_EXITED], 1) + 1 == B) ctl0[CTL_ALL_EXITED] = 1;
+          }
+        }
+      }
+      if (kind == KIND_CHECK) check_done(ctl0, slot, B);
+    }
+    *flag = commit ? 1 : 0;
+  }
+  if (threadIdx.x == 0 && A == 1) {
     float cur[8];
     for (int i = 0; i < 6; ++i) cur[i] = tanhf(outv[i]);
     cur[6] = sigmoidf_(outv[6]);
     cur[7] = outv[6];                                  // gripper logit (MLPSigmoidHead with_logits)
     if (action_dbg != nullptr)
-      for (int i = 0; i < 8; ++i) action_dbg[b * 8 + i] = cur[i];
+      for (int i = 0; i < 8; ++i) action_dbg[b * 64 + i] = cur[i];
     bool commit = false;
     if (ctl != nullptr) {
       float* prev = reinterpret_cast<float*>(ctl + CTL_PREV_ACTION);
@@ -872,23 +969,41 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
   }
 }
 
+// A = multi_step_action (action_head.py:472-473): Wa has 6 A rows, Wg A rows; A > 1 needs act_ext ([B][4][64] f32: previous /
+// committed / ensemble action of 7 A values + A logits) when ctl is given.  action_dbg: [B][64] (pose 6 A | gripper A | logit A).
+extern "C" int deer_head_final_multi(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0,
+                                     const float* lnw1, const float* lnb1, const void* Wa, const float* ba, const void* Wg, const float* bg,
+                                     int* ctl, int kind, int layer, int slot, const float* thresholds, int force, int thr_type, int leq,
+                                     const float* h_tmp, const float* c_tmp, float* h_state, float* c_state, int L, int H, int B,
+                                     float* action_dbg, float eps, int w_is_f32, int A, float* act_ext, void* stream);
+
 extern "C" int deer_head_final(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0,
                                const float* lnw1, const float* lnb1, const void* Wa, const float* ba, const void* Wg, const float* bg,
                                int* ctl, int kind, int layer, int slot, const float* thresholds, int force, int thr_type, int leq,
                                const float* h_tmp, const float* c_tmp, float* h_state, float* c_state, int L, int H, int B,
                                float* action_dbg, float eps, int w_is_f32, void* stream) {
+  return deer_head_final_multi(src, src_stride, in_dim, pro, lnw0, lnb0, lnw1, lnb1, Wa, ba, Wg, bg, ctl, kind, layer, slot, thresholds, force,
+                               thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps, w_is_f32, 1, nullptr, stream);
+}
+
+extern "C" int deer_head_final_multi(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0,
+                                     const float* lnw1, const float* lnb1, const void* Wa, const float* ba, const void* Wg, const float* bg,
+                                     int* ctl, int kind, int layer, int slot, const float* thresholds, int force, int thr_type, int leq,
+                                     const float* h_tmp, const float* c_tmp, float* h_state, float* c_state, int L, int H, int B,
+                                     float* action_dbg, float eps, int w_is_f32, int A, float* act_ext, void* stream) {
   if (in_dim <= 0 || (in_dim & 7) || pro < 0 || pro > 3 || kind < 0 || kind > 2 || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
   if (kind == KIND_CHECK && (thresholds == nullptr || slot < 0 || ctl == nullptr)) return DEER_ERR_SHAPE;
-  const int smem = (2 * in_dim + 16 + 8 + 4) * (int)sizeof(float);
+  if (A < 1 || A > 8 || (A > 1 && ctl != nullptr && act_ext == nullptr)) return DEER_ERR_SHAPE;
+  const int smem = (2 * in_dim + 16 + 64 + 4) * (int)sizeof(float);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (w_is_f32)
     hipLaunchKernelGGL(head_final_kernel<float>, dim3(B), dim3(512), smem, st, src, src_stride, in_dim, pro, lnw0, lnb0, lnw1, lnb1,
                        reinterpret_cast<const float*>(Wa), ba, reinterpret_cast<const float*>(Wg), bg, ctl, kind, layer, slot,
-                       thresholds, force, thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps);
+                       thresholds, force, thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps, A, act_ext);
   else
     hipLaunchKernelGGL(head_final_kernel<bf16_t>, dim3(B), dim3(512), smem, st, src, src_stride, in_dim, pro, lnw0, lnb0, lnw1, lnb1,
                        reinterpret_cast<const bf16_t*>(Wa), ba, reinterpret_cast<const bf16_t*>(Wg), bg, ctl, kind, layer, slot,
-                       thresholds, force, thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps);
+                       thresholds, force, thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps, A, act_ext);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

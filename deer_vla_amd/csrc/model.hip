@@ -115,6 +115,15 @@ struct LlmLayerW {
 };
 struct LstmW { size_t wih, whh, bih, bhh, lnw, lnb; };
 struct FcW { size_t w[2], b[2], lnw[2], lnb[2]; };
+// one DeterministicDecoder: extra_exit (the head of the exit criterion and of every action without layerwise_exit_eval) or one of
+// the per-layer heads lm_exit_modules.j / lm_head (flamingo_mpt.py:236-244,450-457), each with its own LSTM state
+struct HeadW {
+  std::vector<LstmW> lstm;
+  std::vector<FcW> fc;
+  size_t wa, ba, wg, bg;
+  size_t h_state = SIZE_MAX, c_state = SIZE_MAX;    // workspace offsets of this head's LSTM state (per-layer heads)
+  int layer = -1;                                   // exit layer the head serves (per-layer heads)
+};
 
 // f32 activation buffers of the fp32-activation arithmetic (deer_config.precision = 1; batched single-stream schedule only)
 struct PreciseWS {
@@ -163,9 +172,11 @@ struct deer_model {
   size_t state_in = SIZE_MAX, state_emb = SIZE_MAX;
   size_t wte, wkv_all;
   std::vector<LlmLayerW> llm;
-  std::vector<LstmW> lstm;
+  std::vector<LstmW> lstm;         // extra_exit
   std::vector<FcW> fc;
   size_t wa, ba, wg, bg;
+  std::vector<HeadW> lw;            // layerwise_exit_eval: per-layer heads in the reference's registration order (lm_exit_modules.0.., lm_head)
+  size_t act_ext = SIZE_MAX;        // multi_step_action > 1: [B][4][64] f32 = previous / committed / ensemble action of 7 A values (+ A gripper logits)
   // workspace
   Layout wl;
   std::unordered_map<std::string, std::pair<size_t, size_t>> ws_named;
@@ -392,13 +403,14 @@ void build_arena(deer_model* m) {
     m->w_state = add_slot(m, p + "embed_state.weight", HK, d, 2 * d);
     m->b_state = add_slot(m, p + "embed_state.bias", SK_F32, 1, d);
   }
-  m->lstm.resize(m->Lh);
+  auto add_head = [&](const std::string& p, std::vector<LstmW>& lstm, std::vector<FcW>& fc, size_t& wa, size_t& ba, size_t& wg, size_t& bg) {
+  lstm.resize(m->Lh);
   int in_f = d;
   for (int l = 0; l < m->Lh; ++l) {
     std::string r, sfx;
     if (c.lstm_layernorm) { r = p + "rnn.layers." + std::to_string(3 * l) + "."; sfx = "_l0"; }
     else { r = p + "rnn."; sfx = "_l" + std::to_string(l); }
-    LstmW& Lw = m->lstm[l];
+    LstmW& Lw = lstm[l];
     Lw.wih = add_slot(m, r + "weight_ih" + sfx, HK, 4L * H, in_f);
     Lw.whh = add_slot(m, r + "weight_hh" + sfx, HK, 4L * H, H);
     Lw.bih = add_slot(m, r + "bias_ih" + sfx, SK_F32, 1, 4 * H);
@@ -411,26 +423,42 @@ void build_arena(deer_model* m) {
     in_f = H;
   }
   // MLP heads, dropout_mode='layerwise' (action_head.py:86-116): [Drop, (Lin, LN|Id, ReLU, Drop) x n_hidden, Lin, Tanh|Sigmoid]
-  m->fc.resize(m->n_fc);
+  fc.resize(m->n_fc);
   const char* heads[2] = {"actions", "gripper"};
   for (int g = 0; g < 2; ++g) {
     int cur = H;
     for (int i = 0; i < m->n_fc; ++i) {
       const std::string li = p + heads[g] + ".mlp." + std::to_string(1 + 4 * i) + ".";
       const std::string ni = p + heads[g] + ".mlp." + std::to_string(2 + 4 * i) + ".";
-      m->fc[i].w[g] = add_slot(m, li + "weight", HK, m->fc_dims[i], cur);
-      m->fc[i].b[g] = add_slot(m, li + "bias", SK_F32, 1, m->fc_dims[i]);
-      m->fc[i].lnw[g] = m->fc[i].lnb[g] = SIZE_MAX;
+      fc[i].w[g] = add_slot(m, li + "weight", HK, m->fc_dims[i], cur);
+      fc[i].b[g] = add_slot(m, li + "bias", SK_F32, 1, m->fc_dims[i]);
+      fc[i].lnw[g] = fc[i].lnb[g] = SIZE_MAX;
       if (c.mlp_layernorm) {
-        m->fc[i].lnw[g] = add_slot(m, ni + "weight", SK_F32, 1, m->fc_dims[i]);
-        m->fc[i].lnb[g] = add_slot(m, ni + "bias", SK_F32, 1, m->fc_dims[i]);
+        fc[i].lnw[g] = add_slot(m, ni + "weight", SK_F32, 1, m->fc_dims[i]);
+        fc[i].lnb[g] = add_slot(m, ni + "bias", SK_F32, 1, m->fc_dims[i]);
       }
       cur = m->fc_dims[i];
     }
     const std::string lo = p + heads[g] + ".mlp." + std::to_string(1 + 4 * m->n_fc) + ".";
-    const int n_out = g == 0 ? 6 : 1;
-    (g == 0 ? m->wa : m->wg) = add_slot(m, lo + "weight", HK, n_out, cur);
-    (g == 0 ? m->ba : m->bg) = add_slot(m, lo + "bias", SK_F32, 1, n_out);
+    const int A = std::max(1, c.multi_step_action);    // action_head.py:472-473: out_features * multi_step_action outputs per head
+    const int n_out = g == 0 ? 6 * A : A;
+    (g == 0 ? wa : wg) = add_slot(m, lo + "weight", HK, n_out, cur);
+    (g == 0 ? ba : bg) = add_slot(m, lo + "bias", SK_F32, 1, n_out);
+  }
+  };
+  add_head(p, m->lstm, m->fc, m->wa, m->ba, m->wg, m->bg);
+  if (c.layerwise_exit_eval) {   // one head per internal exit + lm_head for the last layer (flamingo_mpt.py:236-244 with multi_exit = True)
+    int j = 0;
+    for (int i = c.exit_interval - 1; i < c.n_layers - 1; i += c.exit_interval, ++j) {
+      m->lw.emplace_back();
+      HeadW& h = m->lw.back();
+      h.layer = i;
+      add_head("lm_exit_modules." + std::to_string(j) + ".", h.lstm, h.fc, h.wa, h.ba, h.wg, h.bg);
+    }
+    m->lw.emplace_back();
+    HeadW& h = m->lw.back();
+    h.layer = c.n_layers - 1;
+    add_head("lm_head.", h.lstm, h.fc, h.wa, h.ba, h.wg, h.bg);
   }
 }
 
@@ -570,7 +598,17 @@ void build_workspace(deer_model* m) {
   m->ctl = named(m, "ctl", (size_t)B * CTL_WORDS * 4);
   m->step_info = named(m, "step_info", 16);
   m->thresholds = named(m, "thresholds", 16 * 4);
-  m->action_dbg = named(m, "action_dbg", (size_t)B * 8 * 4);
+  // every head evaluation's outputs: [B][64] f32 = pose (6 A) | gripper prob (A) | gripper logit (A), A = multi_step_action (A = 1: the
+  // familiar [pose6, prob, logit])
+  m->action_dbg = named(m, "action_dbg", (size_t)B * 64 * 4);
+  m->act_ext = named(m, "act_ext", (size_t)B * 4 * 64 * 4);
+  for (HeadW& h : m->lw) {                                             // per-layer heads: own LSTM state
+    h.h_state = m->wl.add(st);
+    h.c_state = m->wl.add(st);
+  }
+  if (!m->lw.empty()) {                                                // host view: [head][2 (h, c)][Lh][B][H], heads in registration order
+    m->ws_named["lw_state"] = {m->lw.front().h_state, 2 * ((st + 255) & ~size_t(255)) * m->lw.size()};
+  }
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------------------------------
@@ -1222,9 +1260,15 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
 // (value_net.py:120-133,277-297).  kind: PSEUDO (prev action from layer i-1, value_net.py:122-125), CHECK (delta <= threshold ->
 // exit + commit LSTM state), COMMIT (static exit_id / committing call)
 int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, bool use_ctl, bool shadow, bool no_ctl_final, const float* feats,
-              bool use_mask, void* st) {
+              bool use_mask, void* st, int head = 0) {
   const deer_config& c = m->c;
   const int H = m->H, d = m->d, B = m->B;
+  // head 0: extra_exit; head k > 0: the k-th per-layer head of layerwise_exit_eval (own weights, own LSTM state, no pre-pass)
+  if (head < 0 || head > (int)m->lw.size()) return DEER_ERR_SHAPE;
+  const HeadW* hw = head > 0 ? &m->lw[head - 1] : nullptr;
+  const std::vector<LstmW>& lstm_w = hw ? hw->lstm : m->lstm;
+  const std::vector<FcW>& fc_w = hw ? hw->fc : m->fc;
+  const size_t wa = hw ? hw->wa : m->wa, ba = hw ? hw->ba : m->ba, wg = hw ? hw->wg : m->wg, bg = hw ? hw->bg : m->bg;
   const int* ctl = use_ctl ? m->Wk<int>(m->ctl) : nullptr;
   const size_t rows_cap = std::min(B * c.max_text_len, kMaxRows);
   const bool feats_default = feats == nullptr;
@@ -1241,11 +1285,11 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
   }
   float* h_tmp = m->Wk<float>(m->h_tmp);
   float* c_tmp = m->Wk<float>(m->c_tmp);
-  const float* h_prev = m->Wk<float>(m->h_state);
-  const float* c_prev = m->Wk<float>(m->c_state);
+  const float* h_prev = m->Wk<float>(hw ? hw->h_state : m->h_state);
+  const float* c_prev = m->Wk<float>(hw ? hw->c_state : m->c_state);
   const size_t lst = (size_t)B * H;
   for (int l = 0; l < m->Lh; ++l) {
-    const LstmW& Lw = m->lstm[l];
+    const LstmW& Lw = lstm_w[l];
     const float* src;
     long bstride;
     int mode, in_dim;
@@ -1253,14 +1297,14 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
     if (l == 0) { src = pooled; bstride = d; mode = DEER_X_RAW; in_dim = d; }
     else {
       src = h_tmp + (l - 1) * lst; bstride = H; in_dim = H;
-      if (c.lstm_layernorm) { mode = DEER_X_LN; lnw = m->A<float>(m->lstm[l - 1].lnw); lnb = m->A<float>(m->lstm[l - 1].lnb); }
+      if (c.lstm_layernorm) { mode = DEER_X_LN; lnw = m->A<float>(lstm_w[l - 1].lnw); lnb = m->A<float>(lstm_w[l - 1].lnb); }
       else mode = DEER_X_RAW;
     }
     // control steps (the features are this step's hidden states): the recurrent half comes from deer_begin_step's pre-pass; window mode
     // (explicit features, the state moves from frame to frame inside one call) keeps the fused form
     // ... and so does an evaluation enqueued after the host changed h_state without a deer_begin_step in between (reset,
     // reset_env, a manual commit - deer_model_head_state_changed): the pre-pass result would be stale
-    const bool pre = m->head_pre && m->Lh <= 8 && feats_default && m->ghh_valid;
+    const bool pre = m->head_pre && m->Lh <= 8 && feats_default && m->ghh_valid && head == 0;
     Bracket b(m, "deer_head_lstm_layer", 0, 2.0 * 4 * H * (in_dim + (pre ? 0 : H)), st);
     if (pre)
       DEER_TRY(deer_head_lstm_layer_pre(src, bstride, mode, T, in_dim, lnw, lnb, m->A<void>(Lw.wih), m->A<float>(Lw.bih), m->Wk<float>(m->ghh) + 4 * l * lst,
@@ -1272,9 +1316,9 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
   const float* src = h_tmp + (m->Lh - 1) * lst;
   int in_dim = H, sstride = H, pro = DEER_PRO_RAW;
   const float* ln[4] = {nullptr, nullptr, nullptr, nullptr};
-  if (c.lstm_layernorm) { pro = DEER_PRO_LN; ln[0] = m->A<float>(m->lstm.back().lnw); ln[1] = m->A<float>(m->lstm.back().lnb); }
+  if (c.lstm_layernorm) { pro = DEER_PRO_LN; ln[0] = m->A<float>(lstm_w.back().lnw); ln[1] = m->A<float>(lstm_w.back().lnb); }
   for (int fi = 0; fi < m->n_fc; ++fi) {
-    const FcW& F = m->fc[fi];
+    const FcW& F = fc_w[fi];
     const int dim = m->fc_dims[fi];
     float* z = m->Wk<float>(m->z_fc[fi]);
     {
@@ -1288,10 +1332,10 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
   }
   Bracket b(m, "deer_head_final", 0, 0, st);
   const float* thr = m->thr_override ? m->thr_override : m->Wk<float>(m->thresholds);
-  return deer_head_final(src, sstride, in_dim, pro, ln[0], ln[1], ln[2], ln[3], m->A<void>(m->wa), m->A<float>(m->ba), m->A<void>(m->wg), m->A<float>(m->bg),
-                         no_ctl_final ? nullptr : m->Wk<int>(m->ctl), kind, layer, slot, thr, force ? 1 : 0, m->thr_type, m->leq, h_tmp, c_tmp,
-                         m->Wk<float>(shadow ? m->h_shadow : m->h_state), m->Wk<float>(shadow ? m->c_shadow : m->c_state), m->Lh, H, B,
-                         m->Wk<float>(m->action_dbg), kEps, c.precision, st);
+  return deer_head_final_multi(src, sstride, in_dim, pro, ln[0], ln[1], ln[2], ln[3], m->A<void>(wa), m->A<float>(ba), m->A<void>(wg), m->A<float>(bg),
+                               no_ctl_final ? nullptr : m->Wk<int>(m->ctl), kind, layer, slot, thr, force ? 1 : 0, m->thr_type, m->leq, h_tmp, c_tmp,
+                               m->Wk<float>(shadow ? m->h_shadow : m->h_state), m->Wk<float>(shadow ? m->c_shadow : m->c_state), m->Lh, H, B,
+                               m->Wk<float>(m->action_dbg), kEps, c.precision, std::max(1, c.multi_step_action), m->Wk<float>(m->act_ext), st);
 }
 
 // per layer of the dynamic step: (need_pseudo, is_exit, exit slot) - mosaic_gpt_3b.py:397-443, value_net.py:122-125
@@ -1391,6 +1435,7 @@ int deer_model_create(const deer_config* cfg, deer_model** out) {
   if (c.vit_width % c.vit_heads || c.vit_width / c.vit_heads != 64 || c.perc_dim_head != 64 || c.xattn_dim_head != 64) return DEER_ERR_SHAPE;
   if (c.d_model % 32 || c.d_model / c.n_heads > 128 || 2 * c.perc_latents > 128) return DEER_ERR_SHAPE;
   if (c.mlp_num_hidden_layers < 0 || c.mlp_num_hidden_layers > 3 || c.lstm_num_layers < 1) return DEER_ERR_SHAPE;
+  if (c.multi_step_action < 0 || c.multi_step_action > 8 || (c.layerwise_exit_eval && c.use_state)) return DEER_ERR_SHAPE;
   deer_model* m = new deer_model();
   m->c = c;
   const int g = c.image_size / c.patch_size;
@@ -1625,6 +1670,21 @@ int deer_head_eval(deer_model* m, int layer, int T, int kind, int slot, int forc
                    int use_mask, void* stream) {
   if (m->ws == nullptr || layer < 0 || layer >= m->c.n_layers || T <= 0 || kind < 0 || kind > 2) return DEER_ERR_SHAPE;
   return head_eval(m, layer, T, kind, slot, force != 0, use_ctl != 0, shadow != 0, no_ctl_final != 0, feats, use_mask != 0, stream);
+}
+
+// layerwise_exit_eval (flamingo_mpt.py:450-457): the action of exit layer `layer` from that layer's OWN head (head = 1 + its index in the
+// reference's registration order: lm_exit_modules.0 .., lm_head last) on hidden_states[layer], starting from that head's own LSTM state
+// (workspace "lw_state").  The outputs land in "action_dbg", the new state in h_tmp / c_tmp: the caller commits it for the environments
+// that exited at this layer.  deer_model_layerwise_head: head index of an exit layer, or -1.
+int deer_model_layerwise_head(const deer_model* m, int layer) {
+  for (size_t k = 0; k < m->lw.size(); ++k)
+    if (m->lw[k].layer == layer) return (int)k + 1;
+  return -1;
+}
+
+int deer_head_eval_layerwise(deer_model* m, int head, int layer, int T, int use_mask, void* stream) {
+  if (m->ws == nullptr || head < 1 || head > (int)m->lw.size() || layer < 0 || layer >= m->c.n_layers || T <= 0) return DEER_ERR_SHAPE;
+  return head_eval(m, layer, T, DEER_KIND_COMMIT, -1, false, false, false, true, nullptr, use_mask != 0, stream, head);
 }
 
 int deer_step_enqueue(deer_model* m, int T, int use_mask, int exit_id, int shadow, const int* step_info, void* stream) {

@@ -245,13 +245,21 @@ class DeerEngine:
         self.hold_dev = v("step_info", torch.int32)                        # step_info: {hold, seq, host mirror ptr lo, hi}
         self.thresholds = v("thresholds", torch.float32)
         self.thresholds.fill_(1e8)
-        self.action_dbg = v("action_dbg", torch.float32).view(B, 8)
+        # outputs of the last head evaluation: [pose 6 A | gripper prob A | gripper logit A] per environment (A = multi_step_action)
+        self.A = int(getattr(cfg, "multi_step_action", 1))
+        self.action_dbg = v("action_dbg", torch.float32).view(B, 64)[:, :8 * self.A]
+        self.act_ext = v("act_ext", torch.float32).view(B, 4, 64)         # multi_step_action > 1: previous | committed | ensemble action
+        self.act_ext_host = torch.zeros(B, 4, 64, dtype=torch.float32).pin_memory()
+        if getattr(cfg, "layerwise_exit_eval", False):                     # per-layer heads' LSTM state: [head][h, c][L][B][H]
+            n_lw = len(cfg.layerwise_heads())
+            self.lw_state = v("lw_state", torch.float32).view(n_lw, 2, Lh, B, H)
         self.wte = self._buf("lang_encoder.transformer.wte.weight", 0).view(torch.float32 if self.precision == "fp32" else torch.bfloat16).view(cfg.vocab_size, d)
         self.ctl_host = torch.zeros(B * abi.CTL_WORDS, dtype=torch.int32).pin_memory()
         self._ctl_host_np = self.ctl_host.numpy()
         self.step_info_host = torch.zeros(8, 4, dtype=torch.int32).pin_memory()   # ring: an async upload may still be pending
         # host mirror of the verdicts (pinned => device-visible and system-coherent): see csrc/head.hip::check_done
-        self.host_mirror = torch.zeros((1 + B) * abi.CTL_WORDS, dtype=torch.int32).pin_memory()
+        # (multi_step_action > 1: + [B][128] f32 behind the control blocks - the committed and the ensemble action of every environment)
+        self.host_mirror = torch.zeros((1 + B) * abi.CTL_WORDS + (B * 128 if self.A > 1 else 0), dtype=torch.int32).pin_memory()
         self._hm = self.host_mirror.numpy()                                 # polled by the host between graph segments
         self.step_info_pinned = torch.zeros(4, dtype=torch.int32).pin_memory()   # read by the device in pipelined steps
         self._si_np = self.step_info_pinned.numpy()
@@ -394,6 +402,8 @@ class DeerEngine:
         self._drain_side_streams()
         self.h_state.zero_()
         self.c_state.zero_()
+        if hasattr(self, "lw_state"):                              # clear_all_exit_memory clears EVERY head (flamingo_mpt.py:287-301)
+            self.lw_state.zero_()
         self._head_state_changed()
         self.ctl.zero_()
         self._shadow_on = False
@@ -405,6 +415,8 @@ class DeerEngine:
         self._drain_side_streams()
         self.h_state[:, b].zero_()
         self.c_state[:, b].zero_()
+        if hasattr(self, "lw_state"):
+            self.lw_state[:, :, :, b].zero_()
         self._head_state_changed()
         W = abi.CTL_WORDS
         keep = self.ctl[:W].clone() if b == 0 else None            # block 0 also holds the batch-global words (shadow flag, host ptr)
@@ -625,6 +637,8 @@ class DeerEngine:
             self.c_state.copy_(self.c_shadow)
             self._head_state_changed()
         self.ctl_host.copy_(self.ctl, non_blocking=True)
+        if self.A > 1:
+            self.act_ext_host.copy_(self.act_ext, non_blocking=True)
         self.cur_step += 1
         if not sync:
             return None
@@ -705,6 +719,8 @@ class DeerEngine:
             if tm:
                 ev[2].record(main_st)
         self.ctl_host.copy_(self.ctl, non_blocking=True)
+        if self.A > 1:
+            self.act_ext_host.copy_(self.act_ext, non_blocking=True)
         main_st.synchronize()
         if self._time_stages and "ev" in locals():
             self.last_stage_ms = {"vision": ev[0].elapsed_time(ev[1]), "llm_and_exit_checks": ev[1].elapsed_time(ev[2])}
@@ -757,10 +773,14 @@ class DeerEngine:
             self._graphs[key] = g
             self._graphs[(key, "events")] = keep
             self.ctl_host.copy_(self.ctl, non_blocking=True)
+            if self.A > 1:
+                self.act_ext_host.copy_(self.act_ext, non_blocking=True)
             main_st.synchronize()
             return self.read_result()
         g.replay()
         self.ctl_host.copy_(self.ctl, non_blocking=True)
+        if self.A > 1:
+            self.act_ext_host.copy_(self.act_ext, non_blocking=True)
         main_st.synchronize()
         return self.read_result()
 
@@ -833,6 +853,8 @@ class DeerEngine:
             P["native"] = self._make_step_plan(P, plan)
             self._graphs[key] = P
             self.ctl_host.copy_(self.ctl, non_blocking=True)     # first call: verdict through the ordinary read-back
+            if self.A > 1:
+                self.act_ext_host.copy_(self.act_ext, non_blocking=True)
             main_st.synchronize()
             return self.read_result()
 
@@ -844,6 +866,7 @@ class DeerEngine:
             if rc == 3:
                 raise abi.DeerHipError("no exit verdict from the device within 20 s")
             abi.check(rc, "deer_step_plan_run")
+            self._ext_from_mirror()
             return self.read_result()
 
         hm, seq, W = self._hm, self._seq, abi.CTL_WORDS
@@ -909,7 +932,8 @@ class DeerEngine:
             ev[2].record(main_st)
             ev[2].synchronize()
             self.last_stage_ms = {"vision": ev[0].elapsed_time(ev[1]), "llm_and_exit_checks": ev[1].elapsed_time(ev[2])}
-        self._ctl_host_np[:] = hm[W:]                            # keep the ordinary read-back buffer current (ctl_host users)
+        self._ctl_host_np[:] = hm[W:W * (1 + self.B)]            # keep the ordinary read-back buffer current (ctl_host users)
+        self._ext_from_mirror()
         return self.read_result()
 
     # ------------------------------------------------------------------------- calibration (window mode)
@@ -1003,7 +1027,7 @@ class DeerEngine:
                     acts.append(torch.stack([w._head_eval(hg[:, t, i].reshape(G * T, d).contiguous(), commit=False) for i in layers]))
                 sel = torch.stack([hg[g, t, int(rl[idx[g], t])] for g in range(G)])                  # each window's own random layer
                 w._head_eval(sel.reshape(G * T, d).contiguous(), commit=True)
-            a = torch.stack(acts, dim=2)[..., :6]                              # (n_exit+1, G, W/2, 6)
+            a = torch.stack(acts, dim=2)[..., :6 * self.A]                     # (n_exit+1, G, W/2, 6 A): the delta runs over all pose values
             per_window.append(a[:, : min(G, bs - b0)])
         a = torch.cat(per_window, dim=1).cpu()                                 # (n_exit+1, bs, W/2, 6)
         prev, last = a[:-1], a[1:]
@@ -1026,23 +1050,60 @@ class DeerEngine:
         e.record(stream)
         return e
 
+    def _ext_from_mirror(self):
+        """multi_step_action > 1, pipelined steps: the committed / ensemble actions travel with the verdict behind the control blocks of
+        the pinned mirror (csrc/head.hip) - bring them into the read-back buffer read_result decodes"""
+        if self.A > 1:
+            W = abi.CTL_WORDS
+            ext = self._hm[W * (1 + self.B):].view(np.float32).reshape(self.B, 2, 64)
+            self.act_ext_host.numpy()[:, 1:3] = ext
+
     def read_result(self, src=None):
-        """Decode the per-environment control blocks (int32 numpy view; default: the pinned read-back buffer)."""
+        """Decode the per-environment control blocks (int32 numpy view; default: the pinned read-back buffer).  multi_step_action = A > 1:
+        ``pose`` is (6 A,) = A consecutive 6-DoF actions and ``gripper`` / ``gripper_logit`` are (A,) tensors, the layout of the
+        reference head's outputs (action_head.py:472-473, eval_utils.py:468-471)."""
         W = abi.CTL_WORDS
         ci = (self._ctl_host_np if src is None else src).reshape(self.B, W)
         cf = ci.view(np.float32)
         out = []
+        A = self.A
         for b in range(self.B):
             c, f = ci[b], cf[b]
             if int(c[abi.CTL_EXIT_LAYER]) < 0:
                 raise abi.DeerHipError(f"environment {b}: the step ended without an exit verdict (no exit check was forced)")
             a = f[abi.CTL_OUT_ACTION: abi.CTL_OUT_ACTION + 8].copy()
             en = f[abi.CTL_ENS_ACTION: abi.CTL_ENS_ACTION + 8].copy()   # ActionValueNet.get_ensemble_action (dynamic steps only)
-            out.append(dict(exit_layer=int(c[abi.CTL_EXIT_LAYER]), n_evals=int(c[abi.CTL_N_EVALS]),
-                            pose=torch.from_numpy(a[:6]), gripper=float(a[6]), gripper_logit=float(a[7]),
-                            ens_pose=torch.from_numpy(en[:6]), ens_gripper=float(en[6]), ens_count=int(en[7]),
-                            deltas=torch.from_numpy(f[abi.CTL_DELTAS: abi.CTL_DELTAS + 16].copy())))
+            r = dict(exit_layer=int(c[abi.CTL_EXIT_LAYER]), n_evals=int(c[abi.CTL_N_EVALS]),
+                     pose=torch.from_numpy(a[:6]), gripper=float(a[6]), gripper_logit=float(a[7]),
+                     ens_pose=torch.from_numpy(en[:6]), ens_gripper=float(en[6]), ens_count=int(en[7]),
+                     deltas=torch.from_numpy(f[abi.CTL_DELTAS: abi.CTL_DELTAS + 16].copy()))
+            if A > 1:
+                x = self.act_ext_host[b].clone()                      # rows: previous | committed | ensemble
+                r.update(pose=x[1, :6 * A], gripper=x[1, 6 * A:7 * A], gripper_logit=x[1, 7 * A:8 * A],
+                         ens_pose=x[2, :6 * A], ens_gripper=x[2, 6 * A:7 * A])
+            out.append(r)
         return out[0] if self.B == 1 else out
+
+    # ------------------------------------------------------------------------- layerwise_exit_eval (flamingo_mpt.py:450-457)
+    def layerwise_actions(self, exit_layers, T: int, use_mask: bool = False):
+        """The action of every environment from the head of ITS exit layer (``lm_exits[k]`` / ``lm_head``) on hidden_states[k], each head
+        running from its own LSTM state, which advances only for the environments that exited at its layer.  Returns a list of (8 A,)
+        rows [pose | gripper prob | logit] per environment.  One head evaluation per DISTINCT exit layer of the batch (an ablation mode of
+        the reference's harness, eval_calvin.py:330 - not a throughput path)."""
+        rows = [None] * self.B
+        for layer in sorted(set(int(v) for v in exit_layers)):
+            head = self.lib.deer_model_layerwise_head(self._h, layer)
+            if head < 1:
+                raise abi.DeerHipError(f"layerwise_exit_eval: layer {layer} has no head of its own (exit layers: {self.cfg.exit_ids()})")
+            abi.check(self.lib.deer_head_eval_layerwise(self._h, head, layer, T, 1 if (use_mask and self.B > 1) else 0, _cur_stream()),
+                      "deer_head_eval_layerwise")
+            out = self.action_dbg.clone()
+            for b in range(self.B):
+                if int(exit_layers[b]) == layer:
+                    rows[b] = out[b].cpu()
+                    self.lw_state[head - 1, 0, :, b].copy_(self.h_tmp[:, b])      # update_hidden_state=True for this head / environment
+                    self.lw_state[head - 1, 1, :, b].copy_(self.c_tmp[:, b])
+        return rows
 
     def weight_bytes(self) -> int:
         """device bytes of the weight arena (bf16 GEMM operands, f32 norms / biases / gates)"""

@@ -160,15 +160,12 @@ def create_model_and_transforms(clip_vision_encoder_path: str = "ViT-L-14", clip
     # steer training (freeze_embed, train_params, unfreeze_vit, freeze_sampler, debug) or that the reference's MPTFlamingo itself
     # accepts and never reads (no_image_patch, global_latent: flamingo_mpt.py:55-56 are their only occurrences) stay accepted.
     unsupported = {
-        "multi_step_action": (multi_step_action, 1, "the head emits out_features * multi_step_action values (action_head.py:436-470)"),
         "last_action": (bool(last_action), False, "action_head.py concatenates the previous action to the head input"),
         "fwd_pred": (bool(fwd_pred), False, "forward-prediction heads (flamingo_mpt.py:53-54)"),
         "fwd_pred_hand": (bool(fwd_pred_hand), False, "forward-prediction heads (flamingo_mpt.py:53-54)"),
         "residual": (bool(residual), False, "changes init_flamingo's gated x-attn (flamingo_mpt.py:111-121)"),
         "pad_length": (pad_length, -1, "the harness asserts pad_length == -1 for multi-exit nets (eval_utils.py:300)"),
         "refresh": (refresh, -1, "refresh_window re-runs the LSTM over the stored window (action_head.py:561-586)"),
-        "layerwise_exit_eval": (bool(flamingo_kwargs.get("layerwise_exit_eval", False)), False,
-                                "per-exit heads lm_exits[i] instead of extra_exit (flamingo_mpt.py:443-461)"),
         "use_hist": (bool(flamingo_kwargs.get("use_hist", False)), False, "history frames (flamingo_mpt.py:372-373)"),
         "use_diff": (bool(flamingo_kwargs.get("use_diff", False)), False, "diffusion head (SURVEY §2 row 12)"),
         "share_exit": (bool(flamingo_kwargs.get("share_exit", False)), False, "shared exit heads are a training-time layout"),
@@ -176,6 +173,16 @@ def create_model_and_transforms(clip_vision_encoder_path: str = "ViT-L-14", clip
     for name, (got, want, why) in unsupported.items():
         if got != want:
             raise NotImplementedError(f"create_model_and_transforms({name}={got!r}) is not implemented by deer_vla_amd: {why}")
+    # round 5: multi_step_action (6 A pose + A gripper outputs per head call, action_head.py:458,472-473; "Nstep" checkpoints,
+    # eval_calvin.py:384-387) and layerwise_exit_eval (per-layer heads lm_exits[k] / lm_head, flamingo_mpt.py:236-261,450-457;
+    # eval_calvin.py:330,530,539 passes multi_exit=True with it) are built: config fields, arena slots, head kernels
+    layerwise = bool(flamingo_kwargs.get("layerwise_exit_eval", False))
+    if not 1 <= int(multi_step_action) <= DeerConfig.MAX_MULTI_STEP:
+        raise NotImplementedError(f"multi_step_action={multi_step_action!r}: 1 .. {DeerConfig.MAX_MULTI_STEP} actions per head call are built (csrc/head.hip)")
+    if layerwise and not flamingo_kwargs.get("multi_exit", True):
+        raise ValueError("layerwise_exit_eval needs the per-layer heads: multi_exit=False builds nn.Identity exits (flamingo_mpt.py:247-249)")
+    if layerwise and use_state:
+        raise NotImplementedError("layerwise_exit_eval with use_state is not built (the per-layer heads would need their own state embeddings)")
     for name, got in (("use_state", use_state), ("sep_resampler", sep_resampler)):
         if got and not getattr(DeerConfig, "supports_" + name, False):
             raise NotImplementedError(f"create_model_and_transforms({name}=True) is not implemented by deer_vla_amd")
@@ -204,7 +211,9 @@ def create_model_and_transforms(clip_vision_encoder_path: str = "ViT-L-14", clip
         cfg.pooling = pooling
         cfg.window_size = window_size
     # action_head.py:524-536 / flamingo_mpt.py:132-134 variants; a caller-supplied cfg is never mutated
-    cfg = dataclasses.replace(cfg, use_state=bool(use_state) or cfg.use_state, sep_resampler=bool(sep_resampler) or cfg.sep_resampler)
+    cfg = dataclasses.replace(cfg, use_state=bool(use_state) or cfg.use_state, sep_resampler=bool(sep_resampler) or cfg.sep_resampler,
+                              multi_step_action=max(int(multi_step_action), cfg.multi_step_action),
+                              layerwise_exit_eval=layerwise or cfg.layerwise_exit_eval)
     synthetic = state_dict is None
     if synthetic:
         state_dict = syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True)

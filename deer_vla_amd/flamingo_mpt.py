@@ -177,13 +177,16 @@ class MPTFlamingo(nn.Module):
         self.window_size = window_size
         self.use_gripper, self.fusion_mode = use_gripper, fusion_mode
         self.use_state, self.sep_lm_head, self.tcp_rel = bool(getattr(cfg, "use_state", False)), True, False
-        self.replan, self.refresh, self.pad_length, self.act_step = -1, -1, -1, 1
+        self.replan, self.refresh, self.pad_length = -1, -1, -1
+        self.act_step = int(getattr(cfg, "multi_step_action", 1))     # flamingo_mpt.py:94; read by ModelWrapper (eval_utils.py:218,456,466)
         self.decoder_type, self.head_type = "lstm", "deterministic"
         self.use_diff, self.use_hist, self.sep_resampler = False, False, bool(getattr(cfg, "sep_resampler", False))
         self.eoc_token_id, self.media_token_id = cfg.eoc_token_id, cfg.media_token_id
         self.vis_dim, self.lang_dim = cfg.vit_width, cfg.d_model
         self.early_exit_layer = cfg.early_exit_layer
-        self.layerwise_exit_eval = False
+        # per-layer heads lm_exits[k] / lm_head with their own LSTM histories produce the action of exit layer k (flamingo_mpt.py:253,
+        # 450-457; eval_calvin.py:330,539); the exit decision stays with extra_exit, whose state nobody commits in this mode
+        self.layerwise_exit_eval = bool(getattr(cfg, "layerwise_exit_eval", False))
         # host_outputs=True (set by rollout.ModelWrapper, which only reads the action and the exit layer): ``forward`` returns the action
         # as CPU tensors taken from the step's pinned verdict block and ``hidden_states`` as a lazy tuple that is copied off the engine's
         # buffers on first access - no device clone, no extra device read per step.  Default False: eager device tensors like the reference.
@@ -357,8 +360,21 @@ class MPTFlamingo(nn.Module):
             self._sync_controller(ctl)
         r = e.step(vision_x, vision_gripper, lang_x, attention_mask, exit_id=exit_id, env_steps=env_steps)
         r = r if isinstance(r, list) else [r]
+        exits = [x["exit_layer"] for x in r]
+        A = e.A
+        if self.layerwise_exit_eval:                           # every environment's action from the head of ITS exit layer (flamingo_mpt.py:450-457)
+            if ensemble:
+                raise NotImplementedError("use_action_ensemble averages extra_exit's actions; layerwise_exit_eval acts with the per-layer heads")
+            e.h_state.zero_()
+            e.c_state.zero_()
+            e._head_state_changed()
+            use_mask = attention_mask is not None and bool((attention_mask == 0).any())
+            rows = e.layerwise_actions(exits, lang_x.shape[-1], use_mask)
+            return torch.stack([x[:6 * A] for x in rows]), torch.stack([x[6 * A:7 * A] for x in rows]).squeeze(-1) if A == 1 else \
+                torch.stack([x[6 * A:7 * A] for x in rows]), exits
         pk, gk = ("ens_pose", "ens_gripper") if ensemble else ("pose", "gripper")    # ensemble: get_ensemble_action per environment
-        return torch.stack([x[pk] for x in r]), torch.tensor([x[gk] for x in r]), [x["exit_layer"] for x in r]
+        grip = torch.tensor([x[gk] for x in r]) if A == 1 else torch.stack([x[gk] for x in r])
+        return torch.stack([x[pk] for x in r]), grip, exits
 
     def _forward_window(self, vision_x, lang_x, attention_mask, vision_gripper, with_gripper_logits=False, generator=None):
         """Window mode (flamingo_mpt.py:463-517 as ``generate_action_values`` calls it, value_net.py:375-385): the batch rows are
@@ -393,7 +409,8 @@ class MPTFlamingo(nn.Module):
             acts = [w._head_eval(rf[gidx, t].reshape(G * T, cfg.d_model).contiguous(), commit=True) for t in range(Wn)]
             rows.append(torch.stack(acts, dim=1)[: min(G, bs - b0)])                        # (g, W, 8)
         a = torch.cat(rows, dim=0)                                                          # (bs, W, 8)
-        pose, grip, glog = a[..., :6], a[..., 6:7], a[..., 7:8]
+        A = e.A
+        pose, grip, glog = a[..., :6 * A], a[..., 6 * A:7 * A], a[..., 7 * A:8 * A]
         extra = (pose, (grip, glog)) if with_gripper_logits else (pose, grip)
         out = CausalLMOutputWithPast(logits=extra, hidden_states=hidden, exit_layer=cfg.n_layers - 1)
         return out, [], extra, rand_feat, rand_layers.to(hid.device)
@@ -460,12 +477,32 @@ class MPTFlamingo(nn.Module):
             self.llm_inference_time = st["llm_and_exit_checks"] / 1e3 if st else self.forward_time
             self.vision_time = st["vision"] / 1e3 if st else float("nan")
         T = lang_x.reshape(-1).numel()
+        A = e.A
         fast = self.host_outputs and (exit_id is not None or native)
-        if fast:
-            a = torch.cat([r["pose"], torch.tensor([r["gripper"], r["gripper_logit"]], dtype=torch.float32)])   # from the pinned verdict block
+        lw_row = None
+        if self.layerwise_exit_eval:
+            # flamingo_mpt.py:450-457: the action comes from the exit layer's OWN head on hidden_states[exit_layer] (own LSTM history,
+            # update_hidden_state=True); extra_exit only decided where to stop - the reference never commits its state here (nobody calls
+            # update_exit_hidden_state, value_net.py:88-90), and a static exit_id never touches it
+            if not (exit_id is not None or native):
+                raise NotImplementedError("layerwise_exit_eval with a foreign exit controller")
+            e.h_state.zero_()
+            e.c_state.zero_()
+            e._head_state_changed()
+            lw_row = e.layerwise_actions([exit_layer], T)[0]
+        if lw_row is not None:
+            a = lw_row
+            hidden = _LazyHidden(e, exit_layer, T) if fast else None
+        elif fast:
+            if A > 1:
+                a = torch.cat([r["pose"], r["gripper"], r["gripper_logit"]])
+            else:
+                a = torch.cat([r["pose"], torch.tensor([r["gripper"], r["gripper_logit"]], dtype=torch.float32)])   # from the pinned verdict block
             hidden = _LazyHidden(e, exit_layer, T)
         else:
-            if exit_id is not None or native:
+            if (exit_id is not None or native) and A > 1:
+                a = e.act_ext[0, 1, :8 * A].clone()
+            elif exit_id is not None or native:
                 a = e.ctl.view(torch.float32)[abi.CTL_OUT_ACTION: abi.CTL_OUT_ACTION + 8].clone()
             else:
                 a = e.action_dbg[0].clone()
@@ -473,9 +510,12 @@ class MPTFlamingo(nn.Module):
             # of layer i+1); ONE copy, so that the tuple survives the next step overwriting the engine's buffers
             hs = e.hidden[: exit_layer + 1, :T].clone()
             hidden = tuple(hs[i].unsqueeze(0) for i in range(exit_layer + 1))
+        if hidden is None:
+            hs = e.hidden[: exit_layer + 1, :T].clone()
+            hidden = tuple(hs[i].unsqueeze(0) for i in range(exit_layer + 1))
         assert len(hidden) == exit_layer + 1                                                # flamingo_mpt.py:458
-        pose, grip = a[:6].view(1, 1, 6), a[6:7].view(1, 1, 1)
-        logits = (pose, (grip, a[7:8].view(1, 1, 1))) if with_gripper_logits else (pose, grip)
+        pose, grip = a[:6 * A].view(1, 1, 6 * A), a[6 * A:7 * A].view(1, 1, A)               # action_head.py:472-473: A actions per call
+        logits = (pose, (grip, a[7 * A:8 * A].view(1, 1, A))) if with_gripper_logits else (pose, grip)
         vis = e.vis_x_f32.view(1, 1, cfg.n_media, cfg.vit_width)
         media_locations = lang_x.reshape(1, -1) == self.media_token_id                      # flamingo_lm.py:211
         for l in self.lang_encoder._get_decoder_layers():

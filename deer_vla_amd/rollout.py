@@ -125,8 +125,11 @@ class ModelWrapper:
             raise AssertionError("Padding for multi-exit net is not implemented. It requires store feature_cache for each exit separately.")
         if m.fusion_mode in ("two_way", "vit_concat"):
             raise NotImplementedError("fusion_mode %r: the reference asserts out of it for dynamic exit (eval_utils.py:424)" % m.fusion_mode)
-        if m.act_step != 1:
-            raise NotImplementedError("multi-step action heads are not part of DeeR's released configuration")
+        if m.act_step != 1:                                        # eval_utils.py:217-220
+            assert multi_execution <= m.act_step, (multi_execution, m.act_step)
+            if use_action_ensemble:
+                raise NotImplementedError("use_action_ensemble with multi-step action heads: the reference's harness takes the ensemble only "
+                                          "when act_step == 1 (eval_utils.py:456-461)")
         self.model = model
         # this wrapper reads only the action and the exit layer: its OWN forward calls ask for host outputs (step()); the flag is
         # restored after every call, so other callers of the shared model keep eager device tensors
@@ -198,15 +201,23 @@ class ModelWrapper:
             if hasattr(out, "exit_layer"):
                 self.current_exit_layer = out.exit_layer
             # eval_utils.py:454-462: [pose6, gripper > 0.5] of the last time step, gripper scaled to -1 / +1
-            if not self.use_action_ensemble:
-                action = torch.concat((out.logits[0], (out.logits[1] > 0.5).to(out.logits[0].dtype)), dim=2).squeeze(0)[-1]
-            else:                                                   # mean of the last two exits' actions of this step
-                vn = self.exit_controller.module.value_net
-                pose, grip = vn.get_ensemble_action()
-                vn.reset_actions()
-                action = torch.concat((pose, (grip > 0.5).to(pose.dtype)), dim=2).squeeze(0)[-1]
-            action[-1] = (action[-1] - 0.5) * 2
-            action = torch.stack([action] * self.multi_execution, dim=0)
+            if m.act_step != 1:
+                # eval_utils.py:466-475: the head predicted act_step actions; the first multi_execution of them are executed
+                pose = out.logits[0].squeeze(0)[-1].view(m.act_step, -1)
+                grip = (out.logits[1] > 0.5).to(pose.dtype).squeeze(0)[-1].view(m.act_step, -1)
+                action = torch.cat([pose, grip], dim=-1)
+                action[:, -1] = (action[:, -1] - 0.5) * 2
+                action = action[:self.multi_execution]
+            else:
+                if not self.use_action_ensemble:
+                    action = torch.concat((out.logits[0], (out.logits[1] > 0.5).to(out.logits[0].dtype)), dim=2).squeeze(0)[-1]
+                else:                                               # mean of the last two exits' actions of this step
+                    vn = self.exit_controller.module.value_net
+                    pose, grip = vn.get_ensemble_action()
+                    vn.reset_actions()
+                    action = torch.concat((pose, (grip > 0.5).to(pose.dtype)), dim=2).squeeze(0)[-1]
+                action[-1] = (action[-1] - 0.5) * 2
+                action = torch.stack([action] * self.multi_execution, dim=0)
             action = action.cpu().detach().to(dtype=torch.float16).numpy()
         m.set_all_exit_window_size(window_size)
         if m.tcp_rel:
@@ -436,6 +447,11 @@ class BatchedModelWrapper:
                                                               exit_controller=self.exit_controller, exit_id=self.exit_id,
                                                               ensemble=self.use_action_ensemble, env_steps=env_steps)
         self.current_exit_layers = exits
+        A = self.model.module.act_step
+        if A != 1:                                                 # eval_utils.py:466-475 per slot: (B, A, 7), the harness executes the first of them
+            pose = pose.view(self.B, A, 6)
+            act = torch.cat([pose, ((g > 0.5).to(pose.dtype).view(self.B, A, 1) - 0.5) * 2], dim=2)
+            return act[:, 0].to(torch.float16).numpy()
         act = torch.cat([pose, ((g > 0.5).to(pose.dtype).unsqueeze(1) - 0.5) * 2], dim=1)      # eval_utils.py:454-464
         return act.to(torch.float16).numpy()
 

@@ -123,6 +123,9 @@ def param_shapes(cfg: DeerConfig) -> "OrderedDict[str, Tuple[tuple, str]]":
             P[m + "mlp.mlp_down.weight"] = ((d, cfg.mlp_ratio * d), LINEAR)
 
     P.update(head_param_shapes(cfg, "extra_exit."))
+    if getattr(cfg, "layerwise_exit_eval", False):       # flamingo_mpt.py:236-244 with multi_exit=True: one head per internal exit + lm_head
+        for prefix, _ in cfg.layerwise_heads():
+            P.update(head_param_shapes(cfg, prefix))
     return P
 
 
@@ -153,7 +156,8 @@ def head_param_shapes(cfg: DeerConfig, prefix: str) -> "OrderedDict[str, Tuple[t
             P[f"{prefix}rnn.layers.{3 * l + 1}.bias"] = ((H,), LN_B)
         in_f = H
     lin, ln, out = mlp_layer_indices(cfg.mlp_num_hidden_layers)
-    for head, n_out in (("actions", 6), ("gripper", 1)):
+    A = getattr(cfg, "multi_step_action", 1)              # action_head.py:472-473: out_features * multi_step_action outputs
+    for head, n_out in (("actions", 6 * A), ("gripper", A)):
         cur = H
         for li, ni, dim in zip(lin, ln, cfg.mlp_hidden_dims):
             P[f"{prefix}{head}.mlp.{li}.weight"] = ((dim, cur), LINEAR)

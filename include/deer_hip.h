@@ -345,6 +345,16 @@ int deer_head_final(const float* src, int src_stride, int in_dim, int pro, const
                     int layer, int slot, const float* thresholds, int force, int thr_type, int leq, const float* h_tmp,
                     const float* c_tmp, float* h_state, float* c_state, int L, int H, int B, float* action_dbg, float eps,
                     int w_is_f32, void* stream);
+/* the same with multi_step_action = A (action_head.py:458,472-473: Wa [6 A, in_dim], Wg [A, in_dim]; the criterion's delta over all 6 A pose
+ * values; ModelWrapper executes the first multi_execution of the A actions, eval_utils.py:466-475).  action_dbg: [B][64] f32 = pose 6 A |
+ * gripper A | logit A.  A > 1 with a control block: act_ext [B][4][64] f32 holds the previous / committed / ensemble action (the 8-float
+ * fields of the control block then carry the FIRST action), and a host mirror carries [B][128] f32 (committed | ensemble) behind its
+ * (1 + B) * 64 words. */
+int deer_head_final_multi(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0, const float* lnw1,
+                          const float* lnb1, const void* Wa, const float* ba, const void* Wg, const float* bg, int* ctl, int kind,
+                          int layer, int slot, const float* thresholds, int force, int thr_type, int leq, const float* h_tmp,
+                          const float* c_tmp, float* h_state, float* c_state, int L, int H, int B, float* action_dbg, float eps,
+                          int w_is_f32, int multi_step_action, float* act_ext, void* stream);
 /* ExitController.set_timestep (eval_utils.py:662-663) + per-step reset.  step_info: device int32[4] = {hold, step sequence
  * number, host mirror pointer lo, hi} or NULL (no stage hold, no mirror). */
 int deer_ctl_begin_step(int* ctl, const int* step_info, int B, void* stream);

@@ -44,6 +44,10 @@ typedef struct deer_config {
   int sep_resampler;        /* flamingo_mpt.py:132-134,656-659: the gripper camera has its own PerceiverResampler ("perceiver_gripper.*").
                              * The camera frames are then ordered camera-major ([rgb of every env ; gripper of every env]) and every vision
                              * chain holds the frames of ONE camera. */
+  int multi_step_action;    /* A (0 / 1 = one action): the heads emit 6 A pose + A gripper values per call (action_head.py:458,472-473); the
+                             * exit criterion's delta runs over all 6 A pose values (value_net.py:105-133); A <= 8 */
+  int layerwise_exit_eval;  /* flamingo_mpt.py:236-244,253,450-457: per-layer heads "lm_exit_modules.j.*" / "lm_head.*" are ingested next to
+                             * "extra_exit.*", each with its own LSTM state; deer_head_eval_layerwise evaluates one of them */
 } deer_config;
 
 typedef struct deer_model deer_model;
@@ -71,7 +75,8 @@ int deer_model_knows_tensor(const deer_model* m, const char* name);             
 int deer_model_missing_tensors(const deer_model* m, char* buf, int buflen);      /* host only: count of REQUIRED tensors not loaded; names (newline separated) into buf */
 /* host only: location of a named buffer (bytes from the base).  which = 0 arena, 1 workspace.  Workspace names: "img", "vx",
  * "vis_x", "vis_x_f32", "kv_all", "ids", "key_mask", "text_time", "x", "hidden", "h_state", "c_state", "h_tmp", "c_tmp",
- * "h_shadow", "c_shadow", "pooled", "ctl", "thresholds", "step_info", "action_dbg". */
+ * "h_shadow", "c_shadow", "pooled", "ctl", "thresholds", "step_info", "action_dbg" ([n_envs][64]: pose 6 A | gripper A | logit A),
+ * "act_ext" (multi_step_action > 1: [n_envs][4][64] previous / committed / ensemble action), "lw_state" (layerwise_exit_eval). */
 int deer_model_buffer(const deer_model* m, int which, const char* name, long* offset, long* bytes);
 
 /* ---- exit controller configuration (ExitController.__init__ / _set_threshold_value, value_net.py:164-183) ------- */
@@ -122,6 +127,10 @@ int deer_llm_layer(deer_model* m, int layer, int T, int use_mask, int pending_in
 /* one DeterministicDecoder evaluation + exit gate.  feats: NULL = hidden[layer]; kind DEER_KIND_*; slot = exit index */
 int deer_head_eval(deer_model* m, int layer, int T, int kind, int slot, int force, int use_ctl, int shadow, int no_ctl_final,
                    const float* feats, int use_mask, void* stream);
+/* layerwise_exit_eval: head index (1-based, the reference's registration order) of an exit layer or -1; one evaluation of that head on
+ * hidden[layer] from ITS LSTM state (workspace "lw_state": [head][h, c][L][n_envs][H]); outputs in "action_dbg", new state in h_tmp / c_tmp */
+int deer_model_layerwise_head(const deer_model* m, int layer);
+int deer_head_eval_layerwise(deer_model* m, int head, int layer, int T, int use_mask, void* stream);
 /* whole control step on ONE stream (vision batched): begin + vision + media K/V + trunk + heads */
 int deer_step_enqueue(deer_model* m, int T, int use_mask, int exit_id, int shadow, const int* step_info, void* stream);
 /* layers of the dynamic step: returns n and fills need_pseudo[i], is_exit[i], slot[i] for i < n (host only) */

@@ -535,18 +535,34 @@ class OracleDeer:
         self.sd, self.cfg = sd, cfg
         self.extra_exit = OracleHead(sd, cfg, "extra_exit.")
         self.window_size = cfg.window_size
+        # layerwise_exit_eval (flamingo_mpt.py:236-244,253,450-457): one head per internal exit + lm_head for the last layer, each
+        # with its OWN LSTM history (it only advances on the steps that exit at its layer)
+        self.layerwise_exit_eval = bool(getattr(cfg, "layerwise_exit_eval", False))
+        self.lm_exits = {}
+        self.lm_head = None
+        if self.layerwise_exit_eval:
+            for prefix, layer in cfg.layerwise_heads():
+                if prefix == "lm_head.":
+                    self.lm_head = OracleHead(sd, cfg, prefix)
+                else:
+                    self.lm_exits[layer] = OracleHead(sd, cfg, prefix)
+
+    def _heads(self):
+        return [self.extra_exit] + list(self.lm_exits.values()) + ([self.lm_head] if self.lm_head is not None else [])
 
     def get_all_exit_idx(self):
         return self.cfg.exit_ids()
 
-    def set_all_exit_window_size(self, ws):
+    def set_all_exit_window_size(self, ws):                                 # flamingo_mpt.py:275-285: every head
         old = self.extra_exit.window_size
-        self.extra_exit.window_size = ws
+        for h in self._heads():
+            h.window_size = ws
         return old
 
-    def clear_all_exit_memory(self):
-        self.extra_exit.hidden_state = None
-        self.extra_exit.history_memory = []
+    def clear_all_exit_memory(self):                                        # flamingo_mpt.py:287-301: every head
+        for h in self._heads():
+            h.hidden_state = None
+            h.history_memory = []
 
     def encode_vision(self, vision_x, vision_gripper):
         """``_encode_multi_vision_post_fusion`` (flamingo_mpt.py:609-668)."""
@@ -579,7 +595,10 @@ class OracleDeer:
                 exit_id += self.cfg.n_layers
             assert 0 <= exit_id < self.cfg.n_layers
             assert len(hidden) == exit_id + 1                               # :458
-            logits = self.extra_exit(hidden[exit_id], state_tensor=state_tensor)   # commits LSTM state (:459)
+            head = self.extra_exit                                          # :450-457
+            if self.layerwise_exit_eval:
+                head = self.lm_head if exit_id == self.cfg.n_layers - 1 else self.lm_exits[exit_id]
+            logits = head(hidden[exit_id], state_tensor=state_tensor)       # commits that head's LSTM state (:459)
             return {"logits": logits, "exit_layer": exit_layer, "hidden_states": hidden, "vis_x": vis_x}
         return {"logits": None, "exit_layer": exit_layer, "hidden_states": hidden, "vis_x": vis_x}
 

@@ -224,13 +224,17 @@ def gen_head_state(name="head_state.npz"):
     save(name, cfg, seed, feats=feats, state=state, upd=np.asarray(upd), pose=torch.stack(poses), grip=torch.stack(grips))
 
 
-def gen_deer_forward_variant(name, use_state=False, sep_resampler=False):
+def gen_deer_forward_variant(name, use_state=False, sep_resampler=False, layerwise=False, multi_step_action=1):
     """The reference's own MPTFlamingo.forward with ``use_state`` / ``sep_resampler`` (flamingo_mpt.py:132-136,656-659; the state
     reaches ONLY the action head on the post-fusion path: ``_encode_multi_vision_post_fusion`` is called without it, :381).  Static
     exits; with sep_resampler also a dynamic episode (with use_state the reference's ``ActionValueNet`` calls the head without a
-    state tensor, value_net.py:122-129, and raises - dynamic exit does not exist for that variant)."""
+    state tensor, value_net.py:122-129, and raises - dynamic exit does not exist for that variant).
+    layerwise: ``multi_exit=True, layerwise_exit_eval=True`` (eval_calvin.py:530,539): the action of exit layer k comes from that layer's
+    own head ``lm_exits[k]`` / ``lm_head`` (flamingo_mpt.py:450-457), each with its own LSTM history; the exit decision stays with
+    ``extra_exit`` (whose hidden state nobody commits in this mode).  multi_step_action: ``6 A`` pose + ``A`` gripper outputs per
+    head call (action_head.py:472-473)."""
     _dist_init()
-    cfg, seed = llm_cfg(use_state=use_state, sep_resampler=sep_resampler), 7
+    cfg, seed = llm_cfg(use_state=use_state, sep_resampler=sep_resampler, layerwise_exit_eval=layerwise, multi_step_action=multi_step_action), 7
     sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
     lm, mod = build_ref_lang_encoder(cfg, sd)
     extend_instance(lm, FlamingoLMMixin)
@@ -240,7 +244,8 @@ def gen_deer_forward_variant(name, use_state=False, sep_resampler=False):
     model = MPTFlamingo(venc_mod, lm, cfg.eoc_token_id, cfg.media_token_id, vis_dim=cfg.vit_width,
                         cross_attn_every_n_layers=cfg.cross_attn_every_n_layers, window_size=cfg.window_size,
                         use_gripper=True, fusion_mode="post", llm="mpt_dolly_3b", pooling="max", use_state=use_state,
-                        sep_resampler=sep_resampler, early_exit_layer=cfg.early_exit_layer, multi_exit=False,
+                        sep_resampler=sep_resampler, early_exit_layer=cfg.early_exit_layer, multi_exit=bool(layerwise),
+                        layerwise_exit_eval=bool(layerwise), multi_step_action=multi_step_action,
                         exit_interval=cfg.exit_interval, mlp_layernorm=True, lstm_layernorm=True, mlp_num_hidden_layers=2,
                         lstm_num_layers=4).eval()
     sd_model = {k: v for k, v in sd.items() if not k.startswith("vision_encoder.")}
@@ -249,6 +254,9 @@ def gen_deer_forward_variant(name, use_state=False, sep_resampler=False):
         assert k in ref_keys and ref_keys[k] == tuple(v.shape), (k, tuple(v.shape), ref_keys.get(k))
     missing, unexpected = model.load_state_dict(sd_model, strict=False)
     assert not unexpected, unexpected
+    if layerwise:                                            # every per-layer head's parameters are this repo's inventory (config.layerwise_heads)
+        assert not any(k.startswith(("lm_exit_modules.", "lm_head.")) for k in missing), missing
+        assert sorted(model.lm_exits.keys()) == [e for _, e in cfg.layerwise_heads()][:-1]
     if sep_resampler:
         assert not any(k.startswith("perceiver_gripper.") for k in missing), missing
     if use_state:                                            # state_fc (a media token on other fusion paths) is never applied here
@@ -316,6 +324,13 @@ def gen_deer_forward_variant(name, use_state=False, sep_resampler=False):
             outs["dynamic_raises"] = np.asarray(1)
             print(f"  {name}: the reference's dynamic exit with use_state raises {type(e).__name__}: {e}")
     save(name, cfg, seed, ids=ids, mask=mask, rgb=rgb, grip=grip, state=state, bf16_round=1, **outs)
+
+
+def gen_round5_variants():
+    """layerwise_exit_eval and multi_step_action (round 5), each from the reference's own MPTFlamingo.forward"""
+    gen_deer_forward_variant("deer_forward_lw.npz", layerwise=True)
+    gen_deer_forward_variant("deer_forward_ms2.npz", multi_step_action=2)
+    gen_deer_forward_variant("deer_forward_lw_ms3.npz", layerwise=True, multi_step_action=3)
 
 
 def _dist_init():
@@ -853,5 +868,6 @@ if __name__ == "__main__":
     gen_deer_forward()
     gen_deer_forward_variant("deer_forward_state.npz", use_state=True)
     gen_deer_forward_variant("deer_forward_sep.npz", sep_resampler=True)
+    gen_round5_variants()
     gen_hf_mpt_block()
     gen_hf_clip()

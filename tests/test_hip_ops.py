@@ -313,8 +313,11 @@ def test_gemm_tiled_batched_strided(lib):
 
 
 # -------------------------------------------------------------------------------------------- attention
-@pytest.mark.parametrize("B,H,q_len,kv_len", [(2, 16, 257, 257), (2, 8, 64, 320), (2, 2, 17, 17), (1, 1, 5, 68), (1, 3, 100, 33)])
+@pytest.mark.parametrize("B,H,q_len,kv_len", [(2, 16, 257, 257), (8, 16, 257, 257), (3, 16, 200, 270), (2, 8, 64, 320), (2, 2, 17, 17), (1, 1, 5, 68),
+                                              (1, 3, 100, 33)])
 def test_attn_mfma(lib, B, H, q_len, kv_len):
+    """(2, 16, 257, 257) and (8, 16, 257, 257): the ViT shapes - round 5's attn_vit_kernel (V row-major in LDS + transpose reads), one query tile
+    per wave and (>= 128 (head, image) pairs) the looping form; (3, 16, 200, 270): the same kernel with ragged query / key counts."""
     hd = 64
     q = dev(rnd(B, q_len, H * hd, seed=11), torch.bfloat16)
     k = dev(rnd(B, kv_len, H * hd, seed=12), torch.bfloat16)

@@ -132,12 +132,37 @@ def test_factory_fails_loudly_on_keywords_it_does_not_implement():
     from deer_vla_amd.factory import create_model_and_transforms
     base = dict(clip_vision_encoder_path="ViT-L-14", clip_vision_encoder_pretrained="openai", lang_encoder_path="", tokenizer_path="",
                 use_gripper=True, fusion_mode="post", llm_name="mpt_dolly_3b", device="cpu")
-    for kw in (dict(multi_step_action=3), dict(last_action=True), dict(fwd_pred=True), dict(fwd_pred_hand=True), dict(residual=True),
-               dict(pad_length=12), dict(refresh=2), dict(layerwise_exit_eval=True), dict(use_hist=True),
+    for kw in (dict(multi_step_action=9), dict(last_action=True), dict(fwd_pred=True), dict(fwd_pred_hand=True), dict(residual=True),
+               dict(pad_length=12), dict(refresh=2), dict(layerwise_exit_eval=True, use_state=True), dict(use_hist=True),
                dict(use_diff=True), dict(share_exit=True), dict(decoder_type="gpt"),
                dict(head_type="diffusion"), dict(llm_name="llama_9b"), dict(clip_vision_encoder_path="ViT-B-32")):
         with pytest.raises(NotImplementedError):
             create_model_and_transforms(**{**base, **kw})
+    with pytest.raises(ValueError):                       # the per-layer heads only exist with multi_exit=True (flamingo_mpt.py:236-249)
+        create_model_and_transforms(**{**base, "layerwise_exit_eval": True, "multi_exit": False})
+
+
+def test_factory_builds_multi_step_and_layerwise_variants():
+    """Round 5: ``multi_step_action`` ("Nstep" checkpoints, eval_calvin.py:384-387: 6 A + A outputs per head,
+    action_head.py:472-473) and ``layerwise_exit_eval`` (eval_calvin.py:330,530,539: per-layer heads ``lm_exit_modules.j`` / ``lm_head``,
+    flamingo_mpt.py:236-244) no longer raise: the config carries them, the parameter inventory grows by the heads the reference
+    registers (pinned against the reference's own state dict by tests/golden/make_golden.py::gen_round5_variants) and the harness-facing
+    attributes follow (``act_step``, ``layerwise_exit_eval``)."""
+    from deer_vla_amd import synthetic as syn
+    from deer_vla_amd.config import deer_tiny
+    from deer_vla_amd.factory import create_model_and_transforms
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(deer_tiny(multi_step_action=3, layerwise_exit_eval=True), 3)
+    model, _, _ = create_model_and_transforms("ViT-L-14", "openai", "", "", use_gripper=True, fusion_mode="post", llm_name="mpt_dolly_3b",
+                                              state_dict=sd, cfg=cfg, multi_step_action=3, layerwise_exit_eval=True, multi_exit=True, device="cpu")
+    assert model.act_step == 3 and model.layerwise_exit_eval and model.cfg.multi_step_action == 3
+    assert cfg.multi_step_action == 1 and not cfg.layerwise_exit_eval          # the caller's config is not mutated
+    heads = model.cfg.layerwise_heads()
+    assert [e for _, e in heads] == model.cfg.exit_ids() and heads[-1][0] == "lm_head."
+    want = syn.param_shapes(model.cfg)
+    for prefix, _ in heads + [("extra_exit.", -1)]:
+        out = 1 + 4 * model.cfg.mlp_num_hidden_layers
+        assert want[f"{prefix}actions.mlp.{out}.weight"][0][0] == 18 and want[f"{prefix}gripper.mlp.{out}.weight"][0][0] == 3
 
 
 def test_factory_accepts_the_exact_keyword_set_of_the_reference_eval_harness():

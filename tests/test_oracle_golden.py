@@ -324,11 +324,15 @@ def test_action_head_with_robot_state_matches_reference():
         close(gr, g["grip"][t])
 
 
-@pytest.mark.parametrize("name", ["deer_forward_state.npz", "deer_forward_sep.npz"])
+@pytest.mark.parametrize("name", ["deer_forward_state.npz", "deer_forward_sep.npz", "deer_forward_lw.npz", "deer_forward_ms2.npz",
+                                  "deer_forward_lw_ms3.npz"])
 def test_forward_variants_match_reference_mptflamingo(name):
     """``use_state`` (state embedding in the action head; static exits only - the reference's dynamic exit raises TypeError with it,
     value_net.py:122-129, recorded in the fixture) and ``sep_resampler`` (own Perceiver weights for the gripper camera,
-    flamingo_mpt.py:132-134,656-659), against the reference's own MPTFlamingo.forward."""
+    flamingo_mpt.py:132-134,656-659), against the reference's own MPTFlamingo.forward.  Round 5: ``layerwise_exit_eval`` (per-layer
+    heads lm_exits[k] / lm_head with their own LSTM histories act on the exit extra_exit's value net chose, flamingo_mpt.py:450-457)
+    and ``multi_step_action`` (6 A pose + A gripper outputs per head call, action_head.py:472-473; the delta of the exit criterion runs
+    over all 6 A pose values, value_net.py:105-133)."""
     cfg, seed, g = load(name)
     from deer_vla_amd import synthetic as syn
     sd = syn.make_synthetic_state(cfg, seed, bf16_round=bool(int(g["bf16_round"])))
