@@ -71,6 +71,8 @@ SIGNATURES = {
     "deer_head_fc": [P, I, I, I, P, P, P, P, P, P, P, P, I, P, I, F, P, I, I, I, P],
     "deer_head_final": [P, I, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, I, I, P, F, I, P],
     "deer_head_final_multi": [P, I, I, I, P, P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P, P, P, I, I, I, P, F, I, I, P, P],
+    "deer_head_fused_granules": [I, I, I, I, I, P],
+    "deer_head_fused": [P, I, I, P],
     "deer_ctl_begin_step": [P, P, I, P],
     "deer_preprocess_frames": [P, I, I, I, I, P, P, P, P, P, P],
     "deer_preprocess_scratch_bytes": [I, I, I, I],
@@ -91,6 +93,7 @@ SIGNATURES = {
     "deer_model_configure_exit": [P, P, I, I, I, I],
     "deer_model_real_num_exit": [P],
     "deer_model_set_compaction": [P, I],
+    "deer_model_set_head_fused": [P, I],
     "deer_model_head_state_changed": [P],
     "deer_model_set_persistent_layer": [P, I],
     "deer_vit_l14_encode": [P, P, I, P, P],
@@ -115,7 +118,7 @@ SIGNATURES = {
     "deer_step_plan_run": [P, I, I, P, P, P, P, P],
     "deer_step_plan_destroy": [P],
 }
-_RESTYPE = {"deer_hip_arch": c_char_p, "deer_model_arena_bytes": c_long, "deer_model_workspace_bytes": c_long, "deer_preprocess_scratch_bytes": c_long,
+_RESTYPE = {"deer_head_fused_granules": c_long, "deer_hip_arch": c_char_p, "deer_model_arena_bytes": c_long, "deer_model_workspace_bytes": c_long, "deer_preprocess_scratch_bytes": c_long,
             "deer_model_destroy": None, "deer_step_plan_destroy": None}
 
 # constants of include/deer_hip.h
@@ -132,6 +135,13 @@ KIND_PSEUDO, KIND_CHECK, KIND_COMMIT = 0, 1, 2
 THR_TYPES = {"L2": 0, "mean": 1, "max": 2, "cosine": 3}
 
 _lib = None
+
+
+def max_trunk_rows(cfg, precision: str = "bf16") -> int:
+    """LLM rows (n_envs * T) one engine takes: 256 in the bf16 arithmetic (8 environments x the reference's max_length = 32 tokens,
+    data.py:905-919; the hi/lo-plane trunk GEMM runs them in row blocks of 128), 128 in the fp32 arithmetic or when d_model % 64 != 0
+    (one launch of deer_gemm_skinny)."""
+    return 256 if (precision == "bf16" and cfg.d_model % 64 == 0) else 128
 
 
 def skinny_mpad(M: int) -> int:

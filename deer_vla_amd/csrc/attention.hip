@@ -222,7 +222,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
 template <int NWAVE, bool LOOP, int NT>     // NT = key tiles of 16 (kv_len <= 16 NT); PV runs (NT + 1) / 2 chunks of 32 keys
-__global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void attn_vit_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
+__global__ __launch_bounds__(64 * NWAVE, 4) void attn_vit_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
                                                               const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int q_len, int kv_len,
                                                               int ldq, int ldk, int ldv, int ldo, long q_bstride, long k_bstride,
                                                               long v_bstride, long o_bstride, float scale_log2e, int tpw) {
@@ -409,6 +409,14 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
     const bf16_t* q = reinterpret_cast<const bf16_t*>(Q);
     bf16_t* o = reinterpret_cast<bf16_t*>(O);
 #define DEER_VIT_ARGS grid, st, q, kp, vp, o, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride, scale, tpw
+    // env batches (>= 128 (head, image) pairs): ONE 16-wave workgroup per pair walks all 17 query tiles - the head's K / V are staged once
+    // (DEER_ATTN_W16=0: two 8-wave workgroups per pair, each staging them)
+    static const bool w16 = [] { const char* e = getenv("DEER_ATTN_W16"); return e == nullptr || e[0] != '0'; }();
+    if (tpw != nwave && w16) {
+      grid = dim3(1, heads, batch);
+      tpw = tiles;
+      return launch_attn_vit_nt<16, true, 17>(DEER_VIT_ARGS);
+    }
     return tpw != nwave ? launch_attn_vit_nt<8, true, 17>(DEER_VIT_ARGS) : launch_attn_vit_nt<8, false, 17>(DEER_VIT_ARGS);
 #undef DEER_VIT_ARGS
   }

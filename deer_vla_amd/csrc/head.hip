@@ -16,6 +16,7 @@
 // Numerics: weights bf16 (streamed from HBM / Infinity Cache), activations, LSTM state, LayerNorm statistics
 // and the delta in fp32, so the exit decision differs from an fp32 reference only by summation order.
 #include "common.h"
+#include "../../include/deer_hip.h"
 
 #define HB_MAX 8   // max environments per batch
 
@@ -707,19 +708,23 @@ extern "C" int deer_head_fc(const float* src, int src_stride, int in_dim, int pr
 // ---- output Linear (6 tanh + 1 sigmoid) + exit gate, per environment ----------------------------------------------
 // One workgroup per environment.  src: [B][src_stride] (the last hidden Linear's output, [2][in_dim] per env).
 // ctl: env b at ctl + b*CTL_WORDS.  State tensors h/c: [L][B][H] (LH = L, sH = H).  action_dbg: [B][8] or NULL.
-template <typename WT>
-__global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict__ src, int src_stride, int in_dim, int pro,
-                                                         const float* __restrict__ lnw0, const float* __restrict__ lnb0,
-                                                         const float* __restrict__ lnw1, const float* __restrict__ lnb1,
-                                                         const WT* __restrict__ Wa, const float* __restrict__ ba,
-                                                         const WT* __restrict__ Wg, const float* __restrict__ bg, int* ctl0,
-                                                         int kind, int layer, int slot, const float* __restrict__ thresholds,
-                                                         int force, int thr_type, int leq, const float* __restrict__ h_tmp,
-                                                         const float* __restrict__ c_tmp, float* __restrict__ h_state,
-                                                         float* __restrict__ c_state, int L, int H, int B,
-                                                         float* __restrict__ action_dbg, float eps, int A,
-                                                         float* __restrict__ act_ext) {
-  const int b = blockIdx.x;
+// The work of one environment b as a device function of 512 threads: head_final_kernel runs it one workgroup per environment;
+// head_fused_kernel (below) runs it as the last phase of the one-launch evaluation, with the hidden Linear's output staged in LDS
+// (src0 / src1 then point into LDS) and the new LSTM state taken from the tagged exchange granules (GRAN) instead of h_tmp / c_tmp.
+// lds: 2 * in_dim + 16 + 64 + 4 floats.  skip_checked: the caller already evaluated head_skip().
+template <typename WT, bool GRAN>
+__device__ __forceinline__ void head_final_body(int b, const float* s0, const float* s1, float* lds, int in_dim, int pro,
+                                                const float* __restrict__ lnw0, const float* __restrict__ lnb0,
+                                                const float* __restrict__ lnw1, const float* __restrict__ lnb1,
+                                                const WT* __restrict__ Wa, const float* __restrict__ ba,
+                                                const WT* __restrict__ Wg, const float* __restrict__ bg, int* ctl0,
+                                                int kind, int layer, int slot, const float* __restrict__ thresholds,
+                                                int force, int thr_type, int leq, const float* __restrict__ h_tmp,
+                                                const float* __restrict__ c_tmp, float* __restrict__ h_state,
+                                                float* __restrict__ c_state, int L, int H, int B,
+                                                float* __restrict__ action_dbg, float eps, int A,
+                                                float* __restrict__ act_ext, const unsigned long long* hgran,
+                                                const unsigned long long* cgran) {
   if (head_skip(ctl0, kind, layer, B)) {
     // Every workgroup of a CHECK launch reports exactly once, whatever path it takes: a check nobody needed (stage hold)
     // still tells the host that this segment is over, and a workgroup that starts late may see ALL_EXITED raised by a
@@ -745,15 +750,11 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
     const int k = u * 512 + lane * 8;
     pw[u] = (wave < 7 && k < in_dim) ? W8<WT>::load(Wrow + k) : W8<WT>::zero();
   }
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xa = lds;                    // actions-head input [in_dim]
   float* xg = lds + in_dim;           // gripper-head input [in_dim]
   float* red = xg + in_dim;           // [16]
   float* outv = red + 16;             // [64]: 7 A raw outputs (A = multi_step_action <= 8), then the A gripper logits
   int* flag = reinterpret_cast<int*>(outv + 64);
-  const bool grouped = (pro == PRO_GROUP_LN_RELU || pro == PRO_GROUP_RELU);
-  const float* s0 = src + (long)b * src_stride;
-  const float* s1 = s0 + (grouped ? in_dim : 0);
   if (pro == PRO_GROUP_LN_RELU) {
     block_ln(s0, xa, in_dim, lnw0, lnb0, eps, true, red);
     block_ln(s1, xg, in_dim, lnw1, lnb1, eps, true, red);
@@ -963,10 +964,377 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
     for (int i = threadIdx.x; i < L * H; i += blockDim.x) {
       const int l = i / H, u = i - l * H;
       const long o = ((long)l * B + b) * H + u;
-      h_state[o] = h_tmp[o];
-      c_state[o] = c_tmp[o];
+      if (GRAN) {     // written by other workgroups of THIS launch: read through the device-coherent granules (every one is complete by now)
+        h_state[o] = __uint_as_float((unsigned)__hip_atomic_load(hgran + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        c_state[o] = __uint_as_float((unsigned)__hip_atomic_load(cgran + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      } else {
+        h_state[o] = h_tmp[o];
+        c_state[o] = c_tmp[o];
+      }
     }
   }
+}
+
+template <typename WT>
+__global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict__ src, int src_stride, int in_dim, int pro,
+                                                         const float* __restrict__ lnw0, const float* __restrict__ lnb0,
+                                                         const float* __restrict__ lnw1, const float* __restrict__ lnb1,
+                                                         const WT* __restrict__ Wa, const float* __restrict__ ba,
+                                                         const WT* __restrict__ Wg, const float* __restrict__ bg, int* ctl0,
+                                                         int kind, int layer, int slot, const float* __restrict__ thresholds,
+                                                         int force, int thr_type, int leq, const float* __restrict__ h_tmp,
+                                                         const float* __restrict__ c_tmp, float* __restrict__ h_state,
+                                                         float* __restrict__ c_state, int L, int H, int B,
+                                                         float* __restrict__ action_dbg, float eps, int A,
+                                                         float* __restrict__ act_ext) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.x;
+  const bool grouped = (pro == PRO_GROUP_LN_RELU || pro == PRO_GROUP_RELU);
+  const float* s0 = src + (long)b * src_stride;
+  const float* s1 = s0 + (grouped ? in_dim : 0);
+  head_final_body<WT, false>(b, s0, s1, lds, in_dim, pro, lnw0, lnb0, lnw1, lnb1, Wa, ba, Wg, bg, ctl0, kind, layer, slot, thresholds, force,
+                             thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps, A, act_ext, nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// One head evaluation (pool -> L LSTM layers -> hidden Linears -> output Linear + exit gate) as ONE launch (round 5).
+// The eight-launch form above is a chain of dependent latency-bound kernels (64-70 us at one environment, 42-82 MB of weights = 10-16 us
+// of stream): every launch boundary drains the GPU, ramps up again and pays a cold HBM round trip for its weights.  Here G workgroups of
+// 8 waves stay resident for the whole evaluation; wave w owns the SAME rows the separate kernels give a wave (one LSTM hidden unit = its
+// four gate rows, two rows of a hidden Linear) and the vectors that separate the phases - pooled feature, every layer's h, the hidden
+// Linears' outputs: 0.5-2 K floats per environment - travel between workgroups as DATA-TAGGED 8-byte granules {f32 value, tag} written
+// and read with relaxed agent-scope atomics (the guide's hand-off R2: no flag, no fence; a consumer polls the granule itself).  The tag
+// is the number of evaluations the exchange buffer has served (kept beside the error word): nothing is reset between evaluations.  Every phase requests its weight
+// rows BEFORE it gathers its input, so the HBM latency of a phase hides behind the hand-off it has to wait for anyway.
+// The arithmetic per row (k split over the lanes in 512-column steps, in-wave butterfly sums, LayerNorm one wave per row, the output
+// Linear + exit gate = head_final_body) is that of the separate kernels; only control steps with a control block use this form (the
+// window / calibration path and static exits keep the separate kernels).  Every spin is bounded: a timeout raises err[0].
+// Residency: G <= 128 workgroups of 512 threads - they need no particular placement and no other kernel ever waits for them.
+#define HF_SPIN_LIMIT (1 << 22)
+
+__device__ __forceinline__ unsigned long long hf_pack(float v, unsigned tag) {
+  return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
+__device__ __forceinline__ void hf_publish(unsigned long long* g, float v, unsigned tag) {
+  __hip_atomic_store(g, hf_pack(v, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// n tagged granules -> dst (LDS), all threads of the workgroup; 8 requests in flight per thread, late granules are polled one by one
+__device__ __forceinline__ void hf_gather(const unsigned long long* g, int n, float* dst, unsigned tag, int* err) {
+  const int step = blockDim.x;
+  for (int base = threadIdx.x; base < n; base += step * 8) {
+    unsigned long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * step;
+      v[u] = i < n ? __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * step;
+      if (i < n) {
+        int spins = 0;
+        while ((unsigned)(v[u] >> 32) != tag) {
+          if (++spins > HF_SPIN_LIMIT) { *err = 1; break; }
+          __builtin_amdgcn_s_sleep(2);
+          v[u] = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        dst[i] = __uint_as_float((unsigned)v[u]);
+      }
+    }
+  }
+}
+
+// HBT: compile-time bound of the environment loops (1: one environment - the latency-critical case; 8: env batches).  The loops over the
+// LSTM layers / hidden Linears are unrolled with compile-time indices: a runtime index into the by-value argument struct would make
+// hipcc copy the struct to scratch (seen: 1.4 KB of scratch per lane).
+template <typename WT, int HBT>
+__global__ __launch_bounds__(512) void head_fused_kernel(deer_head_fused_args a) {
+  const int B = a.B, H = a.H, d = a.d, L = a.L;
+  int* ctl0 = a.ctl;
+  if (head_skip(ctl0, a.kind, a.layer, B)) {
+    if ((int)blockIdx.x < B && a.kind == KIND_CHECK && threadIdx.x == 0) check_done(ctl0, a.slot, B);
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* raw = lds;                          // [B][max_in]: gathered input of the phase
+  float* xs = lds + (long)B * a.max_in;      // [B][max_in] (grouped phases: [2][B][in]): the phase's normalised input
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int TW = gridDim.x * 8, gw = blockIdx.x * 8 + wave;
+  // tag of this evaluation: err[1] counts the evaluations this exchange buffer has served; the workgroup that runs the last phase bumps
+  // it when everything is over (every workgroup that has any work read it before: the last phase waits for all of their results)
+  const unsigned tag = ((const volatile unsigned*)a.err)[1] + 1u;
+  unsigned long long* gX0 = a.xg;
+  unsigned long long* gH = gX0 + (long)B * d;
+  unsigned long long* gC = gH + (long)L * B * H;
+  unsigned long long* gZ = gC + (long)L * B * H;
+
+  // ---- LSTM layer 0: this wave's four gate rows are requested before anything else ----
+  constexpr int LSTM_PF = 4;
+  const int j0 = gw;                                                  // first hidden unit of this wave (others: j0 + TW, ...)
+  const int jr0 = j0 < H ? j0 : H - 1;
+  typename W8<WT>::reg wi[LSTM_PF][4];
+  {
+    const WT* w_ih = reinterpret_cast<const WT*>(a.w_ih[0]);
+#pragma unroll
+    for (int u = 0; u < LSTM_PF; ++u) {
+      const int k = u * 512 + lane * 8;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wi[u][q] = k < d ? W8<WT>::load_stream(w_ih + ((long)q * H + jr0) * d + k) : W8<WT>::zero();
+    }
+  }
+  // ---- phase 0: token pool, spread over all threads of the launch (head_pool_kernel's arithmetic) ----
+  for (int e = blockIdx.x * 512 + tid; e < B * d; e += gridDim.x * 512) {
+    const int b = e / d, i = e - b * d;
+    const int sl = a.cmap != nullptr ? a.cmap[CMAP_ENV_SLOT + b] : b;
+    float acc = 0.f;
+    if (sl >= 0) {
+      const float* x = a.feats + ((long)sl * a.T) * d + i;
+      const unsigned char* km = a.key_mask != nullptr ? a.key_mask + b * a.T : nullptr;
+      acc = a.avg ? 0.f : -INFINITY;
+      int n = 0;
+      for (int t = 0; t < a.T; ++t) {
+        if (km != nullptr && km[t] == 0) continue;
+        const float v = x[(long)t * d];
+        acc = a.avg ? acc + v : fmaxf(acc, v);
+        ++n;
+      }
+      if (a.avg) acc /= (float)max(n, 1);
+    }
+    hf_publish(gX0 + e, acc, tag);
+  }
+  // ---- LSTM layers ----
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    if (l >= L) break;
+    const int in_dim = l == 0 ? d : H;
+    const WT* w_ih = reinterpret_cast<const WT*>(a.w_ih[l]);
+    if (l > 0) {                                                     // this layer's rows: in flight while the input is gathered
+#pragma unroll
+      for (int u = 0; u < LSTM_PF; ++u) {
+        const int k = u * 512 + lane * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wi[u][q] = k < in_dim ? W8<WT>::load_stream(w_ih + ((long)q * H + jr0) * in_dim + k) : W8<WT>::zero();
+      }
+    }
+    const bool ln = l > 0 && a.lstm_ln;
+    __syncthreads();                                                 // the previous phase's reads of raw / xs are over
+    hf_gather(l == 0 ? gX0 : gH + (long)(l - 1) * B * H, B * in_dim, ln ? raw : xs, tag, a.err);
+    __syncthreads();
+    if (ln) {
+      rows_ln_to_lds(raw, in_dim, xs, in_dim, B, a.ln_w[l > 0 ? l - 1 : 0], a.ln_b[l > 0 ? l - 1 : 0], a.eps, false);
+      __syncthreads();
+    }
+    const float* b_ih = a.b_ih[l];
+    const float* ghh = a.ghh + (long)l * B * 4 * H;
+    const float* c_prev = a.c_prev + (long)l * B * H;
+    for (int j = j0; j < H; j += TW) {
+      float acc[4][HBT];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < HBT; ++b) acc[q][b] = 0.f;
+      if (j == j0) {
+#pragma unroll
+        for (int u = 0; u < LSTM_PF; ++u) {
+          const int k = u * 512 + lane * 8;
+          if (k < in_dim) {
+#pragma unroll
+            for (int b = 0; b < HBT; ++b)
+              if (b < B) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q][b] += W8<WT>::dot(wi[u][q], xs + b * in_dim + k);
+              }
+          }
+        }
+      }
+      for (int k = (j == j0 ? LSTM_PF * 512 : 0) + lane * 8; k < in_dim; k += 512) {
+        typename W8<WT>::reg w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = W8<WT>::load(w_ih + ((long)q * H + j) * in_dim + k);
+#pragma unroll
+        for (int b = 0; b < HBT; ++b)
+          if (b < B) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q][b] += W8<WT>::dot(w[q], xs + b * in_dim + k);
+          }
+      }
+      float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
+#pragma unroll
+      for (int b = 0; b < HBT; ++b)
+        if (b < B) {
+          const float t0 = wave_sum(acc[0][b]), t1 = wave_sum(acc[1][b]), t2 = wave_sum(acc[2][b]), t3 = wave_sum(acc[3][b]);
+          if (lane == b) { gi = t0; gf = t1; gg = t2; go = t3; }
+        }
+      if (lane < B) {
+        const int b = lane;
+        const float* gp = ghh + (long)b * 4 * H + j;
+        gi += b_ih[j] + gp[0]; gf += b_ih[H + j] + gp[H]; gg += b_ih[2 * H + j] + gp[2 * H]; go += b_ih[3 * H + j] + gp[3 * H];
+        const float c2 = sigmoidf_(gf) * c_prev[b * H + j] + sigmoidf_(gi) * tanhf(gg);
+        const float h2 = sigmoidf_(go) * tanhf(c2);
+        const long o = ((long)l * B + b) * H + j;
+        a.c_tmp[o] = c2;
+        a.h_tmp[o] = h2;
+        hf_publish(gC + o, c2, tag);
+        hf_publish(gH + o, h2, tag);
+      }
+    }
+  }
+  // ---- hidden Linears of both MLP heads ----
+  const float* lnw_last = L == 4 ? a.ln_w[3] : L == 3 ? a.ln_w[2] : L == 2 ? a.ln_w[1] : a.ln_w[0];   // LayerNorm of the last LSTM layer's output
+  const float* lnb_last = L == 4 ? a.ln_b[3] : L == 3 ? a.ln_b[2] : L == 2 ? a.ln_b[1] : a.ln_b[0];
+  long zoff = 0;
+  int in_dim = H;
+#pragma unroll
+  for (int fi = 0; fi < 3; ++fi) {
+    if (fi >= a.n_fc) break;
+    const int out_dim = a.fc_dim[fi];
+    const int PG = (out_dim + 1) / 2;                                // row pairs per group
+    const int p0 = gw;
+    const bool live0 = p0 < 2 * PG;
+    const int grp0 = live0 ? p0 / PG : 0, n00 = live0 ? 2 * (p0 - grp0 * PG) : 0;
+    const WT* W0 = reinterpret_cast<const WT*>(grp0 ? a.fw[fi][1] : a.fw[fi][0]);
+    typename W8<WT>::reg pw0[2], pw1[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = u * 512 + lane * 8;
+      pw0[u] = (live0 && k < in_dim) ? W8<WT>::load_stream(W0 + (long)n00 * in_dim + k) : W8<WT>::zero();
+      pw1[u] = (live0 && n00 + 1 < out_dim && k < in_dim) ? W8<WT>::load_stream(W0 + (long)(n00 + 1) * in_dim + k) : W8<WT>::zero();
+    }
+    __syncthreads();
+    if (fi == 0) {                                                   // shared input: [LN of] the last LSTM layer's h
+      hf_gather(gH + (long)(L - 1) * B * H, B * H, a.lstm_ln ? raw : xs, tag, a.err);
+      __syncthreads();
+      if (a.lstm_ln) {
+        rows_ln_to_lds(raw, H, xs, H, B, lnw_last, lnb_last, a.eps, false);
+        __syncthreads();
+      }
+    } else {                                                         // grouped: x_g = relu([LN_g](z[b][g * in ..])) -> xs[g][b][in]
+      hf_gather(gZ + zoff - (long)B * 2 * in_dim, B * 2 * in_dim, raw, tag, a.err);
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        rows_to_lds(raw + g * in_dim, 2 * in_dim, xs + (long)g * B * in_dim, in_dim, B, a.mlp_ln != 0, a.fln_w[fi > 0 ? fi - 1 : 0][g],
+                    a.fln_b[fi > 0 ? fi - 1 : 0][g], a.eps, true);
+      __syncthreads();
+    }
+    for (int p = p0; p < 2 * PG; p += TW) {
+      const int grp = p / PG, n0 = 2 * (p - grp * PG);
+      const bool two = n0 + 1 < out_dim;
+      const WT* W = reinterpret_cast<const WT*>(grp ? a.fw[fi][1] : a.fw[fi][0]);
+      const float* bb = grp ? a.fb[fi][1] : a.fb[fi][0];
+      const float* x = xs + (fi == 0 ? 0 : (long)grp * B * in_dim);
+      float a0[HBT], a1[HBT];
+#pragma unroll
+      for (int b = 0; b < HBT; ++b) a0[b] = a1[b] = 0.f;
+      if (p == p0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = u * 512 + lane * 8;
+          if (k < in_dim) {
+#pragma unroll
+            for (int b = 0; b < HBT; ++b)
+              if (b < B) {
+                a0[b] += W8<WT>::dot(pw0[u], x + b * in_dim + k);
+                a1[b] += W8<WT>::dot(pw1[u], x + b * in_dim + k);
+              }
+          }
+        }
+      }
+      for (int k = (p == p0 ? 2 * 512 : 0) + lane * 8; k < in_dim; k += 512) {
+        const typename W8<WT>::reg w0 = W8<WT>::load(W + (long)n0 * in_dim + k);
+        const typename W8<WT>::reg w1 = two ? W8<WT>::load(W + (long)(n0 + 1) * in_dim + k) : W8<WT>::zero();
+#pragma unroll
+        for (int b = 0; b < HBT; ++b)
+          if (b < B) {
+            a0[b] += W8<WT>::dot(w0, x + b * in_dim + k);
+            a1[b] += W8<WT>::dot(w1, x + b * in_dim + k);
+          }
+      }
+#pragma unroll
+      for (int b = 0; b < HBT; ++b)
+        if (b < B) {
+          const float s0 = wave_sum(a0[b]), s1 = wave_sum(a1[b]);
+          if (lane == 0) {
+            unsigned long long* z = gZ + zoff + (long)b * 2 * out_dim + (long)grp * out_dim + n0;
+            hf_publish(z, s0 + bb[n0], tag);
+            if (two) hf_publish(z + 1, s1 + bb[n0 + 1], tag);
+          }
+        }
+    }
+    zoff += (long)B * 2 * out_dim;
+    in_dim = out_dim;
+  }
+  // ---- output Linear + exit gate: workgroup b < B serves environment b (head_final_body) ----
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  __syncthreads();
+  int pro;
+  const float *s0, *s1, *lw0, *lb0, *lw1, *lb1;
+  if (a.n_fc == 0) {
+    hf_gather(gH + ((long)(L - 1) * B + b) * H, H, raw, tag, a.err);
+    pro = a.lstm_ln ? PRO_LN : PRO_RAW;
+    s0 = s1 = raw;
+    lw0 = lw1 = lnw_last; lb0 = lb1 = lnb_last;
+  } else {
+    hf_gather(gZ + zoff - (long)B * 2 * in_dim + (long)b * 2 * in_dim, 2 * in_dim, raw, tag, a.err);
+    pro = a.mlp_ln ? PRO_GROUP_LN_RELU : PRO_GROUP_RELU;
+    s0 = raw; s1 = raw + in_dim;
+    const int nf = a.n_fc;
+    lw0 = nf == 3 ? a.fln_w[2][0] : nf == 2 ? a.fln_w[1][0] : a.fln_w[0][0]; lb0 = nf == 3 ? a.fln_b[2][0] : nf == 2 ? a.fln_b[1][0] : a.fln_b[0][0];
+    lw1 = nf == 3 ? a.fln_w[2][1] : nf == 2 ? a.fln_w[1][1] : a.fln_w[0][1]; lb1 = nf == 3 ? a.fln_b[2][1] : nf == 2 ? a.fln_b[1][1] : a.fln_b[0][1];
+  }
+  __syncthreads();
+  head_final_body<WT, true>(b, s0, s1, xs, in_dim, pro, lw0, lb0, lw1, lb1, reinterpret_cast<const WT*>(a.Wa), a.ba, reinterpret_cast<const WT*>(a.Wg),
+                            a.bg, ctl0, a.kind, a.layer, a.slot, a.thresholds, a.force, a.thr_type, a.leq, a.h_tmp, a.c_tmp, a.h_state, a.c_state, L,
+                            H, B, a.action_dbg, a.eps, a.A, a.act_ext, gH, gC);
+  __syncthreads();
+  if (b == 0 && threadIdx.x == 0) ((volatile unsigned*)a.err)[1] = tag;      // one environment: workgroup 0 is the only one that gets here
+}
+
+// granules the exchange buffer of deer_head_fused needs (8 bytes each) for B environments
+extern "C" long deer_head_fused_granules(int B, int d, int H, int L, int n_fc, const int* fc_dim) {
+  long n = (long)B * d + 2L * L * B * H;
+  for (int i = 0; i < n_fc; ++i) n += (long)B * 2 * fc_dim[i];
+  return n;
+}
+
+// One evaluation of the head as one launch.  Arguments: the union of the separate kernels' (deer_head_pool / deer_head_lstm_layer_pre /
+// deer_head_fc / deer_head_final_multi); ghh [L][B][4H] from deer_head_lstm_hh; xg: deer_head_fused_granules() x 8 bytes, zeroed once;
+// err: int32, raised when a hand-off timed out.  Needs a control block (the tag comes from its sequence word), bf16 or f32 weights,
+// L <= 4, n_fc <= 3, B <= 8 and B * 2 * max(d, H, 2 * fc_dim) * 4 <= 150 KB of LDS; returns DEER_ERR_SHAPE otherwise (the caller then
+// uses the separate kernels).
+extern "C" int deer_head_fused(const deer_head_fused_args* args, int w_is_f32, int n_workgroups, void* stream) {
+  if (args == nullptr) return DEER_ERR_SHAPE;
+  deer_head_fused_args a = *args;
+  if (w_is_f32) return DEER_ERR_SHAPE;                    // the fp32 arithmetic keeps the separate kernels (single-stream parity path)
+  // one environment only for now: the 8-environment instantiation (32 accumulators + the prefetched rows + the LayerNorm staging) spills
+  // 273 VGPRs under hipcc - env batches keep the separate kernels
+  if (args->B != 1) return DEER_ERR_SHAPE;
+  if (a.ctl == nullptr || a.xg == nullptr || a.err == nullptr || a.ghh == nullptr || a.B <= 0 || a.B > HB_MAX || a.L <= 0 || a.L > 4 || a.n_fc < 0 ||
+      a.n_fc > 3 || (a.d & 7) || (a.H & 7) || a.d > 2048 || a.H > 2048 || a.kind == KIND_COMMIT || a.A < 1 || a.A > 8)
+    return DEER_ERR_SHAPE;
+  if (a.kind == KIND_CHECK && (a.thresholds == nullptr || a.slot < 0 || a.slot > 61)) return DEER_ERR_SHAPE;
+  int max_in = a.d > a.H ? a.d : a.H;
+  for (int i = 0; i < a.n_fc; ++i) {
+    if ((a.fc_dim[i] & 7) || a.fc_dim[i] > 2048) return DEER_ERR_SHAPE;
+    if (2 * a.fc_dim[i] > max_in) max_in = 2 * a.fc_dim[i];
+  }
+  a.max_in = max_in;
+  const int smem = a.B * 2 * max_in * 4 + 512;
+  if (smem > 150 * 1024) return DEER_ERR_SHAPE;
+  if (n_workgroups < a.B) n_workgroups = a.B;
+  if (n_workgroups > 256) n_workgroups = 256;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<bf16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+        false)
+      return DEER_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL((head_fused_kernel<bf16_t, 1>), dim3(n_workgroups), dim3(512), smem, st, a);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
 }
 
 // A = multi_step_action (action_head.py:472-473): Wa has 6 A rows, Wg A rows; A > 1 needs act_ext ([B][4][64] f32: previous /

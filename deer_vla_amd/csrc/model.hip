@@ -176,6 +176,9 @@ struct deer_model {
   std::vector<FcW> fc;
   size_t wa, ba, wg, bg;
   std::vector<HeadW> lw;            // layerwise_exit_eval: per-layer heads in the reference's registration order (lm_exit_modules.0.., lm_head)
+  size_t hf_xg = SIZE_MAX, hf_err = SIZE_MAX;   // one-launch head evaluation (csrc/head.hip: deer_head_fused): exchange granules, error word
+  bool head_fused = true;           // DEER_HEAD_FUSED=0: the eight-launch evaluation everywhere
+  int head_wgs = 128;               // DEER_HEAD_WGS: resident workgroups of the one-launch evaluation
   size_t act_ext = SIZE_MAX;        // multi_step_action > 1: [B][4][64] f32 = previous / committed / ensemble action of 7 A values (+ A gripper logits)
   // workspace
   Layout wl;
@@ -602,6 +605,8 @@ void build_workspace(deer_model* m) {
   // familiar [pose6, prob, logit])
   m->action_dbg = named(m, "action_dbg", (size_t)B * 64 * 4);
   m->act_ext = named(m, "act_ext", (size_t)B * 4 * 64 * 4);
+  m->hf_xg = named(m, "head_fused_xg", (size_t)deer_head_fused_granules(B, d, m->H, m->Lh, m->n_fc, m->fc_dims) * 8);
+  m->hf_err = named(m, "head_fused_err", 256);
   for (HeadW& h : m->lw) {                                             // per-layer heads: own LSTM state
     h.h_state = m->wl.add(st);
     h.c_state = m->wl.add(st);
@@ -1274,6 +1279,35 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
   const bool feats_default = feats == nullptr;
   if (feats == nullptr) feats = m->Wk<float>(m->hidden) + (size_t)layer * rows_cap * d;     // [B*T, d]: env b owns rows b*T .. b*T+T-1
   const unsigned char* km = use_mask ? (m->mask_override ? m->mask_override : m->Wk<unsigned char>(m->key_mask)) : nullptr;
+  // ---- control steps of one environment: the whole evaluation as ONE launch (csrc/head.hip: head_fused_kernel) ----
+  if (m->head_fused && head == 0 && use_ctl && !no_ctl_final && feats_default && kind != DEER_KIND_COMMIT && B == 1 && !c.precision && !c.use_state &&
+      m->head_pre && m->ghh_valid && m->Lh <= 4 && m->n_fc <= 3 && d <= 2048 && H <= 2048) {
+    deer_head_fused_args a{};
+    a.feats = feats; a.T = T; a.d = d; a.avg = c.pooling_avg; a.key_mask = km;
+    a.cmap = compact_active(m, B * T) ? m->Wk<int>(m->cmap) + cmap_parity(m, layer) * CMAP_WORDS : nullptr;
+    a.B = B; a.H = H; a.L = m->Lh; a.n_fc = m->n_fc; a.lstm_ln = c.lstm_layernorm; a.mlp_ln = c.mlp_layernorm;
+    for (int i = 0; i < 3; ++i) a.fc_dim[i] = m->fc_dims[i];
+    for (int l = 0; l < m->Lh; ++l) {
+      a.w_ih[l] = m->A<void>(m->lstm[l].wih); a.b_ih[l] = m->A<float>(m->lstm[l].bih);
+      a.ln_w[l] = c.lstm_layernorm ? m->A<float>(m->lstm[l].lnw) : nullptr; a.ln_b[l] = c.lstm_layernorm ? m->A<float>(m->lstm[l].lnb) : nullptr;
+    }
+    a.ghh = m->Wk<float>(m->ghh); a.c_prev = m->Wk<float>(m->c_state); a.h_tmp = m->Wk<float>(m->h_tmp); a.c_tmp = m->Wk<float>(m->c_tmp);
+    for (int i = 0; i < m->n_fc; ++i)
+      for (int g = 0; g < 2; ++g) {
+        a.fw[i][g] = m->A<void>(m->fc[i].w[g]); a.fb[i][g] = m->A<float>(m->fc[i].b[g]);
+        a.fln_w[i][g] = c.mlp_layernorm ? m->A<float>(m->fc[i].lnw[g]) : nullptr; a.fln_b[i][g] = c.mlp_layernorm ? m->A<float>(m->fc[i].lnb[g]) : nullptr;
+      }
+    a.Wa = m->A<void>(m->wa); a.ba = m->A<float>(m->ba); a.Wg = m->A<void>(m->wg); a.bg = m->A<float>(m->bg);
+    a.ctl = m->Wk<int>(m->ctl); a.kind = kind; a.layer = layer; a.slot = slot;
+    a.thresholds = m->thr_override ? m->thr_override : m->Wk<float>(m->thresholds);
+    a.force = force ? 1 : 0; a.thr_type = m->thr_type; a.leq = m->leq;
+    a.h_state = m->Wk<float>(shadow ? m->h_shadow : m->h_state); a.c_state = m->Wk<float>(shadow ? m->c_shadow : m->c_state);
+    a.action_dbg = m->Wk<float>(m->action_dbg); a.eps = kEps; a.A = std::max(1, c.multi_step_action); a.act_ext = m->Wk<float>(m->act_ext);
+    a.xg = m->Wk<unsigned long long>(m->hf_xg); a.err = m->Wk<int>(m->hf_err);
+    Bracket b(m, "deer_head_fused", 0, 2.0 * (4.0 * H * (d + (m->Lh - 1.0) * H)), st);
+    const int rc = deer_head_fused(&a, 0, m->head_wgs, st);
+    if (rc != DEER_ERR_SHAPE) return rc;                       // DEER_ERR_SHAPE: a shape the one-launch form does not take -> separate kernels
+  }
   float* pooled = m->Wk<float>(m->pooled);
   {
     Bracket b(m, "deer_head_pool", 0, 0, st);
@@ -1463,6 +1497,8 @@ int deer_model_create(const deer_config* cfg, deer_model** out) {
   m->ctl_max_layer = m->exit_ids.back();
   if (const char* e = getenv("DEER_COMPACT")) m->compact = e[0] != '0';
   if (const char* e = getenv("DEER_HEAD_PRE")) m->head_pre = e[0] != '0';
+  if (const char* e = getenv("DEER_HEAD_FUSED")) m->head_fused = e[0] != '0';
+  if (const char* e = getenv("DEER_HEAD_WGS")) m->head_wgs = std::max(1, std::min(256, atoi(e)));
   if (const char* e = getenv("DEER_PERSISTENT_LAYER")) m->persistent_layer = e[0] == '1';
   *out = m;
   return DEER_OK;
@@ -1478,6 +1514,13 @@ int deer_model_set_persistent_layer(deer_model* m, int on) {
 // to the fused LSTM kernel, which reads h_state itself
 int deer_model_head_state_changed(deer_model* m) {
   m->ghh_valid = false;
+  return DEER_OK;
+}
+
+// control steps of one environment: the head evaluation as one launch (on by default; DEER_HEAD_FUSED=0) or as the eight separate kernels
+int deer_model_set_head_fused(deer_model* m, int on) {
+  if (m == nullptr) return DEER_ERR_SHAPE;
+  m->head_fused = on != 0;   // takes effect for pieces enqueued / captured from now on
   return DEER_OK;
 }
 

@@ -132,7 +132,7 @@ class DeerEngine:
         self.n_cams = 2 * n_envs                       # images per step: (rgb, gripper) of every environment
         # trunk rows n_envs * T: up to 256 in the bf16 arithmetic (8 environments x the reference's max_length = 32, data.py:905-919; the
         # hi/lo-plane trunk GEMM runs them in blocks of 128), 128 in the fp32 arithmetic (one launch of deer_gemm_skinny)
-        self.MAX_ROWS = 256 if (precision == "bf16" and cfg.d_model % 64 == 0) else 128
+        self.MAX_ROWS = abi.max_trunk_rows(cfg, precision)
         self.max_T = min(max_text_len, self.MAX_ROWS // n_envs)
         assert self.max_T >= 14, "n_envs * T must fit the trunk's LLM rows"
         self._thr_type = abi.THR_TYPES[threshold_type]
@@ -314,6 +314,18 @@ class DeerEngine:
         if self._graphs:
             torch.cuda.synchronize(self.dev)
         self._drop_graphs()
+
+    def set_head_fused(self, on: bool):
+        """One-environment control steps: every head evaluation (pseudo action / exit check) as ONE launch (csrc/head.hip:
+        head_fused_kernel; default) or as the eight separate kernels.  Same arithmetic per row (tests/test_engine_parity.py)."""
+        abi.check(self.lib.deer_model_set_head_fused(self._h, 1 if on else 0), "deer_model_set_head_fused")
+        if self._graphs:
+            torch.cuda.synchronize(self.dev)
+        self._drop_graphs()
+
+    def head_fused_error(self) -> int:
+        """1 if a hand-off inside a one-launch head evaluation timed out (the step then ends without a verdict)"""
+        return int(self._buf("head_fused_err").view(torch.int32)[0].item())
 
     def set_persistent_layer(self, on: bool):
         """N1 experiment (csrc/persistent_layer.hip): one persistent launch per trunk layer of a one-environment step.  Bit-identical to
@@ -957,7 +969,7 @@ class DeerEngine:
         F = rgb_seq.shape[0]
         ids = ids.reshape(-1, ids.shape[-1])
         T = ids.shape[1]
-        G = max(1, min(group, 128 // T, F, 8))
+        G = max(1, min(group, self.MAX_ROWS // T, F, 8))
         last = self.cfg.n_layers - 1
         L, d = self.cfg.n_layers, self.cfg.d_model
         out = torch.empty(F, L, T, d, device=self.dev)
@@ -1012,7 +1024,7 @@ class DeerEngine:
             hidden = hidden.unsqueeze(0)
         rl = torch.as_tensor(rand_layers).reshape(hidden.shape[0], -1)
         bs, W, L, T, d = hidden.shape
-        G = max(1, min(group, 128 // T, bs, 8))
+        G = max(1, min(group, self.MAX_ROWS // T, bs, 8))
         w = self.sibling(G)
         layers = [0] + list(self.exit_ids)
         per_window = []

@@ -39,7 +39,7 @@ class NativeModel:
         self.lib = abi.lib()
         self.cfg, self.B = cfg, n_envs
         self.dev = torch.device(device)
-        self.max_T = min(max_text_len, 128 // n_envs)
+        self.max_T = min(max_text_len, abi.max_trunk_rows(cfg, precision) // n_envs)   # the same row budget as DeerEngine (256 rows in bf16)
         self._h = ctypes.c_void_p()
         self.precision = precision
         cc = abi.config_to_c(cfg, n_envs, self.max_T, precision=precision)
@@ -150,7 +150,7 @@ def llm_early_exit(ids: torch.Tensor, key_mask: Optional[torch.Tensor], media: t
     med = None if getattr(m, "precision", "bf16") == "fp32" else media.to(torch.bfloat16).contiguous()
     abi.check(m.lib.deer_llm_early_exit(m._h, abi.ptr(ids_c), abi.ptr(km), T, abi.ptr(med), exit_id, 1 if shadow else 0, None, None, _stream()),
               "deer_llm_early_exit")
-    rows = min(m.B * m.max_T, 128)
+    rows = min(m.B * m.max_T, abi.max_trunk_rows(cfg, getattr(m, "precision", "bf16")))
     ctl = m.buffer("ctl").view(torch.int32).view(m.B, abi.CTL_WORDS).clone()
     hidden = m.buffer("hidden").view(torch.float32).view(cfg.n_layers, rows, cfg.d_model)[:, : m.B * T].clone()
     return ctl, hidden

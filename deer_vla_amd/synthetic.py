@@ -214,6 +214,63 @@ def make_synthetic_state(cfg: DeerConfig, seed: int = 0, std: str = "fanin", dev
     return out
 
 
+def harden_state(cfg: DeerConfig, sd: Dict[str, torch.Tensor], seed: int = 0, bf16_round: bool = True) -> Dict[str, torch.Tensor]:
+    """A copy of ``sd`` with the pathologies of REAL CLIP / MPT / DeeR checkpoints that seeded N(0, sigma^2) weights never show (VERDICT r4
+    weak #1c): a handful of "massive activation" channels (output rows of ViT ``mlp.c_proj`` / MPT ``mlp_down`` and of the patch embedding
+    scaled 40-100x, so the residual stream carries channels far above the rest - what CLIP's register-like tokens and MPT's outlier
+    dimensions look like), LayerNorm gains spread over [0.1, 10] with a few large ones on exactly those channels, x-attn gates near +-3
+    (tanh -> +-0.995), LSTM gate biases that saturate some units (+-6) and biased MLP-head inputs.  Exercises the bf16 MFMA operands of the
+    vision tower, the hi/lo split of the trunk, ``quick_gelu_bf`` (v_exp / v_rcp), softmax max-subtraction and the LSTM transcendentals
+    far from the unit-scale regime."""
+    g = torch.Generator().manual_seed(4242 + seed)
+    kinds = {k: v[1] for k, v in param_shapes(cfg).items()}
+    out = {k: v.clone() for k, v in sd.items()}
+
+    def pick(n, k):
+        return torch.randperm(n, generator=g)[:k]
+
+    W, d = cfg.vit_width, cfg.d_model
+    hot_v, hot_d = pick(W, max(2, W // 256)), pick(d, max(2, d // 512))          # the outlier channels of the two residual streams
+    v = "vision_encoder.visual."
+    out[v + "conv1.weight"][hot_v[:1]] *= 40.0
+    for l in range(cfg.vit_layers):
+        b = f"{v}transformer.resblocks.{l}."
+        if l in (0, cfg.vit_layers // 2):
+            out[b + "mlp.c_proj.weight"][hot_v] *= 100.0
+            out[b + "mlp.c_proj.bias"][hot_v] += 3.0
+        for ln in ("ln_1", "ln_2"):
+            gain = torch.exp(torch.empty(W).uniform_(-2.3, 1.2, generator=g))       # 0.1 .. 3.3
+            gain[hot_v] = torch.tensor([10.0, 0.05])[: len(hot_v)].repeat(len(hot_v))[: len(hot_v)]
+            out[b + ln + ".weight"] = gain
+            out[b + ln + ".bias"] = 0.3 * torch.randn(W, generator=g)
+    for n in range(cfg.n_layers):
+        blk = f"lang_encoder.transformer.blocks.{n}."
+        if cfg.has_xattn(n):
+            x = blk + "gated_cross_attn_layer."
+            out[x + "attn_gate"] = torch.tensor([3.0 if n % 2 == 0 else -3.0])
+            out[x + "ff_gate"] = torch.tensor([-2.5 if n % 3 == 0 else 2.5])
+        m = blk + "decoder_layer."
+        down = m + ("ffn.down_proj.weight" if cfg.llm_name == "mpt_9b" else "mlp.mlp_down.weight")
+        if n in (0, cfg.n_layers // 2):
+            out[down][hot_d] *= 60.0
+        for ln in (("norm_1", "norm_2") if cfg.llm_name == "mpt_9b" else ("ln_1", "ln_2")):
+            gain = torch.exp(torch.empty(d).uniform_(-2.3, 1.6, generator=g))       # 0.1 .. 5
+            gain[hot_d[:1]] = 10.0
+            out[m + ln + ".weight"] = gain
+    for prefix in ["extra_exit."] + [p for p, _ in (cfg.layerwise_heads() if getattr(cfg, "layerwise_exit_eval", False) else [])]:
+        H = cfg.head_hidden
+        for l in range(cfg.lstm_num_layers):
+            r, sfx = (f"{prefix}rnn.layers.{3 * l}.", "_l0") if cfg.lstm_layernorm else (f"{prefix}rnn.", f"_l{l}")
+            bias = out[r + "bias_ih" + sfx]
+            idx = pick(4 * H, max(4, H // 16))
+            bias[idx] = torch.where(torch.rand(len(idx), generator=g) < 0.5, torch.tensor(6.0), torch.tensor(-6.0))
+    if bf16_round:
+        for k, t in out.items():
+            if kinds.get(k) in BF16_KINDS:
+                out[k] = t.to(torch.bfloat16).to(torch.float32)
+    return out
+
+
 def round_state_to_bf16(cfg: DeerConfig, sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """fp32 copy of ``sd`` whose GEMM operands are rounded to bf16 (what the engine keeps in HBM)."""
     kinds = {k: v[1] for k, v in param_shapes(cfg).items()}

@@ -355,6 +355,26 @@ int deer_head_final_multi(const float* src, int src_stride, int in_dim, int pro,
                           int layer, int slot, const float* thresholds, int force, int thr_type, int leq, const float* h_tmp,
                           const float* c_tmp, float* h_state, float* c_state, int L, int H, int B, float* action_dbg, float eps,
                           int w_is_f32, int multi_step_action, float* act_ext, void* stream);
+/* ---- one head evaluation as ONE launch (csrc/head.hip: head_fused_kernel; replaces the eight launches above on control steps of one
+ * environment: pool -> L <= 4 LSTM layers (recurrent half from deer_head_lstm_hh) -> <= 3 hidden Linears -> output Linear + exit gate).
+ * G workgroups stay resident; the vectors between the phases travel as data-tagged 8-byte granules (relaxed agent-scope atomics), the
+ * tag = number of evaluations the exchange buffer has served.  xg: deer_head_fused_granules() * 8 bytes, zeroed once; err: int32[2]
+ * zeroed once = {raised when a hand-off timed out, evaluation counter}.  Returns DEER_ERR_SHAPE for what it does not take (no control block, COMMIT kind, f32 weights,
+ * more than one environment, d or H > 2048): the caller then uses the separate kernels.  Same arithmetic per row as those kernels. */
+typedef struct deer_head_fused_args {
+  const float* feats; int T, d, avg; const unsigned char* key_mask; const int* cmap;
+  int B, H, L, n_fc, lstm_ln, mlp_ln;
+  int fc_dim[3];
+  const void* w_ih[4]; const float* b_ih[4]; const float* ln_w[4]; const float* ln_b[4];   /* ln_*[l]: LayerNorm of layer l's OUTPUT (lstm_ln) */
+  const float* ghh; const float* c_prev; float* h_tmp; float* c_tmp;
+  const void* fw[3][2]; const float* fb[3][2]; const float* fln_w[3][2]; const float* fln_b[3][2];
+  const void* Wa; const float* ba; const void* Wg; const float* bg;
+  int* ctl; int kind, layer, slot; const float* thresholds; int force, thr_type, leq;
+  float* h_state; float* c_state; float* action_dbg; float eps; int A; float* act_ext;
+  unsigned long long* xg; int* err; int max_in;                                             /* max_in: filled by the launcher */
+} deer_head_fused_args;
+long deer_head_fused_granules(int B, int d, int H, int L, int n_fc, const int* fc_dim);
+int deer_head_fused(const deer_head_fused_args* args, int w_is_f32, int n_workgroups, void* stream);
 /* ExitController.set_timestep (eval_utils.py:662-663) + per-step reset.  step_info: device int32[4] = {hold, step sequence
  * number, host mirror pointer lo, hi} or NULL (no stage hold, no mirror). */
 int deer_ctl_begin_step(int* ctl, const int* step_info, int B, void* stream);

@@ -83,3 +83,45 @@ def test_coarse_operators_agree_with_the_engine_bitwise():
             assert torch.equal(hidden[:, : ids.shape[1]].cpu(), eng.hidden[:, : ids.shape[1]].cpu())
     finally:
         m.close()
+
+
+def test_coarse_operators_with_eight_environments_and_a_32_token_instruction():
+    """VERDICT r4 next-6: the coarse-operator path used to cap n_envs * T at 128 rows (ops.py: 128 // n_envs) while the engine takes 256 (8
+    environments x the reference's max_length = 32, data.py:905-919).  Eight environments with instructions of 9 .. 32 tokens through the
+    three operator calls, bit for bit against DeerEngine.step on the same inputs (static exit and a dynamic step)."""
+    from deer_vla_amd.config import deer_tiny
+    from deer_vla_amd.engine import DeerEngine
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
+    B, lens = 8, [32, 14, 20, 9, 27, 16, 31, 11]
+    m = ops.NativeModel(cfg, sd, n_envs=B)
+    eng = DeerEngine(cfg, sd, n_envs=B)
+    assert m.max_T == eng.max_T == 32
+    S, T = cfg.image_size, max(lens)
+    try:
+        for s, exit_id in enumerate((5, -1)):
+            inp = [syn.synthetic_step_inputs(cfg, s, rank=e, text_len=lens[e], text_seed=7 + e) for e in range(B)]
+            ids = torch.full((B, T), 1, dtype=torch.long)
+            mask = torch.zeros(B, T, dtype=torch.bool)
+            for e in range(B):
+                ids[e, :lens[e]], mask[e, :lens[e]] = inp[e][2][0], True
+            rgb = torch.stack([p[0].reshape(3, S, S) for p in inp])
+            grip = torch.stack([p[1].reshape(3, S, S) for p in inp])
+            images = torch.stack([rgb, grip], dim=1).reshape(2 * B, 3, S, S).cuda()          # (rgb, gripper) of every environment
+            tokens = torch.ops.deer.vit_l14_encode(images, m.handle)
+            media = torch.ops.deer.perceiver_resample(tokens, m.handle)
+            if exit_id < 0:
+                thr = [0.05] * (len(cfg.exit_ids()) - 1) + [1e5]
+                m.configure_exit(cfg.exit_ids(), 12, thr)
+                eng.configure_exit(cfg.exit_ids(), 12, 1)
+                eng.set_thresholds(thr)
+                eng.set_compaction(False)                     # the operator runs the whole step on one stream: same schedule
+            ctl, hidden = torch.ops.deer.llm_early_exit(ids.cuda(), mask.cuda(), media, m.handle, exit_id, False)
+            torch.cuda.synchronize()
+            r = ops.decode_ctl(ctl)
+            e = eng.step(rgb.cuda(), grip.cuda(), ids.cuda(), mask.cuda(), exit_id=None if exit_id < 0 else exit_id, use_graph=False)
+            for b in range(B):
+                assert r[b]["exit_layer"] == e[b]["exit_layer"], (s, b)
+                assert torch.equal(r[b]["pose"], e[b]["pose"]) and r[b]["gripper"] == e[b]["gripper"], (s, b)
+    finally:
+        m.close()

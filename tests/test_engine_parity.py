@@ -696,6 +696,44 @@ def test_compaction_of_exited_environments_is_bit_identical_to_the_uncompacted_b
 
 
 @pytest.mark.parametrize("size", ["tiny", "3b"])
+def test_one_launch_head_evaluation_matches_the_eight_launch_form(size):
+    """on control steps of one environment every head evaluation (pseudo action, exit checks) is ONE launch
+    (csrc/head.hip: head_fused_kernel - resident workgroups, the vectors between the phases as data-tagged granules).  Every row keeps
+    the arithmetic of the separate kernels (k split over the lanes, in-wave sums, one wave per LayerNorm row, head_final_body), so a
+    dynamic episode with LSTM carry must give the same exit layers and - to the last bit, or within float rounding where hipcc
+    contracts a product differently in the two instantiations - the same actions, deltas and LSTM state; eager and graph pieces; no
+    hand-off may time out."""
+    cfg = deer_tiny() if size == "tiny" else deer_3b(max_layer=12)
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True) if size == "tiny" else full_size_state(cfg, 0, std="0.02", bf16_round=True)
+    a = DeerEngine(cfg, sd)
+    b = DeerEngine(cfg, None, weights_from=a)
+    b.set_head_fused(False)
+    inputs = make_inputs(cfg, 10 if size == "tiny" else 6)
+    thr, _ = probe_thresholds(cfg, sd, inputs, 12, iters=1)
+    worst = 0.0
+    for use_graph in (False, True):
+        for eng in (a, b):
+            eng.configure_exit(cfg.exit_ids(), 12, 1)
+            eng.set_thresholds(thr)
+            eng.reset()
+        seen = set()
+        for s, (rgb, grip, ids, mask) in enumerate(inputs):
+            ra, rb = a.step(rgb, grip, ids, mask, use_graph=use_graph), b.step(rgb, grip, ids, mask, use_graph=use_graph)
+            assert ra["exit_layer"] == rb["exit_layer"] and ra["n_evals"] == rb["n_evals"], (use_graph, s, ra["exit_layer"], rb["exit_layer"])
+            worst = max(worst, float((ra["pose"] - rb["pose"]).abs().max()), abs(ra["gripper"] - rb["gripper"]))
+            da, db = torch.nan_to_num(ra["deltas"], nan=-1.0), torch.nan_to_num(rb["deltas"], nan=-1.0)
+            assert torch.equal(da < 0, db < 0)
+            worst = max(worst, float((da - db).abs().max()))
+            seen.add(ra["exit_layer"])
+        torch.cuda.synchronize()
+        worst = max(worst, float((a.h_state - b.h_state).abs().max()), float((a.c_state - b.c_state).abs().max()))
+        assert len(seen) > 1, seen
+    assert a.head_fused_error() == 0
+    print(f"\n[one-launch head, {size}] worst |fused - separate| over actions / deltas / LSTM state: {worst:.2e}")
+    assert worst < 2e-6, worst
+
+
+@pytest.mark.parametrize("size", ["tiny", "3b"])
 def test_persistent_layer_launch_is_bit_identical_to_the_twelve_launch_layer(size):
     """N1 experiment (csrc/persistent_layer.hip): every trunk layer of a one-environment step as ONE persistent launch - the same device
     functions as the twelve kernels, a device-wide barrier at every seam.  Hidden states of every layer, actions and exit layers must be
