@@ -662,14 +662,21 @@ def run_workload(args, cfg, sd_dev, B, rank, world, local_rank, dist, max_layer,
 
     stats = torch.tensor([elapsed, float(exit_sum), float(n_timed * B)], dtype=torch.float64,
                          device=dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
+    rank_rate = None
     if dist is not None:
         tmax = stats[:1].clone()
+        tmin = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)         # one tiny RCCL all-reduce: the only exchange of the path
         stats[0] = tmax[0]
+        # every rank's own rate over its own timed region (stragglers show up on the first real N > 1 run: VERDICT r4 next-7)
+        per_rank = n_timed * B
+        rank_rate = {"min": round(per_rank / float(tmax[0]), 2), "max": round(per_rank / float(tmin[0]), 2), "unit": "action-steps/s per rank",
+                     "slowest_over_fastest_time": round(float(tmax[0]) / max(float(tmin[0]), 1e-12), 4)}
     t_max, exits, n_steps = float(stats[0]), float(stats[1]), float(stats[2])
     return dict(eng=eng, ctl=ctl, frames=frames, ids=ids, T=T, t_max=t_max, value=n_steps / t_max, avg_exit=exits / n_steps, thr=thr,
-                hist=hist, setup_s=setup_s, on_policy=on_policy, n_timed=n_timed)
+                hist=hist, setup_s=setup_s, on_policy=on_policy, n_timed=n_timed, rank_rate=rank_rate)
 
 
 def main():
@@ -722,6 +729,10 @@ def main():
         "ms_per_step": round(1e3 * t_max / res["n_timed"], 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32 activations, bf16-representable weights", "data": "synthetic",
         "avg_exit_layer": round(res["avg_exit"], 3),
+        # which verdicts the timed region of `value` ran on: "scripted" = the dynamic pipeline with the thresholds forced per step
+        # to the stratified target mix (one environment: depth-stable); "on_policy" = the calibrated criterion on the episode's own deltas
+        # (env batches: a scripted verdict would make all environments leave together).  The other flavour is the `on_policy` object.
+        "verdicts": "scripted" if B == 1 else "on_policy",
         "config": {"workload": "%s DeeR-%s max_layer=%d exit_ratio=%.2f, step mode, %d env(s)/GPU per control "
                                "step, 2x224x224 frames + %d text tokens per env, LSTM history carried over %d-step episodes"
                                % ("OpenFlamingo-9B/MPT-7B" if args.workload == "deer_9b" else "OpenFlamingo-3B/MPT-1B",
@@ -763,6 +774,7 @@ def main():
         out["ranks"] = [{"rank": int(t[0]), "local_rank": int(t[1]), "device": int(t[2]),
                          "device_uuid": bytes(int(x) for x in t[3:]).decode(errors="replace").strip()} for t in allinfo]
         out["distinct_devices"] = len({r["device_uuid"] or r["device"] for r in out["ranks"]})
+        out["per_rank_steps_per_s"] = res.get("rank_rate")
     # step latency at a KNOWN depth: static exit at every exit layer (median of --latency-reps steps, action read on the host)
     if args.latency_reps > 0 and B == 1 and rank == 0:
         frames_, ids_l = res["frames"], res["ids"]

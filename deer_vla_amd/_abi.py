@@ -138,10 +138,13 @@ _lib = None
 
 
 def max_trunk_rows(cfg, precision: str = "bf16") -> int:
-    """LLM rows (n_envs * T) one engine takes: 256 in the bf16 arithmetic (8 environments x the reference's max_length = 32 tokens,
+    """LLM rows (n_envs * T) one engine takes: 512 in the bf16 arithmetic (16 environments x the reference's max_length = 32 tokens,
     data.py:905-919; the hi/lo-plane trunk GEMM runs them in row blocks of 128), 128 in the fp32 arithmetic or when d_model % 64 != 0
     (one launch of deer_gemm_skinny)."""
-    return 256 if (precision == "bf16" and cfg.d_model % 64 == 0) else 128
+    return 512 if (precision == "bf16" and cfg.d_model % 64 == 0) else 128
+
+
+MAX_ENVS = 16        # environments per engine (csrc/common.h: DEER_MAX_ENVS)
 
 
 def skinny_mpad(M: int) -> int:

@@ -97,7 +97,8 @@ def config_from_args(name_args: Dict, ckpt_args: Dict, trunk: Optional[DeerConfi
               mlp_layernorm=bool(ckpt_args["mlp_layernorm"]), lstm_num_layers=ckpt_args["lstm_num_layers"],
               mlp_num_hidden_layers=ckpt_args["mlp_num_hidden_layers"], pooling=ckpt_args["pooling"],
               window_size=name_args["window_size"],
-              use_state=bool(name_args.get("use_state", False)), sep_resampler=bool(name_args.get("sep_resampler", False)))
+              use_state=bool(name_args.get("use_state", False)), sep_resampler=bool(name_args.get("sep_resampler", False)),
+              multi_step_action=int(name_args.get("multi_step_action", 1)))          # "Nstep" in the file name (eval_calvin.py:384-387)
     ee = min(ckpt_args["early_exit_layer"], ckpt_args["max_layer"])
     if trunk is not None:
         from dataclasses import replace
@@ -122,18 +123,24 @@ def apply_hf_mpt_config(cfg: DeerConfig, hf_config) -> DeerConfig:
     DeerConfig; raises on anything this engine's MPT block does not implement (it would otherwise be silently ignored)."""
     import dataclasses
     import json
-    c = json.load(open(hf_config)) if isinstance(hf_config, (str, bytes)) or hasattr(hf_config, "__fspath__") else dict(hf_config)
+    if isinstance(hf_config, (str, bytes)) or hasattr(hf_config, "__fspath__"):
+        with open(hf_config) as f:
+            c = json.load(f)
+    else:
+        c = dict(hf_config)
     ac = c.get("attn_config") or {}
 
     def pick(flat, nested, default=None):
         return c[flat] if flat in c else ac.get(nested, default)
     unsupported = {
-        "alibi": (pick("alibi", "alibi", True), True, "positions come from ALiBi only (mosaic_gpt_3b.py:342-343: no learned wpe is added)"),
+        # ABSENT keys take the HF classes' own defaults (MPTConfig: alibi False, no_bias False, qk_ln False), not the values this engine
+        # happens to support: an underspecified config.json would build learned positions and biases in the reference (ADVICE r4)
+        "alibi": (pick("alibi", "alibi", False), True, "positions come from ALiBi only (mosaic_gpt_3b.py:342-343: no learned wpe is added)"),
         "clip_qkv": (pick("attn_clip_qkv", "clip_qkv"), None, "qkv clamping is not built"),
         "softmax_scale": (pick("softmax_scale", "softmax_scale"), None, "the block scales by 1/sqrt(head_dim)"),
         "prefix_lm": (bool(pick("prefix_lm", "prefix_lm", False)), False, "causal attention only"),
         "attn_uses_sequence_id": (bool(pick("attn_uses_sequence_id", "attn_uses_sequence_id", False)), False, "no packed sequences on this path"),
-        "no_bias": (bool(c.get("no_bias", True)), True, "Linear biases are not ingested (the released MPT checkpoints are bias-free)"),
+        "no_bias": (bool(c.get("no_bias", False)), True, "Linear biases are not ingested (the released MPT checkpoints are bias-free)"),
     }
     for name, (got, want, why) in unsupported.items():
         if got != want:

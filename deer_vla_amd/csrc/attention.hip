@@ -281,16 +281,16 @@ __global__ __launch_bounds__(64 * NWAVE, 4) void attn_vit_kernel(const bf16_t* _
     // ---- S^T tiles: s[t][r] = S[q = c][key = t*16 + g*4 + r] (unscaled) ----
     f32x4 s[2 * NCH];
 #pragma unroll
-    for (int t = 0; t < 2 * NCH; ++t) {
-      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < NT) {
+    for (int t = 0; t < 2 * NCH; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the two halves of the head dimension as the OUTER loop: 17 independent MFMAs in a row, each accumulator's second MFMA 17 issues
+    // after its first (the same sum per score as t-outer: ks = 0 then ks = 1)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c) * AM_KPITCH + ks * 32 + g * 8);
-          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
-        }
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c) * AM_KPITCH + ks * 32 + g * 8);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
       }
-    }
     // keys beyond kv_len live in the last tile only (kv_len > 16 (NT - 1), checked by the launcher)
 #pragma unroll
     for (int r = 0; r < 4; ++r)

@@ -43,12 +43,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // Row map of an env batch with COMPACTION of exited environments (round 4): the trunk keeps the rows of the still-active
 // environments packed at the front of its buffers ("slots"); int32 words: [0] = number of active slots, [1 + s] = environment of slot s,
-// [1 + HB + e] = slot of environment e (-1 once it has exited).  Two copies (parity) per model: a compaction writes the other one while
+// [17 + e] = slot of environment e (-1 once it has exited).  Two copies (parity) per model: a compaction writes the other one while
 // the exit check of the previous exit layer may still read the old one.  NULL map = identity, every environment active.
 #define CMAP_N 0
 #define CMAP_SLOT_ENV 1
-#define CMAP_ENV_SLOT 9
-#define CMAP_WORDS 32
+#define CMAP_ENV_SLOT 17     // up to 16 environments per engine (round 5)
+#define CMAP_WORDS 64
+#define DEER_MAX_ENVS 16
 __device__ __forceinline__ int cmap_active(const int* cmap, int B) { return cmap != nullptr ? cmap[CMAP_N] : B; }
 __device__ __forceinline__ int cmap_env(const int* cmap, int slot) { return cmap != nullptr ? cmap[CMAP_SLOT_ENV + slot] : slot; }
 __device__ __forceinline__ int cmap_slot(const int* cmap, int env) { return cmap != nullptr ? cmap[CMAP_ENV_SLOT + env] : env; }

@@ -412,7 +412,13 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
       // round.  in_proj at 16 frames 38.0-39.4 -> 32.1-33.1 us, c_fc 43.3-44.7 -> 39.9 (hipBLASLt on the same box 30.3-30.7 / 43.6-44.7);
       // at 12 frames (192 workgroups) 31.9 -> 28.8 and 37.0 -> 34.1 (profiles/r03_k_frame_tiles_*.txt)
       const long frames = (M % 257 == 0) ? M / 257 : 0;
-      auto one_round = [&](int bn) { return frames > 0 && (N % bn) == 0 && frames * (N / bn) * batch >= 192 && frames * (N / bn) * batch <= 256; };
+      // ... or exactly two rounds (16 environments per engine: 32 frames x 16 column tiles = 512 workgroups; the second round's prologue
+      // runs while the first round's last workgroups drain)
+      auto one_round = [&](int bn) {
+        if (frames <= 0 || (N % bn) != 0) return false;
+        const long wgs = frames * (N / bn) * batch;
+        return (wgs >= 192 && wgs <= 256) || wgs == 512;
+      };
       if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16) && one_round(192)) tile = 64;
       else if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16) && one_round(256)) tile = 63;
       // ... and the K halves of c_proj (f32 slabs, N = 1024) as 257 x 128 tiles: 16 frames x 8 x 2 = 256 workgroups, 49.8 -> 43.1 us

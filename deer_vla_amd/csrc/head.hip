@@ -18,7 +18,7 @@
 #include "common.h"
 #include "../../include/deer_hip.h"
 
-#define HB_MAX 8   // max environments per batch
+#define HB_MAX 8   // environments per LAUNCH of the GEMV kernels (accumulator registers); batches of up to DEER_MAX_ENVS run in chunks
 
 enum { X_RAW = 0, X_POOL_MAX = 1, X_POOL_AVG = 2, X_LN = 3 };
 enum { PRO_RAW = 0, PRO_LN = 1, PRO_GROUP_LN_RELU = 2, PRO_GROUP_RELU = 3 };
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict_
 
 extern "C" int deer_head_pool(const float* feats, float* pooled, int T, int d, int avg, int B, const unsigned char* key_mask,
                               const int* ctl, int kind, int layer, void* stream) {
-  if (T <= 0 || d <= 0 || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
+  if (T <= 0 || d <= 0 || B <= 0 || B > DEER_MAX_ENVS) return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(head_pool_kernel, dim3((d + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), feats, pooled, T, d,
                      avg, B, key_mask, ctl, kind, layer, static_cast<const float*>(nullptr));
   DEER_LAUNCH_CHECK();
@@ -263,7 +263,7 @@ extern "C" int deer_head_pool(const float* feats, float* pooled, int T, int d, i
 // deer_head_pool on the hidden state of a layer whose rows are packed by the row map `cmap` (env batch with compaction)
 extern "C" int deer_head_pool_active(const float* feats, float* pooled, int T, int d, int avg, int B, const unsigned char* key_mask,
                                      const int* ctl, int kind, int layer, const int* cmap, void* stream) {
-  if (T <= 0 || d <= 0 || B <= 0 || B > HB_MAX || cmap == nullptr) return DEER_ERR_SHAPE;
+  if (T <= 0 || d <= 0 || B <= 0 || B > DEER_MAX_ENVS || cmap == nullptr) return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(head_pool_kernel, dim3((d + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), feats, pooled, T, d,
                      avg, B, key_mask, ctl, kind, layer, static_cast<const float*>(nullptr), cmap);
   DEER_LAUNCH_CHECK();
@@ -273,7 +273,7 @@ extern "C" int deer_head_pool_active(const float* feats, float* pooled, int T, i
 // deer_head_pool with the robot-state embedding added to the pooled feature (DeterministicDecoder(use_state=True), action_head.py:524-536)
 extern "C" int deer_head_pool_state(const float* feats, float* pooled, int T, int d, int avg, int B, const unsigned char* key_mask,
                                     const float* state_emb, const int* ctl, int kind, int layer, void* stream) {
-  if (T <= 0 || d <= 0 || B <= 0 || B > HB_MAX || state_emb == nullptr) return DEER_ERR_SHAPE;
+  if (T <= 0 || d <= 0 || B <= 0 || B > DEER_MAX_ENVS || state_emb == nullptr) return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(head_pool_kernel, dim3((d + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), feats, pooled, T, d,
                      avg, B, key_mask, ctl, kind, layer, state_emb);
   DEER_LAUNCH_CHECK();
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void head_state_embed_kernel(const float* __re
 
 extern "C" int deer_head_state_embed(const float* state, const float* w_arm, const float* b_arm, const float* e_grip, const void* w_state,
                                      const float* b_state, float* out, int d, int B, int w_is_f32, void* stream) {
-  if (d <= 0 || (d & 3) || B <= 0 || B > HB_MAX || 2 * d * 4 > 64 * 1024) return DEER_ERR_SHAPE;
+  if (d <= 0 || (d & 3) || B <= 0 || B > DEER_MAX_ENVS || 2 * d * 4 > 64 * 1024) return DEER_ERR_SHAPE;
   dim3 grid((d + 15) / 16, B);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (w_is_f32)
@@ -477,12 +477,12 @@ static int launch_head_lstm_layer(const float* x_src, long x_bstride, int x_mode
                                   const int* ctl, int kind, int layer, int w_is_f32, void* stream, const float* ghh) {
   if (in_dim <= 0 || (in_dim & 7) || H <= 0 || (H & 7) || x_mode < 0 || x_mode > 3 || (x_mode == X_LN && (ln_w == nullptr || in_dim > 2048)) ||
       ((x_mode == X_LN || x_mode == X_RAW) && (x_bstride & 3)) ||
-      ((x_mode == X_POOL_MAX || x_mode == X_POOL_AVG) && T <= 0) || B <= 0 || B > HB_MAX)
+      ((x_mode == X_POOL_MAX || x_mode == X_POOL_AVG) && T <= 0) || B <= 0 || B > DEER_MAX_ENVS)
     return DEER_ERR_SHAPE;
   // [B][in_dim + H] f32 of activations live in LDS: a batch that does not fit 150 KB goes in several launches (8 environments of
   // the 9B model: in_dim 4096 -> 2 x 4)
   const int per_env = (in_dim + H) * (int)sizeof(float);
-  const int nb_max = (150 * 1024 - 64) / per_env;
+  const int nb_max = std::min(HB_MAX, (150 * 1024 - 64) / per_env);   // and at most HB_MAX environments per launch (accumulator registers)
   if (nb_max < 1) return DEER_ERR_SHAPE;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
@@ -534,7 +534,9 @@ extern "C" int deer_head_lstm_layer_pre(const float* x_src, long x_bstride, int 
 // unit j of layer l, its four gate rows; h_state [L][B][H]).  Once per control step, before the first head evaluation.
 struct deer_lstm_hh_args { const void* w[8]; const float* b[8]; };
 template <typename WT>
-__global__ __launch_bounds__(256) void head_lstm_hh_kernel(deer_lstm_hh_args a, const float* __restrict__ h_state, float* __restrict__ ghh, int H, int B) {
+__global__ __launch_bounds__(256) void head_lstm_hh_kernel(deer_lstm_hh_args a, const float* __restrict__ h_state, float* __restrict__ ghh, int H, int B_all,
+                                                           int b0, int B) {
+  // environments b0 .. b0 + B - 1 of a batch of B_all (h_state [L][B_all][H], ghh [L][B_all][4H])
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [B][H]
   const int l = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 4 + wave;
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(256) void head_lstm_hh_kernel(deer_lstm_hh_args a, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) wh[u][q] = k < H ? W8<WT>::load_stream(w_hh + ((long)q * H + jr) * H + k) : W8<WT>::zero();
   }
-  block_copy_to_lds(h_state + (long)l * B * H, lds, B * H, false);
+  block_copy_to_lds(h_state + ((long)l * B_all + b0) * H, lds, B * H, false);
   __syncthreads();
   if (j >= H) return;
   float acc[4][HB_MAX];
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(256) void head_lstm_hh_kernel(deer_lstm_hh_args a, 
       }
   }
   const float* bh = a.b[l];
-  float* out = ghh + (long)l * B * 4 * H;
+  float* out = ghh + ((long)l * B_all + b0) * 4 * H;
 #pragma unroll
   for (int b = 0; b < HB_MAX; ++b)
     if (b < B) {
@@ -593,18 +595,21 @@ __global__ __launch_bounds__(256) void head_lstm_hh_kernel(deer_lstm_hh_args a, 
 
 extern "C" int deer_head_lstm_hh(const void* const* w_hh, const float* const* b_hh, int L, const float* h_state, float* ghh, int H, int B, int w_is_f32,
                                  void* stream) {
-  if (w_hh == nullptr || b_hh == nullptr || L <= 0 || L > 8 || h_state == nullptr || ghh == nullptr || H <= 0 || (H & 7) || B <= 0 || B > HB_MAX ||
-      (size_t)B * H * sizeof(float) > 64 * 1024)
+  if (w_hh == nullptr || b_hh == nullptr || L <= 0 || L > 8 || h_state == nullptr || ghh == nullptr || H <= 0 || (H & 7) || B <= 0 || B > DEER_MAX_ENVS ||
+      (size_t)HB_MAX * H * sizeof(float) > 64 * 1024)
     return DEER_ERR_SHAPE;
   deer_lstm_hh_args a{};
   for (int l = 0; l < L; ++l) {
     if (w_hh[l] == nullptr || b_hh[l] == nullptr) return DEER_ERR_SHAPE;
     a.w[l] = w_hh[l]; a.b[l] = b_hh[l];
   }
-  const int smem = B * H * (int)sizeof(float);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (w_is_f32) hipLaunchKernelGGL(head_lstm_hh_kernel<float>, dim3((H + 3) / 4, L), dim3(256), smem, st, a, h_state, ghh, H, B);
-  else hipLaunchKernelGGL(head_lstm_hh_kernel<bf16_t>, dim3((H + 3) / 4, L), dim3(256), smem, st, a, h_state, ghh, H, B);
+  for (int b0 = 0; b0 < B; b0 += HB_MAX) {                 // batches above HB_MAX environments: one launch per chunk
+    const int nb = B - b0 < HB_MAX ? B - b0 : HB_MAX;
+    const int smem = nb * H * (int)sizeof(float);
+    if (w_is_f32) hipLaunchKernelGGL(head_lstm_hh_kernel<float>, dim3((H + 3) / 4, L), dim3(256), smem, st, a, h_state, ghh, H, B, b0, nb);
+    else hipLaunchKernelGGL(head_lstm_hh_kernel<bf16_t>, dim3((H + 3) / 4, L), dim3(256), smem, st, a, h_state, ghh, H, B, b0, nb);
+  }
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
@@ -620,8 +625,8 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
                                                       const WT* __restrict__ W0, const float* __restrict__ b0,
                                                       const WT* __restrict__ W1, const float* __restrict__ b1, int out_dim,
                                                       float* __restrict__ dst, int B, float eps, const int* ctl, int kind,
-                                                      int layer) {
-  if (head_skip(ctl, kind, layer, B)) return;
+                                                      int layer, int B_all) {
+  if (head_skip(ctl, kind, layer, B_all)) return;            // src / dst already point at this launch's first environment (B of B_all)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;                     // [B][in_dim]
   const int grp = blockIdx.y;
@@ -687,20 +692,25 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
 extern "C" int deer_head_fc(const float* src, int src_stride, int in_dim, int pro, const float* lnw0, const float* lnb0,
                             const float* lnw1, const float* lnb1, const void* W0, const float* b0, const void* W1, const float* b1,
                             int out_dim, float* dst, int B, float eps, const int* ctl, int kind, int layer, int w_is_f32, void* stream) {
-  if (in_dim <= 0 || (in_dim & 7) || out_dim <= 0 || pro < 0 || pro > 3 || B <= 0 || B > HB_MAX || (src_stride & 3) ||
+  if (in_dim <= 0 || (in_dim & 7) || out_dim <= 0 || pro < 0 || pro > 3 || B <= 0 || B > DEER_MAX_ENVS || (src_stride & 3) ||
       ((pro == PRO_LN || pro == PRO_GROUP_LN_RELU) && in_dim > 2048))
     return DEER_ERR_SHAPE;
-  const int smem = (B * in_dim + 16) * (int)sizeof(float);
-  if (smem > 64 * 1024) return DEER_ERR_SHAPE;
   dim3 grid((out_dim + 7) / 8, 2);
-  if (w_is_f32)
-    hipLaunchKernelGGL(head_fc_kernel<float>, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), src, src_stride, in_dim, pro, lnw0,
-                       lnb0, lnw1, lnb1, reinterpret_cast<const float*>(W0), b0, reinterpret_cast<const float*>(W1), b1, out_dim, dst,
-                       B, eps, ctl, kind, layer);
-  else
-    hipLaunchKernelGGL(head_fc_kernel<bf16_t>, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), src, src_stride, in_dim, pro, lnw0,
-                       lnb0, lnw1, lnb1, reinterpret_cast<const bf16_t*>(W0), b0, reinterpret_cast<const bf16_t*>(W1), b1, out_dim, dst,
-                       B, eps, ctl, kind, layer);
+  for (int e0 = 0; e0 < B; e0 += HB_MAX) {                 // batches above HB_MAX environments: one launch per chunk
+    const int nb = B - e0 < HB_MAX ? B - e0 : HB_MAX;
+    const int smem = (nb * in_dim + 16) * (int)sizeof(float);
+    if (smem > 64 * 1024) return DEER_ERR_SHAPE;
+    const float* s_ = src + (long)e0 * src_stride;
+    float* d_ = dst + (long)e0 * 2 * out_dim;
+    if (w_is_f32)
+      hipLaunchKernelGGL(head_fc_kernel<float>, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), s_, src_stride, in_dim, pro, lnw0,
+                         lnb0, lnw1, lnb1, reinterpret_cast<const float*>(W0), b0, reinterpret_cast<const float*>(W1), b1, out_dim, d_,
+                         nb, eps, ctl, kind, layer, B);
+    else
+      hipLaunchKernelGGL(head_fc_kernel<bf16_t>, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), s_, src_stride, in_dim, pro, lnw0,
+                         lnb0, lnw1, lnb1, reinterpret_cast<const bf16_t*>(W0), b0, reinterpret_cast<const bf16_t*>(W1), b1, out_dim, d_,
+                         nb, eps, ctl, kind, layer, B);
+  }
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
@@ -1012,41 +1022,104 @@ __global__ __launch_bounds__(512) void head_final_kernel(const float* __restrict
 // Residency: G <= 128 workgroups of 512 threads - they need no particular placement and no other kernel ever waits for them.
 #define HF_SPIN_LIMIT (1 << 22)
 
+#define HF_LN_MAXE 4     // float4 per lane: LayerNorm rows of up to 1024 values (LSTM hidden size, hidden Linears)
+// rows_ln_to_lds in two halves: gamma / beta are requested BEFORE the phase's hand-off wait, the rows are normalised after it (the
+// arithmetic and its order are those of rows_ln_to_lds: one wave per row, in-wave sums)
+struct hf_ln_regs { float4 gw[HF_LN_MAXE], gb[HF_LN_MAXE]; };
+__device__ __forceinline__ void hf_ln_prefetch(hf_ln_regs& r, const float* __restrict__ w, const float* __restrict__ bta, int n) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int e = 0; e < HF_LN_MAXE; ++e) {
+    const int i = (lane + 64 * e) * 4;
+    r.gw[e] = (w != nullptr && i < n) ? *reinterpret_cast<const float4*>(w + i) : float4{0.f, 0.f, 0.f, 0.f};
+    r.gb[e] = (bta != nullptr && i < n) ? *reinterpret_cast<const float4*>(bta + i) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+__device__ __forceinline__ void hf_ln_apply(const hf_ln_regs& r, const float* src, long stride, float* dst, int n, int B, float eps, bool relu) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int b = wave; b < B; b += nw) {
+    const float* s = src + (long)b * stride;
+    float* d = dst + b * n;
+    float4 v[HF_LN_MAXE];
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < HF_LN_MAXE; ++e) {
+      const int i = (lane + 64 * e) * 4;
+      v[e] = i < n ? *reinterpret_cast<const float4*>(s + i) : float4{0.f, 0.f, 0.f, 0.f};
+      sum += v[e].x + v[e].y + v[e].z + v[e].w;
+    }
+    const float mean = wave_sum(sum) / n;
+    float var = 0.f;
+#pragma unroll
+    for (int e = 0; e < HF_LN_MAXE; ++e)
+      if ((lane + 64 * e) * 4 < n) {
+        const float a = v[e].x - mean, bq = v[e].y - mean, c = v[e].z - mean, dd = v[e].w - mean;
+        var += a * a + bq * bq + c * c + dd * dd;
+      }
+    const float rstd = rsqrtf(wave_sum(var) / n + eps);
+#pragma unroll
+    for (int e = 0; e < HF_LN_MAXE; ++e) {
+      const int i = (lane + 64 * e) * 4;
+      if (i < n) {
+        float4 y;
+        y.x = (v[e].x - mean) * rstd * r.gw[e].x + r.gb[e].x; y.y = (v[e].y - mean) * rstd * r.gw[e].y + r.gb[e].y;
+        y.z = (v[e].z - mean) * rstd * r.gw[e].z + r.gb[e].z; y.w = (v[e].w - mean) * rstd * r.gw[e].w + r.gb[e].w;
+        if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+        *reinterpret_cast<float4*>(d + i) = y;
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ unsigned long long hf_pack(float v, unsigned tag) {
   return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
 }
 __device__ __forceinline__ void hf_publish(unsigned long long* g, float v, unsigned tag) {
   __hip_atomic_store(g, hf_pack(v, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// n tagged granules -> dst (LDS), all threads of the workgroup; 8 requests in flight per thread, late granules are polled one by one
-__device__ __forceinline__ void hf_gather(const unsigned long long* g, int n, float* dst, unsigned tag, int* err) {
-  const int step = blockDim.x;
+// n tagged granules -> dst (LDS), swept by the first `gw` waves of the workgroup (the others wait at the barrier behind them).  A lane
+// keeps up to 8 requests in flight; granules that have not arrived are requested AGAIN TOGETHER after a short sleep - re-polling them one
+// after the other (the first versions) costs a memory-side round trip per late granule: a freshly loaded copy of the first late one says
+// nothing about the copies of the others, which were loaded before they arrived (profiles/r05_e_head_eval_fused_*: 56-94 us per
+// evaluation against 51-67 for the eight launches).
+__device__ __forceinline__ void hf_gather(const unsigned long long* g, int n, float* dst, unsigned tag, int* err, int gw) {
+  if ((int)threadIdx.x >= 64 * gw) return;
+  const int step = 64 * gw;
   for (int base = threadIdx.x; base < n; base += step * 8) {
     unsigned long long v[8];
+    bool ok[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = base + u * step;
-      v[u] = i < n ? __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    }
+    for (int u = 0; u < 8; ++u) ok[u] = base + u * step >= n;
+    int spins = 0;
+    while (true) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = base + u * step;
-      if (i < n) {
-        int spins = 0;
-        while ((unsigned)(v[u] >> 32) != tag) {
-          if (++spins > HF_SPIN_LIMIT) { *err = 1; break; }
-          __builtin_amdgcn_s_sleep(2);
-          v[u] = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int u = 0; u < 8; ++u)
+        if (!ok[u]) v[u] = __hip_atomic_load(g + base + u * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool pending = false;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (!ok[u]) {
+          if ((unsigned)(v[u] >> 32) == tag) {
+            ok[u] = true;
+            dst[base + u * step] = __uint_as_float((unsigned)v[u]);
+          } else {
+            pending = true;
+          }
         }
-        dst[i] = __uint_as_float((unsigned)v[u]);
-      }
+      if (!pending) break;
+      if (++spins > HF_SPIN_LIMIT || (spins > 4096 && *(volatile int*)err != 0)) { *err = 1; break; }
+      __builtin_amdgcn_s_sleep(4);
     }
   }
 }
 
-// HBT: compile-time bound of the environment loops (1: one environment - the latency-critical case; 8: env batches).  The loops over the
-// LSTM layers / hidden Linears are unrolled with compile-time indices: a runtime index into the by-value argument struct would make
-// hipcc copy the struct to scratch (seen: 1.4 KB of scratch per lane).
+// workgroup barrier that orders LDS traffic only: __syncthreads() carries a release fence, which on gfx9 is `s_waitcnt vmcnt(0)` - it would
+// drain the weight rows a phase has just requested and serialise their HBM round trip with the hand-off the phase waits for next
+__device__ __forceinline__ void hf_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 template <typename WT, int HBT>
 __global__ __launch_bounds__(512) void head_fused_kernel(deer_head_fused_args a) {
   const int B = a.B, H = a.H, d = a.d, L = a.L;
@@ -1063,6 +1136,13 @@ __global__ __launch_bounds__(512) void head_fused_kernel(deer_head_fused_args a)
   // tag of this evaluation: err[1] counts the evaluations this exchange buffer has served; the workgroup that runs the last phase bumps
   // it when everything is over (every workgroup that has any work read it before: the last phase waits for all of their results)
   const unsigned tag = ((const volatile unsigned*)a.err)[1] + 1u;
+  int n_stamp = 0;
+#define HF_STAMP()                                                                     \
+  do {                                                                                 \
+    if (a.trace != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && n_stamp < 64) a.trace[n_stamp] = wall_clock64(); \
+    ++n_stamp;                                                                         \
+  } while (0)
+  HF_STAMP();
   unsigned long long* gX0 = a.xg;
   unsigned long long* gH = gX0 + (long)B * d;
   unsigned long long* gC = gH + (long)L * B * H;
@@ -1082,8 +1162,34 @@ __global__ __launch_bounds__(512) void head_fused_kernel(deer_head_fused_args a)
       for (int q = 0; q < 4; ++q) wi[u][q] = k < d ? W8<WT>::load_stream(w_ih + ((long)q * H + jr0) * d + k) : W8<WT>::zero();
     }
   }
-  // ---- phase 0: token pool, spread over all threads of the launch (head_pool_kernel's arithmetic) ----
-  for (int e = blockIdx.x * 512 + tid; e < B * d; e += gridDim.x * 512) {
+  // ---- phase 0: token pool (head_pool_kernel's arithmetic).  One environment: EVERY workgroup pools all d columns for itself - T rows of
+  // d floats from L2, all T loads of a thread in flight - and the first hand-off disappears; env batches spread the pool over the launch ----
+  if (HBT == 1) {
+    for (int i = tid; i < d; i += 512) {
+      const int sl = a.cmap != nullptr ? a.cmap[CMAP_ENV_SLOT] : 0;
+      float acc = 0.f;
+      if (sl >= 0) {
+        const float* x = a.feats + ((long)sl * a.T) * d + i;
+        acc = a.avg ? 0.f : -INFINITY;
+        int n = 0;
+        for (int t0 = 0; t0 < a.T; t0 += 8) {
+          float v[8];
+          bool on[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            on[u] = t0 + u < a.T && (a.key_mask == nullptr || a.key_mask[t0 + u] != 0);
+            v[u] = on[u] ? x[(long)(t0 + u) * d] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (on[u]) { acc = a.avg ? acc + v[u] : fmaxf(acc, v[u]); ++n; }
+        }
+        if (a.avg) acc /= (float)max(n, 1);
+      }
+      xs[i] = acc;
+    }
+  }
+  for (int e = blockIdx.x * 512 + tid; e < B * d && HBT > 1; e += gridDim.x * 512) {
     const int b = e / d, i = e - b * d;
     const int sl = a.cmap != nullptr ? a.cmap[CMAP_ENV_SLOT + b] : b;
     float acc = 0.f;
@@ -1102,6 +1208,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(deer_head_fused_args a)
     }
     hf_publish(gX0 + e, acc, tag);
   }
+  HF_STAMP();                                                        // pool done (this workgroup)
   // ---- LSTM layers ----
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
@@ -1117,16 +1224,29 @@ __global__ __launch_bounds__(512) void head_fused_kernel(deer_head_fused_args a)
       }
     }
     const bool ln = l > 0 && a.lstm_ln;
-    __syncthreads();                                                 // the previous phase's reads of raw / xs are over
-    hf_gather(l == 0 ? gX0 : gH + (long)(l - 1) * B * H, B * in_dim, ln ? raw : xs, tag, a.err);
-    __syncthreads();
-    if (ln) {
-      rows_ln_to_lds(raw, in_dim, xs, in_dim, B, a.ln_w[l > 0 ? l - 1 : 0], a.ln_b[l > 0 ? l - 1 : 0], a.eps, false);
-      __syncthreads();
-    }
     const float* b_ih = a.b_ih[l];
     const float* ghh = a.ghh + (long)l * B * 4 * H;
     const float* c_prev = a.c_prev + (long)l * B * H;
+    // everything else this phase reads from memory is requested before the hand-off wait as well: the LayerNorm affine of the input and
+    // (lane b) the bias / recurrent half / cell state of this wave's first hidden unit
+    hf_ln_regs lnr;
+    if (ln) hf_ln_prefetch(lnr, a.ln_w[l > 0 ? l - 1 : 0], a.ln_b[l > 0 ? l - 1 : 0], in_dim);
+    float pb[4] = {0.f, 0.f, 0.f, 0.f}, pg[4] = {0.f, 0.f, 0.f, 0.f}, pc = 0.f;
+    if (lane < B && j0 < H) {
+      const float* gp = ghh + (long)lane * 4 * H + j0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { pb[q] = b_ih[q * H + j0]; pg[q] = gp[q * H]; }
+      pc = c_prev[lane * H + j0];
+    }
+    hf_lds_barrier();                                                 // the previous phase's reads of raw / xs are over
+    if (l > 0 || HBT > 1) hf_gather(l == 0 ? gX0 : gH + (long)(l - 1) * B * H, B * in_dim, ln ? raw : xs, tag, a.err, a.gather_waves);
+    hf_lds_barrier();
+    HF_STAMP();                                                      // input gathered
+    if (ln) {
+      hf_ln_apply(lnr, raw, in_dim, xs, in_dim, B, a.eps, false);
+      hf_lds_barrier();
+    }
+    HF_STAMP();                                                      // input normalised
     for (int j = j0; j < H; j += TW) {
       float acc[4][HBT];
 #pragma unroll
@@ -1167,9 +1287,14 @@ __global__ __launch_bounds__(512) void head_fused_kernel(deer_head_fused_args a)
         }
       if (lane < B) {
         const int b = lane;
-        const float* gp = ghh + (long)b * 4 * H + j;
-        gi += b_ih[j] + gp[0]; gf += b_ih[H + j] + gp[H]; gg += b_ih[2 * H + j] + gp[2 * H]; go += b_ih[3 * H + j] + gp[3 * H];
-        const float c2 = sigmoidf_(gf) * c_prev[b * H + j] + sigmoidf_(gi) * tanhf(gg);
+        if (j != j0) {
+          const float* gp = ghh + (long)b * 4 * H + j;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { pb[q] = b_ih[q * H + j]; pg[q] = gp[q * H]; }
+          pc = c_prev[b * H + j];
+        }
+        gi += pb[0] + pg[0]; gf += pb[1] + pg[1]; gg += pb[2] + pg[2]; go += pb[3] + pg[3];
+        const float c2 = sigmoidf_(gf) * pc + sigmoidf_(gi) * tanhf(gg);
         const float h2 = sigmoidf_(go) * tanhf(c2);
         const long o = ((long)l * B + b) * H + j;
         a.c_tmp[o] = c2;
@@ -1178,7 +1303,9 @@ __global__ __launch_bounds__(512) void head_fused_kernel(deer_head_fused_args a)
         hf_publish(gH + o, h2, tag);
       }
     }
+    HF_STAMP();                                                      // layer published (this workgroup)
   }
+  HF_STAMP();                                                        // LSTM layers published (this workgroup)
   // ---- hidden Linears of both MLP heads ----
   const float* lnw_last = L == 4 ? a.ln_w[3] : L == 3 ? a.ln_w[2] : L == 2 ? a.ln_w[1] : a.ln_w[0];   // LayerNorm of the last LSTM layer's output
   const float* lnb_last = L == 4 ? a.ln_b[3] : L == 3 ? a.ln_b[2] : L == 2 ? a.ln_b[1] : a.ln_b[0];
@@ -1200,22 +1327,34 @@ __global__ __launch_bounds__(512) void head_fused_kernel(deer_head_fused_args a)
       pw0[u] = (live0 && k < in_dim) ? W8<WT>::load_stream(W0 + (long)n00 * in_dim + k) : W8<WT>::zero();
       pw1[u] = (live0 && n00 + 1 < out_dim && k < in_dim) ? W8<WT>::load_stream(W0 + (long)(n00 + 1) * in_dim + k) : W8<WT>::zero();
     }
-    __syncthreads();
+    const float* bb0 = grp0 ? a.fb[fi][1] : a.fb[fi][0];
+    const float pbias0 = live0 ? bb0[n00] : 0.f, pbias1 = (live0 && n00 + 1 < out_dim) ? bb0[n00 + 1] : 0.f;
+    hf_ln_regs lnr0, lnr1;                                           // LayerNorm affine of the phase's input, requested before the wait
+    if (fi == 0) {
+      if (a.lstm_ln) hf_ln_prefetch(lnr0, lnw_last, lnb_last, H);
+    } else if (a.mlp_ln) {
+      hf_ln_prefetch(lnr0, a.fln_w[fi > 0 ? fi - 1 : 0][0], a.fln_b[fi > 0 ? fi - 1 : 0][0], in_dim);
+      hf_ln_prefetch(lnr1, a.fln_w[fi > 0 ? fi - 1 : 0][1], a.fln_b[fi > 0 ? fi - 1 : 0][1], in_dim);
+    }
+    hf_lds_barrier();
     if (fi == 0) {                                                   // shared input: [LN of] the last LSTM layer's h
-      hf_gather(gH + (long)(L - 1) * B * H, B * H, a.lstm_ln ? raw : xs, tag, a.err);
-      __syncthreads();
+      hf_gather(gH + (long)(L - 1) * B * H, B * H, a.lstm_ln ? raw : xs, tag, a.err, a.gather_waves);
+      hf_lds_barrier();
       if (a.lstm_ln) {
-        rows_ln_to_lds(raw, H, xs, H, B, lnw_last, lnb_last, a.eps, false);
-        __syncthreads();
+        hf_ln_apply(lnr0, raw, H, xs, H, B, a.eps, false);
+        hf_lds_barrier();
       }
     } else {                                                         // grouped: x_g = relu([LN_g](z[b][g * in ..])) -> xs[g][b][in]
-      hf_gather(gZ + zoff - (long)B * 2 * in_dim, B * 2 * in_dim, raw, tag, a.err);
-      __syncthreads();
+      hf_gather(gZ + zoff - (long)B * 2 * in_dim, B * 2 * in_dim, raw, tag, a.err, a.gather_waves);
+      hf_lds_barrier();
+      if (a.mlp_ln) {
+        hf_ln_apply(lnr0, raw, 2 * in_dim, xs, in_dim, B, a.eps, true);
+        hf_ln_apply(lnr1, raw + in_dim, 2 * in_dim, xs + (long)B * in_dim, in_dim, B, a.eps, true);
+      } else {
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
-        rows_to_lds(raw + g * in_dim, 2 * in_dim, xs + (long)g * B * in_dim, in_dim, B, a.mlp_ln != 0, a.fln_w[fi > 0 ? fi - 1 : 0][g],
-                    a.fln_b[fi > 0 ? fi - 1 : 0][g], a.eps, true);
-      __syncthreads();
+        for (int g = 0; g < 2; ++g) rows_to_lds(raw + g * in_dim, 2 * in_dim, xs + (long)g * B * in_dim, in_dim, B, false, nullptr, nullptr, a.eps, true);
+      }
+      hf_lds_barrier();
     }
     for (int p = p0; p < 2 * PG; p += TW) {
       const int grp = p / PG, n0 = 2 * (p - grp * PG);
@@ -1256,11 +1395,12 @@ __global__ __launch_bounds__(512) void head_fused_kernel(deer_head_fused_args a)
           const float s0 = wave_sum(a0[b]), s1 = wave_sum(a1[b]);
           if (lane == 0) {
             unsigned long long* z = gZ + zoff + (long)b * 2 * out_dim + (long)grp * out_dim + n0;
-            hf_publish(z, s0 + bb[n0], tag);
-            if (two) hf_publish(z + 1, s1 + bb[n0 + 1], tag);
+            hf_publish(z, s0 + (p == p0 ? pbias0 : bb[n0]), tag);
+            if (two) hf_publish(z + 1, s1 + (p == p0 ? pbias1 : bb[n0 + 1]), tag);
           }
         }
     }
+    HF_STAMP();                                                      // hidden Linear published (this workgroup)
     zoff += (long)B * 2 * out_dim;
     in_dim = out_dim;
   }
@@ -1271,12 +1411,12 @@ __global__ __launch_bounds__(512) void head_fused_kernel(deer_head_fused_args a)
   int pro;
   const float *s0, *s1, *lw0, *lb0, *lw1, *lb1;
   if (a.n_fc == 0) {
-    hf_gather(gH + ((long)(L - 1) * B + b) * H, H, raw, tag, a.err);
+    hf_gather(gH + ((long)(L - 1) * B + b) * H, H, raw, tag, a.err, a.gather_waves);
     pro = a.lstm_ln ? PRO_LN : PRO_RAW;
     s0 = s1 = raw;
     lw0 = lw1 = lnw_last; lb0 = lb1 = lnb_last;
   } else {
-    hf_gather(gZ + zoff - (long)B * 2 * in_dim + (long)b * 2 * in_dim, 2 * in_dim, raw, tag, a.err);
+    hf_gather(gZ + zoff - (long)B * 2 * in_dim + (long)b * 2 * in_dim, 2 * in_dim, raw, tag, a.err, a.gather_waves);
     pro = a.mlp_ln ? PRO_GROUP_LN_RELU : PRO_GROUP_RELU;
     s0 = raw; s1 = raw + in_dim;
     const int nf = a.n_fc;
@@ -1284,10 +1424,12 @@ __global__ __launch_bounds__(512) void head_fused_kernel(deer_head_fused_args a)
     lw1 = nf == 3 ? a.fln_w[2][1] : nf == 2 ? a.fln_w[1][1] : a.fln_w[0][1]; lb1 = nf == 3 ? a.fln_b[2][1] : nf == 2 ? a.fln_b[1][1] : a.fln_b[0][1];
   }
   __syncthreads();
+  HF_STAMP();                                                        // final input gathered
   head_final_body<WT, true>(b, s0, s1, xs, in_dim, pro, lw0, lb0, lw1, lb1, reinterpret_cast<const WT*>(a.Wa), a.ba, reinterpret_cast<const WT*>(a.Wg),
                             a.bg, ctl0, a.kind, a.layer, a.slot, a.thresholds, a.force, a.thr_type, a.leq, a.h_tmp, a.c_tmp, a.h_state, a.c_state, L,
                             H, B, a.action_dbg, a.eps, a.A, a.act_ext, gH, gC);
   __syncthreads();
+  HF_STAMP();                                                        // done
   if (b == 0 && threadIdx.x == 0) ((volatile unsigned*)a.err)[1] = tag;      // one environment: workgroup 0 is the only one that gets here
 }
 
@@ -1311,15 +1453,17 @@ extern "C" int deer_head_fused(const deer_head_fused_args* args, int w_is_f32, i
   // 273 VGPRs under hipcc - env batches keep the separate kernels
   if (args->B != 1) return DEER_ERR_SHAPE;
   if (a.ctl == nullptr || a.xg == nullptr || a.err == nullptr || a.ghh == nullptr || a.B <= 0 || a.B > HB_MAX || a.L <= 0 || a.L > 4 || a.n_fc < 0 ||
-      a.n_fc > 3 || (a.d & 7) || (a.H & 7) || a.d > 2048 || a.H > 2048 || a.kind == KIND_COMMIT || a.A < 1 || a.A > 8)
+      a.n_fc > 3 || (a.d & 7) || (a.H & 7) || a.d > 2048 || a.H > 1024 || a.kind == KIND_COMMIT || a.A < 1 || a.A > 8)
     return DEER_ERR_SHAPE;
   if (a.kind == KIND_CHECK && (a.thresholds == nullptr || a.slot < 0 || a.slot > 61)) return DEER_ERR_SHAPE;
   int max_in = a.d > a.H ? a.d : a.H;
   for (int i = 0; i < a.n_fc; ++i) {
-    if ((a.fc_dim[i] & 7) || a.fc_dim[i] > 2048) return DEER_ERR_SHAPE;
+    if ((a.fc_dim[i] & 7) || a.fc_dim[i] > 1024) return DEER_ERR_SHAPE;
     if (2 * a.fc_dim[i] > max_in) max_in = 2 * a.fc_dim[i];
   }
   a.max_in = max_in;
+  static const int gwaves = [] { const char* e = getenv("DEER_HF_GATHER_WAVES"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+  a.gather_waves = gwaves;
   const int smem = a.B * 2 * max_in * 4 + 512;
   if (smem > 150 * 1024) return DEER_ERR_SHAPE;
   if (n_workgroups < a.B) n_workgroups = a.B;
@@ -1359,7 +1503,7 @@ extern "C" int deer_head_final_multi(const float* src, int src_stride, int in_di
                                      int* ctl, int kind, int layer, int slot, const float* thresholds, int force, int thr_type, int leq,
                                      const float* h_tmp, const float* c_tmp, float* h_state, float* c_state, int L, int H, int B,
                                      float* action_dbg, float eps, int w_is_f32, int A, float* act_ext, void* stream) {
-  if (in_dim <= 0 || (in_dim & 7) || pro < 0 || pro > 3 || kind < 0 || kind > 2 || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
+  if (in_dim <= 0 || (in_dim & 7) || pro < 0 || pro > 3 || kind < 0 || kind > 2 || B <= 0 || B > DEER_MAX_ENVS) return DEER_ERR_SHAPE;
   if (kind == KIND_CHECK && (thresholds == nullptr || slot < 0 || ctl == nullptr)) return DEER_ERR_SHAPE;
   if (A < 1 || A > 8 || (A > 1 && ctl != nullptr && act_ext == nullptr)) return DEER_ERR_SHAPE;
   const int smem = (2 * in_dim + 16 + 64 + 4) * (int)sizeof(float);
@@ -1384,7 +1528,7 @@ __global__ void ctl_begin_step_kernel(int* ctl0, const int* hold_src, int B, int
   if (cmap != nullptr && b == 0 && threadIdx.x < 2) {      // both copies of the row map start as the identity: every environment active
     int* cm = cmap + threadIdx.x * CMAP_WORDS;
     cm[CMAP_N] = B;
-    for (int e = 0; e < HB_MAX; ++e) {
+    for (int e = 0; e < DEER_MAX_ENVS; ++e) {
       cm[CMAP_SLOT_ENV + e] = e;
       cm[CMAP_ENV_SLOT + e] = e < B ? e : -1;
     }
@@ -1416,7 +1560,7 @@ __global__ void ctl_begin_step_kernel(int* ctl0, const int* hold_src, int B, int
 }
 
 extern "C" int deer_ctl_begin_step(int* ctl, const int* hold_src, int B, void* stream) {
-  if (ctl == nullptr || B <= 0 || B > HB_MAX) return DEER_ERR_SHAPE;
+  if (ctl == nullptr || B <= 0 || B > DEER_MAX_ENVS) return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(ctl_begin_step_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ctl, hold_src, B, static_cast<int*>(nullptr));
   DEER_LAUNCH_CHECK();
   return DEER_OK;
@@ -1424,7 +1568,7 @@ extern "C" int deer_ctl_begin_step(int* ctl, const int* hold_src, int B, void* s
 
 // the same, also resetting the two copies of the row map (2 x CMAP_WORDS int32) of an env batch with compaction to the identity
 extern "C" int deer_ctl_begin_step_map(int* ctl, const int* hold_src, int B, int* cmap, void* stream) {
-  if (ctl == nullptr || B <= 0 || B > HB_MAX || cmap == nullptr) return DEER_ERR_SHAPE;
+  if (ctl == nullptr || B <= 0 || B > DEER_MAX_ENVS || cmap == nullptr) return DEER_ERR_SHAPE;
   hipLaunchKernelGGL(ctl_begin_step_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ctl, hold_src, B, cmap);
   DEER_LAUNCH_CHECK();
   return DEER_OK;

@@ -22,7 +22,7 @@ namespace {
 
 constexpr float kEps = 1e-5f;
 constexpr int kVitHeadLayers = 3;   // ViT blocks in the first piece of a vision chain (short graph: the GPU idles until it is submitted)
-constexpr int kMaxRows = 256;       // LLM rows (n_envs * T): 8 environments x 32 tokens (data.py:905-919: max_length = 32); the trunk GEMM runs them in blocks of 128
+constexpr int kMaxRows = 512;       // LLM rows (n_envs * T): 16 environments x 32 tokens (data.py:905-919: max_length = 32); the trunk GEMM runs them in blocks of 128
 constexpr int kMaxSplit = 32;
 // LLM rows ABOVE which the trunk projections run on deer_gemm_skinny_hl (pre-split hi/lo activation planes, LDS-DMA ring, 128-column
 // workgroups, GELU/slab reduction once per layer).  Default 0 = always (r03, full-depth step as one graph: 3.79 -> 3.59 ms at one
@@ -176,8 +176,10 @@ struct deer_model {
   std::vector<FcW> fc;
   size_t wa, ba, wg, bg;
   std::vector<HeadW> lw;            // layerwise_exit_eval: per-layer heads in the reference's registration order (lm_exit_modules.0.., lm_head)
+  size_t hf_trace = SIZE_MAX;
   size_t hf_xg = SIZE_MAX, hf_err = SIZE_MAX;   // one-launch head evaluation (csrc/head.hip: deer_head_fused): exchange granules, error word
-  bool head_fused = true;           // DEER_HEAD_FUSED=0: the eight-launch evaluation everywhere
+  bool head_fused = false;          // one-launch head evaluation (measured: 65-71 us against 51 for the eight launches - an experiment like the
+                                    // persistent trunk layer; DEER_HEAD_FUSED=1 / deer_model_set_head_fused switch it on)
   int head_wgs = 128;               // DEER_HEAD_WGS: resident workgroups of the one-launch evaluation
   size_t act_ext = SIZE_MAX;        // multi_step_action > 1: [B][4][64] f32 = previous / committed / ensemble action of 7 A values (+ A gripper logits)
   // workspace
@@ -607,6 +609,7 @@ void build_workspace(deer_model* m) {
   m->act_ext = named(m, "act_ext", (size_t)B * 4 * 64 * 4);
   m->hf_xg = named(m, "head_fused_xg", (size_t)deer_head_fused_granules(B, d, m->H, m->Lh, m->n_fc, m->fc_dims) * 8);
   m->hf_err = named(m, "head_fused_err", 256);
+  m->hf_trace = named(m, "head_fused_trace", 64 * 8);
   for (HeadW& h : m->lw) {                                             // per-layer heads: own LSTM state
     h.h_state = m->wl.add(st);
     h.c_state = m->wl.add(st);
@@ -1281,7 +1284,7 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
   const unsigned char* km = use_mask ? (m->mask_override ? m->mask_override : m->Wk<unsigned char>(m->key_mask)) : nullptr;
   // ---- control steps of one environment: the whole evaluation as ONE launch (csrc/head.hip: head_fused_kernel) ----
   if (m->head_fused && head == 0 && use_ctl && !no_ctl_final && feats_default && kind != DEER_KIND_COMMIT && B == 1 && !c.precision && !c.use_state &&
-      m->head_pre && m->ghh_valid && m->Lh <= 4 && m->n_fc <= 3 && d <= 2048 && H <= 2048) {
+      m->head_pre && m->ghh_valid && m->Lh <= 4 && m->n_fc <= 3 && d <= 2048 && H <= 1024) {
     deer_head_fused_args a{};
     a.feats = feats; a.T = T; a.d = d; a.avg = c.pooling_avg; a.key_mask = km;
     a.cmap = compact_active(m, B * T) ? m->Wk<int>(m->cmap) + cmap_parity(m, layer) * CMAP_WORDS : nullptr;
@@ -1304,6 +1307,8 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
     a.h_state = m->Wk<float>(shadow ? m->h_shadow : m->h_state); a.c_state = m->Wk<float>(shadow ? m->c_shadow : m->c_state);
     a.action_dbg = m->Wk<float>(m->action_dbg); a.eps = kEps; a.A = std::max(1, c.multi_step_action); a.act_ext = m->Wk<float>(m->act_ext);
     a.xg = m->Wk<unsigned long long>(m->hf_xg); a.err = m->Wk<int>(m->hf_err);
+    static const bool hf_trace_on = [] { const char* e = getenv("DEER_HF_TRACE"); return e != nullptr && e[0] == '1'; }();
+    a.trace = hf_trace_on ? m->Wk<unsigned long long>(m->hf_trace) : nullptr;
     Bracket b(m, "deer_head_fused", 0, 2.0 * (4.0 * H * (d + (m->Lh - 1.0) * H)), st);
     const int rc = deer_head_fused(&a, 0, m->head_wgs, st);
     if (rc != DEER_ERR_SHAPE) return rc;                       // DEER_ERR_SHAPE: a shape the one-launch form does not take -> separate kernels
@@ -1464,7 +1469,7 @@ extern "C" {
 int deer_model_create(const deer_config* cfg, deer_model** out) {
   if (cfg == nullptr || out == nullptr) return DEER_ERR_SHAPE;
   const deer_config& c = *cfg;
-  if (c.n_envs < 1 || c.n_envs > 8 || c.max_text_len < 1 || c.n_layers < 1 || c.vit_layers < 1 || c.perc_depth < 1) return DEER_ERR_SHAPE;
+  if (c.n_envs < 1 || c.n_envs > DEER_MAX_ENVS || c.max_text_len < 1 || c.n_layers < 1 || c.vit_layers < 1 || c.perc_depth < 1) return DEER_ERR_SHAPE;
   if (c.image_size % c.patch_size) return DEER_ERR_SHAPE;
   if (c.vit_width % c.vit_heads || c.vit_width / c.vit_heads != 64 || c.perc_dim_head != 64 || c.xattn_dim_head != 64) return DEER_ERR_SHAPE;
   if (c.d_model % 32 || c.d_model / c.n_heads > 128 || 2 * c.perc_latents > 128) return DEER_ERR_SHAPE;
@@ -1517,7 +1522,7 @@ int deer_model_head_state_changed(deer_model* m) {
   return DEER_OK;
 }
 
-// control steps of one environment: the head evaluation as one launch (on by default; DEER_HEAD_FUSED=0) or as the eight separate kernels
+// control steps of one environment: the head evaluation as one launch (DEER_HEAD_FUSED=1; off by default: measured slower) or as the eight separate kernels
 int deer_model_set_head_fused(deer_model* m, int on) {
   if (m == nullptr) return DEER_ERR_SHAPE;
   m->head_fused = on != 0;   // takes effect for pieces enqueued / captured from now on

@@ -245,7 +245,7 @@ extern "C" int deer_resadd_ln_rows(float* x, const float* slab, int s_in, long s
                                    void* out_bf16, void* out_lo, float* out_f32, float* x_copy, int T_rows, int d, float eps, const int* ctl,
                                    const int* cmap, int rows_per_env, const float* x_in, const int* cmap_old, int B, int drop_upto, void* stream) {
   if (T_rows <= 0 || d <= 0 || (d & 3) || d > 4096 || (slab != nullptr && s_in <= 0) || (gamma != nullptr && out_bf16 == nullptr && out_f32 == nullptr) ||
-      cmap == nullptr || rows_per_env <= 0 || ctl == nullptr || B <= 0 || B > 8 || (x_in != nullptr && (cmap_old == nullptr || x_in == x)))
+      cmap == nullptr || rows_per_env <= 0 || ctl == nullptr || B <= 0 || B > DEER_MAX_ENVS || (x_in != nullptr && (cmap_old == nullptr || x_in == x)))
     return DEER_ERR_SHAPE;
   deer_rowmap rm{cmap, rows_per_env, x_in, cmap_old, ctl, B, drop_upto};
   hipLaunchKernelGGL(resadd_ln_kernel<256>, dim3(T_rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,

@@ -127,10 +127,10 @@ class DeerEngine:
         self.dev = torch.device(device)
         if self.dev.index is None:
             self.dev = torch.device("cuda", torch.cuda.current_device())
-        assert 1 <= n_envs <= 8
+        assert 1 <= n_envs <= abi.MAX_ENVS
         self.B = n_envs
         self.n_cams = 2 * n_envs                       # images per step: (rgb, gripper) of every environment
-        # trunk rows n_envs * T: up to 256 in the bf16 arithmetic (8 environments x the reference's max_length = 32, data.py:905-919; the
+        # trunk rows n_envs * T: up to 512 in the bf16 arithmetic (16 environments x the reference's max_length = 32, data.py:905-919; the
         # hi/lo-plane trunk GEMM runs them in blocks of 128), 128 in the fp32 arithmetic (one launch of deer_gemm_skinny)
         self.MAX_ROWS = abi.max_trunk_rows(cfg, precision)
         self.max_T = min(max_text_len, self.MAX_ROWS // n_envs)
@@ -317,7 +317,9 @@ class DeerEngine:
 
     def set_head_fused(self, on: bool):
         """One-environment control steps: every head evaluation (pseudo action / exit check) as ONE launch (csrc/head.hip:
-        head_fused_kernel; default) or as the eight separate kernels.  Same arithmetic per row (tests/test_engine_parity.py)."""
+        head_fused_kernel) instead of the eight separate kernels (default).  Same arithmetic per row (tests/test_engine_parity.py);
+        measured SLOWER (65-71 us against 51 us per evaluation: every hand-off between resident workgroups costs 6-8 us, a kernel
+        boundary 1.4 us + ramp) - an experiment like the persistent trunk layer, kept switchable (DEER_HEAD_FUSED=1)."""
         abi.check(self.lib.deer_model_set_head_fused(self._h, 1 if on else 0), "deer_model_set_head_fused")
         if self._graphs:
             torch.cuda.synchronize(self.dev)
@@ -330,7 +332,12 @@ class DeerEngine:
     def set_persistent_layer(self, on: bool):
         """N1 experiment (csrc/persistent_layer.hip): one persistent launch per trunk layer of a one-environment step.  Bit-identical to
         the twelve-launch layer and slower; needs ALL of its 256 workgroups resident, so only one engine per GPU may use it at a time."""
+        if on and (self._siblings or self.B > 1):
+            # the persistent launch needs ALL of its 256 workgroups resident at once and ignores ALL_EXITED: engines that run beside it on
+            # the same GPU (sibling engines of a window / env batches in flight) cannot promise that (ADVICE r4)
+            raise abi.DeerHipError("set_persistent_layer(True): a stand-alone one-environment engine only (no sibling engines, no env batch)")
         abi.check(self.lib.deer_model_set_persistent_layer(self._h, 1 if on else 0), "deer_model_set_persistent_layer")
+        self._persistent_on = bool(on)
         torch.cuda.synchronize(self.dev)
         self._drop_graphs()
         self._buf("pl_state").view(torch.int32)[:16 * 12 + 16].zero_()   # barrier counters (cumulative over launches) + error words
@@ -876,7 +883,8 @@ class DeerEngine:
             rc = self.lib.deer_step_plan_run(nat["plan"], int(self._si_np[0]), self._seq, ctypes.c_void_p(main_st.cuda_stream),
                                              nat["chain_streams"], nat["head_stream"], nat["ctl_out"], None)
             if rc == 3:
-                raise abi.DeerHipError("no exit verdict from the device within 20 s")
+                raise abi.DeerHipError("no exit verdict from the device within 20 s" + (" (a hand-off of the one-launch head evaluation "
+                                       "timed out)" if self.head_fused_error() else ""))
             abi.check(rc, "deer_step_plan_run")
             self._ext_from_mirror()
             return self.read_result()
@@ -969,7 +977,7 @@ class DeerEngine:
         F = rgb_seq.shape[0]
         ids = ids.reshape(-1, ids.shape[-1])
         T = ids.shape[1]
-        G = max(1, min(group, self.MAX_ROWS // T, F, 8))
+        G = max(1, min(group, self.MAX_ROWS // T, F, abi.MAX_ENVS))
         last = self.cfg.n_layers - 1
         L, d = self.cfg.n_layers, self.cfg.d_model
         out = torch.empty(F, L, T, d, device=self.dev)
@@ -1024,7 +1032,7 @@ class DeerEngine:
             hidden = hidden.unsqueeze(0)
         rl = torch.as_tensor(rand_layers).reshape(hidden.shape[0], -1)
         bs, W, L, T, d = hidden.shape
-        G = max(1, min(group, self.MAX_ROWS // T, bs, 8))
+        G = max(1, min(group, self.MAX_ROWS // T, bs, abi.MAX_ENVS))
         w = self.sibling(G)
         layers = [0] + list(self.exit_ids)
         per_window = []
@@ -1070,10 +1078,17 @@ class DeerEngine:
             ext = self._hm[W * (1 + self.B):].view(np.float32).reshape(self.B, 2, 64)
             self.act_ext_host.numpy()[:, 1:3] = ext
 
+    def _check_device_errors(self):
+        """the experimental persistent trunk layer reports a timed-out barrier in an error word: a step whose kernels gave up waiting ran
+        on with undefined data, so the step raises instead of returning a result"""
+        if getattr(self, "_persistent_on", False) and self.persistent_layer_error() != 0:
+            raise abi.DeerHipError(f"persistent trunk layer: barrier timed out {self.persistent_layer_error_detail()}")
+
     def read_result(self, src=None):
         """Decode the per-environment control blocks (int32 numpy view; default: the pinned read-back buffer).  multi_step_action = A > 1:
         ``pose`` is (6 A,) = A consecutive 6-DoF actions and ``gripper`` / ``gripper_logit`` are (A,) tensors, the layout of the
         reference head's outputs (action_head.py:472-473, eval_utils.py:468-471)."""
+        self._check_device_errors()
         W = abi.CTL_WORDS
         ci = (self._ctl_host_np if src is None else src).reshape(self.B, W)
         cf = ci.view(np.float32)

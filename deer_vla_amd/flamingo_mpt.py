@@ -398,7 +398,7 @@ class MPTFlamingo(nn.Module):
         rand_layers = torch.tensor([exit_ids[int(i)] for i in idx.reshape(-1)]).reshape(bs, Wn)
         rand_feat = hid[torch.arange(F, device=hid.device), rand_layers.reshape(-1).to(hid.device)]      # (F, T, d)
         # extra_exit on the random-layer features, windows as sequences from a zero LSTM state: groups of <= 8 windows per evaluation
-        G = max(1, min(8, e.MAX_ROWS // T, bs))
+        G = max(1, min(8, e.MAX_ROWS // T, bs))   # groups of <= 8 windows per head evaluation
         w = e.sibling(G)
         rows = []
         rf = rand_feat.view(bs, Wn, T, cfg.d_model)

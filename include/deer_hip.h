@@ -236,7 +236,7 @@ int deer_resadd_ln_multirow(float* x, const float* slab, int s_in, long slab_str
 
 /* ---- env batch with COMPACTION of exited environments (the reference stops every environment at its own layer,
  * mosaic_gpt_3b.py:438-443): the rows of the still-active environments stay packed at the front of the trunk's buffers.  Row map `cmap`
- * (int32, CMAP_WORDS = 32 per copy): [0] = active slots, [1 + s] = environment of slot s, [9 + e] = slot of environment e or -1.  The
+ * (int32, CMAP_WORDS = 64 per copy): [0] = active slots, [1 + s] = environment of slot s, [17 + e] = slot of environment e or -1 (up to 16 environments).  The
  * *_active / *_rows entry points are the kernels above restricted to the active slots (rows_per_env rows each); per-environment inputs
  * (media K/V, text_time, key mask, control blocks) stay in environment order and are reached through the map. ---- */
 int deer_resadd_ln_rows(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* gamma, const float* beta, void* out_bf16,
@@ -312,7 +312,7 @@ int deer_embed_tokens(const long long* ids, const void* wte_bf16, float* x, int*
 int deer_broadcast_rows(const float* src, float* dst, long n, int batch, void* stream);   /* helpers.py:128 */
 
 /* ---- action head + exit gate (robot_flamingo/models/action_head.py:499-611, value_net.py:105-133,277-297) -----
- * All three evaluate a BATCH of B <= 8 independent environments per launch (weights read once): features [B][T][d],
+ * All three evaluate a BATCH of B <= 16 independent environments (weights read once per 8 environments: batches above 8 run in two halves): features [B][T][d],
  * LSTM state tensors [L][B][H], control blocks ctl + b*DEER_CTL_WORDS, exit decision per environment. */
 int deer_head_pool(const float* feats, float* pooled, int T, int d, int avg, int B, const unsigned char* key_mask, const int* ctl,
                    int kind, int layer, void* stream);
@@ -371,7 +371,8 @@ typedef struct deer_head_fused_args {
   const void* Wa; const float* ba; const void* Wg; const float* bg;
   int* ctl; int kind, layer, slot; const float* thresholds; int force, thr_type, leq;
   float* h_state; float* c_state; float* action_dbg; float eps; int A; float* act_ext;
-  unsigned long long* xg; int* err; int max_in;                                             /* max_in: filled by the launcher */
+  unsigned long long* xg; int* err; int max_in, gather_waves;                               /* max_in, gather_waves: filled by the launcher */
+  unsigned long long* trace;                                                                /* NULL, or 64 x u64: 100 MHz time stamps of workgroup 0 at the phase boundaries (tools/bench_head_eval.py) */
 } deer_head_fused_args;
 long deer_head_fused_granules(int B, int d, int H, int L, int n_fc, const int* fc_dim);
 int deer_head_fused(const deer_head_fused_args* args, int w_is_f32, int n_workgroups, void* stream);

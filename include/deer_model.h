@@ -85,7 +85,8 @@ int deer_model_buffer(const deer_model* m, int which, const char* name, long* of
  * (DEER_COMPACT=0 at creation turns it off); changing it affects what is enqueued / captured afterwards.  Results per environment are
  * bit-identical either way. */
 int deer_model_set_compaction(deer_model* m, int on);
-/* one-environment control steps: head evaluation as ONE launch (deer_head_fused, default) or as the eight separate kernels */
+/* one-environment control steps: head evaluation as ONE launch (deer_head_fused; an experiment, off by default: measured slower than the
+ * eight separate kernels) or as the eight separate kernels (default) */
 int deer_model_set_head_fused(deer_model* m, int on);
 /* N1 experiment (csrc/persistent_layer.hip): every trunk layer of a one-environment step as ONE persistent launch (12 phases, device-wide
  * barriers) instead of twelve launches.  Bit-identical, slower, and only safe with ONE engine per GPU: off unless DEER_PERSISTENT_LAYER=1. */

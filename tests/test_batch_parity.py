@@ -41,18 +41,26 @@ def setup():
 
 
 def batch_inputs(cfg, B, s, dev, step_offset=0):
-    per_env = [syn.synthetic_step_inputs(cfg, s + step_offset, rank=e, text_seed=7 + e) for e in range(B)]
+    # environments beyond the eight committed traces replay them (environment e sees the inputs of trace e % 8)
+    per_env = [syn.synthetic_step_inputs(cfg, s + step_offset, rank=e % 8, text_seed=7 + e % 8) for e in range(B)]
     rgb = torch.stack([p[0] for p in per_env]).to(dev, torch.bfloat16)
     grip = torch.stack([p[1] for p in per_env]).to(dev, torch.bfloat16)
     ids = torch.cat([p[2] for p in per_env]).to(dev)
     return rgb, grip, ids
 
 
-def test_eight_environment_dynamic_episode_matches_each_environments_oracle_trace(setup):
+@pytest.mark.parametrize("n_envs", [8, 16])
+def test_eight_environment_dynamic_episode_matches_each_environments_oracle_trace(setup, n_envs):
+    """n_envs = 16 (round 5): one engine carries 16 environments - 32 camera frames per vision chain (two rounds of
+    frame tiles per GEMM launch), 224 trunk rows (two row blocks), head evaluations in two halves of eight.  Environments e and e + 8
+    replay trace e of the committed eight; 24 steps."""
     z, cfg, eng, B = setup
     n = int(z["n_steps"])
+    if n_envs != B:
+        eng = DeerEngine(cfg, None, n_envs=n_envs, weights_from=eng)
+        B, n = n_envs, 24
     thr = [float(t) for t in z["thr"]]
-    ref_exit, ref_act, margin = z["exit"], z["action"], z["margin"]
+    ref_exit, ref_act, margin = (np.concatenate([z[k]] * (B // 8)) for k in ("exit", "action", "margin"))
     eng.configure_exit(cfg.exit_ids(), int(z["max_layer"]), 1)
     eng.set_thresholds(thr)
     eng.reset()
@@ -90,7 +98,7 @@ def test_eight_environment_dynamic_episode_matches_each_environments_oracle_trac
                knife_edge_flips=flips, mismatches_outside_band=outside, worst_action_err=worst)
     out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, "batch_parity_report.json"), "w") as fh:
+        with open(os.path.join(out_dir, "batch_parity_report.json" if B == 8 else f"batch{B}_parity_report.json"), "w") as fh:
             json.dump(rep, fh, indent=1)
     print(f"\n[env batch of {B}, {n} steps, full size] {compared} env-steps, exits {rep['exit_hist']}, knife-edge env-steps {knife} "
           f"(engine decided differently on {len(flips)}), outside the band {len(outside)}, worst |action - oracle| {worst:.2e}")

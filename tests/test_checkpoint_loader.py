@@ -171,6 +171,12 @@ def test_loader_reads_the_block_arithmetic_from_the_hf_config_json(tmp_path):
     for bad in ({"attn_clip_qkv": 6.0}, {"softmax_scale": 0.1}, {"prefix_lm": True}, {"no_bias": False}, {"alibi": False}):
         with pytest.raises(NotImplementedError):
             ck.apply_hf_mpt_config(base, {**MOSAIC_GPT_1B_CONFIG, **bad})
+    # a config.json that OMITS alibi / no_bias means the HF defaults (learned positions, biased Linears), not what this engine builds
+    for drop in ("alibi", "no_bias"):
+        with pytest.raises(NotImplementedError):
+            ck.apply_hf_mpt_config(base, {k: v for k, v in MOSAIC_GPT_1B_CONFIG.items() if k != drop})
+    with pytest.raises(NotImplementedError):
+        ck.apply_hf_mpt_config(deer_9b(), {**MPT_7B_CONFIG, "attn_config": {k: v for k, v in MPT_7B_CONFIG["attn_config"].items() if k != "alibi"}})
     with pytest.raises(NotImplementedError):
         ck.apply_hf_mpt_config(deer_9b(), {**MPT_7B_CONFIG, "norm_type": "rmsnorm"})
     with pytest.raises(ValueError):

@@ -157,6 +157,8 @@ def test_bench_with_eight_ranks_through_torch_distributed_run():
     assert out["backend"] == ("nccl" if real else "gloo")
     assert sorted(r["rank"] for r in out["ranks"]) == list(range(8))
     assert out["distinct_devices"] == (8 if real else 1)
+    pr = out["per_rank_steps_per_s"]                              # stragglers are visible in the line
+    assert 0 < pr["min"] <= pr["max"] and pr["slowest_over_fastest_time"] >= 1.0 and abs(pr["min"] * 8 - out["value"]) < 0.02 * out["value"] + 1
     assert abs(out["config"]["per_gpu_steps_per_s"] * 8 - out["value"]) < 0.05 * out["value"]
     from deer_vla_amd import distributed as dd2
     seqs = list(range(224))

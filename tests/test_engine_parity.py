@@ -419,7 +419,7 @@ def run_env_batch_against_independent_oracles(cfg, sd, eng, env_inputs, thr, sps
     return compared, flips, seen
 
 
-@pytest.mark.parametrize("B,sps", [(2, 1), (4, 1), (3, 2), (8, 1)])
+@pytest.mark.parametrize("B,sps", [(2, 1), (4, 1), (3, 2), (8, 1), (16, 1), (12, 2)])
 def test_batched_environments_match_independent_oracle_runs(B, sps):
     """n_envs environments per step (one env batch per rank): every environment must behave exactly like an
     independent single-environment run - its own exit layer (exact), action (1e-2), LSTM carry - while sharing the
@@ -631,7 +631,9 @@ def test_window_mode_calibration_full_size_batched_vs_oracle(max_layer):
 
 @pytest.mark.parametrize("B,lens,use_graph,exits", [(8, None, True, None), (8, None, False, None), (3, [14, 9, 11], True, None),
                                                    (8, [32, 14, 20, 9, 27, 16, 31, 11], True, None), (2, None, True, None),
-                                                   (8, None, True, [1, 2, 3, 4, 5]), (8, None, False, [1, 2, 3, 4, 5]), (4, [14, 9, 11, 20], True, [1, 2, 3, 4, 5])])
+                                                   (8, None, True, [1, 2, 3, 4, 5]), (8, None, False, [1, 2, 3, 4, 5]), (4, [14, 9, 11, 20], True, [1, 2, 3, 4, 5]),
+                                                   (16, None, True, None), (16, [32, 14, 20, 9, 27, 16, 31, 11, 12, 30, 10, 25, 13, 18, 22, 15], True, None),
+                                                   (13, None, False, [1, 2, 3, 4, 5])])
 def test_compaction_of_exited_environments_is_bit_identical_to_the_uncompacted_batch(B, lens, use_graph, exits):
     """SURVEY 8(f).4 / VERDICT r3 item 3a: in an env batch the rows of an environment that has exited leave the trunk two layers after its
     exit check (gathering first row operation + row map, csrc/model.hip).  No arithmetic depends on a row's position, so every
@@ -697,8 +699,9 @@ def test_compaction_of_exited_environments_is_bit_identical_to_the_uncompacted_b
 
 @pytest.mark.parametrize("size", ["tiny", "3b"])
 def test_one_launch_head_evaluation_matches_the_eight_launch_form(size):
-    """on control steps of one environment every head evaluation (pseudo action, exit checks) is ONE launch
-    (csrc/head.hip: head_fused_kernel - resident workgroups, the vectors between the phases as data-tagged granules).  Every row keeps
+    """on control steps of one environment every head evaluation (pseudo action, exit checks) CAN run as ONE launch
+    (csrc/head.hip: head_fused_kernel - resident workgroups, the vectors between the phases as data-tagged granules; off by default: it
+    measured slower than the eight launches, profiles/r05_e_*).  Every row keeps
     the arithmetic of the separate kernels (k split over the lanes, in-wave sums, one wave per LayerNorm row, head_final_body), so a
     dynamic episode with LSTM carry must give the same exit layers and - to the last bit, or within float rounding where hipcc
     contracts a product differently in the two instantiations - the same actions, deltas and LSTM state; eager and graph pieces; no
@@ -707,6 +710,7 @@ def test_one_launch_head_evaluation_matches_the_eight_launch_form(size):
     sd = syn.make_synthetic_state(cfg, 3, bf16_round=True) if size == "tiny" else full_size_state(cfg, 0, std="0.02", bf16_round=True)
     a = DeerEngine(cfg, sd)
     b = DeerEngine(cfg, None, weights_from=a)
+    a.set_head_fused(True)                                        # off by default since it measured slower
     b.set_head_fused(False)
     inputs = make_inputs(cfg, 10 if size == "tiny" else 6)
     thr, _ = probe_thresholds(cfg, sd, inputs, 12, iters=1)

@@ -57,6 +57,15 @@ def run(eng, label, n=12):
             us = timed(g) - (timed(gc) if cold else 0.0)
         print(f"{label:34s} {'cold weights' if cold else 'hot weights '}: {us:7.1f} us per evaluation", flush=True)
     assert eng.head_fused_error() == 0
+    if os.environ.get("DEER_HF_TRACE") == "1" and "launch" in label:
+        eng.enqueue_head(5, T, abi.KIND_CHECK, slot=2)
+        torch.cuda.synchronize()
+        t = eng._buf("head_fused_trace").view(torch.int64).cpu().tolist()
+        t = [v for v in t if v > 0]
+        names = ["start", "pool"] + [x for l in range(4) for x in (f"L{l} gathered", f"L{l} normalised", f"L{l} published")] + ["lstm end"] + \
+                [x for i in range(2) for x in (f"fc{i} published",)] + ["final gathered", "done"]
+        print("   phase time stamps of workgroup 0 (us since start; 100 MHz clock):")
+        print("   " + "  ".join(f"{names[i] if i < len(names) else i}={(v - t[0]) / 100.0:.1f}" for i, v in enumerate(t)))
 
 
 base = DeerEngine(cfg, sd)
@@ -65,4 +74,5 @@ run(base, "eight separate kernels")
 for w in wgs_list:
     os.environ["DEER_HEAD_WGS"] = str(w)
     e = DeerEngine(cfg, None, weights_from=base)
+    e.set_head_fused(True)
     run(e, f"one launch, {w} workgroups")

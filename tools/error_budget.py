@@ -1,22 +1,29 @@
 """Where the bf16 path's distance to the fp32 oracle comes from (full-size 3B model, static exit at the last layer, first step of an
 episode): the three coarse operators are fed either their own upstream result or the ORACLE's, so every stage's own contribution
-to the action error shows up alone.  usage: error_budget.py [n_steps]"""
+to the action error shows up alone.  usage: error_budget.py [n_steps] [3b|tiny] [easy|hard] [text_len]
+(hard: synthetic.harden_state - outlier channels, wide LayerNorm gains, x-attn gates near +-3, saturated LSTM biases: tests/test_hard_inputs.py)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from deer_vla_amd import synthetic as syn, ops
-from deer_vla_amd.config import deer_3b
+from deer_vla_amd.config import deer_3b, deer_tiny
 from oracle import deer_oracle as orc
 
 torch.set_num_threads(32)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-cfg = deer_3b(max_layer=12)
-sd = syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True)
+size = sys.argv[2] if len(sys.argv) > 2 else "3b"
+hard = len(sys.argv) > 3 and sys.argv[3] == "hard"
+TL = int(sys.argv[4]) if len(sys.argv) > 4 else 14
+cfg = deer_3b(max_layer=12) if size == "3b" else deer_tiny()
+sd = syn.make_synthetic_state(cfg, seed=0, std="0.02", bf16_round=True) if size == "3b" else syn.make_synthetic_state(cfg, 3, bf16_round=True)
+if hard:
+    sd = syn.harden_state(cfg, sd, seed=TL if size == "tiny" else 0)
+print(f"config {size}, {'hard' if hard else 'easy'} weights, {TL} text tokens")
 m = ops.NativeModel(cfg, sd)
 S, E = cfg.image_size, cfg.n_layers - 1
 rows = []
 for s in range(N):
-    rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, s)
+    rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, s, text_len=TL)
     rgb, grip = rgb.bfloat16().float(), grip.bfloat16().float()             # both arms see the same (bf16-exact) frames
     od = orc.OracleDeer(sd, cfg)
     od.set_all_exit_window_size(1)                                          # step mode (eval_utils.py:246)
