@@ -13,6 +13,8 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdeer_hip.so")
+if os.environ.get("DEER_HIP_LIB"):       # tools only (tools/ktrace_trunk.py: the same library built with phase time stamps, `make ktrace`)
+    LIB_PATH = os.path.join(_HERE, "lib", os.environ["DEER_HIP_LIB"])
 CSRC = os.path.join(_HERE, "csrc")
 
 P, I, L, F = c_void_p, c_int, c_long, c_float

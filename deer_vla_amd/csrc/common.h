@@ -146,6 +146,24 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 
 // Kernels on the early-exit path return at entry once the exit flag is set (device-side
 // termination: no host round trip per layer).
+// Phase time stamps (TOOLS ONLY: `make ktrace` builds lib/libdeer_hip_ktrace.so with -DDEER_KTRACE; the product library compiles
+// KT() to nothing).  Thread 0 of workgroup (0, 0) writes the 100 MHz real-time counter to slot `base + i` of a device array installed
+// with the translation unit's setter (KT_DEFINE(name) -> extern "C" deer_ktrace_set_<name>(ptr)); tools/ktrace_trunk.py reads them.
+#ifdef DEER_KTRACE
+#define KT_DEFINE(name)                                                                                       \
+  static __device__ long long* deer_ktrace_ptr_##name = nullptr;                                                     \
+  extern "C" int deer_ktrace_set_##name(long long* p) {                                                       \
+    return hipMemcpyToSymbol(HIP_SYMBOL(deer_ktrace_ptr_##name), &p, sizeof(p)) == hipSuccess ? DEER_OK : DEER_ERR_LAUNCH; \
+  }
+#define KT(name, first_wg, slot)                                                                                    \
+  do {                                                                                                        \
+    if ((first_wg) && threadIdx.x == 0 && deer_ktrace_ptr_##name != nullptr) deer_ktrace_ptr_##name[slot] = (long long)__builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define KT_DEFINE(name)
+#define KT(name, first_wg, slot) do { } while (0)
+#endif
+
 #define DEER_RETURN_IF_EXITED(ctl) \
   do {                             \
     if ((ctl) != nullptr && ((const volatile int*)(ctl))[CTL_ALL_EXITED] != 0) return; \

@@ -19,6 +19,7 @@
 // Activations enter every MFMA as bf16 hi + lo; all reductions are in a fixed order (bit-identical across
 // schedules and sibling engines).
 #include "common.h"
+#include <type_traits>
 #include <algorithm>
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -147,6 +148,17 @@ extern "C" int deer_trunk_wide_gemm(const void* a_hi, const void* a_lo, const vo
 // ---------------------------------------------------------------------------------------------------------------------------
 #define TM_MAXT 16
 #define TM_LDS_FLOATS (3 * TM_MAXT * 132 + TM_MAXT * (TM_MAXT + 1) + 2 * TM_MAXT * 2)
+#if defined(DEER_KTRACE) && !defined(DEER_BODIES_ONLY)
+KT_DEFINE(mpt_attn)
+#define MKT(slot) KT(mpt_attn, h == 0, slot)
+#else
+#define MKT(slot) do { } while (0)
+#endif
+// Round 5 (tools/ktrace_trunk.py: the five-barrier form spent 1.9 us on the moments, 1.9 on the q k v loads, 1.3 on the scores, 2.3
+// on the softmax and 2.8 on P V of a 10.2 us launch): the q k v pieces are REQUESTED before the moments are combined (one latency
+// instead of two), the moments are combined in one pass over registers, and a query row is ONE WAVE from scores to output - lane =
+// (key j = lane / 4, quarter of the head dimension): partial dot products meet by two xor-shuffles, the softmax runs over the 16
+// key groups by four more, P V takes the probabilities from lane registers (v_readlane) - two barriers instead of five.
 template <int NT>     // threads of the workgroup (256; 512 as a phase of the persistent layer)
 __device__ __forceinline__ void trunk_mpt_attn_body(const float* __restrict__ qkv, const float* __restrict__ stats, int d_model, int hd,
                                                     const float* __restrict__ q_ln_w, const float* __restrict__ k_ln_w, float eps,
@@ -156,34 +168,67 @@ __device__ __forceinline__ void trunk_mpt_attn_body(const float* __restrict__ qk
   float (*qs)[128 + 4] = reinterpret_cast<float (*)[128 + 4]>(lds);
   float (*ks)[128 + 4] = reinterpret_cast<float (*)[128 + 4]>(lds + TM_MAXT * 132);
   float (*vs)[128 + 4] = reinterpret_cast<float (*)[128 + 4]>(lds + 2 * TM_MAXT * 132);
-  float (*sim)[TM_MAXT + 1] = reinterpret_cast<float (*)[TM_MAXT + 1]>(lds + 3 * TM_MAXT * 132);
   float (*mom)[TM_MAXT][2] = reinterpret_cast<float (*)[TM_MAXT][2]>(lds + 3 * TM_MAXT * 132 + TM_MAXT * (TM_MAXT + 1));   // (mean, rstd) of the q / k row over d_model
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * d_model;
   const bool qk_ln = q_ln_w != nullptr;
+  MKT(8);
+  // ---- requests first: the first 8 moment groups of this thread (returned first: vmcnt counts in order), then this thread's float4
+  //      pieces of q | k | v of head h (T * hd / 4 <= 512 pieces) ----
+  const int st_which = (tid >> 7) & 1, st_r = (tid >> 3) & 15, st_part = tid & 7;
+  const int G = d_model >> 5, per = G >> 3;                     // launcher: d_model % 256 == 0
+  const float* sp = stats + (((long)st_which * G + st_part * per) * 16 + st_r) * 2;
+  float2 v[8];
+  if (qk_ln && tid < 256) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (u < per) ? *reinterpret_cast<const float2*>(sp + (long)u * 32) : float2{0.f, 0.f};
+  }
+  const int hd4 = hd >> 2;
+  constexpr int PIECES = (TM_MAXT * 32 + NT - 1) / NT;
+  float4 qr[PIECES], kr[PIECES], vr[PIECES], gq[PIECES], gk[PIECES];
+#pragma unroll
+  for (int u = 0; u < PIECES; ++u) {
+    const int idx = tid + u * NT;
+    if (idx < T * hd4) {
+      const int t = idx / hd4, dd = (idx - t * hd4) * 4;
+      const float* p = qkv + (long)t * ld + h * hd + dd;
+      qr[u] = *reinterpret_cast<const float4*>(p);
+      kr[u] = *reinterpret_cast<const float4*>(p + d_model);
+      vr[u] = *reinterpret_cast<const float4*>(p + 2 * d_model);
+      if (qk_ln) {
+        gq[u] = *reinterpret_cast<const float4*>(q_ln_w + h * hd + dd);
+        gk[u] = *reinterpret_cast<const float4*>(k_ln_w + h * hd + dd);
+      }
+    }
+  }
   if (qk_ln && tid < 256) {
     // 2 x 16 rows x G groups of 32 columns: thread (which, r, part) combines G/8 groups, the 8 parts of a row meet by xor-shuffles
     // (equal group sizes -> mean = average of the group means; M2 = sum of the group M2 + 32 * sum (group mean - mean)^2)
-    const int which = tid >> 7, r = (tid >> 3) & 15, part = tid & 7;
-    const int G = d_model >> 5, per = G >> 3;                   // launcher: d_model % 256 == 0
-    const float* sp = stats + (((long)which * G + part * per) * 16 + r) * 2;
+    const int which = st_which, r = st_r, part = st_part;
     float ms = 0.f, m2 = 0.f;
-    for (int j0 = 0; j0 < per; j0 += 8) {
-      float2 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (j0 + u < per) ? *reinterpret_cast<const float2*>(sp + (long)(j0 + u) * 32) : float2{0.f, 0.f};
+    for (int u = 0; u < 8; ++u) { ms += v[u].x; m2 += v[u].y; }
+    for (int j0 = 8; j0 < per; j0 += 8) {                       // d_model > 2048
+      float2 w[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { ms += v[u].x; m2 += v[u].y; }
+      for (int u = 0; u < 8; ++u) w[u] = (j0 + u < per) ? *reinterpret_cast<const float2*>(sp + (long)(j0 + u) * 32) : float2{0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { ms += w[u].x; m2 += w[u].y; }
     }
     ms += __shfl_xor(ms, 1, 64); ms += __shfl_xor(ms, 2, 64); ms += __shfl_xor(ms, 4, 64);
     const float mean = ms / (float)G;
     float dv = 0.f;
-    for (int j0 = 0; j0 < per; j0 += 8) {
-      float mg[8];
+    if (per <= 8) {                                             // the group means are still in registers (d_model <= 2048)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) mg[u] = (j0 + u < per) ? sp[(long)(j0 + u) * 32] : mean;
+      for (int u = 0; u < 8; ++u) dv += (u < per) ? (v[u].x - mean) * (v[u].x - mean) : 0.f;
+    } else {
+      for (int j0 = 0; j0 < per; j0 += 8) {
+        float mg[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) dv += (mg[u] - mean) * (mg[u] - mean);
+        for (int u = 0; u < 8; ++u) mg[u] = (j0 + u < per) ? sp[(long)(j0 + u) * 32] : mean;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dv += (mg[u] - mean) * (mg[u] - mean);
+      }
     }
     m2 += 32.f * dv;
     m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
@@ -193,65 +238,101 @@ __device__ __forceinline__ void trunk_mpt_attn_body(const float* __restrict__ qk
     }
   }
   __syncthreads();
-  const int hd4 = hd >> 2;
-  for (int idx = tid; idx < T * hd4; idx += NT) {
-    const int t = idx / hd4, dd = (idx - t * hd4) * 4;
-    const float* p = qkv + (long)t * ld + h * hd + dd;
-    float4 q = *reinterpret_cast<const float4*>(p);
-    float4 k = *reinterpret_cast<const float4*>(p + d_model);
-    if (qk_ln) {
-      const float4 gq = *reinterpret_cast<const float4*>(q_ln_w + h * hd + dd), gk = *reinterpret_cast<const float4*>(k_ln_w + h * hd + dd);
-      const float mq = mom[0][t][0], rq = mom[0][t][1], mk = mom[1][t][0], rk = mom[1][t][1];
-      q.x = (q.x - mq) * rq * gq.x; q.y = (q.y - mq) * rq * gq.y; q.z = (q.z - mq) * rq * gq.z; q.w = (q.w - mq) * rq * gq.w;
-      k.x = (k.x - mk) * rk * gk.x; k.y = (k.y - mk) * rk * gk.y; k.z = (k.z - mk) * rk * gk.z; k.w = (k.w - mk) * rk * gk.w;
+  MKT(9);
+#pragma unroll
+  for (int u = 0; u < PIECES; ++u) {
+    const int idx = tid + u * NT;
+    if (idx < T * hd4) {
+      const int t = idx / hd4, dd = (idx - t * hd4) * 4;
+      float4 q = qr[u], k = kr[u];
+      if (qk_ln) {
+        const float mq = mom[0][t][0], rq = mom[0][t][1], mk = mom[1][t][0], rk = mom[1][t][1];
+        q.x = (q.x - mq) * rq * gq[u].x; q.y = (q.y - mq) * rq * gq[u].y; q.z = (q.z - mq) * rq * gq[u].z; q.w = (q.w - mq) * rq * gq[u].w;
+        k.x = (k.x - mk) * rk * gk[u].x; k.y = (k.y - mk) * rk * gk[u].y; k.z = (k.z - mk) * rk * gk[u].z; k.w = (k.w - mk) * rk * gk[u].w;
+      }
+      *reinterpret_cast<float4*>(&qs[t][dd]) = q;
+      *reinterpret_cast<float4*>(&ks[t][dd]) = k;
+      *reinterpret_cast<float4*>(&vs[t][dd]) = vr[u];
     }
-    *reinterpret_cast<float4*>(&qs[t][dd]) = q;
-    *reinterpret_cast<float4*>(&ks[t][dd]) = k;
-    *reinterpret_cast<float4*>(&vs[t][dd]) = *reinterpret_cast<const float4*>(p + 2 * d_model);
   }
   __syncthreads();
+  MKT(10);
   const float sc = rsqrtf((float)hd);
   const float slope = exp2f(-alibi_slope_base * (float)(h + 1) / (float)n_heads);
-  for (int idx = tid; idx < T * T; idx += NT) {
-    const int i = idx / T, j = idx - i * T;
-    float a = 0.f;
-    if (j <= i)
-      for (int dd = 0; dd < hd; dd += 4) {
-        const float4 qv = *reinterpret_cast<const float4*>(&qs[i][dd]);
-        const float4 kv = *reinterpret_cast<const float4*>(&ks[j][dd]);
-        a += qv.x * kv.x + qv.y * kv.y + qv.z * kv.z + qv.w * kv.w;
+  const int j = lane >> 2, part = lane & 3;                    // key of this lane, quarter of the head dimension
+  auto rows = [&](auto hd_tag) {
+    constexpr int HDC = decltype(hd_tag)::value;                // 128: unrolled, unconditional LDS reads (stale rows are selected away); 0: any hd
+    const int qd = HDC ? HDC / 4 : hd >> 2;
+    const int d0 = part * qd;
+    for (int i = wave; i < T; i += NT / 64) {
+      float a = 0.f;
+      if (HDC) {
+        float4 qv[HDC ? HDC / 16 : 1], kv[HDC ? HDC / 16 : 1];
+#pragma unroll
+        for (int u = 0; u < HDC / 16; ++u) {
+          qv[u] = *reinterpret_cast<const float4*>(&qs[i][d0 + 4 * u]);
+          kv[u] = *reinterpret_cast<const float4*>(&ks[j][d0 + 4 * u]);
+        }
+#pragma unroll
+        for (int u = 0; u < HDC / 16; ++u) a += qv[u].x * kv[u].x + qv[u].y * kv[u].y + qv[u].z * kv[u].z + qv[u].w * kv[u].w;
+      } else if (j <= i) {
+        if ((qd & 3) == 0) {
+          for (int dd = 0; dd < qd; dd += 4) {
+            const float4 qv = *reinterpret_cast<const float4*>(&qs[i][d0 + dd]);
+            const float4 kv = *reinterpret_cast<const float4*>(&ks[j][d0 + dd]);
+            a += qv.x * kv.x + qv.y * kv.y + qv.z * kv.z + qv.w * kv.w;
+          }
+        } else {
+          for (int dd = 0; dd < qd; ++dd) a += qs[i][d0 + dd] * ks[j][d0 + dd];
+        }
       }
-    a = a * sc - (float)(T - 1 - j) * slope;
-    if (j > i || (key_mask != nullptr && key_mask[j] == 0)) a = -INFINITY;
-    sim[i][j] = a;
-  }
-  __syncthreads();
-  for (int i = wave; i < T; i += NT / 64) {
-    float v = (lane < T) ? sim[i][lane] : -INFINITY;
-    const float mx = wave_max(v);
-    const float p = (lane < T) ? expf(v - mx) : 0.f;
-    const float sum = wave_sum(p);
-    if (lane < T) sim[i][lane] = p / sum;
-  }
-  __syncthreads();
-  for (int idx = tid; idx < T * hd; idx += NT) {
-    const int t = idx / hd, dd = idx - t * hd;
-    float a = 0.f;
-    for (int j = 0; j <= t; ++j) a += sim[t][j] * vs[j][dd];
-    const bf16_t hi = f2bf(a);
-    out_hi[(long)t * ldo + h * hd + dd] = hi;
-    out_lo[(long)t * ldo + h * hd + dd] = f2bf(a - bf2f(hi));
-  }
+      if (j > i) a = 0.f;                                         // (stale LDS rows of the unrolled form)
+      a += __shfl_xor(a, 1, 64);
+      a += __shfl_xor(a, 2, 64);
+      a = a * sc - (float)(T - 1 - j) * slope;
+      if (j > i || (key_mask != nullptr && key_mask[min(j, T - 1)] == 0)) a = -INFINITY;
+      float mx = a;
+      mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float pr = (j <= i) ? expf(a - mx) : 0.f;
+      float sum = pr;
+      sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+      pr = pr / sum;
+      // P V: lane owns output columns 2 * lane, 2 * lane + 1 of the head; p_j from lane 4 j
+      const int dd = 2 * lane;
+      const bool col_ok = HDC ? true : dd < hd;
+      float o0 = 0.f, o1 = 0.f;
+      float2 vv[TM_MAXT];
+#pragma unroll
+      for (int jj = 0; jj < TM_MAXT; ++jj)
+        vv[jj] = (HDC || (jj <= i && col_ok)) ? *reinterpret_cast<const float2*>(&vs[jj][col_ok ? dd : 0]) : float2{0.f, 0.f};
+#pragma unroll
+      for (int jj = 0; jj < TM_MAXT; ++jj) {
+        const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr), jj * 4));
+        o0 += (jj <= i) ? pj * vv[jj].x : 0.f;
+        o1 += (jj <= i) ? pj * vv[jj].y : 0.f;
+      }
+      if (col_ok) {
+        const uint32_t hi2 = pack2bf(o0, o1);
+        const uint32_t lo2 = pack2bf(o0 - __uint_as_float(hi2 << 16), o1 - __uint_as_float(hi2 & 0xffff0000u));
+        *reinterpret_cast<uint32_t*>(out_hi + (long)i * ldo + h * hd + dd) = hi2;
+        *reinterpret_cast<uint32_t*>(out_lo + (long)i * ldo + h * hd + dd) = lo2;
+      }
+    }
+  };
+  if (hd == 128) rows(std::integral_constant<int, 128>{});
+  else rows(std::integral_constant<int, 0>{});
+  MKT(13);
 }
 
 #ifndef DEER_BODIES_ONLY
-__global__ __launch_bounds__(256) void trunk_mpt_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ stats, int d_model, int hd,
+__global__ __launch_bounds__(1024) void trunk_mpt_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ stats, int d_model, int hd,
                                                              const float* __restrict__ q_ln_w, const float* __restrict__ k_ln_w, float eps,
                                                              const unsigned char* __restrict__ key_mask, float alibi_slope_base, int n_heads,
                                                              bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo, int T, const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ __attribute__((aligned(16))) float lds[TM_LDS_FLOATS];
-  trunk_mpt_attn_body<256>(qkv, stats, d_model, hd, q_ln_w, k_ln_w, eps, key_mask, alibi_slope_base, n_heads, out_hi, out_lo, ldo, T, blockIdx.x, lds);
+  trunk_mpt_attn_body<1024>(qkv, stats, d_model, hd, q_ln_w, k_ln_w, eps, key_mask, alibi_slope_base, n_heads, out_hi, out_lo, ldo, T, blockIdx.x, lds);
 }
 
 extern "C" int deer_trunk_mpt_attn(const float* qkv, const float* stats, int d_model, int n_heads, const float* q_ln_w, const float* k_ln_w, float eps,
@@ -262,7 +343,7 @@ extern "C" int deer_trunk_mpt_attn(const float* qkv, const float* stats, int d_m
       out_lo == nullptr)
     return DEER_ERR_SHAPE;
   if ((q_ln_w == nullptr) != (k_ln_w == nullptr) || (q_ln_w != nullptr && stats == nullptr)) return DEER_ERR_SHAPE;
-  hipLaunchKernelGGL(trunk_mpt_attn_kernel, dim3(n_heads), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qkv, stats, d_model, hd, q_ln_w, k_ln_w,
+  hipLaunchKernelGGL(trunk_mpt_attn_kernel, dim3(n_heads), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), qkv, stats, d_model, hd, q_ln_w, k_ln_w,
                      eps, key_mask, alibi_bias_max, n_heads, reinterpret_cast<bf16_t*>(out_hi), reinterpret_cast<bf16_t*>(out_lo), ldo, T, ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;

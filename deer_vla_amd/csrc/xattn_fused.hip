@@ -19,6 +19,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define XF_HD 64
 #define XF_KP 72           // K rows: 64 + 8 bf16
 #define XF_MAXKV 128
+#if defined(DEER_KTRACE) && !defined(DEER_BODIES_ONLY)
+KT_DEFINE(xattn)
+#define XKT(slot) KT(xattn, bx == 0 && by == 0, slot)
+#else
+#define XKT(slot) do { } while (0)
+#endif
 
 // PACKED (one environment, <= 16 rows): the activation arrives as bf16 hi / lo planes in MFMA-fragment order (xn = hi plane, xlo = lo
 // plane; deer_resadd_ln_packed) - one coalesced 1 KiB read per k-tile and plane instead of 16 rows x 16 B per lane
@@ -45,7 +51,12 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int h = bx / NS, cs = bx - h * NS, b = by;
+  // NS < 0 (experiment, DEER_XF_MAP=1): the |NS| column shares of a head sit on ONE XCD (workgroup bx runs on XCD bx % 8: h = bx % heads),
+  // so that its L2 fetches the head's Wq once for all shares
+  const bool xmap = NS < 0;
+  if (xmap) NS = -NS;
+  const int h = xmap ? bx % heads : bx / NS, cs = xmap ? bx / heads : bx - h * NS, b = by;
+  XKT(0);
   const float* xb = xn + (long)b * T * d;
   const bf16_t* kvb = kv + (long)env * n_kv * ldkv + h * XF_HD;
   const int ktiles = d >> 5;
@@ -72,6 +83,7 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
     }
   }
 
+  XKT(1);
   // ---- q_h = xn Wq_h^T: the 8 waves split K (fragment kt = wave, wave + 8, ...), partial sums meet in LDS ----
   f32x4 acc[4][MT];
 #pragma unroll
@@ -90,7 +102,7 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
     for (int u = 0; u < XU; ++u) {                              // the weight fragments + the activation pieces in flight
       const int kt = min(kt0 + u * XF_NW, ktiles - 1);
 #pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) w[u][t4] = __builtin_nontemporal_load(wq + ((long)t4 * ktiles + kt) * 64);
+      for (int t4 = 0; t4 < 4; ++t4) w[u][t4] = xmap ? wq[((long)t4 * ktiles + kt) * 64] : __builtin_nontemporal_load(wq + ((long)t4 * ktiles + kt) * 64);
       if (PACKED) {
         ph[u] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(xn) + ((long)kt * 64 + lane) * 8);
         pl[u] = *reinterpret_cast<const bf16x8*>(xlo + ((long)kt * 64 + lane) * 8);
@@ -137,6 +149,7 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
       }
     }
   }
+  XKT(2);
   // lane holds q_partial[m = j*16 + c][n = t4*16 + g*4 .. +3]
 #pragma unroll
   for (int t4 = 0; t4 < 4; ++t4)
@@ -159,6 +172,7 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
     }
   }
   __syncthreads();
+  XKT(3);
   for (int idx = tid; idx < MPAD * XF_HD; idx += 64 * XF_NW) {          // q = sum over the 8 K-slices (fixed order), scaled, -> bf16
     float s = 0.f;
 #pragma unroll
@@ -166,6 +180,7 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
     qs[(idx >> 6) * XF_KP + (idx & 63)] = f2bf(s * scale);
   }
   __syncthreads();
+  XKT(4);
 
   // ---- attention of head h: wave j < MT owns query rows j*16 .. j*16+15 (swapped QK^T as in attention.hip) ----
   if (wave < MT) {
@@ -242,7 +257,9 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
                 pack2bf(v2 - __uint_as_float(h23 << 16), v3 - __uint_as_float(h23 & 0xffff0000u))};
     }
   }
+  XKT(5);
   __syncthreads();
+  XKT(6);
 
   // ---- y[:, cols of this workgroup] = o_h Wo[cols, h*64 .. h*64+63]^T : one f32 slab per head ----
   float* dst = out + (long)h * slab_stride + (long)b * T * d;
@@ -266,6 +283,7 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
       }
     }
   }
+  XKT(7);
 }
 
 template <int MT, bool PACKED = false>
@@ -324,6 +342,8 @@ static int launch_xattn_fused(const float* xn, const void* x_lo_packed, int d, c
   int NS = (tiles + 4 * XF_NW - 1) / (4 * XF_NW);              // <= 4 tiles per wave
   if (ns_mul > 1 && tiles % (NS * ns_mul * XF_NW) == 0) NS *= ns_mul;
   if (tiles % (NS * XF_NW) != 0) return DEER_ERR_SHAPE;
+  static const bool xf_map = [] { const char* e = getenv("DEER_XF_MAP"); return e != nullptr && e[0] == '1'; }();
+  const int ns_arg = (xf_map && heads == 8) ? -NS : NS;
   const int mt = (T + 15) >> 4;
   const int mpad = mt * 16;
   const int smem = XF_NW * mpad * XF_HD * 4 + (mpad * XF_KP + XF_MAXKV * XF_KP + XF_HD * (XF_MAXKV + 8) + 2 * mpad * XF_KP) * 2;
@@ -340,7 +360,7 @@ static int launch_xattn_fused(const float* xn, const void* x_lo_packed, int d, c
     }                                                                                                                           \
     hipLaunchKernelGGL(kern, grid, dim3(64 * XF_NW), smem, st, xn, d, reinterpret_cast<const bf16_t*>(Wq_p),                   \
                        reinterpret_cast<const bf16_t*>(kv), ldkv, inner, text_time, n_per_media, n_kv,                          \
-                       reinterpret_cast<const bf16_t*>(Wo_p), out, slab_stride, T, heads, NS, scale, ctl,                        \
+                       reinterpret_cast<const bf16_t*>(Wo_p), out, slab_stride, T, heads, ns_arg, scale, ctl,                    \
                        reinterpret_cast<const bf16_t*>(x_lo_packed), cmap);                                                     \
   } while (0)
   if (x_lo_packed != nullptr) DEER_XF_LAUNCH(1, true);

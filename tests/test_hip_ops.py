@@ -967,7 +967,7 @@ def test_xattn_fused_packed_matches_f32_operand_form(lib, T, d):
 
 
 @pytest.mark.parametrize("T", [1, 5, 14, 16])
-@pytest.mark.parametrize("d,heads", [(2048, 16), (256, 2)])
+@pytest.mark.parametrize("d,heads", [(2048, 16), (256, 2), (4096, 32), (256, 4), (768, 32)])   # head widths 128 (unrolled form) / 64 / 24; 16 moment groups per part at 4096
 @pytest.mark.parametrize("qk_ln,mask", [(True, False), (True, True), (False, False)])
 def test_trunk_mpt_attn(lib, T, d, heads, qk_ln, mask):
     """MPT attention on final q|k|v with the q/k LayerNorm over d_model reconstructed from 32-column moments (Chan's combination) -
