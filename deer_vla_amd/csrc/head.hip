@@ -16,6 +16,14 @@
 // Numerics: weights bf16 (streamed from HBM / Infinity Cache), activations, LSTM state, LayerNorm statistics
 // and the delta in fp32, so the exit decision differs from an fp32 reference only by summation order.
 #include "common.h"
+#ifdef DEER_KTRACE
+KT_DEFINE(head)
+#define HKT(slot) KT(head, b == 0, slot)
+#define LKT(slot) KT(head, blockIdx.x == 0, slot)
+#else
+#define HKT(slot) do { } while (0)
+#define LKT(slot) do { } while (0)
+#endif
 #include "../../include/deer_hip.h"
 
 #define HB_MAX 8   // environments per LAUNCH of the GEMV kernels (accumulator registers); batches of up to DEER_MAX_ENVS run in chunks
@@ -129,6 +137,47 @@ __device__ __forceinline__ void block_ln(const float* __restrict__ src, float* d
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     float y = (src[i] - mean) * rstd * w[i] + b[i];
     dst[i] = relu ? fmaxf(y, 0.f) : y;
+  }
+}
+
+// LayerNorm of ONE row of n <= 2048 values (n % 4 == 0) by ONE wave: the row lives in registers, no block barrier (head_final_body runs
+// the actions-head and the gripper-head LayerNorm side by side on two waves: 3.7 -> 1.2 us of every evaluation, tools/ktrace_head.py)
+__device__ __forceinline__ void wave_ln_row(const float* __restrict__ src, float* dst, int n, const float* __restrict__ w,
+                                            const float* __restrict__ bta, float eps, bool relu) {
+  const int lane = threadIdx.x & 63;
+  float4 v[8], gw[8], gb[8];
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int i = (lane + 64 * e) * 4;
+    v[e] = gw[e] = gb[e] = float4{0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+      v[e] = *reinterpret_cast<const float4*>(src + i);
+      gw[e] = *reinterpret_cast<const float4*>(w + i);
+      gb[e] = *reinterpret_cast<const float4*>(bta + i);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sum += v[e].x + v[e].y + v[e].z + v[e].w;
+  const float mean = wave_sum(sum) / n;
+  float var = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if ((lane + 64 * e) * 4 < n) {
+      const float a = v[e].x - mean, bq = v[e].y - mean, c = v[e].z - mean, dd = v[e].w - mean;
+      var += a * a + bq * bq + c * c + dd * dd;
+    }
+  const float rstd = rsqrtf(wave_sum(var) / n + eps);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int i = (lane + 64 * e) * 4;
+    if (i < n) {
+      float4 y;
+      y.x = (v[e].x - mean) * rstd * gw[e].x + gb[e].x; y.y = (v[e].y - mean) * rstd * gw[e].y + gb[e].y;
+      y.z = (v[e].z - mean) * rstd * gw[e].z + gb[e].z; y.w = (v[e].w - mean) * rstd * gw[e].w + gb[e].w;
+      if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+      *reinterpret_cast<float4*>(dst + i) = y;
+    }
   }
 }
 
@@ -347,6 +396,7 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
   if (ghh != nullptr) ghh += (long)b0 * 4 * H; else h_prev += (long)b0 * H;
   c_prev += (long)b0 * H; h_out += (long)b0 * H; c_out += (long)b0 * H;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  LKT(16);
   float* xs = lds;                    // [B][in_dim]
   float* hs = lds + B * in_dim;       // [B][H]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -356,6 +406,18 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
   // issued BEFORE the activations are staged (pool / LayerNorm / copy into LDS), so the HBM round trip overlaps the staging and
   // there is one exposed memory latency per launch instead of one per k-step.
   constexpr int LSTM_PF = 4;
+  // the gate constants of (environment = lane, unit j) - biases, the W_hh h term of the step, c - do not depend on the dot products:
+  // requested with the weights (they used to be a second L2 round trip behind the wave sums, 0.8 us of a 5.8 us launch)
+  float pgb[4] = {0.f, 0.f, 0.f, 0.f}, pgh[4] = {0.f, 0.f, 0.f, 0.f}, pc = 0.f;   // kept apart until the gates: an add here would wait for them
+  if (lane < B) {
+    const float* second = ghh != nullptr ? ghh + (long)lane * 4 * H : b_hh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      pgb[q] = b_ih[q * H + jr];
+      pgh[q] = second[q * H + jr];
+    }
+    pc = c_prev[lane * H + jr];
+  }
   typename W8<WT>::reg wi[LSTM_PF][4], wh[2][4];
 #pragma unroll
   for (int u = 0; u < LSTM_PF; ++u) {
@@ -371,6 +433,7 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
     for (int q = 0; q < 4; ++q)
       wh[u][q] = (ghh == nullptr && k < H) ? W8<WT>::load_stream(w_hh + ((long)q * H + jr) * H + k) : W8<WT>::zero();
   }
+  LKT(17);
   if (x_mode == X_LN || x_mode == X_RAW) {
     rows_to_lds(x_src, x_bstride, xs, in_dim, B, x_mode == X_LN, ln_w, ln_b, eps, false);
   } else {
@@ -391,6 +454,7 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
   }
   if (ghh == nullptr) block_copy_to_lds(h_prev, hs, B * H, false);
   __syncthreads();
+  LKT(18);
 
   if (j >= H) return;
   float acc[4][HB_MAX];
@@ -446,6 +510,7 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
       }
   }
   }
+  LKT(19);
   // wave totals land in every lane; lane b then does environment b's gate arithmetic (B transcendental chains in parallel)
   float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
 #pragma unroll
@@ -456,19 +521,12 @@ __global__ __launch_bounds__(256) void head_lstm_layer_kernel(const float* __res
     }
   if (lane < B) {
     const int b = lane;
-    if (ghh != nullptr) {
-      const float* gp = ghh + (long)b * 4 * H + j;
-      gi += b_ih[j] + gp[0]; gf += b_ih[H + j] + gp[H]; gg += b_ih[2 * H + j] + gp[2 * H]; go += b_ih[3 * H + j] + gp[3 * H];
-    } else {
-      gi += b_ih[j] + b_hh[j];
-      gf += b_ih[H + j] + b_hh[H + j];
-      gg += b_ih[2 * H + j] + b_hh[2 * H + j];
-      go += b_ih[3 * H + j] + b_hh[3 * H + j];
-    }
-    const float c2 = sigmoidf_(gf) * c_prev[b * H + j] + sigmoidf_(gi) * tanhf(gg);
+    gi += pgb[0] + pgh[0]; gf += pgb[1] + pgh[1]; gg += pgb[2] + pgh[2]; go += pgb[3] + pgh[3];
+    const float c2 = sigmoidf_(gf) * pc + sigmoidf_(gi) * tanhf(gg);
     c_out[b * H + j] = c2;
     h_out[b * H + j] = sigmoidf_(go) * tanhf(c2);
   }
+  LKT(20);
 }
 
 static int launch_head_lstm_layer(const float* x_src, long x_bstride, int x_mode, int T, int in_dim, const float* ln_w,
@@ -743,6 +801,7 @@ __device__ __forceinline__ void head_final_body(int b, const float* s0, const fl
     if (kind == KIND_CHECK && threadIdx.x == 0) check_done(ctl0, slot, B);
     return;
   }
+  HKT(0);
   int* ctl = (ctl0 != nullptr) ? ctl0 + b * CTL_WORDS : nullptr;
   if (ctl != nullptr) {
     // this environment already exited in this step, or (stage hold) does not need this evaluation
@@ -760,12 +819,31 @@ __device__ __forceinline__ void head_final_body(int b, const float* s0, const fl
     const int k = u * 512 + lane * 8;
     pw[u] = (wave < 7 && k < in_dim) ? W8<WT>::load(Wrow + k) : W8<WT>::zero();
   }
+  HKT(1);
   float* xa = lds;                    // actions-head input [in_dim]
   float* xg = lds + in_dim;           // gripper-head input [in_dim]
   float* red = xg + in_dim;           // [16]
   float* outv = red + 16;             // [64]: 7 A raw outputs (A = multi_step_action <= 8), then the A gripper logits
   int* flag = reinterpret_cast<int*>(outv + 64);
-  if (pro == PRO_GROUP_LN_RELU) {
+  // the control block of this environment and the threshold of this check: staged by the one wave with no output row (wave 7), so that
+  // thread 0's protocol section below reads LDS instead of walking a chain of dependent L2 round trips, and the host mirror leaves as
+  // ONE wave store of the staged block (it used to be 64 serial loads + stores to host memory: 7.3 us of every committing evaluation)
+  __shared__ int sctl[CTL_WORDS];
+  __shared__ float sthr;
+  __shared__ int sshadow;
+  if (wave == 7 && ctl != nullptr) {
+    sctl[lane] = ctl[lane];
+    if (lane == 0) {
+      sthr = (kind == KIND_CHECK && thresholds != nullptr && slot >= 0) ? thresholds[slot] : 0.f;
+      sshadow = ctl0[CTL_SHADOW];
+    }
+  }
+  float bias_w = 0.f;                                 // bias of this wave's output row, requested beside the weights
+  if (A == 1 && wave < 7 && lane == 0) bias_w = (wave < 6) ? ba[wave] : bg[0];
+  if (pro == PRO_GROUP_LN_RELU && in_dim <= 2048 && (in_dim & 3) == 0) {
+    if (wave == 0) wave_ln_row(s0, xa, in_dim, lnw0, lnb0, eps, true);
+    else if (wave == 1) wave_ln_row(s1, xg, in_dim, lnw1, lnb1, eps, true);
+  } else if (pro == PRO_GROUP_LN_RELU) {
     block_ln(s0, xa, in_dim, lnw0, lnb0, eps, true, red);
     block_ln(s1, xg, in_dim, lnw1, lnb1, eps, true, red);
   } else if (pro == PRO_LN) {
@@ -780,6 +858,7 @@ __device__ __forceinline__ void head_final_body(int b, const float* s0, const fl
   }
   if (threadIdx.x == 0) *flag = 0;
   __syncthreads();
+  HKT(2);
   if (wave < 7) {
     const float* x = (wave < 6) ? xa : xg;
     float a = 0.f;
@@ -790,7 +869,11 @@ __device__ __forceinline__ void head_final_body(int b, const float* s0, const fl
     }
     for (int k = 2 * 512 + lane * 8; k < in_dim; k += 512) a += W8<WT>::dot(W8<WT>::load(Wrow + k), x + k);
     a = wave_sum(a);
-    if (lane == 0 && A == 1) outv[wave] = a + ((wave < 6) ? ba[wave] : bg[0]);
+    if (lane == 0 && A == 1) {                         // every wave finishes its own output: tanh (pose) / logit + sigmoid (gripper) side by side
+      const float r = a + bias_w;
+      if (wave < 6) outv[wave] = tanhf(r);
+      else { outv[6] = sigmoidf_(r); outv[7] = r; }
+    }
   }
   if (A > 1) {
     // multi_step_action (action_head.py:472-473): 6 A pose rows of Wa then A gripper rows of Wg; wave w takes rows w, w + 8, ...
@@ -805,6 +888,7 @@ __device__ __forceinline__ void head_final_body(int b, const float* s0, const fl
     }
   }
   __syncthreads();
+  HKT(3);
   if (threadIdx.x == 0 && A > 1) {
     // ---- the same protocol as below over 7 A values; actions live in act_ext[b] = {previous | committed | ensemble}[64]; the first
     // executed action ([pose 0..5, gripper 0, logit 0]) is mirrored into the control block's 8-float fields ----
@@ -889,73 +973,92 @@ __device__ __forceinline__ void head_final_body(int b, const float* s0, const fl
     }
     *flag = commit ? 1 : 0;
   }
-  if (threadIdx.x == 0 && A == 1) {
-    float cur[8];
-    for (int i = 0; i < 6; ++i) cur[i] = tanhf(outv[i]);
-    cur[6] = sigmoidf_(outv[6]);
-    cur[7] = outv[6];                                  // gripper logit (MLPSigmoidHead with_logits)
-    if (action_dbg != nullptr)
-      for (int i = 0; i < 8; ++i) action_dbg[b * 64 + i] = cur[i];
-    bool commit = false;
-    if (ctl != nullptr) {
-      float* prev = reinterpret_cast<float*>(ctl + CTL_PREV_ACTION);
-      float* outa = reinterpret_cast<float*>(ctl + CTL_OUT_ACTION);
-      float* deltas = reinterpret_cast<float*>(ctl + CTL_DELTAS);
-      const bool hold = ctl[CTL_HOLD] != 0;
-      if (kind == KIND_PSEUDO) {
-        for (int i = 0; i < 8; ++i) prev[i] = cur[i];
-        ctl[CTL_PREV_REAL] = 0;                         // not a member of action_list (value_net.py:120-123)
-      } else if (kind == KIND_CHECK && !hold) {
-        float delta;                                    // value_net.py:105-117
-        if (thr_type == THR_COSINE) {
-          float na = 0.f, nb = 0.f, ab = 0.f;
-          for (int i = 0; i < 6; ++i) { na += cur[i] * cur[i]; nb += prev[i] * prev[i]; }
-          na = fmaxf(sqrtf(na), 1e-5f); nb = fmaxf(sqrtf(nb), 1e-5f);
-          for (int i = 0; i < 6; ++i) ab += (cur[i] / na) * (prev[i] / nb);
-          delta = 1.f - ab;
-        } else {
-          float acc = 0.f;
-          for (int i = 0; i < 6; ++i) {
-            const float d = fabsf(cur[i] - prev[i]);
-            if (thr_type == THR_L2) acc += d * d;
-            else if (thr_type == THR_MEAN) acc += d;
-            else acc = fmaxf(acc, d);
+  if (wave == 0 && A == 1) {
+    // ---- protocol section: lane 0 decides on the STAGED control block (every write goes to the device block and to the staged copy),
+    //      the wave then stores the staged block into the host mirror, lane 0 publishes ----
+    int commit_i = 0, mirror_i = 0;
+    if (lane == 0) {
+      float cur[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cur[i] = outv[i];      // tanh(pose 0..5), gripper prob, gripper logit (MLPSigmoidHead with_logits)
+      if (action_dbg != nullptr)
+        for (int i = 0; i < 8; ++i) action_dbg[b * 64 + i] = cur[i];
+      HKT(4);
+      bool commit = false;
+      if (ctl != nullptr) {
+        auto wi = [&](int idx, int v) { ctl[idx] = v; sctl[idx] = v; };
+        auto wf = [&](int idx, float v) { reinterpret_cast<float*>(ctl)[idx] = v; reinterpret_cast<float*>(sctl)[idx] = v; };
+        const float* sprev = reinterpret_cast<const float*>(sctl + CTL_PREV_ACTION);
+        const bool hold = sctl[CTL_HOLD] != 0;
+        if (kind == KIND_PSEUDO) {
+          for (int i = 0; i < 8; ++i) wf(CTL_PREV_ACTION + i, cur[i]);
+          wi(CTL_PREV_REAL, 0);                           // not a member of action_list (value_net.py:120-123)
+        } else if (kind == KIND_CHECK && !hold) {
+          float prev[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) prev[i] = sprev[i];
+          float delta;                                    // value_net.py:105-117
+          if (thr_type == THR_COSINE) {
+            float na = 0.f, nb = 0.f, ab = 0.f;
+            for (int i = 0; i < 6; ++i) { na += cur[i] * cur[i]; nb += prev[i] * prev[i]; }
+            na = fmaxf(sqrtf(na), 1e-5f); nb = fmaxf(sqrtf(nb), 1e-5f);
+            for (int i = 0; i < 6; ++i) ab += (cur[i] / na) * (prev[i] / nb);
+            delta = 1.f - ab;
+          } else {
+            float acc = 0.f;
+            for (int i = 0; i < 6; ++i) {
+              const float d = fabsf(cur[i] - prev[i]);
+              if (thr_type == THR_L2) acc += d * d;
+              else if (thr_type == THR_MEAN) acc += d;
+              else acc = fmaxf(acc, d);
+            }
+            delta = (thr_type == THR_L2) ? sqrtf(acc / 6.f) : (thr_type == THR_MEAN ? acc / 6.f : acc);
           }
-          delta = (thr_type == THR_L2) ? sqrtf(acc / 6.f) : (thr_type == THR_MEAN ? acc / 6.f : acc);
-        }
-        if (slot >= 0 && slot < 16) deltas[slot] = delta;
-        {                                               // get_ensemble_action(): mean over action_list[-2:] of this step (value_net.py:92-95)
-          float* ens = reinterpret_cast<float*>(ctl + CTL_ENS_ACTION);
-          const bool two = ctl[CTL_PREV_REAL] != 0;
-          for (int i = 0; i < 7; ++i) ens[i] = two ? 0.5f * (prev[i] + cur[i]) : cur[i];
-          ens[7] = two ? 2.f : 1.f;
-          ctl[CTL_PREV_REAL] = 1;
-        }
-        for (int i = 0; i < 8; ++i) prev[i] = cur[i];   // action_list.append(action)
-        const bool below = delta <= thresholds[slot];
-        if ((below == (leq != 0)) || force) {           // value_net.py:293
-          ctl[CTL_CUR_EXIT_ID] = layer;
+          if (slot >= 0 && slot < 16) wf(CTL_DELTAS + slot, delta);
+          {                                               // get_ensemble_action(): mean over action_list[-2:] of this step (value_net.py:92-95)
+            const bool two = sctl[CTL_PREV_REAL] != 0;
+            for (int i = 0; i < 7; ++i) wf(CTL_ENS_ACTION + i, two ? 0.5f * (prev[i] + cur[i]) : cur[i]);
+            wf(CTL_ENS_ACTION + 7, two ? 2.f : 1.f);
+            wi(CTL_PREV_REAL, 1);
+          }
+          for (int i = 0; i < 8; ++i) wf(CTL_PREV_ACTION + i, cur[i]);   // action_list.append(action)
+          const bool below = delta <= sthr;
+          if ((below == (leq != 0)) || force) {           // value_net.py:293
+            wi(CTL_CUR_EXIT_ID, layer);
+            commit = true;
+          }
+        } else {                                          // KIND_COMMIT, or CHECK while holding a stage
           commit = true;
         }
-      } else {                                          // KIND_COMMIT, or CHECK while holding a stage
-        commit = true;
-      }
-      ctl[CTL_N_EVALS] += 1;
-      if (commit && ctl0[CTL_SHADOW] != 0) {
-        // calibration: remember the FIRST exit that fires, keep evaluating the deeper exits (no EXIT_FLAG)
-        if (ctl[CTL_COMMITTED] != 0) commit = false;
-        else ctl[CTL_COMMITTED] = 1;
-        if (commit) {
-          for (int i = 0; i < 8; ++i) outa[i] = cur[i];
-          ctl[CTL_EXIT_LAYER] = layer;
+        HKT(5);
+        wi(CTL_N_EVALS, sctl[CTL_N_EVALS] + 1);
+        if (commit && sshadow != 0) {
+          // calibration: remember the FIRST exit that fires, keep evaluating the deeper exits (no EXIT_FLAG)
+          if (sctl[CTL_COMMITTED] != 0) commit = false;
+          else wi(CTL_COMMITTED, 1);
+          if (commit) {
+            for (int i = 0; i < 8; ++i) wf(CTL_OUT_ACTION + i, cur[i]);
+            wi(CTL_EXIT_LAYER, layer);
+          }
+        } else if (commit) {
+          for (int i = 0; i < 8; ++i) wf(CTL_OUT_ACTION + i, cur[i]);
+          wi(CTL_EXIT_LAYER, layer);                      // EXIT_LAYER before EXIT_FLAG (resadd_body.h: rowmap_dropped)
+          wi(CTL_EXIT_FLAG, 1);
+          mirror_i = host_mirror(ctl0) != nullptr ? 1 : 0;
         }
-      } else if (commit) {
-        for (int i = 0; i < 8; ++i) outa[i] = cur[i];
-        ctl[CTL_EXIT_LAYER] = layer;
-        ctl[CTL_EXIT_FLAG] = 1;
-        int* hm = host_mirror(ctl0);
-        if (hm != nullptr)                               // this environment's verdict, readable by the host right away
-          for (int i = 0; i < CTL_WORDS; ++i) hm[CTL_WORDS * (1 + b) + i] = ctl[i];
+      }
+      commit_i = commit ? 1 : 0;
+    }
+    mirror_i = __builtin_amdgcn_readfirstlane(mirror_i);
+    if (mirror_i) {
+      // this environment's verdict, readable by the host right away: the staged block as one wave store (lane 0's LDS writes above are
+      // in program order in front of these reads; the release stores of check_done / the system fence below wait for the wave's stores)
+      int* hmw = host_mirror(ctl0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      hmw[CTL_WORDS * (1 + b) + lane] = sctl[lane];
+    }
+    if (lane == 0) {
+      if (mirror_i || (commit_i && ctl != nullptr && sshadow == 0)) {
         // last environment of the batch to exit raises the batch-global flag (one workgroup per environment runs
         // concurrently, hence the device-scope atomic)
         if (B == 1) {
@@ -965,12 +1068,35 @@ __device__ __forceinline__ void head_final_body(int b, const float* s0, const fl
           if (atomicAdd(&ctl0[CTL_N_EXITED], 1) + 1 == B) ctl0[CTL_ALL_EXITED] = 1;
         }
       }
-      if (kind == KIND_CHECK) check_done(ctl0, slot, B);
+      HKT(6);
+      if (ctl != nullptr && kind == KIND_CHECK) check_done(ctl0, slot, B);
+      HKT(7);
+      *flag = commit_i;
     }
-    *flag = commit ? 1 : 0;
   }
   __syncthreads();
-  if (*flag && h_state != nullptr) {                    // DeterministicDecoder.hidden_state = h_n (action_head.py:555-556)
+  HKT(8);
+  if (!GRAN && *flag && h_state != nullptr && (H & 3) == 0) {   // DeterministicDecoder.hidden_state = h_n (action_head.py:555-556)
+    const int h4 = H >> 2, n4 = L * h4;                   // float4 pieces, two per thread in flight (L * H = 4096: 512 threads, one round)
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 2 * blockDim.x) {
+      float4 hv[2], cv[2];
+      long o[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = i0 + u * blockDim.x;
+        const int l = min(i, n4 - 1) / h4, q = min(i, n4 - 1) - l * h4;
+        o[u] = ((long)l * B + b) * H + (long)q * 4;
+        hv[u] = *reinterpret_cast<const float4*>(h_tmp + o[u]);
+        cv[u] = *reinterpret_cast<const float4*>(c_tmp + o[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (i0 + u * (int)blockDim.x < n4) {
+          *reinterpret_cast<float4*>(h_state + o[u]) = hv[u];
+          *reinterpret_cast<float4*>(c_state + o[u]) = cv[u];
+        }
+    }
+  } else if (*flag && h_state != nullptr) {
     for (int i = threadIdx.x; i < L * H; i += blockDim.x) {
       const int l = i / H, u = i - l * H;
       const long o = ((long)l * B + b) * H + u;
@@ -983,6 +1109,7 @@ __device__ __forceinline__ void head_final_body(int b, const float* s0, const fl
       }
     }
   }
+  HKT(9);
 }
 
 template <typename WT>
