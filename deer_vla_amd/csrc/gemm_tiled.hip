@@ -162,6 +162,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // of WAVES issuing loads on it (~8-9 GB/s per wave: 4 waves 8 TB/s chip-wide, 8 waves 16 TB/s, 16 waves 20 TB/s),
 // not by how many loads each wave keeps in flight - so these kernels run 8-16 waves per workgroup and are sized so
 // that two workgroups fit on a CU.
+#ifdef DEER_KTRACE
+KT_DEFINE(gemm)
+// the four ViT projections by shape: in_proj -> slots 0.., out_proj 8.., c_fc 16.., c_proj 24.. (stamps of workgroup (0, 0, 0))
+#define GKT(slot) KT(gemm, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && kt_base >= 0, kt_base + (slot))
+#else
+#define GKT(slot) do { } while (0)
+#endif
 template <int BM, int BN, int WM, int WN, int D, int DBG = 0, int U = 1, int PIPE = 0>   // DBG (ablation only): 1 = no MFMA/ds_read, 2 = no DMA in the loop
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
                                                                         const bf16_t* __restrict__ W, int ldw, long strideW,
@@ -170,6 +177,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
                                                                         int M, int N, int K, int epi,
                                                                         const float* __restrict__ gate, const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
+#ifdef DEER_KTRACE
+  const int kt_base = (N == 3072 && K == 1024) ? 0 : (N == 4096 && K == 1024) ? 16 : (N == 1024 && (int)gridDim.z * K == 1024) ? 8 : (N == 1024 && (int)gridDim.z * K == 4096) ? 24 : -1;
+#endif
+  GKT(0);
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;               // 16x16 MFMA tiles per wave
   constexpr int CH = (BM + BN) / 8;                                 // 1 KiB DMA chunks (8 rows x 128 B) per stage
@@ -267,9 +278,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
   constexpr int INFLIGHT = (U == 1) ? D - 1 : D - U;
 #pragma unroll
   for (int t = 0; t < INFLIGHT; ++t) issue(t);
+  // Round 5 (tools/ktrace_gemm.py, profiles/r05_i_*): one loop body (U K-steps) takes 0.6 us at M = 257 - not a memory round trip (touching
+  // the rest of both operand panels behind the prologue, so that every DMA hits this XCD's L2, left the loop at 5.1 us for K = 1024 and
+  // cost 3 us in front of it) but the CU's fill rate: 16 KB per K-step and workgroup, two workgroups per CU = 107 GB/s per CU.
+  GKT(1);
   for (int kt = 0; kt < nk; kt += U) {
     wait_vmcnt<(INFLIGHT - U) * CPW>();         // this wave's part of tiles kt .. kt+U-1 has landed
     __builtin_amdgcn_s_barrier();               // ... everybody's part; and everybody finished reading the tiles before kt
+    if (kt == 0) GKT(2);
+    if (kt == U) GKT(3);
     if (DBG != 2) {
 #pragma unroll
       for (int u = 0; u < U; ++u) issue(kt + INFLIGHT + u);   // refill the slots freed by the previous iteration
@@ -297,6 +314,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
 
   }
 
+  GKT(4);
   const float gs = (epi == EPI_RESADD_F32 && gate != nullptr) ? tanhf(*gate) : 1.f;
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
@@ -330,6 +348,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
       }
     }
   }
+  GKT(5);
 }
 
 template <int BM, int BN, int WM, int WN, int D, int DBG = 0, int U = 1, int PIPE = 0>
