@@ -368,6 +368,13 @@ static int launch_ring272(const bf16_t* A, int lda, long strideA, const bf16_t* 
 // TM = MFMA row tiles per wave: 4 = a whole frame per workgroup (16 + 1 row tiles); 2 = HALF a frame (8 + 1 row tiles: rows 0..128 of the
 // frame, the 129th being the dealt-out row tile, or rows 129..256 with no extra tile) - 32 half frames x 1024 / 128 = 256 workgroups for
 // the N = 1024 projections of 16 frames without splitting K.
+#ifdef DEER_KTRACE
+KT_DEFINE(frame)
+// by shape: in_proj -> slots 0.., c_fc 8.., c_proj halves 16.. (stamps of workgroup 0)
+#define FKT(slot) KT(frame, blockIdx.x == 0 && blockIdx.z == 0 && kt_base >= 0, kt_base + (slot))
+#else
+#define FKT(slot) do { } while (0)
+#endif
 template <int TM, int WN, int TN, int D>
 __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
                                                                const bf16_t* __restrict__ W, int ldw, long strideW,
@@ -375,6 +382,10 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
                                                                long strideC, int M, int N, int K, int epi, int tile_rows,
                                                                const float* __restrict__ gate, const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
+#ifdef DEER_KTRACE
+  const int kt_base = (N == 3072) ? 0 : (N == 4096) ? 8 : (N == 1024) ? 16 : -1;
+#endif
+  FKT(0);
   constexpr int NW = 4 * WN, BN = 16 * WN * TN, RT = 4 * TM, CH = RT + 1 + BN / 16, STAGE = CH * 1024;
   constexpr int CPW = (CH + NW - 1) / NW, N_HI = CH - (CPW - 1) * NW;
   static_assert(TN >= 1 && TN <= 4 && (WN == 2 || WN == 4) && (TM == 2 || TM == 4), "wave grid");
@@ -455,9 +466,12 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
     };
 #pragma unroll
     for (int t = 0; t < D - 1; ++t) issue(t);
+    FKT(1);
     for (int kt = 0; kt < nk; ++kt) {
       p8_wait_vmcnt<(D - 2) * CPWL>();
       __builtin_amdgcn_s_barrier();
+      if (kt == 0) FKT(2);
+      if (kt == 8) FKT(3);
       issue(kt + D - 1);
       const unsigned char* st = smem + (kt % D) * STAGE;
       bf16x8 af[TM], wf[TN], afx;
@@ -479,6 +493,7 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
   if (wave < N_HI) run(std::integral_constant<int, CPW>{});
   else run(std::integral_constant<int, CPW - 1>{});
 
+  FKT(4);
   const float gs = (epi == P8_EPI_RESADD_F32 && gate != nullptr) ? tanhf(*gate) : 1.f;
   const bool to_bf16 = epi == P8_EPI_BF16 || epi == P8_EPI_QGELU_BF16 || epi == P8_EPI_GELU_BF16;
   // bf16 outputs leave through LDS: the accumulator layout gives a lane 4 columns of ONE row (8 bytes; a wave store touches 16 rows,
@@ -531,6 +546,7 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
   }
   if (has_x) store(RT * 16 + c, (wn * TN + wm) * 16 + g * 4, accx);
   if (staged) BIGM_SYNC();
+  FKT(5);
   if (to_bf16) {
     constexpr int PPR = BN / 8;                               // 16-byte pieces per row
     const int pieces = rows_valid * PPR;
@@ -548,6 +564,7 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
       *reinterpret_cast<uint4*>(Cf + (long)r * ldc + cp * 4) = *reinterpret_cast<const uint4*>(smem + r * FPITCH + cp * 16);
     }
   }
+  FKT(6);
 }
 
 template <int TM, int WN, int TN, int D>
@@ -572,6 +589,195 @@ static int launch_frame(const bf16_t* A, int lda, long strideA, const bf16_t* W,
   const int tiles = row_tiles * (N / BN);
   hipLaunchKernelGGL(kern, dim3(tiles, 1, batch), dim3(WN * 256), smem_bytes, st, A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M,
                      N, K, epi, tile_rows, gate, ctl);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// frame8 (round 5; prototyped in round 3 as tools/frame8.hip): the frame tile on EIGHT waves.  The 16-wave kernel above spends as many
+// LDS cycles on fragment reads as its SIMDs spend on MFMAs (tools/ktrace_frame.py: 1.0 us per K-step of 32 against 0.52 us of MFMA
+// issue; 16 waves x 9 ds_read_b128 = 147 KB per K-step through a 128 B/clk LDS); 16 waves leave 128 VGPRs per wave, which excludes
+// bigger wave tiles.  Here 4 x 2 waves, wave tile 64 rows x (TN x 16) columns (BN = 32 TN: 256 or 192): 34 (26) MFMAs behind 13 (11)
+// fragment reads per K-step and wave instead of 17 behind 9, the reads running one W fragment ahead of the MFMAs
+// (sched_group_barrier), the LDS-DMA in its MUBUF form so that the compiler counts lgkmcnt for the fragment reads alone (32-bit byte
+// offsets: operands below 4 GiB).  The 17th MFMA row tile (the frame's 257th row) is dealt out XT 16 x 16 tiles per wave.  bf16
+// epilogues only (bias, QuickGELU / GELU), staged through LDS like the 16-wave kernel.
+__device__ __forceinline__ void f8_dma16(const void* base, unsigned voff, unsigned soff, void* lds) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000), (p8_lptr_t*)lds, 16, voff,
+                                           soff, 0, 0);
+}
+
+template <int TN, int D>
+__global__ __launch_bounds__(512) void gemm_frame8_kernel(const bf16_t* __restrict__ A, int lda, long strideA, const bf16_t* __restrict__ W,
+                                                           int ldw, long strideW, const float* __restrict__ bias, void* __restrict__ Cv, int ldc,
+                                                           long strideC, int M, int N, int K, int epi, const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
+  constexpr int NW = 8, BN = 32 * TN, CH = 17 + BN / 16, STAGE = CH * 1024, XT = BN / 16 / 8 + ((BN / 16) % 8 ? 1 : 0);
+  constexpr int CPW = (CH + NW - 1) / NW, N_HI = CH - (CPW - 1) * NW;
+  static_assert(D * STAGE <= 160 * 1024 && (D - 2) * CPW <= 63, "LDS / vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c = lane & 15, g = lane >> 4;
+  const int tiles_n = N / BN, rows_n = gridDim.x / tiles_n;
+  int rt, ct;
+  {                                                          // XCD blocks, as in gemm_frame_kernel
+    int gr = 0, gc = 0;
+    long best = 1L << 60;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r_ = 1 << e, c_ = 8 >> e;
+      if (rows_n % r_ == 0 && tiles_n % c_ == 0) {
+        const long cost = (long)(rows_n / r_) * 257 + (long)(tiles_n / c_) * BN;
+        if (cost < best) { best = cost; gr = r_; gc = c_; }
+      }
+    }
+    const int bid = blockIdx.x, nb = gridDim.x;
+    if (gr != 0) {
+      const int xcd = bid & 7, idx = bid >> 3, bc = tiles_n / gc, br = rows_n / gr;
+      rt = (xcd / gc) * br + idx / bc;
+      ct = (xcd % gc) * bc + idx % bc;
+    } else {
+      const int xq = nb >> 3, xr = nb & 7, xcd = bid & 7;
+      const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+      rt = tile / tiles_n;
+      ct = tile % tiles_n;
+    }
+  }
+  const int m0 = rt * 257, n0 = ct * BN;
+  const int rows_valid = min(257, M - m0);
+  A += (long)blockIdx.z * strideA;
+  W += (long)blockIdx.z * strideW;
+
+  const int lr = lane >> 2;
+  const int ls = ((lane & 3) ^ ((0x1320 >> (((lr >> 2) & 3) * 4)) & 3)) * 8;
+  const bf16_t* base[CPW];
+  unsigned vo[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int q = min(wave + i * NW, CH - 1);
+    const bool is_a = q < 17;
+    base[i] = is_a ? A : W;
+    vo[i] = is_a ? (unsigned)(((long)min(m0 + q * 16 + lr, M - 1) * lda + ls) * 2) : (unsigned)(((long)min(n0 + (q - 17) * 16 + lr, N - 1) * ldw + ls) * 2);
+  }
+  const int nk = K >> 5;
+  f32x4 acc[TN][4], accx[XT];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int x = 0; x < XT; ++x) accx[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr_sw = (g ^ ((0x1320 >> (((c >> 2) & 3) * 4)) & 3)) << 4;
+  const int a_off = (wm * 64 + c) * 64 + fr_sw;
+  const int x_off = (256 + c) * 64 + fr_sw;
+  const int w_off = 17 * 1024 + (wn * TN * 16 + c) * 64 + fr_sw;
+  // the dealt-out row tile: column tiles xi = wm * XT + x of this wave's column group (x < XT), if xi < TN
+  auto run = [&](auto cpw_tag) {
+    constexpr int CPWL = decltype(cpw_tag)::value;
+    auto issue = [&](int t) {
+      const int k0 = min(t, nk - 1) << 5;
+      unsigned char* st = smem + (t % D) * STAGE;
+#pragma unroll
+      for (int i = 0; i < CPWL; ++i) f8_dma16(base[i], vo[i], k0 * 2, st + (wave + i * NW) * 1024);
+    };
+#pragma unroll
+    for (int t = 0; t < D - 1; ++t) issue(t);
+    for (int kt = 0; kt < nk; ++kt) {
+      p8_wait_vmcnt<(D - 2) * CPWL>();
+      __builtin_amdgcn_s_barrier();
+      issue(kt + D - 1);
+      const unsigned char* st = smem + (kt % D) * STAGE;
+      bf16x8 af[4], wf[TN];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const bf16x8*>(st + a_off + j * 1024);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + w_off + i * 1024);
+      const bf16x8 afx = *reinterpret_cast<const bf16x8*>(st + x_off);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int x = 0; x < XT; ++x) {
+        bf16x8 wx = wf[0];
+#pragma unroll
+        for (int e = 1; e < TN; ++e) wx = (wm * XT + x == e) ? wf[e] : wx;
+        accx[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wx, afx, accx[x], 0, 0, 0);
+      }
+      // A fragments + the first TWO W fragments, then per W fragment: its 4 MFMAs, the read of the fragment after next (reads run one
+      // group of MFMAs ahead); the dealt-out tiles last
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // W fragment i+2 ... and finally the extra A fragment (no-op once exhausted)
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, XT, 0);
+    }
+    p8_wait_vmcnt<0>();
+  };
+  if (wave < N_HI) run(std::integral_constant<int, CPW>{});
+  else run(std::integral_constant<int, CPW - 1>{});
+
+  constexpr int CPITCH = BN * 2 + 16;
+  static_assert(272 * CPITCH <= 160 * 1024, "C staging");
+  auto put = [&](int r, int n, const f32x4& a) {               // row r of the frame, columns n0 + n .. n0 + n + 3
+    float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3];
+    if (bias != nullptr) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + n);
+      v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+    }
+    if (epi == P8_EPI_QGELU_BF16) {
+      v0 = quick_gelu_bf(v0); v1 = quick_gelu_bf(v1); v2 = quick_gelu_bf(v2); v3 = quick_gelu_bf(v3);
+    } else if (epi == P8_EPI_GELU_BF16) {
+      v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+    }
+    *reinterpret_cast<uint2*>(smem + r * CPITCH + n * 2) = uint2{pack2bf(v0, v1), pack2bf(v2, v3)};
+  };
+  BIGM_SYNC();                                                 // every wave has read its last fragments: the ring becomes the C tile
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = (wn * TN + i) * 16 + g * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) put(wm * 64 + j * 16 + c, n, acc[i][j]);
+  }
+#pragma unroll
+  for (int x = 0; x < XT; ++x) {
+    const int xi = wm * XT + x;
+    if (xi < TN) put(256 + c, (wn * TN + xi) * 16 + g * 4, accx[x]);
+  }
+  BIGM_SYNC();
+  constexpr int PPR = BN / 8;
+  const int pieces = rows_valid * PPR;
+  bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv) + (long)blockIdx.z * strideC + (long)m0 * ldc + n0;
+  for (int p = tid; p < pieces; p += 512) {
+    const int r = p / PPR, cp = p - r * PPR;
+    *reinterpret_cast<uint4*>(Cb + (long)r * ldc + cp * 8) = *reinterpret_cast<const uint4*>(smem + r * CPITCH + cp * 16);
+  }
+}
+
+template <int TN, int D>
+static int launch_frame8(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C, int ldc,
+                         long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl, hipStream_t st) {
+  constexpr int BN = 32 * TN;
+  const bool to_bf16 = epi == P8_EPI_BF16 || epi == P8_EPI_QGELU_BF16 || epi == P8_EPI_GELU_BF16;
+  if ((N % BN) || (K & 31) || M <= 0 || (M % 257) || batch <= 0 || !to_bf16) return DEER_ERR_SHAPE;
+  // MUBUF byte offsets are 32 bits: every operand (one batch slice) has to end below 4 GiB
+  if ((long)M * lda * 2 >= (1L << 32) || (long)N * ldw * 2 >= (1L << 32)) return DEER_ERR_SHAPE;
+  constexpr int ring_bytes = D * (17 + BN / 16) * 1024, c_bytes = 272 * (BN * 2 + 16);
+  constexpr int smem_bytes = ring_bytes > c_bytes ? ring_bytes : c_bytes;
+  static std::atomic<bool> attr_set{false};
+  auto kern = &gemm_frame8_kernel<TN, D>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
+      return DEER_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int tiles = (M / 257) * (N / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles, 1, batch), dim3(512), smem_bytes, st, A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, epi,
+                     ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
@@ -628,6 +834,8 @@ int deer_launch_gemm_ring32(int variant, const bf16_t* A, int lda, long strideA,
     // 50-55 us against 42.8 for the 257 x 128 tiles of the two K halves):
     case 21: return launch_frame<2, 4, 2, 5>(P8_ARGS);      // 129 | 128 x 128, 16 waves (32 x 32 wave tiles), 85 KB
     case 22: return launch_frame<2, 2, 4, 4>(P8_ARGS);      // 129 | 128 x 128, 8 waves (32 x 64 wave tiles), 68 KB
+    case 23: return launch_frame8<8, 4>(P8_ARGS);           // frame8: 257 x 256, 8 waves (64 x 128 wave tiles), 132 KB
+    case 24: return launch_frame8<6, 4>(P8_ARGS);           // frame8: 257 x 192, 8 waves (64 x 96 wave tiles), 116 KB
     default: return DEER_ERR_SHAPE;
   }
 #undef P8_ARGS

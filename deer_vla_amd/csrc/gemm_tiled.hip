@@ -438,8 +438,10 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
         const long wgs = frames * (N / bn) * batch;
         return (wgs >= 192 && wgs <= 256) || wgs == 512;
       };
-      if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16) && one_round(192)) tile = 64;
-      else if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16) && one_round(256)) tile = 63;
+      // DEER_GEMM_FRAME8=1: the same tiles on eight waves (csrc/gemm_bigm.hip: gemm_frame8_kernel)
+      static const bool frame8 = [] { const char* e = getenv("DEER_GEMM_FRAME8"); return e != nullptr && e[0] == '1'; }();
+      if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16) && one_round(192)) tile = frame8 ? 75 : 64;
+      else if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16) && one_round(256)) tile = frame8 ? 74 : 63;
       // ... and the K halves of c_proj (f32 slabs, N = 1024) as 257 x 128 tiles: 16 frames x 8 x 2 = 256 workgroups, 49.8 -> 43.1 us
       else if (sel256 && big_sel && (K & 31) == 0 && epi == EPI_F32 && one_round(128)) tile = 67;
       else if (sel256 && big_sel && (N & 255) == 0 && (K & 31) == 0 && n256 >= 192 && n256 <= 256) tile = 61;
@@ -507,6 +509,7 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59: case 60: case 61: case 62:            // 16 waves, 32-column K-steps, deep ring (csrc/gemm_bigm.hip)
     case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71:                                     // one camera frame per row tile, balanced (csrc/gemm_bigm.hip)
     case 72: case 73:                                                                                                    // half a frame per row tile
+    case 74: case 75:                                                                                                    // frame8: one frame per row tile on eight waves (round 5)
       return deer_launch_gemm_ring32(tile - 51, DEER_ARGS);
     case 26: return launch_ring<64, 64, 2, 4, 4, 0, 1, 1>(DEER_ARGS);    // register-pipelined K loop (fragments of k+1 read under the MFMAs of k)
     case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)

@@ -229,15 +229,17 @@ def test_skinny_hl_producers_and_exit_flag(lib):
 
 
 # ------------------------------------------------------------------------------------------- tiled GEMM
-@pytest.mark.parametrize("tile", [17, 39, 45, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 0])
+@pytest.mark.parametrize("tile", [17, 39, 45, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74, 75, 0])
 @pytest.mark.parametrize("M", [2056, 3084, 4112, 4096, 300])
 @pytest.mark.parametrize("N,K,epi", [(3072, 1024, "bf16"), (4096, 1024, "qgelu"), (1024, 1024, "f32"), (1024, 4096, "f32")])
 def test_gemm_tiled_big_m_tiles(lib, tile, M, N, K, epi):
     """The tiles `gemm_dispatch` auto-selects for an env batch / calibration window (M = 257 x 8 / 12 / 16 frames: 17 = 128x128 / 16
     waves, 39 = 192x128, 45 = 128x192) on the four ViT-L projection shapes, called directly AND through the selector (tile 0), against
     fp32 torch math; the ragged last row block (M % 128 = 8, 12, 16) and every epilogue the tower uses."""
-    if tile in (64, 65) and N % 192:
+    if tile in (64, 65, 75) and N % 192:
         pytest.skip("192-column frame tiles")
+    if tile in (74, 75) and (epi == "f32" or M % 257):
+        pytest.skip("frame8 tiles (eight waves, csrc/gemm_bigm.hip: gemm_frame8_kernel): whole camera frames, bf16 epilogues only")
     A = dev(rnd(M, K, seed=61), torch.bfloat16)
     W = dev(rnd(N, K, seed=62, scale=K ** -0.5), torch.bfloat16)
     bias = dev(rnd(N, seed=63, scale=0.1))
