@@ -1007,7 +1007,8 @@ Pending pending_of_down(const deer_model* m, int R) {
 bool r16_ok(const deer_model* m, int T) {
   static const bool on = [] { const char* e = getenv("DEER_TRUNK_R16"); return e == nullptr || e[0] != '0'; }();
   const deer_config& c = m->c;
-  return on && !c.precision && m->B == 1 && T <= 16 && (m->d == 2048 || m->d == 256) && block_hl(m, T) && (((long)c.xattn_ff_mult * m->d) & 63) == 0 &&
+  // d = 4096 (MPT-7B, round 5): no q/k LayerNorm there - the wide GEMM's 16-column form has no moments epilogue
+  return on && !c.precision && m->B == 1 && T <= 16 && (m->d == 2048 || m->d == 256 || (m->d == 4096 && !c.attn_qk_ln)) && block_hl(m, T) && (((long)c.xattn_ff_mult * m->d) & 63) == 0 &&
          (m->d & 127) == 0 && m->d / c.n_heads <= 128 && ((m->d / c.n_heads) & 3) == 0;
 }
 

@@ -29,23 +29,26 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 enum { TR_EPI_F32 = 0, TR_EPI_GELU_PLANES = 1, TR_EPI_F32_STATS = 2 };
 
-// workgroup = 32 output columns (2 MFMA column tiles), 8 waves x KS k-tiles of 32 (K = 256 * KS)
+// workgroup = 16 CT output columns (CT MFMA column tiles), 8 waves x KS k-tiles of 32 (K = 256 * KS): CT = 2 up to K = 2048, CT = 1 at
+// K = 4096 (MPT-7B, round 5: 16 k-tiles per wave - the weight + activation fragments of TWO column tiles would not fit the registers;
+// the workgroup streams the same 128 KB of weights either way)
 // (bodies are device functions taking the LOGICAL workgroup index: csrc/persistent_layer.hip runs them as phases of one launch)
-template <int KS, int EPI>
+template <int KS, int EPI, int CT = 2>
 __device__ __forceinline__ void trunk_wide_gemm_body(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo,
                                                      const bf16_t* __restrict__ Wp, float* __restrict__ out_f32,
                                                      bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo,
                                                      float* __restrict__ stats, int T, int bx, float* opart /* LDS: TR_NW * 16 * TR_OPITCH floats */) {
-  constexpr int KT = KS * TR_NW;
+  static_assert(CT == 2 || EPI != TR_EPI_F32_STATS, "the q/k LayerNorm moments are per 32 columns");
+  constexpr int KT = KS * TR_NW, NC = 16 * CT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int kt0 = wave * KS;                                   // this wave's k-tiles: kt0 .. kt0 + KS - 1
-  // every request of the wave is issued before anything is consumed: 2 KS weight fragments (HBM, non-temporal) + 2 KS activation
+  // every request of the wave is issued before anything is consumed: CT KS weight fragments (HBM, non-temporal) + 2 KS activation
   // fragments (L2) of 1 KiB each
-  u32x4 w[2][KS];
+  u32x4 w[CT][KS];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + ((long)(bx * 2 + t) * KT + kt0) * 64 + lane;
+  for (int t = 0; t < CT; ++t) {
+    const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + ((long)(bx * CT + t) * KT + kt0) * 64 + lane;
 #pragma unroll
     for (int s = 0; s < KS; ++s) w[t][s] = __builtin_nontemporal_load(wp + s * 64);
   }
@@ -55,26 +58,29 @@ __device__ __forceinline__ void trunk_wide_gemm_body(const bf16_t* __restrict__ 
     ah[s] = *reinterpret_cast<const bf16x8*>(Ahi + ((long)(kt0 + s) * 64 + lane) * 8);
     al[s] = *reinterpret_cast<const bf16x8*>(Alo + ((long)(kt0 + s) * 64 + lane) * 8);
   }
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int s = 0; s < KS; ++s)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < CT; ++t) {
       const bf16x8 wf = __builtin_bit_cast(bf16x8, w[t][s]);
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, ah[s], acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, al[s], acc[t], 0, 0, 0);
     }
   // K partials of the 8 waves -> LDS -> summed in wave order; lane holds out[m = c][n = 16 t + 4 g .. + 3]
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < CT; ++t)
     *reinterpret_cast<float4*>(opart + (wave * 16 + c) * TR_OPITCH + t * 16 + g * 4) = float4{acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
   __syncthreads();
-  const int m = tid >> 5, n = tid & 31;                          // one output element per thread: 16 rows x 32 columns
+  if (CT == 1 && tid >= 16 * NC) return;                         // 16 rows x 16 columns: the first 256 threads (no barrier follows)
+  const int m = CT == 2 ? tid >> 5 : tid >> 4, n = CT == 2 ? tid & 31 : tid & 15;   // one output element per thread: 16 rows x NC columns
   float v = 0.f;
 #pragma unroll
   for (int wv = 0; wv < TR_NW; ++wv) v += opart[(wv * 16 + m) * TR_OPITCH + n];
-  const int col = bx * 32 + n;
+  const int col = bx * NC + n;
   if (EPI == TR_EPI_GELU_PLANES) {
     v = gelu_erf(v);
     const float vn = __shfl_down(v, 1, 64);
@@ -98,27 +104,28 @@ __device__ __forceinline__ void trunk_wide_gemm_body(const bf16_t* __restrict__ 
   }
 }
 
-template <int KS, int EPI>
+template <int KS, int EPI, int CT = 2>
 __global__ __launch_bounds__(64 * TR_NW) void trunk_wide_gemm_kernel(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo,
                                                                     const bf16_t* __restrict__ Wp, float* __restrict__ out_f32,
                                                                     bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo,
                                                                     float* __restrict__ stats, int T, const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ __attribute__((aligned(16))) float opart[TR_NW * 16 * TR_OPITCH];
-  trunk_wide_gemm_body<KS, EPI>(Ahi, Alo, Wp, out_f32, out_hi, out_lo, ldo, stats, T, blockIdx.x, opart);
+  trunk_wide_gemm_body<KS, EPI, CT>(Ahi, Alo, Wp, out_f32, out_hi, out_lo, ldo, stats, T, blockIdx.x, opart);
 }
 
 #ifndef DEER_BODIES_ONLY
 // y = A W^T for the wide bias-free Linears at <= 16 rows.  a_hi / a_lo: the activation as bf16 planes in MFMA-fragment order
 // [K/32][64 lanes][8] (lane = 16 * (k % 32 / 8) + row; written by deer_resadd_ln_packed), Wp packed [N/16][K/32][64][8].
 // epi: 0 = out_f32 [T][ldo]; 1 = exact GELU -> ROW-MAJOR bf16 hi / lo planes [T][ldo]; 2 = out_f32 + stats [N/32][16][2] (mean, centred
-// sum of squares of the row over each 32-column group).  K = 256 or 2048.
+// sum of squares of the row over each 32-column group; not at K = 4096).  K = 256, 2048 or 4096.
 extern "C" int deer_trunk_wide_gemm(const void* a_hi, const void* a_lo, const void* Wp, int N, int K, int epi, float* out_f32, void* out_hi,
                                     void* out_lo, int ldo, float* stats, int T, const int* ctl, void* stream) {
   if (a_hi == nullptr || a_lo == nullptr || Wp == nullptr || T <= 0 || T > 16 || N <= 0 || (N & 31) || epi < 0 || epi > 2) return DEER_ERR_SHAPE;
   if (epi == TR_EPI_GELU_PLANES ? (out_hi == nullptr || out_lo == nullptr || (ldo & 1)) : out_f32 == nullptr) return DEER_ERR_SHAPE;
   if (epi == TR_EPI_F32_STATS && stats == nullptr) return DEER_ERR_SHAPE;
-  if (K != 256 && K != 2048) return DEER_ERR_SHAPE;
+  if (K != 256 && K != 2048 && K != 4096) return DEER_ERR_SHAPE;
+  if (K == 4096 && epi == TR_EPI_F32_STATS) return DEER_ERR_SHAPE;   // (MPT-7B has no q/k LayerNorm; the moments are per 32 columns)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bf16_t* ah = reinterpret_cast<const bf16_t*>(a_hi);
   const bf16_t* al = reinterpret_cast<const bf16_t*>(a_lo);
@@ -133,7 +140,10 @@ extern "C" int deer_trunk_wide_gemm(const void* a_hi, const void* a_lo, const vo
     else if (epi == 1) DEER_TWG(KS_, 1);      \
     else DEER_TWG(KS_, 2);                    \
   } while (0)
-  if (K == 2048) DEER_TWG_E(8); else DEER_TWG_E(1);
+  if (K == 4096) {                                            // 16 columns per workgroup
+    if (epi == 0) hipLaunchKernelGGL((trunk_wide_gemm_kernel<16, 0, 1>), dim3(N / 16), dim3(64 * TR_NW), 0, st, ah, al, wp, out_f32, oh, ol, ldo, stats, T, ctl);
+    else hipLaunchKernelGGL((trunk_wide_gemm_kernel<16, 1, 1>), dim3(N / 16), dim3(64 * TR_NW), 0, st, ah, al, wp, out_f32, oh, ol, ldo, stats, T, ctl);
+  } else if (K == 2048) DEER_TWG_E(8); else DEER_TWG_E(1);
 #undef DEER_TWG_E
 #undef DEER_TWG
   DEER_LAUNCH_CHECK();

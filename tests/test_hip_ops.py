@@ -883,12 +883,14 @@ def _pack_planes(a):
 
 
 @pytest.mark.parametrize("T", [1, 14, 16])
-@pytest.mark.parametrize("K,N", [(2048, 8192), (2048, 6144), (2048, 512), (256, 768), (256, 1024)])
+@pytest.mark.parametrize("K,N", [(2048, 8192), (2048, 6144), (2048, 512), (256, 768), (256, 1024), (4096, 12288), (4096, 16384), (4096, 1024)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_trunk_wide_gemm(lib, T, K, N, epi):
     """The wide Linears at <= 16 rows with the K split inside the workgroup (final results, no slabs): plain f32 / exact GELU -> bf16
     hi + lo planes / f32 + 32-column moments, against fp64 torch math on the same bf16 operands (hi + lo).  3e-5 relative (fp32
     accumulation order); GELU planes reproduce the f32 value to bf16^2; rows >= T are never written."""
+    if K == 4096 and epi == 2:
+        pytest.skip("K = 4096 (MPT-7B: 16 columns per workgroup) has no 32-column moments epilogue - MPT-7B has no q/k LayerNorm")
     A = dev(rnd(T, K, seed=3))
     W = dev(rnd(N, K, seed=7, scale=K ** -0.5), torch.bfloat16)
     Wp = _pack(lib, W)
@@ -918,7 +920,7 @@ def test_trunk_wide_gemm(lib, T, K, N, epi):
 
 
 @pytest.mark.parametrize("T", [1, 14, 16])
-@pytest.mark.parametrize("d", [256, 2048])
+@pytest.mark.parametrize("d", [256, 2048, 4096])
 def test_resadd_ln_packed_is_the_split_form_in_fragment_order(lib, T, d):
     """deer_resadd_ln_packed = deer_resadd_ln_split with the planes permuted into MFMA-fragment order: the residual stream is
     bit-identical; the LayerNorm output (hi + lo) agrees to fp32 rounding (the packed form reduces the row statistics over 512 threads
