@@ -885,6 +885,21 @@ def main():
             except Exception as e:
                 out["window"] = {"error": f"{type(e).__name__}: {e}"}
         rb["eng"] = None
+        rb = None
+        # the largest env batch one engine takes (round 5: 16 environments, 512 trunk rows): weights streamed once per 16
+        from deer_vla_amd import _abi as abi
+        if args.batched_envs < abi.MAX_ENVS and rank == 0 and world == 1 and args.precision == "bf16" and not args.no_two_groups:
+            try:
+                torch.cuda.empty_cache()
+                nb2 = max(nb // 2, 15)
+                r16 = run_workload(args, cfg, sd, abi.MAX_ENVS, rank, world, local_rank, dist, max_layer, nb2, max(args.warmup // 3, 5))
+                out["batched_max_envs"] = {"envs_per_gpu": abi.MAX_ENVS, "value": round(r16["value"], 2), "unit": "action-steps/s", "steps": nb2,
+                                           "ms_per_step": round(1e3 * r16["t_max"] / nb2, 4),
+                                           "ms_per_env_step": round(1e3 * r16["t_max"] / (nb2 * abi.MAX_ENVS), 4),
+                                           "avg_exit_layer": round(r16["avg_exit"], 3)}
+                r16["eng"] = None
+            except Exception as e:
+                out["batched_max_envs"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if not (args.no_cpu_baseline or world > 1):
             cb = cpu_baseline(cfg, sd, ctl, None, args.cpu_budget_s, args.cpu_threads, rank, full_protocol=args.cpu_full_protocol)

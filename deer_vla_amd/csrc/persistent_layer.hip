@@ -154,7 +154,7 @@ extern "C" int deer_trunk_layer_persistent(const deer_trunk_layer_args* a, void*
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // dynamic LDS: the largest phase - the slab GEMM's ring (4 stages x 24 KiB), the fused x-attn (75 KB), the wide GEMM's partials, the attention
   constexpr int smem = 4 * (4 * 2 + 16) * 1024;
-  static_assert(smem >= XF_NW * 16 * XF_HD * 4 + (16 * XF_KP + XF_MAXKV * XF_KP + XF_HD * (XF_MAXKV + 8) + 2 * 16 * XF_KP) * 2, "x-attn LDS");
+  static_assert(smem >= XF_NW * 16 * XF_HD * 4 + (16 * XF_KP + 2 * XF_MAXKV * XF_KP + 2 * 16 * XF_KP) * 2, "x-attn LDS");
   static_assert(smem >= TM_LDS_FLOATS * 4 && smem >= TR_NW * 16 * TR_OPITCH * 4, "LDS");
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {

@@ -14,6 +14,8 @@
 #include <cstdlib>
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) short xf_s16x4_t;
+typedef __attribute__((address_space(3))) xf_s16x4_t xf_lds_s16x4_t;
 
 #define XF_NW 8            // waves per workgroup
 #define XF_HD 64
@@ -44,10 +46,9 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
   float* red = reinterpret_cast<float*>(smem_raw);                                   // [NW][MPAD][64] f32 partial q
   bf16_t* qs = reinterpret_cast<bf16_t*>(red + XF_NW * MPAD * XF_HD);                // [MPAD][72] bf16 q (scaled)
   bf16_t* Ks = qs + MPAD * XF_KP;                                                    // [128][72]
-  bf16_t* Vt = Ks + XF_MAXKV * XF_KP;                                                // [64][128 + 8]
-  bf16_t* oh = Vt + XF_HD * (XF_MAXKV + 8);                                          // [MPAD][72] o hi
+  bf16_t* Vs = Ks + XF_MAXKV * XF_KP;                                                // [128][72] ROW-major (round 5): read transposed
+  bf16_t* oh = Vs + XF_MAXKV * XF_KP;                                                // [MPAD][72] o hi
   bf16_t* ol = oh + MPAD * XF_KP;                                                    // [MPAD][72] o lo
-  constexpr int vpitch = XF_MAXKV + 8;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -163,12 +164,9 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
     const int idx = tid + i * 512, row = idx >> 3, seg = idx & 7;
     if (row < XF_MAXKV) {
       *reinterpret_cast<uint4*>(Ks + row * XF_KP + seg * 8) = kreg[i];
-      const uint32_t v[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        Vt[(seg * 8 + 2 * e) * vpitch + row] = (bf16_t)(v[e] & 0xffffu);
-        Vt[(seg * 8 + 2 * e + 1) * vpitch + row] = (bf16_t)(v[e] >> 16);
-      }
+      // V stays row-major (one conflict-free 16-byte store; the transposing 2-byte stores of rounds 2-4 were eight-way bank-conflicted):
+      // the P V operand is fetched with ds_read_b64_tr_b16 like csrc/attention.hip::attn_vit_kernel
+      *reinterpret_cast<uint4*>(Vs + row * XF_KP + seg * 8) = vreg[i];
     }
   }
   __syncthreads();
@@ -229,6 +227,7 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    xf_lds_s16x4_t* vt = (xf_lds_s16x4_t*)(Vs + (g * 4 + (c >> 2)) * XF_KP + (c & 3) * 4);   // transpose-read base of this lane (generic -> LDS: C-style cast)
 #pragma unroll
     for (int ch = 0; ch < NT / 2; ++ch) {
       uint4 pw;
@@ -239,9 +238,11 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
       const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16_t* vp = Vt + (dt * 16 + c) * vpitch + ch * 32 + g * 4;
-        const uint2 lo2 = *reinterpret_cast<const uint2*>(vp);
-        const uint2 hi2 = *reinterpret_cast<const uint2*>(vp + 16);
+        // k-slot (g, j < 4) <-> key 32 ch + 4 g + j, (g, j >= 4) <-> key 32 ch + 16 + 4 g + (j - 4): a 16-lane group hands in the 16
+        // eight-byte pieces of a [4 keys][16 d] block, lane c receives column c (tools/tr_probe.hip)
+        const xf_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vt + ((ch * 32) * XF_KP + dt * 16) / 4);
+        const xf_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vt + ((ch * 32 + 16) * XF_KP + dt * 16) / 4);
+        const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
         const uint4 vw = uint4{lo2.x, lo2.y, hi2.x, hi2.y};
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[dt], 0, 0, 0);
       }
@@ -346,7 +347,7 @@ static int launch_xattn_fused(const float* xn, const void* x_lo_packed, int d, c
   const int ns_arg = (xf_map && heads == 8) ? -NS : NS;
   const int mt = (T + 15) >> 4;
   const int mpad = mt * 16;
-  const int smem = XF_NW * mpad * XF_HD * 4 + (mpad * XF_KP + XF_MAXKV * XF_KP + XF_HD * (XF_MAXKV + 8) + 2 * mpad * XF_KP) * 2;
+  const int smem = XF_NW * mpad * XF_HD * 4 + (mpad * XF_KP + 2 * XF_MAXKV * XF_KP + 2 * mpad * XF_KP) * 2;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(heads * NS, batch);
 #define DEER_XF_LAUNCH(MT_, PK_)                                                                                                \

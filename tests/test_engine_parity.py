@@ -419,7 +419,7 @@ def run_env_batch_against_independent_oracles(cfg, sd, eng, env_inputs, thr, sps
     return compared, flips, seen
 
 
-@pytest.mark.parametrize("B,sps", [(2, 1), (4, 1), (3, 2), (8, 1), (16, 1), (12, 2)])
+@pytest.mark.parametrize("B,sps", [(2, 1), (4, 1), (3, 2), (8, 1), (16, 2)])   # 12 / 13 environments: the compaction and batch-parity tests
 def test_batched_environments_match_independent_oracle_runs(B, sps):
     """n_envs environments per step (one env batch per rank): every environment must behave exactly like an
     independent single-environment run - its own exit layer (exact), action (1e-2), LSTM carry - while sharing the
