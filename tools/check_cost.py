@@ -32,6 +32,12 @@ def timed(fn):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
+# CHECK_COST_PRIO=1: the caller's stream (vision chain 0, the trunk) is a HIGH-priority stream; the engine's side stream (chain 1, head
+# evaluations) keeps the default priority
+if os.environ.get("CHECK_COST_PRIO") == "1":
+    _hp = torch.cuda.Stream(priority=-1)
+    torch.cuda.set_stream(_hp)
+    print("high-priority caller stream", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "")
 print(f"{'exit layer':>10s} {'static ms':>10s} {'dynamic ms':>11s} {'difference us':>14s}   (checks that ran before the firing one)")
 rows = []
 for k, layer in enumerate(exits):
