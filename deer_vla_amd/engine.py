@@ -490,11 +490,12 @@ class DeerEngine:
         self.enqueue_head(exit_id, T, abi.KIND_COMMIT, use_ctl=False, use_mask=use_mask and self.B > 1)
 
     def _drain_side_streams(self):
-        cur = None
+        # an unconditional stream-wait (event record + wait: ~6 us of host time, nothing on the device when the stream is idle);
+        # `if not st.query()` in front of it cost 27 us per call on this stack (hipStreamQuery) - 53 us of every step during which
+        # the GPU waited for the host (tools/host_gap.py, round 5)
+        cur = torch.cuda.current_stream()
         for st in (self._side_stream, *self._extra_streams):
-            if not st.query():                                    # usually idle: the verdict came from the last thing queued on it
-                cur = cur or torch.cuda.current_stream()
-                cur.wait_stream(st)
+            cur.wait_stream(st)
 
     def _chain_stream(self, c: int):
         """stream of vision chain c >= 2 (chain 0: caller's stream, chain 1: the side stream)"""

@@ -1,5 +1,7 @@
-"""Host-side share of a dynamic control step: time from step() entry to the first graph submission (the GPU is idle until then),
-and from the verdict to step() returning.  usage: host_gap.py"""
+"""Host-side share of a dynamic control step: the native step driver (csrc/step_driver.hip: deer_step_plan_run) blocks from the first
+graph submission to the verdict; whatever step() spends OUTSIDE it (draining the side streams, the D2D input staging, step bookkeeping,
+reading the result) is time the GPU waits for the host (the staging copies excepted).  Full 3B size, every step exits at the first check.
+usage: python tools/host_gap.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,27 +18,30 @@ rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, 0)
 rgb, grip, ids = rgb.cuda().bfloat16(), grip.cuda().bfloat16(), ids.cuda()
 for _ in range(5):
     eng.step(rgb, grip, ids, None)
-marks = {}
-orig = eng._replay_vision_chains
-def patched(*a, **k):
-    marks["submit"] = time.perf_counter()
-    return orig(*a, **k)
-eng._replay_vision_chains = patched
-N = 200
-pre = tot = 0.0
-t_prev_end = None
-gap = 0.0
+acc = {"native": 0.0, "load": 0.0, "read": 0.0}
+orig_run = eng.lib.deer_step_plan_run
+def run(*a):
+    t = time.perf_counter()
+    r = orig_run(*a)
+    acc["native"] += time.perf_counter() - t
+    return r
+class LibProxy:
+    def __init__(self, lib): self._lib = lib
+    def __getattr__(self, n): return run if n == "deer_step_plan_run" else getattr(self._lib, n)
+eng.lib = LibProxy(eng.lib)
+orig_load, orig_read = eng.load_inputs, eng.read_result
+def load(*a, **k):
+    t = time.perf_counter(); r = orig_load(*a, **k); acc["load"] += time.perf_counter() - t; return r
+def read(*a, **k):
+    t = time.perf_counter(); r = orig_read(*a, **k); acc["read"] += time.perf_counter() - t; return r
+eng.load_inputs, eng.read_result = load, read
+N = 300
 torch.cuda.synchronize()
-t_all = time.perf_counter()
-for i in range(N):
-    t0 = time.perf_counter()
-    r = eng.step(rgb, grip, ids, None)
-    t1 = time.perf_counter()
-    pre += marks.get("submit", t0) - t0
-    tot += t1 - t0
-    if t_prev_end is not None:
-        gap += t0 - t_prev_end
-    t_prev_end = t1
-t_all = time.perf_counter() - t_all
-print(f"exit layer {r['exit_layer']}: step() {1e6 * tot / N:.1f} us, of which before the first graph submission {1e6 * pre / N:.1f} us; "
-      f"loop overhead between steps {1e6 * gap / (N - 1):.1f} us; wall per step {1e6 * t_all / N:.1f} us")
+t0 = time.perf_counter()
+for _ in range(N):
+    eng.step(rgb, grip, ids, None)
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / N * 1e6
+nat, ld, rd = (acc[k] / N * 1e6 for k in ("native", "load", "read"))
+print(f"wall per step {wall:.1f} us; inside the native driver (first submission .. verdict) {nat:.1f} us; outside it {wall - nat:.1f} us "
+      f"(input staging calls {ld:.1f} us, result read {rd:.1f} us, the rest {wall - nat - ld - rd:.1f} us)")
