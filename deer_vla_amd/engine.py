@@ -163,6 +163,7 @@ class DeerEngine:
         # environment, 778 vs 862 at eight)
         self._one_graph = os.environ.get("DEER_ONE_GRAPH") == "1"
         self._side_stream = torch.cuda.Stream(device=self.dev)
+        self._drain_events: Dict[torch.cuda.Stream, torch.cuda.Event] = {}
         self._plans = []                                                   # native step plans (own HIP events): freed with the graphs
         self._native_step = os.environ.get("DEER_NATIVE_STEP", "1") == "1"   # 0: the Python submission / polling loop (debugging)
         self._extra_streams: List[torch.cuda.Stream] = []
@@ -494,8 +495,13 @@ class DeerEngine:
         # `if not st.query()` in front of it cost 27 us per call on this stack (hipStreamQuery) - 53 us of every step during which
         # the GPU waited for the host (tools/host_gap.py, round 5)
         cur = torch.cuda.current_stream()
+        evs = self._drain_events
         for st in (self._side_stream, *self._extra_streams):
-            cur.wait_stream(st)
+            ev = evs.get(st)
+            if ev is None:
+                ev = evs[st] = torch.cuda.Event()                 # one event per side stream, re-recorded every step
+            ev.record(st)
+            cur.wait_event(ev)
 
     def _chain_stream(self, c: int):
         """stream of vision chain c >= 2 (chain 0: caller's stream, chain 1: the side stream)"""
