@@ -1039,9 +1039,42 @@ class DeerEngine:
             hidden = hidden.unsqueeze(0)
         rl = torch.as_tensor(rand_layers).reshape(hidden.shape[0], -1)
         bs, W, L, T, d = hidden.shape
+        layers = [0] + list(self.exit_ids)
+        NL = len(layers)
+        NE = NL + 1
+        Gw = min(group, bs, abi.MAX_ENVS // NE, self.MAX_ROWS // (NE * T))
+        if Gw >= 1:
+            # Round 5: the NL candidate layers of a time step AND the history feature are the "environments" of ONE head evaluation
+            # (slot k < NL of a window: layer k's feature, slot NL: the random layer's; all from the same LSTM state, which every slot of
+            # the window holds) - 11 evaluations per window instead of 53 (one per time step instead of NL + 1), the weights read once each
+            w = self.sibling(Gw * NE)
+            Lh, H = w.h_state.shape[0], w.h_state.shape[-1]
+            per_window = []
+            for b0 in range(0, bs, Gw):
+                idx = [min(b0 + i, bs - 1) for i in range(Gw)]
+                hg = hidden[idx]                                                   # (Gw, W, L, T, d)
+                lay = torch.tensor([layers + [0]] * Gw)                            # (Gw, NE): the last slot is rewritten per time step
+                w.h_state.zero_()
+                w.c_state.zero_()
+                acts = []
+                gi = torch.arange(Gw).unsqueeze(1).expand(Gw, NE)
+                for t in range(W - 1):
+                    for g in range(Gw):
+                        lay[g, NL] = int(rl[idx[g], t])
+                    feats = hg[:, t][gi, lay]                                       # (Gw, NE, T, d)
+                    out = w._head_eval(feats.reshape(Gw * NE * T, d).contiguous(), commit=False).view(Gw, NE, -1)
+                    if t >= W // 2 - 1:
+                        acts.append(out[:, :NL].transpose(0, 1))                   # (NL, Gw, 8 A)
+                    # update_hidden_state=True for the history feature: its new state becomes the state of every slot of the window
+                    ht, ct = w.h_tmp.view(Lh, Gw, NE, H), w.c_tmp.view(Lh, Gw, NE, H)
+                    w.h_state.view(Lh, Gw, NE, H).copy_(ht[:, :, NL:NL + 1].expand(Lh, Gw, NE, H))
+                    w.c_state.view(Lh, Gw, NE, H).copy_(ct[:, :, NL:NL + 1].expand(Lh, Gw, NE, H))
+                    w._head_state_changed()
+                a = torch.stack(acts, dim=2)[..., :6 * self.A]                     # (NL, Gw, W/2, 6 A)
+                per_window.append(a[:, : min(Gw, bs - b0)])
+            return self._values_from_actions(torch.cat(per_window, dim=1).cpu(), threshold_type)
         G = max(1, min(group, self.MAX_ROWS // T, bs, abi.MAX_ENVS))
         w = self.sibling(G)
-        layers = [0] + list(self.exit_ids)
         per_window = []
         for b0 in range(0, bs, G):
             idx = [min(b0 + i, bs - 1) for i in range(G)]
@@ -1056,7 +1089,11 @@ class DeerEngine:
                 w._head_eval(sel.reshape(G * T, d).contiguous(), commit=True)
             a = torch.stack(acts, dim=2)[..., :6 * self.A]                     # (n_exit+1, G, W/2, 6 A): the delta runs over all pose values
             per_window.append(a[:, : min(G, bs - b0)])
-        a = torch.cat(per_window, dim=1).cpu()                                 # (n_exit+1, bs, W/2, 6)
+        return self._values_from_actions(torch.cat(per_window, dim=1).cpu(), threshold_type)
+
+    @staticmethod
+    def _values_from_actions(a: torch.Tensor, threshold_type: str) -> torch.Tensor:
+        """a: (n_exit+1, bs, W/2, 6 A) actions of layer 0 and of every exit -> deltas between consecutive exits (value_net.py:105-117,160)"""
         prev, last = a[:-1], a[1:]
         dlt = (prev - last).abs()
         if threshold_type == "mean":
