@@ -773,9 +773,24 @@ extern "C" int deer_head_fc(const float* src, int src_stride, int in_dim, int pr
   return DEER_OK;
 }
 
+// EXIT_FLAG of an environment, published BEHIND its EXIT_LAYER.  In an env batch the gather of a compaction layer (resadd_body.h) may
+// run beside this exit check and must never see FLAG = 1 together with a stale LAYER (its workgroups would build different packings):
+// agent-scope release in front of a relaxed agent-scope store of the flag, the reader loads the flags, fences (acquire) and then loads
+// the layers.  One environment: nothing reads the pair concurrently (no compaction) - plain store.
+__device__ __forceinline__ void publish_exit_flag(int* ctl, int B) {
+  if (B > 1) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the compiler may drop the wait behind the write-back (MI355X guide, G16)
+    __hip_atomic_store(ctl + CTL_EXIT_FLAG, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    ctl[CTL_EXIT_FLAG] = 1;
+  }
+}
+
 // ---- output Linear (6 tanh + 1 sigmoid) + exit gate, per environment ----------------------------------------------
 // One workgroup per environment.  src: [B][src_stride] (the last hidden Linear's output, [2][in_dim] per env).
-// ctl: env b at ctl + b*CTL_WORDS.  State tensors h/c: [L][B][H] (LH = L, sH = H).  action_dbg: [B][8] or NULL.
+// ctl: env b at ctl + b*CTL_WORDS.  State tensors h/c: [L][B][H] (LH = L, sH = H).  action_dbg: [B][64] f32 (64-float stride per
+// environment: pose 6 A | gripper prob A | logit A, A = multi_step_action) or NULL.
 // The work of one environment b as a device function of 512 threads: head_final_kernel runs it one workgroup per environment;
 // head_fused_kernel (below) runs it as the last phase of the one-launch evaluation, with the hidden Linear's output staged in LDS
 // (src0 / src1 then point into LDS) and the new LSTM state taken from the tagged exchange granules (GRAN) instead of h_tmp / c_tmp.
@@ -954,7 +969,7 @@ __device__ __forceinline__ void head_final_body(int b, const float* s0, const fl
         o8[7] = outv[NA];
         ctl[CTL_EXIT_LAYER] = layer;
         if (!shadow_on) {
-          ctl[CTL_EXIT_FLAG] = 1;
+          publish_exit_flag(ctl, B);                      // EXIT_LAYER ordered in front of EXIT_FLAG (resadd_body.h: rowmap_dropped_mask)
           int* hm = host_mirror(ctl0);
           if (hm != nullptr) {
             for (int i = 0; i < CTL_WORDS; ++i) hm[CTL_WORDS * (1 + b) + i] = ctl[i];
@@ -1042,8 +1057,9 @@ __device__ __forceinline__ void head_final_body(int b, const float* s0, const fl
           }
         } else if (commit) {
           for (int i = 0; i < 8; ++i) wf(CTL_OUT_ACTION + i, cur[i]);
-          wi(CTL_EXIT_LAYER, layer);                      // EXIT_LAYER before EXIT_FLAG (resadd_body.h: rowmap_dropped)
-          wi(CTL_EXIT_FLAG, 1);
+          wi(CTL_EXIT_LAYER, layer);                      // EXIT_LAYER ordered in front of EXIT_FLAG (resadd_body.h: rowmap_dropped_mask)
+          publish_exit_flag(ctl, B);
+          sctl[CTL_EXIT_FLAG] = 1;
           mirror_i = host_mirror(ctl0) != nullptr ? 1 : 0;
         }
       }

@@ -610,12 +610,16 @@ void build_workspace(deer_model* m) {
   m->hf_xg = named(m, "head_fused_xg", (size_t)deer_head_fused_granules(B, d, m->H, m->Lh, m->n_fc, m->fc_dims) * 8);
   m->hf_err = named(m, "head_fused_err", 256);
   m->hf_trace = named(m, "head_fused_trace", 64 * 8);
-  for (HeadW& h : m->lw) {                                             // per-layer heads: own LSTM state
-    h.h_state = m->wl.add(st);
-    h.c_state = m->wl.add(st);
-  }
-  if (!m->lw.empty()) {                                                // host view: [head][2 (h, c)][Lh][B][H], heads in registration order
-    m->ws_named["lw_state"] = {m->lw.front().h_state, 2 * ((st + 255) & ~size_t(255)) * m->lw.size()};
+  if (!m->lw.empty()) {                                                // per-layer heads: own LSTM state, ONE dense block
+    // host view: [head][2 (h, c)][Lh][B][H], heads in registration order (dense whatever st is: st is a multiple of 32 bytes, H % 8 == 0)
+    const size_t base = m->wl.add(2 * st * m->lw.size());
+    size_t k = 0;
+    for (HeadW& h : m->lw) {
+      h.h_state = base + (2 * k) * st;
+      h.c_state = base + (2 * k + 1) * st;
+      ++k;
+    }
+    m->ws_named["lw_state"] = {base, 2 * st * m->lw.size()};
   }
 }
 
@@ -929,7 +933,9 @@ struct RowCtx {
 };
 
 bool block_hl(const deer_model* m, int R);
-bool compact_on(const deer_model* m) { return m->compact && m->B > 1 && !m->c.precision; }
+// ... not with layerwise_exit_eval: the per-layer heads read hidden_states[layer] in ENVIRONMENT order after the step, when that layer's
+// row map has long been overwritten by later compaction layers - an ablation mode, not a throughput path
+bool compact_on(const deer_model* m) { return m->compact && m->B > 1 && !m->c.precision && !m->c.layerwise_exit_eval; }
 // ... on the hi/lo-plane path of BOTH halves of a layer (every K a multiple of 64)
 bool compact_active(const deer_model* m, int R) { return compact_on(m) && block_hl(m, R) && ((((long)m->c.xattn_ff_mult * m->d) & 63) == 0); }
 

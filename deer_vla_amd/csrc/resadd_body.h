@@ -11,7 +11,7 @@
 // Which environments leave is decided ONLY from verdicts the launch stream has ordered in front of this kernel: an
 // environment is dropped iff it exited at a layer <= `drop_upto` (= this layer - 2: the step driver makes the trunk wait for that check).
 // The check of layer - 1 may still be running beside this kernel and raise EXIT_FLAG while the workgroups read it (consecutive exit
-// layers, exit_interval = 1): head_final stores EXIT_LAYER (= layer - 1 > drop_upto) before EXIT_FLAG, so every workgroup sees either
+// layers): head_final publishes EXIT_LAYER (= layer - 1 > drop_upto) in front of EXIT_FLAG (release / acquire), so every workgroup sees either
 // "not exited" or "exited too late to drop" and all of them build the same packing; that environment leaves one compaction later.
 struct deer_rowmap {
   const int* cmap;          // map of this layer (gather mode: WRITTEN by workgroup 0)
@@ -23,11 +23,23 @@ struct deer_rowmap {
   int drop_upto;            // gather mode: deepest exit layer whose environments leave the packing
 };
 
-__device__ __forceinline__ bool rowmap_dropped(const deer_rowmap& rm, int e) {
-  const volatile int* c = (const volatile int*)rm.ctl0 + e * CTL_WORDS;
-  if (c[CTL_EXIT_FLAG] == 0) return false;
-  const int el = c[CTL_EXIT_LAYER];
-  return el >= 0 && el <= rm.drop_upto;
+// bit e: environment e leaves the packing.  The exit check of layer - 1 may publish its verdict while this runs: flags first (relaxed,
+// agent scope), ONE acquire fence, then the exit layers of the flagged environments - pairs with head.hip::publish_exit_flag, so a raised
+// flag always comes with its own EXIT_LAYER.  B <= 16.
+__device__ __forceinline__ unsigned rowmap_dropped_mask(const deer_rowmap& rm) {
+  int* c = const_cast<int*>(rm.ctl0);
+  unsigned flagged = 0;
+  for (int e = 0; e < rm.B; ++e)
+    if (__hip_atomic_load(c + e * CTL_WORDS + CTL_EXIT_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) flagged |= 1u << e;
+  if (flagged == 0) return 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  unsigned m = 0;
+  for (int e = 0; e < rm.B; ++e) {
+    if (!(flagged >> e & 1)) continue;
+    const int el = __hip_atomic_load(c + e * CTL_WORDS + CTL_EXIT_LAYER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (el >= 0 && el <= rm.drop_upto) m |= 1u << e;
+  }
+  return m;
 }
 
 // LayerNorm arithmetic shared by every row kernel (one row per workgroup here, R rows per workgroup in norm_embed.hip): every product and
@@ -69,10 +81,11 @@ __device__ __forceinline__ void resadd_ln_body(float* __restrict__ x, const floa
       if (threadIdx.x == 0) {
         const int slot = r / T, t = r - slot * T;
         const int n_old = rm.cmap_old[CMAP_N];
+        const unsigned gone = rowmap_dropped_mask(rm);
         int kept = 0, src = -1;
         for (int s = 0; s < n_old; ++s) {
           const int e = rm.cmap_old[CMAP_SLOT_ENV + s];
-          if (rowmap_dropped(rm, e)) continue;
+          if (gone >> e & 1) continue;
           if (kept == slot) src = s * T + t;
           if (r == 0) {                                    // workgroup 0 publishes the new map
             int* cm = const_cast<int*>(rm.cmap);
@@ -86,7 +99,7 @@ __device__ __forceinline__ void resadd_ln_body(float* __restrict__ x, const floa
           cm[CMAP_N] = kept;
           for (int s = 0; s < n_old; ++s) {
             const int e = rm.cmap_old[CMAP_SLOT_ENV + s];
-            if (rowmap_dropped(rm, e)) cm[CMAP_ENV_SLOT + e] = -1;
+            if (gone >> e & 1) cm[CMAP_ENV_SLOT + e] = -1;
           }
           for (int e = 0; e < rm.B; ++e)
             if (rm.cmap_old[CMAP_ENV_SLOT + e] < 0) cm[CMAP_ENV_SLOT + e] = -1;

@@ -619,6 +619,11 @@ class DeerEngine:
             self._shadow_on = bool(shadow)
         if exit_id is not None and exit_id < 0:
             exit_id += self.cfg.n_layers
+        if exit_id is None and self.exit_ids[0] == 0:
+            # exit_interval = 1 makes layer 0 an exit; the reference's ActionValueNet has no action to compare its action with and asserts
+            # (value_net.py:119, tests/golden/deer_forward_int1.npz) - the engine refuses instead of inventing a criterion
+            raise NotImplementedError("dynamic exit with layer 0 in the exit list: the first layer similarity is not implemented "
+                                      "(the reference asserts i > 0, value_net.py:119); use exit ids >= 1 or a static exit_id")
         hold = 0                                                  # bit b: environment b is inside a stage (csrc/head.hip: CTL_HOLD per environment)
         if exit_id is None and self.steps_per_stage != 1:
             steps = getattr(self, "_env_steps", None) or [self.cur_step] * self.B

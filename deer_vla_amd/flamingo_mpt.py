@@ -376,12 +376,14 @@ class MPTFlamingo(nn.Module):
         grip = torch.tensor([x[gk] for x in r]) if A == 1 else torch.stack([x[gk] for x in r])
         return torch.stack([x[pk] for x in r]), grip, exits
 
-    def _forward_window(self, vision_x, lang_x, attention_mask, vision_gripper, with_gripper_logits=False, generator=None):
+    def _forward_window(self, vision_x, lang_x, attention_mask, vision_gripper, with_gripper_logits=False, generator=None, rand_layers=None):
         """Window mode (flamingo_mpt.py:463-517 as ``generate_action_values`` calls it, value_net.py:375-385): the batch rows are
         bs * window_size frames (one instruction per row); every layer's hidden state is returned, the history fed to
         ``extra_exit`` comes from a random exit layer per (window, time step) ("sampling strategy 1", :485-497) and the head runs the
         windows as sequences from a zero state (action_head.py:588-595).  Returns (output, [], extra_exit_output,
-        rand_layer_feat, rand_layer_indices) like the reference with ``return_in_feat=True``.  The frames run as batch rows through
+        rand_layer_feat, rand_layer_indices) like the reference with ``return_in_feat=True``.  The head pools over ALL T rows of a
+        right-padded instruction like the reference's (no mask reaches ``DeterministicDecoder``, action_head.py:519-520;
+        tests/golden/deer_window_padded.npz).  The frames run as batch rows through
         the env-batch engine (``DeerEngine.window_hidden_states``), the windows as the environments of the head evaluations."""
         e, cfg = self.engine, self.cfg
         Wn = self.window_size
@@ -394,8 +396,12 @@ class MPTFlamingo(nn.Module):
                                      attention_mask.reshape(F, T).to(e.dev) if attention_mask is not None else None)     # (F, L, T, d)
         hidden = tuple(hid[:, l] for l in range(cfg.n_layers))
         exit_ids = self.get_all_exit_idx()
-        idx = torch.randint(0, len(exit_ids), (bs, Wn), generator=generator)                 # :485
-        rand_layers = torch.tensor([exit_ids[int(i)] for i in idx.reshape(-1)]).reshape(bs, Wn)
+        if rand_layers is None:
+            idx = torch.randint(0, len(exit_ids), (bs, Wn), generator=generator)             # :485
+            rand_layers = torch.tensor([exit_ids[int(i)] for i in idx.reshape(-1)]).reshape(bs, Wn)
+        else:                                             # the history layers of a recorded reference call (parity tests)
+            rand_layers = torch.as_tensor(rand_layers).reshape(bs, Wn).long().cpu()
+            assert all(int(v) in exit_ids for v in rand_layers.reshape(-1)), "rand_layers must be exit layers"
         rand_feat = hid[torch.arange(F, device=hid.device), rand_layers.reshape(-1).to(hid.device)]      # (F, T, d)
         # extra_exit on the random-layer features, windows as sequences from a zero LSTM state: groups of <= 8 windows per evaluation
         G = max(1, min(8, e.MAX_ROWS // T, bs))   # groups of <= 8 windows per head evaluation

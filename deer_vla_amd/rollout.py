@@ -384,6 +384,9 @@ class BatchedModelWrapper:
         assert m.n_envs > 1, "build the model with n_envs > 1 (create_model_and_transforms(..., n_envs=B))"
         if use_action_ensemble and (exit_controller is None or exit_id is not None):
             raise ValueError("use_action_ensemble needs the dynamic exit (eval_utils.py:457-461)")
+        if use_action_ensemble and m.act_step != 1:                # the same refusal as ModelWrapper
+            raise NotImplementedError("use_action_ensemble with multi-step action heads: the reference's harness takes the ensemble only "
+                                      "when act_step == 1 (eval_utils.py:456-461)")
         self.use_action_ensemble = bool(use_action_ensemble)
         self.model, self.B = model, m.n_envs
         self.cast_type = cast_dtype

@@ -171,7 +171,7 @@ class ExitController:
         native controller (it configures the device-side gate instead); a foreign LLM loop, ``lang_encoder(...)`` called directly
         with this controller, and the tests do."""
         assert self.thresholds is not None, "Please set thresholds before calling forward"
-        assert isinstance(i, int), "index muast be integer"
+        assert isinstance(i, int), f"the layer index must be an int, got {type(i).__name__}"
         if i not in self.exit_id_list:
             return False
         if self.cur_step % self.steps_per_stage != 0:            # still in a stage: reuse the previous exit id

@@ -326,6 +326,207 @@ def gen_deer_forward_variant(name, use_state=False, sep_resampler=False, layerwi
     save(name, cfg, seed, ids=ids, mask=mask, rgb=rgb, grip=grip, state=state, bf16_round=1, **outs)
 
 
+def gen_deer_forward_r6(name, cfg_kw=None, thr_types=("L2",), exit_id_list=None, n_steps=8):
+    """Round 6: the reference's own MPTFlamingo.forward for the head / criterion variants its constructors take and that only the CPU
+    oracle was pinned on so far: plain ``nn.LSTM`` + MLP heads without LayerNorm (action_head.py:72-79,86-116), ``pooling='avg'``
+    (:480-483) with three hidden layers, and one dynamic-exit episode (LSTM carried, ModelWrapper.step protocol) per ``threshold_type`` of
+    ``ActionValueNet.get_delta`` (value_net.py:105-117: mean / L2 / max / cosine).  ``exit_id_list``: the controller's exit list when it is
+    not the model's own (consecutive exits 1, 2, 3, 4: ``ExitController`` takes any list, value_net.py:164-173).  Thresholds sit in the
+    widest gap of each exit's never-exit deltas; recorded per type as ``<type>_*``."""
+    _dist_init()
+    cfg, seed = llm_cfg(**(cfg_kw or {})), 7
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
+    lm, mod = build_ref_lang_encoder(cfg, sd)
+    extend_instance(lm, FlamingoLMMixin)
+    lm.set_decoder_layers_attr_name("transformer.blocks")
+    venc_mod = nn.Module()
+    venc_mod.visual = _OracleVisual(cfg, sd)
+    model = MPTFlamingo(venc_mod, lm, cfg.eoc_token_id, cfg.media_token_id, vis_dim=cfg.vit_width,
+                        cross_attn_every_n_layers=cfg.cross_attn_every_n_layers, window_size=cfg.window_size,
+                        use_gripper=True, fusion_mode="post", llm="mpt_dolly_3b", pooling=cfg.pooling,
+                        early_exit_layer=cfg.early_exit_layer, multi_exit=False, exit_interval=cfg.exit_interval,
+                        mlp_layernorm=cfg.mlp_layernorm, lstm_layernorm=cfg.lstm_layernorm,
+                        mlp_num_hidden_layers=cfg.mlp_num_hidden_layers, lstm_num_layers=cfg.lstm_num_layers).eval()
+    assert model.get_all_exit_idx() == cfg.exit_ids()
+    sd_model = {k: v for k, v in sd.items() if not k.startswith("vision_encoder.")}
+    ref_keys = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    for k, v in sd_model.items():
+        assert k in ref_keys and ref_keys[k] == tuple(v.shape), (k, tuple(v.shape), ref_keys.get(k))
+    missing, unexpected = model.load_state_dict(sd_model, strict=False)
+    assert not unexpected, unexpected
+    assert not any(k.startswith("extra_exit.") for k in missing), missing
+    T, S = 8, cfg.image_size
+    ids = torch.tensor([[cfg.media_token_id, 5, 17, 3, 42, 8, cfg.eoc_token_id, 0]])
+    mask = torch.ones(1, T, dtype=torch.bool)
+    rgb = seeded("deer.rgb", (n_steps, 1, 1, 1, 3, S, S))
+    grip = seeded("deer.grip", (n_steps, 1, 1, 1, 3, S, S))
+    state = torch.zeros(1, 1, 1, 15)
+    model.set_all_exit_window_size(1)
+    outs = {}
+    for eid in (3, 4):                                       # static exits, LSTM carried over the steps
+        model.clear_all_exit_memory()
+        ps, gs = [], []
+        for s_ in range(n_steps):
+            o = model(vision_x=rgb[s_], lang_x=ids, attention_mask=mask, vision_gripper=grip[s_], state_tensor=state,
+                      return_feature=True, deterministic=True, exit_id=eid, dynamic_early_exit=False, exit_controller=None)
+            ps.append(o.logits[0])
+            gs.append(o.logits[1])
+        outs[f"static{eid}_pose"], outs[f"static{eid}_grip"] = torch.stack(ps), torch.stack(gs)
+    exit_ids = list(exit_id_list) if exit_id_list is not None else model.get_all_exit_idx()
+    for ttype in thr_types:
+        model.clear_all_exit_memory()
+        vn = _RecVN(exit_list=exit_ids, exit_head=model.extra_exit, interval=cfg.exit_interval, window_size=cfg.window_size,
+                    threshold_type=ttype)
+        ctl = ExitController(vn, exit_id_list=exit_ids, steps_per_stage=1, leq=True, exit_dist="exp", max_layer=12)
+        real = len([x for x in exit_ids if x <= ctl.max_layer])
+        ctl._set_threshold_value([-1.0] * real)              # never-exit pass (not recorded): the scale of every exit's deltas
+        for s_ in range(n_steps):
+            ctl.set_timestep(s_)
+            model(vision_x=rgb[s_], lang_x=ids, attention_mask=mask, vision_gripper=grip[s_], state_tensor=state, return_feature=True,
+                  deterministic=True, exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
+        thr = [gap_threshold([v for (i, v) in vn.rec if i == e], 0.2, 0.8) for e in exit_ids[:real]]
+        thr[-1] = 1e5
+
+        def episode(thr):
+            model.clear_all_exit_memory()
+            vn.reset_actions()
+            vn.rec = []
+            ctl._set_threshold_value(thr)
+            ex, ps, gs = [], [], []
+            for s_ in range(n_steps):
+                ctl.set_timestep(s_)
+                o = model(vision_x=rgb[s_], lang_x=ids, attention_mask=mask, vision_gripper=grip[s_], state_tensor=state, return_feature=True,
+                          deterministic=True, exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
+                ex.append(o.exit_layer)
+                ps.append(o.logits[0])
+                gs.append(o.logits[1])
+            thr_by = dict(zip(exit_ids, thr))
+            marg = min([abs(v - thr_by[i]) / thr_by[i] for (i, v) in vn.rec if thr_by[i] < 1e4] or [1.0])
+            return ex, ps, gs, list(vn.rec), marg
+
+        # on-policy refinement (the deltas an exit sees depend on where the earlier steps exited: the LSTM carries the history): re-pick
+        # every threshold in the widest gap of the deltas the policy visits, keep the set with the largest minimum margin
+        best = None
+        for _ in range(6):
+            ex, ps, gs, rec, marg = episode(thr)
+            if best is None or marg > best[0]:
+                best = (marg, list(thr))
+            if marg > 0.08:
+                break
+            new_thr = list(thr)
+            for k, e in enumerate(exit_ids[:real - 1]):
+                vals = [v for (i, v) in rec if i == e]
+                if len(vals) >= 4:
+                    new_thr[k] = gap_threshold(vals, 0.15, 0.85)
+            if new_thr == thr:
+                break
+            thr = new_thr
+        thr = best[1]
+        ex, ps, gs, rec, marg = episode(thr)
+        vn.rec = rec
+        print(f"  {name} {ttype}: exits={ex} thr={np.round(thr, 5).tolist()} min margin {marg:.3f}")
+        outs.update({f"{ttype}_thr": np.asarray(thr), f"{ttype}_exit": np.asarray(ex), f"{ttype}_pose": torch.stack(ps),
+                     f"{ttype}_grip": torch.stack(gs), f"{ttype}_rec_layer": np.asarray([i for i, _ in vn.rec]),
+                     f"{ttype}_rec_delta": np.asarray([v for _, v in vn.rec]), f"{ttype}_min_margin": marg})
+    save(name, cfg, seed, ids=ids, mask=mask, rgb=rgb, grip=grip, bf16_round=1, exit_ids=np.asarray(exit_ids),
+         thr_types=np.frombuffer(",".join(thr_types).encode(), dtype=np.uint8), **outs)
+
+
+def gen_exit_interval_1():
+    """exit_interval = 1 makes layer 0 an exit (flamingo_mpt.py:239-250): the reference's dynamic exit then fails in
+    ``ActionValueNet.forward`` (``assert i > 0, 'the first layer similarity is not implemented yet'``, value_net.py:119).  Pinned as data:
+    the exception type; static exits work."""
+    _dist_init()
+    cfg, seed = llm_cfg(exit_interval=1), 7
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
+    lm, mod = build_ref_lang_encoder(cfg, sd)
+    extend_instance(lm, FlamingoLMMixin)
+    lm.set_decoder_layers_attr_name("transformer.blocks")
+    venc_mod = nn.Module()
+    venc_mod.visual = _OracleVisual(cfg, sd)
+    model = MPTFlamingo(venc_mod, lm, cfg.eoc_token_id, cfg.media_token_id, vis_dim=cfg.vit_width,
+                        cross_attn_every_n_layers=cfg.cross_attn_every_n_layers, window_size=cfg.window_size,
+                        use_gripper=True, fusion_mode="post", llm="mpt_dolly_3b", pooling="max",
+                        early_exit_layer=cfg.early_exit_layer, multi_exit=False, exit_interval=1,
+                        mlp_layernorm=True, lstm_layernorm=True, mlp_num_hidden_layers=2, lstm_num_layers=4).eval()
+    assert model.get_all_exit_idx() == cfg.exit_ids() == [0, 1, 2, 3, 4]
+    model.load_state_dict({k: v for k, v in sd.items() if not k.startswith("vision_encoder.")}, strict=False)
+    S = cfg.image_size
+    ids = torch.tensor([[cfg.media_token_id, 5, 17, 3, 42, 8, cfg.eoc_token_id, 0]])
+    mask = torch.ones(1, 8, dtype=torch.bool)
+    rgb, grip = seeded("deer.rgb", (1, 1, 1, 1, 3, S, S)), seeded("deer.grip", (1, 1, 1, 1, 3, S, S))
+    model.set_all_exit_window_size(1)
+    vn = ActionValueNet(exit_list=model.get_all_exit_idx(), exit_head=model.extra_exit, interval=1, window_size=cfg.window_size, threshold_type="L2")
+    ctl = ExitController(vn, exit_id_list=model.get_all_exit_idx(), steps_per_stage=1, leq=True, exit_dist="exp", max_layer=12)
+    ctl._set_threshold_value([1e5] * 5)
+    ctl.set_timestep(0)
+    try:
+        model(vision_x=rgb[0], lang_x=ids, attention_mask=mask, vision_gripper=grip[0], state_tensor=torch.zeros(1, 1, 1, 15), return_feature=True,
+              deterministic=True, exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
+        raised = ""
+    except AssertionError as e:
+        raised = f"AssertionError: {e}"
+    model.clear_all_exit_memory()
+    o = model(vision_x=rgb[0], lang_x=ids, attention_mask=mask, vision_gripper=grip[0], state_tensor=torch.zeros(1, 1, 1, 15), return_feature=True,
+              deterministic=True, exit_id=0, dynamic_early_exit=False, exit_controller=None)
+    print(f"  exit_interval=1: dynamic exit raises {raised!r}; static exit 0 pose {o.logits[0].reshape(-1)[:3].tolist()}")
+    save("deer_forward_int1.npz", cfg, seed, ids=ids, mask=mask, rgb=rgb, grip=grip, bf16_round=1,
+         dynamic_raises=np.frombuffer(raised.encode(), dtype=np.uint8), static0_pose=o.logits[0], static0_grip=o.logits[1])
+
+
+def gen_window_padded(name="deer_window_padded.npz"):
+    """Window-mode calibration call of the reference (``generate_action_values``, value_net.py:333-386 -> MPTFlamingo.forward's all-exits
+    branch, flamingo_mpt.py:463-517) on a batch of windows whose instructions have DIFFERENT lengths, right-padded to the longest
+    (data.py:905-919 ``padding="longest"``) with the attention mask the tokenizer returns: the pad rows run through the trunk as queries
+    (the mask only removes them as attention keys), and ``DeterministicDecoder`` pools over ALL T rows, pad rows included
+    (action_head.py:519-520: no mask reaches the head).  Records every layer's hidden states, the random history layers the reference
+    drew, extra_exit's window outputs and ``ActionValueNet(mode='generate')`` deltas."""
+    _dist_init()
+    cfg, seed = llm_cfg(window_size=4), 7
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
+    model, lm = build_ref_mptflamingo(cfg, sd)
+    model.load_state_dict({k: v for k, v in sd.items() if not k.startswith("vision_encoder.")}, strict=False)
+    W, bs, S = cfg.window_size, 3, cfg.image_size
+    lens = [8, 5, 6]
+    T = max(lens)
+    body = [[5, 17, 3, 42, 8], [9, 33], [61, 7, 12]]
+    ids = torch.full((bs, T), 96, dtype=torch.long)                      # 96: the <PAD> id of this toy vocabulary
+    mask = torch.zeros(bs, T, dtype=torch.bool)
+    for b in range(bs):
+        row = [cfg.media_token_id] + body[b] + [cfg.eoc_token_id, 0]
+        assert len(row) == lens[b]
+        ids[b, :lens[b]] = torch.tensor(row)
+        mask[b, :lens[b]] = True
+    rgb = seeded("win.rgb", (bs, W, 3, S, S))
+    grip = seeded("win.grip", (bs, W, 3, S, S))
+    # generate_action_values' reshaping (value_net.py:333-372): (bs, W, ...) -> (bs*W, 1, 1, 3, S, S); ids / mask repeated per frame
+    images = rgb.unsqueeze(2).unsqueeze(2).flatten(0, 1)
+    gripper = grip.unsqueeze(2).unsqueeze(2).flatten(0, 1)
+    input_ids = ids.unsqueeze(1).repeat(1, W, 1).flatten(0, 1)
+    attention_mask = mask.unsqueeze(1).repeat(1, W, 1).flatten(0, 1)
+    torch.manual_seed(1234)
+    import random as _r
+    _r.seed(1234)
+    final_output, exit_outputs, extra, rand_feat, rand_idx = model(vision_x=images, lang_x=input_ids, attention_mask=attention_mask,
+                                                                   vision_gripper=gripper, state_tensor=None, with_gripper_logits=True,
+                                                                   return_in_feat=True, only_extra_exit=True)
+    feats = final_output.hidden_states
+    vn = ActionValueNet(exit_list=model.get_all_exit_idx(), exit_head=model.extra_exit, interval=cfg.exit_interval, window_size=W, threshold_type="L2")
+    delta = vn(feats, mode="generate", rand_layer_feat=rand_feat)
+    print(f"  {name}: hidden {len(feats)} x {tuple(feats[0].shape)}, rand layers {rand_idx.tolist()}, delta {tuple(delta.shape)}")
+    save(name, cfg, seed, ids=ids, mask=mask, rgb=rgb, grip=grip, hidden=torch.stack(feats), rand_layers=rand_idx, extra_pose=extra[0],
+         extra_grip=extra[1][0], extra_grip_logits=extra[1][1], delta=delta, lens=np.asarray(lens), bf16_round=1)
+
+
+def gen_round6_variants():
+    gen_deer_forward_r6("deer_forward_plain.npz", cfg_kw=dict(lstm_layernorm=False, mlp_layernorm=False), thr_types=("L2", "mean"))
+    gen_deer_forward_r6("deer_forward_avg3.npz", cfg_kw=dict(pooling="avg", mlp_num_hidden_layers=3), thr_types=("L2", "cosine"))
+    gen_deer_forward_r6("deer_forward_thr.npz", thr_types=("mean", "max", "cosine"))
+    gen_deer_forward_r6("deer_forward_consec.npz", thr_types=("L2", "max"), exit_id_list=[1, 2, 3, 4])
+    gen_exit_interval_1()
+    gen_window_padded()
+
+
 def gen_round5_variants():
     """layerwise_exit_eval and multi_step_action (round 5), each from the reference's own MPTFlamingo.forward"""
     gen_deer_forward_variant("deer_forward_lw.npz", layerwise=True)
@@ -469,6 +670,14 @@ def gen_thresholds():
                 ctl.set_threshold(args, None, None, ratio, model_name, values=values[:real].clone())
                 T = torch.stack([torch.as_tensor(ctl.thresholds[i]) for i in ctl.exit_id_list[:real]])
                 out[f"T_{model_name}_{ratio}_{max_layer}"] = T
+    # round 6: the other exit distributions / the ">= threshold" criterion of the same solver (value_net.py:214-231,248-258); for 'gauss'
+    # and 'gamma' ``exit_ratio`` is the centre / the shape parameter (eval_calvin.py passes it through unchanged)
+    for dist, leq, ratio, max_layer in (("gamma", True, 2.0, 12), ("gamma", True, 1.5, 8), ("gauss", True, 2.0, 12), ("gauss", True, 0.5, 8),
+                                        ("exp", False, 0.8, 12), ("gamma", False, 3.0, 12)):
+        ctl = ExitController(None, exit_id_list=cfg.exit_ids(), steps_per_stage=1, leq=leq, exit_dist=dist, max_layer=max_layer)
+        real = len([x for x in ctl.exit_id_list if x <= ctl.max_layer])
+        ctl.set_threshold(args, None, None, ratio, "mpt_dolly_3b", values=values[:real].clone())
+        out[f"D_{dist}_{int(leq)}_{ratio}_{max_layer}"] = torch.stack([torch.as_tensor(ctl.thresholds[i]) for i in ctl.exit_id_list[:real]])
     save("thresholds.npz", cfg, 0, **out)
 
 
@@ -869,5 +1078,6 @@ if __name__ == "__main__":
     gen_deer_forward_variant("deer_forward_state.npz", use_state=True)
     gen_deer_forward_variant("deer_forward_sep.npz", sep_resampler=True)
     gen_round5_variants()
+    gen_round6_variants()
     gen_hf_mpt_block()
     gen_hf_clip()

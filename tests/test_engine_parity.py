@@ -560,8 +560,9 @@ def _window_reference(cfg, sd, frames, W):
         hid = []
         for t in range(W):
             rgb, grip, ids_t, mask = fr[t]
-            h, _ = orc.llm_forward(sd, cfg, ids_t, mask, model.encode_vision(rgb, grip), exit_id=cfg.n_layers - 1)
+            h = model.forward(rgb, ids_t, mask, grip, exit_id=cfg.n_layers - 1)["hidden_states"]   # memoised per input (conftest.py)
             hid.append(torch.stack([x[0] for x in h]))
+        model.clear_all_exit_memory()
         out.append(torch.stack(hid))
     return torch.stack(out)
 
@@ -599,13 +600,20 @@ def test_window_mode_forward_frames_as_batch_rows_vs_oracle(tiny):
     assert len(o2) == 5 and len(o2[0].hidden_states) == cfg.n_layers and torch.equal(torch.stack(o2[0].hidden_states), torch.stack(out.hidden_states))
 
 
+_WINDOW_REF = {}
+
+
 @pytest.mark.parametrize("max_layer", [12, 4])
 def test_window_mode_calibration_full_size_batched_vs_oracle(max_layer):
     """the 12-frame history window as batch rows at FULL size (ViT at M = 8*514 rows, trunk at 112 rows):
     calibration deltas (value_net.py:134-160) of one 12-step window against the fp32 oracle.  max_layer = 4 is BASELINE configs[1]
     (DeeR-S, "12-step history": 5 layers built, exit ids {1, 3, 4})."""
     cfg = deer_3b(max_layer=max_layer)
-    sd = full_size_state(cfg, 0, std="0.02", bf16_round=True)
+    # one weight set for both cases: every tensor is seeded by its NAME (synthetic.make_synthetic_state), so the five-layer DeeR-S model
+    # is the first five layers of the twelve-layer one - and so are the oracle's hidden states, computed once for both
+    cfg12 = deer_3b(max_layer=12)
+    sd12 = full_size_state(cfg12, 0, std="0.02", bf16_round=True)
+    sd = {k: sd12[k] for k in syn.param_shapes(cfg)}
     eng = DeerEngine(cfg, sd)
     W = 12
     exit_ids = cfg.exit_ids()
@@ -615,7 +623,9 @@ def test_window_mode_calibration_full_size_batched_vs_oracle(max_layer):
     gripper = torch.stack([f[1].reshape(3, S, S) for f in frames[0]]).cuda().bfloat16()
     ids = frames[0][0][2].cuda()
     hid = eng.window_hidden_states(images, gripper, ids, None)                   # (W, L, T, d): two groups of 8 / 4 frames
-    ref = _window_reference(cfg, sd, frames, W)[0]
+    if "ref12" not in _WINDOW_REF:
+        _WINDOW_REF["ref12"] = _window_reference(cfg12, sd12, frames, W)[0]
+    ref = _WINDOW_REF["ref12"][:, :cfg.n_layers]
     for l in sorted({0, cfg.n_layers // 2, cfg.n_layers - 1}):
         assert float((hid[:, l].cpu() - ref[:, l]).norm() / ref[:, l].norm()) < 2e-2, l
     g = torch.Generator().manual_seed(4)

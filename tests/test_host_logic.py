@@ -17,6 +17,11 @@ def test_product_threshold_solver_matches_reference_goldens():
         assert torch.equal(T, g[key].float()), key
         ctl.set_threshold_from_values(values, float(ratio), model_name)
         assert ctl.threshold_list() == [float(x) for x in g[key]]
+    for key in [k for k in g if k.startswith("D_")]:       # round 6: 'gamma' / 'gauss' / the ">=" criterion (value_net.py:214-231,248-258)
+        _, dist, leq, ratio, max_layer = key.split("_")
+        ctl = vn.ExitController(None, cfg.exit_ids(), max_layer=int(max_layer), exit_dist=dist, leq=bool(int(leq)))
+        T = vn.solve_thresholds(values[: ctl.real_num_exit].clone(), ctl.real_num_exit, float(ratio), dist, bool(int(leq)))
+        assert torch.equal(T, g[key].float()), key
 
 
 def test_exit_structure_of_baseline_configs():

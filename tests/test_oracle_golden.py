@@ -142,6 +142,14 @@ def test_threshold_solver_matches_reference():
         assert float(T[-1]) == 1e8
     # mpt_9b disables the first exit (value_net.py:235-236): its threshold stays at -1e8
     assert float(g["T_mpt_9b_0.8_12"][0]) == -1e8
+    # round 6: exit_dist 'gamma' / 'gauss' and the ">= threshold" criterion (value_net.py:214-231,248-258)
+    d_keys = [k for k in g if k.startswith("D_")]
+    assert {k.split("_")[1] for k in d_keys} == {"gamma", "gauss", "exp"}
+    for key in d_keys:
+        _, dist, leq, ratio, max_layer = key.split("_")
+        ctl = orc.OracleExitController(None, cfg.exit_ids(), max_layer=int(max_layer), exit_dist=dist, leq=bool(int(leq)))
+        T = orc.solve_thresholds(values[: ctl.real_num_exit].clone(), ctl.real_num_exit, float(ratio), dist, bool(int(leq)))
+        close(T, g[key], rtol=0, atol=0)
 
 
 def test_multi_exit_loop_matches_reference_mosaic_gpt():
@@ -360,3 +368,138 @@ def test_forward_variants_match_reference_mptflamingo(name):
         assert o["exit_layer"] == int(g["dyn_exit"][s]), s
         close(o["logits"][0], g["dyn_pose"][s], atol=1e-5)
         close(o["logits"][1], g["dyn_grip"][s], atol=1e-5)
+
+
+R6_VARIANTS = ["deer_forward_plain.npz", "deer_forward_avg3.npz", "deer_forward_thr.npz", "deer_forward_consec.npz"]
+
+
+@pytest.mark.parametrize("name", R6_VARIANTS)
+def test_round6_head_and_criterion_variants_match_reference_mptflamingo(name):
+    """Round 6: plain ``nn.LSTM`` + MLP heads without LayerNorm (action_head.py:72-79,86-116), ``pooling='avg'`` with
+    three hidden layers (:480-483), every ``threshold_type`` of ``ActionValueNet.get_delta`` (value_net.py:105-117) and a controller over
+    CONSECUTIVE exit layers, each as static exits and as dynamic-exit episodes of the reference's own MPTFlamingo.forward."""
+    cfg, seed, g = load(name)
+    from deer_vla_amd import synthetic as syn
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=bool(int(g["bf16_round"])))
+    model = orc.OracleDeer(sd, cfg)
+    model.set_all_exit_window_size(1)
+    ids, mask, rgb, grip = g["ids"].long(), g["mask"].bool(), g["rgb"], g["grip"]
+    for eid in (3, 4):
+        model.clear_all_exit_memory()
+        for s in range(rgb.shape[0]):
+            o = model.forward(rgb[s], ids, mask, grip[s], exit_id=eid)
+            close(o["logits"][0], g[f"static{eid}_pose"][s], atol=1e-5)
+            close(o["logits"][1], g[f"static{eid}_grip"][s], atol=1e-5)
+    exit_ids = [int(v) for v in g["exit_ids"]]
+    for ttype in s2str(g["thr_types"]).split(","):
+        model.clear_all_exit_memory()
+        vn = orc.OracleValueNet(exit_ids, model.extra_exit, cfg.exit_interval, cfg.window_size, ttype)
+        ctl = orc.OracleExitController(vn, exit_ids, steps_per_stage=1, max_layer=12)
+        ctl._set_threshold_value([float(t) for t in g[ttype + "_thr"]])
+        for s in range(rgb.shape[0]):
+            ctl.set_timestep(s)
+            o = model.forward(rgb[s], ids, mask, grip[s], dynamic_early_exit=True, exit_controller=ctl)
+            assert o["exit_layer"] == int(g[ttype + "_exit"][s]), (ttype, s)
+            close(o["logits"][0], g[ttype + "_pose"][s], atol=1e-5)
+            close(o["logits"][1], g[ttype + "_grip"][s], atol=1e-5)
+        assert float(g[ttype + "_min_margin"]) > 0.05            # decisions far from the knife edge: exact exits are a fair demand of a bf16 path
+
+
+def test_exit_interval_one_is_rejected_like_the_reference():
+    """``exit_interval=1`` makes layer 0 an exit; the reference's dynamic exit then dies in ``ActionValueNet.forward`` (``assert i > 0``,
+    value_net.py:119) - recorded in the fixture; static exits (also exit 0) work."""
+    cfg, seed, g = load("deer_forward_int1.npz")
+    assert cfg.exit_ids()[0] == 0 and s2str(g["dynamic_raises"]).startswith("AssertionError")
+    from deer_vla_amd import synthetic as syn
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
+    model = orc.OracleDeer(sd, cfg)
+    model.set_all_exit_window_size(1)
+    ids, mask, rgb, grip = g["ids"].long(), g["mask"].bool(), g["rgb"], g["grip"]
+    vn = orc.OracleValueNet(cfg.exit_ids(), model.extra_exit, cfg.exit_interval, cfg.window_size, "L2")
+    ctl = orc.OracleExitController(vn, cfg.exit_ids(), max_layer=12)
+    ctl._set_threshold_value([1e5] * 5)
+    ctl.set_timestep(0)
+    with pytest.raises(AssertionError):
+        model.forward(rgb[0], ids, mask, grip[0], dynamic_early_exit=True, exit_controller=ctl)
+    model.clear_all_exit_memory()
+    o = model.forward(rgb[0], ids, mask, grip[0], exit_id=0)
+    close(o["logits"][0], g["static0_pose"], atol=1e-5)
+    close(o["logits"][1], g["static0_grip"], atol=1e-5)
+
+
+def test_window_mode_with_right_padded_instructions_matches_reference():
+    """The calibration call on a batch of windows with DIFFERENT instruction lengths (value_net.py:333-386, data.py:905-919
+    ``padding="longest"``): pad rows run through the trunk as queries and the head pools over all T rows, pad rows included
+    (action_head.py:519-520 - no mask reaches the head)."""
+    cfg, seed, g = load("deer_window_padded.npz")
+    from deer_vla_amd import synthetic as syn
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
+    model = orc.OracleDeer(sd, cfg)
+    W = cfg.window_size
+    ids, mask, rgb, grip = g["ids"].long(), g["mask"].bool(), g["rgb"], g["grip"]
+    bs, T = ids.shape
+    assert sorted(set(int(v) for v in g["lens"])) != [T]          # really mixed lengths
+    hid = []
+    for b in range(bs):
+        for t in range(W):
+            S = cfg.image_size
+            vis = model.encode_vision(rgb[b, t].view(1, 1, 1, 3, S, S), grip[b, t].view(1, 1, 1, 3, S, S))
+            h, _ = orc.llm_forward(sd, cfg, ids[b:b + 1], mask[b:b + 1], vis, exit_id=cfg.n_layers - 1)
+            hid.append(torch.stack([x[0] for x in h]))               # (L, T, d)
+    hid = torch.stack(hid, dim=1)                                    # (L, bs*W, T, d)
+    close(hid, g["hidden"], atol=2e-5)
+    rl = g["rand_layers"].reshape(-1)
+    rand_feat = torch.stack([hid[int(rl[j]), j] for j in range(bs * W)])
+    head = model.extra_exit
+    head.window_size = W
+    a, (gr, gl) = head(rand_feat, with_gripper_logits=True)
+    close(a, g["extra_pose"], atol=1e-5)
+    close(gr, g["extra_grip"], atol=1e-5)
+    close(gl, g["extra_grip_logits"], atol=2e-5)
+    vn = orc.OracleValueNet(cfg.exit_ids(), head, cfg.exit_interval, W, "L2")
+    delta = vn(tuple(hid[l] for l in range(cfg.n_layers)), mode="generate", rand_layer_feat=rand_feat)
+    assert float((delta - g["delta"]).abs().max()) < 1e-5
+    # the pool really sees the pad rows: with them masked out of the pool the window outputs differ
+    masked = rand_feat.clone()
+    for j in range(bs * W):
+        masked[j, int(g["lens"][j // W]):] = -1e9                    # max pool ignores them
+    a2, _ = head(masked, with_gripper_logits=True)
+    assert float((a2 - a).abs().max()) > 1e-4
+
+
+def test_trunk_memo_replays_the_lazy_exit_loop_bit_for_bit():
+    """OracleDeer.TRUNK_MEMO (test speed: full-depth hidden states of an input computed once, the exit loop replayed over them) gives the
+    same exit layers, the same number of hidden states and the same bits as the lazy loop - dynamic episodes with LSTM carry run twice and
+    static exits (also a negative exit_id)."""
+    from deer_vla_amd import synthetic as syn
+    from deer_vla_amd.config import deer_tiny
+    cfg = deer_tiny()
+    sd = syn.make_synthetic_state(cfg, 3, bf16_round=True)
+    inputs = [syn.synthetic_step_inputs(cfg, s, text_len=11) for s in range(5)]
+
+    def run(memo):
+        orc.OracleDeer.TRUNK_MEMO = {} if memo else None
+        try:
+            m = orc.OracleDeer(sd, cfg)
+            m.set_all_exit_window_size(1)
+            vn = orc.OracleValueNet(cfg.exit_ids(), m.extra_exit, cfg.exit_interval, 1, "L2")
+            ctl = orc.OracleExitController(vn, cfg.exit_ids(), max_layer=12)
+            ctl._set_threshold_value([0.02, 0.02, 1e5])
+            out = []
+            for _ in range(2):
+                m.clear_all_exit_memory()
+                vn.reset_actions()
+                for s_, (rgb, grip, ids, mask) in enumerate(inputs):
+                    ctl.set_timestep(s_)
+                    o = m.forward(rgb, ids, mask, grip, dynamic_early_exit=True, exit_controller=ctl)
+                    out.append((o["exit_layer"], o["logits"][0].clone(), torch.stack(o["hidden_states"])))
+                rgb, grip, ids, mask = inputs[0]
+                o = m.forward(rgb, ids, mask, grip, exit_id=-2)
+                out.append((o["exit_layer"], o["logits"][0].clone(), torch.stack(o["hidden_states"])))
+            return out
+        finally:
+            orc.OracleDeer.TRUNK_MEMO = None
+    a, b = run(False), run(True)
+    assert len({x[0] for x in a}) > 1
+    for x, y in zip(a, b):
+        assert x[0] == y[0] and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2])
