@@ -254,7 +254,7 @@ def two_groups_leg(cfg, rb, B, steps, burn_in, local_rank, stagger=True, G=4):
         per = []
         for s in range(len(rb["frames"])):
             pe = [syn.synthetic_step_inputs(cfg, s, rank=1000 * g + e, text_seed=7 + e) for e in range(B)]
-            per.append((torch.stack([p[0] for p in pe]).to(e1.dev, torch.bfloat16), torch.stack([p[1] for p in pe]).to(e1.dev, torch.bfloat16)))
+            per.append((torch.stack([p[0] for p in pe]).to(e1.dev, e1.img_dtype), torch.stack([p[1] for p in pe]).to(e1.dev, e1.img_dtype)))
         pools.append(per)
     streams = [torch.cuda.Stream(device=e1.dev) for _ in range(G)]
 
@@ -565,8 +565,8 @@ def run_workload(args, cfg, sd_dev, B, rank, world, local_rank, dist, max_layer,
     frames = []
     for s in range(POOL):
         per_env = [syn.synthetic_step_inputs(cfg, s, rank=rank * B + e, text_seed=7 + e) for e in range(B)]
-        frames.append((torch.stack([p[0] for p in per_env]).to(dev, torch.bfloat16),
-                       torch.stack([p[1] for p in per_env]).to(dev, torch.bfloat16)))
+        frames.append((torch.stack([p[0] for p in per_env]).to(dev, eng.img_dtype),      # resident in the engine's own frame format
+                       torch.stack([p[1] for p in per_env]).to(dev, eng.img_dtype)))
     ids = torch.cat([p[2] for p in per_env]).to(dev)          # (B, T): one instruction per environment
     T = ids.shape[1]
 
@@ -743,7 +743,11 @@ def main():
                   % ("MPT-7B" if args.workload == "deer_9b" else ("REDUCED-DIMS TEST MODEL (not a result)" if args.workload == "tiny" else "MPT-1B"), max_layer),
         "value": round(value, 2), "unit": "action-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * t_max / res["n_timed"], 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32 activations, bf16-representable weights", "data": "synthetic",
+        "vs_baseline": None, "dtype": ("bf16" if res["eng"].tower == "bf16" else "fp16+bf16") if args.precision == "bf16" else "f32 activations, bf16-representable weights",
+        "dtype_note": "16-bit MFMA operands, f32 accumulation everywhere; vision tower (ViT-L/14 x2, Perceiver, media K/V) in %s = %s; LLM trunk: bf16 "
+                      "weights, f32 activations fed as bf16 hi + lo; head f32 state" % (res["eng"].tower, "the reference's evaluation arithmetic (fp32 weights under "
+                      "fp16 autocast, eval_utils.py:333)" if res["eng"].tower == "fp16" else "a --precision bf16 reference run"),
+        "data": "synthetic",
         "avg_exit_layer": round(res["avg_exit"], 3),
         # which verdicts the timed region of `value` ran on: "scripted" = the dynamic pipeline with the thresholds forced per step
         # to the stratified target mix (one environment: depth-stable); "on_policy" = the calibrated criterion on the episode's own deltas

@@ -24,6 +24,16 @@ SIGNATURES = {
     "deer_gemm_bf16_nt": [P, I, L, P, I, P, P, I, L, I, I, I, I, I, P, I, P, P],
     "deer_gemm_bf16_nt_wbatch": [P, I, L, P, I, L, P, P, I, L, I, I, I, I, I, I, P, P],
     "deer_gemm_bf16_nt_splitk": [P, I, P, I, P, I, I, I, I, I, P, P],
+    # round 6: the vision tower's fp16 arithmetic (same arguments as the bf16 family)
+    "deer_gemm_f16_nt": [P, I, L, P, I, P, P, I, L, I, I, I, I, I, P, I, P, P],
+    "deer_gemm_f16_nt_wbatch": [P, I, L, P, I, L, P, P, I, L, I, I, I, I, I, I, P, P],
+    "deer_gemm_f16_nt_splitk": [P, I, P, I, P, I, I, I, I, I, P, P],
+    "deer_attn_f16_hd64": [P, P, P, P, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
+    "deer_attn_f16_hd64_2seg": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, L, F, P],
+    "deer_layernorm_rows_f16": [P, L, L, I, I, P, P, P, P, L, L, I, F, P],
+    "deer_layernorm_rows_multi_f16": [P, L, L, I, I, P, P, I, L, P, L, L, L, I, F, P],
+    "deer_resadd_ln_f16": [P, P, I, L, P, P, P, P, P, P, P, I, I, F, P, P],
+    "deer_vit_im2col_f16": [P, I, I, I, I, P, I, P],
     "deer_gemm_skinny": [P, I, P, I, L, I, P, P, I, I, I, I, P, P],
     "deer_skinny_splitk": [I, I, I],
     "deer_gemm_skinny_hl": [P, P, I, P, P, I, I, I, I, P, P],
@@ -129,7 +139,7 @@ CTL_PREV_ACTION, CTL_OUT_ACTION, CTL_DELTAS, CTL_WORDS = 8, 16, 24, 64
 CTL_N_EXITED, CTL_SEQ, CTL_HOST_PTR, CTL_EVALS_DONE = 40, 41, 42, 44
 CTL_PREV_REAL, CTL_ENS_ACTION = 45, 48
 HOSTM_PROGRESS, HOSTM_DONE = 0, 1
-EPI_BF16, EPI_F32, EPI_QGELU_BF16, EPI_GELU_BF16, EPI_RESADD_F32 = 0, 1, 2, 3, 4
+EPI_BF16, EPI_F32, EPI_QGELU_BF16, EPI_GELU_BF16, EPI_RESADD_F32, EPI_BF16OUT = 0, 1, 2, 3, 4, 5
 A_BF16, A_SLABS_GELU, A_SLABS, A_F32 = 0, 1, 2, 3
 X_RAW, X_POOL_MAX, X_POOL_AVG, X_LN = 0, 1, 2, 3
 PRO_RAW, PRO_LN, PRO_GROUP_LN_RELU, PRO_GROUP_RELU = 0, 1, 2, 3
@@ -163,13 +173,14 @@ class DeerConfigC(ctypes.Structure):
         "cross_attn_every_n_layers", "xattn_heads", "xattn_dim_head", "xattn_ff_mult", "media_token_id",
         "mpt7b_names", "exit_interval",
         "head_hidden", "lstm_num_layers", "lstm_layernorm", "mlp_layernorm", "mlp_num_hidden_layers", "pooling_avg",
-        "n_envs", "max_text_len", "n_chains", "precision", "use_state", "sep_resampler", "multi_step_action", "layerwise_exit_eval")]
+        "n_envs", "max_text_len", "n_chains", "precision", "use_state", "sep_resampler", "multi_step_action", "layerwise_exit_eval",
+        "tower_f16")]
 
 
 PRECISIONS = {"bf16": 0, "fp32": 1}
 
 
-def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0, precision: str = "bf16") -> DeerConfigC:
+def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0, precision: str = "bf16", tower: str = "bf16") -> DeerConfigC:
     c = DeerConfigC()
     for k in ("image_size", "patch_size", "vit_width", "vit_layers", "vit_heads", "vit_mlp", "perc_depth", "perc_heads",
               "perc_dim_head", "perc_latents", "perc_ff_mult", "vocab_size", "d_model", "n_heads", "mlp_ratio",
@@ -190,6 +201,9 @@ def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0, precisio
     c.sep_resampler = 1 if getattr(cfg, "sep_resampler", False) else 0
     c.multi_step_action = int(getattr(cfg, "multi_step_action", 1))
     c.layerwise_exit_eval = 1 if getattr(cfg, "layerwise_exit_eval", False) else 0
+    if tower not in ("bf16", "fp16"):
+        raise ValueError(f"tower must be 'bf16' or 'fp16', got {tower!r}")
+    c.tower_f16 = 1 if (tower == "fp16" and precision == "bf16") else 0
     return c
 
 

@@ -26,7 +26,7 @@
 // Optional extras (gated x-attn inside the LLM, helpers.py:192-232): Q given as f32 split-K partial slabs
 // (q_slabs > 0: Q points to f32, reduced while loading), keys masked by media time (text_time[q] == key/n_per_media + 1,
 // rows with text_time == 0 zeroed), f32 output, early-exit control block.
-template <bool XATTN, int NWAVE, bool LOOP = false>
+template <bool XATTN, int NWAVE, bool LOOP = false, bool F16 = false>   // F16: q / k / v / P / o in fp16 (the vision tower's fp16 arithmetic)
 __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __restrict__ Qv, const bf16_t* __restrict__ Kp,
                                                         const bf16_t* __restrict__ V, void* __restrict__ Ov,
                                                         int q_len, int kv_len, int ldq, int ldk, int ldv, int ldo,
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c) * AM_KPITCH + ks * 32 + g * 8);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+        s[t] = mfma16<F16>(kf, qf[ks], s[t]);
       }
     }
   }
@@ -171,10 +171,10 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
   for (int ch = 0; ch < AM_MAXT / 2; ++ch) {
     if (ch * 2 < nt) {
       uint4 pw;
-      pw.x = pack2bf(s[2 * ch][0], s[2 * ch][1]);
-      pw.y = pack2bf(s[2 * ch][2], s[2 * ch][3]);
-      pw.z = pack2bf(s[2 * ch + 1][0], s[2 * ch + 1][1]);
-      pw.w = pack2bf(s[2 * ch + 1][2], s[2 * ch + 1][3]);
+      pw.x = pack2x<F16>(s[2 * ch][0], s[2 * ch][1]);
+      pw.y = pack2x<F16>(s[2 * ch][2], s[2 * ch][3]);
+      pw.z = pack2x<F16>(s[2 * ch + 1][0], s[2 * ch + 1][1]);
+      pw.w = pack2x<F16>(s[2 * ch + 1][2], s[2 * ch + 1][3]);
       const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
         const uint2 lo = *reinterpret_cast<const uint2*>(vp);
         const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
         vw.x = lo.x; vw.y = lo.y; vw.z = hi.x; vw.w = hi.y;
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[dt], 0, 0, 0);
+        o[dt] = mfma16<F16>(__builtin_bit_cast(bf16x8, vw), pf, o[dt]);
       }
     }
   }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
             float4{o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
       else
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Ov) + off + dt * 16) =
-            uint2{pack2bf(o[dt][0] * inv, o[dt][1] * inv), pack2bf(o[dt][2] * inv, o[dt][3] * inv)};
+            uint2{pack2x<F16>(o[dt][0] * inv, o[dt][1] * inv), pack2x<F16>(o[dt][2] * inv, o[dt][3] * inv)};
     }
   }
   }   // query tiles of this wave
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
-template <int NWAVE, bool LOOP, int NT>     // NT = key tiles of 16 (kv_len <= 16 NT); PV runs (NT + 1) / 2 chunks of 32 keys
+template <int NWAVE, bool LOOP, int NT, bool F16>     // NT = key tiles of 16 (kv_len <= 16 NT); PV runs (NT + 1) / 2 chunks of 32 keys
 __global__ __launch_bounds__(64 * NWAVE, 4) void attn_vit_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
                                                               const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int q_len, int kv_len,
                                                               int ldq, int ldk, int ldv, int ldo, long q_bstride, long k_bstride,
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64 * NWAVE, 4) void attn_vit_kernel(const bf16_t* _
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c) * AM_KPITCH + ks * 32 + g * 8);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+        s[t] = mfma16<F16>(kf, qf[ks], s[t]);
       }
     // keys beyond kv_len live in the last tile only (kv_len > 16 (NT - 1), checked by the launcher)
 #pragma unroll
@@ -320,10 +320,10 @@ __global__ __launch_bounds__(64 * NWAVE, 4) void attn_vit_kernel(const bf16_t* _
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       uint4 pw;
-      pw.x = pack2bf(s[2 * ch][0], s[2 * ch][1]);
-      pw.y = pack2bf(s[2 * ch][2], s[2 * ch][3]);
-      pw.z = pack2bf(s[2 * ch + 1][0], s[2 * ch + 1][1]);      // tile NT (odd NT: beyond the keys) holds zeros
-      pw.w = pack2bf(s[2 * ch + 1][2], s[2 * ch + 1][3]);
+      pw.x = pack2x<F16>(s[2 * ch][0], s[2 * ch][1]);
+      pw.y = pack2x<F16>(s[2 * ch][2], s[2 * ch][3]);
+      pw.z = pack2x<F16>(s[2 * ch + 1][0], s[2 * ch + 1][1]);      // tile NT (odd NT: beyond the keys) holds zeros
+      pw.w = pack2x<F16>(s[2 * ch + 1][2], s[2 * ch + 1][3]);
       const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -331,24 +331,24 @@ __global__ __launch_bounds__(64 * NWAVE, 4) void attn_vit_kernel(const bf16_t* _
         const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vt + ((ch * 32 + 16) * AM_KPITCH + dt * 16) / 4);
         const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
         const uint4 vw = uint4{l2.x, l2.y, h2.x, h2.y};
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[dt], 0, 0, 0);
+        o[dt] = mfma16<F16>(__builtin_bit_cast(bf16x8, vw), pf, o[dt]);
       }
     }
     if (q0 + c < q_len) {                                    // lane holds O[q = q0 + c][d = dt*16 + g*4 .. +3]
       bf16_t* op = O + b * o_bstride + (long)(q0 + c) * ldo + h * AM_HD + g * 4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        *reinterpret_cast<uint2*>(op + dt * 16) = uint2{pack2bf(o[dt][0] * inv, o[dt][1] * inv), pack2bf(o[dt][2] * inv, o[dt][3] * inv)};
+        *reinterpret_cast<uint2*>(op + dt * 16) = uint2{pack2x<F16>(o[dt][0] * inv, o[dt][1] * inv), pack2x<F16>(o[dt][2] * inv, o[dt][3] * inv)};
     }
   }
 }
 
-template <int NWAVE, bool LOOP, int NT>
+template <int NWAVE, bool LOOP, int NT, bool F16>
 static int launch_attn_vit_nt(dim3 grid, hipStream_t st, const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, int q_len, int kv_len, int ldq,
                               int ldk, int ldv, int ldo, long q_bstride, long k_bstride, long v_bstride, long o_bstride, float scale, int tpw) {
   constexpr int smem = (NT * 16 + ((NT + 1) / 2) * 32) * AM_KPITCH * 2;
   static std::atomic<bool> attr_set{false};
-  auto kern = &attn_vit_kernel<NWAVE, LOOP, NT>;
+  auto kern = &attn_vit_kernel<NWAVE, LOOP, NT, F16>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return DEER_ERR_LAUNCH;
     attr_set = true;
@@ -359,6 +359,7 @@ static int launch_attn_vit_nt(dim3 grid, hipStream_t st, const bf16_t* Q, const 
   return DEER_OK;
 }
 
+template <bool F16 = false>
 static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O, int batch, int heads, int q_len, int kv_len,
                             int ldq, int ldk, int ldv, int ldo, long q_bstride, long k_bstride, long v_bstride, long o_bstride,
                             float scale, int q_slabs, long q_slab_stride, const int* text_time, int n_per_media, int out_is_f32,
@@ -375,11 +376,11 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
   static std::atomic<bool> attr_set{false};
   constexpr int max_smem = (AM_MAXT * 16 * AM_KPITCH + AM_HD * (AM_MAXT * 16 + 8)) * 2;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, 4, false, F16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             max_smem) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, 8, false, F16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             max_smem) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, 8, true, F16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             max_smem) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             max_smem) != hipSuccess)
@@ -415,21 +416,22 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
     if (tpw != nwave && w16) {
       grid = dim3(1, heads, batch);
       tpw = tiles;
-      return launch_attn_vit_nt<16, true, 17>(DEER_VIT_ARGS);
+      return launch_attn_vit_nt<16, true, 17, F16>(DEER_VIT_ARGS);
     }
-    return tpw != nwave ? launch_attn_vit_nt<8, true, 17>(DEER_VIT_ARGS) : launch_attn_vit_nt<8, false, 17>(DEER_VIT_ARGS);
+    return tpw != nwave ? launch_attn_vit_nt<8, true, 17, F16>(DEER_VIT_ARGS) : launch_attn_vit_nt<8, false, 17, F16>(DEER_VIT_ARGS);
 #undef DEER_VIT_ARGS
   }
 #define DEER_ATTN_ARGS Q, kp, vp, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride, scale, q_slabs, \
                        q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2, tpw
-  if (q_slabs > 0)
+  if (q_slabs > 0) {
+    if (F16) return DEER_ERR_SHAPE;                         // the x-attn form (f32 q slabs) exists in bf16 only
     hipLaunchKernelGGL((attn_mfma_kernel<true, 4>), grid, dim3(256), smem, st, DEER_ATTN_ARGS);
-  else if (wide && tpw != nwave)
-    hipLaunchKernelGGL((attn_mfma_kernel<false, 8, true>), grid, dim3(512), smem, st, DEER_ATTN_ARGS);
+  } else if (wide && tpw != nwave)
+    hipLaunchKernelGGL((attn_mfma_kernel<false, 8, true, F16>), grid, dim3(512), smem, st, DEER_ATTN_ARGS);
   else if (wide)
-    hipLaunchKernelGGL((attn_mfma_kernel<false, 8>), grid, dim3(512), smem, st, DEER_ATTN_ARGS);
+    hipLaunchKernelGGL((attn_mfma_kernel<false, 8, false, F16>), grid, dim3(512), smem, st, DEER_ATTN_ARGS);
   else
-    hipLaunchKernelGGL((attn_mfma_kernel<false, 4>), grid, dim3(256), smem, st, DEER_ATTN_ARGS);
+    hipLaunchKernelGGL((attn_mfma_kernel<false, 4, false, F16>), grid, dim3(256), smem, st, DEER_ATTN_ARGS);
 #undef DEER_ATTN_ARGS
   DEER_LAUNCH_CHECK();
   return DEER_OK;
@@ -451,6 +453,26 @@ extern "C" int deer_attn_mfma_hd64_2seg(const void* Q, const void* K1, const voi
                                         void* stream) {
   if (K2 == nullptr || V2 == nullptr || kv1 < 0 || kv2 <= 0) return DEER_ERR_SHAPE;
   return launch_attn_mfma(Q, K1, V1, O, batch, heads, q_len, kv1 + kv2, ldq, ld1, ld1, ldo, q_bstride, bstride1, bstride1, o_bstride,
+                          scale, 0, 0, nullptr, 1, 0, nullptr, stream, K2, V2, kv1, ld2, bstride2);
+}
+
+// ---- the same two entry points on fp16 q / k / v with an fp16 result (round 6: the vision tower's fp16 arithmetic) ----
+extern "C" int deer_attn_f16_hd64(const void* Q, const void* K, const void* V, void* O, int batch, int heads,
+                                   int q_len, int kv_len, int ldq, int ldk, int ldv, int ldo, long q_bstride,
+                                   long k_bstride, long v_bstride, long o_bstride, float scale, void* stream) {
+  return launch_attn_mfma<true>(Q, K, V, O, batch, heads, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride,
+                          scale, 0, 0, nullptr, 1, 0, nullptr, stream);
+}
+
+// Keys/values in two segments: keys [0, kv1) from (K1, V1), keys [kv1, kv1+kv2) from (K2, V2).  PerceiverAttention
+// (helpers.py:47-73) attends over [media tokens ; latents]; the media K/V of every layer are produced up front by one
+// batched GEMM (media tokens are layer-invariant), the latent K/V by the per-layer q|k|v projection of the latents.
+extern "C" int deer_attn_f16_hd64_2seg(const void* Q, const void* K1, const void* V1, const void* K2, const void* V2, void* O,
+                                        int batch, int heads, int q_len, int kv1, int kv2, int ldq, int ld1, int ld2, int ldo,
+                                        long q_bstride, long bstride1, long bstride2, long o_bstride, float scale,
+                                        void* stream) {
+  if (K2 == nullptr || V2 == nullptr || kv1 < 0 || kv2 <= 0) return DEER_ERR_SHAPE;
+  return launch_attn_mfma<true>(Q, K1, V1, O, batch, heads, q_len, kv1 + kv2, ldq, ld1, ld1, ldo, q_bstride, bstride1, bstride1, o_bstride,
                           scale, 0, 0, nullptr, 1, 0, nullptr, stream, K2, V2, kv1, ld2, bstride2);
 }
 

@@ -66,6 +66,34 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
+// ---- the vision tower's 16-bit format (round 6): bf16 or IEEE fp16 --------------------------------------------------------------------------
+// The reference evaluates with fp32 weights under fp16 autocast (eval_utils.py:333, README.md:161-167): every Linear of the ViT / Perceiver
+// runs on fp16 operands and leaves an fp16 result, LayerNorm / softmax / the residual stream stay f32.  v_mfma_f32_16x16x32_f16 issues at
+// the bf16 rate, OpenAI CLIP weights are fp16-native, and an fp16 activation carries 11 significand bits where bf16 carries 8 - so the
+// tower kernels are templates over the format (F16 = true: fp16 operands / results; storage stays `bf16_t` = 16 raw bits) and the model
+// picks one per engine (deer_config.tower_f16).  The LLM trunk keeps its bf16 hi + lo planes (f32-equivalent activations).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 deer_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {      // v_cvt_pk_f16_f32: round-to-nearest-even, overflow -> inf like torch .half()
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((deer_f2){lo, hi}, deer_h2));
+}
+__device__ __forceinline__ bf16_t f2h(float f) { return (bf16_t)(pack2h(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ float h2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+template <bool F16> __device__ __forceinline__ uint32_t pack2x(float lo, float hi) { return F16 ? pack2h(lo, hi) : pack2bf(lo, hi); }
+template <bool F16> __device__ __forceinline__ bf16_t f2x(float f) { return F16 ? f2h(f) : f2bf(f); }
+template <bool F16> __device__ __forceinline__ float x2f(bf16_t v) { return F16 ? h2f(v) : bf2f(v); }
+// one 16x16x32 MFMA on fragments held as 8 x 16 raw bits
+template <bool F16> __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// GEMM epilogue codes shared by csrc/gemm_tiled.hip and csrc/gemm_bigm.hip (include/deer_hip.h: DEER_EPI_*).  "16" = the family's own
+// 16-bit format; EPI_BF16OUT stores bf16 whatever the operands are (fp16 tower -> the bf16 K/V the trunk's x-attn reads).
+enum { DEER_E_16 = 0, DEER_E_F32 = 1, DEER_E_QGELU_16 = 2, DEER_E_GELU_16 = 3, DEER_E_RESADD_F32 = 4, DEER_E_BF16OUT = 5 };
+template <bool F16> __device__ __forceinline__ uint32_t pack2_epi(float lo, float hi, int epi) {
+  return (F16 && epi != DEER_E_BF16OUT) ? pack2h(lo, hi) : pack2bf(lo, hi);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -24,7 +24,9 @@
 #include "common.h"
 #include <type_traits>
 
-enum { P8_EPI_BF16 = 0, P8_EPI_F32 = 1, P8_EPI_QGELU_BF16 = 2, P8_EPI_GELU_BF16 = 3, P8_EPI_RESADD_F32 = 4 };
+// "BF16" = the family's 16-bit format (bf16, or fp16 when F16); P8_EPI_BF16OUT stores bf16 whatever the operands are
+enum { P8_EPI_BF16 = DEER_E_16, P8_EPI_F32 = DEER_E_F32, P8_EPI_QGELU_BF16 = DEER_E_QGELU_16, P8_EPI_GELU_BF16 = DEER_E_GELU_16,
+       P8_EPI_RESADD_F32 = DEER_E_RESADD_F32, P8_EPI_BF16OUT = DEER_E_BF16OUT };
 
 typedef __attribute__((address_space(1))) const void p8_gptr_t;
 typedef __attribute__((address_space(3))) void p8_lptr_t;
@@ -60,7 +62,7 @@ __device__ __forceinline__ void p8_wait_vmcnt() {
 // its MFMAs in 2k+1, group 1 one interval later): a slot read in interval Y may be refilled from Y+2 on - READ(k) refills the slot of
 // stage k-2 with stage k+D-2; a wave's counted vmcnt in READ(k) retires stage k+1, which group 0 reads from interval 2k+2 on (after
 // the barrier that follows group 1's wait).
-template <int BM, int BN, int D, bool STAG = false>
+template <int BM, int BN, int D, bool STAG = false, bool F16 = false>
 __global__ __launch_bounds__(1024) void gemm_ring32_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
                                                             const bf16_t* __restrict__ W, int ldw, long strideW,
                                                             const float* __restrict__ bias, void* __restrict__ Cv, int ldc,
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(1024) void gemm_ring32_kernel(const bf16_t* __restr
       for (int j = 0; j < TM; ++j)
         if (j < mv) {
 #pragma unroll
-          for (int i = 0; i < TN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < TN; ++i) acc[i][j] = mfma16<F16>(wf[i], af[j], acc[i][j]);
         }
       __builtin_amdgcn_s_setprio(0);
       BIGM_SYNC();
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(1024) void gemm_ring32_kernel(const bf16_t* __restr
     for (int j = 0; j < TM; ++j)
       if (j < mv) {                              // wave-uniform: a ragged last row tile computes only the MFMA tiles that hold a valid row
 #pragma unroll
-        for (int i = 0; i < TN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TN; ++i) acc[i][j] = mfma16<F16>(wf[i], af[j], acc[i][j]);
       }
   }
   }
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(1024) void gemm_ring32_kernel(const bf16_t* __restr
         } else if (epi == P8_EPI_GELU_BF16) {
           v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
         }
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + off) = uint2{pack2bf(v0, v1), pack2bf(v2, v3)};
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + off) = uint2{pack2_epi<F16>(v0, v1, epi), pack2_epi<F16>(v2, v3, epi)};
       }
     }
   }
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(1024) void gemm_ring32_kernel(const bf16_t* __restr
 // row tiles 5 | 4 | 4 | 4 per wave row (one wave of every row on each SIMD) and 64 columns per wave column.  A stage is 17 A chunks (16
 // rows x 64 B) + 16 W chunks: wave w issues A chunk w and W chunk w, wave 0 also A chunk 16 - its loop is instantiated with its own
 // counted vmcnt (3 DMAs per stage instead of 2).
-template <int D>
+template <int D, bool F16>
 __global__ __launch_bounds__(1024) void gemm_ring272_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
                                                              const bf16_t* __restrict__ W, int ldw, long strideW,
                                                              const float* __restrict__ bias, void* __restrict__ Cv, int ldc,
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(1024) void gemm_ring272_kernel(const bf16_t* __rest
         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(st + w_off + i * 16 * 64);
 #pragma unroll
         for (int j = 0; j < TMX; ++j)
-          if (j < tm) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[j], acc[i][j], 0, 0, 0);
+          if (j < tm) acc[i][j] = mfma16<F16>(wf, af[j], acc[i][j]);
       }
     }
     p8_wait_vmcnt<0>();
@@ -330,13 +332,13 @@ __global__ __launch_bounds__(1024) void gemm_ring272_kernel(const bf16_t* __rest
         } else if (epi == P8_EPI_GELU_BF16) {
           v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
         }
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + off) = uint2{pack2bf(v0, v1), pack2bf(v2, v3)};
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + off) = uint2{pack2_epi<F16>(v0, v1, epi), pack2_epi<F16>(v2, v3, epi)};
       }
     }
   }
 }
 
-template <int D>
+template <bool F16, int D>
 static int launch_ring272(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
                           int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl,
                           hipStream_t st) {
@@ -344,7 +346,7 @@ static int launch_ring272(const bf16_t* A, int lda, long strideA, const bf16_t* 
   const int tile_rows = (M % 257 == 0) ? 257 : 272;         // M = 257 n (n camera frames): one frame per row tile
   constexpr int smem_bytes = D * 33 * 1024;
   static std::atomic<bool> attr_set{false};
-  auto kern = &gemm_ring272_kernel<D>;
+  auto kern = &gemm_ring272_kernel<D, F16>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
       return DEER_ERR_LAUNCH;
@@ -375,7 +377,7 @@ KT_DEFINE(frame)
 #else
 #define FKT(slot) do { } while (0)
 #endif
-template <int TM, int WN, int TN, int D>
+template <int TM, int WN, int TN, int D, bool F16>
 __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
                                                                const bf16_t* __restrict__ W, int ldw, long strideW,
                                                                const float* __restrict__ bias, void* __restrict__ Cv, int ldc,
@@ -483,10 +485,10 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TM; ++j) acc[i][j] = mfma16<F16>(wf[i], af[j], acc[i][j]);
 #pragma unroll
       for (int e = 0; e < TN; ++e)
-        if (has_x && wm == e) accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[e], afx, accx, 0, 0, 0);
+        if (has_x && wm == e) accx = mfma16<F16>(wf[e], afx, accx);
     }
     p8_wait_vmcnt<0>();
   };
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
 
   FKT(4);
   const float gs = (epi == P8_EPI_RESADD_F32 && gate != nullptr) ? tanhf(*gate) : 1.f;
-  const bool to_bf16 = epi == P8_EPI_BF16 || epi == P8_EPI_QGELU_BF16 || epi == P8_EPI_GELU_BF16;
+  const bool to_bf16 = epi == P8_EPI_BF16 || epi == P8_EPI_QGELU_BF16 || epi == P8_EPI_GELU_BF16 || epi == P8_EPI_BF16OUT;
   // bf16 outputs leave through LDS: the accumulator layout gives a lane 4 columns of ONE row (8 bytes; a wave store touches 16 rows,
   // 32 bytes each - the epilogue of the direct form is store-ISSUE bound, ~5 us of a 40 us launch); staged, a lane stores 16 bytes
   // of a row and a wave 1 KiB of whole 128-byte lines, half as many instructions.  Row pitch BN*2 + 16 bytes: the ds_write_b64 of a
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
       } else if (epi == P8_EPI_GELU_BF16) {
         v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
       }
-      *reinterpret_cast<uint2*>(smem + r * CPITCH + n * 2) = uint2{pack2bf(v0, v1), pack2bf(v2, v3)};
+      *reinterpret_cast<uint2*>(smem + r * CPITCH + n * 2) = uint2{pack2_epi<F16>(v0, v1, epi), pack2_epi<F16>(v2, v3, epi)};
       return;
     }
     if (f32_staged) {
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(WN * 256) void gemm_frame_kernel(const bf16_t* __re
   FKT(6);
 }
 
-template <int TM, int WN, int TN, int D>
+template <bool F16, int TM, int WN, int TN, int D>
 static int launch_frame(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
                         int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl,
                         hipStream_t st) {
@@ -579,7 +581,7 @@ static int launch_frame(const bf16_t* A, int lda, long strideA, const bf16_t* W,
   constexpr int rc_bytes = ring_bytes > c_bytes ? ring_bytes : c_bytes;
   constexpr int smem_bytes = rc_bytes > f_bytes ? rc_bytes : f_bytes;   // the ring, then the staged C tile (bf16, or f32 where it fits)
   static std::atomic<bool> attr_set{false};
-  auto kern = &gemm_frame_kernel<TM, WN, TN, D>;
+  auto kern = &gemm_frame_kernel<TM, WN, TN, D, F16>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
       return DEER_ERR_LAUNCH;
@@ -607,7 +609,7 @@ __device__ __forceinline__ void f8_dma16(const void* base, unsigned voff, unsign
                                            soff, 0, 0);
 }
 
-template <int TN, int D>
+template <int TN, int D, bool F16>
 __global__ __launch_bounds__(512) void gemm_frame8_kernel(const bf16_t* __restrict__ A, int lda, long strideA, const bf16_t* __restrict__ W,
                                                            int ldw, long strideW, const float* __restrict__ bias, void* __restrict__ Cv, int ldc,
                                                            long strideC, int M, int N, int K, int epi, const int* ctl) {
@@ -698,13 +700,13 @@ __global__ __launch_bounds__(512) void gemm_frame8_kernel(const bf16_t* __restri
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<F16>(wf[i], af[j], acc[i][j]);
 #pragma unroll
       for (int x = 0; x < XT; ++x) {
         bf16x8 wx = wf[0];
 #pragma unroll
         for (int e = 1; e < TN; ++e) wx = (wm * XT + x == e) ? wf[e] : wx;
-        accx[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wx, afx, accx[x], 0, 0, 0);
+        accx[x] = mfma16<F16>(wx, afx, accx[x]);
       }
       // A fragments + the first TWO W fragments, then per W fragment: its 4 MFMAs, the read of the fragment after next (reads run one
       // group of MFMAs ahead); the dealt-out tiles last
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(512) void gemm_frame8_kernel(const bf16_t* __restri
     } else if (epi == P8_EPI_GELU_BF16) {
       v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
     }
-    *reinterpret_cast<uint2*>(smem + r * CPITCH + n * 2) = uint2{pack2bf(v0, v1), pack2bf(v2, v3)};
+    *reinterpret_cast<uint2*>(smem + r * CPITCH + n * 2) = uint2{pack2_epi<F16>(v0, v1, epi), pack2_epi<F16>(v2, v3, epi)};
   };
   BIGM_SYNC();                                                 // every wave has read its last fragments: the ring becomes the C tile
 #pragma unroll
@@ -758,18 +760,18 @@ __global__ __launch_bounds__(512) void gemm_frame8_kernel(const bf16_t* __restri
   }
 }
 
-template <int TN, int D>
+template <bool F16, int TN, int D>
 static int launch_frame8(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C, int ldc,
                          long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl, hipStream_t st) {
   constexpr int BN = 32 * TN;
-  const bool to_bf16 = epi == P8_EPI_BF16 || epi == P8_EPI_QGELU_BF16 || epi == P8_EPI_GELU_BF16;
+  const bool to_bf16 = epi == P8_EPI_BF16 || epi == P8_EPI_QGELU_BF16 || epi == P8_EPI_GELU_BF16 || epi == P8_EPI_BF16OUT;
   if ((N % BN) || (K & 31) || M <= 0 || (M % 257) || batch <= 0 || !to_bf16) return DEER_ERR_SHAPE;
   // MUBUF byte offsets are 32 bits: every operand (one batch slice) has to end below 4 GiB
   if ((long)M * lda * 2 >= (1L << 32) || (long)N * ldw * 2 >= (1L << 32)) return DEER_ERR_SHAPE;
   constexpr int ring_bytes = D * (17 + BN / 16) * 1024, c_bytes = 272 * (BN * 2 + 16);
   constexpr int smem_bytes = ring_bytes > c_bytes ? ring_bytes : c_bytes;
   static std::atomic<bool> attr_set{false};
-  auto kern = &gemm_frame8_kernel<TN, D>;
+  auto kern = &gemm_frame8_kernel<TN, D, F16>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
       return DEER_ERR_LAUNCH;
@@ -782,14 +784,14 @@ static int launch_frame8(const bf16_t* A, int lda, long strideA, const bf16_t* W
   return DEER_OK;
 }
 
-template <int BM, int BN, int D, bool STAG = false>
+template <bool F16, int BM, int BN, int D, bool STAG = false>
 static int launch_ring32(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
                          int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl,
                          hipStream_t st) {
   if ((N & 15) || (K & 31) || M <= 0 || batch <= 0) return DEER_ERR_SHAPE;
   constexpr int smem_bytes = D * (BM + BN) * 64;
   static std::atomic<bool> attr_set{false};
-  auto kern = &gemm_ring32_kernel<BM, BN, D, STAG>;
+  auto kern = &gemm_ring32_kernel<BM, BN, D, STAG, F16>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
       return DEER_ERR_LAUNCH;
@@ -804,39 +806,45 @@ static int launch_ring32(const bf16_t* A, int lda, long strideA, const bf16_t* W
 
 // variant: 0 = 256x256 / 5 stages (160 KB), 1 = 256x256 / 4 stages, 2 = 128x128 / 8 stages (128 KB), 3 = 256x256 / 2 stages,
 //          4 = 256x256 / 3 stages, 5 = 128x128 / 5 stages (80 KB: two workgroups per CU), 6 / 7 = 257(272)x256 / 3 / 4 stages
+template <bool F16>
 int deer_launch_gemm_ring32(int variant, const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias,
                             void* C, int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl,
                             hipStream_t st) {
 #define P8_ARGS A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, batch, epi, gate, ctl, st
   switch (variant) {
-    case 0: return launch_ring32<256, 256, 5>(P8_ARGS);
-    case 1: return launch_ring32<256, 256, 4>(P8_ARGS);
-    case 2: return launch_ring32<128, 128, 8>(P8_ARGS);
-    case 3: return launch_ring32<256, 256, 2>(P8_ARGS);
-    case 4: return launch_ring32<256, 256, 3>(P8_ARGS);
-    case 5: return launch_ring32<128, 128, 5>(P8_ARGS);
-    case 8: return launch_ring32<256, 256, 5, true>(P8_ARGS);   // staggered wave groups, two barriers per K-step
-    case 9: return launch_ring32<128, 128, 5, true>(P8_ARGS);
-    case 10: return launch_ring32<256, 256, 4, true>(P8_ARGS);
-    case 11: return launch_ring32<128, 128, 8, true>(P8_ARGS);
-    case 6: return launch_ring272<3>(P8_ARGS);              // one camera frame (257 rows) per row tile, 99 KB ring
-    case 7: return launch_ring272<4>(P8_ARGS);              // the same, 132 KB ring
-    case 12: return launch_frame<4, 4, 4, 4>(P8_ARGS);         // frame tiles, balanced 17th row tile: 257 x 256, 16 waves, 132 KB
-    case 13: return launch_frame<4, 4, 3, 4>(P8_ARGS);         // 257 x 192, 16 waves, 116 KB
-    case 14: return launch_frame<4, 4, 3, 5>(P8_ARGS);         // 257 x 192, 145 KB ring
-    case 15: return launch_frame<4, 2, 4, 3>(P8_ARGS);         // 257 x 128, 8 waves, 75 KB: two workgroups per CU
-    case 16: return launch_frame<4, 4, 2, 4>(P8_ARGS);         // 257 x 128, 16 waves, 100 KB
-    case 17: return launch_frame<4, 4, 1, 4>(P8_ARGS);         // 257 x 64, 16 waves, 84 KB
-    case 18: return launch_frame<4, 2, 2, 3>(P8_ARGS);         // 257 x 64, 8 waves, 63 KB: two workgroups per CU
-    case 19: return launch_frame<4, 4, 4, 3>(P8_ARGS);         // 257 x 256, 99 KB
-    case 20: return launch_frame<4, 2, 4, 4>(P8_ARGS);         // 257 x 128, 8 waves, 100 KB
+    case 0: return launch_ring32<F16, 256, 256, 5>(P8_ARGS);
+    case 1: return launch_ring32<F16, 256, 256, 4>(P8_ARGS);
+    case 2: return launch_ring32<F16, 128, 128, 8>(P8_ARGS);
+    case 3: return launch_ring32<F16, 256, 256, 2>(P8_ARGS);
+    case 4: return launch_ring32<F16, 256, 256, 3>(P8_ARGS);
+    case 5: return launch_ring32<F16, 128, 128, 5>(P8_ARGS);
+    case 8: return launch_ring32<F16, 256, 256, 5, true>(P8_ARGS);   // staggered wave groups, two barriers per K-step
+    case 9: return launch_ring32<F16, 128, 128, 5, true>(P8_ARGS);
+    case 10: return launch_ring32<F16, 256, 256, 4, true>(P8_ARGS);
+    case 11: return launch_ring32<F16, 128, 128, 8, true>(P8_ARGS);
+    case 6: return launch_ring272<F16, 3>(P8_ARGS);              // one camera frame (257 rows) per row tile, 99 KB ring
+    case 7: return launch_ring272<F16, 4>(P8_ARGS);              // the same, 132 KB ring
+    case 12: return launch_frame<F16, 4, 4, 4, 4>(P8_ARGS);         // frame tiles, balanced 17th row tile: 257 x 256, 16 waves, 132 KB
+    case 13: return launch_frame<F16, 4, 4, 3, 4>(P8_ARGS);         // 257 x 192, 16 waves, 116 KB
+    case 14: return launch_frame<F16, 4, 4, 3, 5>(P8_ARGS);         // 257 x 192, 145 KB ring
+    case 15: return launch_frame<F16, 4, 2, 4, 3>(P8_ARGS);         // 257 x 128, 8 waves, 75 KB: two workgroups per CU
+    case 16: return launch_frame<F16, 4, 4, 2, 4>(P8_ARGS);         // 257 x 128, 16 waves, 100 KB
+    case 17: return launch_frame<F16, 4, 4, 1, 4>(P8_ARGS);         // 257 x 64, 16 waves, 84 KB
+    case 18: return launch_frame<F16, 4, 2, 2, 3>(P8_ARGS);         // 257 x 64, 8 waves, 63 KB: two workgroups per CU
+    case 19: return launch_frame<F16, 4, 4, 4, 3>(P8_ARGS);         // 257 x 256, 99 KB
+    case 20: return launch_frame<F16, 4, 2, 4, 4>(P8_ARGS);         // 257 x 128, 8 waves, 100 KB
     // HALF frames (measured, not auto-selected: out_proj at 16 frames 18.0 us against 17.3 for the 128x128 ring; c_proj without the K split
     // 50-55 us against 42.8 for the 257 x 128 tiles of the two K halves):
-    case 21: return launch_frame<2, 4, 2, 5>(P8_ARGS);      // 129 | 128 x 128, 16 waves (32 x 32 wave tiles), 85 KB
-    case 22: return launch_frame<2, 2, 4, 4>(P8_ARGS);      // 129 | 128 x 128, 8 waves (32 x 64 wave tiles), 68 KB
-    case 23: return launch_frame8<8, 4>(P8_ARGS);           // frame8: 257 x 256, 8 waves (64 x 128 wave tiles), 132 KB
-    case 24: return launch_frame8<6, 4>(P8_ARGS);           // frame8: 257 x 192, 8 waves (64 x 96 wave tiles), 116 KB
+    case 21: return launch_frame<F16, 2, 4, 2, 5>(P8_ARGS);      // 129 | 128 x 128, 16 waves (32 x 32 wave tiles), 85 KB
+    case 22: return launch_frame<F16, 2, 2, 4, 4>(P8_ARGS);      // 129 | 128 x 128, 8 waves (32 x 64 wave tiles), 68 KB
+    case 23: return launch_frame8<F16, 8, 4>(P8_ARGS);           // frame8: 257 x 256, 8 waves (64 x 128 wave tiles), 132 KB
+    case 24: return launch_frame8<F16, 6, 4>(P8_ARGS);           // frame8: 257 x 192, 8 waves (64 x 96 wave tiles), 116 KB
     default: return DEER_ERR_SHAPE;
   }
 #undef P8_ARGS
 }
+
+template int deer_launch_gemm_ring32<false>(int, const bf16_t*, int, long, const bf16_t*, int, long, const float*, void*, int, long, int, int, int, int, int,
+                                            const float*, const int*, hipStream_t);
+template int deer_launch_gemm_ring32<true>(int, const bf16_t*, int, long, const bf16_t*, int, long, const float*, void*, int, long, int, int, int, int, int,
+                                           const float*, const int*, hipStream_t);

@@ -15,12 +15,13 @@
 #include "common.h"
 #include <cstdlib>
 
-enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_QGELU_BF16 = 2, EPI_GELU_BF16 = 3, EPI_RESADD_F32 = 4 };
+enum { EPI_BF16 = DEER_E_16, EPI_F32 = DEER_E_F32, EPI_QGELU_BF16 = DEER_E_QGELU_16, EPI_GELU_BF16 = DEER_E_GELU_16, EPI_RESADD_F32 = DEER_E_RESADD_F32,
+       EPI_BF16OUT = DEER_E_BF16OUT };   // "BF16" = the kernel family's 16-bit format (bf16, or fp16 when F16)
 
 #define GT_BK 64
 #define GT_PITCH 72
 
-template <int BM, int BN>
+template <int BM, int BN, bool F16>
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
                                                          const bf16_t* __restrict__ W, int ldw, long strideW,
                                                          const float* __restrict__ bias, void* __restrict__ Cv,
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restric
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<F16>(wf[i], af[j], acc[i][j]);
     }
     if (kt + 1 < nk) swrite(buf ^ 1);
     __syncthreads();
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restric
         } else if (epi == EPI_GELU_BF16) {
           v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
         }
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + off) = uint2{pack2bf(v0, v1), pack2bf(v2, v3)};
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + off) = uint2{pack2_epi<F16>(v0, v1, epi), pack2_epi<F16>(v2, v3, epi)};
       }
     }
   }
@@ -169,7 +170,7 @@ KT_DEFINE(gemm)
 #else
 #define GKT(slot) do { } while (0)
 #endif
-template <int BM, int BN, int WM, int WN, int D, int DBG = 0, int U = 1, int PIPE = 0>   // DBG (ablation only): 1 = no MFMA/ds_read, 2 = no DMA in the loop
+template <int BM, int BN, int WM, int WN, int D, int DBG = 0, int U = 1, int PIPE = 0, bool F16 = false>   // DBG (ablation only): 1 = no MFMA/ds_read, 2 = no DMA in the loop
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf16_t* __restrict__ A, int lda, long strideA,
                                                                         const bf16_t* __restrict__ W, int ldw, long strideW,
                                                                         const float* __restrict__ bias,
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int j = 0; j < TM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[set][kk][i], fa[set][kk][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16<F16>(fw[set][kk][i], fa[set][kk][j], acc[i][j]);
     };
 #pragma unroll
     for (int t = 0; t < D - 1; ++t) issue(t);
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int j = 0; j < TM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16<F16>(wf[i], af[j], acc[i][j]);
       }
     }
   }
@@ -344,14 +345,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tiled_ring_kernel(const bf1
         } else if (epi == EPI_GELU_BF16) {
           v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
         }
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + off) = uint2{pack2bf(v0, v1), pack2bf(v2, v3)};
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + off) = uint2{pack2_epi<F16>(v0, v1, epi), pack2_epi<F16>(v2, v3, epi)};
       }
     }
   }
   GKT(5);
 }
 
-template <int BM, int BN, int WM, int WN, int D, int DBG = 0, int U = 1, int PIPE = 0>
+template <bool F16, int BM, int BN, int WM, int WN, int D, int DBG = 0, int U = 1, int PIPE = 0>
 static int launch_ring(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
                        int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate,
                        const int* ctl, hipStream_t st) {
@@ -359,7 +360,7 @@ static int launch_ring(const bf16_t* A, int lda, long strideA, const bf16_t* W, 
   static_assert(smem <= 160 * 1024, "LDS");
   static std::atomic<bool> attr_set{false};
   if (PIPE && ((K / GT_BK) & 1)) return DEER_ERR_SHAPE;   // pipelined loop is unrolled by two K-steps
-  auto kern = &gemm_tiled_ring_kernel<BM, BN, WM, WN, D, DBG, U, PIPE>;
+  auto kern = &gemm_tiled_ring_kernel<BM, BN, WM, WN, D, DBG, U, PIPE, F16>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return DEER_ERR_LAUNCH;
@@ -372,13 +373,13 @@ static int launch_ring(const bf16_t* A, int lda, long strideA, const bf16_t* W, 
   return DEER_OK;
 }
 
-template <int BM, int BN>
+template <bool F16, int BM, int BN>
 static int launch_tiled(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
                         int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate,
                         const int* ctl, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * GT_PITCH * (int)sizeof(bf16_t);
   static std::atomic<bool> attr_set{false};
-  auto kern = &gemm_tiled_kernel<BM, BN>;
+  auto kern = &gemm_tiled_kernel<BM, BN, F16>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return DEER_ERR_LAUNCH;
@@ -391,6 +392,7 @@ static int launch_tiled(const bf16_t* A, int lda, long strideA, const bf16_t* W,
 }
 
 // csrc/gemm_bigm.hip
+template <bool F16>
 int deer_launch_gemm_ring32(int variant, const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias,
                             void* C, int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl,
                             hipStream_t st);
@@ -399,10 +401,11 @@ int deer_launch_gemm_ring32(int variant, const bf16_t* A, int lda, long strideA,
 //       LDS-ring DMA kernels (K % 64 == 0): 4 = 64x64 / 8 waves / 4 stages, 5 = 128x64 / 8 waves / 3 stages,
 //       6 = 64x64 / 16 waves / 6 stages, 7 = 128x128 / 16 waves / 3 stages, 8 = 64x128 / 8 waves / 3 stages,
 //       9 = 32x64 / 4 waves... (see switch)
+template <bool F16>
 static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, int ldw, long strideW, const float* bias,
                          void* C, int ldc, long strideC, int M, int N, int K, int batch, int epi,
                          const float* gate, int tile, const int* ctl, void* stream) {
-  if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 15) || (lda & 7) || (ldw & 7) || (ldc & 3) || epi < 0 || epi > 4)
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 15) || (lda & 7) || (ldw & 7) || (ldc & 3) || epi < 0 || epi > 5)
     return DEER_ERR_SHAPE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool ring_ok = (K % GT_BK) == 0;
@@ -440,8 +443,8 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
       };
       // DEER_GEMM_FRAME8=1: the same tiles on eight waves (csrc/gemm_bigm.hip: gemm_frame8_kernel)
       static const bool frame8 = [] { const char* e = getenv("DEER_GEMM_FRAME8"); return e != nullptr && e[0] == '1'; }();
-      if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16) && one_round(192)) tile = frame8 ? 75 : 64;
-      else if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16) && one_round(256)) tile = frame8 ? 74 : 63;
+      if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16 || epi == EPI_BF16OUT) && one_round(192)) tile = frame8 ? 75 : 64;
+      else if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16 || epi == EPI_BF16OUT) && one_round(256)) tile = frame8 ? 74 : 63;
       // ... and the K halves of c_proj (f32 slabs, N = 1024) as 257 x 128 tiles: 16 frames x 8 x 2 = 256 workgroups, 49.8 -> 43.1 us
       else if (sel256 && big_sel && (K & 31) == 0 && epi == EPI_F32 && one_round(128)) tile = 67;
       else if (sel256 && big_sel && (N & 255) == 0 && (K & 31) == 0 && n256 >= 192 && n256 <= 256) tile = 61;
@@ -462,59 +465,59 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
   const bf16_t* w = reinterpret_cast<const bf16_t*>(W);
 #define DEER_ARGS a, lda, strideA, w, ldw, strideW, bias, C, ldc, strideC, M, N, K, batch, epi, gate, ctl, st
   switch (tile) {
-    case 1: return launch_tiled<64, 64>(DEER_ARGS);
-    case 2: return launch_tiled<64, 128>(DEER_ARGS);
-    case 3: return launch_tiled<128, 128>(DEER_ARGS);
-    case 4: return launch_ring<64, 64, 2, 4, 4>(DEER_ARGS);
-    case 5: return launch_ring<128, 64, 4, 2, 3>(DEER_ARGS);
-    case 6: return launch_ring<64, 64, 4, 4, 6>(DEER_ARGS);
-    case 7: return launch_ring<128, 128, 4, 4, 3>(DEER_ARGS);
-    case 8: return launch_ring<64, 128, 2, 4, 3>(DEER_ARGS);
-    case 9: return launch_ring<32, 64, 2, 2, 6>(DEER_ARGS);
-    case 10: return launch_ring<128, 128, 2, 4, 3>(DEER_ARGS);
-    case 12: return launch_ring<64, 64, 2, 4, 6, 0, 2>(DEER_ARGS);   // two K-steps per barrier
-    case 13: return launch_ring<64, 64, 2, 4, 8, 0, 2>(DEER_ARGS);
-    case 14: return launch_ring<64, 64, 2, 4, 8, 0, 4>(DEER_ARGS);   // four K-steps per barrier
-    case 15: return launch_ring<64, 128, 2, 4, 4, 0, 2>(DEER_ARGS);
-    case 16: return launch_ring<64, 64, 2, 4, 4, 0, 2>(DEER_ARGS);
-    case 17: return launch_ring<128, 128, 4, 4, 2>(DEER_ARGS);       // shallow ring, two workgroups per CU (64 KB LDS each)
+    case 1: return launch_tiled<F16, 64, 64>(DEER_ARGS);
+    case 2: return launch_tiled<F16, 64, 128>(DEER_ARGS);
+    case 3: return launch_tiled<F16, 128, 128>(DEER_ARGS);
+    case 4: return launch_ring<F16, 64, 64, 2, 4, 4>(DEER_ARGS);
+    case 5: return launch_ring<F16, 128, 64, 4, 2, 3>(DEER_ARGS);
+    case 6: return launch_ring<F16, 64, 64, 4, 4, 6>(DEER_ARGS);
+    case 7: return launch_ring<F16, 128, 128, 4, 4, 3>(DEER_ARGS);
+    case 8: return launch_ring<F16, 64, 128, 2, 4, 3>(DEER_ARGS);
+    case 9: return launch_ring<F16, 32, 64, 2, 2, 6>(DEER_ARGS);
+    case 10: return launch_ring<F16, 128, 128, 2, 4, 3>(DEER_ARGS);
+    case 12: return launch_ring<F16, 64, 64, 2, 4, 6, 0, 2>(DEER_ARGS);   // two K-steps per barrier
+    case 13: return launch_ring<F16, 64, 64, 2, 4, 8, 0, 2>(DEER_ARGS);
+    case 14: return launch_ring<F16, 64, 64, 2, 4, 8, 0, 4>(DEER_ARGS);   // four K-steps per barrier
+    case 15: return launch_ring<F16, 64, 128, 2, 4, 4, 0, 2>(DEER_ARGS);
+    case 16: return launch_ring<F16, 64, 64, 2, 4, 4, 0, 2>(DEER_ARGS);
+    case 17: return launch_ring<F16, 128, 128, 4, 4, 2>(DEER_ARGS);       // shallow ring, two workgroups per CU (64 KB LDS each)
     // 64x64 WAVE tiles (4x4 MFMA tiles per wave): one ds_read_b128 per two MFMAs instead of one per MFMA - the 32x32 wave tiles of
     // tiles 7/17 spend as many LDS cycles on fragment reads as the SIMDs spend on MFMAs (16 waves x 4 reads x 4 clk = 4 x 4 MFMAs x 16 clk)
-    case 18: return launch_ring<128, 128, 2, 2, 2>(DEER_ARGS);       // 4 waves, 64 KB: two workgroups per CU
-    case 19: return launch_ring<128, 128, 2, 2, 4>(DEER_ARGS);       // 4 waves, 128 KB ring
-    case 20: return launch_ring<256, 128, 4, 2, 3>(DEER_ARGS);       // 8 waves, 144 KB ring
-    case 21: return launch_ring<256, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves, 96 KB
-    case 22: return launch_ring<128, 256, 2, 4, 3>(DEER_ARGS);       // 8 waves, 144 KB ring
-    case 23: return launch_ring<256, 256, 4, 4, 2>(DEER_ARGS);       // 16 waves, 128 KB
-    case 25: return launch_ring<128, 128, 2, 2, 3>(DEER_ARGS);       // 4 waves, 96 KB
-    case 27: return launch_ring<128, 128, 2, 4, 2>(DEER_ARGS);       // 8 waves (64x32 wave tiles), 64 KB: two workgroups per CU
-    case 28: return launch_ring<128, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves (32x64 wave tiles), 64 KB
-    case 29: return launch_ring<128, 256, 2, 4, 2>(DEER_ARGS);       // 8 waves (64x64), 96 KB
-    case 30: return launch_ring<256, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves (64x64), 96 KB
-    case 32: return launch_ring<256, 256, 2, 4, 2>(DEER_ARGS);       // 8 waves, 128x64 wave tiles (64 MFMAs per wave per barrier), 128 KB
-    case 33: return launch_ring<256, 128, 2, 4, 3>(DEER_ARGS);       // 8 waves, 128x32 wave tiles, 144 KB ring
+    case 18: return launch_ring<F16, 128, 128, 2, 2, 2>(DEER_ARGS);       // 4 waves, 64 KB: two workgroups per CU
+    case 19: return launch_ring<F16, 128, 128, 2, 2, 4>(DEER_ARGS);       // 4 waves, 128 KB ring
+    case 20: return launch_ring<F16, 256, 128, 4, 2, 3>(DEER_ARGS);       // 8 waves, 144 KB ring
+    case 21: return launch_ring<F16, 256, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves, 96 KB
+    case 22: return launch_ring<F16, 128, 256, 2, 4, 3>(DEER_ARGS);       // 8 waves, 144 KB ring
+    case 23: return launch_ring<F16, 256, 256, 4, 4, 2>(DEER_ARGS);       // 16 waves, 128 KB
+    case 25: return launch_ring<F16, 128, 128, 2, 2, 3>(DEER_ARGS);       // 4 waves, 96 KB
+    case 27: return launch_ring<F16, 128, 128, 2, 4, 2>(DEER_ARGS);       // 8 waves (64x32 wave tiles), 64 KB: two workgroups per CU
+    case 28: return launch_ring<F16, 128, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves (32x64 wave tiles), 64 KB
+    case 29: return launch_ring<F16, 128, 256, 2, 4, 2>(DEER_ARGS);       // 8 waves (64x64), 96 KB
+    case 30: return launch_ring<F16, 256, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves (64x64), 96 KB
+    case 32: return launch_ring<F16, 256, 256, 2, 4, 2>(DEER_ARGS);       // 8 waves, 128x64 wave tiles (64 MFMAs per wave per barrier), 128 KB
+    case 33: return launch_ring<F16, 256, 128, 2, 4, 3>(DEER_ARGS);       // 8 waves, 128x32 wave tiles, 144 KB ring
     // row tiles that are NOT a power of two: M = 257 * images is always "a power of two plus a bit" (2056, 4112), so 128-row tiles end
     // in a nearly empty extra row of workgroups (17 x 32 = 544 for the fc1 of 8 images: one more than the 512 co-resident slots)
-    case 35: return launch_ring<160, 128, 2, 2, 2>(DEER_ARGS);       // 4 waves (80x64 wave tiles), 72 KB: two workgroups per CU
-    case 36: return launch_ring<160, 128, 2, 2, 3>(DEER_ARGS);       // same, 108 KB ring
-    case 37: return launch_ring<160, 64, 2, 2, 2>(DEER_ARGS);        // 4 waves (80x32), 56 KB
-    case 38: return launch_ring<192, 128, 2, 2, 2>(DEER_ARGS);       // 4 waves (96x64), 80 KB
-    case 39: return launch_ring<192, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves (48x64), 80 KB
-    case 40: return launch_ring<192, 128, 2, 4, 2>(DEER_ARGS);       // 8 waves (96x32), 80 KB
-    case 41: return launch_ring<96, 128, 2, 2, 2>(DEER_ARGS);        // 4 waves (48x64), 56 KB
-    case 42: return launch_ring<192, 64, 4, 1, 2>(DEER_ARGS);        // 4 waves (48x64), 64 KB
-    case 43: return launch_ring<128, 192, 2, 4, 2>(DEER_ARGS);       // 8 waves (64x48), 80 KB
-    case 45: return launch_ring<128, 192, 4, 2, 2>(DEER_ARGS);       // 8 waves (32x96), 80 KB
-    case 46: return launch_ring<96, 128, 2, 2, 3>(DEER_ARGS);        // 4 waves (48x64), 84 KB
+    case 35: return launch_ring<F16, 160, 128, 2, 2, 2>(DEER_ARGS);       // 4 waves (80x64 wave tiles), 72 KB: two workgroups per CU
+    case 36: return launch_ring<F16, 160, 128, 2, 2, 3>(DEER_ARGS);       // same, 108 KB ring
+    case 37: return launch_ring<F16, 160, 64, 2, 2, 2>(DEER_ARGS);        // 4 waves (80x32), 56 KB
+    case 38: return launch_ring<F16, 192, 128, 2, 2, 2>(DEER_ARGS);       // 4 waves (96x64), 80 KB
+    case 39: return launch_ring<F16, 192, 128, 4, 2, 2>(DEER_ARGS);       // 8 waves (48x64), 80 KB
+    case 40: return launch_ring<F16, 192, 128, 2, 4, 2>(DEER_ARGS);       // 8 waves (96x32), 80 KB
+    case 41: return launch_ring<F16, 96, 128, 2, 2, 2>(DEER_ARGS);        // 4 waves (48x64), 56 KB
+    case 42: return launch_ring<F16, 192, 64, 4, 1, 2>(DEER_ARGS);        // 4 waves (48x64), 64 KB
+    case 43: return launch_ring<F16, 128, 192, 2, 4, 2>(DEER_ARGS);       // 8 waves (64x48), 80 KB
+    case 45: return launch_ring<F16, 128, 192, 4, 2, 2>(DEER_ARGS);       // 8 waves (32x96), 80 KB
+    case 46: return launch_ring<F16, 96, 128, 2, 2, 3>(DEER_ARGS);        // 4 waves (48x64), 84 KB
     case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59: case 60: case 61: case 62:            // 16 waves, 32-column K-steps, deep ring (csrc/gemm_bigm.hip)
     case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71:                                     // one camera frame per row tile, balanced (csrc/gemm_bigm.hip)
     case 72: case 73:                                                                                                    // half a frame per row tile
     case 74: case 75:                                                                                                    // frame8: one frame per row tile on eight waves (round 5)
-      return deer_launch_gemm_ring32(tile - 51, DEER_ARGS);
-    case 26: return launch_ring<64, 64, 2, 4, 4, 0, 1, 1>(DEER_ARGS);    // register-pipelined K loop (fragments of k+1 read under the MFMAs of k)
-    case 24: return launch_ring<64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)
-    case 34: return launch_ring<64, 64, 2, 4, 4, 2>(DEER_ARGS);
-    case 44: return launch_ring<64, 64, 2, 4, 8>(DEER_ARGS);      // deeper ring
+      return deer_launch_gemm_ring32<F16>(tile - 51, DEER_ARGS);
+    case 26: return launch_ring<F16, 64, 64, 2, 4, 4, 0, 1, 1>(DEER_ARGS);    // register-pipelined K loop (fragments of k+1 read under the MFMAs of k)
+    case 24: return launch_ring<F16, 64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)
+    case 34: return launch_ring<F16, 64, 64, 2, 4, 4, 2>(DEER_ARGS);
+    case 44: return launch_ring<F16, 64, 64, 2, 4, 8>(DEER_ARGS);      // deeper ring
     default: return DEER_ERR_SHAPE;
   }
 #undef DEER_ARGS
@@ -523,14 +526,14 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
 extern "C" int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const void* W, int ldw, const float* bias,
                                  void* C, int ldc, long strideC, int M, int N, int K, int batch, int epi,
                                  const float* gate, int tile, const int* ctl, void* stream) {
-  return gemm_dispatch(A, lda, strideA, W, ldw, 0, bias, C, ldc, strideC, M, N, K, batch, epi, gate, tile, ctl, stream);
+  return gemm_dispatch<false>(A, lda, strideA, W, ldw, 0, bias, C, ldc, strideC, M, N, K, batch, epi, gate, tile, ctl, stream);
 }
 
 // Batched form with a per-batch weight: C[z] = A[z] * W[z]^T (Perceiver to_kv of all layers on their own norm_media output).
 extern "C" int deer_gemm_bf16_nt_wbatch(const void* A, int lda, long strideA, const void* W, int ldw, long strideW,
                                         const float* bias, void* C, int ldc, long strideC, int M, int N, int K, int batch,
                                         int epi, int tile, const int* ctl, void* stream) {
-  return gemm_dispatch(A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, batch, epi, nullptr, tile, ctl, stream);
+  return gemm_dispatch<false>(A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, batch, epi, nullptr, tile, ctl, stream);
 }
 
 // Split-K form for the latency-bound shapes (few output tiles, long K: ViT c_proj 514x1024x4096 leaves 112 CUs idle
@@ -540,6 +543,32 @@ extern "C" int deer_gemm_bf16_nt_splitk(const void* A, int lda, const void* W, i
                                         int splitk, int tile, const int* ctl, void* stream) {
   if (splitk <= 0 || K % splitk != 0 || ((K / splitk) & 7)) return DEER_ERR_SHAPE;
   const int ks = K / splitk;
-  return gemm_dispatch(A, lda, ks, W, ldw, ks, nullptr, slab, N, (long)M * N, M, N, ks, splitk, EPI_F32, nullptr, tile, ctl,
+  return gemm_dispatch<false>(A, lda, ks, W, ldw, ks, nullptr, slab, N, (long)M * N, M, N, ks, splitk, EPI_F32, nullptr, tile, ctl,
+                       stream);
+}
+
+// ---- the same three entry points on fp16 operands (round 6: the vision tower's fp16 arithmetic = the reference's amp run).  A, W fp16;
+// epi DEER_EPI_BF16 / QGELU / GELU store fp16, DEER_EPI_BF16OUT stores bf16 (media K/V for the trunk's x-attn) -----------------------
+extern "C" int deer_gemm_f16_nt(const void* A, int lda, long strideA, const void* W, int ldw, const float* bias,
+                                 void* C, int ldc, long strideC, int M, int N, int K, int batch, int epi,
+                                 const float* gate, int tile, const int* ctl, void* stream) {
+  return gemm_dispatch<true>(A, lda, strideA, W, ldw, 0, bias, C, ldc, strideC, M, N, K, batch, epi, gate, tile, ctl, stream);
+}
+
+// Batched form with a per-batch weight: C[z] = A[z] * W[z]^T (Perceiver to_kv of all layers on their own norm_media output).
+extern "C" int deer_gemm_f16_nt_wbatch(const void* A, int lda, long strideA, const void* W, int ldw, long strideW,
+                                        const float* bias, void* C, int ldc, long strideC, int M, int N, int K, int batch,
+                                        int epi, int tile, const int* ctl, void* stream) {
+  return gemm_dispatch<true>(A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, batch, epi, nullptr, tile, ctl, stream);
+}
+
+// Split-K form for the latency-bound shapes (few output tiles, long K: ViT c_proj 514x1024x4096 leaves 112 CUs idle
+// for 64 K-steps): slab[s][M][N] (f32) = A[:, Ks] * W[:, Ks]^T, s = 0..splitk-1, reduced by the consumer
+// (deer_resadd_ln, which also adds the bias) - deterministic, no atomics.
+extern "C" int deer_gemm_f16_nt_splitk(const void* A, int lda, const void* W, int ldw, float* slab, int M, int N, int K,
+                                        int splitk, int tile, const int* ctl, void* stream) {
+  if (splitk <= 0 || K % splitk != 0 || ((K / splitk) & 7)) return DEER_ERR_SHAPE;
+  const int ks = K / splitk;
+  return gemm_dispatch<true>(A, lda, ks, W, ldw, ks, nullptr, slab, N, (long)M * N, M, N, ks, splitk, EPI_F32, nullptr, tile, ctl,
                        stream);
 }

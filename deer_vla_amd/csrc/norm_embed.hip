@@ -8,6 +8,7 @@
 // Row r of batch b is read at  x + b*in_bstride + r*in_rstride  and written at  out + b*out_bstride + r*out_rstride
 // (lets the Perceiver write LN_media(x) and LN_latents(latents) into one [x; latents] buffer, helpers.py:51).
 // one workgroup per row; the row lives in registers (float4 per thread), two block reductions.
+template <bool F16>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, long in_rstride, long in_bstride,
                                                       int rows_per_batch, int total_rows, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, bf16_t* __restrict__ out_bf,
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
           const float4 bt = *reinterpret_cast<const float4*>(bt_ + (long)i4 * 4);
           y.x += bt.x; y.y += bt.y; y.z += bt.z; y.w += bt.w;
         }
-        if (out_bf != nullptr) *reinterpret_cast<uint2*>(out_bf + o + (long)i4 * 4) = uint2{pack2bf(y.x, y.y), pack2bf(y.z, y.w)};
+        if (out_bf != nullptr) *reinterpret_cast<uint2*>(out_bf + o + (long)i4 * 4) = uint2{pack2x<F16>(y.x, y.y), pack2x<F16>(y.z, y.w)};
         if (out_f32 != nullptr) *reinterpret_cast<float4*>(out_f32 + o + (long)i4 * 4) = y;
       }
     }
@@ -69,7 +70,7 @@ extern "C" int deer_layernorm_rows(const float* x, long in_rstride, long in_bstr
       (out_bf16 == nullptr && out_f32 == nullptr) || (in_rstride & 3) || (in_bstride & 3) || (out_rstride & 3) || (out_bstride & 3))
     return DEER_ERR_SHAPE;
   const int total = rows_per_batch * batch;
-  hipLaunchKernelGGL(ln_rows_kernel, dim3(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(ln_rows_kernel<false>, dim3(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      x, in_rstride, in_bstride, rows_per_batch, total, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16),
                      out_f32, out_rstride, out_bstride, C, eps, 1, 0L, 0L);
   DEER_LAUNCH_CHECK();
@@ -88,7 +89,42 @@ extern "C" int deer_layernorm_rows_multi(const float* x, long in_rstride, long i
       (out_bstride & 3))
     return DEER_ERR_SHAPE;
   const int total = rows_per_batch * batch;
-  hipLaunchKernelGGL(ln_rows_kernel, dim3(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(ln_rows_kernel<false>, dim3(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     x, in_rstride, in_bstride, rows_per_batch, total, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16),
+                     (float*)nullptr, out_rstride, out_bstride, C, eps, n_sets, param_stride, out_set_stride);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// ---- the same two entry points with the 16-bit output in fp16 (round 6: the vision tower's fp16 arithmetic; the argument is still called
+// out_bf16) ----
+extern "C" int deer_layernorm_rows_f16(const float* x, long in_rstride, long in_bstride, int rows_per_batch, int batch,
+                                   const float* gamma, const float* beta, void* out_bf16, float* out_f32,
+                                   long out_rstride, long out_bstride, int C, float eps, void* stream) {
+  if (rows_per_batch <= 0 || batch <= 0 || C <= 0 || (C & 3) || C > 4096 || gamma == nullptr ||
+      (out_bf16 == nullptr && out_f32 == nullptr) || (in_rstride & 3) || (in_bstride & 3) || (out_rstride & 3) || (out_bstride & 3))
+    return DEER_ERR_SHAPE;
+  const int total = rows_per_batch * batch;
+  hipLaunchKernelGGL(ln_rows_kernel<true>, dim3(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     x, in_rstride, in_bstride, rows_per_batch, total, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16),
+                     out_f32, out_rstride, out_bstride, C, eps, 1, 0L, 0L);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+// One pass of statistics, n_sets affine outputs: out[s] = LN(x) * gamma[s] + beta[s] (gamma/beta rows param_stride apart,
+// outputs out_set_stride apart).  The Perceiver applies a different norm_media to the SAME media tokens in each of its
+// layers (helpers.py:47), so all of them are produced up front.
+extern "C" int deer_layernorm_rows_multi_f16(const float* x, long in_rstride, long in_bstride, int rows_per_batch, int batch,
+                                         const float* gamma, const float* beta, int n_sets, long param_stride, void* out_bf16,
+                                         long out_set_stride, long out_rstride, long out_bstride, int C, float eps,
+                                         void* stream) {
+  if (rows_per_batch <= 0 || batch <= 0 || C <= 0 || (C & 3) || C > 4096 || gamma == nullptr || out_bf16 == nullptr ||
+      n_sets <= 0 || (param_stride & 3) || (out_set_stride & 3) || (in_rstride & 3) || (in_bstride & 3) || (out_rstride & 3) ||
+      (out_bstride & 3))
+    return DEER_ERR_SHAPE;
+  const int total = rows_per_batch * batch;
+  hipLaunchKernelGGL(ln_rows_kernel<true>, dim3(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      x, in_rstride, in_bstride, rows_per_batch, total, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16),
                      (float*)nullptr, out_rstride, out_bstride, C, eps, n_sets, param_stride, out_set_stride);
   DEER_LAUNCH_CHECK();
@@ -100,7 +136,7 @@ extern "C" int deer_layernorm_rows_multi(const float* x, long in_rstride, long i
 // residual update (helpers.py:267-279: x + tanh(gate) * y; MPT block: x + y) and the following LayerNorm.
 #include "resadd_body.h"
 
-template <int NT>
+template <int NT, bool F16 = false>
 __global__ __launch_bounds__(NT) void resadd_ln_kernel(float* __restrict__ x, const float* __restrict__ slab, int s_in,
                                                        long slab_stride, const float* __restrict__ gate,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -109,7 +145,7 @@ __global__ __launch_bounds__(NT) void resadd_ln_kernel(float* __restrict__ x, co
                                                        const float* __restrict__ bias, bf16_t* __restrict__ out_lo, int packed = 0,
                                                        deer_rowmap rm = deer_rowmap{nullptr, 0, nullptr, nullptr, nullptr, 0, 0}) {
   DEER_RETURN_IF_EXITED(ctl);
-  resadd_ln_body<NT>(x, slab, s_in, slab_stride, gate, gamma, beta, out_bf, out_f32, x_copy, d, eps, ctl, bias, out_lo, packed, rm, blockIdx.x);
+  resadd_ln_body<NT, F16>(x, slab, s_in, slab_stride, gate, gamma, beta, out_bf, out_f32, x_copy, d, eps, ctl, bias, out_lo, packed, rm, blockIdx.x);
 }
 
 // ---- the same row op for the env-batch vision tower (thousands of 1024-wide rows): R rows per workgroup ----------------------------
@@ -137,7 +173,7 @@ __device__ __forceinline__ void block_sum_rows(float (&v)[R], float* red) {   //
   }
 }
 
-template <int R>
+template <int R, bool F16>
 __global__ __launch_bounds__(256) void resadd_ln_multirow_kernel(float* __restrict__ x, const float* __restrict__ slab, int s_in, long slab_stride,
                                                                  const float* __restrict__ gate, const float* __restrict__ bias,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -187,24 +223,47 @@ __global__ __launch_bounds__(256) void resadd_ln_multirow_kernel(float* __restri
     const float rstd = rsqrtf(q[r] / D + eps);
     float4 y = ln_norm4(v[r], mean[r], rstd, g);
     if (beta != nullptr) y = ln_add4(y, bb);
-    *reinterpret_cast<uint2*>(out_bf + off[r]) = uint2{pack2bf(y.x, y.y), pack2bf(y.z, y.w)};
+    *reinterpret_cast<uint2*>(out_bf + off[r]) = uint2{pack2x<F16>(y.x, y.y), pack2x<F16>(y.z, y.w)};
   }
 }
 
-// rows_per_wg: 2 or 4.  d must be 1024, out bf16; no control block (the vision tower runs before the first exit check).
-extern "C" int deer_resadd_ln_multirow(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
-                                       const float* gamma, const float* beta, void* out_bf16, int T, int d, float eps, int rows_per_wg,
-                                       void* stream) {
+// rows_per_wg: 2 or 4.  d must be 1024, out bf16 (fp16 when F16); no control block (the vision tower runs before the first exit check).
+template <bool F16>
+static int resadd_ln_multirow(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
+                              const float* gamma, const float* beta, void* out_bf16, int T, int d, float eps, int rows_per_wg, void* stream) {
   if (T <= 0 || d != 1024 || x == nullptr || (slab != nullptr && s_in <= 0) || (gamma != nullptr && out_bf16 == nullptr) ||
       (rows_per_wg != 2 && rows_per_wg != 4))
     return DEER_ERR_SHAPE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (rows_per_wg == 2)
-    hipLaunchKernelGGL(resadd_ln_multirow_kernel<2>, dim3((T + 1) / 2), dim3(256), 0, st, x, slab, s_in, slab_stride, gate, bias, gamma, beta,
+    hipLaunchKernelGGL((resadd_ln_multirow_kernel<2, F16>), dim3((T + 1) / 2), dim3(256), 0, st, x, slab, s_in, slab_stride, gate, bias, gamma, beta,
                        reinterpret_cast<bf16_t*>(out_bf16), eps, T);
   else
-    hipLaunchKernelGGL(resadd_ln_multirow_kernel<4>, dim3((T + 3) / 4), dim3(256), 0, st, x, slab, s_in, slab_stride, gate, bias, gamma, beta,
+    hipLaunchKernelGGL((resadd_ln_multirow_kernel<4, F16>), dim3((T + 3) / 4), dim3(256), 0, st, x, slab, s_in, slab_stride, gate, bias, gamma, beta,
                        reinterpret_cast<bf16_t*>(out_bf16), eps, T);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
+extern "C" int deer_resadd_ln_multirow(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
+                                       const float* gamma, const float* beta, void* out_bf16, int T, int d, float eps, int rows_per_wg,
+                                       void* stream) {
+  return resadd_ln_multirow<false>(x, slab, s_in, slab_stride, gate, bias, gamma, beta, out_bf16, T, d, eps, rows_per_wg, stream);
+}
+
+template <bool F16>
+static int resadd_ln(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias, const float* gamma,
+                     const float* beta, void* out_bf16, float* out_f32, float* x_copy, int T, int d, float eps, const int* ctl, void* stream) {
+  if (T <= 0 || d <= 0 || (d & 3) || d > 4096 || (slab != nullptr && s_in <= 0) ||
+      (gamma != nullptr && out_bf16 == nullptr && out_f32 == nullptr))
+    return DEER_ERR_SHAPE;
+  // env-batch vision rows: several rows per workgroup (bit-identical per row; DEER_RESADD_ROWS=1 keeps the one-row kernel, 2 / 4 force R)
+  static const int rows_knob = [] { const char* e = getenv("DEER_RESADD_ROWS"); return e ? atoi(e) : 0; }();
+  if (d == 1024 && T >= 2048 && out_f32 == nullptr && x_copy == nullptr && ctl == nullptr && rows_knob != 1 && (slab != nullptr || gamma != nullptr))
+    return resadd_ln_multirow<F16>(x, slab, s_in, slab_stride, gate, bias, gamma, beta, out_bf16, T, d, eps, rows_knob == 4 ? 4 : 2, stream);
+  hipLaunchKernelGGL((resadd_ln_kernel<256, F16>), dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in,
+                     slab_stride, gate, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl, bias,
+                     static_cast<bf16_t*>(nullptr), 0, deer_rowmap{nullptr, 0, nullptr, nullptr, nullptr, 0, 0});
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
@@ -212,18 +271,14 @@ extern "C" int deer_resadd_ln_multirow(float* x, const float* slab, int s_in, lo
 extern "C" int deer_resadd_ln(float* x, const float* slab, int s_in, long slab_stride, const float* gate,
                               const float* bias, const float* gamma, const float* beta, void* out_bf16, float* out_f32, float* x_copy, int T,
                               int d, float eps, const int* ctl, void* stream) {
-  if (T <= 0 || d <= 0 || (d & 3) || d > 4096 || (slab != nullptr && s_in <= 0) ||
-      (gamma != nullptr && out_bf16 == nullptr && out_f32 == nullptr))
-    return DEER_ERR_SHAPE;
-  // env-batch vision rows: several rows per workgroup (bit-identical per row; DEER_RESADD_ROWS=1 keeps the one-row kernel, 2 / 4 force R)
-  static const int rows_knob = [] { const char* e = getenv("DEER_RESADD_ROWS"); return e ? atoi(e) : 0; }();
-  if (d == 1024 && T >= 2048 && out_f32 == nullptr && x_copy == nullptr && ctl == nullptr && rows_knob != 1 && (slab != nullptr || gamma != nullptr))
-    return deer_resadd_ln_multirow(x, slab, s_in, slab_stride, gate, bias, gamma, beta, out_bf16, T, d, eps, rows_knob == 4 ? 4 : 2, stream);
-  hipLaunchKernelGGL(resadd_ln_kernel<256>, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in,
-                     slab_stride, gate, gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl, bias,
-                     static_cast<bf16_t*>(nullptr));
-  DEER_LAUNCH_CHECK();
-  return DEER_OK;
+  return resadd_ln<false>(x, slab, s_in, slab_stride, gate, bias, gamma, beta, out_bf16, out_f32, x_copy, T, d, eps, ctl, stream);
+}
+
+// the same with the 16-bit LayerNorm output in fp16 (round 6: the vision tower's fp16 arithmetic)
+extern "C" int deer_resadd_ln_f16(float* x, const float* slab, int s_in, long slab_stride, const float* gate,
+                                  const float* bias, const float* gamma, const float* beta, void* out_f16, float* out_f32, float* x_copy, int T,
+                                  int d, float eps, const int* ctl, void* stream) {
+  return resadd_ln<true>(x, slab, s_in, slab_stride, gate, bias, gamma, beta, out_f16, out_f32, x_copy, T, d, eps, ctl, stream);
 }
 
 // deer_resadd_ln with the LayerNorm output ALSO as two bf16 planes hi = bf16(y), lo = bf16(y - hi) (the pre-split activation operand
@@ -267,9 +322,11 @@ extern "C" int deer_resadd_ln_packed(float* x, const float* slab, int s_in, long
   return DEER_OK;
 }
 
-// ---- ViT patch embedding, step 1: im2col of 14x14/14 patches -> bf16 [N*P, Kpad] -----------------------
+// ---- ViT patch embedding, step 1: im2col of 14x14/14 patches -> 16-bit [N*P, Kpad] -----------------------
 // k = ch*p*p + py*p + px matches conv1.weight[W,3,p,p].reshape(W, 3*p*p); columns >= 3*p*p are zero.
-__global__ void im2col_kernel(const void* __restrict__ img, int img_is_bf16, int N, int S, int p, int gw,
+// img_kind: 0 = f32 frames, 1 = bf16, 2 = fp16; OUT_F16: patches in fp16 (else bf16).  Same-format frames are copied bit for bit.
+template <bool OUT_F16>
+__global__ void im2col_kernel(const void* __restrict__ img, int img_kind, int N, int S, int p, int gw,
                               bf16_t* __restrict__ out, int Kpad) {
   const long total = (long)N * gw * gw * Kpad;
   const int kk = 3 * p * p;
@@ -283,22 +340,37 @@ __global__ void im2col_kernel(const void* __restrict__ img, int img_is_bf16, int
       const int gy = pi / gw, gx = pi - gy * gw;
       const int ch = k / (p * p), rem = k - ch * p * p, py = rem / p, px = rem - py * p;
       const long src = (((long)n * 3 + ch) * S + (gy * p + py)) * S + gx * p + px;
-      v = img_is_bf16 ? reinterpret_cast<const bf16_t*>(img)[src] : f2bf(reinterpret_cast<const float*>(img)[src]);
+      if (img_kind == (OUT_F16 ? 2 : 1)) v = reinterpret_cast<const bf16_t*>(img)[src];
+      else {
+        const float f = img_kind == 0 ? reinterpret_cast<const float*>(img)[src]
+                                      : (img_kind == 1 ? bf2f(reinterpret_cast<const bf16_t*>(img)[src]) : h2f(reinterpret_cast<const bf16_t*>(img)[src]));
+        v = f2x<OUT_F16>(f);
+      }
     }
     out[idx] = v;
   }
 }
 
-extern "C" int deer_vit_im2col(const void* img, int img_is_bf16, int N, int S, int patch, void* out, int Kpad,
-                               void* stream) {
-  if (N <= 0 || S <= 0 || patch <= 0 || S % patch != 0 || Kpad < 3 * patch * patch) return DEER_ERR_SHAPE;
+template <bool OUT_F16>
+static int vit_im2col(const void* img, int img_kind, int N, int S, int patch, void* out, int Kpad, void* stream) {
+  if (N <= 0 || S <= 0 || patch <= 0 || S % patch != 0 || Kpad < 3 * patch * patch || img_kind < 0 || img_kind > 2) return DEER_ERR_SHAPE;
   const int gw = S / patch;
   const long total = (long)N * gw * gw * Kpad;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), img, img_is_bf16,
+  hipLaunchKernelGGL(im2col_kernel<OUT_F16>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), img, img_kind,
                      N, S, patch, gw, reinterpret_cast<bf16_t*>(out), Kpad);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
+}
+
+extern "C" int deer_vit_im2col(const void* img, int img_is_bf16, int N, int S, int patch, void* out, int Kpad,
+                               void* stream) {
+  return vit_im2col<false>(img, img_is_bf16 ? 1 : 0, N, S, patch, out, Kpad, stream);
+}
+
+// fp16 patches (round 6); img_kind: 0 = f32 frames, 1 = bf16, 2 = fp16
+extern "C" int deer_vit_im2col_f16(const void* img, int img_kind, int N, int S, int patch, void* out, int Kpad, void* stream) {
+  return vit_im2col<true>(img, img_kind, N, S, patch, out, Kpad, stream);
 }
 
 // ---- ViT patch embedding, step 2: [cls ; patches] + positional embedding, then ln_pre ----

@@ -113,10 +113,11 @@ class DeerEngine:
     workspace) and the pinned host buffers, ingests the reference state dict by name, and feeds the step to the GPU as HIP-graph
     pieces.  The kernel ORDER of every piece lives in the C++ model object; nothing here touches a kernel directly."""
     LOOKAHEAD = 1        # trunk layers the host keeps in flight beyond an undecided exit check
+    DEFAULT_TOWER = "fp16"   # 16-bit format of the vision tower in the product arithmetic (see __init__)
 
     def __init__(self, cfg: DeerConfig, state_dict: Optional[Dict[str, torch.Tensor]], device="cuda", max_text_len: int = 32,
                  n_envs: int = 1, threshold_type: str = "L2", leq: bool = True, segmented: bool = True, precision: str = "bf16",
-                 weights_from: Optional["DeerEngine"] = None):
+                 weights_from: Optional["DeerEngine"] = None, tower: Optional[str] = None):
         """n_envs: independent environments evaluated per control step (one "env batch" per rank).  They share every
         weight read: the ViT sees M = 514*n_envs rows, the LLM n_envs*T rows, each environment keeps its own LSTM state,
         thresholds are shared and every environment exits at its own layer (device side)."""
@@ -134,14 +135,23 @@ class DeerEngine:
         # hi/lo-plane trunk GEMM runs them in blocks of 128), 128 in the fp32 arithmetic (one launch of deer_gemm_skinny)
         self.MAX_ROWS = abi.max_trunk_rows(cfg, precision)
         self.max_T = min(max_text_len, self.MAX_ROWS // n_envs)
-        assert self.max_T >= 14, "n_envs * T must fit the trunk's LLM rows"
+        assert self.max_T >= 1, "n_envs * T must fit the trunk's LLM rows"      # load_inputs checks every instruction against max_T
         self._thr_type = abi.THR_TYPES[threshold_type]
         self._leq = 1 if leq else 0
         self._h = ctypes.c_void_p()
         # precision="fp32": fp32 activations everywhere (csrc/precise.hip) - the parity arithmetic of north_star's 1e-3 clause; single-
         # stream schedule, one graph per step
         self.precision = precision
-        cc = config_to_c(cfg, n_envs, self.max_T, precision=precision)
+        # tower: the 16-bit format of the vision tower (ViT-L/14, Perceiver, media K/V projection) in the product arithmetic -
+        # "fp16": IEEE fp16 operands / results on v_mfma_f32_16x16x32_f16 = the reference's evaluation arithmetic (fp32 weights under
+        # fp16 autocast, eval_utils.py:333; OpenAI CLIP weights are fp16-native), "bf16": a `--precision bf16` / amp_bf16 reference run.
+        # Same kernels, same speed; LayerNorm / softmax / residual stream f32 either way.  Default: DEER_TOWER, else DEFAULT_TOWER.
+        if tower is None:
+            tower = weights_from.tower if weights_from is not None else os.environ.get("DEER_TOWER", self.DEFAULT_TOWER)
+        if weights_from is not None and tower != weights_from.tower:
+            raise ValueError("engines over one weight arena share the tower format (the GEMM weights are stored in it)")
+        self.tower = tower if precision == "bf16" else "fp32"
+        cc = config_to_c(cfg, n_envs, self.max_T, precision=precision, tower=tower if precision == "bf16" else "bf16")
         abi.check(self.lib.deer_model_create(ctypes.byref(cc), ctypes.byref(self._h)), "deer_model_create")
         with torch.cuda.device(self.dev):
             self.workspace = torch.zeros(self.lib.deer_model_workspace_bytes(self._h), dtype=torch.uint8, device=self.dev)
@@ -225,9 +235,12 @@ class DeerEngine:
         rows = min(B * self.max_T, self.MAX_ROWS)
         self.max_rows = rows
         v = lambda name, dt: self._buf(name).view(dt)
-        self.img = v("img", torch.float32 if self.precision == "fp32" else torch.bfloat16).view(N, 3, S, S)   # static input buffer (camera frames)
+        # camera frames in the tower's operand format (fp16 keeps every 8-bit pixel level apart after CLIP normalisation; bf16 merges some)
+        self.img_dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[self.tower]
+        self.img = v("img", self.img_dtype).view(N, 3, S, S)               # static input buffer (camera frames)
         self.vx = v("vx", torch.float32).view(N, cfg.n_patches + 1, W)     # ViT residual stream (fp32)
-        self.vis_x = v("vis_x", torch.bfloat16).view(N * nl, W)            # media tokens [rgb latents ; gripper latents] per env
+        self.media_dtype = torch.float16 if self.tower == "fp16" else torch.bfloat16
+        self.vis_x = v("vis_x", self.media_dtype).view(N * nl, W)          # media tokens [rgb latents ; gripper latents] per env
         self.vis_x_f32 = v("vis_x_f32", torch.float32).view(N * nl, W)
         self.kv_all = v("kv_all", torch.bfloat16)
         self.ids = v("ids", torch.int64)
@@ -976,7 +989,8 @@ class DeerEngine:
             return self
         e = self._siblings.get((n_envs, index))
         if e is None:
-            e = DeerEngine(self.cfg, None, device=self.dev, max_text_len=self.max_T, n_envs=n_envs, weights_from=self, segmented=self.segmented, precision=self.precision)
+            e = DeerEngine(self.cfg, None, device=self.dev, max_text_len=self.max_T, n_envs=n_envs, weights_from=self, segmented=self.segmented, precision=self.precision,
+                           tower=None if self.precision != "bf16" else self.tower)
             self._siblings[(n_envs, index)] = e
         return e
 

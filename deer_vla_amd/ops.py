@@ -33,7 +33,7 @@ class NativeModel:
     ingests a reference state dict.  No orchestration here - that is the spine's; ``DeerEngine`` adds graph scheduling on top."""
 
     def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], device="cuda", n_envs: int = 1, max_text_len: int = 32,
-                 precision: str = "bf16"):
+                 precision: str = "bf16", tower: Optional[str] = None):
         if not torch.cuda.is_available():
             raise abi.DeerHipError("deer_vla_amd needs a HIP device (no CPU fallback)")
         self.lib = abi.lib()
@@ -42,7 +42,13 @@ class NativeModel:
         self.max_T = min(max_text_len, abi.max_trunk_rows(cfg, precision) // n_envs)   # the same row budget as DeerEngine (256 rows in bf16)
         self._h = ctypes.c_void_p()
         self.precision = precision
-        cc = abi.config_to_c(cfg, n_envs, self.max_T, precision=precision)
+        # 16-bit format of the vision tower and of the media tokens the operators hand around ("fp16" = the reference's amp run; engine.py)
+        import os
+        from .engine import DeerEngine
+        self.tower = (tower or os.environ.get("DEER_TOWER", DeerEngine.DEFAULT_TOWER)) if precision == "bf16" else "fp32"
+        self.img_dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[self.tower]
+        self.media_dtype = torch.float16 if self.tower == "fp16" else torch.bfloat16
+        cc = abi.config_to_c(cfg, n_envs, self.max_T, precision=precision, tower=self.tower if precision == "bf16" else "bf16")
         abi.check(self.lib.deer_model_create(ctypes.byref(cc), ctypes.byref(self._h)), "deer_model_create")
         with torch.cuda.device(self.dev):
             self.arena = torch.zeros(self.lib.deer_model_arena_bytes(self._h), dtype=torch.uint8, device=self.dev)
@@ -103,10 +109,10 @@ def _model(handle: int) -> NativeModel:
 
 @torch.library.custom_op("deer::vit_l14_encode", mutates_args=(), device_types="cuda")
 def vit_l14_encode(images: torch.Tensor, model: int) -> torch.Tensor:
-    """images (N,3,S,S) bf16/f32 CLIP-normalised -> patch tokens (N,256,W) f32 (x[:,1:], no ln_post)."""
+    """images (N,3,S,S) CLIP-normalised (any float dtype; converted to the tower's format) -> patch tokens (N,256,W) f32 (x[:,1:], no ln_post)."""
     m = _model(model)
     cfg = m.cfg
-    img = images.to(torch.float32 if getattr(m, "precision", "bf16") == "fp32" else torch.bfloat16).contiguous()
+    img = images.to(m.img_dtype).contiguous()
     out = torch.empty(img.shape[0], cfg.n_patches, cfg.vit_width, dtype=torch.float32, device=img.device)
     abi.check(m.lib.deer_vit_l14_encode(m._h, abi.ptr(img), img.shape[0], abi.ptr(out), _stream()), "deer_vit_l14_encode")
     return out
@@ -120,11 +126,11 @@ def _(images, model):
 
 @torch.library.custom_op("deer::perceiver_resample", mutates_args=(), device_types="cuda")
 def perceiver_resample(tokens: torch.Tensor, model: int) -> torch.Tensor:
-    """patch tokens (N,256,W) f32 -> media tokens (N*64, W) bf16 in frame order (rgb, gripper per environment)."""
+    """patch tokens (N,256,W) f32 -> media tokens (N*64, W) in the tower's 16-bit format (fp16 / bf16), frame order (rgb, gripper per environment)."""
     m = _model(model)
     cfg = m.cfg
     tok = tokens.to(torch.float32).contiguous()
-    out = torch.empty(tok.shape[0] * cfg.perc_latents, cfg.vit_width, dtype=torch.bfloat16, device=tok.device)
+    out = torch.empty(tok.shape[0] * cfg.perc_latents, cfg.vit_width, dtype=m.media_dtype, device=tok.device)
     abi.check(m.lib.deer_perceiver_resample(m._h, abi.ptr(tok), tok.shape[0], abi.ptr(out), None, _stream()), "deer_perceiver_resample")
     return out
 
@@ -132,13 +138,13 @@ def perceiver_resample(tokens: torch.Tensor, model: int) -> torch.Tensor:
 @perceiver_resample.register_fake
 def _(tokens, model):
     m = _model(model)
-    return tokens.new_empty((tokens.shape[0] * m.cfg.perc_latents, m.cfg.vit_width), dtype=torch.bfloat16)
+    return tokens.new_empty((tokens.shape[0] * m.cfg.perc_latents, m.cfg.vit_width), dtype=m.media_dtype)
 
 
 @torch.library.custom_op("deer::llm_early_exit", mutates_args=(), device_types="cuda")
 def llm_early_exit(ids: torch.Tensor, key_mask: Optional[torch.Tensor], media: torch.Tensor, model: int, exit_id: int,
                    shadow: bool) -> Tuple[torch.Tensor, torch.Tensor]:
-    """ids (n_envs,T) int64, key_mask (n_envs,T) or None, media (n_envs*128, W) bf16; exit_id >= 0 static, < 0 dynamic (the
+    """ids (n_envs,T) int64, key_mask (n_envs,T) or None, media (n_envs*128, W) in the tower's 16-bit format; exit_id >= 0 static, < 0 dynamic (the
     model's configured controller).  Returns (ctl int32 [n_envs,64]: exit layer, action, deltas - include/deer_hip.h -,
     hidden f32 [n_layers, n_envs*T, d]); the LSTM state of the head is carried inside the model."""
     m = _model(model)
@@ -147,7 +153,7 @@ def llm_early_exit(ids: torch.Tensor, key_mask: Optional[torch.Tensor], media: t
     T = ids_c.reshape(m.B, -1).shape[1]
     km = key_mask.to(torch.uint8).contiguous() if key_mask is not None else None
     # fp32-activation models keep their media tokens in f32 inside the model (the bf16 tensor handed around is only a view of them)
-    med = None if getattr(m, "precision", "bf16") == "fp32" else media.to(torch.bfloat16).contiguous()
+    med = None if getattr(m, "precision", "bf16") == "fp32" else media.to(m.media_dtype).contiguous()
     abi.check(m.lib.deer_llm_early_exit(m._h, abi.ptr(ids_c), abi.ptr(km), T, abi.ptr(med), exit_id, 1 if shadow else 0, None, None, _stream()),
               "deer_llm_early_exit")
     rows = min(m.B * m.max_T, abi.max_trunk_rows(cfg, getattr(m, "precision", "bf16")))

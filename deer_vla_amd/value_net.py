@@ -220,8 +220,8 @@ def generate_action_values(args, model, value_net: ActionValueNet, calvin_loader
         mask = None
         if attention_mask is not None:
             mask = attention_mask.to(eng.dev).unsqueeze(1).expand(bs, W, attention_mask.shape[-1]).reshape(bs * W, -1)
-        hid = eng.window_hidden_states(images.reshape(bs * W, 3, S, S).to(eng.dev, torch.bfloat16),
-                                       gripper.reshape(bs * W, 3, S, S).to(eng.dev, torch.bfloat16), ids, mask)
+        hid = eng.window_hidden_states(images.reshape(bs * W, 3, S, S).to(eng.dev, eng.img_dtype),
+                                       gripper.reshape(bs * W, 3, S, S).to(eng.dev, eng.img_dtype), ids, mask)
         hid = hid.view(bs, W, *hid.shape[1:])
         out.append(eng.generate_values(hid, rand_layers, value_net.threshold_type))
     return torch.cat(out, dim=1), None

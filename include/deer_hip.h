@@ -60,6 +60,7 @@ extern "C" {
 #define DEER_EPI_QGELU_BF16 2
 #define DEER_EPI_GELU_BF16 3
 #define DEER_EPI_RESADD_F32 4
+#define DEER_EPI_BF16OUT 5   /* bf16 store whatever the operand format (deer_gemm_f16_nt: fp16 tower -> bf16 media K/V for the trunk's x-attn) */
 /* skinny-GEMM A operand sources */
 #define DEER_A_BF16 0
 #define DEER_A_SLABS_GELU 1
@@ -102,6 +103,40 @@ int deer_gemm_bf16_nt_wbatch(const void* A, int lda, long strideA, const void* W
  * the consumer (deer_resadd_ln) sums the slabs, adds the bias and applies the residual + following LayerNorm. */
 int deer_gemm_bf16_nt_splitk(const void* A, int lda, const void* W, int ldw, float* slab, int M, int N, int K, int splitk,
                              int tile, const int* ctl, void* stream);
+
+/* ---- the vision tower's fp16 arithmetic (round 6) --------------------------------------------------------------------------------
+ * The reference's evaluation runs fp32 weights under fp16 autocast (robot_flamingo/eval/eval_utils.py:333 `torch.cuda.amp.autocast(enabled=
+ * self.amp)`, README.md:161-167 `--precision fp32 --amp 1`): every nn.Linear / conv of open_clip's ViT-L/14 and of the PerceiverResampler
+ * computes on fp16 operands and returns fp16, LayerNorm / softmax / residual adds run in f32.  The same kernels as the bf16 family above,
+ * instantiated on v_mfma_f32_16x16x32_f16 (same issue rate): A, W IEEE fp16; DEER_EPI_BF16 / QGELU_BF16 / GELU_BF16 store FP16 here,
+ * DEER_EPI_BF16OUT stores bf16; f32 accumulation and f32 epilogue arithmetic as before.  Same arguments, same tile codes. */
+int deer_gemm_f16_nt(const void* A, int lda, long strideA, const void* W, int ldw, const float* bias, void* C, int ldc,
+                     long strideC, int M, int N, int K, int batch, int epi, const float* gate, int tile, const int* ctl,
+                     void* stream);
+int deer_gemm_f16_nt_wbatch(const void* A, int lda, long strideA, const void* W, int ldw, long strideW, const float* bias,
+                            void* C, int ldc, long strideC, int M, int N, int K, int batch, int epi, int tile, const int* ctl,
+                            void* stream);
+int deer_gemm_f16_nt_splitk(const void* A, int lda, const void* W, int ldw, float* slab, int M, int N, int K, int splitk,
+                            int tile, const int* ctl, void* stream);
+/* deer_attn_mfma_hd64 / _2seg on fp16 q / k / v with an fp16 result (P rounded to fp16 for the P V MFMA; scores, softmax, O in f32) */
+int deer_attn_f16_hd64(const void* Q, const void* K, const void* V, void* O, int batch, int heads, int q_len, int kv_len,
+                       int ldq, int ldk, int ldv, int ldo, long q_bstride, long k_bstride, long v_bstride, long o_bstride,
+                       float scale, void* stream);
+int deer_attn_f16_hd64_2seg(const void* Q, const void* K1, const void* V1, const void* K2, const void* V2, void* O, int batch,
+                            int heads, int q_len, int kv1, int kv2, int ldq, int ld1, int ld2, int ldo, long q_bstride, long bstride1,
+                            long bstride2, long o_bstride, float scale, void* stream);
+/* deer_layernorm_rows / _multi / deer_resadd_ln with the 16-bit LayerNorm output in fp16 (the A operand of deer_gemm_f16_nt) */
+int deer_layernorm_rows_f16(const float* x, long in_rstride, long in_bstride, int rows_per_batch, int batch, const float* gamma,
+                            const float* beta, void* out_f16, float* out_f32, long out_rstride, long out_bstride, int C, float eps,
+                            void* stream);
+int deer_layernorm_rows_multi_f16(const float* x, long in_rstride, long in_bstride, int rows_per_batch, int batch,
+                                  const float* gamma, const float* beta, int n_sets, long param_stride, void* out_f16,
+                                  long out_set_stride, long out_rstride, long out_bstride, int C, float eps, void* stream);
+int deer_resadd_ln_f16(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
+                       const float* gamma, const float* beta, void* out_f16, float* out_f32, float* x_copy, int T, int d, float eps,
+                       const int* ctl, void* stream);
+/* im2col with fp16 patches; img_kind: 0 = f32 frames, 1 = bf16, 2 = fp16 (copied bit for bit) */
+int deer_vit_im2col_f16(const void* img, int img_kind, int N, int S, int patch, void* out_f16, int Kpad, void* stream);
 
 /* ---- MFMA GEMM, M <= 128 (weight-streaming): part[ks][Mpad][N] = A[:, Kslice ks] * W[:, Kslice ks]^T ------
  * Replaces the bias-free nn.Linear calls of the MPT GPTBlock (EXTERNAL; constructed mosaic_gpt_3b.py:104-106,

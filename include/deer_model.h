@@ -48,6 +48,11 @@ typedef struct deer_config {
                              * exit criterion's delta runs over all 6 A pose values (value_net.py:105-133); A <= 8 */
   int layerwise_exit_eval;  /* flamingo_mpt.py:236-244,253,450-457: per-layer heads "lm_exit_modules.j.*" / "lm_head.*" are ingested next to
                              * "extra_exit.*", each with its own LSTM state; deer_head_eval_layerwise evaluates one of them */
+  int tower_f16;            /* round 6 (precision = 0 only): 1 = the vision tower (ViT, Perceiver, media K/V projection) computes on IEEE fp16
+                             * operands with fp16 results - the reference's evaluation arithmetic (fp32 weights under fp16 autocast,
+                             * eval_utils.py:333): weights of those GEMMs are stored as fp16, the camera frames ("img") are fp16, LayerNorm /
+                             * softmax statistics and the residual stream stay f32, the media K/V leave as bf16 for the trunk's x-attn.
+                             * 0 = bf16 operands / results (a `--precision bf16` / amp_bf16 reference run). */
 } deer_config;
 
 typedef struct deer_model deer_model;
@@ -97,7 +102,8 @@ int deer_model_real_num_exit(const deer_model* m);
 /* ---- the three coarse operators of SURVEY.md §8b ------------------------------------------------------------------ */
 /* images: bf16 [n_images,3,S,S] (already CLIP-normalised); tokens_out: f32 [n_images,256,W] patch tokens (x[:,1:], no ln_post)
  * or NULL to leave them in the workspace only (the Perceiver reads them there). */
-int deer_vit_l14_encode(deer_model* m, const void* images_bf16, int n_images, float* tokens_out, void* stream);   /* images: f32 when precision = 1 */
+int deer_vit_l14_encode(deer_model* m, const void* images_bf16, int n_images, float* tokens_out, void* stream);   /* images: f32 when precision = 1, fp16 when tower_f16 */
+/* (tower_f16: every `*_bf16` media / image argument below carries IEEE fp16 instead - the tower's 16-bit format) */
 /* tokens: f32 [n_images,256,W] or NULL (= the workspace tokens of the last deer_vit_l14_encode); media_bf16_out / media_f32_out:
  * [n_images*64, W] latents of every image in image order (rgb, gripper per environment = the post-fusion concat of
  * flamingo_mpt.py:661) or NULL to leave them in the workspace. */

@@ -595,9 +595,15 @@ class OracleDeer:
     def _memo_key(self, vision_x, vision_gripper, lang_x, attention_mask):
         import json
         if not hasattr(self, "_fp"):
-            ks = sorted(self.sd)
-            self._fp = (len(ks), json.dumps(self.cfg.to_dict(), sort_keys=True, default=str),
-                        tuple(float(self.sd[k].double().sum()) for k in (ks[0], ks[len(ks) // 2], ks[-1])))
+            # fingerprint of the WHOLE state (two states that differ anywhere - e.g. synthetic.harden_state on top of a plain one - must not
+            # share entries): every tensor contributes, small ones in full, large ones through a strided sample of 4096 elements
+            acc = []
+            for k in sorted(self.sd):
+                t = self.sd[k].reshape(-1)
+                if t.numel() > (1 << 16):
+                    t = t[:: t.numel() // 4096]
+                acc.append(float(t.double().sum()) + 3.0 * float(t.double().abs().sum()))
+            self._fp = (len(acc), json.dumps(self.cfg.to_dict(), sort_keys=True, default=str), hash(tuple(acc)))
         f = lambda t: (tuple(t.shape), float(t.double().sum()), float(t.double().abs().sum()), float(t.reshape(-1)[:: max(1, t.numel() // 97)].double().sum()))
         return (self._fp, f(vision_x), f(vision_gripper), tuple(lang_x.reshape(-1).tolist()), tuple(attention_mask.reshape(-1).int().tolist()))
 

@@ -1,16 +1,17 @@
-"""Numerics on HARD inputs (VERDICT r4 weak #1c / next-3): every other parity test runs on seeded N(0, sigma^2) weights, where activations
-stay O(1).  Real CLIP / MPT / DeeR checkpoints do not: a few residual-stream channels sit 50-100x above the rest ("massive activations"),
-LayerNorm gains spread over two decades, tanh(gate) of a trained x-attn layer is near +-1, LSTM gates saturate.  ``synthetic.harden_state``
-plants those pathologies into the synthetic weights; the engine (bf16 MFMA operands in the vision tower, bf16 hi + lo activations in the
-trunk, v_exp / v_rcp QuickGELU, softmax with max-subtraction, f32 LSTM) is then held to the SAME gates as everywhere else against the
-f32 CPU oracle on the same bf16-representable weights: no inf / NaN anywhere and, at the FULL 3B size, actions within 1e-2 (measured
-9.5e-3: the easy weights give 2.7e-3).  At the TINY size the 1e-2 bound BREAKS (measured 2.1e-2 .. 2.7e-2): two outlier channels are
-1.6 % of a 128-wide residual stream (0.3 % at ViT-L's 1024) and the common-mode component they put on every GEMM output eats the bf16
-mantissa of the token-specific signal.  tools/error_budget.py says where (profiles/r05_d_error_budget_hard_weights.txt): with the
-ORACLE's ViT tokens the same step is within 1.3e-3, with the oracle's media tokens 8e-4 - it is the bf16 vision tower (qkv / c_fc
-outputs and LayerNorm outputs stored as bf16), the trunk's hi/lo split and the f32 head are not affected; precision="fp32" holds 1.3e-4.
-The tiny tests therefore gate on 5e-2 and REPORT the error and the first exit-layer flip; gpurun_out/hard_inputs_report.json holds the
-numbers DESIGN.md quotes."""
+"""Numerics on HARD inputs (VERDICT r4 weak #1c / next-3, r5 item 2): every other parity test runs on seeded N(0, sigma^2) weights, where
+activations stay O(1).  Real CLIP / MPT / DeeR checkpoints do not: a few residual-stream channels sit 50-100x above the rest ("massive
+activations"), LayerNorm gains spread over two decades, tanh(gate) of a trained x-attn layer is near +-1, LSTM gates saturate.
+``synthetic.harden_state`` plants those pathologies into the synthetic weights; the engine is then held to the SAME gates as everywhere else
+against the f32 CPU oracle on the same bf16-representable weights: no inf / NaN anywhere, actions within 1e-2, exit layers identical
+outside the knife-edge band.
+
+Round 6: with the vision tower in IEEE fp16 (the reference's evaluation arithmetic - fp32 weights under fp16 autocast, eval_utils.py:333;
+the engine's default) the gates HOLD with room: full 3B size 3.0e-3 worst over 24 steps (bf16 tower: 9.7e-3), tiny size 3.3e-3 ... 8.9e-3
+with no exit flip (bf16 tower: 1.9e-2 ... 2.7e-2 and one flip outside the band - the common-mode component an outlier channel puts on
+every GEMM output eats the 8-bit significand of bf16 LayerNorm / qkv / c_fc outputs; fp16 carries 11 bits).  The bf16 tower stays
+selectable (tower="bf16": a `--precision bf16` reference run) and keeps its round-5 gates (5e-2 tiny, 1e-2 full) as a regression bound.
+tools/tower_format.py prints both side by side (profiles/r06_c_tower_format_fp16_vs_bf16.json); gpurun_out/hard_inputs_report.json holds
+the numbers of the last run."""
 import json
 import os
 
@@ -62,8 +63,8 @@ def _oracle_episode(cfg, sd, inputs, thr):
     return out, vn.rec
 
 
-@pytest.mark.parametrize("text_len", [9, 14, 32])
-def test_hard_weights_tiny_episode_matches_oracle(text_len):
+@pytest.mark.parametrize("tower,text_len", [("fp16", 9), ("fp16", 14), ("fp16", 32), ("bf16", 14)])
+def test_hard_weights_tiny_episode_matches_oracle(tower, text_len):
     cfg = deer_tiny()
     sd = syn.harden_state(cfg, syn.make_synthetic_state(cfg, 3), seed=text_len)
     n_steps = 12
@@ -75,7 +76,7 @@ def test_hard_weights_tiny_episode_matches_oracle(text_len):
     ref, rec = _oracle_episode(cfg, sd, inputs, thr)
     ratio = max(_outlier_ratio(h) for h in ref0[0][4]["hidden_states"])
     assert ratio > 15, ratio                                     # the planted outlier channels really dominate the residual stream
-    eng = DeerEngine(cfg, sd, max_text_len=32)
+    eng = DeerEngine(cfg, sd, max_text_len=32, tower=tower)
     eng.configure_exit(cfg.exit_ids(), 12, 1)
     eng.set_thresholds(thr)
     eng.reset()
@@ -86,15 +87,19 @@ def test_hard_weights_tiny_episode_matches_oracle(text_len):
         assert torch.isfinite(r["pose"]).all() and r["gripper"] == r["gripper"]
         torch.cuda.synchronize()
         assert bool(torch.isfinite(eng.hidden[: r["exit_layer"] + 1, :text_len]).all()) and bool(torch.isfinite(eng.vx).all())
-        if r["exit_layer"] != ex:                                # reported, not asserted: at this size the action error reaches the margins
+        if r["exit_layer"] != ex:
             flip = dict(step=s, engine=r["exit_layer"], oracle=ex, oracle_margin=margin)
+            assert tower == "bf16" or margin <= BAND, ("exit flip outside the knife-edge band", flip)   # bf16 tower: reported (module docstring)
             break                                                # the LSTM histories diverge from here
         worst = max(worst, float((r["pose"] - pose).abs().max()), abs(r["gripper"] - g))
         seen.add(ex)
         compared += 1
-    _report(f"tiny_T{text_len}", worst_action_err=worst, first_exit_flip=flip, steps_compared=compared, outlier_ratio=ratio,
+    _report(f"tiny_T{text_len}_{tower}", worst_action_err=worst, first_exit_flip=flip, steps_compared=compared, outlier_ratio=ratio,
             min_margin=min_margin(rec, dict(zip(cfg.exit_ids(), thr))))
-    assert compared >= 2 and worst < 5e-2, (worst, flip)          # the 1e-2 bound does not hold here (module docstring); fp32 arithmetic: 1.3e-4
+    if tower == "fp16":                                           # the standard gate, every step of the episode
+        assert compared == n_steps and flip is None and worst < ACTION_TOL, (worst, flip, compared)
+    else:
+        assert compared >= 2 and worst < 5e-2, (worst, flip)      # bf16 tower: the 1e-2 bound does not hold at this size (module docstring)
 
 
 def test_hard_weights_tiny_fp32_arithmetic():
@@ -114,17 +119,21 @@ def test_hard_weights_tiny_fp32_arithmetic():
     _report("tiny_fp32", worst_action_err=worst)
 
 
-def test_hard_weights_full_size_3b_matches_oracle():
-    """FULL size (ViT-L/14 x 2, MPT-1B x 12 layers): static exits 1 / 5 / 11 with LSTM carry and a dynamic step, stage by stage"""
+@pytest.mark.parametrize("tower,n_steps,gate", [("fp16", 24, 4e-3), ("bf16", 3, ACTION_TOL)])
+def test_hard_weights_full_size_3b_matches_oracle(tower, n_steps, gate):
+    """FULL size (ViT-L/14 x 2, MPT-1B x 12 layers): static exits 11 / 5 / 1 in turn with LSTM carry, stage by stage.  fp16 tower: 24 steps,
+    worst action error 3.0e-3 measured (gate 4e-3); bf16 tower: the round-5 three steps inside 1e-2 (9.5e-3 measured)."""
     cfg = deer_3b(max_layer=12)
     base = full_size_state(cfg, 0, std="0.02", bf16_round=True)
     sd = syn.harden_state(cfg, base, seed=0)
-    eng = DeerEngine(cfg, sd)
+    eng = DeerEngine(cfg, sd, tower=tower)
     model = orc.OracleDeer(sd, cfg)
     model.set_all_exit_window_size(1)
     worst, stage = 0.0, {}
-    for s, eid in enumerate((11, 5, 1)):
-        rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, s, text_len=20 if s == 1 else 14)
+    exits = (11, 5, 1)
+    for s in range(n_steps):
+        eid = exits[s % 3]
+        rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, s, text_len=20 if s % 3 == 1 else 14)
         o = model.forward(rgb, ids, mask, grip, exit_id=eid)
         r = eng.step(rgb, grip, ids, mask, exit_id=eid, use_graph=False)
         torch.cuda.synchronize()
@@ -132,14 +141,15 @@ def test_hard_weights_full_size_3b_matches_oracle():
         assert bool(torch.isfinite(eng.vx).all()) and bool(torch.isfinite(eng.vis_x_f32).all()) and bool(torch.isfinite(eng.hidden[: eid + 1, :T]).all())
         vis, ref_vis = eng.vis_x_f32.cpu(), o["vis_x"].reshape(cfg.n_media, cfg.vit_width)
         stage[f"step{s}_media_rel"] = float((vis - ref_vis).norm() / ref_vis.norm())
-        for i in sorted({0, eid // 2, eid}):
-            a, b = eng.hidden[i, :T].cpu(), o["hidden_states"][i][0]
-            stage[f"step{s}_hidden{i}_rel"] = float((a - b).norm() / b.norm())
-            stage[f"step{s}_hidden{i}_outlier_ratio"] = _outlier_ratio(b)
+        if s < 3:
+            for i in sorted({0, eid // 2, eid}):
+                a, b = eng.hidden[i, :T].cpu(), o["hidden_states"][i][0]
+                stage[f"step{s}_hidden{i}_rel"] = float((a - b).norm() / b.norm())
+                stage[f"step{s}_hidden{i}_outlier_ratio"] = _outlier_ratio(b)
         err = max(float((r["pose"] - o["logits"][0].reshape(-1)).abs().max()), abs(r["gripper"] - float(o["logits"][1])))
         stage[f"step{s}_exit{eid}_action_err"] = err
         worst = max(worst, err)
-    _report("full_3b", worst_action_err=worst, **stage)
-    assert max(v for k, v in stage.items() if k.endswith("_rel")) < 3e-2, stage
+    _report(f"full_3b_{tower}", worst_action_err=worst, **stage)
+    assert max(v for k, v in stage.items() if k.endswith("_rel")) < (3e-2 if tower == "bf16" else 5e-3), stage
     assert max(v for k, v in stage.items() if k.endswith("outlier_ratio")) > 15, stage
-    assert worst < ACTION_TOL, (worst, stage)
+    assert worst < gate, (worst, stage)

@@ -229,10 +229,23 @@ def test_skinny_hl_producers_and_exit_flag(lib):
 
 
 # ------------------------------------------------------------------------------------------- tiled GEMM
-@pytest.mark.parametrize("tile", [17, 39, 45, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74, 75, 0])
-@pytest.mark.parametrize("M", [2056, 3084, 4112, 4096, 300])
+BIG_TILES = [17, 39, 45, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74, 75]
+# every tile on the 16-frame batch (whole frames) and on a small ragged M; the selector (tile 0) and the tiles it picks on the 8 / 12-frame
+# batches and on a power-of-two M; the fp16 instantiation (round 6: the vision tower's fp16 arithmetic) on the selector and on one tile of
+# every kernel of csrc/gemm_bigm.hip + the 128x128 ring of csrc/gemm_tiled.hip
+BIG_CASES = ([("bf16", t, M) for t in BIG_TILES for M in (4112, 300)] + [("bf16", 0, M) for M in (2056, 3084, 4112, 4096, 300)] +
+             [("bf16", t, M) for t in (17, 39, 45, 63, 64, 67) for M in (2056, 3084)] +
+             [("f16", t, M) for t in (0, 17, 39, 51, 57, 63, 64, 67, 72, 74, 75) for M in (4112, 300)] + [("f16", 0, M) for M in (2056, 3084)])
+
+
+def _fmt(dt):
+    """(torch dtype, suffix of the C entry points) of a 16-bit format of the vision tower"""
+    return (torch.float16, "f16") if dt == "f16" else (torch.bfloat16, "bf16")
+
+
+@pytest.mark.parametrize("dt,tile,M", BIG_CASES)
 @pytest.mark.parametrize("N,K,epi", [(3072, 1024, "bf16"), (4096, 1024, "qgelu"), (1024, 1024, "f32"), (1024, 4096, "f32")])
-def test_gemm_tiled_big_m_tiles(lib, tile, M, N, K, epi):
+def test_gemm_tiled_big_m_tiles(lib, dt, tile, M, N, K, epi):
     """The tiles `gemm_dispatch` auto-selects for an env batch / calibration window (M = 257 x 8 / 12 / 16 frames: 17 = 128x128 / 16
     waves, 39 = 192x128, 45 = 128x192) on the four ViT-L projection shapes, called directly AND through the selector (tile 0), against
     fp32 torch math; the ragged last row block (M % 128 = 8, 12, 16) and every epilogue the tower uses."""
@@ -240,21 +253,23 @@ def test_gemm_tiled_big_m_tiles(lib, tile, M, N, K, epi):
         pytest.skip("192-column frame tiles")
     if tile in (74, 75) and (epi == "f32" or M % 257):
         pytest.skip("frame8 tiles (eight waves, csrc/gemm_bigm.hip: gemm_frame8_kernel): whole camera frames, bf16 epilogues only")
-    A = dev(rnd(M, K, seed=61), torch.bfloat16)
-    W = dev(rnd(N, K, seed=62, scale=K ** -0.5), torch.bfloat16)
+    tdt, sfx = _fmt(dt)
+    A = dev(rnd(M, K, seed=61), tdt)
+    W = dev(rnd(N, K, seed=62, scale=K ** -0.5), tdt)
     bias = dev(rnd(N, seed=63, scale=0.1))
     ref = A.float() @ W.float().t() + bias
     e = {"bf16": abi.EPI_BF16, "qgelu": abi.EPI_QGELU_BF16, "f32": abi.EPI_F32}[epi]
-    C = torch.full((M + 8, N), float("nan"), device="cuda", dtype=torch.float32 if epi == "f32" else torch.bfloat16)
-    abi.check(lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(W), K, abi.ptr(bias), abi.ptr(C), N, 0, M, N, K, 1, e, None, tile, None, st()), "gemm")
+    C = torch.full((M + 8, N), float("nan"), device="cuda", dtype=torch.float32 if epi == "f32" else tdt)
+    abi.check(getattr(lib, f"deer_gemm_{sfx}_nt")(abi.ptr(A), K, 0, abi.ptr(W), K, abi.ptr(bias), abi.ptr(C), N, 0, M, N, K, 1, e, None, tile, None, st()), "gemm")
     torch.cuda.synchronize()
     assert torch.isnan(C[M:].float()).all()                                  # nothing written past row M
+    tol16 = 4e-3 if dt == "bf16" else 5e-4                                   # one rounding of the output: 2^-9 (bf16) / 2^-12 (fp16) relative
     if epi == "f32":
         assert rel_err(C[:M], ref) < 2e-5
     elif epi == "bf16":
-        assert rel_err(C[:M].float(), ref) < 4e-3
+        assert rel_err(C[:M].float(), ref) < tol16
     else:
-        assert rel_err(C[:M].float(), ref * torch.sigmoid(1.702 * ref)) < 4e-3
+        assert rel_err(C[:M].float(), ref * torch.sigmoid(1.702 * ref)) < (tol16 if dt == "bf16" else 1e-3)   # quick_gelu_bf: v_exp + v_rcp
 
 
 @pytest.mark.parametrize("M", [2056, 4112])
@@ -269,29 +284,35 @@ def test_gemm_tiled_big_m_splitk_halves(lib, M):
     assert rel_err(slab.sum(0), A.float() @ W.float().t()) < 2e-5
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 0])
+@pytest.mark.parametrize("dt,tile", [("bf16", t) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 0)] + [("f16", t) for t in (1, 4, 8, 16, 0)])
 @pytest.mark.parametrize("M,N,K", [(514, 3072, 1024), (514, 1024, 4096), (128, 1024, 512), (37, 128, 640), (640, 1024, 1024)])
-def test_gemm_tiled_epilogues(lib, tile, M, N, K):
-    A = dev(rnd(M, K, seed=5), torch.bfloat16)
-    W = dev(rnd(N, K, seed=6, scale=K ** -0.5), torch.bfloat16)
+def test_gemm_tiled_epilogues(lib, dt, tile, M, N, K):
+    """every epilogue of the small-M kernels in both 16-bit formats; fp16 family: DEER_EPI_BF16OUT stores bf16 (media K/V for the trunk)"""
+    tdt, sfx = _fmt(dt)
+    tol16 = 4e-3 if dt == "bf16" else 5e-4
+    A = dev(rnd(M, K, seed=5), tdt)
+    W = dev(rnd(N, K, seed=6, scale=K ** -0.5), tdt)
     bias = dev(rnd(N, seed=7, scale=0.1))
     ref = A.float() @ W.float().t() + bias
+    fn = getattr(lib, f"deer_gemm_{sfx}_nt")
 
     def run(epi, C, gate=None, b=bias):
-        abi.check(lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(W), K, abi.ptr(b), abi.ptr(C), N, 0, M, N, K, 1, epi, abi.ptr(gate),
-                                        tile, None, st()), "gemm")
+        abi.check(fn(abi.ptr(A), K, 0, abi.ptr(W), K, abi.ptr(b), abi.ptr(C), N, 0, M, N, K, 1, epi, abi.ptr(gate), tile, None, st()), "gemm")
         torch.cuda.synchronize()
 
     C = torch.zeros(M, N, device="cuda")
     run(abi.EPI_F32, C)
     assert rel_err(C, ref) < 2e-5
-    Cb = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    Cb = torch.zeros(M, N, device="cuda", dtype=tdt)
     run(abi.EPI_BF16, Cb)
-    assert rel_err(Cb.float(), ref) < 4e-3                   # one bf16 rounding of the output
+    assert rel_err(Cb.float(), ref) < tol16                  # one rounding of the output
     run(abi.EPI_QGELU_BF16, Cb)
-    assert rel_err(Cb.float(), ref * torch.sigmoid(1.702 * ref)) < 4e-3
+    assert rel_err(Cb.float(), ref * torch.sigmoid(1.702 * ref)) < max(tol16, 1e-3)
     run(abi.EPI_GELU_BF16, Cb)
-    assert rel_err(Cb.float(), torch.nn.functional.gelu(ref)) < 4e-3
+    assert rel_err(Cb.float(), torch.nn.functional.gelu(ref)) < tol16
+    Cx = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    run(abi.EPI_BF16OUT, Cx)                                 # bf16 store whatever the operand format
+    assert rel_err(Cx.float(), ref) < 4e-3 and torch.equal(Cx, ref_round_bf16(C))
     R0 = dev(rnd(M, N, seed=8))
     R = R0.clone()
     gate = torch.tensor([0.5], device="cuda")
@@ -300,6 +321,11 @@ def test_gemm_tiled_epilogues(lib, tile, M, N, K):
     R = R0.clone()
     run(abi.EPI_RESADD_F32, R, None, None)
     assert rel_err(R, R0 + (ref - bias)) < 2e-5
+
+
+def ref_round_bf16(c_f32):
+    """the bf16 rounding of the kernel's own f32 result (same accumulation order): EPI_BF16OUT must equal it bit for bit"""
+    return c_f32.to(torch.bfloat16)
 
 
 def test_gemm_tiled_batched_strided(lib):
@@ -317,24 +343,26 @@ def test_gemm_tiled_batched_strided(lib):
 # -------------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("B,H,q_len,kv_len", [(2, 16, 257, 257), (8, 16, 257, 257), (3, 16, 200, 270), (2, 8, 64, 320), (2, 2, 17, 17), (1, 1, 5, 68),
                                               (1, 3, 100, 33)])
-def test_attn_mfma(lib, B, H, q_len, kv_len):
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_attn_mfma(lib, dt, B, H, q_len, kv_len):
     """(2, 16, 257, 257) and (8, 16, 257, 257): the ViT shapes - round 5's attn_vit_kernel (V row-major in LDS + transpose reads), one query tile
     per wave and (>= 128 (head, image) pairs) the looping form; (3, 16, 200, 270): the same kernel with ragged query / key counts."""
     hd = 64
-    q = dev(rnd(B, q_len, H * hd, seed=11), torch.bfloat16)
-    k = dev(rnd(B, kv_len, H * hd, seed=12), torch.bfloat16)
-    v = dev(rnd(B, kv_len, H * hd, seed=13), torch.bfloat16)
-    o = torch.zeros(B, q_len, H * hd, device="cuda", dtype=torch.bfloat16)
+    tdt, _ = _fmt(dt)
+    q = dev(rnd(B, q_len, H * hd, seed=11), tdt)
+    k = dev(rnd(B, kv_len, H * hd, seed=12), tdt)
+    v = dev(rnd(B, kv_len, H * hd, seed=13), tdt)
+    o = torch.zeros(B, q_len, H * hd, device="cuda", dtype=tdt)
     scale = hd ** -0.5
-    abi.check(lib.deer_attn_mfma_hd64(abi.ptr(q), abi.ptr(k), abi.ptr(v), abi.ptr(o), B, H, q_len, kv_len, H * hd, H * hd, H * hd, H * hd,
+    abi.check((lib.deer_attn_f16_hd64 if dt == "f16" else lib.deer_attn_mfma_hd64)(abi.ptr(q), abi.ptr(k), abi.ptr(v), abi.ptr(o), B, H, q_len, kv_len, H * hd, H * hd, H * hd, H * hd,
                                       q_len * H * hd, kv_len * H * hd, kv_len * H * hd, q_len * H * hd, scale, st()), "attn")
     torch.cuda.synchronize()
     qf = q.float().view(B, q_len, H, hd).transpose(1, 2)
     kf = k.float().view(B, kv_len, H, hd).transpose(1, 2)
     vf = v.float().view(B, kv_len, H, hd).transpose(1, 2)
     ref = (torch.softmax(qf @ kf.transpose(-1, -2) * scale, -1) @ vf).transpose(1, 2).reshape(B, q_len, H * hd)
-    assert rel_err(o.float(), ref) < 8e-3                    # P and O are rounded to bf16
-    assert float((o.float() - ref).abs().max()) < 3e-2
+    assert rel_err(o.float(), ref) < (8e-3 if dt == "bf16" else 1e-3)   # P and O are rounded to the 16-bit format
+    assert float((o.float() - ref).abs().max()) < (3e-2 if dt == "bf16" else 4e-3)
 
 
 @pytest.mark.parametrize("B,H,q_len,kv1,kv2", [(2, 8, 64, 256, 64), (1, 2, 16, 16, 16), (2, 2, 64, 17, 5), (1, 1, 5, 0, 33)])
@@ -563,6 +591,85 @@ def test_vit_patch_embed(lib):
     ref = torch.cat([cls.view(1, 1, W).expand(N, 1, W), patch.view(N, P, W)], 1) + pos
     ref = torch.nn.functional.layer_norm(ref, (W,), g, b)
     assert float((x - ref).abs().max()) < 2e-5
+
+
+def test_fp16_family_of_the_vision_tower(lib):
+    """Round 6: the fp16 twins of the tower's remaining entry points (include/deer_hip.h: "the vision tower's fp16 arithmetic") against fp32
+    torch math on fp16-exact inputs - two-segment attention, LayerNorm rows (one and several affine sets), the slab-reducing residual +
+    LayerNorm row op (one row per workgroup and the multi-row form at >= 2048 rows), im2col from f32 / bf16 / fp16 frames, the
+    weight-batched and the split-K GEMM.  One 16-bit rounding of a result is 2^-12 relative (bf16: 2^-9)."""
+    h = torch.float16
+    # two-segment attention (Perceiver)
+    B, H, q_len, kv1, kv2, hd = 2, 8, 64, 256, 64, 64
+    inner = H * hd
+    qkv = dev(rnd(B, q_len, 3 * inner, seed=71), h)
+    mkv = dev(rnd(B, kv1, 2 * inner, seed=73), h)
+    o = torch.zeros(B, q_len, inner, device="cuda", dtype=h)
+    abi.check(lib.deer_attn_f16_hd64_2seg(abi.ptr(qkv), abi.ptr(mkv), abi.ptr(mkv, inner * 2), abi.ptr(qkv, inner * 2), abi.ptr(qkv, 2 * inner * 2),
+                                          abi.ptr(o), B, H, q_len, kv1, kv2, 3 * inner, 2 * inner, 3 * inner, inner, q_len * 3 * inner,
+                                          kv1 * 2 * inner, kv2 * 3 * inner, q_len * inner, hd ** -0.5, st()), "attn 2seg f16")
+    torch.cuda.synchronize()
+    qf = qkv[..., :inner].float().view(B, q_len, H, hd).transpose(1, 2)
+    kf = torch.cat([mkv[..., :inner], qkv[..., inner:2 * inner]], 1).float().view(B, kv1 + kv2, H, hd).transpose(1, 2)
+    vf = torch.cat([mkv[..., inner:], qkv[..., 2 * inner:]], 1).float().view(B, kv1 + kv2, H, hd).transpose(1, 2)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * hd ** -0.5, -1) @ vf).transpose(1, 2).reshape(B, q_len, inner)
+    assert rel_err(o.float(), ref) < 1e-3
+    # LayerNorm rows, one and several affine sets
+    N, P, C, L = 2, 16, 1024, 6
+    x = dev(rnd(N, P + 1, C, seed=81))
+    g, b = dev(1 + 0.1 * rnd(L, C, seed=82)), dev(0.1 * rnd(L, C, seed=83))
+    out = torch.zeros(L, N * P, C, device="cuda", dtype=h)
+    abi.check(lib.deer_layernorm_rows_multi_f16(abi.ptr(x, C * 4), C, (P + 1) * C, P, N, abi.ptr(g), abi.ptr(b), L, C, abi.ptr(out),
+                                                N * P * C, C, P * C, C, 1e-5, st()), "ln multi f16")
+    out1 = torch.zeros(N * (P + 1), C, device="cuda", dtype=h)
+    abi.check(lib.deer_layernorm_rows_f16(abi.ptr(x), C, 0, N * (P + 1), 1, abi.ptr(g), abi.ptr(b), abi.ptr(out1), None, C, 0, C, 1e-5, st()), "ln f16")
+    torch.cuda.synchronize()
+    for l in range(L):
+        assert rel_err(out[l].float(), torch.nn.functional.layer_norm(x[:, 1:], (C,), g[l], b[l]).reshape(N * P, C)) < 5e-4
+    assert rel_err(out1.float(), torch.nn.functional.layer_norm(x, (C,), g[0], b[0]).reshape(-1, C)) < 5e-4
+    # residual + LayerNorm row op: 14 rows (one per workgroup) and 2057 rows (multi-row form), bit-identical x in both 16-bit formats
+    for T in (14, 2057):
+        d, s_in = 1024, 2
+        x0 = dev(rnd(T, d, seed=22))
+        slab = dev(rnd(s_in, T, d, seed=23))
+        bias = dev(0.1 * rnd(d, seed=25))
+        gm = dev(1 + 0.1 * rnd(d, seed=24))
+        xa, xb = x0.clone(), x0.clone()
+        oh = torch.zeros(T, d, device="cuda", dtype=h)
+        ob = torch.zeros(T, d, device="cuda", dtype=torch.bfloat16)
+        abi.check(lib.deer_resadd_ln_f16(abi.ptr(xa), abi.ptr(slab), s_in, T * d, None, abi.ptr(bias), abi.ptr(gm), None, abi.ptr(oh), None, None, T, d, 1e-5, None, st()), "resadd f16")
+        abi.check(lib.deer_resadd_ln(abi.ptr(xb), abi.ptr(slab), s_in, T * d, None, abi.ptr(bias), abi.ptr(gm), None, abi.ptr(ob), None, None, T, d, 1e-5, None, st()), "resadd")
+        torch.cuda.synchronize()
+        xr = x0 + slab.sum(0) + bias
+        assert torch.equal(xa, xb) and float((xa - xr).abs().max()) < 1e-5
+        ln = torch.nn.functional.layer_norm(xr, (d,), gm)
+        assert rel_err(oh.float(), ln) < 5e-4 and rel_err(ob.float(), ln) < 4e-3
+    # im2col: f32 / bf16 / fp16 frames -> fp16 patches
+    Ni, S, p = 2, 56, 14
+    kk, Kpad = 588, 640
+    img = dev(rnd(Ni, 3, S, S, seed=25))
+    ref_col = torch.nn.functional.unfold(img, p, stride=p).transpose(1, 2).reshape(Ni * 16, kk)
+    col = torch.full((Ni * 16, Kpad), 9.0, device="cuda", dtype=h)
+    for kind, src in ((0, img), (1, img.to(torch.bfloat16)), (2, img.to(h))):
+        col.fill_(9.0)
+        abi.check(lib.deer_vit_im2col_f16(abi.ptr(src), kind, Ni, S, p, abi.ptr(col), Kpad, st()), "im2col f16")
+        torch.cuda.synchronize()
+        want = ref_col.to(h) if kind != 1 else ref_col.to(torch.bfloat16).to(h)
+        assert torch.equal(col[:, :kk], want) and float(col[:, kk:].abs().max()) == 0.0
+    # weight-batched and split-K GEMM
+    Lb, M, Nn, K = 6, 96, 128, 256
+    A = dev(rnd(Lb, M, K, seed=84), h)
+    W = dev(rnd(Lb, Nn, K, seed=85, scale=K ** -0.5), h)
+    Cc = torch.zeros(Lb, M, Nn, device="cuda", dtype=h)
+    abi.check(lib.deer_gemm_f16_nt_wbatch(abi.ptr(A), K, M * K, abi.ptr(W), K, Nn * K, None, abi.ptr(Cc), Nn, M * Nn, M, Nn, K, Lb, abi.EPI_BF16, 0, None, st()), "wbatch f16")
+    M2, N2, K2, S2 = 514, 1024, 4096, 2
+    A2 = dev(rnd(M2, K2, seed=64), h)
+    W2 = dev(rnd(N2, K2, seed=65, scale=K2 ** -0.5), h)
+    slab2 = torch.zeros(S2, M2, N2, device="cuda")
+    abi.check(lib.deer_gemm_f16_nt_splitk(abi.ptr(A2), K2, abi.ptr(W2), K2, abi.ptr(slab2), M2, N2, K2, S2, 0, None, st()), "splitk f16")
+    torch.cuda.synchronize()
+    assert rel_err(Cc.float(), torch.einsum("lmk,lnk->lmn", A.float(), W.float())) < 5e-4
+    assert rel_err(slab2.sum(0), A2.float() @ W2.float().t()) < 2e-5
 
 
 def test_embed_tokens_and_text_time(lib):
