@@ -65,9 +65,10 @@ def parse():
                     help="CPU leg with BASELINE.md section 3's full 20 warm-up + 100 timed steps (minutes) instead of the bounded sample")
     ap.add_argument("--window-reps", type=int, default=10,
                     help="window-mode (threshold calibration) leg: windows of cfg.window_size frame pairs timed as batch rows (0 = skip)")
-    ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
-                    help="bf16: the product arithmetic (BASELINE's dtype). fp32: the fp32-activation parity arithmetic (csrc/precise.hip) - "
-                         "a separate, slower line for DESIGN.md, never the headline")
+    ap.add_argument("--precision", choices=("fp16", "bf16", "fp32"), default="fp16",
+                    help="fp16 (default): the product arithmetic on IEEE fp16 operands = the reference's evaluation arithmetic (fp32 weights under fp16 "
+                         "autocast, eval_utils.py:333). bf16: the same kernels on bf16 operands (a --precision bf16 reference run; BASELINE's dtype floor). "
+                         "fp32: the fp32-activation parity arithmetic (csrc/precise.hip) - a secondary figure for DESIGN.md, never the headline")
     ap.add_argument("--no-two-groups", action="store_true", help="skip the leg with several env batches in flight per GPU")
     ap.add_argument("--batched-groups", type=int, default=4,
                     help="env batches of --batched-envs environments in flight per GPU in the `batched_groups` leg (own stream and host thread each)")
@@ -743,10 +744,10 @@ def main():
                   % ("MPT-7B" if args.workload == "deer_9b" else ("REDUCED-DIMS TEST MODEL (not a result)" if args.workload == "tiny" else "MPT-1B"), max_layer),
         "value": round(value, 2), "unit": "action-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * t_max / res["n_timed"], 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": ("bf16" if res["eng"].tower == "bf16" else "fp16+bf16") if args.precision == "bf16" else "f32 activations, bf16-representable weights",
-        "dtype_note": "16-bit MFMA operands, f32 accumulation everywhere; vision tower (ViT-L/14 x2, Perceiver, media K/V) in %s = %s; LLM trunk: bf16 "
-                      "weights, f32 activations fed as bf16 hi + lo; head f32 state" % (res["eng"].tower, "the reference's evaluation arithmetic (fp32 weights under "
-                      "fp16 autocast, eval_utils.py:333)" if res["eng"].tower == "fp16" else "a --precision bf16 reference run"),
+        "vs_baseline": None, "dtype": args.precision if args.precision != "fp32" else "f32 activations, bf16-representable weights",
+        "dtype_note": ("16-bit MFMA operands (%s weights, %s results in the vision tower, %s hi + lo activation planes in the trunk), f32 accumulation / "
+                       "LayerNorm / softmax / LSTM state; fp16 = the reference's evaluation arithmetic (fp32 weights under fp16 autocast, eval_utils.py:333), "
+                       "bf16 = a --precision bf16 reference run" % ((args.precision,) * 3)) if args.precision != "fp32" else "csrc/precise.hip",
         "data": "synthetic",
         "avg_exit_layer": round(res["avg_exit"], 3),
         # which verdicts the timed region of `value` ran on: "scripted" = the dynamic pipeline with the thresholds forced per step
@@ -857,7 +858,7 @@ def main():
                                    "id, no exit checks, host reads the action after every step"}
     if os.environ.get("DEER_PERSISTENT_LAYER") == "1":     # N1 experiment: never the default; say so on the line
         out["experiment"] = {"persistent_layer": True, "barrier_error_word": eng.persistent_layer_error(), "first_timeout": eng.persistent_layer_error_detail()}
-    if rank == 0 and world == 1 and B == 1 and args.surface_steps > 0 and args.precision == "bf16":
+    if rank == 0 and world == 1 and B == 1 and args.surface_steps > 0 and args.precision != "fp32":
         try:                                               # auxiliary single-rank leg: its failure must not cost the bench line
             out["surface"] = surface_leg(cfg, eng, res["thr"], res["frames"], res["ids"], args.surface_steps)
         except Exception as e:
@@ -878,7 +879,7 @@ def main():
                           "avg_exit_layer": round(rb["avg_exit"], 3),
                           "note": "all environments of a rank advance in lock step through the same graph pieces; same kernels, "
                                   "same thresholds solver, per-environment exit decisions on the device"}
-        if rank == 0 and world == 1 and args.precision == "bf16" and not args.no_two_groups:
+        if rank == 0 and world == 1 and args.precision != "fp32" and not args.no_two_groups:
             try:                                           # auxiliary single-rank leg: its failure must not cost the bench line
                 out["batched_groups"] = two_groups_leg(cfg, rb, args.batched_envs, nb, 60, local_rank, G=args.batched_groups)
             except Exception as e:
@@ -892,7 +893,7 @@ def main():
         rb = None
         # the largest env batch one engine takes (round 5: 16 environments, 512 trunk rows): weights streamed once per 16
         from deer_vla_amd import _abi as abi
-        if args.batched_envs < abi.MAX_ENVS and rank == 0 and world == 1 and args.precision == "bf16" and not args.no_two_groups:
+        if args.batched_envs < abi.MAX_ENVS and rank == 0 and world == 1 and args.precision != "fp32" and not args.no_two_groups:
             try:
                 torch.cuda.empty_cache()
                 nb2 = max(nb // 2, 15)

@@ -34,6 +34,25 @@ SIGNATURES = {
     "deer_layernorm_rows_multi_f16": [P, L, L, I, I, P, P, I, L, P, L, L, L, I, F, P],
     "deer_resadd_ln_f16": [P, P, I, L, P, P, P, P, P, P, P, I, I, F, P, P],
     "deer_vit_im2col_f16": [P, I, I, I, I, P, I, P],
+    # round 6: the trunk on fp16 operands (twins of the bf16 entry points, same arguments)
+    "deer_gemm_skinny_f16": [P, I, P, I, L, I, P, P, I, I, I, I, P, P],
+    "deer_gemm_skinny_hl_f16": [P, P, I, P, P, I, I, I, I, P, P],
+    "deer_gemm_skinny_hl_rows_f16": [P, P, I, P, P, I, I, I, I, I, P, P],
+    "deer_gemm_skinny_hl_active_f16": [P, P, I, P, P, I, I, I, I, I, P, P, I, P],
+    "deer_slab_gelu_split_f16": [P, I, L, I, P, P, I, I, P, P],
+    "deer_slab_gelu_split_active_f16": [P, I, L, I, P, P, I, I, P, P, I, P],
+    "deer_resadd_ln_split_f16": [P, P, I, L, P, P, P, P, P, P, P, P, I, I, F, P, P],
+    "deer_resadd_ln_rows_f16": [P, P, I, L, P, P, P, P, P, P, P, I, I, F, P, P, I, P, P, I, I, P],
+    "deer_resadd_ln_packed_f16": [P, P, I, L, P, P, P, P, P, P, P, P, I, I, F, P, P],
+    "deer_trunk_wide_gemm_f16": [P, P, P, I, I, I, P, P, P, I, P, I, P, P],
+    "deer_trunk_mpt_attn_f16": [P, P, I, I, P, P, F, P, F, P, P, I, I, P, P],
+    "deer_xattn_fused_f16": [P, I, P, P, I, I, P, I, I, P, P, L, I, I, I, F, P, P],
+    "deer_xattn_fused_active_f16": [P, I, P, P, I, I, P, I, I, P, P, L, I, I, I, F, P, P, P],
+    "deer_xattn_fused_packed_f16": [P, P, I, P, P, I, I, P, I, I, P, P, L, I, I, F, P, P],
+    "deer_xattn_mfma_f16": [P, I, L, I, P, I, I, P, I, P, I, I, I, I, I, I, F, P, P],
+    "deer_mpt_attn_small_hl_f16": [P, I, L, I, I, P, P, F, P, F, P, P, P, I, I, I, P, P],
+    "deer_mpt_attn_small_hl_active_f16": [P, I, L, I, I, P, P, F, P, F, P, P, P, I, I, I, P, P, P],
+    "deer_embed_tokens_f16": [P, P, P, P, I, I, I, I, I, P],
     "deer_gemm_skinny": [P, I, P, I, L, I, P, P, I, I, I, I, P, P],
     "deer_skinny_splitk": [I, I, I],
     "deer_gemm_skinny_hl": [P, P, I, P, P, I, I, I, I, P, P],
@@ -149,11 +168,11 @@ THR_TYPES = {"L2": 0, "mean": 1, "max": 2, "cosine": 3}
 _lib = None
 
 
-def max_trunk_rows(cfg, precision: str = "bf16") -> int:
+def max_trunk_rows(cfg, precision: str = "fp16") -> int:
     """LLM rows (n_envs * T) one engine takes: 512 in the bf16 arithmetic (16 environments x the reference's max_length = 32 tokens,
     data.py:905-919; the hi/lo-plane trunk GEMM runs them in row blocks of 128), 128 in the fp32 arithmetic or when d_model % 64 != 0
     (one launch of deer_gemm_skinny)."""
-    return 512 if (precision == "bf16" and cfg.d_model % 64 == 0) else 128
+    return 512 if (precision != "fp32" and cfg.d_model % 64 == 0) else 128
 
 
 MAX_ENVS = 16        # environments per engine (csrc/common.h: DEER_MAX_ENVS)
@@ -177,10 +196,32 @@ class DeerConfigC(ctypes.Structure):
         "tower_f16")]
 
 
-PRECISIONS = {"bf16": 0, "fp32": 1}
+# precision of an engine -> (deer_config.precision, deer_config.tower_f16):
+#   "fp16"  the product arithmetic on IEEE fp16 operands (default): fp16 weights everywhere, fp16 results in the vision tower, fp16 hi + lo
+#           activation planes in the trunk, f32 accumulation / LayerNorm / softmax / LSTM state - the reference's evaluation arithmetic
+#           (fp32 weights under fp16 autocast, eval_utils.py:333, README.md:161-167)
+#   "bf16"  the same kernels on bf16 operands - a `--precision bf16` / amp_bf16 reference run (eval_calvin.py:559-560)
+#   "fp32"  f32 activations and f32 (or bf16 hi + lo) weights end to end (csrc/precise.hip): the parity arithmetic, 4-5x slower
+PRECISIONS = {"fp16": (0, 1), "bf16": (0, 0), "fp32": (1, 0)}
+DEFAULT_PRECISION = "fp16"
 
 
-def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0, precision: str = "bf16", tower: str = "bf16") -> DeerConfigC:
+def resolve_precision(precision) -> str:
+    """None -> DEER_PRECISION or the default; validates the name"""
+    if precision is None:
+        precision = os.environ.get("DEER_PRECISION", DEFAULT_PRECISION)
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
+    return precision
+
+
+def torch_dtype16(precision: str):
+    """torch dtype of the 16-bit tensors an engine of this precision exchanges (camera frames, media tokens, K / V, wte): f32 for "fp32" """
+    import torch
+    return {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[precision]
+
+
+def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0, precision: str = DEFAULT_PRECISION) -> DeerConfigC:
     c = DeerConfigC()
     for k in ("image_size", "patch_size", "vit_width", "vit_layers", "vit_heads", "vit_mlp", "perc_depth", "perc_heads",
               "perc_dim_head", "perc_latents", "perc_ff_mult", "vocab_size", "d_model", "n_heads", "mlp_ratio",
@@ -196,14 +237,11 @@ def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0, precisio
     c.n_envs, c.max_text_len, c.n_chains = n_envs, max_text_len, n_chains
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
-    c.precision = PRECISIONS[precision]
+    c.precision, c.tower_f16 = PRECISIONS[precision]
     c.use_state = 1 if getattr(cfg, "use_state", False) else 0
     c.sep_resampler = 1 if getattr(cfg, "sep_resampler", False) else 0
     c.multi_step_action = int(getattr(cfg, "multi_step_action", 1))
     c.layerwise_exit_eval = 1 if getattr(cfg, "layerwise_exit_eval", False) else 0
-    if tower not in ("bf16", "fp16"):
-        raise ValueError(f"tower must be 'bf16' or 'fp16', got {tower!r}")
-    c.tower_f16 = 1 if (tower == "fp16" and precision == "bf16") else 0
     return c
 
 

@@ -266,9 +266,11 @@ def load_checkpoint_files(deer_ckpt: str, openflamingo_ckpt: Optional[str] = Non
 
 def build_model_from_checkpoint(deer_ckpt: str, openflamingo_ckpt: Optional[str] = None, clip_state: Optional[str] = None,
                                 mpt_state: Optional[str] = None, max_layer: Optional[int] = None, device="cuda", strict: bool = True,
-                                trunk: Optional[DeerConfig] = None, precision: str = "bf16", n_envs: int = 1, mpt_config: Optional[str] = None):
-    """-> (MPTFlamingo, info) ready for ``forward`` / ``ModelWrapper``; raises when tensors are missing (strict).  precision="fp32" keeps
-    the checkpoint's f32 weights (f32 / hi+lo copies on the device) - the arithmetic of a reference run at ``--precision fp32``."""
+                                trunk: Optional[DeerConfig] = None, precision: Optional[str] = None, n_envs: int = 1, mpt_config: Optional[str] = None):
+    """-> (MPTFlamingo, info) ready for ``forward`` / ``ModelWrapper``; raises when tensors are missing (strict).  precision: None / "fp16" = the
+    product arithmetic on fp16 operands (the README's `--precision fp32 --amp 1` evaluation: every Linear on fp16-rounded weights under
+    autocast), "bf16" = a ``--precision bf16`` run, "fp32" keeps the checkpoint's f32 weights (f32 / hi+lo copies on the device) - the
+    arithmetic of a reference run at ``--precision fp32`` without amp."""
     from .flamingo_mpt import MPTFlamingo
     cfg, sd, info = load_checkpoint_files(deer_ckpt, openflamingo_ckpt, clip_state, mpt_state, max_layer, trunk, mpt_config)
     if strict and info["missing"]:

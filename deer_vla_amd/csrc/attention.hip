@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
         if (XATTN) {                                           // f32 split-K partials -> sum -> bf16
           const float* qp = reinterpret_cast<const float*>(Qv) + b * q_bstride + h * AM_HD + (long)(q0 + c) * ldq + ks * 32 + g * 8;
           const float4 a0 = slab_sum4(qp, q_slabs, q_slab_stride), a1 = slab_sum4(qp + 4, q_slabs, q_slab_stride);
-          v = uint4{pack2bf(a0.x, a0.y), pack2bf(a0.z, a0.w), pack2bf(a1.x, a1.y), pack2bf(a1.z, a1.w)};
+          v = uint4{pack2x<F16>(a0.x, a0.y), pack2x<F16>(a0.z, a0.w), pack2x<F16>(a1.x, a1.y), pack2x<F16>(a1.z, a1.w)};
         } else {
           v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(Qv) + b * q_bstride + h * AM_HD +
                                               (long)(q0 + c) * ldq + ks * 32 + g * 8);
@@ -382,7 +382,7 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
                             max_smem) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, 8, true, F16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             max_smem) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<true, 4, false, F16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             max_smem) != hipSuccess)
       return DEER_ERR_LAUNCH;
     attr_set = true;
@@ -424,8 +424,7 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
 #define DEER_ATTN_ARGS Q, kp, vp, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride, scale, q_slabs, \
                        q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2, tpw
   if (q_slabs > 0) {
-    if (F16) return DEER_ERR_SHAPE;                         // the x-attn form (f32 q slabs) exists in bf16 only
-    hipLaunchKernelGGL((attn_mfma_kernel<true, 4>), grid, dim3(256), smem, st, DEER_ATTN_ARGS);
+    hipLaunchKernelGGL((attn_mfma_kernel<true, 4, false, F16>), grid, dim3(256), smem, st, DEER_ATTN_ARGS);
   } else if (wide && tpw != nwave)
     hipLaunchKernelGGL((attn_mfma_kernel<false, 8, true, F16>), grid, dim3(512), smem, st, DEER_ATTN_ARGS);
   else if (wide)
@@ -478,14 +477,26 @@ extern "C" int deer_attn_f16_hd64_2seg(const void* Q, const void* K1, const void
 
 // MaskedCrossAttention core on the MFMA kernel: q = sum_s qslab[s] (f32 [batch*T, ldqs], head h at column h*64),
 // kv bf16 [batch*n_kv, ldkv] (k at column h*64, v at inner + h*64), media mask from text_time, out f32/bf16 [batch*T, ldo].
-extern "C" int deer_xattn_mfma(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv, int inner,
+template <bool F16>
+static int xattn_mfma(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv, int inner,
                                const int* text_time, int n_per_media, void* out, int out_is_f32, int ldo, int T, int n_kv,
                                int heads, int batch, float scale, const int* ctl, void* stream) {
   if (s_in <= 0 || n_per_media <= 0 || text_time == nullptr) return DEER_ERR_SHAPE;
   const bf16_t* kvp = reinterpret_cast<const bf16_t*>(kv);
-  return launch_attn_mfma(qslab, kvp, kvp + inner, out, batch, heads, T, n_kv, ldqs, ldkv, ldkv, ldo, (long)T * ldqs,
+  return launch_attn_mfma<F16>(qslab, kvp, kvp + inner, out, batch, heads, T, n_kv, ldqs, ldkv, ldkv, ldo, (long)T * ldqs,
                           (long)n_kv * ldkv, (long)n_kv * ldkv, (long)T * ldo, scale, s_in, slab_stride, text_time, n_per_media,
                           out_is_f32, ctl, stream);
+}
+
+extern "C" int deer_xattn_mfma(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv, int inner,
+                               const int* text_time, int n_per_media, void* out, int out_is_f32, int ldo, int T, int n_kv,
+                               int heads, int batch, float scale, const int* ctl, void* stream) {
+  return xattn_mfma<false>(qslab, s_in, slab_stride, ldqs, kv, ldkv, inner, text_time, n_per_media, out, out_is_f32, ldo, T, n_kv, heads, batch, scale, ctl, stream);
+}
+extern "C" int deer_xattn_mfma_f16(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv, int inner,
+                                   const int* text_time, int n_per_media, void* out, int out_is_f32, int ldo, int T, int n_kv,
+                                   int heads, int batch, float scale, const int* ctl, void* stream) {   // fp16 K / V (round 6)
+  return xattn_mfma<true>(qslab, s_in, slab_stride, ldqs, kv, ldkv, inner, text_time, n_per_media, out, out_is_f32, ldo, T, n_kv, heads, batch, scale, ctl, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -636,6 +647,7 @@ __global__ __launch_bounds__(256) void qkv_reduce_ln_kernel(const float* __restr
   }
 }
 
+template <bool F16 = false>
 __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __restrict__ qkv, int d_model, int hd,
                                                              const unsigned char* __restrict__ key_mask,
                                                              float alibi_slope_base, int n_heads,
@@ -696,9 +708,9 @@ __global__ __launch_bounds__(256) void mpt_attn_small_kernel(const float* __rest
     for (int j = 0; j <= t; ++j) a += sim[t][j] * vs[j][d];
     if (out_is_f32) reinterpret_cast<float*>(out)[(long)t * ldo + h * hd + d] = a;
     else {
-      const bf16_t hi = f2bf(a);
+      const bf16_t hi = f2x<F16>(a);
       reinterpret_cast<bf16_t*>(out)[(long)t * ldo + h * hd + d] = hi;
-      if (out_lo != nullptr) out_lo[(long)t * ldo + h * hd + d] = f2bf(a - bf2f(hi));    // second plane: a = hi + lo
+      if (out_lo != nullptr) out_lo[(long)t * ldo + h * hd + d] = f2x<F16>(a - x2f<F16>(hi));    // second plane: a = hi + lo
     }
   }
 }
@@ -716,14 +728,15 @@ extern "C" int deer_mpt_attn_small(const float* qkvslab, int s_in, long slab_str
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(qkv_reduce_ln_kernel, dim3(T * batch, 3), dim3(256), 0, st, qkvslab, s_in, slab_stride, d_model, q_ln_w, k_ln_w,
                      eps, qkv_ws, ctl);
-  hipLaunchKernelGGL(mpt_attn_small_kernel, dim3(n_heads, batch), dim3(256), 0, st, qkv_ws, d_model, hd, key_mask, alibi_bias_max,
-                     n_heads, out, out_is_f32, ldo, T, ctl, static_cast<bf16_t*>(nullptr));
+  hipLaunchKernelGGL(mpt_attn_small_kernel<false>, dim3(n_heads, batch), dim3(256), 0, st, qkv_ws, d_model, hd, key_mask, alibi_bias_max,
+                     n_heads, out, out_is_f32, ldo, T, ctl, static_cast<bf16_t*>(nullptr), static_cast<const int*>(nullptr));
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
 
 // deer_mpt_attn_small_hl for an env batch with compaction: slots of `cmap` (T rows each) instead of environments
-extern "C" int deer_mpt_attn_small_hl_active(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w,
+template <bool F16>
+static int mpt_attn_small_hl_active(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w,
                                              const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws,
                                              void* out_hi, void* out_lo, int ldo, int T, int batch, const int* ctl, const int* cmap, void* stream) {
   const int hd = d_model / n_heads;
@@ -734,14 +747,15 @@ extern "C" int deer_mpt_attn_small_hl_active(const float* qkvslab, int s_in, lon
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(qkv_reduce_ln_kernel, dim3(T * batch, 3), dim3(256), 0, st, qkvslab, s_in, slab_stride, d_model, q_ln_w, k_ln_w,
                      eps, qkv_ws, ctl, cmap, T);
-  hipLaunchKernelGGL(mpt_attn_small_kernel, dim3(n_heads, batch), dim3(256), 0, st, qkv_ws, d_model, hd, key_mask, alibi_bias_max,
+  hipLaunchKernelGGL(mpt_attn_small_kernel<F16>, dim3(n_heads, batch), dim3(256), 0, st, qkv_ws, d_model, hd, key_mask, alibi_bias_max,
                      n_heads, out_hi, 0, ldo, T, ctl, reinterpret_cast<bf16_t*>(out_lo), cmap);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
 
 // the same op with the output as two bf16 planes hi / lo [batch*T, ldo] (activation operand of deer_gemm_skinny_hl)
-extern "C" int deer_mpt_attn_small_hl(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads,
+template <bool F16>
+static int mpt_attn_small_hl(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads,
                                       const float* q_ln_w, const float* k_ln_w, float eps, const unsigned char* key_mask,
                                       float alibi_bias_max, float* qkv_ws, void* out_hi, void* out_lo, int ldo, int T, int batch,
                                       const int* ctl, void* stream) {
@@ -753,8 +767,33 @@ extern "C" int deer_mpt_attn_small_hl(const float* qkvslab, int s_in, long slab_
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(qkv_reduce_ln_kernel, dim3(T * batch, 3), dim3(256), 0, st, qkvslab, s_in, slab_stride, d_model, q_ln_w, k_ln_w,
                      eps, qkv_ws, ctl);
-  hipLaunchKernelGGL(mpt_attn_small_kernel, dim3(n_heads, batch), dim3(256), 0, st, qkv_ws, d_model, hd, key_mask, alibi_bias_max,
-                     n_heads, out_hi, 0, ldo, T, ctl, reinterpret_cast<bf16_t*>(out_lo));
+  hipLaunchKernelGGL(mpt_attn_small_kernel<F16>, dim3(n_heads, batch), dim3(256), 0, st, qkv_ws, d_model, hd, key_mask, alibi_bias_max,
+                     n_heads, out_hi, 0, ldo, T, ctl, reinterpret_cast<bf16_t*>(out_lo), static_cast<const int*>(nullptr));
   DEER_LAUNCH_CHECK();
   return DEER_OK;
+}
+
+extern "C" int deer_mpt_attn_small_hl_active(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w,
+                                             const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws,
+                                             void* out_hi, void* out_lo, int ldo, int T, int batch, const int* ctl, const int* cmap, void* stream) {
+  return mpt_attn_small_hl_active<false>(qkvslab, s_in, slab_stride, d_model, n_heads, q_ln_w, k_ln_w, eps, key_mask, alibi_bias_max, qkv_ws, out_hi, out_lo, ldo, T,
+                                         batch, ctl, cmap, stream);
+}
+extern "C" int deer_mpt_attn_small_hl_active_f16(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w,
+                                                 const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws,
+                                                 void* out_hi, void* out_lo, int ldo, int T, int batch, const int* ctl, const int* cmap, void* stream) {
+  return mpt_attn_small_hl_active<true>(qkvslab, s_in, slab_stride, d_model, n_heads, q_ln_w, k_ln_w, eps, key_mask, alibi_bias_max, qkv_ws, out_hi, out_lo, ldo, T,
+                                        batch, ctl, cmap, stream);
+}
+extern "C" int deer_mpt_attn_small_hl(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w, const float* k_ln_w,
+                                      float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws, void* out_hi, void* out_lo, int ldo,
+                                      int T, int batch, const int* ctl, void* stream) {
+  return mpt_attn_small_hl<false>(qkvslab, s_in, slab_stride, d_model, n_heads, q_ln_w, k_ln_w, eps, key_mask, alibi_bias_max, qkv_ws, out_hi, out_lo, ldo, T, batch,
+                                  ctl, stream);
+}
+extern "C" int deer_mpt_attn_small_hl_f16(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w,
+                                          const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws, void* out_hi,
+                                          void* out_lo, int ldo, int T, int batch, const int* ctl, void* stream) {   // fp16 hi / lo planes (round 6)
+  return mpt_attn_small_hl<true>(qkvslab, s_in, slab_stride, d_model, n_heads, q_ln_w, k_ln_w, eps, key_mask, alibi_bias_max, qkv_ws, out_hi, out_lo, ldo, T, batch,
+                                 ctl, stream);
 }

@@ -87,6 +87,15 @@ template <bool F16> __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, 
   if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// hi / lo split of two f32 values: hi = fmt(v), lo = fmt(v - hi) - the LLM trunk feeds every MFMA with both planes (two MFMAs per weight
+// fragment), so the activation side of a product carries ~16 (bf16) / ~22 (fp16) significand bits
+template <bool F16> __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack2x<F16>(a, b);
+  float ha, hb;
+  if constexpr (F16) { ha = h2f((bf16_t)(hi & 0xffffu)); hb = h2f((bf16_t)(hi >> 16)); }
+  else { ha = __uint_as_float(hi << 16); hb = __uint_as_float(hi & 0xffff0000u); }
+  lo = pack2x<F16>(a - ha, b - hb);
+}
 // GEMM epilogue codes shared by csrc/gemm_tiled.hip and csrc/gemm_bigm.hip (include/deer_hip.h: DEER_EPI_*).  "16" = the family's own
 // 16-bit format; EPI_BF16OUT stores bf16 whatever the operands are (fp16 tower -> the bf16 K/V the trunk's x-attn reads).
 enum { DEER_E_16 = 0, DEER_E_F32 = 1, DEER_E_QGELU_16 = 2, DEER_E_GELU_16 = 3, DEER_E_RESADD_F32 = 4, DEER_E_BF16OUT = 5 };

@@ -39,7 +39,7 @@ enum { A_BF16 = 0, A_SLABS_GELU = 1, A_SLABS = 2, A_F32 = 3 };
 // Weight fragments are double-buffered in registers (wA / wB): the loads of chunk c+1 are issued BEFORE the MFMAs of chunk
 // c and fly during its barriers and the staging of chunk c+1; the first chunk's loads are issued before anything else, so the
 // activation staging (L2 latency) hides under the first HBM round trip instead of preceding it.
-template <int MT, bool SPLIT, int NW, int WU>
+template <int MT, bool SPLIT, int NW, int WU, bool F16 = false>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __restrict__ Av, int lda,
                                                           const float* __restrict__ Aslab, int s_in, long slab_stride_in,
                                                           int a_mode, const bf16_t* __restrict__ Wp,
@@ -98,12 +98,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
             if (a_mode == A_SLABS_GELU) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
           }
         }
-        const uint32_t h01 = pack2bf(s.x, s.y), h23 = pack2bf(s.z, s.w);
+        uint32_t h01, h23, l01, l23;
+        split2<F16>(s.x, s.y, h01, l01);
+        split2<F16>(s.z, s.w, h23, l23);
         *reinterpret_cast<uint2*>(As + row * pitch + seg * 4) = uint2{h01, h23};
-        if (SPLIT)
-          *reinterpret_cast<uint2*>(Al + row * pitch + seg * 4) =
-              uint2{pack2bf(s.x - __uint_as_float(h01 << 16), s.y - __uint_as_float(h01 & 0xffff0000u)),
-                    pack2bf(s.z - __uint_as_float(h23 << 16), s.w - __uint_as_float(h23 & 0xffff0000u))};
+        if (SPLIT) *reinterpret_cast<uint2*>(Al + row * pitch + seg * 4) = uint2{l01, l23};
       }
     }
   };
@@ -122,10 +121,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const void* __rest
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
           const bf16x8 af = *reinterpret_cast<const bf16x8*>(as + j * 16 * pitch + u * 32);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[j], 0, 0, 0);
+          acc[j] = mfma16<F16>(wf, af, acc[j]);
           if (SPLIT) {
             const bf16x8 lf = *reinterpret_cast<const bf16x8*>(al + j * 16 * pitch + u * 32);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, lf, acc[j], 0, 0, 0);
+            acc[j] = mfma16<F16>(wf, lf, acc[j]);
           }
         }
       }
@@ -187,7 +186,7 @@ __device__ __forceinline__ void sk_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-template <int MT, int D>
+template <int MT, int D, bool F16 = false>
 __device__ __forceinline__ void gemm_skinny_hl_body(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo, int lda,
                                                     const bf16_t* __restrict__ Wp, float* __restrict__ part, int M, int N, int K, int KR,
                                                     int part_rows, int bx, int by) {
@@ -258,8 +257,8 @@ __device__ __forceinline__ void gemm_skinny_hl_body(const bf16_t* __restrict__ A
       for (int j = 0; j < MT; ++j) {
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(st + a_row + j * 2048 + sw);
         const bf16x8 al = *reinterpret_cast<const bf16x8*>(st + a_row + (MTL * 16 + j * 16) * 128 + sw);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, ah, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, al, acc[j], 0, 0, 0);
+        acc[j] = mfma16<F16>(wf, ah, acc[j]);
+        acc[j] = mfma16<F16>(wf, al, acc[j]);
       }
     }
   }
@@ -274,12 +273,12 @@ __device__ __forceinline__ void gemm_skinny_hl_body(const bf16_t* __restrict__ A
   }
 }
 
-template <int MT, int D>
+template <int MT, int D, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_skinny_hl_kernel(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo, int lda,
                                                             const bf16_t* __restrict__ Wp, float* __restrict__ part, int M, int N,
                                                             int K, int KR, const int* ctl, int part_rows) {
   DEER_RETURN_IF_EXITED(ctl);
-  gemm_skinny_hl_body<MT, D>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y);
+  gemm_skinny_hl_body<MT, D, F16>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y);
 }
 
 #ifndef DEER_BODIES_ONLY
@@ -287,6 +286,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_hl_kernel(const bf16_t* __res
 // slots x rows_per_env, minus the rows of earlier row blocks - and the workgroup runs the body specialised for that many MFMA row tiles
 // (its own ring depth, DMA counts and waits: exactly the kernel a launch with that M would have run).  A launch costs what its ACTIVE rows
 // cost: 15.4 us at 112 rows, 6.9 us at 14 (r03).  Rows beyond the active ones are not written.
+template <bool F16>
 __global__ __launch_bounds__(512) void gemm_skinny_hl_dyn_kernel(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo, int lda,
                                                                 const bf16_t* __restrict__ Wp, float* __restrict__ part, int M_max, int N,
                                                                 int K, int KR, const int* ctl, int part_rows, const int* __restrict__ cmap,
@@ -295,14 +295,14 @@ __global__ __launch_bounds__(512) void gemm_skinny_hl_dyn_kernel(const bf16_t* _
   const int M = min(M_max, cmap[CMAP_N] * rows_per_env - row0);
   if (M <= 0) return;
   switch ((M + 15) >> 4) {
-    case 1: gemm_skinny_hl_body<1, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
-    case 2: gemm_skinny_hl_body<2, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
-    case 3: gemm_skinny_hl_body<3, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
-    case 4: gemm_skinny_hl_body<4, 4>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
-    case 5: gemm_skinny_hl_body<5, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
-    case 6: gemm_skinny_hl_body<6, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
-    case 7: gemm_skinny_hl_body<7, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
-    default: gemm_skinny_hl_body<8, 3>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    case 1: gemm_skinny_hl_body<1, 4, F16>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    case 2: gemm_skinny_hl_body<2, 4, F16>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    case 3: gemm_skinny_hl_body<3, 4, F16>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    case 4: gemm_skinny_hl_body<4, 4, F16>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    case 5: gemm_skinny_hl_body<5, 3, F16>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    case 6: gemm_skinny_hl_body<6, 3, F16>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    case 7: gemm_skinny_hl_body<7, 3, F16>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
+    default: gemm_skinny_hl_body<8, 3, F16>(Ahi, Alo, lda, Wp, part, M, N, K, KR, part_rows, blockIdx.x, blockIdx.y); break;
   }
 }
 
@@ -315,32 +315,50 @@ extern "C" int deer_skinny_hl_splitk(int M, int N, int K) {
   return s;
 }
 
+template <bool F16>
 static int launch_skinny_hl(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk, const int* ctl,
                             void* stream, int part_rows);
 
+// every entry point of the trunk exists twice: on bf16 operands (weights packed bf16, activation planes bf16 hi / lo) and - suffix _f16,
+// round 6 - on IEEE fp16 operands (weights fp16 = what fp16 autocast feeds a Linear, planes fp16 hi / lo): same arguments, same kernels
+// instantiated on v_mfma_f32_16x16x32_f16
 extern "C" int deer_gemm_skinny_hl(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K,
                                    int splitk, const int* ctl, void* stream) {
-  return launch_skinny_hl(Ahi, Alo, lda, Wp, part, M, N, K, splitk, ctl, stream, 16 * ((M + 15) / 16));
+  return launch_skinny_hl<false>(Ahi, Alo, lda, Wp, part, M, N, K, splitk, ctl, stream, 16 * ((M + 15) / 16));
+}
+extern "C" int deer_gemm_skinny_hl_f16(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K,
+                                       int splitk, const int* ctl, void* stream) {
+  return launch_skinny_hl<true>(Ahi, Alo, lda, Wp, part, M, N, K, splitk, ctl, stream, 16 * ((M + 15) / 16));
 }
 
 // More than 128 rows (8 environments x 32-token instructions: data.py:905-919 pads to the longest of the batch, max_length = 32; or
 // more environments per engine): row blocks of <= 128 rows, one launch each, into slabs of `slab_rows` rows (>= 16 * ceil(M / 16)) -
 // part[ks][slab_rows][N].  The weights of the later blocks come from the Infinity Cache (33 MB per projection).
-extern "C" int deer_gemm_skinny_hl_rows(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
-                                        int slab_rows, const int* ctl, void* stream) {
+template <bool F16>
+static int gemm_skinny_hl_rows(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
+                               int slab_rows, const int* ctl, void* stream) {
   if (M <= 0 || M > 512 || slab_rows < 16 * ((M + 15) / 16)) return DEER_ERR_SHAPE;
   for (int r0 = 0; r0 < M; r0 += 128) {
     const int mb = std::min(128, M - r0);
-    const int rc = launch_skinny_hl(reinterpret_cast<const bf16_t*>(Ahi) + (long)r0 * lda, reinterpret_cast<const bf16_t*>(Alo) + (long)r0 * lda, lda, Wp,
-                                    part + (long)r0 * N, mb, N, K, splitk, ctl, stream, slab_rows);
+    const int rc = launch_skinny_hl<F16>(reinterpret_cast<const bf16_t*>(Ahi) + (long)r0 * lda, reinterpret_cast<const bf16_t*>(Alo) + (long)r0 * lda, lda, Wp,
+                                         part + (long)r0 * N, mb, N, K, splitk, ctl, stream, slab_rows);
     if (rc != DEER_OK) return rc;
   }
   return DEER_OK;
 }
+extern "C" int deer_gemm_skinny_hl_rows(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
+                                        int slab_rows, const int* ctl, void* stream) {
+  return gemm_skinny_hl_rows<false>(Ahi, Alo, lda, Wp, part, M, N, K, splitk, slab_rows, ctl, stream);
+}
+extern "C" int deer_gemm_skinny_hl_rows_f16(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
+                                            int slab_rows, const int* ctl, void* stream) {
+  return gemm_skinny_hl_rows<true>(Ahi, Alo, lda, Wp, part, M, N, K, splitk, slab_rows, ctl, stream);
+}
 
 // deer_gemm_skinny_hl_rows for an env batch with compaction: M = the rows of ALL environments (the launch geometry), the valid rows are read
 // from `cmap` on the device (active slots x rows_per_env)
-extern "C" int deer_gemm_skinny_hl_active(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
+template <bool F16>
+static int gemm_skinny_hl_active(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
                                           int slab_rows, const int* ctl, const int* cmap, int rows_per_env, void* stream) {
   if (M <= 0 || M > 512 || slab_rows < 16 * ((M + 15) / 16) || cmap == nullptr || rows_per_env <= 0 || N <= 0 || (N & 15) || K <= 0 || (K & 63) ||
       splitk <= 0 || (K % (splitk * 64)) != 0 || (lda & 7) || Ahi == nullptr || Alo == nullptr || Wp == nullptr || part == nullptr)
@@ -349,7 +367,7 @@ extern "C" int deer_gemm_skinny_hl_active(const void* Ahi, const void* Alo, int 
   static_assert(smem >= 4 * (4 * 4 + 16) * 1024 && smem <= 160 * 1024, "LDS");
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_hl_dyn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_hl_dyn_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return DEER_ERR_LAUNCH;
     attr_set = true;
   }
@@ -357,7 +375,7 @@ extern "C" int deer_gemm_skinny_hl_active(const void* Ahi, const void* Alo, int 
   dim3 grid((N + 127) / 128, splitk);
   for (int r0 = 0; r0 < M; r0 += 128) {
     const int mb = std::min(128, M - r0);
-    hipLaunchKernelGGL(gemm_skinny_hl_dyn_kernel, grid, dim3(512), smem, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(gemm_skinny_hl_dyn_kernel<F16>, grid, dim3(512), smem, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const bf16_t*>(Ahi) + (long)r0 * lda, reinterpret_cast<const bf16_t*>(Alo) + (long)r0 * lda, lda,
                        reinterpret_cast<const bf16_t*>(Wp), part + (long)r0 * N, mb, N, K, KR, ctl, slab_rows, cmap, rows_per_env, r0);
   }
@@ -365,6 +383,16 @@ extern "C" int deer_gemm_skinny_hl_active(const void* Ahi, const void* Alo, int 
   return DEER_OK;
 }
 
+extern "C" int deer_gemm_skinny_hl_active(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
+                                          int slab_rows, const int* ctl, const int* cmap, int rows_per_env, void* stream) {
+  return gemm_skinny_hl_active<false>(Ahi, Alo, lda, Wp, part, M, N, K, splitk, slab_rows, ctl, cmap, rows_per_env, stream);
+}
+extern "C" int deer_gemm_skinny_hl_active_f16(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
+                                              int slab_rows, const int* ctl, const int* cmap, int rows_per_env, void* stream) {
+  return gemm_skinny_hl_active<true>(Ahi, Alo, lda, Wp, part, M, N, K, splitk, slab_rows, ctl, cmap, rows_per_env, stream);
+}
+
+template <bool F16>
 static int launch_skinny_hl(const void* Ahi, const void* Alo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk, const int* ctl,
                             void* stream, int part_rows) {
   if (M <= 0 || M > 128 || N <= 0 || (N & 15) || K <= 0 || (K & 63) || splitk <= 0 || (K % (splitk * 64)) != 0 || (lda & 7))
@@ -382,7 +410,7 @@ static int launch_skinny_hl(const void* Ahi, const void* Alo, int lda, const voi
     constexpr int smem = D_ * (4 * ((MT_ + 1) & ~1) + 16) * 1024;                                                            \
     static_assert(smem <= 160 * 1024, "LDS");                                                                                \
     static std::atomic<bool> attr_set{false};                                                                                            \
-    auto kern = &gemm_skinny_hl_kernel<MT_, D_>;                                                                             \
+    auto kern = &gemm_skinny_hl_kernel<MT_, D_, F16>;                                                                             \
     if (!attr_set) {                                                                                                         \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=     \
           hipSuccess) return DEER_ERR_LAUNCH;                                                                                \
@@ -409,6 +437,7 @@ static int launch_skinny_hl(const void* Ahi, const void* Alo, int lda, const voi
 // ---- producer of the env-batch kernel's activation for the down-projections: GELU(sum of the up-projection's slabs) as
 // bf16 hi / lo planes [rows][C].  One pass over the slabs (the kernel above re-did this sum + GELU + split in EVERY column group
 // of the consumer: 8x for the 2048-wide down-projections).
+template <bool F16>
 __global__ __launch_bounds__(256) void slab_gelu_split_kernel(const float* __restrict__ slab, int s_in, long stride, int gelu,
                                                               bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long total4,
                                                               const int* ctl, const int* __restrict__ cmap = nullptr, long per_env4 = 0) {
@@ -417,36 +446,55 @@ __global__ __launch_bounds__(256) void slab_gelu_split_kernel(const float* __res
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
     float4 s = slab_sum4(slab + i * 4, s_in, stride);
     if (gelu) { s.x = gelu_erf(s.x); s.y = gelu_erf(s.y); s.z = gelu_erf(s.z); s.w = gelu_erf(s.w); }
-    const uint32_t h01 = pack2bf(s.x, s.y), h23 = pack2bf(s.z, s.w);
+    uint32_t h01, h23, l01, l23;
+    split2<F16>(s.x, s.y, h01, l01);
+    split2<F16>(s.z, s.w, h23, l23);
     *reinterpret_cast<uint2*>(hi + i * 4) = uint2{h01, h23};
-    *reinterpret_cast<uint2*>(lo + i * 4) =
-        uint2{pack2bf(s.x - __uint_as_float(h01 << 16), s.y - __uint_as_float(h01 & 0xffff0000u)),
-              pack2bf(s.z - __uint_as_float(h23 << 16), s.w - __uint_as_float(h23 & 0xffff0000u))};
+    *reinterpret_cast<uint2*>(lo + i * 4) = uint2{l01, l23};
   }
 }
 
-extern "C" int deer_slab_gelu_split(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows,
+template <bool F16>
+static int slab_gelu_split(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows,
                                     int C, const int* ctl, void* stream) {
   if (slab == nullptr || s_in <= 0 || out_hi == nullptr || out_lo == nullptr || rows <= 0 || C <= 0 || (C & 3)) return DEER_ERR_SHAPE;
   const long total4 = (long)rows * C / 4;
   const int blocks = (int)std::min<long>((total4 + 255) / 256, 2048);
-  hipLaunchKernelGGL(slab_gelu_split_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slab, s_in, slab_stride,
+  hipLaunchKernelGGL(slab_gelu_split_kernel<F16>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slab, s_in, slab_stride,
                      gelu, reinterpret_cast<bf16_t*>(out_hi), reinterpret_cast<bf16_t*>(out_lo), total4, ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
 
 // the same restricted to the active slots of an env batch with compaction (rows_per_env rows per slot)
-extern "C" int deer_slab_gelu_split_active(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows, int C,
+template <bool F16>
+static int slab_gelu_split_active(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows, int C,
                                            const int* ctl, const int* cmap, int rows_per_env, void* stream) {
   if (slab == nullptr || s_in <= 0 || out_hi == nullptr || out_lo == nullptr || rows <= 0 || C <= 0 || (C & 3) || cmap == nullptr || rows_per_env <= 0)
     return DEER_ERR_SHAPE;
   const long total4 = (long)rows * C / 4;
   const int blocks = (int)std::min<long>((total4 + 255) / 256, 2048);
-  hipLaunchKernelGGL(slab_gelu_split_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slab, s_in, slab_stride,
+  hipLaunchKernelGGL(slab_gelu_split_kernel<F16>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slab, s_in, slab_stride,
                      gelu, reinterpret_cast<bf16_t*>(out_hi), reinterpret_cast<bf16_t*>(out_lo), total4, ctl, cmap, (long)rows_per_env * C / 4);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
+}
+
+extern "C" int deer_slab_gelu_split(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows, int C, const int* ctl,
+                                    void* stream) {
+  return slab_gelu_split<false>(slab, s_in, slab_stride, gelu, out_hi, out_lo, rows, C, ctl, stream);
+}
+extern "C" int deer_slab_gelu_split_f16(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows, int C, const int* ctl,
+                                        void* stream) {
+  return slab_gelu_split<true>(slab, s_in, slab_stride, gelu, out_hi, out_lo, rows, C, ctl, stream);
+}
+extern "C" int deer_slab_gelu_split_active(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows, int C,
+                                           const int* ctl, const int* cmap, int rows_per_env, void* stream) {
+  return slab_gelu_split_active<false>(slab, s_in, slab_stride, gelu, out_hi, out_lo, rows, C, ctl, cmap, rows_per_env, stream);
+}
+extern "C" int deer_slab_gelu_split_active_f16(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows, int C,
+                                               const int* ctl, const int* cmap, int rows_per_env, void* stream) {
+  return slab_gelu_split_active<true>(slab, s_in, slab_stride, gelu, out_hi, out_lo, rows, C, ctl, cmap, rows_per_env, stream);
 }
 
 // ---- weight packing: row-major W[N,K] bf16 -> Wp[N/16][K/32][64][8] (done once at load time) ----
@@ -489,7 +537,8 @@ extern "C" int deer_skinny_splitk(int M, int N, int K) {
   return s;
 }
 
-extern "C" int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int s_in, long slab_stride_in, int a_mode,
+template <bool F16>
+static int gemm_skinny(const void* A, int lda, const float* Aslab, int s_in, long slab_stride_in, int a_mode,
                                 const void* Wp, float* part, int M, int N, int K, int splitk, const int* ctl,
                                 void* stream) {
   if (M <= 0 || M > 128 || N <= 0 || (N & 15) || K <= 0 || (K & 31) || splitk <= 0 || (K % (splitk * 32)) != 0)
@@ -511,7 +560,7 @@ extern "C" int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int 
 #define DEER_SK_LAUNCH(MT_, SP_, NW_, WU_)                                                                                     \
   do {                                                                                                                         \
     static std::atomic<bool> attr_set{false};                                                                                              \
-    auto kern = &gemm_skinny_kernel<MT_, SP_, NW_, WU_>;                                                                       \
+    auto kern = &gemm_skinny_kernel<MT_, SP_, NW_, WU_, F16>;                                                                       \
     if (!attr_set) {                                                                                                           \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) !=  \
           hipSuccess) return DEER_ERR_LAUNCH;                                                                                  \
@@ -537,5 +586,13 @@ extern "C" int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int 
 #undef DEER_SK_LAUNCH
   DEER_LAUNCH_CHECK();
   return DEER_OK;
+}
+extern "C" int deer_gemm_skinny(const void* A, int lda, const float* Aslab, int s_in, long slab_stride_in, int a_mode, const void* Wp, float* part,
+                                int M, int N, int K, int splitk, const int* ctl, void* stream) {
+  return gemm_skinny<false>(A, lda, Aslab, s_in, slab_stride_in, a_mode, Wp, part, M, N, K, splitk, ctl, stream);
+}
+extern "C" int deer_gemm_skinny_f16(const void* A, int lda, const float* Aslab, int s_in, long slab_stride_in, int a_mode, const void* Wp, float* part,
+                                    int M, int N, int K, int splitk, const int* ctl, void* stream) {
+  return gemm_skinny<true>(A, lda, Aslab, s_in, slab_stride_in, a_mode, Wp, part, M, N, K, splitk, ctl, stream);
 }
 #endif  // DEER_BODIES_ONLY

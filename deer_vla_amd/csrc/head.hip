@@ -112,6 +112,24 @@ template <> struct W8<bf16_t> {
   static __device__ __forceinline__ reg load_stream(const bf16_t* p) { return ld_stream16(p); }
   static __device__ __forceinline__ float dot(const reg& w, const float* x) { return dot8(w, x); }
 };
+// IEEE fp16 rows (round 6: w_kind = 2 - what fp16 autocast feeds the head's Linears / LSTM; 11 significand bits where bf16 keeps 8)
+struct half_t { uint16_t v; };
+template <> struct W8<half_t> {
+  typedef uint4 reg;
+  static __device__ __forceinline__ reg zero() { return uint4{0, 0, 0, 0}; }
+  static __device__ __forceinline__ reg load(const half_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ reg load_stream(const half_t* p) { return ld_stream16(reinterpret_cast<const bf16_t*>(p)); }
+  static __device__ __forceinline__ float dot(const reg& w, const float* x) {
+    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a += h2f((bf16_t)(u[i] & 0xffffu)) * x[2 * i];
+      a += h2f((bf16_t)(u[i] >> 16)) * x[2 * i + 1];
+    }
+    return a;
+  }
+};
 template <> struct W8<float> {
   struct reg { float4 a, b; };
   static __device__ __forceinline__ reg zero() { return reg{float4{0.f, 0.f, 0.f, 0.f}, float4{0.f, 0.f, 0.f, 0.f}}; }
@@ -365,11 +383,11 @@ extern "C" int deer_head_state_embed(const float* state, const float* w_arm, con
   if (d <= 0 || (d & 3) || B <= 0 || B > DEER_MAX_ENVS || 2 * d * 4 > 64 * 1024) return DEER_ERR_SHAPE;
   dim3 grid((d + 15) / 16, B);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (w_is_f32)
-    hipLaunchKernelGGL(head_state_embed_kernel<float>, grid, dim3(256), 2 * d * 4, st, state, w_arm, b_arm, e_grip,
+  if (w_is_f32 == 1) hipLaunchKernelGGL(head_state_embed_kernel<float>, grid, dim3(256), 2 * d * 4, st, state, w_arm, b_arm, e_grip,
                        reinterpret_cast<const float*>(w_state), b_state, out, d);
-  else
-    hipLaunchKernelGGL(head_state_embed_kernel<bf16_t>, grid, dim3(256), 2 * d * 4, st, state, w_arm, b_arm, e_grip,
+    else if (w_is_f32 == 2) hipLaunchKernelGGL(head_state_embed_kernel<half_t>, grid, dim3(256), 2 * d * 4, st, state, w_arm, b_arm, e_grip,
+                       reinterpret_cast<const half_t*>(w_state), b_state, out, d);
+    else hipLaunchKernelGGL(head_state_embed_kernel<bf16_t>, grid, dim3(256), 2 * d * 4, st, state, w_arm, b_arm, e_grip,
                        reinterpret_cast<const bf16_t*>(w_state), b_state, out, d);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
@@ -555,12 +573,13 @@ static int launch_head_lstm_layer(const float* x_src, long x_bstride, int x_mode
   for (int b0 = 0; b0 < B; b0 += nb_even) {
     const int nb = B - b0 < nb_even ? B - b0 : nb_even;
     const int smem = nb * per_env + 64;
-    if (w_is_f32)
-      hipLaunchKernelGGL(head_lstm_layer_kernel<float>, dim3((H + 3) / 4), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), x_src,
+    if (w_is_f32 == 1) hipLaunchKernelGGL(head_lstm_layer_kernel<float>, dim3((H + 3) / 4), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), x_src,
                          x_bstride, x_mode, T, in_dim, ln_w, ln_b, reinterpret_cast<const float*>(w_ih),
                          reinterpret_cast<const float*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, b0, nb, eps, ctl, kind, layer, ghh);
-    else
-      hipLaunchKernelGGL(head_lstm_layer_kernel<bf16_t>, dim3((H + 3) / 4), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), x_src,
+    else if (w_is_f32 == 2) hipLaunchKernelGGL(head_lstm_layer_kernel<half_t>, dim3((H + 3) / 4), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), x_src,
+                         x_bstride, x_mode, T, in_dim, ln_w, ln_b, reinterpret_cast<const half_t*>(w_ih),
+                         reinterpret_cast<const half_t*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, b0, nb, eps, ctl, kind, layer, ghh);
+    else hipLaunchKernelGGL(head_lstm_layer_kernel<bf16_t>, dim3((H + 3) / 4), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), x_src,
                          x_bstride, x_mode, T, in_dim, ln_w, ln_b, reinterpret_cast<const bf16_t*>(w_ih),
                          reinterpret_cast<const bf16_t*>(w_hh), b_ih, b_hh, h_prev, c_prev, h_out, c_out, H, B, b0, nb, eps, ctl, kind, layer, ghh);
   }
@@ -665,7 +684,8 @@ extern "C" int deer_head_lstm_hh(const void* const* w_hh, const float* const* b_
   for (int b0 = 0; b0 < B; b0 += HB_MAX) {                 // batches above HB_MAX environments: one launch per chunk
     const int nb = B - b0 < HB_MAX ? B - b0 : HB_MAX;
     const int smem = nb * H * (int)sizeof(float);
-    if (w_is_f32) hipLaunchKernelGGL(head_lstm_hh_kernel<float>, dim3((H + 3) / 4, L), dim3(256), smem, st, a, h_state, ghh, H, B, b0, nb);
+    if (w_is_f32 == 1) hipLaunchKernelGGL(head_lstm_hh_kernel<float>, dim3((H + 3) / 4, L), dim3(256), smem, st, a, h_state, ghh, H, B, b0, nb);
+    else if (w_is_f32 == 2) hipLaunchKernelGGL(head_lstm_hh_kernel<half_t>, dim3((H + 3) / 4, L), dim3(256), smem, st, a, h_state, ghh, H, B, b0, nb);
     else hipLaunchKernelGGL(head_lstm_hh_kernel<bf16_t>, dim3((H + 3) / 4, L), dim3(256), smem, st, a, h_state, ghh, H, B, b0, nb);
   }
   DEER_LAUNCH_CHECK();
@@ -760,12 +780,13 @@ extern "C" int deer_head_fc(const float* src, int src_stride, int in_dim, int pr
     if (smem > 64 * 1024) return DEER_ERR_SHAPE;
     const float* s_ = src + (long)e0 * src_stride;
     float* d_ = dst + (long)e0 * 2 * out_dim;
-    if (w_is_f32)
-      hipLaunchKernelGGL(head_fc_kernel<float>, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), s_, src_stride, in_dim, pro, lnw0,
+    if (w_is_f32 == 1) hipLaunchKernelGGL(head_fc_kernel<float>, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), s_, src_stride, in_dim, pro, lnw0,
                          lnb0, lnw1, lnb1, reinterpret_cast<const float*>(W0), b0, reinterpret_cast<const float*>(W1), b1, out_dim, d_,
                          nb, eps, ctl, kind, layer, B);
-    else
-      hipLaunchKernelGGL(head_fc_kernel<bf16_t>, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), s_, src_stride, in_dim, pro, lnw0,
+    else if (w_is_f32 == 2) hipLaunchKernelGGL(head_fc_kernel<half_t>, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), s_, src_stride, in_dim, pro, lnw0,
+                         lnb0, lnw1, lnb1, reinterpret_cast<const half_t*>(W0), b0, reinterpret_cast<const half_t*>(W1), b1, out_dim, d_,
+                         nb, eps, ctl, kind, layer, B);
+    else hipLaunchKernelGGL(head_fc_kernel<bf16_t>, grid, dim3(256), smem, reinterpret_cast<hipStream_t>(stream), s_, src_stride, in_dim, pro, lnw0,
                          lnb0, lnw1, lnb1, reinterpret_cast<const bf16_t*>(W0), b0, reinterpret_cast<const bf16_t*>(W1), b1, out_dim, d_,
                          nb, eps, ctl, kind, layer, B);
   }
@@ -1591,7 +1612,7 @@ extern "C" long deer_head_fused_granules(int B, int d, int H, int L, int n_fc, c
 extern "C" int deer_head_fused(const deer_head_fused_args* args, int w_is_f32, int n_workgroups, void* stream) {
   if (args == nullptr) return DEER_ERR_SHAPE;
   deer_head_fused_args a = *args;
-  if (w_is_f32) return DEER_ERR_SHAPE;                    // the fp32 arithmetic keeps the separate kernels (single-stream parity path)
+  if (w_is_f32) return DEER_ERR_SHAPE;                    // bf16 weights only: the fp32 / fp16 arithmetics keep the separate kernels
   // one environment only for now: the 8-environment instantiation (32 accumulators + the prefetched rows + the LayerNorm staging) spills
   // 273 VGPRs under hipcc - env batches keep the separate kernels
   if (args->B != 1) return DEER_ERR_SHAPE;
@@ -1651,12 +1672,13 @@ extern "C" int deer_head_final_multi(const float* src, int src_stride, int in_di
   if (A < 1 || A > 8 || (A > 1 && ctl != nullptr && act_ext == nullptr)) return DEER_ERR_SHAPE;
   const int smem = (2 * in_dim + 16 + 64 + 4) * (int)sizeof(float);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (w_is_f32)
-    hipLaunchKernelGGL(head_final_kernel<float>, dim3(B), dim3(512), smem, st, src, src_stride, in_dim, pro, lnw0, lnb0, lnw1, lnb1,
+  if (w_is_f32 == 1) hipLaunchKernelGGL(head_final_kernel<float>, dim3(B), dim3(512), smem, st, src, src_stride, in_dim, pro, lnw0, lnb0, lnw1, lnb1,
                        reinterpret_cast<const float*>(Wa), ba, reinterpret_cast<const float*>(Wg), bg, ctl, kind, layer, slot,
                        thresholds, force, thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps, A, act_ext);
-  else
-    hipLaunchKernelGGL(head_final_kernel<bf16_t>, dim3(B), dim3(512), smem, st, src, src_stride, in_dim, pro, lnw0, lnb0, lnw1, lnb1,
+    else if (w_is_f32 == 2) hipLaunchKernelGGL(head_final_kernel<half_t>, dim3(B), dim3(512), smem, st, src, src_stride, in_dim, pro, lnw0, lnb0, lnw1, lnb1,
+                       reinterpret_cast<const half_t*>(Wa), ba, reinterpret_cast<const half_t*>(Wg), bg, ctl, kind, layer, slot,
+                       thresholds, force, thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps, A, act_ext);
+    else hipLaunchKernelGGL(head_final_kernel<bf16_t>, dim3(B), dim3(512), smem, st, src, src_stride, in_dim, pro, lnw0, lnb0, lnw1, lnb1,
                        reinterpret_cast<const bf16_t*>(Wa), ba, reinterpret_cast<const bf16_t*>(Wg), bg, ctl, kind, layer, slot,
                        thresholds, force, thr_type, leq, h_tmp, c_tmp, h_state, c_state, L, H, B, action_dbg, eps, A, act_ext);
   DEER_LAUNCH_CHECK();

@@ -57,7 +57,8 @@ __global__ void ingest_rows_kernel(const SrcT* __restrict__ src, void* __restric
 
 // row-major W[N,K] (f32 or bf16) -> MFMA-fragment order Wp[N/16][K/32][64 lanes][8] bf16 (the layout deer_gemm_skinny streams)
 // LO: the second plane of the fp32 arithmetic, bf16(w - bf16(w)) - together with the hi plane ~16 mantissa bits of every weight
-template <typename SrcT, bool LO = false>
+// F16: fp16 fragments (deer_config.tower_f16: the whole product arithmetic on fp16 operands)
+template <typename SrcT, bool LO = false, bool F16 = false>
 __global__ void ingest_pack_kernel(const SrcT* __restrict__ W, bf16_t* __restrict__ Wp, int N, int K) {
   const long total = (long)(N >> 4) * (K >> 5) * 64;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -74,7 +75,7 @@ __global__ void ingest_pack_kernel(const SrcT* __restrict__ W, bf16_t* __restric
         a -= bf2f(f2bf(a));
         b -= bf2f(f2bf(b));
       }
-      o[e] = pack2bf(a, b);
+      o[e] = pack2x<F16>(a, b);
     }
     *reinterpret_cast<uint4*>(Wp + idx * 8) = uint4{o[0], o[1], o[2], o[3]};
   }
@@ -159,6 +160,8 @@ struct ProfRec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
 
 struct deer_model {
   deer_config c;
+  int wkind = 0;                    // head weight rows: 0 = bf16, 1 = f32 (precision = 1), 2 = fp16 (tower_f16) - csrc/head.hip
+  bool f16 = false;                 // every 16-bit operand of the product arithmetic in IEEE fp16 (deer_config.tower_f16)
   // derived
   int P, tok, W, kpad, nl, p_inner, Lp, d, xinner, n_xattn, H, Lh, B, N, n_fc;
   int fc_dims[3];
@@ -348,7 +351,7 @@ void build_arena(deer_model* m) {
   }
   // ---- LLM: projections pre-packed in MFMA-fragment order; to_kv of all x-attn layers concatenated (media is layer-invariant)
   const int d = m->d, xin = m->xinner;
-  m->wte = add_slot(m, "lang_encoder.transformer.wte.weight", c.precision ? SK_F32 : SK_BF16, c.vocab_size, d);
+  m->wte = add_slot(m, "lang_encoder.transformer.wte.weight", c.precision ? SK_F32 : (c.tower_f16 ? SK_F16 : SK_BF16), c.vocab_size, d);
   m->n_xattn = 0;
   for (int n = 0; n < c.n_layers; ++n)
     if ((n + 1) % c.cross_attn_every_n_layers == 0) ++m->n_xattn;
@@ -400,7 +403,7 @@ void build_arena(deer_model* m) {
   }
   // ---- action head (DeterministicDecoder, action_head.py:408-497): LN-LSTM = [LSTM, LN, Dropout] x L under rnn.layers.{3l, 3l+1}
   const std::string p = "extra_exit.";
-  const int HK = c.precision ? SK_F32 : SK_BF16;      // head weights: bf16, or f32 for the fp32 arithmetic
+  const int HK = c.precision ? SK_F32 : (c.tower_f16 ? SK_F16 : SK_BF16);      // head weights: bf16 / fp16, or f32 for the fp32 arithmetic
   const int H = m->H;
   if (c.use_state) {                                   // action_head.py:443-453
     m->w_arm = add_slot(m, p + "embed_arm_state.0.weight", SK_F32, d, 6);
@@ -896,9 +899,9 @@ int media_kv(deer_model* m, void* st) {
   if (m->c.precision) return media_kv_f32(m, st);
   if (!m->n_xattn) return DEER_OK;
   const void* media = m->media_override ? m->media_override : m->Wk<void>(m->vis_x);
-  // fp16 tower: fp16 media tokens x fp16 to_kv weights, the K / V leave as bf16 (what the trunk's x-attn kernels read)
-  return gemm(m, media, m->A<void>(m->wkv_all), m->Wk<void>(m->kv_all), (long)m->N * m->nl, (long)m->n_xattn * 2 * m->xinner, m->W,
-              m->c.tower_f16 ? DEER_EPI_BF16OUT : DEER_EPI_BF16, nullptr, st);
+  // the K / V leave in the arithmetic's own 16-bit format (fp16 engines: fp16 K / V for the *_f16 x-attn kernels)
+  return gemm(m, media, m->A<void>(m->wkv_all), m->Wk<void>(m->kv_all), (long)m->N * m->nl, (long)m->n_xattn * 2 * m->xinner, m->W, DEER_EPI_BF16,
+              nullptr, st);
 }
 
 // ---- LLM ----------------------------------------------------------------------------------------------------------------
@@ -915,13 +918,13 @@ int skinny(deer_model* m, const void* Wp, long N, long K, int R, float* out_slab
   *stride_out = (long)mpad * N;
   {
     Bracket b(m, "deer_gemm_skinny", 2.0 * R * N * K, 2.0 * N * K, st);    // algorithmic bytes = the bf16 weights, once
-    DEER_TRY(deer_gemm_skinny(A, lda, a_slab, s_in, (long)mpad * K, a_mode, Wp, out_slab, R, (int)N, (int)K, S, ctl, st));
+    DEER_TRY((m->f16 ? deer_gemm_skinny_f16 : deer_gemm_skinny)(A, lda, a_slab, s_in, (long)mpad * K, a_mode, Wp, out_slab, R, (int)N, (int)K, S, ctl, st));
   }
   if (planes == 2) {   // fp32 arithmetic: W = hi + lo (two bf16 planes); the lo plane's products go into S more slabs of the same consumer
     auto it = m->pack_lo.find((size_t)(reinterpret_cast<const char*>(Wp) - m->arena));
     if (it == m->pack_lo.end()) return DEER_ERR_SHAPE;
     Bracket b(m, "deer_gemm_skinny", 2.0 * R * N * K, 2.0 * N * K, st);
-    DEER_TRY(deer_gemm_skinny(A, lda, a_slab, s_in, (long)mpad * K, a_mode, m->A<void>(it->second), out_slab + (size_t)S * mpad * N, R, (int)N, (int)K, S, ctl, st));
+    DEER_TRY((m->f16 ? deer_gemm_skinny_f16 : deer_gemm_skinny)(A, lda, a_slab, s_in, (long)mpad * K, a_mode, m->A<void>(it->second), out_slab + (size_t)S * mpad * N, R, (int)N, (int)K, S, ctl, st));
   }
   return DEER_OK;
 }
@@ -973,9 +976,9 @@ int skinny_hl(deer_model* m, const void* Wp, long N, long K, int R, float* out_s
   *stride_out = (long)mpad * N;
   Bracket b(m, "deer_gemm_skinny_hl", 2.0 * R * N * K, 2.0 * N * K, st);    // algorithmic bytes = the bf16 weights, once
   if (rc != nullptr && rc->cmap != nullptr)
-    return deer_gemm_skinny_hl_active(hi, lo, lda, Wp, out_slab, R, (int)N, (int)K, S, mpad, ctl, rc->cmap, rc->T, st);
-  if (R > 128) return deer_gemm_skinny_hl_rows(hi, lo, lda, Wp, out_slab, R, (int)N, (int)K, S, mpad, ctl, st);
-  return deer_gemm_skinny_hl(hi, lo, lda, Wp, out_slab, R, (int)N, (int)K, S, ctl, st);
+    return (m->f16 ? deer_gemm_skinny_hl_active_f16 : deer_gemm_skinny_hl_active)(hi, lo, lda, Wp, out_slab, R, (int)N, (int)K, S, mpad, ctl, rc->cmap, rc->T, st);
+  if (R > 128) return (m->f16 ? deer_gemm_skinny_hl_rows_f16 : deer_gemm_skinny_hl_rows)(hi, lo, lda, Wp, out_slab, R, (int)N, (int)K, S, mpad, ctl, st);
+  return (m->f16 ? deer_gemm_skinny_hl_f16 : deer_gemm_skinny_hl)(hi, lo, lda, Wp, out_slab, R, (int)N, (int)K, S, ctl, st);
 }
 
 // GELU(sum of the up-projection's slabs) -> hi / lo planes [R][C] (the activation of the down-projection)
@@ -983,8 +986,8 @@ int gelu_split(deer_model* m, const float* slab, int S, long stride, int R, long
   Bracket b(m, "deer_slab_gelu_split", 0, 4.0 * S * R * C + 4.0 * R * C, st);
   bf16_t* h = m->Wk<bf16_t>(m->h_hl);
   if (rc != nullptr && rc->cmap != nullptr)
-    return deer_slab_gelu_split_active(slab, S, stride, 1, h, h + m->hl_plane_h, R, (int)C, ctl, rc->cmap, rc->T, st);
-  return deer_slab_gelu_split(slab, S, stride, 1, h, h + m->hl_plane_h, R, (int)C, ctl, st);
+    return (m->f16 ? deer_slab_gelu_split_active_f16 : deer_slab_gelu_split_active)(slab, S, stride, 1, h, h + m->hl_plane_h, R, (int)C, ctl, rc->cmap, rc->T, st);
+  return (m->f16 ? deer_slab_gelu_split_f16 : deer_slab_gelu_split)(slab, S, stride, 1, h, h + m->hl_plane_h, R, (int)C, ctl, st);
 }
 
 // resadd with the LayerNorm output as hi / lo planes in xn_hl (rows x d)
@@ -993,9 +996,9 @@ int resadd_split(deer_model* m, int R, const Pending* p, const float* gamma, con
   Bracket b(m, "deer_resadd_ln", 0, 4.0 * R * m->d * ((p ? p->S : 0) + 3), st);
   bf16_t* h = m->Wk<bf16_t>(m->xn_hl);
   if (rc != nullptr && rc->cmap != nullptr)
-    return deer_resadd_ln_rows(rc->x, p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, gamma, beta, h, h + m->hl_plane_d,
+    return (m->f16 ? deer_resadd_ln_rows_f16 : deer_resadd_ln_rows)(rc->x, p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, gamma, beta, h, h + m->hl_plane_d,
                                nullptr, x_copy, R, m->d, kEps, ctl, rc->cmap, rc->T, rc->x_in, rc->cmap_old, m->B, rc->drop_upto, st);
-  return deer_resadd_ln_split(rc ? rc->x : m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma,
+  return (m->f16 ? deer_resadd_ln_split_f16 : deer_resadd_ln_split)(rc ? rc->x : m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma,
                               beta, h, h + m->hl_plane_d, nullptr, x_copy, R, m->d, kEps, ctl, st);
 }
 
@@ -1003,7 +1006,7 @@ int resadd(deer_model* m, int R, const Pending* p, const float* gamma, const flo
            const RowCtx* rc = nullptr) {
   Bracket b(m, "deer_resadd_ln", 0, 4.0 * R * m->d * ((p ? p->S : 0) + 3), st);
   if (rc != nullptr && rc->cmap != nullptr)
-    return deer_resadd_ln_rows(rc->x, p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, gamma, beta, nullptr, nullptr,
+    return (m->f16 ? deer_resadd_ln_rows_f16 : deer_resadd_ln_rows)(rc->x, p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, gamma, beta, nullptr, nullptr,
                                gamma ? m->Wk<float>(m->xn) : nullptr, x_copy, R, m->d, kEps, ctl, rc->cmap, rc->T, rc->x_in, rc->cmap_old, m->B, rc->drop_upto, st);
   return deer_resadd_ln(rc ? rc->x : m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma, beta,
                         nullptr, gamma ? m->Wk<float>(m->xn) : nullptr, x_copy, R, m->d, kEps, ctl, st);
@@ -1031,14 +1034,14 @@ bool r16_ok(const deer_model* m, int T) {
 int resadd_packed(deer_model* m, int R, const Pending* p, const float* gamma, const float* beta, float* x_copy, const int* ctl, void* st) {
   Bracket b(m, "deer_resadd_ln", 0, 4.0 * R * m->d * ((p ? p->S : 0) + 3), st);
   bf16_t* h = m->Wk<bf16_t>(m->xn_hl);
-  return deer_resadd_ln_packed(m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma, beta, h,
+  return (m->f16 ? deer_resadd_ln_packed_f16 : deer_resadd_ln_packed)(m->Wk<float>(m->x), p ? p->slab : nullptr, p ? p->S : 0, p ? p->stride : 0, p ? p->gate : nullptr, nullptr, gamma, beta, h,
                                h + m->hl_plane_d, nullptr, x_copy, R, m->d, kEps, ctl, st);
 }
 
 int wide_gemm(deer_model* m, const void* Wp, long N, int epi, float* out_f32, bf16_t* out_hi, bf16_t* out_lo, long ldo, int T, const int* ctl, void* st) {
   Bracket b(m, "deer_trunk_wide_gemm", 2.0 * T * N * m->d, 2.0 * N * m->d, st);      // algorithmic bytes = the bf16 weights, once
   const bf16_t* h = m->Wk<bf16_t>(m->xn_hl);
-  return deer_trunk_wide_gemm(h, h + m->hl_plane_d, Wp, (int)N, m->d, epi, out_f32, out_hi, out_lo, (int)ldo, m->Wk<float>(m->ln_stats), T, ctl, st);
+  return (m->f16 ? deer_trunk_wide_gemm_f16 : deer_trunk_wide_gemm)(h, h + m->hl_plane_d, Wp, (int)N, m->d, epi, out_f32, out_hi, out_lo, (int)ldo, m->Wk<float>(m->ln_stats), T, ctl, st);
 }
 
 int llm_layer_r16(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool finalize, bool use_ctl, void* st) {
@@ -1066,7 +1069,7 @@ int llm_layer_r16(deer_model* m, int i, int T, bool use_mask, bool pending_in, b
   long stride;
   // N1 experiment (csrc/persistent_layer.hip): the whole layer as ONE persistent launch - same device functions, same order, bit-identical
   // results, SLOWER; never the default (a persistent launch needs all of its workgroups resident: one engine per GPU)
-  if (m->persistent_layer && L.has_xa && c.xattn_ff_mult == 4 && c.mlp_ratio == 4) {
+  if (m->persistent_layer && !m->f16 && L.has_xa && c.xattn_ff_mult == 4 && c.mlp_ratio == 4) {
     const XattnW& X = L.xa;
     deer_trunk_layer_args a{};
     a.T = T; a.d = d; a.xinner = xin; a.heads = c.xattn_heads; a.n_heads = c.n_heads; a.ffw = (int)ffw; a.n_kv = 2 * m->nl; a.n_per_media = 2 * m->nl;
@@ -1098,7 +1101,7 @@ int llm_layer_r16(deer_model* m, int i, int T, bool use_mask, bool pending_in, b
     if ((size_t)c.xattn_heads * 16 * d > m->slab_a_elems) return DEER_ERR_SHAPE;
     {
       Bracket b(m, "deer_xattn_fused", 2.0 * T * d * xin * 2, 2.0 * 2 * xin * d, st);
-      DEER_TRY(deer_xattn_fused_packed(xh, xh + m->hl_plane_d, d, m->A<void>(X.wq), kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, n_media,
+      DEER_TRY((m->f16 ? deer_xattn_fused_packed_f16 : deer_xattn_fused_packed)(xh, xh + m->hl_plane_d, d, m->A<void>(X.wq), kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, n_media,
                                        m->A<void>(X.wo), slab_a, 16L * d, T, c.xattn_heads, 1.0f / sqrtf((float)c.xattn_dim_head), ctl, st));
     }
     pend = Pending{slab_a, c.xattn_heads, 16L * d, m->A<float>(X.ag)};
@@ -1117,7 +1120,7 @@ int llm_layer_r16(deer_model* m, int i, int T, bool use_mask, bool pending_in, b
   {
     Bracket b(m, "deer_trunk_mpt_attn", 0, 0, st);
     const unsigned char* km = m->mask_override ? m->mask_override : m->Wk<unsigned char>(m->key_mask);
-    DEER_TRY(deer_trunk_mpt_attn(qkv, m->Wk<float>(m->ln_stats), d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
+    DEER_TRY((m->f16 ? deer_trunk_mpt_attn_f16 : deer_trunk_mpt_attn)(qkv, m->Wk<float>(m->ln_stats), d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
                                  (float)c.alibi_bias_max, aoh, aol, d, T, ctl, st));
   }
   DEER_TRY(skinny_hl(m, m->A<void>(L.wo), d, d, T, slab_a, m->slab_a_elems, aoh, aol, d, ctl, st, &S, &stride));
@@ -1205,10 +1208,10 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
       if ((size_t)c.xattn_heads * mpad * d > m->slab_a_elems) return DEER_ERR_SHAPE;
       Bracket b(m, "deer_xattn_fused", 2.0 * R * d * xin * 2, 2.0 * 2 * xin * d, st);
       if (rc != nullptr)
-        DEER_TRY(deer_xattn_fused_active(xn, d, m->A<void>(X.wq), kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, n_media, m->A<void>(X.wo),
+        DEER_TRY((m->f16 ? deer_xattn_fused_active_f16 : deer_xattn_fused_active)(xn, d, m->A<void>(X.wq), kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, n_media, m->A<void>(X.wo),
                                          slab_a, (long)mpad * d, T, c.xattn_heads, B, 1.0f / sqrtf((float)c.xattn_dim_head), ctl, rc->cmap, st));
       else
-        DEER_TRY(deer_xattn_fused(xn, d, m->A<void>(X.wq), kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, n_media, m->A<void>(X.wo),
+        DEER_TRY((m->f16 ? deer_xattn_fused_f16 : deer_xattn_fused)(xn, d, m->A<void>(X.wq), kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, n_media, m->A<void>(X.wo),
                                   slab_a, (long)mpad * d, T, c.xattn_heads, B, 1.0f / sqrtf((float)c.xattn_dim_head), ctl, st));
       S = c.xattn_heads;
       stride = (long)mpad * d;
@@ -1216,7 +1219,7 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
       DEER_TRY(skinny(m, m->A<void>(X.wq), xin, d, R, slab_b, m->slab_b_elems, xn, d, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
       {
         Bracket b(m, "deer_xattn_mfma", 0, 0, st);
-        DEER_TRY(deer_xattn_mfma(slab_b, S, stride, xin, kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, ao, 1, xin, T, n_media,
+        DEER_TRY((m->f16 ? deer_xattn_mfma_f16 : deer_xattn_mfma)(slab_b, S, stride, xin, kv, m->n_xattn * 2 * xin, xin, m->Wk<int>(m->text_time), n_media, ao, 1, xin, T, n_media,
                                  c.xattn_heads, B, 1.0f / sqrtf((float)c.xattn_dim_head), ctl, st));
       }
       DEER_TRY(skinny(m, m->A<void>(X.wo), d, xin, R, slab_a, m->slab_a_elems, ao, xin, nullptr, 0, DEER_A_F32, ctl, st, &S, &stride));
@@ -1247,10 +1250,10 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
     {
       Bracket b(m, "deer_mpt_attn_small", 0, 0, st);
       if (rc != nullptr)
-        DEER_TRY(deer_mpt_attn_small_hl_active(slab_b, S, stride, d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
+        DEER_TRY((m->f16 ? deer_mpt_attn_small_hl_active_f16 : deer_mpt_attn_small_hl_active)(slab_b, S, stride, d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
                                                (float)c.alibi_bias_max, m->Wk<float>(m->qkv_ws), aoh, aoh + m->hl_plane_d, d, T, B, ctl, rc->cmap, st));
       else
-        DEER_TRY(deer_mpt_attn_small_hl(slab_b, S, stride, d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
+        DEER_TRY((m->f16 ? deer_mpt_attn_small_hl_f16 : deer_mpt_attn_small_hl)(slab_b, S, stride, d, c.n_heads, m->A<float>(L.qlnw), m->A<float>(L.klnw), kEps, use_mask ? km : nullptr,
                                         (float)c.alibi_bias_max, m->Wk<float>(m->qkv_ws), aoh, aoh + m->hl_plane_d, d, T, B, ctl, st));
     }
     DEER_TRY(skinny_hl(m, m->A<void>(L.wo), d, d, R, slab_a, m->slab_a_elems, aoh, aoh + m->hl_plane_d, d, ctl, st, &S, &stride, rc));
@@ -1300,7 +1303,7 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
   if (feats == nullptr) feats = m->Wk<float>(m->hidden) + (size_t)layer * rows_cap * d;     // [B*T, d]: env b owns rows b*T .. b*T+T-1
   const unsigned char* km = use_mask ? (m->mask_override ? m->mask_override : m->Wk<unsigned char>(m->key_mask)) : nullptr;
   // ---- control steps of one environment: the whole evaluation as ONE launch (csrc/head.hip: head_fused_kernel) ----
-  if (m->head_fused && head == 0 && use_ctl && !no_ctl_final && feats_default && kind != DEER_KIND_COMMIT && B == 1 && !c.precision && !c.use_state &&
+  if (m->head_fused && !m->f16 && head == 0 && use_ctl && !no_ctl_final && feats_default && kind != DEER_KIND_COMMIT && B == 1 && !c.precision && !c.use_state &&
       m->head_pre && m->ghh_valid && m->Lh <= 4 && m->n_fc <= 3 && d <= 2048 && H <= 1024) {
     deer_head_fused_args a{};
     a.feats = feats; a.T = T; a.d = d; a.avg = c.pooling_avg; a.key_mask = km;
@@ -1364,10 +1367,10 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
     Bracket b(m, "deer_head_lstm_layer", 0, 2.0 * 4 * H * (in_dim + (pre ? 0 : H)), st);
     if (pre)
       DEER_TRY(deer_head_lstm_layer_pre(src, bstride, mode, T, in_dim, lnw, lnb, m->A<void>(Lw.wih), m->A<float>(Lw.bih), m->Wk<float>(m->ghh) + 4 * l * lst,
-                                        c_prev + l * lst, h_tmp + l * lst, c_tmp + l * lst, H, B, kEps, ctl, kind, layer, c.precision, st));
+                                        c_prev + l * lst, h_tmp + l * lst, c_tmp + l * lst, H, B, kEps, ctl, kind, layer, m->wkind, st));
     else
       DEER_TRY(deer_head_lstm_layer(src, bstride, mode, T, in_dim, lnw, lnb, m->A<void>(Lw.wih), m->A<void>(Lw.whh), m->A<float>(Lw.bih), m->A<float>(Lw.bhh),
-                                    h_prev + l * lst, c_prev + l * lst, h_tmp + l * lst, c_tmp + l * lst, H, B, kEps, ctl, kind, layer, c.precision, st));
+                                    h_prev + l * lst, c_prev + l * lst, h_tmp + l * lst, c_tmp + l * lst, H, B, kEps, ctl, kind, layer, m->wkind, st));
   }
   const float* src = h_tmp + (m->Lh - 1) * lst;
   int in_dim = H, sstride = H, pro = DEER_PRO_RAW;
@@ -1380,7 +1383,7 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
     {
       Bracket b(m, "deer_head_fc", 0, 0, st);
       DEER_TRY(deer_head_fc(src, sstride, in_dim, pro, ln[0], ln[1], ln[2], ln[3], m->A<void>(F.w[0]), m->A<float>(F.b[0]), m->A<void>(F.w[1]),
-                            m->A<float>(F.b[1]), dim, z, B, kEps, ctl, kind, layer, c.precision, st));
+                            m->A<float>(F.b[1]), dim, z, B, kEps, ctl, kind, layer, m->wkind, st));
     }
     src = z; in_dim = dim; sstride = 2 * dim;
     if (c.mlp_layernorm) { pro = DEER_PRO_GROUP_LN_RELU; ln[0] = m->A<float>(F.lnw[0]); ln[1] = m->A<float>(F.lnb[0]); ln[2] = m->A<float>(F.lnw[1]); ln[3] = m->A<float>(F.lnb[1]); }
@@ -1391,7 +1394,7 @@ int head_eval(deer_model* m, int layer, int T, int kind, int slot, bool force, b
   return deer_head_final_multi(src, sstride, in_dim, pro, ln[0], ln[1], ln[2], ln[3], m->A<void>(wa), m->A<float>(ba), m->A<void>(wg), m->A<float>(bg),
                                no_ctl_final ? nullptr : m->Wk<int>(m->ctl), kind, layer, slot, thr, force ? 1 : 0, m->thr_type, m->leq, h_tmp, c_tmp,
                                m->Wk<float>(shadow ? m->h_shadow : m->h_state), m->Wk<float>(shadow ? m->c_shadow : m->c_state), m->Lh, H, B,
-                               m->Wk<float>(m->action_dbg), kEps, c.precision, std::max(1, c.multi_step_action), m->Wk<float>(m->act_ext), st);
+                               m->Wk<float>(m->action_dbg), kEps, m->wkind, std::max(1, c.multi_step_action), m->Wk<float>(m->act_ext), st);
 }
 
 // per layer of the dynamic step: (need_pseudo, is_exit, exit slot) - mosaic_gpt_3b.py:397-443, value_net.py:122-125
@@ -1428,7 +1431,7 @@ int embed(deer_model* m, int T, void* st) {
   const long long* ids = m->ids_override ? m->ids_override : m->Wk<long long>(m->ids);
   if (m->c.precision)
     return deer_embed_tokens_f32(ids, m->A<float>(m->wte), m->Wk<float>(m->x), m->Wk<int>(m->text_time), T, m->B, m->d, m->c.vocab_size, m->c.media_token_id, st);
-  return deer_embed_tokens(ids, m->A<void>(m->wte), m->Wk<float>(m->x), m->Wk<int>(m->text_time), T, m->B, m->d, m->c.vocab_size, m->c.media_token_id, st);
+  return (m->f16 ? deer_embed_tokens_f16 : deer_embed_tokens)(ids, m->A<void>(m->wte), m->Wk<float>(m->x), m->Wk<int>(m->text_time), T, m->B, m->d, m->c.vocab_size, m->c.media_token_id, st);
 }
 
 int llm_dynamic(deer_model* m, int T, bool use_mask, bool shadow, void* st) {
@@ -1455,7 +1458,7 @@ int state_embed(deer_model* m, void* st) {
   if (!m->c.use_state) return DEER_OK;
   Bracket b(m, "deer_head_state_embed", 0, 0, st);
   return deer_head_state_embed(m->Wk<float>(m->state_in), m->A<float>(m->w_arm), m->A<float>(m->b_arm), m->A<float>(m->e_grip), m->A<void>(m->w_state),
-                               m->A<float>(m->b_state), m->Wk<float>(m->state_emb), m->d, m->B, m->c.precision, st);
+                               m->A<float>(m->b_state), m->Wk<float>(m->state_emb), m->d, m->B, m->wkind, st);
 }
 
 int llm_static(deer_model* m, int T, bool use_mask, int exit_id, void* st) {
@@ -1495,6 +1498,8 @@ int deer_model_create(const deer_config* cfg, deer_model** out) {
   if (c.tower_f16 && c.precision) return DEER_ERR_SHAPE;     // the fp32 arithmetic has no 16-bit tower
   deer_model* m = new deer_model();
   m->c = c;
+  m->f16 = c.tower_f16 != 0;
+  m->wkind = c.precision ? 1 : (m->f16 ? 2 : 0);
   const int g = c.image_size / c.patch_size;
   m->P = g * g;
   m->tok = m->P + 1;
@@ -1597,7 +1602,10 @@ int deer_model_load_tensor(deer_model* m, const char* name, const void* src, int
     if ((s.rows & 15) || (s.cols & 31)) return DEER_ERR_SHAPE;
     const long tot = (s.rows >> 4) * (s.cols >> 5) * 64;
     const int pb = (int)std::min<long>((tot + 255) / 256, 4096);
-    if (src_is_bf16) hipLaunchKernelGGL(ingest_pack_kernel<bf16_t>, dim3(pb), dim3(256), 0, st, (const bf16_t*)src, m->A<bf16_t>(s.dst[0]), (int)s.rows, s.cols);
+    if (m->c.tower_f16) {
+      if (src_is_bf16) hipLaunchKernelGGL((ingest_pack_kernel<bf16_t, false, true>), dim3(pb), dim3(256), 0, st, (const bf16_t*)src, m->A<bf16_t>(s.dst[0]), (int)s.rows, s.cols);
+      else hipLaunchKernelGGL((ingest_pack_kernel<float, false, true>), dim3(pb), dim3(256), 0, st, (const float*)src, m->A<bf16_t>(s.dst[0]), (int)s.rows, s.cols);
+    } else if (src_is_bf16) hipLaunchKernelGGL(ingest_pack_kernel<bf16_t>, dim3(pb), dim3(256), 0, st, (const bf16_t*)src, m->A<bf16_t>(s.dst[0]), (int)s.rows, s.cols);
     else hipLaunchKernelGGL(ingest_pack_kernel<float>, dim3(pb), dim3(256), 0, st, (const float*)src, m->A<bf16_t>(s.dst[0]), (int)s.rows, s.cols);
     if (s.dst[1] != SIZE_MAX) {
       if (src_is_bf16) hipLaunchKernelGGL((ingest_pack_kernel<bf16_t, true>), dim3(pb), dim3(256), 0, st, (const bf16_t*)src, m->A<bf16_t>(s.dst[1]), (int)s.rows, s.cols);
@@ -1704,7 +1712,7 @@ int deer_begin_step(deer_model* m, const int* step_info, void* stream) {
     const void* w[8];
     const float* bb[8];
     for (int l = 0; l < m->Lh; ++l) { w[l] = m->A<void>(m->lstm[l].whh); bb[l] = m->A<float>(m->lstm[l].bhh); }
-    DEER_TRY(deer_head_lstm_hh(w, bb, m->Lh, m->Wk<float>(m->h_state), m->Wk<float>(m->ghh), m->H, m->B, m->c.precision, stream));
+    DEER_TRY(deer_head_lstm_hh(w, bb, m->Lh, m->Wk<float>(m->h_state), m->Wk<float>(m->ghh), m->H, m->B, m->wkind, stream));
     m->ghh_valid = true;
   }
   Bracket b(m, "deer_ctl_begin_step", 0, 0, stream);

@@ -283,12 +283,13 @@ extern "C" int deer_resadd_ln_f16(float* x, const float* slab, int s_in, long sl
 
 // deer_resadd_ln with the LayerNorm output ALSO as two bf16 planes hi = bf16(y), lo = bf16(y - hi) (the pre-split activation operand
 // of deer_gemm_skinny_hl); out_f32 optional (deer_xattn_fused reads it).
-extern "C" int deer_resadd_ln_split(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
+template <bool F16>
+static int resadd_ln_split(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
                                     const float* gamma, const float* beta, void* out_hi, void* out_lo, float* out_f32, float* x_copy,
                                     int T, int d, float eps, const int* ctl, void* stream) {
   if (T <= 0 || d <= 0 || (d & 3) || d > 4096 || (slab != nullptr && s_in <= 0) || gamma == nullptr || out_hi == nullptr || out_lo == nullptr)
     return DEER_ERR_SHAPE;
-  hipLaunchKernelGGL(resadd_ln_kernel<256>, dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
+  hipLaunchKernelGGL((resadd_ln_kernel<256, F16>), dim3(T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
                      gamma, beta, reinterpret_cast<bf16_t*>(out_hi), out_f32, x_copy, d, eps, ctl, bias, reinterpret_cast<bf16_t*>(out_lo));
   DEER_LAUNCH_CHECK();
   return DEER_OK;
@@ -296,14 +297,15 @@ extern "C" int deer_resadd_ln_split(float* x, const float* slab, int s_in, long 
 
 // Env batches with compaction of exited environments: deer_resadd_ln / deer_resadd_ln_split (out_lo != NULL) restricted to the active slots
 // of `cmap` (rows_per_env rows per slot); x_in != NULL: the gathering first row operation of a compaction layer (see deer_rowmap above)
-extern "C" int deer_resadd_ln_rows(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* gamma, const float* beta,
+template <bool F16>
+static int resadd_ln_rows(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* gamma, const float* beta,
                                    void* out_bf16, void* out_lo, float* out_f32, float* x_copy, int T_rows, int d, float eps, const int* ctl,
                                    const int* cmap, int rows_per_env, const float* x_in, const int* cmap_old, int B, int drop_upto, void* stream) {
   if (T_rows <= 0 || d <= 0 || (d & 3) || d > 4096 || (slab != nullptr && s_in <= 0) || (gamma != nullptr && out_bf16 == nullptr && out_f32 == nullptr) ||
       cmap == nullptr || rows_per_env <= 0 || ctl == nullptr || B <= 0 || B > DEER_MAX_ENVS || (x_in != nullptr && (cmap_old == nullptr || x_in == x)))
     return DEER_ERR_SHAPE;
   deer_rowmap rm{cmap, rows_per_env, x_in, cmap_old, ctl, B, drop_upto};
-  hipLaunchKernelGGL(resadd_ln_kernel<256>, dim3(T_rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
+  hipLaunchKernelGGL((resadd_ln_kernel<256, F16>), dim3(T_rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
                      gamma, beta, reinterpret_cast<bf16_t*>(out_bf16), out_f32, x_copy, d, eps, ctl, static_cast<const float*>(nullptr),
                      reinterpret_cast<bf16_t*>(out_lo), 0, rm);
   DEER_LAUNCH_CHECK();
@@ -311,15 +313,50 @@ extern "C" int deer_resadd_ln_rows(float* x, const float* slab, int s_in, long s
 }
 
 // the same with the two planes in MFMA-fragment order [d/32][64][8] (T <= 16 rows: lane = 16 * (k % 32 / 8) + row); d % 32 == 0
-extern "C" int deer_resadd_ln_packed(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
+template <bool F16>
+static int resadd_ln_packed(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
                                      const float* gamma, const float* beta, void* out_hi, void* out_lo, float* out_f32, float* x_copy,
                                      int T, int d, float eps, const int* ctl, void* stream) {
   if (T <= 0 || T > 16 || d <= 0 || (d & 31) || d > 4096 || (slab != nullptr && s_in <= 0) || gamma == nullptr || out_hi == nullptr || out_lo == nullptr)
     return DEER_ERR_SHAPE;
-  hipLaunchKernelGGL(resadd_ln_kernel<512>, dim3(T), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
+  hipLaunchKernelGGL((resadd_ln_kernel<512, F16>), dim3(T), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), x, slab, s_in, slab_stride, gate,
                      gamma, beta, reinterpret_cast<bf16_t*>(out_hi), out_f32, x_copy, d, eps, ctl, bias, reinterpret_cast<bf16_t*>(out_lo), 1);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
+}
+
+// C entry points of the three forms above: bf16 planes, and - suffix _f16, round 6 - fp16 planes (operands of the *_f16 trunk GEMMs)
+extern "C" int deer_resadd_ln_split(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias, const float* gamma,
+                                    const float* beta, void* out_hi, void* out_lo, float* out_f32, float* x_copy, int T, int d, float eps, const int* ctl,
+                                    void* stream) {
+  return resadd_ln_split<false>(x, slab, s_in, slab_stride, gate, bias, gamma, beta, out_hi, out_lo, out_f32, x_copy, T, d, eps, ctl, stream);
+}
+extern "C" int deer_resadd_ln_split_f16(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias, const float* gamma,
+                                        const float* beta, void* out_hi, void* out_lo, float* out_f32, float* x_copy, int T, int d, float eps,
+                                        const int* ctl, void* stream) {
+  return resadd_ln_split<true>(x, slab, s_in, slab_stride, gate, bias, gamma, beta, out_hi, out_lo, out_f32, x_copy, T, d, eps, ctl, stream);
+}
+extern "C" int deer_resadd_ln_rows(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* gamma, const float* beta,
+                                   void* out_bf16, void* out_lo, float* out_f32, float* x_copy, int T_rows, int d, float eps, const int* ctl,
+                                   const int* cmap, int rows_per_env, const float* x_in, const int* cmap_old, int B, int drop_upto, void* stream) {
+  return resadd_ln_rows<false>(x, slab, s_in, slab_stride, gate, gamma, beta, out_bf16, out_lo, out_f32, x_copy, T_rows, d, eps, ctl, cmap, rows_per_env, x_in,
+                               cmap_old, B, drop_upto, stream);
+}
+extern "C" int deer_resadd_ln_rows_f16(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* gamma, const float* beta,
+                                       void* out_f16, void* out_lo, float* out_f32, float* x_copy, int T_rows, int d, float eps, const int* ctl,
+                                       const int* cmap, int rows_per_env, const float* x_in, const int* cmap_old, int B, int drop_upto, void* stream) {
+  return resadd_ln_rows<true>(x, slab, s_in, slab_stride, gate, gamma, beta, out_f16, out_lo, out_f32, x_copy, T_rows, d, eps, ctl, cmap, rows_per_env, x_in,
+                              cmap_old, B, drop_upto, stream);
+}
+extern "C" int deer_resadd_ln_packed(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias, const float* gamma,
+                                     const float* beta, void* out_hi, void* out_lo, float* out_f32, float* x_copy, int T, int d, float eps, const int* ctl,
+                                     void* stream) {
+  return resadd_ln_packed<false>(x, slab, s_in, slab_stride, gate, bias, gamma, beta, out_hi, out_lo, out_f32, x_copy, T, d, eps, ctl, stream);
+}
+extern "C" int deer_resadd_ln_packed_f16(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias, const float* gamma,
+                                         const float* beta, void* out_hi, void* out_lo, float* out_f32, float* x_copy, int T, int d, float eps,
+                                         const int* ctl, void* stream) {
+  return resadd_ln_packed<true>(x, slab, s_in, slab_stride, gate, bias, gamma, beta, out_hi, out_lo, out_f32, x_copy, T, d, eps, ctl, stream);
 }
 
 // ---- ViT patch embedding, step 1: im2col of 14x14/14 patches -> 16-bit [N*P, Kpad] -----------------------
@@ -405,6 +442,7 @@ extern "C" int deer_vit_embed_lnpre(const float* patch, const float* cls, const 
 
 // ---- token embedding (mosaic_gpt_3b.py:341) + media bookkeeping (flamingo_lm.py:211, helpers.py:208) ----
 // x[t] = wte[ids[t]] (bf16 table -> f32 residual stream); text_time[t] = cumsum(ids == media_token_id).
+template <bool F16>
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* __restrict__ ids, const bf16_t* __restrict__ wte,
                                                            float* __restrict__ x, int* __restrict__ text_time, int T, int d,
                                                            int vocab, int media_id) {
@@ -412,7 +450,7 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* __re
   long long id = ids[row];
   if (id < 0) id = 0;
   if (id >= vocab) id = vocab - 1;
-  for (int i = threadIdx.x; i < d; i += 256) x[(long)row * d + i] = bf2f(wte[id * d + i]);
+  for (int i = threadIdx.x; i < d; i += 256) x[(long)row * d + i] = x2f<F16>(wte[id * d + i]);
   if (threadIdx.x == 0) {
     int c = 0;
     for (int j = 0; j <= t; ++j) c += (ids[e0 + j] == media_id) ? 1 : 0;
@@ -420,13 +458,21 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* __re
   }
 }
 
-extern "C" int deer_embed_tokens(const long long* ids, const void* wte, float* x, int* text_time, int T, int batch, int d,
-                                 int vocab, int media_id, void* stream) {
+template <bool F16>
+static int embed_tokens(const long long* ids, const void* wte, float* x, int* text_time, int T, int batch, int d, int vocab, int media_id, void* stream) {
   if (T <= 0 || batch <= 0 || d <= 0 || vocab <= 0) return DEER_ERR_SHAPE;
-  hipLaunchKernelGGL(embed_tokens_kernel, dim3(T * batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ids,
+  hipLaunchKernelGGL(embed_tokens_kernel<F16>, dim3(T * batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ids,
                      reinterpret_cast<const bf16_t*>(wte), x, text_time, T, d, vocab, media_id);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
+}
+extern "C" int deer_embed_tokens(const long long* ids, const void* wte, float* x, int* text_time, int T, int batch, int d,
+                                 int vocab, int media_id, void* stream) {
+  return embed_tokens<false>(ids, wte, x, text_time, T, batch, d, vocab, media_id, stream);
+}
+extern "C" int deer_embed_tokens_f16(const long long* ids, const void* wte, float* x, int* text_time, int T, int batch, int d,
+                                     int vocab, int media_id, void* stream) {   // fp16 embedding table (round 6)
+  return embed_tokens<true>(ids, wte, x, text_time, T, batch, d, vocab, media_id, stream);
 }
 
 // ---- broadcast a [rows, C] f32 parameter to `batch` copies (Perceiver latents, helpers.py:128) -------------

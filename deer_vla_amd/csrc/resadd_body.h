@@ -64,7 +64,7 @@ __device__ __forceinline__ float4 ln_add4(const float4 y, const float4 b) {
 
 // NT threads per row: 256, or 512 for the one-environment trunk (<= 16 rows: the launch is a latency chain - with 512 threads a thread
 // owns ONE float4 column of a 2048-wide row and all of its slab loads are in flight together, one L2 round trip instead of four)
-template <int NT, bool F16 = false>   // F16: out_bf receives fp16 (the vision tower's fp16 arithmetic; no hi / lo planes there)
+template <int NT, bool F16 = false>   // F16: the 16-bit outputs (out_bf, and the hi / lo planes out_bf + out_lo) are fp16
 __device__ __forceinline__ void resadd_ln_body(float* __restrict__ x, const float* __restrict__ slab, int s_in,
                                                         long slab_stride, const float* __restrict__ gate,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -168,16 +168,16 @@ __device__ __forceinline__ void resadd_ln_body(float* __restrict__ x, const floa
       float4 y = ln_norm4(v[j], mean, rstd, gv[j]);
       if (beta != nullptr) y = ln_add4(y, bv[j]);
       if (out_bf != nullptr) {
-        const uint32_t h01 = pack2x<F16>(y.x, y.y), h23 = pack2x<F16>(y.z, y.w);
+        uint32_t h01, h23, l01, l23;
+        split2<F16>(y.x, y.y, h01, l01);
+        split2<F16>(y.z, y.w, h23, l23);
         // packed: MFMA-fragment order [k-tile][lane = 16 * (k % 32 / 8) + row][8] - the <= 16 rows of one environment read back as ONE
         // contiguous 1 KiB per k-tile and plane (deer_trunk_wide_gemm, deer_xattn_fused_packed)
         const int col = i4 * 4;
         const long o = packed ? (((long)(col >> 5) * 64 + ((col & 31) >> 3) * 16 + r) * 8 + (col & 7)) : ((long)r * d + col);
         *reinterpret_cast<uint2*>(out_bf + o) = uint2{h01, h23};
-        if (!F16 && out_lo != nullptr)      // second bf16 plane: y = hi + lo to ~16 mantissa bits (activation operand of deer_gemm_skinny_hl)
-          *reinterpret_cast<uint2*>(out_lo + o) =
-              uint2{pack2bf(y.x - __uint_as_float(h01 << 16), y.y - __uint_as_float(h01 & 0xffff0000u)),
-                    pack2bf(y.z - __uint_as_float(h23 << 16), y.w - __uint_as_float(h23 & 0xffff0000u))};
+        if (out_lo != nullptr)      // second plane: y = hi + lo to ~16 (bf16) / ~22 (fp16) significand bits (activation operand of deer_gemm_skinny_hl)
+          *reinterpret_cast<uint2*>(out_lo + o) = uint2{l01, l23};
       }
       if (out_f32 != nullptr) *reinterpret_cast<float4*>(out_f32 + (long)r * d + (long)i4 * 4) = y;
     }

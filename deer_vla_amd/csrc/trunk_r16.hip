@@ -33,7 +33,7 @@ enum { TR_EPI_F32 = 0, TR_EPI_GELU_PLANES = 1, TR_EPI_F32_STATS = 2 };
 // K = 4096 (MPT-7B, round 5: 16 k-tiles per wave - the weight + activation fragments of TWO column tiles would not fit the registers;
 // the workgroup streams the same 128 KB of weights either way)
 // (bodies are device functions taking the LOGICAL workgroup index: csrc/persistent_layer.hip runs them as phases of one launch)
-template <int KS, int EPI, int CT = 2>
+template <int KS, int EPI, int CT = 2, bool F16 = false>
 __device__ __forceinline__ void trunk_wide_gemm_body(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo,
                                                      const bf16_t* __restrict__ Wp, float* __restrict__ out_f32,
                                                      bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo,
@@ -67,8 +67,8 @@ __device__ __forceinline__ void trunk_wide_gemm_body(const bf16_t* __restrict__ 
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       const bf16x8 wf = __builtin_bit_cast(bf16x8, w[t][s]);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, ah[s], acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, al[s], acc[t], 0, 0, 0);
+      acc[t] = mfma16<F16>(wf, ah[s], acc[t]);
+      acc[t] = mfma16<F16>(wf, al[s], acc[t]);
     }
   // K partials of the 8 waves -> LDS -> summed in wave order; lane holds out[m = c][n = 16 t + 4 g .. + 3]
 #pragma unroll
@@ -85,9 +85,10 @@ __device__ __forceinline__ void trunk_wide_gemm_body(const bf16_t* __restrict__ 
     v = gelu_erf(v);
     const float vn = __shfl_down(v, 1, 64);
     if ((n & 1) == 0 && m < T) {
-      const uint32_t h = pack2bf(v, vn);
+      uint32_t h, l;
+      split2<F16>(v, vn, h, l);
       *reinterpret_cast<uint32_t*>(out_hi + (long)m * ldo + col) = h;
-      *reinterpret_cast<uint32_t*>(out_lo + (long)m * ldo + col) = pack2bf(v - __uint_as_float(h << 16), vn - __uint_as_float(h & 0xffff0000u));
+      *reinterpret_cast<uint32_t*>(out_lo + (long)m * ldo + col) = l;
     }
   } else {
     if (m < T) out_f32[(long)m * ldo + col] = v;
@@ -104,14 +105,14 @@ __device__ __forceinline__ void trunk_wide_gemm_body(const bf16_t* __restrict__ 
   }
 }
 
-template <int KS, int EPI, int CT = 2>
+template <int KS, int EPI, int CT = 2, bool F16 = false>
 __global__ __launch_bounds__(64 * TR_NW) void trunk_wide_gemm_kernel(const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo,
                                                                     const bf16_t* __restrict__ Wp, float* __restrict__ out_f32,
                                                                     bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo,
                                                                     float* __restrict__ stats, int T, const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ __attribute__((aligned(16))) float opart[TR_NW * 16 * TR_OPITCH];
-  trunk_wide_gemm_body<KS, EPI, CT>(Ahi, Alo, Wp, out_f32, out_hi, out_lo, ldo, stats, T, blockIdx.x, opart);
+  trunk_wide_gemm_body<KS, EPI, CT, F16>(Ahi, Alo, Wp, out_f32, out_hi, out_lo, ldo, stats, T, blockIdx.x, opart);
 }
 
 #ifndef DEER_BODIES_ONLY
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(64 * TR_NW) void trunk_wide_gemm_kernel(const bf16_
 // [K/32][64 lanes][8] (lane = 16 * (k % 32 / 8) + row; written by deer_resadd_ln_packed), Wp packed [N/16][K/32][64][8].
 // epi: 0 = out_f32 [T][ldo]; 1 = exact GELU -> ROW-MAJOR bf16 hi / lo planes [T][ldo]; 2 = out_f32 + stats [N/32][16][2] (mean, centred
 // sum of squares of the row over each 32-column group; not at K = 4096).  K = 256, 2048 or 4096.
-extern "C" int deer_trunk_wide_gemm(const void* a_hi, const void* a_lo, const void* Wp, int N, int K, int epi, float* out_f32, void* out_hi,
+template <bool F16>
+static int trunk_wide_gemm(const void* a_hi, const void* a_lo, const void* Wp, int N, int K, int epi, float* out_f32, void* out_hi,
                                     void* out_lo, int ldo, float* stats, int T, const int* ctl, void* stream) {
   if (a_hi == nullptr || a_lo == nullptr || Wp == nullptr || T <= 0 || T > 16 || N <= 0 || (N & 31) || epi < 0 || epi > 2) return DEER_ERR_SHAPE;
   if (epi == TR_EPI_GELU_PLANES ? (out_hi == nullptr || out_lo == nullptr || (ldo & 1)) : out_f32 == nullptr) return DEER_ERR_SHAPE;
@@ -133,7 +135,7 @@ extern "C" int deer_trunk_wide_gemm(const void* a_hi, const void* a_lo, const vo
   bf16_t* oh = reinterpret_cast<bf16_t*>(out_hi);
   bf16_t* ol = reinterpret_cast<bf16_t*>(out_lo);
 #define DEER_TWG(KS_, EPI_) \
-  hipLaunchKernelGGL((trunk_wide_gemm_kernel<KS_, EPI_>), dim3(N / 32), dim3(64 * TR_NW), 0, st, ah, al, wp, out_f32, oh, ol, ldo, stats, T, ctl)
+  hipLaunchKernelGGL((trunk_wide_gemm_kernel<KS_, EPI_, 2, F16>), dim3(N / 32), dim3(64 * TR_NW), 0, st, ah, al, wp, out_f32, oh, ol, ldo, stats, T, ctl)
 #define DEER_TWG_E(KS_)                       \
   do {                                        \
     if (epi == 0) DEER_TWG(KS_, 0);           \
@@ -141,13 +143,21 @@ extern "C" int deer_trunk_wide_gemm(const void* a_hi, const void* a_lo, const vo
     else DEER_TWG(KS_, 2);                    \
   } while (0)
   if (K == 4096) {                                            // 16 columns per workgroup
-    if (epi == 0) hipLaunchKernelGGL((trunk_wide_gemm_kernel<16, 0, 1>), dim3(N / 16), dim3(64 * TR_NW), 0, st, ah, al, wp, out_f32, oh, ol, ldo, stats, T, ctl);
-    else hipLaunchKernelGGL((trunk_wide_gemm_kernel<16, 1, 1>), dim3(N / 16), dim3(64 * TR_NW), 0, st, ah, al, wp, out_f32, oh, ol, ldo, stats, T, ctl);
+    if (epi == 0) hipLaunchKernelGGL((trunk_wide_gemm_kernel<16, 0, 1, F16>), dim3(N / 16), dim3(64 * TR_NW), 0, st, ah, al, wp, out_f32, oh, ol, ldo, stats, T, ctl);
+    else hipLaunchKernelGGL((trunk_wide_gemm_kernel<16, 1, 1, F16>), dim3(N / 16), dim3(64 * TR_NW), 0, st, ah, al, wp, out_f32, oh, ol, ldo, stats, T, ctl);
   } else if (K == 2048) DEER_TWG_E(8); else DEER_TWG_E(1);
 #undef DEER_TWG_E
 #undef DEER_TWG
   DEER_LAUNCH_CHECK();
   return DEER_OK;
+}
+extern "C" int deer_trunk_wide_gemm(const void* a_hi, const void* a_lo, const void* Wp, int N, int K, int epi, float* out_f32, void* out_hi,
+                                    void* out_lo, int ldo, float* stats, int T, const int* ctl, void* stream) {
+  return trunk_wide_gemm<false>(a_hi, a_lo, Wp, N, K, epi, out_f32, out_hi, out_lo, ldo, stats, T, ctl, stream);
+}
+extern "C" int deer_trunk_wide_gemm_f16(const void* a_hi, const void* a_lo, const void* Wp, int N, int K, int epi, float* out_f32, void* out_hi,
+                                        void* out_lo, int ldo, float* stats, int T, const int* ctl, void* stream) {   // fp16 weights / planes (round 6)
+  return trunk_wide_gemm<true>(a_hi, a_lo, Wp, N, K, epi, out_f32, out_hi, out_lo, ldo, stats, T, ctl, stream);
 }
 #endif  // DEER_BODIES_ONLY
 
@@ -169,7 +179,7 @@ KT_DEFINE(mpt_attn)
 // instead of two), the moments are combined in one pass over registers, and a query row is ONE WAVE from scores to output - lane =
 // (key j = lane / 4, quarter of the head dimension): partial dot products meet by two xor-shuffles, the softmax runs over the 16
 // key groups by four more, P V takes the probabilities from lane registers (v_readlane) - two barriers instead of five.
-template <int NT>     // threads of the workgroup (256; 512 as a phase of the persistent layer)
+template <int NT, bool F16 = false>     // threads of the workgroup (256; 512 as a phase of the persistent layer); F16: fp16 hi / lo output planes
 __device__ __forceinline__ void trunk_mpt_attn_body(const float* __restrict__ qkv, const float* __restrict__ stats, int d_model, int hd,
                                                     const float* __restrict__ q_ln_w, const float* __restrict__ k_ln_w, float eps,
                                                     const unsigned char* __restrict__ key_mask, float alibi_slope_base, int n_heads,
@@ -323,8 +333,8 @@ __device__ __forceinline__ void trunk_mpt_attn_body(const float* __restrict__ qk
         o1 += (jj <= i) ? pj * vv[jj].y : 0.f;
       }
       if (col_ok) {
-        const uint32_t hi2 = pack2bf(o0, o1);
-        const uint32_t lo2 = pack2bf(o0 - __uint_as_float(hi2 << 16), o1 - __uint_as_float(hi2 & 0xffff0000u));
+        uint32_t hi2, lo2;
+        split2<F16>(o0, o1, hi2, lo2);
         *reinterpret_cast<uint32_t*>(out_hi + (long)i * ldo + h * hd + dd) = hi2;
         *reinterpret_cast<uint32_t*>(out_lo + (long)i * ldo + h * hd + dd) = lo2;
       }
@@ -336,16 +346,18 @@ __device__ __forceinline__ void trunk_mpt_attn_body(const float* __restrict__ qk
 }
 
 #ifndef DEER_BODIES_ONLY
+template <bool F16>
 __global__ __launch_bounds__(1024) void trunk_mpt_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ stats, int d_model, int hd,
                                                              const float* __restrict__ q_ln_w, const float* __restrict__ k_ln_w, float eps,
                                                              const unsigned char* __restrict__ key_mask, float alibi_slope_base, int n_heads,
                                                              bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo, int T, const int* ctl) {
   DEER_RETURN_IF_EXITED(ctl);
   __shared__ __attribute__((aligned(16))) float lds[TM_LDS_FLOATS];
-  trunk_mpt_attn_body<1024>(qkv, stats, d_model, hd, q_ln_w, k_ln_w, eps, key_mask, alibi_slope_base, n_heads, out_hi, out_lo, ldo, T, blockIdx.x, lds);
+  trunk_mpt_attn_body<1024, F16>(qkv, stats, d_model, hd, q_ln_w, k_ln_w, eps, key_mask, alibi_slope_base, n_heads, out_hi, out_lo, ldo, T, blockIdx.x, lds);
 }
 
-extern "C" int deer_trunk_mpt_attn(const float* qkv, const float* stats, int d_model, int n_heads, const float* q_ln_w, const float* k_ln_w, float eps,
+template <bool F16>
+static int trunk_mpt_attn(const float* qkv, const float* stats, int d_model, int n_heads, const float* q_ln_w, const float* k_ln_w, float eps,
                                    const unsigned char* key_mask, float alibi_bias_max, void* out_hi, void* out_lo, int ldo, int T, const int* ctl,
                                    void* stream) {
   const int hd = d_model / n_heads;
@@ -353,9 +365,19 @@ extern "C" int deer_trunk_mpt_attn(const float* qkv, const float* stats, int d_m
       out_lo == nullptr)
     return DEER_ERR_SHAPE;
   if ((q_ln_w == nullptr) != (k_ln_w == nullptr) || (q_ln_w != nullptr && stats == nullptr)) return DEER_ERR_SHAPE;
-  hipLaunchKernelGGL(trunk_mpt_attn_kernel, dim3(n_heads), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), qkv, stats, d_model, hd, q_ln_w, k_ln_w,
+  hipLaunchKernelGGL(trunk_mpt_attn_kernel<F16>, dim3(n_heads), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), qkv, stats, d_model, hd, q_ln_w, k_ln_w,
                      eps, key_mask, alibi_bias_max, n_heads, reinterpret_cast<bf16_t*>(out_hi), reinterpret_cast<bf16_t*>(out_lo), ldo, T, ctl);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
+}
+extern "C" int deer_trunk_mpt_attn(const float* qkv, const float* stats, int d_model, int n_heads, const float* q_ln_w, const float* k_ln_w, float eps,
+                                   const unsigned char* key_mask, float alibi_bias_max, void* out_hi, void* out_lo, int ldo, int T, const int* ctl,
+                                   void* stream) {
+  return trunk_mpt_attn<false>(qkv, stats, d_model, n_heads, q_ln_w, k_ln_w, eps, key_mask, alibi_bias_max, out_hi, out_lo, ldo, T, ctl, stream);
+}
+extern "C" int deer_trunk_mpt_attn_f16(const float* qkv, const float* stats, int d_model, int n_heads, const float* q_ln_w, const float* k_ln_w, float eps,
+                                       const unsigned char* key_mask, float alibi_bias_max, void* out_hi, void* out_lo, int ldo, int T, const int* ctl,
+                                       void* stream) {   // fp16 hi / lo output planes (round 6)
+  return trunk_mpt_attn<true>(qkv, stats, d_model, n_heads, q_ln_w, k_ln_w, eps, key_mask, alibi_bias_max, out_hi, out_lo, ldo, T, ctl, stream);
 }
 #endif  // DEER_BODIES_ONLY

@@ -30,7 +30,7 @@ KT_DEFINE(xattn)
 
 // PACKED (one environment, <= 16 rows): the activation arrives as bf16 hi / lo planes in MFMA-fragment order (xn = hi plane, xlo = lo
 // plane; deer_resadd_ln_packed) - one coalesced 1 KiB read per k-tile and plane instead of 16 rows x 16 B per lane
-template <int MT, bool PACKED>
+template <int MT, bool PACKED, bool F16 = false>   // F16: weights, K / V and every 16-bit intermediate in fp16
 __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, int d, const bf16_t* __restrict__ Wq_p,
                                                                 const bf16_t* __restrict__ kv, int ldkv, int inner,
                                                                 const int* __restrict__ text_time, int n_per_media, int n_kv,
@@ -127,24 +127,23 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
               const bf16x8 wf = __builtin_bit_cast(bf16x8, w[u][t4]);
-              acc[t4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, ph[u], acc[t4][j], 0, 0, 0);
-              acc[t4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pl[u], acc[t4][j], 0, 0, 0);
+              acc[t4][j] = mfma16<F16>(wf, ph[u], acc[t4][j]);
+              acc[t4][j] = mfma16<F16>(wf, pl[u], acc[t4][j]);
             }
             continue;
           }
           const float4 x0 = a[PACKED ? 0 : u][j][0], x1 = a[PACKED ? 0 : u][j][1];
-          const uint32_t h0 = pack2bf(x0.x, x0.y), h1 = pack2bf(x0.z, x0.w), h2 = pack2bf(x1.x, x1.y), h3 = pack2bf(x1.z, x1.w);
-          const uint4 hi = uint4{h0, h1, h2, h3};
-          const uint4 lo = uint4{pack2bf(x0.x - __uint_as_float(h0 << 16), x0.y - __uint_as_float(h0 & 0xffff0000u)),
-                                 pack2bf(x0.z - __uint_as_float(h1 << 16), x0.w - __uint_as_float(h1 & 0xffff0000u)),
-                                 pack2bf(x1.x - __uint_as_float(h2 << 16), x1.y - __uint_as_float(h2 & 0xffff0000u)),
-                                 pack2bf(x1.z - __uint_as_float(h3 << 16), x1.w - __uint_as_float(h3 & 0xffff0000u))};
+          uint4 hi, lo;
+          split2<F16>(x0.x, x0.y, hi.x, lo.x);
+          split2<F16>(x0.z, x0.w, hi.y, lo.y);
+          split2<F16>(x1.x, x1.y, hi.z, lo.z);
+          split2<F16>(x1.z, x1.w, hi.w, lo.w);
           const bf16x8 ah = __builtin_bit_cast(bf16x8, hi), al = __builtin_bit_cast(bf16x8, lo);
 #pragma unroll
           for (int t4 = 0; t4 < 4; ++t4) {
             const bf16x8 wf = __builtin_bit_cast(bf16x8, w[u][t4]);
-            acc[t4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, ah, acc[t4][j], 0, 0, 0);
-            acc[t4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, al, acc[t4][j], 0, 0, 0);
+            acc[t4][j] = mfma16<F16>(wf, ah, acc[t4][j]);
+            acc[t4][j] = mfma16<F16>(wf, al, acc[t4][j]);
           }
         }
       }
@@ -175,7 +174,7 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < XF_NW; ++w) s += red[w * MPAD * XF_HD + idx];
-    qs[(idx >> 6) * XF_KP + (idx & 63)] = f2bf(s * scale);
+    qs[(idx >> 6) * XF_KP + (idx & 63)] = f2x<F16>(s * scale);
   }
   __syncthreads();
   XKT(4);
@@ -196,7 +195,7 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + c) * XF_KP + ks * 32 + g * 8);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+        s[t] = mfma16<F16>(kf, qf[ks], s[t]);
       }
     }
     float mx = -INFINITY;
@@ -231,10 +230,10 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
 #pragma unroll
     for (int ch = 0; ch < NT / 2; ++ch) {
       uint4 pw;
-      pw.x = pack2bf(s[2 * ch][0], s[2 * ch][1]);
-      pw.y = pack2bf(s[2 * ch][2], s[2 * ch][3]);
-      pw.z = pack2bf(s[2 * ch + 1][0], s[2 * ch + 1][1]);
-      pw.w = pack2bf(s[2 * ch + 1][2], s[2 * ch + 1][3]);
+      pw.x = pack2x<F16>(s[2 * ch][0], s[2 * ch][1]);
+      pw.y = pack2x<F16>(s[2 * ch][2], s[2 * ch][3]);
+      pw.z = pack2x<F16>(s[2 * ch + 1][0], s[2 * ch + 1][1]);
+      pw.w = pack2x<F16>(s[2 * ch + 1][2], s[2 * ch + 1][3]);
       const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -244,18 +243,18 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
         const xf_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vt + ((ch * 32 + 16) * XF_KP + dt * 16) / 4);
         const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
         const uint4 vw = uint4{lo2.x, lo2.y, hi2.x, hi2.y};
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[dt], 0, 0, 0);
+        o[dt] = mfma16<F16>(__builtin_bit_cast(bf16x8, vw), pf, o[dt]);
       }
     }
     // lane holds O[q = q0 + c][dd = dt*16 + g*4 .. +3]  ->  bf16 hi + lo rows for the output projection
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       const float v0 = o[dt][0] * inv, v1 = o[dt][1] * inv, v2 = o[dt][2] * inv, v3 = o[dt][3] * inv;
-      const uint32_t h01 = pack2bf(v0, v1), h23 = pack2bf(v2, v3);
+      uint32_t h01, h23, l01, l23;
+      split2<F16>(v0, v1, h01, l01);
+      split2<F16>(v2, v3, h23, l23);
       *reinterpret_cast<uint2*>(oh + (q0 + c) * XF_KP + dt * 16 + g * 4) = uint2{h01, h23};
-      *reinterpret_cast<uint2*>(ol + (q0 + c) * XF_KP + dt * 16 + g * 4) =
-          uint2{pack2bf(v0 - __uint_as_float(h01 << 16), v1 - __uint_as_float(h01 & 0xffff0000u)),
-                pack2bf(v2 - __uint_as_float(h23 << 16), v3 - __uint_as_float(h23 & 0xffff0000u))};
+      *reinterpret_cast<uint2*>(ol + (q0 + c) * XF_KP + dt * 16 + g * 4) = uint2{l01, l23};
     }
   }
   XKT(5);
@@ -276,8 +275,8 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
           const bf16x8 wf = __builtin_bit_cast(bf16x8, wo[i][kk]);
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(oh + (j * 16 + c) * XF_KP + kk * 32 + g * 8);
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(ol + (j * 16 + c) * XF_KP + kk * 32 + g * 8);
-          y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, ah, y, 0, 0, 0);
-          y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, al, y, 0, 0, 0);
+          y = mfma16<F16>(wf, ah, y);
+          y = mfma16<F16>(wf, al, y);
         }
         const int m = j * 16 + c;
         if (m < T) *reinterpret_cast<float4*>(dst + (long)m * d + nt * 16 + g * 4) = float4{y[0], y[1], y[2], y[3]};
@@ -287,7 +286,7 @@ __device__ __forceinline__ void xattn_fused_body(const float* __restrict__ xn, i
   XKT(7);
 }
 
-template <int MT, bool PACKED = false>
+template <int MT, bool PACKED = false, bool F16 = false>
 __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __restrict__ xn, int d, const bf16_t* __restrict__ Wq_p,
                                                                 const bf16_t* __restrict__ kv, int ldkv, int inner,
                                                                 const int* __restrict__ text_time, int n_per_media, int n_kv,
@@ -295,7 +294,7 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
                                                                 int T, int heads, int NS, float scale, const int* ctl,
                                                                 const bf16_t* __restrict__ xlo = nullptr, const int* __restrict__ cmap = nullptr) {
   DEER_RETURN_IF_EXITED(ctl);
-  xattn_fused_body<MT, PACKED>(xn, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T, heads, NS, scale, xlo, cmap,
+  xattn_fused_body<MT, PACKED, F16>(xn, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T, heads, NS, scale, xlo, cmap,
                                blockIdx.x, blockIdx.y);
 }
 
@@ -303,6 +302,7 @@ __global__ __launch_bounds__(64 * XF_NW) void xattn_fused_kernel(const float* __
 // xn: f32 [batch*T, d] = LN(x) of the block's attention branch; Wq_p / Wo_p: to_q [inner, d] and to_out [d, inner] in the packed
 // layout of deer_pack_weight_mfma16; kv: bf16 [batch*n_kv, ldkv] (k of head h at column h*64, v at inner + h*64); out: f32
 // [heads][slab_stride] with slab_stride >= batch*T*d - slab h holds head h's contribution to all rows.  T <= 32, n_kv <= 128.
+template <bool F16>
 static int launch_xattn_fused(const float* xn, const void* x_lo_packed, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
                               int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch, float scale,
                               const int* ctl, void* stream, const int* cmap = nullptr);
@@ -310,7 +310,7 @@ static int launch_xattn_fused(const float* xn, const void* x_lo_packed, int d, c
 extern "C" int deer_xattn_fused(const float* xn, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
                                 int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch,
                                 float scale, const int* ctl, void* stream) {
-  return launch_xattn_fused(xn, nullptr, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T, heads, batch, scale, ctl, stream);
+  return launch_xattn_fused<false>(xn, nullptr, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T, heads, batch, scale, ctl, stream);
 }
 
 // deer_xattn_fused for an env batch with compaction: grid rows are SLOTS of `cmap`
@@ -318,7 +318,7 @@ extern "C" int deer_xattn_fused_active(const float* xn, int d, const void* Wq_p,
                                        int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch,
                                        float scale, const int* ctl, const int* cmap, void* stream) {
   if (cmap == nullptr) return DEER_ERR_SHAPE;
-  return launch_xattn_fused(xn, nullptr, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T, heads, batch, scale, ctl, stream, cmap);
+  return launch_xattn_fused<false>(xn, nullptr, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T, heads, batch, scale, ctl, stream, cmap);
 }
 
 // the same for ONE environment of <= 16 rows with LN(x) as bf16 hi / lo planes in MFMA-fragment order (deer_resadd_ln_packed)
@@ -326,10 +326,35 @@ extern "C" int deer_xattn_fused_packed(const void* x_hi, const void* x_lo, int d
                                        const int* text_time, int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T,
                                        int heads, float scale, const int* ctl, void* stream) {
   if (x_lo == nullptr || T > 16) return DEER_ERR_SHAPE;
-  return launch_xattn_fused(reinterpret_cast<const float*>(x_hi), x_lo, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T,
+  return launch_xattn_fused<false>(reinterpret_cast<const float*>(x_hi), x_lo, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T,
                             heads, 1, scale, ctl, stream);
 }
 
+// ---- the same three entry points on fp16 operands: Wq / Wo packed fp16, K / V fp16, hi / lo planes fp16 (round 6) ----
+extern "C" int deer_xattn_fused_f16(const float* xn, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
+                                int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch,
+                                float scale, const int* ctl, void* stream) {
+  return launch_xattn_fused<true>(xn, nullptr, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T, heads, batch, scale, ctl, stream);
+}
+
+// deer_xattn_fused for an env batch with compaction: grid rows are SLOTS of `cmap`
+extern "C" int deer_xattn_fused_active_f16(const float* xn, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
+                                       int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch,
+                                       float scale, const int* ctl, const int* cmap, void* stream) {
+  if (cmap == nullptr) return DEER_ERR_SHAPE;
+  return launch_xattn_fused<true>(xn, nullptr, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T, heads, batch, scale, ctl, stream, cmap);
+}
+
+// the same for ONE environment of <= 16 rows with LN(x) as bf16 hi / lo planes in MFMA-fragment order (deer_resadd_ln_packed)
+extern "C" int deer_xattn_fused_packed_f16(const void* x_hi, const void* x_lo, int d, const void* Wq_p, const void* kv, int ldkv, int inner,
+                                       const int* text_time, int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T,
+                                       int heads, float scale, const int* ctl, void* stream) {
+  if (x_lo == nullptr || T > 16) return DEER_ERR_SHAPE;
+  return launch_xattn_fused<true>(reinterpret_cast<const float*>(x_hi), x_lo, d, Wq_p, kv, ldkv, inner, text_time, n_per_media, n_kv, Wo_p, out, slab_stride, T,
+                            heads, 1, scale, ctl, stream);
+}
+
+template <bool F16>
 static int launch_xattn_fused(const float* xn, const void* x_lo_packed, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
                               int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch, float scale,
                               const int* ctl, void* stream, const int* cmap) {
@@ -353,7 +378,7 @@ static int launch_xattn_fused(const float* xn, const void* x_lo_packed, int d, c
 #define DEER_XF_LAUNCH(MT_, PK_)                                                                                                \
   do {                                                                                                                          \
     static std::atomic<bool> attr_set{false};                                                                                               \
-    auto kern = &xattn_fused_kernel<MT_, PK_>;                                                                                  \
+    auto kern = &xattn_fused_kernel<MT_, PK_, F16>;                                                                                  \
     if (!attr_set) {                                                                                                            \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) !=  \
           hipSuccess) return DEER_ERR_LAUNCH;                                                                                   \

@@ -113,11 +113,10 @@ class DeerEngine:
     workspace) and the pinned host buffers, ingests the reference state dict by name, and feeds the step to the GPU as HIP-graph
     pieces.  The kernel ORDER of every piece lives in the C++ model object; nothing here touches a kernel directly."""
     LOOKAHEAD = 1        # trunk layers the host keeps in flight beyond an undecided exit check
-    DEFAULT_TOWER = "fp16"   # 16-bit format of the vision tower in the product arithmetic (see __init__)
 
     def __init__(self, cfg: DeerConfig, state_dict: Optional[Dict[str, torch.Tensor]], device="cuda", max_text_len: int = 32,
-                 n_envs: int = 1, threshold_type: str = "L2", leq: bool = True, segmented: bool = True, precision: str = "bf16",
-                 weights_from: Optional["DeerEngine"] = None, tower: Optional[str] = None):
+                 n_envs: int = 1, threshold_type: str = "L2", leq: bool = True, segmented: bool = True, precision: Optional[str] = None,
+                 weights_from: Optional["DeerEngine"] = None):
         """n_envs: independent environments evaluated per control step (one "env batch" per rank).  They share every
         weight read: the ViT sees M = 514*n_envs rows, the LLM n_envs*T rows, each environment keeps its own LSTM state,
         thresholds are shared and every environment exits at its own layer (device side)."""
@@ -133,25 +132,24 @@ class DeerEngine:
         self.n_cams = 2 * n_envs                       # images per step: (rgb, gripper) of every environment
         # trunk rows n_envs * T: up to 512 in the bf16 arithmetic (16 environments x the reference's max_length = 32, data.py:905-919; the
         # hi/lo-plane trunk GEMM runs them in blocks of 128), 128 in the fp32 arithmetic (one launch of deer_gemm_skinny)
+        # precision (include/deer_model.h, _abi.PRECISIONS): "fp16" (default) / "bf16" = the product arithmetic on fp16 / bf16 operands,
+        # "fp32" = the parity arithmetic.  Engines over one weight arena share it (the weights are stored in that format).
+        if precision is None and weights_from is not None:
+            precision = weights_from.precision
+        precision = abi.resolve_precision(precision)
+        if weights_from is not None and precision != weights_from.precision:
+            raise ValueError("engines over one weight arena share the precision (the weights are stored in its format)")
         self.MAX_ROWS = abi.max_trunk_rows(cfg, precision)
         self.max_T = min(max_text_len, self.MAX_ROWS // n_envs)
         assert self.max_T >= 1, "n_envs * T must fit the trunk's LLM rows"      # load_inputs checks every instruction against max_T
         self._thr_type = abi.THR_TYPES[threshold_type]
         self._leq = 1 if leq else 0
         self._h = ctypes.c_void_p()
-        # precision="fp32": fp32 activations everywhere (csrc/precise.hip) - the parity arithmetic of north_star's 1e-3 clause; single-
-        # stream schedule, one graph per step
+        # "fp32": fp32 activations everywhere (csrc/precise.hip) - the parity arithmetic of north_star's 1e-3 clause; single-stream
+        # schedule, one graph per step.  "fp16" / "bf16": the product arithmetic (graph pieces, two vision chains, env batches to 16).
         self.precision = precision
-        # tower: the 16-bit format of the vision tower (ViT-L/14, Perceiver, media K/V projection) in the product arithmetic -
-        # "fp16": IEEE fp16 operands / results on v_mfma_f32_16x16x32_f16 = the reference's evaluation arithmetic (fp32 weights under
-        # fp16 autocast, eval_utils.py:333; OpenAI CLIP weights are fp16-native), "bf16": a `--precision bf16` / amp_bf16 reference run.
-        # Same kernels, same speed; LayerNorm / softmax / residual stream f32 either way.  Default: DEER_TOWER, else DEFAULT_TOWER.
-        if tower is None:
-            tower = weights_from.tower if weights_from is not None else os.environ.get("DEER_TOWER", self.DEFAULT_TOWER)
-        if weights_from is not None and tower != weights_from.tower:
-            raise ValueError("engines over one weight arena share the tower format (the GEMM weights are stored in it)")
-        self.tower = tower if precision == "bf16" else "fp32"
-        cc = config_to_c(cfg, n_envs, self.max_T, precision=precision, tower=tower if precision == "bf16" else "bf16")
+        self.product = precision != "fp32"
+        cc = config_to_c(cfg, n_envs, self.max_T, precision=precision)
         abi.check(self.lib.deer_model_create(ctypes.byref(cc), ctypes.byref(self._h)), "deer_model_create")
         with torch.cuda.device(self.dev):
             self.workspace = torch.zeros(self.lib.deer_model_workspace_bytes(self._h), dtype=torch.uint8, device=self.dev)
@@ -167,7 +165,7 @@ class DeerEngine:
             self._make_views()
         self._siblings: Dict[int, "DeerEngine"] = {}
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
-        self.segmented = segmented and precision == "bf16"   # dynamic steps fed in per-layer graph pieces (see _step_segmented)
+        self.segmented = segmented and self.product         # dynamic steps fed in per-layer graph pieces (see _step_segmented)
         # DEER_ONE_GRAPH=1: dynamic steps as ONE graph with branches - no host on the decision path at all, but every kernel behind
         # the exit still launches and returns at entry (see _step_one_graph; measured slower: 242 vs 352 steps/s at one
         # environment, 778 vs 862 at eight)
@@ -235,14 +233,15 @@ class DeerEngine:
         rows = min(B * self.max_T, self.MAX_ROWS)
         self.max_rows = rows
         v = lambda name, dt: self._buf(name).view(dt)
-        # camera frames in the tower's operand format (fp16 keeps every 8-bit pixel level apart after CLIP normalisation; bf16 merges some)
-        self.img_dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[self.tower]
+        # camera frames / media tokens / K|V / wte in the arithmetic's 16-bit format (fp16 keeps every 8-bit pixel level apart after CLIP
+        # normalisation; bf16 merges some); f32 for the parity arithmetic
+        self.img_dtype = abi.torch_dtype16(self.precision)
         self.img = v("img", self.img_dtype).view(N, 3, S, S)               # static input buffer (camera frames)
         self.vx = v("vx", torch.float32).view(N, cfg.n_patches + 1, W)     # ViT residual stream (fp32)
-        self.media_dtype = torch.float16 if self.tower == "fp16" else torch.bfloat16
+        self.media_dtype = torch.float16 if self.precision == "fp16" else torch.bfloat16
         self.vis_x = v("vis_x", self.media_dtype).view(N * nl, W)          # media tokens [rgb latents ; gripper latents] per env
         self.vis_x_f32 = v("vis_x_f32", torch.float32).view(N * nl, W)
-        self.kv_all = v("kv_all", torch.bfloat16)
+        self.kv_all = v("kv_all", self.media_dtype)
         self.ids = v("ids", torch.int64)
         self.key_mask = v("key_mask", torch.uint8)
         self.key_mask.fill_(1)
@@ -267,7 +266,7 @@ class DeerEngine:
         if getattr(cfg, "layerwise_exit_eval", False):                     # per-layer heads' LSTM state: [head][h, c][L][B][H]
             n_lw = len(cfg.layerwise_heads())
             self.lw_state = v("lw_state", torch.float32).view(n_lw, 2, Lh, B, H)
-        self.wte = self._buf("lang_encoder.transformer.wte.weight", 0).view(torch.float32 if self.precision == "fp32" else torch.bfloat16).view(cfg.vocab_size, d)
+        self.wte = self._buf("lang_encoder.transformer.wte.weight", 0).view(torch.float32 if self.precision == "fp32" else self.media_dtype).view(cfg.vocab_size, d)
         self.ctl_host = torch.zeros(B * abi.CTL_WORDS, dtype=torch.int32).pin_memory()
         self._ctl_host_np = self.ctl_host.numpy()
         self.step_info_host = torch.zeros(8, 4, dtype=torch.int32).pin_memory()   # ring: an async upload may still be pending
@@ -989,8 +988,7 @@ class DeerEngine:
             return self
         e = self._siblings.get((n_envs, index))
         if e is None:
-            e = DeerEngine(self.cfg, None, device=self.dev, max_text_len=self.max_T, n_envs=n_envs, weights_from=self, segmented=self.segmented, precision=self.precision,
-                           tower=None if self.precision != "bf16" else self.tower)
+            e = DeerEngine(self.cfg, None, device=self.dev, max_text_len=self.max_T, n_envs=n_envs, weights_from=self, segmented=self.segmented, precision=self.precision)
             self._siblings[(n_envs, index)] = e
         return e
 

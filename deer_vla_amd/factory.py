@@ -148,7 +148,7 @@ def create_model_and_transforms(clip_vision_encoder_path: str = "ViT-L-14", clip
                                 decoder_type="lstm", hidden_size=None, freeze_sampler=False, fwd_pred=False,
                                 fwd_pred_hand=False, no_image_patch=False, global_latent=1, refresh=-1,
                                 head_type="deterministic", state_dict=None, cfg: Optional[DeerConfig] = None, device="cuda",
-                                n_envs: int = 1, precision: str = "bf16", **flamingo_kwargs):
+                                n_envs: int = 1, precision: Optional[str] = None, **flamingo_kwargs):
     if clip_vision_encoder_path != "ViT-L-14":
         raise NotImplementedError("only the CLIP ViT-L/14 tower of the released checkpoints is implemented")
     if "mpt" not in llm_name:

@@ -161,16 +161,17 @@ class LangEncoder:
 
 class MPTFlamingo(nn.Module):
     def __init__(self, cfg: DeerConfig, state_dict: Optional[Dict[str, torch.Tensor]] = None, window_size: int = 12,
-                 use_gripper: bool = True, fusion_mode: str = "post", device="cuda", n_envs: int = 1, precision: str = "bf16",
-                 tower: Optional[str] = None, **unused):
+                 use_gripper: bool = True, fusion_mode: str = "post", device="cuda", n_envs: int = 1, precision: Optional[str] = None, **unused):
         super().__init__()
         if unused:
             raise TypeError(f"MPTFlamingo: keywords {sorted(unused)} are not implemented by deer_vla_amd (they would be silently ignored)")
         if not use_gripper or fusion_mode != "post":
             raise NotImplementedError("released DeeR checkpoints use use_gripper=True, fusion_mode='post' (flamingo_mpt.py:380-381)")
         self.cfg = cfg
-        self.precision = precision        # "bf16": the product arithmetic; "fp32": fp32 activations everywhere (parity arithmetic, ~4x slower)
-        self.tower = tower                # product arithmetic: 16-bit format of the vision tower, "fp16" (the reference's amp run) | "bf16"; None = engine default
+        # "fp16" (default): the product arithmetic on IEEE fp16 operands = the reference's evaluation arithmetic (fp32 weights under fp16
+        # autocast, eval_utils.py:333); "bf16": the same on bf16 operands (a --precision bf16 / amp_bf16 run); "fp32": fp32 activations
+        # everywhere (parity arithmetic, ~4x slower)
+        self.precision = abi.resolve_precision(precision)
         self._device = device
         self.n_envs = n_envs                                      # environments per control step ("one env batch per rank")
         self._sd: Dict[str, torch.Tensor] = dict(state_dict) if state_dict is not None else {}
@@ -213,7 +214,7 @@ class MPTFlamingo(nn.Module):
             missing = [k for k in param_shapes(self.cfg) if k not in self._sd]
             if missing:
                 raise RuntimeError(f"{len(missing)} parameters missing before the first forward, e.g. {missing[:3]}")
-            self._engine = DeerEngine(self.cfg, self._sd, device=self._device, n_envs=self.n_envs, precision=self.precision, tower=self.tower)
+            self._engine = DeerEngine(self.cfg, self._sd, device=self._device, n_envs=self.n_envs, precision=self.precision)
             self.extra_exit = DeterministicDecoder(self._engine, self.window_size)
             self.lm_head = self.extra_exit
         return self._engine
@@ -222,7 +223,7 @@ class MPTFlamingo(nn.Module):
         """A second model over the SAME device weights (own workspace, LSTM state, exit controller): a further env batch that can be
         stepped concurrently with this one from another host thread / stream (rollout.evaluate_policy_batched(groups=...))."""
         other = MPTFlamingo(self.cfg, None, window_size=self.window_size, use_gripper=self.use_gripper, fusion_mode=self.fusion_mode,
-                            device=self._device, n_envs=self.n_envs, precision=self.precision, tower=self.tower)
+                            device=self._device, n_envs=self.n_envs, precision=self.precision)
         other._sd = self._sd
         other._engine = DeerEngine(self.cfg, None, device=self._device, n_envs=self.n_envs, precision=self.precision, weights_from=self.engine)
         other.extra_exit = DeterministicDecoder(other._engine, self.window_size)
@@ -264,40 +265,29 @@ class MPTFlamingo(nn.Module):
         return missing, unexpected
 
     def set_precision(self, precision: str):
-        """"bf16" (default: the product arithmetic) or "fp32" (fp32 activations end to end, csrc/precise.hip).  The reference's
-        ``model.float()`` / ``model.half()`` / ``model.bfloat16()`` casts (eval_calvin.py:559-564) select the vision tower's 16-bit
-        format inside the product arithmetic (set_tower)."""
+        """"fp16" (default) / "bf16": the product arithmetic on fp16 / bf16 operands; "fp32": fp32 activations end to end
+        (csrc/precise.hip).  Rebuilds the engine on a change (the weights are stored in the arithmetic's format)."""
+        precision = abi.resolve_precision(precision)
         if precision != self.precision:
             self.precision = precision
             self._engine = None
-        return self
-
-    def set_tower(self, tower: Optional[str]):
-        """16-bit format of the vision tower in the product arithmetic: "fp16" (fp32 weights under fp16 autocast - the README's evaluation,
-        eval_utils.py:333) or "bf16" (a `--precision bf16` / amp_bf16 run); None = the engine's default.  Rebuilds the engine on a change
-        (the tower's GEMM weights are stored in that format)."""
-        if tower is not None:
-            cur = self._engine.tower if self._engine is not None else self.tower
-            if self._engine is not None and tower != cur:
-                self._engine = None                           # rebuilt with the new format on next use
-            self.tower = tower
         return self
 
     def to(self, *a, **k):
         return self
 
     # eval_calvin.py:559-564 casts the module by `--precision`: .bfloat16() for bf16 / amp_bf16, .half() for fp16, .float() otherwise (the
-    # README's `--precision fp32 --amp 1`).  Here the casts choose the ARITHMETIC of the vision tower the same way - bf16 operands for a
-    # bf16 run, fp16 operands for the fp16 / amp (fp32 weights under fp16 autocast) runs; the trunk and the head are one arithmetic
-    # (bf16 weights, f32-equivalent activations).  precision="fp32" engines ignore them.
+    # README's `--precision fp32 --amp 1`: fp32 weights whose Linears then run under fp16 autocast, eval_utils.py:333).  Here the casts choose
+    # the 16-bit format of the product arithmetic the same way: bf16 operands for a bf16 run, fp16 operands for the fp16 / fp32 + amp runs.
+    # An engine the caller asked to be "fp32" (parity arithmetic) keeps it.
     def float(self):
-        return self.set_tower("fp16") if self.precision == "bf16" else self
+        return self if self.precision == "fp32" else self.set_precision("fp16")
 
     def half(self):
-        return self.set_tower("fp16") if self.precision == "bf16" else self
+        return self if self.precision == "fp32" else self.set_precision("fp16")
 
     def bfloat16(self):
-        return self.set_tower("bf16") if self.precision == "bf16" else self
+        return self if self.precision == "fp32" else self.set_precision("bf16")
 
     # ---- exits bookkeeping (flamingo_mpt.py:268-306) ----------------------------------------------------------
     def get_all_exit_idx(self):

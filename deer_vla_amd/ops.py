@@ -33,22 +33,20 @@ class NativeModel:
     ingests a reference state dict.  No orchestration here - that is the spine's; ``DeerEngine`` adds graph scheduling on top."""
 
     def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], device="cuda", n_envs: int = 1, max_text_len: int = 32,
-                 precision: str = "bf16", tower: Optional[str] = None):
+                 precision: Optional[str] = None):
         if not torch.cuda.is_available():
             raise abi.DeerHipError("deer_vla_amd needs a HIP device (no CPU fallback)")
         self.lib = abi.lib()
         self.cfg, self.B = cfg, n_envs
         self.dev = torch.device(device)
-        self.max_T = min(max_text_len, abi.max_trunk_rows(cfg, precision) // n_envs)   # the same row budget as DeerEngine (256 rows in bf16)
+        precision = abi.resolve_precision(precision)        # "fp16" (default) / "bf16": product arithmetic on fp16 / bf16 operands; "fp32": parity arithmetic
+        self.max_T = min(max_text_len, abi.max_trunk_rows(cfg, precision) // n_envs)   # the same row budget as DeerEngine (512 rows in the product arithmetic)
         self._h = ctypes.c_void_p()
         self.precision = precision
-        # 16-bit format of the vision tower and of the media tokens the operators hand around ("fp16" = the reference's amp run; engine.py)
-        import os
-        from .engine import DeerEngine
-        self.tower = (tower or os.environ.get("DEER_TOWER", DeerEngine.DEFAULT_TOWER)) if precision == "bf16" else "fp32"
-        self.img_dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[self.tower]
-        self.media_dtype = torch.float16 if self.tower == "fp16" else torch.bfloat16
-        cc = abi.config_to_c(cfg, n_envs, self.max_T, precision=precision, tower=self.tower if precision == "bf16" else "bf16")
+        # format of the camera frames / media tokens the operators hand around
+        self.img_dtype = abi.torch_dtype16(precision)
+        self.media_dtype = torch.float16 if precision == "fp16" else torch.bfloat16
+        cc = abi.config_to_c(cfg, n_envs, self.max_T, precision=precision)
         abi.check(self.lib.deer_model_create(ctypes.byref(cc), ctypes.byref(self._h)), "deer_model_create")
         with torch.cuda.device(self.dev):
             self.arena = torch.zeros(self.lib.deer_model_arena_bytes(self._h), dtype=torch.uint8, device=self.dev)
@@ -153,10 +151,10 @@ def llm_early_exit(ids: torch.Tensor, key_mask: Optional[torch.Tensor], media: t
     T = ids_c.reshape(m.B, -1).shape[1]
     km = key_mask.to(torch.uint8).contiguous() if key_mask is not None else None
     # fp32-activation models keep their media tokens in f32 inside the model (the bf16 tensor handed around is only a view of them)
-    med = None if getattr(m, "precision", "bf16") == "fp32" else media.to(m.media_dtype).contiguous()
+    med = None if m.precision == "fp32" else media.to(m.media_dtype).contiguous()
     abi.check(m.lib.deer_llm_early_exit(m._h, abi.ptr(ids_c), abi.ptr(km), T, abi.ptr(med), exit_id, 1 if shadow else 0, None, None, _stream()),
               "deer_llm_early_exit")
-    rows = min(m.B * m.max_T, abi.max_trunk_rows(cfg, getattr(m, "precision", "bf16")))
+    rows = min(m.B * m.max_T, abi.max_trunk_rows(cfg, m.precision))
     ctl = m.buffer("ctl").view(torch.int32).view(m.B, abi.CTL_WORDS).clone()
     hidden = m.buffer("hidden").view(torch.float32).view(cfg.n_layers, rows, cfg.d_model)[:, : m.B * T].clone()
     return ctl, hidden

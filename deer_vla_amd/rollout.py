@@ -141,7 +141,7 @@ class ModelWrapper:
         self.text_process_fn = functools.partial(preprocess_text_calvin, tokenizer=tokenizer)
         self.image_process_fn = functools.partial(preprocess_image, image_processor=image_processor)
         self.fusion_mode = m.fusion_mode
-        self.amp = amp                                             # amp = fp16 autocast = the engine's default tower arithmetic (MPTFlamingo.set_tower)
+        self.amp = amp                                             # amp = fp16 autocast = the engine's default arithmetic, precision="fp16" 
         self.head_type = m.head_type
         self.exit_id = exit_id
         self.dynamic_early_exit = early_exit

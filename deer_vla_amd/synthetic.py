@@ -278,6 +278,14 @@ def round_state_to_bf16(cfg: DeerConfig, sd: Dict[str, torch.Tensor]) -> Dict[st
             for k, t in sd.items()}
 
 
+def round_state_to_fp16(cfg: DeerConfig, sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """fp32 copy of ``sd`` whose GEMM operands are rounded to IEEE fp16 (what a precision="fp16" engine keeps in HBM - and what fp16 autocast
+    feeds every Linear of the reference)."""
+    kinds = {k: v[1] for k, v in param_shapes(cfg).items()}
+    return {k: (t.to(torch.float16).to(torch.float32) if kinds.get(k) in BF16_KINDS else t.clone())
+            for k, t in sd.items()}
+
+
 def synthetic_step_inputs(cfg: DeerConfig, step: int, rank: int = 0, text_len: int = 14,
                           text_seed: int = 7):
     """SURVEY §8(d) synthetic inputs: rgb, gripper ~ N(0,1) (1,1,1,3,S,S) with seed

@@ -430,6 +430,62 @@ int deer_spin_us(int us, void* stream);
 const char* deer_hip_arch(void);
 int deer_hip_abi_version(void);
 
+/* ---- the LLM trunk and the head on IEEE fp16 operands (round 6) ------------------------------------------------------------------------
+ * The reference's evaluation arithmetic is fp32 weights under fp16 autocast (robot_flamingo/eval/eval_utils.py:333, README.md:161-167):
+ * every nn.Linear of the MPT blocks (mosaic_gpt_3b.py:413-417), of GatedCrossAttentionBlock (helpers.py:188,231,15-22) and of the action
+ * head multiplies fp16-ROUNDED weights.  bf16-rounded weights are 2.6e-2 from that on the action at the full 3B size, fp16-rounded ones
+ * 9e-4 (tools/amp_difference.py full --parts, profiles/r06_*).  Every trunk entry point above therefore has a twin that reads weights
+ * packed as fp16 (deer_model_load_tensor with deer_config.tower_f16) and activation planes fp16 hi / lo on v_mfma_f32_16x16x32_f16 -
+ * same arguments, same kernels, same speed (the trunk is HBM-bound; same bytes).  K / V of the gated x-attn arrive as fp16
+ * (deer_gemm_f16_nt with DEER_EPI_BF16 = "the family's 16-bit format").  The head entry points take the weight kind in their
+ * `w_is_f32` argument: 0 = bf16 rows, 1 = f32 rows, 2 = fp16 rows. */
+int deer_gemm_skinny_f16(const void* A, int lda, const float* Aslab, int s_in, long slab_stride_in, int a_mode, const void* Wp,
+                     float* part, int M, int N, int K, int splitk, const int* ctl, void* stream);
+int deer_gemm_skinny_hl_f16(const void* A_hi, const void* A_lo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
+                        const int* ctl, void* stream);
+int deer_gemm_skinny_hl_rows_f16(const void* A_hi, const void* A_lo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk,
+                             int slab_rows, const int* ctl, void* stream);
+int deer_gemm_skinny_hl_active_f16(const void* A_hi, const void* A_lo, int lda, const void* Wp, float* part, int M, int N, int K, int splitk, int slab_rows,
+                               const int* ctl, const int* cmap, int rows_per_env, void* stream);
+int deer_slab_gelu_split_f16(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows, int C,
+                         const int* ctl, void* stream);
+int deer_slab_gelu_split_active_f16(const float* slab, int s_in, long slab_stride, int gelu, void* out_hi, void* out_lo, int rows, int C, const int* ctl,
+                                const int* cmap, int rows_per_env, void* stream);
+int deer_resadd_ln_split_f16(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias,
+                         const float* gamma, const float* beta, void* out_hi, void* out_lo, float* out_f32, float* x_copy, int T,
+                         int d, float eps, const int* ctl, void* stream);
+int deer_resadd_ln_rows_f16(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* gamma, const float* beta, void* out_bf16,
+                        void* out_lo, float* out_f32, float* x_copy, int T_rows, int d, float eps, const int* ctl, const int* cmap, int rows_per_env,
+                        const float* x_in, const int* cmap_old, int B, int drop_upto, void* stream);
+int deer_resadd_ln_packed_f16(float* x, const float* slab, int s_in, long slab_stride, const float* gate, const float* bias, const float* gamma,
+                          const float* beta, void* out_hi, void* out_lo, float* out_f32, float* x_copy, int T, int d, float eps, const int* ctl,
+                          void* stream);
+int deer_trunk_wide_gemm_f16(const void* a_hi, const void* a_lo, const void* Wp, int N, int K, int epi, float* out_f32, void* out_hi, void* out_lo,
+                         int ldo, float* stats, int T, const int* ctl, void* stream);
+int deer_trunk_mpt_attn_f16(const float* qkv, const float* stats, int d_model, int n_heads, const float* q_ln_w, const float* k_ln_w, float eps,
+                        const unsigned char* key_mask, float alibi_bias_max, void* out_hi, void* out_lo, int ldo, int T, const int* ctl,
+                        void* stream);
+int deer_xattn_fused_f16(const float* xn, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
+                     int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch,
+                     float scale, const int* ctl, void* stream);
+int deer_xattn_fused_active_f16(const float* xn, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time, int n_per_media, int n_kv,
+                            const void* Wo_p, float* out, long slab_stride, int T, int heads, int batch, float scale, const int* ctl, const int* cmap,
+                            void* stream);
+int deer_xattn_fused_packed_f16(const void* x_hi, const void* x_lo, int d, const void* Wq_p, const void* kv, int ldkv, int inner, const int* text_time,
+                            int n_per_media, int n_kv, const void* Wo_p, float* out, long slab_stride, int T, int heads, float scale,
+                            const int* ctl, void* stream);
+int deer_xattn_mfma_f16(const float* qslab, int s_in, long slab_stride, int ldqs, const void* kv, int ldkv, int inner,
+                    const int* text_time, int n_per_media, void* out, int out_is_f32, int ldo, int T, int n_kv, int heads,
+                    int batch, float scale, const int* ctl, void* stream);
+int deer_mpt_attn_small_hl_f16(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w,
+                           const float* k_ln_w, float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws,
+                           void* out_hi, void* out_lo, int ldo, int T, int batch, const int* ctl, void* stream);
+int deer_mpt_attn_small_hl_active_f16(const float* qkvslab, int s_in, long slab_stride, int d_model, int n_heads, const float* q_ln_w, const float* k_ln_w,
+                                  float eps, const unsigned char* key_mask, float alibi_bias_max, float* qkv_ws, void* out_hi, void* out_lo, int ldo, int T,
+                                  int batch, const int* ctl, const int* cmap, void* stream);
+int deer_embed_tokens_f16(const long long* ids, const void* wte_bf16, float* x, int* text_time, int T, int batch, int d, int vocab,
+                      int media_id, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

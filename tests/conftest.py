@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # the CPU oracle is fastest on 32 threads on the GPU box's 256-logical-core host (bench.py's thread sweep: 1.34 full-size steps/s at 32,
+    # 0.65 at 64, 0.26 at 128 - oversubscribed intra-op pools); torch's default is one thread per core
+    import torch
+    if (os.cpu_count() or 1) > 32:
+        torch.set_num_threads(32)
 
 
 # Execution order of the test FILES (the driver runs `pytest tests/ -x`: whatever sits behind the first failure counts as untested, so the

@@ -95,15 +95,15 @@ def make_inputs(cfg, n_steps, text_len=14):
 
 
 # ----------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tower", ["fp16", "bf16"])
-def test_engine_matches_reference_golden_forward(tower):
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_engine_matches_reference_golden_forward(precision):
     """HIP engine vs the reference's own MPTFlamingo.forward outputs (static exit ids = BASELINE config[0],
-    and the dynamic-exit step protocol with LSTM carry), with the vision tower in fp16 (default: the reference's amp arithmetic) and in
-    bf16 (a --precision bf16 run)."""
+    and the dynamic-exit step protocol with LSTM carry), in the product arithmetic on fp16 operands (default: the reference's amp
+    arithmetic) and on bf16 operands (a --precision bf16 run)."""
     cfg, seed, g = load("deer_forward.npz")
     sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
-    eng = DeerEngine(cfg, sd, tower=tower)
-    assert eng.tower == tower and eng.img.dtype == (torch.float16 if tower == "fp16" else torch.bfloat16)
+    eng = DeerEngine(cfg, sd, precision=precision)
+    assert eng.precision == precision and eng.img.dtype == (torch.float16 if precision == "fp16" else torch.bfloat16)
     ids, mask = g["ids"].long(), g["mask"].bool()
     rgb, grip = g["rgb"], g["grip"]
     for eid in (3, 4, -1):
@@ -139,11 +139,11 @@ def tiny():
     return cfg, sd, eng
 
 
-@pytest.mark.parametrize("tower", ["fp16", "bf16"])
-def test_tiny_vision_and_hidden_states_vs_oracle(tiny, tower):
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_tiny_vision_and_hidden_states_vs_oracle(tiny, precision):
     cfg, sd, eng = tiny
-    if tower == "bf16":
-        eng = DeerEngine(cfg, sd, tower="bf16")
+    if precision == "bf16":
+        eng = DeerEngine(cfg, sd, precision="bf16")
     rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, 0)
     model = orc.OracleDeer(sd, cfg)
     model.set_all_exit_window_size(1)
@@ -152,7 +152,7 @@ def test_tiny_vision_and_hidden_states_vs_oracle(tiny, tower):
     r = eng.step(rgb, grip, ids, mask, exit_id=cfg.n_layers - 1, use_graph=False)
     vis = eng.vis_x_f32.cpu()
     ref_vis = o["vis_x"].reshape(cfg.n_media, cfg.vit_width)
-    assert float((vis - ref_vis).abs().max()) < 6e-2 and float((vis - ref_vis).norm() / ref_vis.norm()) < (1e-2 if tower == "bf16" else 1.5e-3)
+    assert float((vis - ref_vis).abs().max()) < 6e-2 and float((vis - ref_vis).norm() / ref_vis.norm()) < (1e-2 if precision == "bf16" else 1.5e-3)
     T = ids.shape[1]
     for i in range(cfg.n_layers):
         a, b = eng.hidden[i, :T].cpu(), o["hidden_states"][i][0]
@@ -626,8 +626,8 @@ def test_window_mode_calibration_full_size_batched_vs_oracle(max_layer):
     exit_ids = cfg.exit_ids()
     frames = [[syn.synthetic_step_inputs(cfg, 100 + t) for t in range(W)]]
     S = cfg.image_size
-    images = torch.stack([f[0].reshape(3, S, S) for f in frames[0]]).cuda().bfloat16()
-    gripper = torch.stack([f[1].reshape(3, S, S) for f in frames[0]]).cuda().bfloat16()
+    images = torch.stack([f[0].reshape(3, S, S) for f in frames[0]]).cuda().to(eng.img_dtype)
+    gripper = torch.stack([f[1].reshape(3, S, S) for f in frames[0]]).cuda().to(eng.img_dtype)
     ids = frames[0][0][2].cuda()
     hid = eng.window_hidden_states(images, gripper, ids, None)                   # (W, L, T, d): two groups of 8 / 4 frames
     if "ref12" not in _WINDOW_REF:
@@ -688,8 +688,8 @@ def test_compaction_of_exited_environments_is_bit_identical_to_the_uncompacted_b
         eng_off.reset()
         rec = [[] for _ in exit_ids]
         for s in range(6):
-            rgb = torch.stack([env_inputs[e][s][0] for e in range(B)]).cuda().bfloat16()
-            grip = torch.stack([env_inputs[e][s][1] for e in range(B)]).cuda().bfloat16()
+            rgb = torch.stack([env_inputs[e][s][0] for e in range(B)]).cuda().to(eng_on.img_dtype)
+            grip = torch.stack([env_inputs[e][s][1] for e in range(B)]).cuda().to(eng_on.img_dtype)
             for r in eng_off.step(rgb, grip, ids, mask if len(set(lens)) > 1 else None, use_graph=False, shadow=True):
                 for k in range(len(exit_ids)):
                     rec[k].append(float(r["deltas"][k]))
@@ -699,8 +699,8 @@ def test_compaction_of_exited_environments_is_bit_identical_to_the_uncompacted_b
         eng.set_thresholds(thr)
         eng.reset()
     for s in range(n_steps):
-        rgb = torch.stack([env_inputs[e][s][0] for e in range(B)]).cuda().bfloat16()
-        grip = torch.stack([env_inputs[e][s][1] for e in range(B)]).cuda().bfloat16()
+        rgb = torch.stack([env_inputs[e][s][0] for e in range(B)]).cuda().to(eng_on.img_dtype)
+        grip = torch.stack([env_inputs[e][s][1] for e in range(B)]).cuda().to(eng_on.img_dtype)
         ra = eng_on.step(rgb, grip, ids, mask if len(set(lens)) > 1 else None, use_graph=use_graph)
         rb = eng_off.step(rgb, grip, ids, mask if len(set(lens)) > 1 else None, use_graph=use_graph)
         for e in range(B):

@@ -35,7 +35,7 @@ def _dump_report():
             json.dump(REPORT, fh, indent=1)
 
 
-def replay_episode(z, tag, n_steps=None, n_envs=1, precision="bf16"):
+def replay_episode(z, tag, n_steps=None, n_envs=1, precision="fp16"):
     cfg = DeerConfig(**json.loads(bytes(z[tag + "_cfg_json"]).decode()))
     max_layer = int(z[tag + "_max_layer"])
     thr = [float(t) for t in z[tag + "_thr"]]
@@ -68,7 +68,7 @@ def replay_episode(z, tag, n_steps=None, n_envs=1, precision="bf16"):
     rep = dict(steps=n, thresholds=thr, exit_hist={int(k): v for k, v in sorted(hist.items())},
                knife_edge_steps=int((margin[:n] <= BAND).sum()), knife_edge_flips=flips, mismatches_outside_band=outside,
                worst_action_err=worst, worst_action_err_step=worst_at, band=BAND)
-    REPORT[tag if precision == "bf16" else tag + "_" + precision] = rep
+    REPORT[tag if precision == "fp16" else tag + "_" + precision] = rep
     _dump_report()
     print(f"\n[{tag} {precision}] {n} steps, exits {rep['exit_hist']}, knife-edge steps {rep['knife_edge_steps']} "
           f"(engine decided differently on {len(flips)}), mismatches outside the band {len(outside)}, "

@@ -329,7 +329,7 @@ def test_env_batch_takes_the_references_long_instructions_and_rejects_what_does_
         ctl._set_threshold_value([0.02] * (ctl.real_num_exit - 1) + [1e5])
         return model, proc, tok, vn, ctl
 
-    model, proc, tok, vn, ctl = build("bf16")
+    model, proc, tok, vn, ctl = build("fp16")
     w = ro.BatchedModelWrapper(model, tok, proc, torch.float32, exit_controller=ctl)
     assert model.engine.max_T == 32
     w.check_instructions(longs)                                    # every long instruction of the reference's file fits

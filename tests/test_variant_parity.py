@@ -31,14 +31,14 @@ def _head_only_cfg(cfg):
                                perc_latents=8, perc_depth=1, xattn_heads=2, xattn_dim_head=64, n_layers_total=4, early_exit_layer=1)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 2e-3)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("fp16", 2e-3), ("bf16", 2e-3)])
 @pytest.mark.parametrize("name", ["head_ln.npz", "head_plain.npz", "head_avg3.npz"])
 def test_engine_head_matches_reference_deterministic_decoder(name, precision, tol):
     """DeterministicDecoder step sequence with the commit / stash protocol (action_head.py:548-558) and the 12-step window call
     (:588-595) on the engine's head kernels.  fp32 arithmetic (f32 head weights): against the REFERENCE module's recorded outputs, 2e-5.
-    Product arithmetic (bf16 head weights, f32 activations): the fixture's weights are not bf16-representable, so the expected values
-    come from the oracle head (pinned on the same fixture by tests/test_oracle_golden.py) run on the bf16-ROUNDED weights the engine
-    holds - what remains is summation order."""
+    Product arithmetic (fp16 or bf16 head weights, f32 activations): the fixture's weights are not representable in 16 bits, so the
+    expected values come from the oracle head (pinned on the same fixture by tests/test_oracle_golden.py) run on the ROUNDED weights
+    the engine holds - what remains is summation order."""
     from oracle import deer_oracle as orc
     cfg0, seed, g = load(name)
     cfg = _head_only_cfg(cfg0)
@@ -49,8 +49,9 @@ def test_engine_head_matches_reference_deterministic_decoder(name, precision, to
             assert torch.equal(v, sd[k]), k
     W = cfg0.window_size
     exp = {k: g[k] for k in ("pose", "grip", "h", "c", "wpose", "wgrip", "wgrip_logits")}
-    if precision == "bf16":
-        o = orc.OracleHead(syn.round_state_to_bf16(cfg0, ref_sd), cfg0)
+    if precision != "fp32":
+        rsd = syn.round_state_to_bf16(cfg0, ref_sd) if precision == "bf16" else syn.round_state_to_fp16(cfg0, ref_sd)
+        o = orc.OracleHead(rsd, cfg0)
         o.window_size = 1
         ps, gs, hs, cs = [], [], [], []
         for t in range(g["feats"].shape[0]):
@@ -60,7 +61,7 @@ def test_engine_head_matches_reference_deterministic_decoder(name, precision, to
             z = torch.zeros(cfg0.lstm_num_layers, 1, cfg0.head_hidden)
             hs.append(z if o.hidden_state is None else o.hidden_state[0].clone())
             cs.append(z if o.hidden_state is None else o.hidden_state[1].clone())
-        o2 = orc.OracleHead(syn.round_state_to_bf16(cfg0, ref_sd), cfg0)
+        o2 = orc.OracleHead(rsd, cfg0)
         o2.window_size = W
         wa, (wg, wl) = o2(g["wfeat"], with_gripper_logits=True)
         o2.last_action = True
@@ -92,7 +93,8 @@ def test_engine_head_matches_reference_deterministic_decoder(name, precision, to
     assert float((out[:, -1:, 7:8] - exp["wgrip_logits"]).abs().max()) < 4 * tol
 
 
-R6 = [("deer_forward_plain.npz", "bf16"), ("deer_forward_avg3.npz", "bf16"), ("deer_forward_thr.npz", "bf16"), ("deer_forward_consec.npz", "bf16"),
+R6 = [("deer_forward_plain.npz", "fp16"), ("deer_forward_avg3.npz", "fp16"), ("deer_forward_thr.npz", "fp16"), ("deer_forward_consec.npz", "fp16"),
+      ("deer_forward_plain.npz", "bf16"), ("deer_forward_thr.npz", "bf16"),
       ("deer_forward_plain.npz", "fp32"), ("deer_forward_avg3.npz", "fp32"), ("deer_forward_thr.npz", "fp32")]
 
 
@@ -103,7 +105,7 @@ def test_engine_matches_reference_forward_for_head_and_criterion_variants(name, 
     cfg, seed, g = load(name)
     sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
     eng = DeerEngine(cfg, sd, precision=precision)
-    tol = ACTION_TOL if precision == "bf16" else 1e-3
+    tol = ACTION_TOL if precision != "fp32" else 1e-3
     ids, mask, rgb, grip = g["ids"].long(), g["mask"].bool(), g["rgb"], g["grip"]
     for eid in (3, 4):
         eng.reset()
@@ -132,7 +134,7 @@ def test_engine_matches_reference_forward_for_head_and_criterion_variants(name, 
                 layer, d_ref = ref_deltas[k]
                 assert int(layer) == e
                 d = float(r["deltas"][slot])
-                assert abs(d - d_ref) < max(0.06 * abs(d_ref), 3e-4 if precision == "bf16" else 2e-5), (ttype, s, e, d, d_ref)
+                assert abs(d - d_ref) < max(0.06 * abs(d_ref), 3e-4 if precision != "fp32" else 2e-5), (ttype, s, e, d, d_ref)
                 k += 1
         assert k == len(ref_deltas)
 
@@ -152,7 +154,7 @@ def test_exit_interval_one_dynamic_exit_is_refused_like_the_reference():
     assert abs(r["gripper"] - float(g["static0_grip"])) < ACTION_TOL
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["fp16", "bf16", "fp32"])
 def test_window_mode_on_right_padded_instructions_matches_reference(precision):
     """``generate_action_values`` on a batch of windows with instructions of different lengths (value_net.py:333-386): every layer's hidden
     state at EVERY row (pad rows are queries like any other), extra_exit over the reference's random history layers, and the calibration
@@ -173,19 +175,19 @@ def test_window_mode_on_right_padded_instructions_matches_reference(precision):
                                                                          rand_layers=g["rand_layers"])
     hid = torch.stack(out.hidden_states).cpu()                   # (L, bs*W, T, d)
     ref = g["hidden"]
-    rel = 2e-2 if precision == "bf16" else 1e-4
+    rel = 2e-2 if precision != "fp32" else 1e-4
     assert float((hid - ref).norm() / ref.norm()) < rel
     pad = ~attention_mask                                         # the pad rows on their own (they must be real, not zeros / garbage)
     assert float((hid[:, pad] - ref[:, pad]).norm() / ref[:, pad].norm()) < rel
     assert torch.equal(rand_idx.cpu(), g["rand_layers"])
-    tol = ACTION_TOL if precision == "bf16" else 1e-3
+    tol = ACTION_TOL if precision != "fp32" else 1e-3
     assert float((extra[0].cpu() - g["extra_pose"]).abs().max()) < tol
     assert float((extra[1][0].cpu() - g["extra_grip"]).abs().max()) < tol
     eng = model.engine
     eng.configure_exit(cfg.exit_ids(), 12, 1)
     vals = eng.generate_values(hid.permute(1, 0, 2, 3).reshape(bs, W, cfg.n_layers, T, cfg.d_model).to(eng.dev), g["rand_layers"], "L2")
     assert vals.shape == g["delta"].shape
-    assert float((vals - g["delta"]).abs().max()) < (5e-3 if precision == "bf16" else 1e-4), (vals, g["delta"])
+    assert float((vals - g["delta"]).abs().max()) < (5e-3 if precision != "fp32" else 1e-4), (vals, g["delta"])
 
 
 def test_layerwise_exit_eval_env_batch_with_staggered_exits_matches_independent_oracle_runs():

@@ -22,9 +22,10 @@ from oracle import deer_oracle as orc
 torch.set_grad_enabled(False)
 which = sys.argv[1] if len(sys.argv) > 1 else "tiny"
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-cfg = deer_tiny() if which == "tiny" else deer_tiny(image_size=112, vit_width=256, vit_layers=6, vit_heads=4, vit_mlp=1024, perc_depth=3,
+from deer_vla_amd.config import deer_3b
+cfg = deer_3b(max_layer=12) if which == "full" else deer_tiny() if which == "tiny" else deer_tiny(image_size=112, vit_width=256, vit_layers=6, vit_heads=4, vit_mlp=1024, perc_depth=3,
                                                      d_model=512, n_heads=4, n_layers_total=12, early_exit_layer=7, head_hidden=256)
-sd = syn.make_synthetic_state(cfg, 3, bf16_round=False)
+sd = syn.make_synthetic_state(cfg, 3, bf16_round=False, std="0.02" if which == "full" else "fanin")
 sd_bf = syn.round_state_to_bf16(cfg, sd)
 inputs = [syn.synthetic_step_inputs(cfg, s) for s in range(n_steps)]
 last = cfg.n_layers - 1
@@ -44,7 +45,45 @@ def episode(state, amp_dtype=None):
     return torch.stack(out)
 
 
+def rounded(parts, fmt=torch.bfloat16):
+    """sd with the GEMM operands of the named parts ("tower": ViT + Perceiver + x-attn to_kv, "trunk": MPT blocks + x-attn q / out / ff + wte,
+    "head": extra_exit) rounded to `fmt`"""
+    kinds = {k: v[1] for k, v in syn.param_shapes(cfg).items()}
+    out = {}
+    for k, t in sd.items():
+        part = "head" if k.startswith(("extra_exit.", "lm_exit_modules.", "lm_head.")) else \
+            ("tower" if k.startswith(("vision_encoder.", "perceiver")) or k.endswith("attn.to_kv.weight") else "trunk")
+        out[k] = t.to(fmt).to(torch.float32) if (kinds.get(k) in syn.BF16_KINDS and part in parts) else t.clone()
+    return out
+
+
+def mixed():
+    """the engine's round-6 product arithmetic restated on the oracle: tower weights fp16 AND the tower's Linears under fp16 autocast is
+    approximated by fp16-rounded tower weights in f32 arithmetic (the activation side is what the GPU suite measures: <= 1.3e-3 at full size);
+    trunk + head weights bf16"""
+    st = rounded({"trunk", "head"})
+    t16 = rounded({"tower"}, torch.float16)
+    for k in st:
+        if k.startswith(("vision_encoder.", "perceiver")) or k.endswith("attn.to_kv.weight"):
+            st[k] = t16[k]
+    return st
+
+
 ref = episode(sd)
+if "--parts" in sys.argv:
+    print(f"config {which}: which weights' bf16 rounding moves the action (f32 arithmetic, max |action - f32| over {n_steps} steps)")
+    variants = (("tower only -> bf16", lambda: rounded({"tower"})), ("tower only -> fp16", lambda: rounded({"tower"}, torch.float16)),
+                ("trunk only -> bf16", lambda: rounded({"trunk"})), ("trunk only -> fp16", lambda: rounded({"trunk"}, torch.float16)),
+                ("head only -> bf16", lambda: rounded({"head"})), ("head only -> fp16", lambda: rounded({"head"}, torch.float16)),
+                ("tower fp16 + trunk bf16 + head bf16", mixed),
+                ("everything -> fp16 (an amp run's weights: autocast casts every Linear's weight to fp16)", lambda: rounded({"tower", "trunk", "head"}, torch.float16)),
+                ("everything -> bf16 (the engine's weights up to round 5; a --precision bf16 run)", lambda: sd_bf))
+    for name, mk in variants:
+        st = mk()
+        d = (episode(st) - ref).abs()
+        del st
+        print(f"  {name:90s} {float(d.max()):.3e}   mean {float(d.mean()):.3e}", flush=True)
+    sys.exit(0)
 rows = [("reference amp (f32 weights, fp16 autocast)", episode(sd, torch.float16)),
         ("reference amp_bf16 (f32 weights, bf16 autocast)", episode(sd, torch.bfloat16)),
         ("f32 arithmetic on bf16-rounded weights (the engine's bf16 path is within 2.7e-3 of this)", episode(sd_bf))]

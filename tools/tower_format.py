@@ -66,7 +66,7 @@ def episode(cfg, sd, inputs, towers=("bf16", "fp16")):
     ref, _ = oracle_episode(cfg, sd, inputs, thr)
     res = {}
     for tower in towers:
-        eng = DeerEngine(cfg, sd, max_text_len=32, tower=tower)
+        eng = DeerEngine(cfg, sd, max_text_len=32, precision=tower)
         eng.configure_exit(cfg.exit_ids(), 12, 1)
         eng.set_thresholds(thr)
         eng.reset()
@@ -101,7 +101,7 @@ def static_steps(cfg, sd, n_steps, towers=("bf16", "fp16")):
         refs.append((rgb, grip, ids, mask, exits[s % 3], o["logits"][0].reshape(-1), float(o["logits"][1]), o["vis_x"]))
     res = {}
     for tower in towers:
-        eng = DeerEngine(cfg, sd, tower=tower)
+        eng = DeerEngine(cfg, sd, precision=tower)
         eng.reset()
         worst, media = 0.0, 0.0
         for rgb, grip, ids, mask, eid, pose, g, vis in refs:
