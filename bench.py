@@ -319,8 +319,8 @@ def surface_leg(cfg, eng, thr, frames, ids, steps, warmup=20):
     vn = ActionValueNet(model.get_all_exit_idx(), None, cfg.exit_interval, cfg.window_size, "L2")
     ctl = ExitController(vn, model.get_all_exit_idx(), max_layer=eng._max_layer_arg)
     ctl._set_threshold_value(list(thr))
-    proc = GpuImageProcessor(cfg.image_size, device=eng.dev)
-    w = ro.ModelWrapper(model, SyntheticTokenizer(cfg), proc, torch.bfloat16, early_exit=True, exit_controller=ctl)
+    proc = GpuImageProcessor(cfg.image_size, device=eng.dev, dtype=eng.img_dtype)
+    w = ro.ModelWrapper(model, SyntheticTokenizer(cfg), proc, eng.img_dtype, early_exit=True, exit_controller=ctl)
     rng = np.random.default_rng(5)
     obs = [{"rgb_obs": {"rgb_static": rng.integers(0, 255, (200, 200, 3), dtype=np.uint8),
                         "rgb_gripper": rng.integers(0, 255, (84, 84, 3), dtype=np.uint8)}, "robot_obs": np.zeros(15, np.float32)} for _ in range(16)]

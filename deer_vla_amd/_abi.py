@@ -106,6 +106,7 @@ SIGNATURES = {
     "deer_head_fused": [P, I, I, P],
     "deer_ctl_begin_step": [P, P, I, P],
     "deer_preprocess_frames": [P, I, I, I, I, P, P, P, P, P, P],
+    "deer_preprocess_frames_f16": [P, I, I, I, I, P, P, P, P, P, P],
     "deer_preprocess_scratch_bytes": [I, I, I, I],
     "deer_spin_us": [I, P],
     "deer_hip_arch": [],

@@ -73,6 +73,7 @@ __global__ void pp_horizontal_kernel(const unsigned char* __restrict__ src, unsi
 }
 
 // vertical pass + center crop + ToTensor + Normalize: tmp [N][H][OW][3] u8 -> out [N][3][S][S] (bf16 and/or f32)
+template <bool F16>
 __global__ void pp_vertical_kernel(const unsigned char* __restrict__ tmp, bf16_t* __restrict__ out_bf, float* __restrict__ out_f32, int N, int H, int OW,
                                    int OH, int S, int crop_x, int crop_y, float m0, float m1, float m2, float r0, float r1, float r2) {
   const long total = (long)N * S * S;
@@ -89,14 +90,15 @@ __global__ void pp_vertical_kernel(const unsigned char* __restrict__ tmp, bf16_t
     const float v0 = ((float)pp_clip8(s0) / 255.0f - m0) / r0, v1 = ((float)pp_clip8(s1) / 255.0f - m1) / r1,
                 v2 = ((float)pp_clip8(s2) / 255.0f - m2) / r2;
     const long o = ((long)n * 3 * S + y) * S + x, plane = (long)S * S;
-    if (out_bf != nullptr) { out_bf[o] = f2bf(v0); out_bf[o + plane] = f2bf(v1); out_bf[o + 2 * plane] = f2bf(v2); }
+    if (out_bf != nullptr) { out_bf[o] = f2x<F16>(v0); out_bf[o + plane] = f2x<F16>(v1); out_bf[o + 2 * plane] = f2x<F16>(v2); }
     if (out_f32 != nullptr) { out_f32[o] = v0; out_f32[o + plane] = v1; out_f32[o + 2 * plane] = v2; }
   }
 }
 
 // src: uint8 [N][H][W][3] (device); tmp: uint8 scratch of N*H*OW*3 bytes, OW = max(S, round(W * S / min(W, H))); out_bf16 / out_f32:
 // [N][3][S][S] (either may be NULL).  mean / std: host float[3].
-extern "C" int deer_preprocess_frames(const unsigned char* src, int N, int H, int W, int S, const float* mean, const float* std_, unsigned char* tmp,
+template <bool F16>
+static int preprocess_frames(const unsigned char* src, int N, int H, int W, int S, const float* mean, const float* std_, unsigned char* tmp,
                                       void* out_bf16, float* out_f32, void* stream) {
   if (src == nullptr || tmp == nullptr || N <= 0 || H <= 0 || W <= 0 || S <= 0 || mean == nullptr || std_ == nullptr ||
       (out_bf16 == nullptr && out_f32 == nullptr))
@@ -111,10 +113,20 @@ extern "C" int deer_preprocess_frames(const unsigned char* src, int N, int H, in
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long t1 = (long)N * H * OW, t2 = (long)N * S * S;
   hipLaunchKernelGGL(pp_horizontal_kernel, dim3((unsigned)((t1 + 255) / 256 > 4096 ? 4096 : (t1 + 255) / 256)), dim3(256), 0, st, src, tmp, N, H, W, OW);
-  hipLaunchKernelGGL(pp_vertical_kernel, dim3((unsigned)((t2 + 255) / 256 > 4096 ? 4096 : (t2 + 255) / 256)), dim3(256), 0, st, tmp,
+  hipLaunchKernelGGL(pp_vertical_kernel<F16>, dim3((unsigned)((t2 + 255) / 256 > 4096 ? 4096 : (t2 + 255) / 256)), dim3(256), 0, st, tmp,
                      reinterpret_cast<bf16_t*>(out_bf16), out_f32, N, H, OW, OH, S, crop_x, crop_y, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2]);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
+}
+
+extern "C" int deer_preprocess_frames(const unsigned char* src, int N, int H, int W, int S, const float* mean, const float* std_, unsigned char* tmp,
+                                      void* out_bf16, float* out_f32, void* stream) {
+  return preprocess_frames<false>(src, N, H, W, S, mean, std_, tmp, out_bf16, out_f32, stream);
+}
+// the same with the 16-bit output in IEEE fp16 (round 6: the frame format of a precision = "fp16" engine; every 8-bit pixel level stays distinct)
+extern "C" int deer_preprocess_frames_f16(const unsigned char* src, int N, int H, int W, int S, const float* mean, const float* std_, unsigned char* tmp,
+                                          void* out_f16, float* out_f32, void* stream) {
+  return preprocess_frames<true>(src, N, H, W, S, mean, std_, tmp, out_f16, out_f32, stream);
 }
 
 // scratch bytes deer_preprocess_frames needs for N frames of H x W (host only)

@@ -62,12 +62,16 @@ class ClipImageProcessor:
 
 class GpuImageProcessor:
     """The same transform as ``ClipImageProcessor`` on the GPU (csrc/preprocess.hip: PIL's two-pass fixed-point bicubic resampler
-    restated bit-exactly + crop + normalise, two launches per call): uint8 frames (H, W, 3) or (N, H, W, 3) -> (N, 3, S, S) bf16 on the
-    device.  ``on_device = True`` tells ``ModelWrapper`` to hand the raw camera frames over instead of running PIL on the host."""
+    restated bit-exactly + crop + normalise, two launches per call): uint8 frames (H, W, 3) or (N, H, W, 3) -> (N, 3, S, S) fp16 (or bf16) on
+    the device.  ``on_device = True`` tells ``ModelWrapper`` to hand the raw camera frames over instead of running PIL on the host."""
     on_device = True
 
-    def __init__(self, size: int = 224, device="cuda"):
+    def __init__(self, size: int = 224, device="cuda", dtype: torch.dtype = torch.float16):
+        """dtype: the 16-bit format of the frames handed to the engine - torch.float16 (default: the frame format of the default fp16
+        arithmetic; every 8-bit pixel level stays distinct after normalisation) or torch.bfloat16 (a precision="bf16" engine)"""
         from . import _abi as abi
+        assert dtype in (torch.float16, torch.bfloat16)
+        self.dtype = dtype
         self.size, self.dev, self.lib, self._abi = size, torch.device(device), abi.lib(), abi
         import ctypes
         self._mean = (ctypes.c_float * 3)(*CLIP_MEAN)
@@ -88,10 +92,11 @@ class GpuImageProcessor:
         tmp = getattr(self._tls, "tmp", None)
         if tmp is None or tmp.numel() < need:
             tmp = self._tls.tmp = torch.empty(need, dtype=torch.uint8, device=self.dev)
-        out = torch.empty(N, 3, self.size, self.size, dtype=torch.float32 if out_f32 else torch.bfloat16, device=self.dev)
+        out = torch.empty(N, 3, self.size, self.size, dtype=torch.float32 if out_f32 else self.dtype, device=self.dev)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         abi = self._abi
-        abi.check(self.lib.deer_preprocess_frames(abi.ptr(x), N, H, W, self.size, self._mean, self._std, abi.ptr(tmp),
+        fn = self.lib.deer_preprocess_frames_f16 if self.dtype == torch.float16 else self.lib.deer_preprocess_frames
+        abi.check(fn(abi.ptr(x), N, H, W, self.size, self._mean, self._std, abi.ptr(tmp),
                                                   None if out_f32 else abi.ptr(out), abi.ptr(out) if out_f32 else None, st), "deer_preprocess_frames")
         return out
 

@@ -421,6 +421,9 @@ int deer_ctl_begin_step(int* ctl, const int* step_info, int B, void* stream);
  * deer_preprocess_scratch_bytes(N, H, W, S) bytes; mean / std_: HOST float[3]. */
 int deer_preprocess_frames(const unsigned char* src, int N, int H, int W, int S, const float* mean, const float* std_,
                            unsigned char* tmp, void* out_bf16, float* out_f32, void* stream);
+/* deer_preprocess_frames with the 16-bit output in IEEE fp16 (the frame format of a fp16 engine) */
+int deer_preprocess_frames_f16(const unsigned char* src, int N, int H, int W, int S, const float* mean, const float* std_,
+                           unsigned char* tmp, void* out_bf16, float* out_f32, void* stream);
 long deer_preprocess_scratch_bytes(int N, int H, int W, int S);
 
 /* keeps `stream` busy for ~us microseconds (profiling aid: lets the host enqueue ahead of the GPU) */

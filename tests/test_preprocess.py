@@ -21,8 +21,10 @@ def test_gpu_preprocessing_matches_pil_bit_for_bit(hw):
     out = gpu(frames, out_f32=True).cpu()
     assert out.shape == ref.shape == (3, 3, 224, 224)
     assert float((out - ref).abs().max()) == 0.0, float((out - ref).abs().max())
-    bf = gpu(frames).float().cpu()                                     # the engine's input dtype
-    assert float((bf - ref).abs().max()) <= 1e-2
+    h16 = gpu(frames)                                                  # the engine's input format (fp16 by default): every pixel level distinct
+    assert h16.dtype == torch.float16 and torch.equal(h16.cpu(), ref.to(torch.float16))
+    bf = GpuImageProcessor(224, dtype=torch.bfloat16)(frames)
+    assert bf.dtype == torch.bfloat16 and torch.equal(bf.cpu(), ref.to(torch.bfloat16))
 
 
 def test_model_wrapper_takes_raw_frames_through_the_gpu_processor():
@@ -37,7 +39,7 @@ def test_model_wrapper_takes_raw_frames_through_the_gpu_processor():
                                                    llm_name="mpt_dolly_3b", state_dict=sd, cfg=cfg)
     acts = []
     for p in (proc, GpuImageProcessor(cfg.image_size)):
-        w = ro.ModelWrapper(model, tok, p, torch.bfloat16, exit_id=3)
+        w = ro.ModelWrapper(model, tok, p, torch.float32, exit_id=3)      # cast_dtype of the README's `--precision fp32 --amp 1` evaluation (frames stay f32 / fp16)
         env = ro.SyntheticEnv(seed=5)
         obs = env.get_obs()
         a = []
