@@ -170,7 +170,17 @@ def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6, traffic_key=None):
     else:
         achieved, peak, unit = d["bytes"] / d["us"] / 1e3, HBM_PEAK_GBS, "GB/s"
     traffic, traffic_src = pmc_traffic(dom, traffic_key)
-    return {"kernel": dom, "bound": KERNEL_BOUND[dom], "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+    # What actually binds the small-M GEMM class: not the matrix pipe but the L2 -> LDS operand fill.  A 64 x 64 output tile
+    # pulls (64 + 64) x K x 2 B for 2 x 64 x 64 x K FLOP = 1 B per 32 FLOP through its CU, whatever the split-K; at M = 514 the tile cannot
+    # grow without leaving CUs idle (432 tiles of in_proj on 256 CUs).  Reported beside the contract's MFMA fraction: the fill rate the
+    # launch sustains end to end against the measured L2 bandwidth of the chip (34.5 TB/s, MI355X_MICROARCH.md).
+    l2_fill = None
+    if dom == "deer_gemm_bf16_nt" and traffic_key is not None and traffic_key.endswith("envs1"):
+        fill_gbs = d["flops"] / 32.0 / d["us"] / 1e3
+        l2_fill = {"bytes_per_flop": 1 / 32.0, "achieved_GBs": round(fill_gbs, 1), "peak_GBs": 34500.0, "frac": round(fill_gbs / 34500.0, 4),
+                   "note": "whole-launch average incl. the ~3 us prologue / epilogue of a 10 us launch; inside the K loop the ring fills at 107 GB/s per CU "
+                           "= 27 TB/s = 0.79 of the L2 peak (tools/ktrace_gemm.py)"}
+    return {"kernel": dom, "bound": KERNEL_BOUND[dom], "l2_fill": l2_fill, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)",
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]),
             "avg_launch_us": round(d["us"] / d["n"], 2), "launches_per_step": d["n"] // (n_pass - 1),
