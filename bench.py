@@ -180,7 +180,10 @@ def measure_roofline(eng, cfg, frames, ids, n_pass: int = 6, traffic_key=None):
         l2_fill = {"bytes_per_flop": 1 / 32.0, "achieved_GBs": round(fill_gbs, 1), "peak_GBs": 34500.0, "frac": round(fill_gbs / 34500.0, 4),
                    "note": "whole-launch average incl. the ~3 us prologue / epilogue of a 10 us launch; inside the K loop the ring fills at 107 GB/s per CU "
                            "= 27 TB/s = 0.79 of the L2 peak (tools/ktrace_gemm.py)"}
-    return {"kernel": dom, "bound": KERNEL_BOUND[dom], "l2_fill": l2_fill, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+    # the class names are the bf16 entry points (the profiler's labels); an fp16 engine launches their `_f16` twins - same kernel
+    # templates, same arguments (include/deer_hip.h)
+    entry = dom.replace("_bf16_", "_f16_") if getattr(eng, "precision", "") == "fp16" and "_bf16_" in dom else (dom + "_f16" if getattr(eng, "precision", "") == "fp16" else dom)
+    return {"kernel": dom, "entry_point": entry, "bound": KERNEL_BOUND[dom], "l2_fill": l2_fill, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)",
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]),
             "avg_launch_us": round(d["us"] / d["n"], 2), "launches_per_step": d["n"] // (n_pass - 1),
@@ -669,8 +672,20 @@ def run_workload(args, cfg, sd_dev, B, rank, world, local_rank, dist, max_layer,
         dt, xs, hist = timed(n_on, args.burn_in + warmup)
         on_policy = {"value": round(world * n_on * B / dt, 2), "unit": "action-steps/s", "steps": n_on, "avg_exit_layer": round(xs / (n_on * B), 3),
                      "exit_hist": hist, "thresholds": [round(x, 6) for x in thr],
-                     "note": "dynamic exits decided by the calibrated thresholds on the synthetic episode's own deltas (this rank's "
-                             "replica x world; not barrier-timed across ranks)"}
+                     "note": "dynamic exits decided by the calibrated thresholds on the synthetic episode's own deltas"}
+        if dist is not None:
+            # N > 1: the on-policy leg over ALL ranks - slowest rank's time, every rank's steps and exit layers -
+            # so that the N-GPU line can be set beside the 1-GPU `on_policy` object; the per-rank min / max rate next to it
+            ops = torch.tensor([dt, float(xs), float(n_on * B)], dtype=torch.float64,
+                               device=dev if dist.get_backend() == "nccl" else "cpu")
+            omax, omin = ops[:1].clone(), ops[:1].clone()
+            dist.all_reduce(omax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(omin, op=dist.ReduceOp.MIN)
+            dist.all_reduce(ops, op=dist.ReduceOp.SUM)
+            on_policy["value"] = round(float(ops[2]) / float(omax[0]), 2)
+            on_policy["avg_exit_layer"] = round(float(ops[1]) / float(ops[2]), 3)
+            on_policy["per_rank_steps_per_s"] = {"min": round(n_on * B / float(omax[0]), 2), "max": round(n_on * B / float(omin[0]), 2)}
+            on_policy["exit_hist_rank0"] = on_policy.pop("exit_hist")
     if B > 1:
         # env batches: every environment exits at its own layer by the real criterion (thresholds are shared by the batch, so a
         # scripted verdict would make all environments leave together) - this leg IS the on-policy one

@@ -194,10 +194,10 @@ class DeerConfigC(ctypes.Structure):
         "mpt7b_names", "exit_interval",
         "head_hidden", "lstm_num_layers", "lstm_layernorm", "mlp_layernorm", "mlp_num_hidden_layers", "pooling_avg",
         "n_envs", "max_text_len", "n_chains", "precision", "use_state", "sep_resampler", "multi_step_action", "layerwise_exit_eval",
-        "tower_f16")]
+        "operands_f16")]
 
 
-# precision of an engine -> (deer_config.precision, deer_config.tower_f16):
+# precision of an engine -> (deer_config.precision, deer_config.operands_f16):
 #   "fp16"  the product arithmetic on IEEE fp16 operands (default): fp16 weights everywhere, fp16 results in the vision tower, fp16 hi + lo
 #           activation planes in the trunk, f32 accumulation / LayerNorm / softmax / LSTM state - the reference's evaluation arithmetic
 #           (fp32 weights under fp16 autocast, eval_utils.py:333, README.md:161-167)
@@ -238,7 +238,7 @@ def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0, precisio
     c.n_envs, c.max_text_len, c.n_chains = n_envs, max_text_len, n_chains
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
-    c.precision, c.tower_f16 = PRECISIONS[precision]
+    c.precision, c.operands_f16 = PRECISIONS[precision]
     c.use_state = 1 if getattr(cfg, "use_state", False) else 0
     c.sep_resampler = 1 if getattr(cfg, "sep_resampler", False) else 0
     c.multi_step_action = int(getattr(cfg, "multi_step_action", 1))

@@ -71,7 +71,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f
 // runs on fp16 operands and leaves an fp16 result, LayerNorm / softmax / the residual stream stay f32.  v_mfma_f32_16x16x32_f16 issues at
 // the bf16 rate, OpenAI CLIP weights are fp16-native, and an fp16 activation carries 11 significand bits where bf16 carries 8 - so the
 // tower kernels are templates over the format (F16 = true: fp16 operands / results; storage stays `bf16_t` = 16 raw bits) and the model
-// picks one per engine (deer_config.tower_f16).  The LLM trunk keeps its bf16 hi + lo planes (f32-equivalent activations).
+// picks one per engine (deer_config.operands_f16).  The LLM trunk keeps its bf16 hi + lo planes (f32-equivalent activations).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 deer_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2h(float lo, float hi) {      // v_cvt_pk_f16_f32: round-to-nearest-even, overflow -> inf like torch .half()

@@ -57,7 +57,7 @@ __global__ void ingest_rows_kernel(const SrcT* __restrict__ src, void* __restric
 
 // row-major W[N,K] (f32 or bf16) -> MFMA-fragment order Wp[N/16][K/32][64 lanes][8] bf16 (the layout deer_gemm_skinny streams)
 // LO: the second plane of the fp32 arithmetic, bf16(w - bf16(w)) - together with the hi plane ~16 mantissa bits of every weight
-// F16: fp16 fragments (deer_config.tower_f16: the whole product arithmetic on fp16 operands)
+// F16: fp16 fragments (deer_config.operands_f16: the whole product arithmetic on fp16 operands)
 template <typename SrcT, bool LO = false, bool F16 = false>
 __global__ void ingest_pack_kernel(const SrcT* __restrict__ W, bf16_t* __restrict__ Wp, int N, int K) {
   const long total = (long)(N >> 4) * (K >> 5) * 64;
@@ -81,7 +81,7 @@ __global__ void ingest_pack_kernel(const SrcT* __restrict__ W, bf16_t* __restric
   }
 }
 
-enum SlotKind { SK_F32 = 0, SK_BF16 = 1, SK_PACK = 2, SK_F16 = 3 };   // SK_F16: fp16 rows (vision-tower GEMM operands, deer_config.tower_f16)
+enum SlotKind { SK_F32 = 0, SK_BF16 = 1, SK_PACK = 2, SK_F16 = 3 };   // SK_F16: fp16 rows (vision-tower GEMM operands, deer_config.operands_f16)
 
 struct Slot {
   int kind;
@@ -160,8 +160,8 @@ struct ProfRec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
 
 struct deer_model {
   deer_config c;
-  int wkind = 0;                    // head weight rows: 0 = bf16, 1 = f32 (precision = 1), 2 = fp16 (tower_f16) - csrc/head.hip
-  bool f16 = false;                 // every 16-bit operand of the product arithmetic in IEEE fp16 (deer_config.tower_f16)
+  int wkind = 0;                    // head weight rows: 0 = bf16, 1 = f32 (precision = 1), 2 = fp16 (operands_f16) - csrc/head.hip
+  bool f16 = false;                 // every 16-bit operand of the product arithmetic in IEEE fp16 (deer_config.operands_f16)
   // derived
   int P, tok, W, kpad, nl, p_inner, Lp, d, xinner, n_xattn, H, Lh, B, N, n_fc;
   int fc_dims[3];
@@ -293,7 +293,7 @@ void build_arena(deer_model* m) {
   const std::string v = "vision_encoder.visual.";
   const int kk = 3 * c.patch_size * c.patch_size;
   // GEMM operands of the vision tower / Perceiver / x-attn K|V projection: bf16 for the product arithmetic, f32 for the fp32 one
-  const int GK = c.precision ? SK_F32 : (c.tower_f16 ? SK_F16 : SK_BF16);
+  const int GK = c.precision ? SK_F32 : (c.operands_f16 ? SK_F16 : SK_BF16);
   const size_t we = c.precision ? 4 : 2;
   m->conv = add_slot(m, v + "conv1.weight", GK, W, kk, true, m->kpad);
   m->cls = add_slot(m, v + "class_embedding", SK_F32, 1, W);
@@ -351,11 +351,11 @@ void build_arena(deer_model* m) {
   }
   // ---- LLM: projections pre-packed in MFMA-fragment order; to_kv of all x-attn layers concatenated (media is layer-invariant)
   const int d = m->d, xin = m->xinner;
-  m->wte = add_slot(m, "lang_encoder.transformer.wte.weight", c.precision ? SK_F32 : (c.tower_f16 ? SK_F16 : SK_BF16), c.vocab_size, d);
+  m->wte = add_slot(m, "lang_encoder.transformer.wte.weight", c.precision ? SK_F32 : (c.operands_f16 ? SK_F16 : SK_BF16), c.vocab_size, d);
   m->n_xattn = 0;
   for (int n = 0; n < c.n_layers; ++n)
     if ((n + 1) % c.cross_attn_every_n_layers == 0) ++m->n_xattn;
-  const int GKx = c.precision ? SK_F32 : (c.tower_f16 ? SK_F16 : SK_BF16);   // x-attn to_kv: the media K/V GEMM belongs to the tower's arithmetic
+  const int GKx = c.precision ? SK_F32 : (c.operands_f16 ? SK_F16 : SK_BF16);   // x-attn to_kv: the media K/V GEMM belongs to the tower's arithmetic
   const size_t wex = c.precision ? 4 : 2;
   m->wkv_all = m->n_xattn ? m->al.add((size_t)m->n_xattn * 2 * xin * W * wex) : SIZE_MAX;
   m->llm.resize(c.n_layers);
@@ -403,7 +403,7 @@ void build_arena(deer_model* m) {
   }
   // ---- action head (DeterministicDecoder, action_head.py:408-497): LN-LSTM = [LSTM, LN, Dropout] x L under rnn.layers.{3l, 3l+1}
   const std::string p = "extra_exit.";
-  const int HK = c.precision ? SK_F32 : (c.tower_f16 ? SK_F16 : SK_BF16);      // head weights: bf16 / fp16, or f32 for the fp32 arithmetic
+  const int HK = c.precision ? SK_F32 : (c.operands_f16 ? SK_F16 : SK_BF16);      // head weights: bf16 / fp16, or f32 for the fp32 arithmetic
   const int H = m->H;
   if (c.use_state) {                                   // action_head.py:443-453
     m->w_arm = add_slot(m, p + "embed_arm_state.0.weight", SK_F32, d, 6);
@@ -635,13 +635,13 @@ int gemm(deer_model* m, const void* A, const void* Wt, void* C, long M, long N, 
   const double out_b = (epi == DEER_EPI_F32 || epi == DEER_EPI_RESADD_F32) ? 4.0 : 2.0;
   // the profiler's class name stays "deer_gemm_bf16_nt" for both 16-bit formats (one kernel family; bench.py's roofline keys on it)
   Bracket b(m, "deer_gemm_bf16_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + out_b * M * N, st);
-  if (m->c.tower_f16) return deer_gemm_f16_nt(A, lda, 0, Wt, (int)K, bias, C, ldc, 0, (int)M, (int)N, (int)K, 1, epi, nullptr, 0, nullptr, st);
+  if (m->c.operands_f16) return deer_gemm_f16_nt(A, lda, 0, Wt, (int)K, bias, C, ldc, 0, (int)M, (int)N, (int)K, 1, epi, nullptr, 0, nullptr, st);
   return deer_gemm_bf16_nt(A, lda, 0, Wt, (int)K, bias, C, ldc, 0, (int)M, (int)N, (int)K, 1, epi, nullptr, 0, nullptr, st);
 }
 
 int gemm_splitk(deer_model* m, const void* A, const void* Wt, float* slab, long M, long N, long K, int S, void* st) {
   Bracket b(m, "deer_gemm_bf16_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + 4.0 * S * M * N, st);
-  if (m->c.tower_f16) return deer_gemm_f16_nt_splitk(A, (int)K, Wt, (int)K, slab, (int)M, (int)N, (int)K, S, 0, nullptr, st);
+  if (m->c.operands_f16) return deer_gemm_f16_nt_splitk(A, (int)K, Wt, (int)K, slab, (int)M, (int)N, (int)K, S, 0, nullptr, st);
   return deer_gemm_bf16_nt_splitk(A, (int)K, Wt, (int)K, slab, (int)M, (int)N, (int)K, S, 0, nullptr, st);
 }
 
@@ -649,7 +649,7 @@ int gemm_splitk(deer_model* m, const void* A, const void* Wt, float* slab, long 
 int vresadd(deer_model* m, float* x, const float* slab, int S, long rows, int C, const float* bias, const float* gamma, const float* beta,
             void* out_bf, float* out_f32, void* st) {
   Bracket b(m, "deer_resadd_ln", 0, 4.0 * rows * C * (S + 2) + (out_bf ? 2.0 : 0.0) * rows * C, st);
-  if (m->c.tower_f16)
+  if (m->c.operands_f16)
     return deer_resadd_ln_f16(x, slab, S, rows * C, nullptr, bias, gamma, beta, gamma ? out_bf : nullptr, gamma ? out_f32 : nullptr, nullptr,
                               (int)rows, C, kEps, nullptr, st);
   return deer_resadd_ln(x, slab, S, rows * C, nullptr, bias, gamma, beta, gamma ? out_bf : nullptr, gamma ? out_f32 : nullptr, nullptr,
@@ -658,7 +658,7 @@ int vresadd(deer_model* m, float* x, const float* slab, int S, long rows, int C,
 
 int ln_rows(deer_model* m, const float* x, const float* gamma, const float* beta, void* out_bf, long rows, int C, void* st) {
   Bracket b(m, "deer_layernorm_rows", 8.0 * rows * C, 6.0 * rows * C, st);
-  if (m->c.tower_f16) return deer_layernorm_rows_f16(x, C, 0, (int)rows, 1, gamma, beta, out_bf, nullptr, C, 0, C, kEps, st);
+  if (m->c.operands_f16) return deer_layernorm_rows_f16(x, C, 0, (int)rows, 1, gamma, beta, out_bf, nullptr, C, 0, C, kEps, st);
   return deer_layernorm_rows(x, C, 0, (int)rows, 1, gamma, beta, out_bf, nullptr, C, 0, C, kEps, st);
 }
 
@@ -680,7 +680,7 @@ int patch_embed(deer_model* m, const VisionWS& ws, void* st) {
   } else {
     {
       Bracket b(m, "deer_vit_im2col", 0, 0, st);
-      if (c.tower_f16) DEER_TRY(deer_vit_im2col_f16(img, 2, ws.n, c.image_size, c.patch_size, m->Wk<void>(ws.im2col), m->kpad, st));   // fp16 frames
+      if (c.operands_f16) DEER_TRY(deer_vit_im2col_f16(img, 2, ws.n, c.image_size, c.patch_size, m->Wk<void>(ws.im2col), m->kpad, st));   // fp16 frames
       else DEER_TRY(deer_vit_im2col(img, 1, ws.n, c.image_size, c.patch_size, m->Wk<void>(ws.im2col), m->kpad, st));
     }
     DEER_TRY(gemm(m, m->Wk<void>(ws.im2col), m->A<void>(m->conv), m->Wk<void>(ws.patch_out), (long)ws.n * P, W, m->kpad, DEER_EPI_F32, nullptr, st));
@@ -727,12 +727,12 @@ int perceiver(deer_model* m, const VisionWS& ws, void* st) {
   const long tok_bstride = m->tokens_override ? (long)P * W : (long)tok * W;
   {
     Bracket b(m, "deer_layernorm_rows", 8.0 * N * P * W, (4.0 + 2.0 * Lp) * N * P * W, st);
-    DEER_TRY((c.tower_f16 ? deer_layernorm_rows_multi_f16 : deer_layernorm_rows_multi)(tokens, W, tok_bstride, P, N, m->A<float>(PS.nm_w), m->A<float>(PS.nm_b), Lp, W,
+    DEER_TRY((c.operands_f16 ? deer_layernorm_rows_multi_f16 : deer_layernorm_rows_multi)(tokens, W, tok_bstride, P, N, m->A<float>(PS.nm_w), m->A<float>(PS.nm_b), Lp, W,
                                        m->Wk<void>(ws.p_mln), (long)N * P * W, W, (long)P * W, W, kEps, st));
   }
   {
     Bracket b(m, "deer_gemm_bf16_nt", 2.0 * Lp * N * P * 2 * inner * W, 2.0 * Lp * ((double)N * P * W + 2.0 * inner * W + (double)N * P * 2 * inner), st);
-    DEER_TRY((c.tower_f16 ? deer_gemm_f16_nt_wbatch : deer_gemm_bf16_nt_wbatch)(m->Wk<void>(ws.p_mln), W, (long)N * P * W, m->A<void>(PS.wkv_all), W, 2L * inner * W, nullptr,
+    DEER_TRY((c.operands_f16 ? deer_gemm_f16_nt_wbatch : deer_gemm_bf16_nt_wbatch)(m->Wk<void>(ws.p_mln), W, (long)N * P * W, m->A<void>(PS.wkv_all), W, 2L * inner * W, nullptr,
                                       m->Wk<void>(ws.p_mkv), 2 * inner, (long)N * P * 2 * inner, N * P, 2 * inner, W, Lp, DEER_EPI_BF16, 0,
                                       nullptr, st));
   }
@@ -745,7 +745,7 @@ int perceiver(deer_model* m, const VisionWS& ws, void* st) {
     const char* mkv = m->Wk<char>(ws.p_mkv) + (size_t)li * N * P * 2 * inner * 2;
     {
       Bracket b(m, "deer_attn_mfma_hd64", 4.0 * N * c.perc_heads * nl * (P + nl) * 64, 0, st);
-      DEER_TRY((c.tower_f16 ? deer_attn_f16_hd64_2seg : deer_attn_mfma_hd64_2seg)(qkv, mkv, mkv + (size_t)inner * 2, qkv + (size_t)inner * 2, qkv + (size_t)2 * inner * 2, m->Wk<void>(ws.p_ao), N,
+      DEER_TRY((c.operands_f16 ? deer_attn_f16_hd64_2seg : deer_attn_mfma_hd64_2seg)(qkv, mkv, mkv + (size_t)inner * 2, qkv + (size_t)inner * 2, qkv + (size_t)2 * inner * 2, m->Wk<void>(ws.p_ao), N,
                                         c.perc_heads, nl, P, nl, 3 * inner, 2 * inner, 3 * inner, inner, (long)nl * 3 * inner, (long)P * 2 * inner,
                                         (long)nl * 3 * inner, (long)nl * inner, 1.0f / sqrtf((float)c.perc_dim_head), st));
     }
@@ -777,7 +777,7 @@ int vit_blocks(deer_model* m, const VisionWS& ws, int lo, int hi, void* st) {
     DEER_TRY(gemm(m, m->Wk<void>(ws.v_ln), m->A<void>(L.wqkv), qkv, R, 3 * W, W, DEER_EPI_BF16, m->A<float>(L.bqkv), st));
     {
       Bracket b(m, "deer_attn_mfma_hd64", 4.0 * N * H * tok * tok * 64, 0, st);
-      DEER_TRY((c.tower_f16 ? deer_attn_f16_hd64 : deer_attn_mfma_hd64)(qkv, qkv + (size_t)W * 2, qkv + (size_t)2 * W * 2, m->Wk<void>(ws.v_ao), N, H, tok, tok, 3 * W, 3 * W, 3 * W, W,
+      DEER_TRY((c.operands_f16 ? deer_attn_f16_hd64 : deer_attn_mfma_hd64)(qkv, qkv + (size_t)W * 2, qkv + (size_t)2 * W * 2, m->Wk<void>(ws.v_ao), N, H, tok, tok, 3 * W, 3 * W, 3 * W, W,
                                    (long)tok * 3 * W, (long)tok * 3 * W, (long)tok * 3 * W, (long)tok * W, 0.125f, st));
     }
     DEER_TRY(gemm_splitk(m, m->Wk<void>(ws.v_ao), m->A<void>(L.wo), m->Wk<float>(ws.v_slab), R, W, W, So, st));
@@ -1495,10 +1495,10 @@ int deer_model_create(const deer_config* cfg, deer_model** out) {
   if (c.d_model % 32 || c.d_model / c.n_heads > 128 || 2 * c.perc_latents > 128) return DEER_ERR_SHAPE;
   if (c.mlp_num_hidden_layers < 0 || c.mlp_num_hidden_layers > 3 || c.lstm_num_layers < 1) return DEER_ERR_SHAPE;
   if (c.multi_step_action < 0 || c.multi_step_action > 8 || (c.layerwise_exit_eval && c.use_state)) return DEER_ERR_SHAPE;
-  if (c.tower_f16 && c.precision) return DEER_ERR_SHAPE;     // the fp32 arithmetic has no 16-bit tower
+  if (c.operands_f16 && c.precision) return DEER_ERR_SHAPE;     // the fp32 arithmetic has no 16-bit tower
   deer_model* m = new deer_model();
   m->c = c;
-  m->f16 = c.tower_f16 != 0;
+  m->f16 = c.operands_f16 != 0;
   m->wkind = c.precision ? 1 : (m->f16 ? 2 : 0);
   const int g = c.image_size / c.patch_size;
   m->P = g * g;
@@ -1602,7 +1602,7 @@ int deer_model_load_tensor(deer_model* m, const char* name, const void* src, int
     if ((s.rows & 15) || (s.cols & 31)) return DEER_ERR_SHAPE;
     const long tot = (s.rows >> 4) * (s.cols >> 5) * 64;
     const int pb = (int)std::min<long>((tot + 255) / 256, 4096);
-    if (m->c.tower_f16) {
+    if (m->c.operands_f16) {
       if (src_is_bf16) hipLaunchKernelGGL((ingest_pack_kernel<bf16_t, false, true>), dim3(pb), dim3(256), 0, st, (const bf16_t*)src, m->A<bf16_t>(s.dst[0]), (int)s.rows, s.cols);
       else hipLaunchKernelGGL((ingest_pack_kernel<float, false, true>), dim3(pb), dim3(256), 0, st, (const float*)src, m->A<bf16_t>(s.dst[0]), (int)s.rows, s.cols);
     } else if (src_is_bf16) hipLaunchKernelGGL(ingest_pack_kernel<bf16_t>, dim3(pb), dim3(256), 0, st, (const bf16_t*)src, m->A<bf16_t>(s.dst[0]), (int)s.rows, s.cols);

@@ -438,7 +438,7 @@ int deer_hip_abi_version(void);
  * every nn.Linear of the MPT blocks (mosaic_gpt_3b.py:413-417), of GatedCrossAttentionBlock (helpers.py:188,231,15-22) and of the action
  * head multiplies fp16-ROUNDED weights.  bf16-rounded weights are 2.6e-2 from that on the action at the full 3B size, fp16-rounded ones
  * 9e-4 (tools/amp_difference.py full --parts, profiles/r06_*).  Every trunk entry point above therefore has a twin that reads weights
- * packed as fp16 (deer_model_load_tensor with deer_config.tower_f16) and activation planes fp16 hi / lo on v_mfma_f32_16x16x32_f16 -
+ * packed as fp16 (deer_model_load_tensor with deer_config.operands_f16) and activation planes fp16 hi / lo on v_mfma_f32_16x16x32_f16 -
  * same arguments, same kernels, same speed (the trunk is HBM-bound; same bytes).  K / V of the gated x-attn arrive as fp16
  * (deer_gemm_f16_nt with DEER_EPI_BF16 = "the family's 16-bit format").  The head entry points take the weight kind in their
  * `w_is_f32` argument: 0 = bf16 rows, 1 = f32 rows, 2 = fp16 rows. */

@@ -32,10 +32,10 @@ typedef struct deer_config {
   int mpt7b_names;          /* 1: norm_1 / ffn.up_proj / ffn.down_proj parameter names (modeling_gpt_9b.py), 0: ln_1 / mlp.mlp_up */
   int exit_interval;
   int head_hidden, lstm_num_layers, lstm_layernorm, mlp_layernorm, mlp_num_hidden_layers, pooling_avg;
-  int n_envs;               /* environments evaluated per control step (1..8) */
-  int max_text_len;         /* longest instruction (tokens); n_envs * T must be <= 128 rows */
+  int n_envs;               /* environments evaluated per control step (1..16) */
+  int max_text_len;         /* longest instruction (tokens); n_envs * T must be <= 512 rows (128 with precision = 1) */
   int n_chains;             /* independent vision chains of the two-stream schedule (0 = default 2) */
-  int precision;            /* 0: bf16 MFMA operands in the vision tower / x-attn (the product path); 1: fp32 arithmetic -
+  int precision;            /* 0: 16-bit MFMA operands (the product path; format: operands_f16 below); 1: fp32 arithmetic -
                              * f32 activations and f32 (or bf16 hi + lo) weight copies everywhere (csrc/precise.hip; single-stream schedule;
                              * ~1/10 of the vision tower's throughput, 1.8x the arena) */
   int use_state;            /* DeterministicDecoder(use_state=True), action_head.py:524-536: the embedded robot state (workspace buffer
@@ -48,11 +48,13 @@ typedef struct deer_config {
                              * exit criterion's delta runs over all 6 A pose values (value_net.py:105-133); A <= 8 */
   int layerwise_exit_eval;  /* flamingo_mpt.py:236-244,253,450-457: per-layer heads "lm_exit_modules.j.*" / "lm_head.*" are ingested next to
                              * "extra_exit.*", each with its own LSTM state; deer_head_eval_layerwise evaluates one of them */
-  int tower_f16;            /* round 6 (precision = 0 only): 1 = the vision tower (ViT, Perceiver, media K/V projection) computes on IEEE fp16
-                             * operands with fp16 results - the reference's evaluation arithmetic (fp32 weights under fp16 autocast,
-                             * eval_utils.py:333): weights of those GEMMs are stored as fp16, the camera frames ("img") are fp16, LayerNorm /
-                             * softmax statistics and the residual stream stay f32, the media K/V leave as bf16 for the trunk's x-attn.
-                             * 0 = bf16 operands / results (a `--precision bf16` / amp_bf16 reference run). */
+  int operands_f16;         /* round 6 (precision = 0 only): the 16-bit FORMAT of the whole path.  1 = every 16-bit MFMA operand is IEEE
+                             * fp16 - weights of the vision tower / trunk / head, LayerNorm
+                             * and GEMM results of the tower, the trunk's hi + lo activation planes, media and trunk K/V, the embedding
+                             * table, the camera frames ("img") - the reference's evaluation arithmetic (fp32 weights under fp16 autocast,
+                             * eval_utils.py:333); accumulation, LayerNorm / softmax statistics, residual streams, LSTM state stay f32.
+                             * 0 = the same kernels on bf16 operands (a `--precision bf16` / amp_bf16 reference run).
+                             * Python: precision = "fp16" (default) | "bf16" | "fp32"  (deer_vla_amd/_abi.py PRECISIONS). */
 } deer_config;
 
 typedef struct deer_model deer_model;
@@ -68,7 +70,7 @@ int deer_model_bind(deer_model* m, void* arena, void* workspace);
  * "vision_encoder.visual.transformer.resblocks.3.attn.in_proj_weight", "perceiver.layers.0.0.to_kv.weight",
  * "lang_encoder.transformer.blocks.5.decoder_layer.attn.Wqkv.weight", "extra_exit.rnn.layers.0.weight_ih_l0").
  * src: DEVICE pointer, f32 (src_is_bf16 = 0) or bf16 (1), `numel` elements in the reference's layout; the model converts
- * and re-lays it out (bf16; MFMA-fragment packing for the LLM projections; conv1 reshaped + zero-padded; Perceiver
+ * and re-lays it out (rounded once to the operand format - fp16 or bf16, see operands_f16; MFMA-fragment packing for the LLM projections; conv1 reshaped + zero-padded; Perceiver
  * to_q/to_kv stacked; x-attn to_kv of all layers concatenated).  Returns DEER_ERR_SHAPE for an unknown name / wrong size. */
 int deer_model_load_tensor(deer_model* m, const char* name, const void* src, int src_is_bf16, long numel, void* stream);
 /* host only: adopt the weight arena (and the loaded state) of another model built from the same shape description with a
@@ -102,8 +104,8 @@ int deer_model_real_num_exit(const deer_model* m);
 /* ---- the three coarse operators of SURVEY.md §8b ------------------------------------------------------------------ */
 /* images: bf16 [n_images,3,S,S] (already CLIP-normalised); tokens_out: f32 [n_images,256,W] patch tokens (x[:,1:], no ln_post)
  * or NULL to leave them in the workspace only (the Perceiver reads them there). */
-int deer_vit_l14_encode(deer_model* m, const void* images_bf16, int n_images, float* tokens_out, void* stream);   /* images: f32 when precision = 1, fp16 when tower_f16 */
-/* (tower_f16: every `*_bf16` media / image argument below carries IEEE fp16 instead - the tower's 16-bit format) */
+int deer_vit_l14_encode(deer_model* m, const void* images_bf16, int n_images, float* tokens_out, void* stream);   /* images: f32 when precision = 1, fp16 when operands_f16 */
+/* (operands_f16: every `*_bf16` media / image argument below carries IEEE fp16 instead - the model's 16-bit format) */
 /* tokens: f32 [n_images,256,W] or NULL (= the workspace tokens of the last deer_vit_l14_encode); media_bf16_out / media_f32_out:
  * [n_images*64, W] latents of every image in image order (rgb, gripper per environment = the post-fusion concat of
  * flamingo_mpt.py:661) or NULL to leave them in the workspace. */

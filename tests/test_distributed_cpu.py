@@ -147,7 +147,7 @@ def test_bench_with_eight_ranks_through_torch_distributed_run():
         env.update(DEER_BENCH_SINGLE_DEVICE="1", DEER_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port",
            str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2", "--workload", "tiny", "--calib-steps", "24",
-           "--burn-in", "0", "--on-policy-steps", "0", "--scripted-steps", "0", "--latency-reps", "0", "--no-cpu-baseline", "--batched-envs", "0",
+           "--burn-in", "0", "--on-policy-steps", "6", "--scripted-steps", "0", "--latency-reps", "0", "--no-cpu-baseline", "--batched-envs", "0",
            "--surface-steps", "0", "--no-roofline"]
     p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -160,6 +160,9 @@ def test_bench_with_eight_ranks_through_torch_distributed_run():
     pr = out["per_rank_steps_per_s"]                              # stragglers are visible in the line
     assert 0 < pr["min"] <= pr["max"] and pr["slowest_over_fastest_time"] >= 1.0 and abs(pr["min"] * 8 - out["value"]) < 0.02 * out["value"] + 1
     assert abs(out["config"]["per_gpu_steps_per_s"] * 8 - out["value"]) < 0.05 * out["value"]
+    op = out["on_policy"]                                         # the real criterion over all ranks too
+    assert op["steps"] == 6 and op["value"] > 0 and 0 < op["per_rank_steps_per_s"]["min"] <= op["per_rank_steps_per_s"]["max"]
+    assert abs(op["per_rank_steps_per_s"]["min"] * 8 - op["value"]) < 0.02 * op["value"] + 1 and 1.0 <= op["avg_exit_layer"] <= 12.0
     from deer_vla_amd import distributed as dd2
     seqs = list(range(224))
     assert [len(dd2.shard_sequences(seqs, r, 8)) for r in range(8)] == [28] * 8 and dd2.shard_sequences(seqs, 7, 8)[-1] == 223
