@@ -82,12 +82,19 @@ def golden():
     return np.load(GOLD)
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
 @pytest.mark.parametrize("tag", ["b08", "b10", "s08"])
-def test_full_size_360_step_episode_matches_oracle_trace(golden, tag):
-    rep = replay_episode(golden, tag)
-    assert rep["worst_action_err"] < ACTION_TOL, rep
+def test_full_size_360_step_episode_matches_oracle_trace(golden, tag, precision):
+    """The product arithmetic (fp16, the default) and the bf16 instantiation of the same kernels against the f32 oracle trace: the margin
+    rule for both; for fp16 also the figures round 6 measured (2.9e-4 on the action, NO flip in the 36 knife-edge steps of the three
+    episodes) with a little room - a knife-edge step is decided by a delta within 1e-2 of its threshold, one flip there is not an error,
+    a handful would say the arithmetic moved."""
+    rep = replay_episode(golden, tag, precision=precision)
+    assert rep["worst_action_err"] < (1e-3 if precision == "fp16" else ACTION_TOL), rep
     assert not rep["mismatches_outside_band"], rep["mismatches_outside_band"]
     assert len(rep["exit_hist"]) > 1 or tag == "s08", rep["exit_hist"]
+    if precision == "fp16":
+        assert len(rep["knife_edge_flips"]) <= 1, rep["knife_edge_flips"]
 
 
 @pytest.mark.parametrize("tag", ["b08", "b10", "s08"])

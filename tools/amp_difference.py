@@ -3,8 +3,9 @@ arithmetic, or a written decision that bf16 stands in for amp with the measured 
 
 The README's evaluation commands run ``--precision fp32 --amp 1`` (README.md:161-167; eval_utils.py:333:
 ``torch.cuda.amp.autocast(enabled=self.amp)``): f32 weights, every Linear / matmul in fp16 under autocast, LayerNorm / softmax in f32.
-The engine accepts the harness's ``amp`` / ``cast_dtype`` arguments and computes in its own arithmetic: bf16 MFMA operands
-with an f32 residual stream in the vision tower, bf16 weights x (bf16 hi + lo) activations in the trunk, f32 LSTM state.
+Up to round 5 the engine computed on bf16 operands whatever the harness's ``amp`` / ``cast_dtype`` said; this tool's result (the
+bf16 rounding of the WEIGHTS is 2e-2 ... 3e-2 on the action, the reference's fp16 autocast 4e-3) is why round 6 made IEEE fp16 the
+default operand format (``--parts`` splits the weight rounding by tower / trunk / head).
 
 CPU-only (runs in the build container): the oracle's restatement of the step (oracle/deer_oracle.py, pinned to the reference) on
 UNROUNDED f32 weights in four arithmetics - f32; torch.autocast(cpu, float16) = the reference's amp; torch.autocast(cpu, bfloat16) = the
