@@ -21,7 +21,7 @@ def pytest_configure(config):
 # reference-golden / oracle parity tests of the whole step run first, the per-kernel shape sweeps and the long stress runs last)
 _ORDER = ["test_abi_cpu", "test_oracle_golden", "test_host_logic", "test_metrics_golden", "test_variant_parity", "test_dropin_surface",
           "test_engine_parity", "test_coarse_ops", "test_precision_fp32", "test_checkpoint_loader", "test_rollout", "test_preprocess",
-          "test_episode_parity", "test_batch_parity", "test_hard_inputs", "test_distributed_cpu", "test_hip_ops", "test_schedule_stress"]
+          "test_config_fuzz", "test_episode_parity", "test_batch_parity", "test_hard_inputs", "test_distributed_cpu", "test_hip_ops", "test_schedule_stress"]
 
 
 def pytest_collection_modifyitems(config, items):

@@ -1,0 +1,166 @@
+"""Combination fuzz (round 6): every variant the engine implements has its own reference-import golden, but each golden exercises ONE
+variant at a time.  Here seeded random COMBINATIONS of them - head shape (LayerNorm / plain LSTM and MLP, 2 / 3 hidden layers, max / avg
+pool), ``multi_step_action``, ``layerwise_exit_eval``, ``sep_resampler``, ``use_state``, exit interval and depth, the criterion's
+``threshold_type``, env-batch size, instruction lengths (mixed inside a batch, 3 .. 32 tokens), the arithmetic - run through the drop-in
+surface (``MPTFlamingo.forward`` for one environment, ``step_env_batch`` for a batch, the product's ``ExitController`` /
+``ActionValueNet``) against the fp32 CPU oracle run once per environment with the same arguments (``OracleDeer.forward``,
+``OracleExitController``), on static exits and on a dynamic episode with LSTM carry.  Rules as everywhere else in this suite: actions within
+1e-2 (1e-3 for precision="fp32"), exit layers identical wherever the oracle's decision is not knife-edge (|delta - thr| > max(1e-2 thr, 3e-4)); an
+environment whose knife-edge decision flips is left out from that step on."""
+import os
+import random
+
+import pytest
+import torch
+
+from deer_vla_amd import synthetic as syn
+from deer_vla_amd.config import deer_tiny
+from oracle import deer_oracle as orc
+
+pytestmark = pytest.mark.gpu
+BAND = 1e-2
+N_CASES = int(os.environ.get("DEER_FUZZ_CASES", "40"))            # a hunt: DEER_FUZZ_CASES=400 (about 1 s per case)
+
+
+def draw(seed):
+    r = random.Random(9000 + seed)
+    kw = dict(lstm_layernorm=r.random() < 0.6, mlp_layernorm=r.random() < 0.6, mlp_num_hidden_layers=r.choice([2, 2, 3]),
+              pooling=r.choice(["max", "max", "avg"]), multi_step_action=r.choice([1, 1, 2, 3]), layerwise_exit_eval=r.random() < 0.3,
+              sep_resampler=r.random() < 0.3, exit_interval=r.choice([2, 2, 3]), early_exit_layer=r.choice([5, 7]))
+    kw["use_state"] = (not kw["layerwise_exit_eval"]) and r.random() < 0.12
+    B = 1 if kw["use_state"] else r.choice([1, 1, 2, 3, 5])
+    precision = r.choice(["fp16", "fp16", "fp16", "bf16", "fp32"]) if B == 1 else r.choice(["fp16", "fp16", "bf16"])
+    lens = [r.randint(3, 32) for _ in range(B)]
+    if B * max(lens) > 128:                                       # row budget of a tiny batch is not the point here
+        lens = [min(t, 128 // B) for t in lens]
+    return kw, B, precision, lens, r.choice(["L2", "L2", "mean", "max", "cosine"]), r.randint(0, 10 ** 6)
+
+
+class RecVN(orc.OracleValueNet):
+    def __call__(self, feats, i=None, mode="infer", rand_layer_feat=None):
+        v = super().__call__(feats, i, mode, rand_layer_feat)
+        self.rec.append((i, float(v)))
+        return v
+
+
+def gap_threshold(vals):
+    v = sorted(vals)
+    a, b = int(len(v) * 0.2), max(int(len(v) * 0.8), int(len(v) * 0.2) + 2)
+    b = min(b, len(v))
+    gaps = [(v[i + 1] - v[i], i) for i in range(a, b - 1)]
+    if not gaps:
+        return 0.5 * (v[0] + v[-1])
+    _, i = max(gaps)
+    return 0.5 * (v[i] + v[i + 1])
+
+
+def oracle_dynamic(cfg, sd, inputs, thr, ttype, abs_band=3e-4):
+    """one environment's dynamic episode on the oracle: [(exit layer, pose, gripper, margin of the tightest check in bands)]"""
+    model = orc.OracleDeer(sd, cfg)
+    model.set_all_exit_window_size(1)
+    vn = RecVN(cfg.exit_ids(), model.extra_exit, cfg.exit_interval, 1, ttype)
+    vn.rec = []
+    ctl = orc.OracleExitController(vn, cfg.exit_ids(), steps_per_stage=1, max_layer=12)
+    ctl._set_threshold_value(thr)
+    tb = dict(zip(cfg.exit_ids(), thr))
+    out = []
+    for s, (rgb, grip, ids, mask) in enumerate(inputs):
+        ctl.set_timestep(s)
+        n0 = len(vn.rec)
+        o = model.forward(rgb, ids, mask, grip, dynamic_early_exit=True, exit_controller=ctl)
+        # margin of the tightest check of the step, in units of its knife-edge band: a check is knife-edge if |delta - thr| is within 1e-2
+        # of the threshold OR within the absolute error a 16-bit action can put on a delta (cosine distances sit at 1e-4: a relative band
+        # alone would call a 2e-5 gap "safe")
+        m = [abs(v - tb[i]) / max(BAND * abs(tb[i]), abs_band) for (i, v) in vn.rec[n0:] if tb[i] < 1e4]
+        out.append((o["exit_layer"], o["logits"][0].reshape(-1), o["logits"][1].reshape(-1), min(m) if m else float("inf")))
+    return out, vn.rec
+
+
+def batch_tensors(env_inputs, s, B):
+    rgb = torch.stack([env_inputs[e][s][0] for e in range(B)])
+    grip = torch.stack([env_inputs[e][s][1] for e in range(B)])
+    T = max(env_inputs[e][s][2].shape[1] for e in range(B))
+    ids = torch.zeros(B, T, dtype=torch.long)
+    mask = torch.zeros(B, T, dtype=torch.bool)
+    for e in range(B):
+        te = env_inputs[e][s][2].shape[1]
+        ids[e, :te], mask[e, :te] = env_inputs[e][s][2][0], True
+    return rgb, grip, ids, mask
+
+
+@pytest.mark.parametrize("case", range(N_CASES))
+def test_random_combination_of_variants_matches_the_oracle(case):
+    from deer_vla_amd import factory
+    from deer_vla_amd.value_net import ActionValueNet, ExitController
+    kw, B, precision, lens, ttype, wseed = draw(case)
+    cfg = deer_tiny(**kw)
+    A = cfg.multi_step_action
+    tol = 1e-2 if precision != "fp32" else 1e-3
+    sd = syn.make_synthetic_state(cfg, wseed % 1000, bf16_round=True)
+    n_steps = 8
+    env_inputs = [[syn.synthetic_step_inputs(cfg, s, rank=e, text_len=lens[e], text_seed=wseed % 97 + e) for s in range(n_steps)] for e in range(B)]
+    g = torch.Generator().manual_seed(wseed)
+    state = torch.randn(n_steps, 1, 1, 1, 15, generator=g)
+    state[..., -1] = torch.where(torch.rand(n_steps, 1, 1, 1, generator=g) < 0.5, -1.0, 1.0)
+    model, _, _ = factory.create_model_and_transforms(
+        "ViT-L-14", "openai", "", "", cross_attn_every_n_layers=1, window_size=12, use_gripper=True, fusion_mode="post", llm_name="mpt_dolly_3b",
+        state_dict=sd, cfg=cfg, use_state=cfg.use_state, sep_resampler=cfg.sep_resampler, multi_step_action=A,
+        layerwise_exit_eval=cfg.layerwise_exit_eval, multi_exit=cfg.layerwise_exit_eval, n_envs=B, precision=precision)
+    exit_ids = cfg.exit_ids()
+    desc = (case, kw, B, precision, lens, ttype)
+
+    # ---- static exits (one environment: the reference's forward; LSTM carried over the steps) ----
+    if B == 1:
+        omodel = orc.OracleDeer(sd, cfg)
+        omodel.set_all_exit_window_size(1)
+        rs = random.Random(wseed)
+        model.clear_all_exit_memory()
+        for s in range(4):
+            eid = rs.choice(exit_ids)
+            rgb, grip, ids, mask = env_inputs[0][s]
+            st = state[s] if cfg.use_state else None
+            ref = omodel.forward(rgb, ids, mask, grip, state_tensor=st, exit_id=eid)
+            o = model(vision_x=rgb.cuda(), lang_x=ids.cuda(), attention_mask=mask.cuda(), vision_gripper=grip.cuda(),
+                      state_tensor=None if st is None else st.cuda(), return_feature=True, deterministic=True, exit_id=eid)
+            assert tuple(o.logits[0].shape) == (1, 1, 6 * A) and tuple(o.logits[1].shape) == (1, 1, A), desc
+            assert float((o.logits[0].cpu().reshape(-1) - ref["logits"][0].reshape(-1)).abs().max()) < tol, (desc, s, eid)
+            assert float((o.logits[1].cpu().reshape(-1) - ref["logits"][1].reshape(-1)).abs().max()) < tol, (desc, s, eid)
+    if cfg.use_state:
+        return                                                    # the reference's dynamic exit raises with use_state (value_net.py:122-129)
+
+    # ---- thresholds in the widest gaps of environment 0's never-exit deltas; then every environment's own oracle episode ----
+    real = orc.OracleExitController(None, exit_ids, max_layer=12).real_num_exit
+    _, rec = oracle_dynamic(cfg, sd, env_inputs[0], [-1.0 if ttype != "cosine" else -3.0] * real, ttype)
+    thr = [gap_threshold([v for (i, v) in rec if i == e]) for e in exit_ids[:real]]
+    thr[-1] = 1e5
+    refs = [oracle_dynamic(cfg, sd, env_inputs[e], thr, ttype, 3e-4 if precision != "fp32" else 2e-5)[0] for e in range(B)]
+
+    vn = ActionValueNet(model.get_all_exit_idx(), model.extra_exit, cfg.exit_interval, cfg.window_size, ttype)
+    ctl = ExitController(vn, model.get_all_exit_idx(), steps_per_stage=1, leq=True, exit_dist="exp", max_layer=12)
+    ctl._set_threshold_value(thr)
+    model.clear_all_exit_memory()
+    alive, compared, seen = [True] * B, 0, set()
+    for s in range(n_steps):
+        ctl.set_timestep(s)
+        if B == 1:
+            rgb, grip, ids, mask = env_inputs[0][s]
+            o = model(vision_x=rgb.cuda(), lang_x=ids.cuda(), attention_mask=mask.cuda(), vision_gripper=grip.cuda(), return_feature=True,
+                      deterministic=True, exit_id=None, dynamic_early_exit=True, exit_controller=ctl)
+            got = [(o.exit_layer, o.logits[0].cpu().reshape(-1), o.logits[1].cpu().reshape(-1))]
+        else:
+            rgb, grip, ids, mask = batch_tensors(env_inputs, s, B)
+            pose, gr, exits = model.step_env_batch(rgb.cuda(), ids.cuda(), mask.cuda(), grip.cuda(), exit_controller=ctl)
+            got = [(exits[e], pose[e].cpu().reshape(-1), gr[e].cpu().reshape(-1)) for e in range(B)]
+        for e in range(B):
+            if not alive[e]:
+                continue
+            ex, p_ref, g_ref, margin = refs[e][s]
+            if got[e][0] != ex:
+                assert margin <= 1.0, ("exit mismatch outside the knife-edge band", desc, e, s, got[e][0], ex, margin)
+                alive[e] = False
+                continue
+            assert float((got[e][1] - p_ref).abs().max()) < tol, (desc, e, s, ex)
+            assert float((got[e][2] - g_ref).abs().max()) < tol, (desc, e, s, ex)
+            compared += 1
+            seen.add(ex)
+    assert compared >= 0.6 * B * n_steps, (desc, compared)
