@@ -172,3 +172,87 @@ def test_random_combination_of_variants_matches_the_oracle(case):
             compared += 1
             seen.add(ex)
     assert compared >= 0.6 * B * n_steps or (flips and compared >= 1), (desc, compared, flips)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the calibration call (value_net.py:333-386): random window batches
+N_WINDOW_CASES = int(os.environ.get("DEER_FUZZ_WINDOW_CASES", "16"))
+
+
+def draw_window(seed):
+    r = random.Random(7000 + seed)
+    kw = dict(lstm_layernorm=r.random() < 0.6, mlp_layernorm=r.random() < 0.6, mlp_num_hidden_layers=r.choice([2, 2, 3]),
+              pooling=r.choice(["max", "max", "avg"]), multi_step_action=r.choice([1, 1, 2, 3]), exit_interval=r.choice([2, 2, 3]),
+              early_exit_layer=r.choice([5, 7]), sep_resampler=r.random() < 0.25)
+    W, bs = r.choice([2, 3, 4, 6, 12]), r.choice([1, 1, 2, 3])
+    if bs * W > 24:
+        bs = max(1, 24 // W)
+    precision = r.choice(["fp16", "fp16", "fp16", "bf16", "fp32"])
+    tmax = 128 // (bs * W) if precision == "fp32" else 24                 # the fp32 arithmetic keeps 128 trunk rows
+    lens = [r.randint(3, max(3, min(24, tmax))) for _ in range(bs)]
+    return kw, W, bs, precision, lens, r.choice(["L2", "L2", "mean", "max", "cosine"]), r.randint(0, 10 ** 6)
+
+
+@pytest.mark.parametrize("case", range(N_WINDOW_CASES))
+def test_random_window_batch_calibration_call_matches_the_oracle(case):
+    """``generate_action_values`` (value_net.py:333-386) on random window batches: bs windows of W frames, every window with its own
+    instruction right-padded to the longest (pad rows are queries like any other and are pooled by the head, action_head.py:519-520),
+    random history layers per (window, step), random head shape / criterion / arithmetic: every layer's hidden state at every row,
+    extra_exit over the history, and the calibration deltas against the oracle's restatement of the same call."""
+    from deer_vla_amd.flamingo_mpt import MPTFlamingo
+    kw, W, bs, precision, lens, ttype, wseed = draw_window(case)
+    cfg = deer_tiny(window_size=W, **kw)
+    A = cfg.multi_step_action
+    sd = syn.make_synthetic_state(cfg, wseed % 1000, bf16_round=True)
+    desc = (case, kw, W, bs, precision, lens, ttype)
+    T = max(lens)
+    exit_ids = cfg.exit_ids()
+    S = cfg.image_size
+    frames = [[syn.synthetic_step_inputs(cfg, 13 * b + t, rank=wseed % 7, text_len=lens[b], text_seed=wseed % 89 + b) for t in range(W)] for b in range(bs)]
+    ids = torch.full((bs, T), 1, dtype=torch.long)
+    mask = torch.zeros(bs, T, dtype=torch.bool)
+    for b in range(bs):
+        ids[b, :lens[b]], mask[b, :lens[b]] = frames[b][0][2][0], True
+    g = torch.Generator().manual_seed(wseed)
+    rl = torch.tensor([[exit_ids[int(i)] for i in torch.randint(0, len(exit_ids), (W,), generator=g)] for _ in range(bs)])
+    # oracle: every frame through the static forward with the PADDED instruction of its window
+    omodel = orc.OracleDeer(sd, cfg)
+    omodel.set_all_exit_window_size(1)
+    ref = []
+    for b in range(bs):
+        for t in range(W):
+            h = omodel.forward(frames[b][t][0], ids[b:b + 1], mask[b:b + 1], frames[b][t][1], exit_id=cfg.n_layers - 1)["hidden_states"]
+            ref.append(torch.stack([x[0] for x in h]))                         # (L, T, d)
+        omodel.clear_all_exit_memory()
+    ref = torch.stack(ref, dim=1)                                              # (L, bs*W, T, d)
+    model = MPTFlamingo(cfg, sd, window_size=W, precision=precision)
+    vx = torch.stack([f[0].reshape(1, 1, 3, S, S) for fr in frames for f in fr])
+    vg = torch.stack([f[1].reshape(1, 1, 3, S, S) for fr in frames for f in fr])
+    input_ids = ids.unsqueeze(1).repeat(1, W, 1).flatten(0, 1)
+    attention_mask = mask.unsqueeze(1).repeat(1, W, 1).flatten(0, 1)
+    out, exit_outputs, extra, rand_feat, rand_idx = model._forward_window(vx, input_ids, attention_mask, vg, with_gripper_logits=True, rand_layers=rl)
+    hid = torch.stack(out.hidden_states).cpu()
+    rel = {"fp16": 1e-2, "bf16": 2.5e-2, "fp32": 1e-4}[precision]
+    assert hid.shape == ref.shape and float((hid - ref).norm() / ref.norm()) < rel, (desc, float((hid - ref).norm() / ref.norm()))
+    pad = ~attention_mask
+    if bool(pad.any()):
+        assert float((hid[:, pad] - ref[:, pad]).norm() / ref[:, pad].norm()) < 2 * rel, desc
+    tol = {"fp16": 1e-2, "bf16": 2.5e-2, "fp32": 1e-3}[precision]
+    head = orc.OracleHead(sd, cfg, "extra_exit.")
+    head.window_size = W
+    rf = torch.stack([ref[int(rl[b, t]), b * W + t] for b in range(bs) for t in range(W)])      # (bs*W, T, d)
+    a_ref, g_ref = head(rf)
+    assert tuple(extra[0].shape) == (bs, W, 6 * A), desc
+    assert float((extra[0].cpu() - a_ref.reshape(bs, W, 6 * A)).abs().max()) < tol, desc
+    assert float((extra[1][0].cpu().reshape(-1) - g_ref.reshape(-1)).abs().max()) < tol, desc
+    if W < 4:
+        return                                                   # generate mode needs window_size // 2 - 1 >= 1 steps of history
+    eng = model.engine
+    eng.configure_exit(exit_ids, 12, 1)
+    vals = eng.generate_values(hid.permute(1, 0, 2, 3).reshape(bs, W, cfg.n_layers, T, cfg.d_model).to(eng.dev), rl, ttype)
+    vn = orc.OracleValueNet(exit_ids, head, cfg.exit_interval, W, ttype)
+    vref = vn(tuple(ref[l] for l in range(cfg.n_layers)), mode="generate", rand_layer_feat=rf)
+    assert vals.shape == vref.shape, (desc, vals.shape, vref.shape)
+    err = (vals.cpu() - vref).abs()
+    lim = torch.maximum(0.08 * vref.abs(), torch.full_like(vref, {"fp16": 5e-3, "bf16": 1.2e-2, "fp32": 1e-4}[precision]))
+    assert bool((err <= lim).all()), (desc, float(err.max()), vals, vref)
