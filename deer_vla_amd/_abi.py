@@ -194,7 +194,7 @@ class DeerConfigC(ctypes.Structure):
         "mpt7b_names", "exit_interval",
         "head_hidden", "lstm_num_layers", "lstm_layernorm", "mlp_layernorm", "mlp_num_hidden_layers", "pooling_avg",
         "n_envs", "max_text_len", "n_chains", "precision", "use_state", "sep_resampler", "multi_step_action", "layerwise_exit_eval",
-        "operands_f16")]
+        "operands_f16", "fusion_pre")]
 
 
 # precision of an engine -> (deer_config.precision, deer_config.operands_f16):
@@ -243,6 +243,7 @@ def config_to_c(cfg, n_envs: int, max_text_len: int, n_chains: int = 0, precisio
     c.sep_resampler = 1 if getattr(cfg, "sep_resampler", False) else 0
     c.multi_step_action = int(getattr(cfg, "multi_step_action", 1))
     c.layerwise_exit_eval = 1 if getattr(cfg, "layerwise_exit_eval", False) else 0
+    c.fusion_pre = 1 if getattr(cfg, "fusion_mode", "post") == "pre" else 0
     return c
 
 

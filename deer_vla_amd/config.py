@@ -60,6 +60,9 @@ class DeerConfig:
     # ---- harness ablations / checkpoint-name variants (round 5) ---------------------------------------------------------------------
     multi_step_action: int = 1      # the heads emit 6 * A pose values and A gripper values per call (action_head.py:458,472-473; "Nstep" in a
                                     # checkpoint name, eval_calvin.py:384-387); ModelWrapper executes the first multi_execution of them
+    fusion_mode: str = "post"       # "post" (released checkpoints): one PerceiverResampler call per camera, 2 x perc_latents media tokens
+                                    # (flamingo_mpt.py:609-668); "pre" (round 6): both cameras' patch tokens through ONE call, perc_latents
+                                    # media tokens (flamingo_mpt.py:585-607)
     layerwise_exit_eval: bool = False   # the action of exit layer k comes from that layer's OWN head lm_exits[k] / lm_head (flamingo_mpt.py:253-261,
                                         # 450-457; eval_calvin.py:330,530,539) instead of extra_exit; the exit DECISION stays with extra_exit
 
@@ -92,8 +95,8 @@ class DeerConfig:
 
     @property
     def n_media(self) -> int:
-        """Media tokens seen by the gated x-attn: rgb + gripper latents (flamingo_mpt.py:661)."""
-        return 2 * self.perc_latents
+        """Media tokens seen by the gated x-attn: rgb + gripper latents (flamingo_mpt.py:661); one set of latents with pre fusion (:602)."""
+        return self.perc_latents if self.fusion_mode == "pre" else 2 * self.perc_latents
 
     @property
     def mlp_hidden_dims(self) -> List[int]:

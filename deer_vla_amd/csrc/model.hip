@@ -164,6 +164,8 @@ struct deer_model {
   bool f16 = false;                 // every 16-bit operand of the product arithmetic in IEEE fp16 (deer_config.operands_f16)
   // derived
   int P, tok, W, kpad, nl, p_inner, Lp, d, xinner, n_xattn, H, Lh, B, N, n_fc;
+  bool fuse_pre = false;            // deer_config.fusion_pre: ONE Perceiver call per environment over both cameras' patch tokens (flamingo_mpt.py:585-607)
+  int n_media = 0;                  // media tokens per environment seen by the gated x-attn: 2 nl (post fusion) or nl (pre fusion)
   int fc_dims[3];
   // arena
   Layout al;
@@ -535,6 +537,7 @@ void build_workspace(deer_model* m) {
   if (const char* e = getenv("DEER_CHAINS")) n_ch = atoi(e);
   n_ch = std::max(1, std::min(N, n_ch));
   if (c.sep_resampler) n_ch = 2;                       // camera-major frames: chain 0 = every env's rgb frame, chain 1 = the gripper frames
+  if (c.fusion_pre) n_ch = 1;                          // the Perceiver joins the two cameras of an environment: one chain holds both
   const int per = (N + n_ch - 1) / n_ch;
   for (int ch = 0; ch < n_ch; ++ch) {
     const int lo = ch * per, hi = std::min(N, (ch + 1) * per);
@@ -714,7 +717,11 @@ int perceiver(deer_model* m, const VisionWS& ws, void* st) {
   const PercSet& PS = m->ps[ws.cam];
   void* out_bf = ws.out_bf != SIZE_MAX ? m->Wk<void>(ws.out_bf) : m->Wk<void>(ws.vis_x);
   float* out_f32 = ws.out_f32 != SIZE_MAX ? m->Wk<float>(ws.out_f32) : m->Wk<float>(ws.vis_x_f32);
-  const int P = m->P, W = m->W, tok = m->tok, nl = m->nl, inner = m->p_inner, Lp = m->Lp, N = ws.n;
+  const int P = m->P, W = m->W, tok = m->tok, nl = m->nl, inner = m->p_inner, Lp = m->Lp;
+  // pre fusion (flamingo_mpt.py:598-602): the patch tokens of an environment's two frames are ONE media sequence of 2 P tokens for ONE set
+  // of latents.  The media side below works on frames (its LayerNorm / K|V rows are written contiguously: [frame][P] = [env][2 P]); the
+  // latent side on `N` latent sets attending `PM` media tokens each.
+  const int NF = ws.n, N = m->fuse_pre ? ws.n / 2 : ws.n, PM = m->fuse_pre ? 2 * P : P;
   // Media side once for all layers: one LayerNorm pass with every layer's norm_media affine, one batched GEMM with every layer's
   // to_kv.  Per layer only the 64 latents move: q|k|v projection, attention over [media K/V ; latent K/V] (two segments,
   // helpers.py:51 without the concat), to_out and the FF - each residual projection split-K, closed by the reducer that also
@@ -726,14 +733,14 @@ int perceiver(deer_model* m, const VisionWS& ws, void* st) {
   const float* tokens = m->tokens_override ? m->tokens_override + (size_t)ws.first * P * W : m->Wk<float>(ws.vx) + W;   // skip the cls row
   const long tok_bstride = m->tokens_override ? (long)P * W : (long)tok * W;
   {
-    Bracket b(m, "deer_layernorm_rows", 8.0 * N * P * W, (4.0 + 2.0 * Lp) * N * P * W, st);
-    DEER_TRY((c.operands_f16 ? deer_layernorm_rows_multi_f16 : deer_layernorm_rows_multi)(tokens, W, tok_bstride, P, N, m->A<float>(PS.nm_w), m->A<float>(PS.nm_b), Lp, W,
-                                       m->Wk<void>(ws.p_mln), (long)N * P * W, W, (long)P * W, W, kEps, st));
+    Bracket b(m, "deer_layernorm_rows", 8.0 * NF * P * W, (4.0 + 2.0 * Lp) * NF * P * W, st);
+    DEER_TRY((c.operands_f16 ? deer_layernorm_rows_multi_f16 : deer_layernorm_rows_multi)(tokens, W, tok_bstride, P, NF, m->A<float>(PS.nm_w), m->A<float>(PS.nm_b), Lp, W,
+                                       m->Wk<void>(ws.p_mln), (long)NF * P * W, W, (long)P * W, W, kEps, st));
   }
   {
-    Bracket b(m, "deer_gemm_bf16_nt", 2.0 * Lp * N * P * 2 * inner * W, 2.0 * Lp * ((double)N * P * W + 2.0 * inner * W + (double)N * P * 2 * inner), st);
-    DEER_TRY((c.operands_f16 ? deer_gemm_f16_nt_wbatch : deer_gemm_bf16_nt_wbatch)(m->Wk<void>(ws.p_mln), W, (long)N * P * W, m->A<void>(PS.wkv_all), W, 2L * inner * W, nullptr,
-                                      m->Wk<void>(ws.p_mkv), 2 * inner, (long)N * P * 2 * inner, N * P, 2 * inner, W, Lp, DEER_EPI_BF16, 0,
+    Bracket b(m, "deer_gemm_bf16_nt", 2.0 * Lp * NF * P * 2 * inner * W, 2.0 * Lp * ((double)NF * P * W + 2.0 * inner * W + (double)NF * P * 2 * inner), st);
+    DEER_TRY((c.operands_f16 ? deer_gemm_f16_nt_wbatch : deer_gemm_bf16_nt_wbatch)(m->Wk<void>(ws.p_mln), W, (long)NF * P * W, m->A<void>(PS.wkv_all), W, 2L * inner * W, nullptr,
+                                      m->Wk<void>(ws.p_mkv), 2 * inner, (long)NF * P * 2 * inner, NF * P, 2 * inner, W, Lp, DEER_EPI_BF16, 0,
                                       nullptr, st));
   }
   DEER_TRY(ln_rows(m, m->Wk<float>(ws.p_lat), m->A<float>(PS.L[0].nlw), m->A<float>(PS.L[0].nlb), m->Wk<void>(ws.p_latln), (long)N * nl, W, st));
@@ -742,11 +749,11 @@ int perceiver(deer_model* m, const VisionWS& ws, void* st) {
   for (int li = 0; li < Lp; ++li) {
     const PercLayerW& L = PS.L[li];
     DEER_TRY(gemm(m, m->Wk<void>(ws.p_latln), m->A<void>(L.wqkv), qkv, (long)N * nl, 3 * inner, W, DEER_EPI_BF16, nullptr, st));
-    const char* mkv = m->Wk<char>(ws.p_mkv) + (size_t)li * N * P * 2 * inner * 2;
+    const char* mkv = m->Wk<char>(ws.p_mkv) + (size_t)li * NF * P * 2 * inner * 2;
     {
-      Bracket b(m, "deer_attn_mfma_hd64", 4.0 * N * c.perc_heads * nl * (P + nl) * 64, 0, st);
+      Bracket b(m, "deer_attn_mfma_hd64", 4.0 * N * c.perc_heads * nl * (PM + nl) * 64, 0, st);
       DEER_TRY((c.operands_f16 ? deer_attn_f16_hd64_2seg : deer_attn_mfma_hd64_2seg)(qkv, mkv, mkv + (size_t)inner * 2, qkv + (size_t)inner * 2, qkv + (size_t)2 * inner * 2, m->Wk<void>(ws.p_ao), N,
-                                        c.perc_heads, nl, P, nl, 3 * inner, 2 * inner, 3 * inner, inner, (long)nl * 3 * inner, (long)P * 2 * inner,
+                                        c.perc_heads, nl, PM, nl, 3 * inner, 2 * inner, 3 * inner, inner, (long)nl * 3 * inner, (long)PM * 2 * inner,
                                         (long)nl * 3 * inner, (long)nl * inner, 1.0f / sqrtf((float)c.perc_dim_head), st));
     }
     DEER_TRY(gemm_splitk(m, m->Wk<void>(ws.p_ao), m->A<void>(L.wo), m->Wk<float>(ws.v_slab), (long)N * nl, W, inner, Pa, st));
@@ -843,8 +850,9 @@ int perceiver_f32(deer_model* m, const VisionWS& ws, void* st) {
   const PercSet& PS = m->ps[ws.cam];
   void* out_bf = ws.out_bf != SIZE_MAX ? m->Wk<void>(ws.out_bf) : m->Wk<void>(ws.vis_x);
   float* out_f32 = ws.out_f32 != SIZE_MAX ? m->Wk<float>(ws.out_f32) : m->Wk<float>(ws.vis_x_f32);
-  const int P = m->P, W = m->W, tok = m->tok, nl = m->nl, inner = m->p_inner, Lp = m->Lp, N = ws.n;
-  const long NL = (long)N * nl, NP = (long)N * P, ffw = (long)c.perc_ff_mult * W;
+  const int P = m->P, W = m->W, tok = m->tok, nl = m->nl, inner = m->p_inner, Lp = m->Lp;
+  const int NF = ws.n, N = m->fuse_pre ? ws.n / 2 : ws.n, PM = m->fuse_pre ? 2 * P : P;      // pre fusion: see perceiver()
+  const long NL = (long)N * nl, NP = (long)NF * P, ffw = (long)c.perc_ff_mult * W;
   {
     Bracket b(m, "deer_broadcast_rows", 0, 0, st);
     DEER_TRY(deer_broadcast_rows(m->A<float>(PS.latents), m->Wk<float>(ws.p_lat), (long)nl * W, N, st));
@@ -864,16 +872,16 @@ int perceiver_f32(deer_model* m, const VisionWS& ws, void* st) {
     const PercLayerW& L = PS.L[li];
     {   // norm_media of this layer on the (layer-invariant) media tokens, then its to_kv (helpers.py:47-56)
       Bracket b(m, "deer_layernorm_rows", 8.0 * NP * W, 8.0 * NP * W, st);
-      DEER_TRY(deer_layernorm_rows(tokens, W, tok_bstride, P, N, m->A<float>(PS.nm_w) + (size_t)li * W, m->A<float>(PS.nm_b) + (size_t)li * W,
+      DEER_TRY(deer_layernorm_rows(tokens, W, tok_bstride, P, NF, m->A<float>(PS.nm_w) + (size_t)li * W, m->A<float>(PS.nm_b) + (size_t)li * W,
                                    nullptr, mln, W, (long)P * W, W, kEps, st));
     }
     DEER_TRY(gemmf(m, mln, W, m->A<float>(PS.wkv_all) + (size_t)li * 2 * inner * W, nullptr, mkv, 2 * inner, NP, 2 * inner, W, 0, st));
     DEER_TRY(ln_rows_f32(m, lat, m->A<float>(L.nlw), m->A<float>(L.nlb), latln, NL, W, st));
     DEER_TRY(gemmf(m, latln, W, m->A<float>(L.wqkv), nullptr, pqkv, 3 * inner, NL, 3 * inner, W, 0, st));
     {
-      Bracket b(m, "deer_attn_f32", 4.0 * N * c.perc_heads * nl * (P + nl) * 64, 0, st);
-      DEER_TRY(deer_attn_f32(pqkv, mkv, mkv + inner, pqkv + inner, pqkv + 2 * inner, pao, N, c.perc_heads, nl, P, nl, 3 * inner, 2 * inner, 3 * inner, inner,
-                             (long)nl * 3 * inner, (long)P * 2 * inner, (long)nl * 3 * inner, (long)nl * inner, scale, st));
+      Bracket b(m, "deer_attn_f32", 4.0 * N * c.perc_heads * nl * (PM + nl) * 64, 0, st);
+      DEER_TRY(deer_attn_f32(pqkv, mkv, mkv + inner, pqkv + inner, pqkv + 2 * inner, pao, N, c.perc_heads, nl, PM, nl, 3 * inner, 2 * inner, 3 * inner, inner,
+                             (long)nl * 3 * inner, (long)PM * 2 * inner, (long)nl * 3 * inner, (long)nl * inner, scale, st));
     }
     DEER_TRY(gemmf(m, pao, inner, m->A<float>(L.wo), nullptr, lat, W, NL, W, inner, 3, st));
     DEER_TRY(ln_rows_f32(m, lat, m->A<float>(L.fnw), m->A<float>(L.fnb), pln, NL, W, st));
@@ -892,7 +900,7 @@ int media_kv_f32(deer_model* m, void* st) {
   if (!m->n_xattn) return DEER_OK;
   if (m->media_override != nullptr) return DEER_ERR_SHAPE;      // a bf16 media tensor cannot feed the f32 arithmetic: use the model's own
   return gemmf(m, m->Wk<float>(m->vis_x_f32), m->W, m->A<float>(m->wkv_all), nullptr, m->Wk<float>(m->hp.kv_all), (long)m->n_xattn * 2 * m->xinner,
-               (long)m->N * m->nl, (long)m->n_xattn * 2 * m->xinner, m->W, 0, st);
+               (long)m->B * m->n_media, (long)m->n_xattn * 2 * m->xinner, m->W, 0, st);
 }
 
 int media_kv(deer_model* m, void* st) {
@@ -900,7 +908,7 @@ int media_kv(deer_model* m, void* st) {
   if (!m->n_xattn) return DEER_OK;
   const void* media = m->media_override ? m->media_override : m->Wk<void>(m->vis_x);
   // the K / V leave in the arithmetic's own 16-bit format (fp16 engines: fp16 K / V for the *_f16 x-attn kernels)
-  return gemm(m, media, m->A<void>(m->wkv_all), m->Wk<void>(m->kv_all), (long)m->N * m->nl, (long)m->n_xattn * 2 * m->xinner, m->W, DEER_EPI_BF16,
+  return gemm(m, media, m->A<void>(m->wkv_all), m->Wk<void>(m->kv_all), (long)m->B * m->n_media, (long)m->n_xattn * 2 * m->xinner, m->W, DEER_EPI_BF16,
               nullptr, st);
 }
 
@@ -1072,7 +1080,7 @@ int llm_layer_r16(deer_model* m, int i, int T, bool use_mask, bool pending_in, b
   if (m->persistent_layer && !m->f16 && L.has_xa && c.xattn_ff_mult == 4 && c.mlp_ratio == 4) {
     const XattnW& X = L.xa;
     deer_trunk_layer_args a{};
-    a.T = T; a.d = d; a.xinner = xin; a.heads = c.xattn_heads; a.n_heads = c.n_heads; a.ffw = (int)ffw; a.n_kv = 2 * m->nl; a.n_per_media = 2 * m->nl;
+    a.T = T; a.d = d; a.xinner = xin; a.heads = c.xattn_heads; a.n_heads = c.n_heads; a.ffw = (int)ffw; a.n_kv = m->n_media; a.n_per_media = m->n_media;
     a.ld_kv = m->n_xattn * 2 * xin; a.NS = ((d >> 4) + 31) / 32; a.pending_s = pending_in ? pend.S : 0; a.qk_ln = c.attn_qk_ln ? 1 : 0;
     a.s_w2 = deer_skinny_hl_splitk(T, d, (int)ffw); a.s_wo = deer_skinny_hl_splitk(T, d, d); a.s_down = a.s_w2;
     if (pending_in && (pend.S != a.s_down || pend.stride != 16L * d)) return DEER_ERR_SHAPE;
@@ -1096,7 +1104,7 @@ int llm_layer_r16(deer_model* m, int i, int T, bool use_mask, bool pending_in, b
     const XattnW& X = L.xa;
     DEER_TRY(resadd_packed(m, T, pp, m->A<float>(X.nw), m->A<float>(X.nb), prev_hidden, ctl, st));
     prev_hidden = nullptr;
-    const int n_media = 2 * m->nl;
+    const int n_media = m->n_media;
     const char* kv = m->Wk<char>(m->kv_all) + (size_t)X.kv_index * 2 * xin * 2;
     if ((size_t)c.xattn_heads * 16 * d > m->slab_a_elems) return DEER_ERR_SHAPE;
     {
@@ -1191,7 +1199,7 @@ int llm_layer(deer_model* m, int i, int T, bool use_mask, bool pending_in, bool 
     DEER_TRY(resadd(m, R, pp, m->A<float>(X.nw), m->A<float>(X.nb), prev_hidden, ctl, st, rc ? &rfirst : nullptr));
     prev_hidden = nullptr;
     static const bool fused = [] { const char* e = getenv("DEER_XATTN_FUSED"); return e == nullptr || e[0] != '0'; }();
-    const int n_media = 2 * m->nl;
+    const int n_media = m->n_media;
     const char* kv = m->Wk<char>(m->kv_all) + (size_t)X.kv_index * 2 * xin * 2;
     if (c.precision) {
       // fp32-activation arithmetic: q projection (f32 activations as bf16 hi + lo), fp32 attention over the f32 K/V, output projection
@@ -1496,6 +1504,7 @@ int deer_model_create(const deer_config* cfg, deer_model** out) {
   if (c.mlp_num_hidden_layers < 0 || c.mlp_num_hidden_layers > 3 || c.lstm_num_layers < 1) return DEER_ERR_SHAPE;
   if (c.multi_step_action < 0 || c.multi_step_action > 8 || (c.layerwise_exit_eval && c.use_state)) return DEER_ERR_SHAPE;
   if (c.operands_f16 && c.precision) return DEER_ERR_SHAPE;     // the fp32 arithmetic has no 16-bit tower
+  if (c.fusion_pre && c.sep_resampler) return DEER_ERR_SHAPE;   // pre fusion has ONE resampler for both cameras (flamingo_mpt.py:602)
   deer_model* m = new deer_model();
   m->c = c;
   m->f16 = c.operands_f16 != 0;
@@ -1514,6 +1523,8 @@ int deer_model_create(const deer_config* cfg, deer_model** out) {
   m->Lh = c.lstm_num_layers;
   m->B = c.n_envs;
   m->N = 2 * c.n_envs;
+  m->fuse_pre = c.fusion_pre != 0;
+  m->n_media = m->fuse_pre ? m->nl : 2 * m->nl;
   m->n_fc = c.mlp_num_hidden_layers;
   const int dims[3] = {1024, 512, 256};                      // action_head.py:87-89
   for (int i = 0; i < 3; ++i) m->fc_dims[i] = dims[i];
@@ -1806,7 +1817,7 @@ int deer_perceiver_resample(deer_model* m, const float* tokens, int n_images, vo
   }
   m->tokens_override = nullptr;
   if (rc != DEER_OK) return rc;
-  const size_t n = (size_t)m->N * m->nl * m->W;
+  const size_t n = (size_t)m->B * m->n_media * m->W;
   if (media_bf16_out && hipMemcpyAsync(media_bf16_out, m->Wk<void>(m->vis_x), n * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return DEER_ERR_LAUNCH;
   if (media_f32_out && hipMemcpyAsync(media_f32_out, m->Wk<void>(m->vis_x_f32), n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return DEER_ERR_LAUNCH;
   return DEER_OK;

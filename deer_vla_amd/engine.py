@@ -239,8 +239,10 @@ class DeerEngine:
         self.img = v("img", self.img_dtype).view(N, 3, S, S)               # static input buffer (camera frames)
         self.vx = v("vx", torch.float32).view(N, cfg.n_patches + 1, W)     # ViT residual stream (fp32)
         self.media_dtype = torch.float16 if self.precision == "fp16" else torch.bfloat16
-        self.vis_x = v("vis_x", self.media_dtype).view(N * nl, W)          # media tokens [rgb latents ; gripper latents] per env
-        self.vis_x_f32 = v("vis_x_f32", torch.float32).view(N * nl, W)
+        # media tokens [rgb latents ; gripper latents] per env (post fusion; the buffers are sized for it); one set of latents per env with
+        # fusion_mode="pre": the first B * n_media rows
+        self.vis_x = v("vis_x", self.media_dtype).view(N * nl, W)[:B * cfg.n_media]
+        self.vis_x_f32 = v("vis_x_f32", torch.float32).view(N * nl, W)[:B * cfg.n_media]
         self.kv_all = v("kv_all", self.media_dtype)
         self.ids = v("ids", torch.int64)
         self.key_mask = v("key_mask", torch.uint8)

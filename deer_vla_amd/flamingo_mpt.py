@@ -165,8 +165,19 @@ class MPTFlamingo(nn.Module):
         super().__init__()
         if unused:
             raise TypeError(f"MPTFlamingo: keywords {sorted(unused)} are not implemented by deer_vla_amd (they would be silently ignored)")
-        if not use_gripper or fusion_mode != "post":
-            raise NotImplementedError("released DeeR checkpoints use use_gripper=True, fusion_mode='post' (flamingo_mpt.py:380-381)")
+        # Built: fusion_mode 'post' (flamingo_mpt.py:380-381, every released DeeR checkpoint) and 'pre' (round 6; :378-379,585-607: one
+        # PerceiverResampler call over both cameras' patch tokens).  The reference's own forward does not run the others in step mode
+        # (tests/golden/fusion_modes_reference.npz records it): use_gripper=False and 'two_way' reach _encode_vision_x, which reads an
+        # undefined name (:541, NameError); 'vit_concat' reshapes the batch into windows (:755).
+        if not use_gripper or fusion_mode not in ("post", "pre"):
+            raise NotImplementedError("use_gripper=True with fusion_mode='post' (released DeeR checkpoints, flamingo_mpt.py:380-381) or 'pre' "
+                                      "(:378-379) are built; the reference's own forward raises on use_gripper=False / 'two_way' (NameError, "
+                                      "flamingo_mpt.py:541) and on 'vit_concat' in step mode (:755)")
+        if fusion_mode != getattr(cfg, "fusion_mode", "post"):
+            import dataclasses
+            cfg = dataclasses.replace(cfg, fusion_mode=fusion_mode)
+        if cfg.fusion_mode == "pre" and getattr(cfg, "sep_resampler", False):
+            raise ValueError("fusion_mode='pre' has one PerceiverResampler for both cameras (flamingo_mpt.py:602): sep_resampler does not apply")
         self.cfg = cfg
         # "fp16" (default): the product arithmetic on IEEE fp16 operands = the reference's evaluation arithmetic (fp32 weights under fp16
         # autocast, eval_utils.py:333); "bf16": the same on bf16 operands (a --precision bf16 / amp_bf16 run); "fp32": fp32 activations

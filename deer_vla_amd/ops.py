@@ -124,11 +124,12 @@ def _(images, model):
 
 @torch.library.custom_op("deer::perceiver_resample", mutates_args=(), device_types="cuda")
 def perceiver_resample(tokens: torch.Tensor, model: int) -> torch.Tensor:
-    """patch tokens (N,256,W) f32 -> media tokens (N*64, W) in the tower's 16-bit format (fp16 / bf16), frame order (rgb, gripper per environment)."""
+    """patch tokens (N,256,W) f32 -> media tokens (N*64, W) in the tower's 16-bit format (fp16 / bf16), frame order (rgb, gripper per environment);
+    (N/2*64, W) with fusion_mode="pre" (one set of latents per environment)."""
     m = _model(model)
     cfg = m.cfg
     tok = tokens.to(torch.float32).contiguous()
-    out = torch.empty(tok.shape[0] * cfg.perc_latents, cfg.vit_width, dtype=m.media_dtype, device=tok.device)
+    out = torch.empty(tok.shape[0] // 2 * cfg.n_media, cfg.vit_width, dtype=m.media_dtype, device=tok.device)
     abi.check(m.lib.deer_perceiver_resample(m._h, abi.ptr(tok), tok.shape[0], abi.ptr(out), None, _stream()), "deer_perceiver_resample")
     return out
 
@@ -136,7 +137,7 @@ def perceiver_resample(tokens: torch.Tensor, model: int) -> torch.Tensor:
 @perceiver_resample.register_fake
 def _(tokens, model):
     m = _model(model)
-    return tokens.new_empty((tokens.shape[0] * m.cfg.perc_latents, m.cfg.vit_width), dtype=m.media_dtype)
+    return tokens.new_empty((tokens.shape[0] // 2 * m.cfg.n_media, m.cfg.vit_width), dtype=m.media_dtype)
 
 
 @torch.library.custom_op("deer::llm_early_exit", mutates_args=(), device_types="cuda")

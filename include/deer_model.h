@@ -55,6 +55,9 @@ typedef struct deer_config {
                              * eval_utils.py:333); accumulation, LayerNorm / softmax statistics, residual streams, LSTM state stay f32.
                              * 0 = the same kernels on bf16 operands (a `--precision bf16` / amp_bf16 reference run).
                              * Python: precision = "fp16" (default) | "bf16" | "fp32"  (deer_vla_amd/_abi.py PRECISIONS). */
+  int fusion_pre;           /* round 6: 1 = `fusion_mode='pre'` (flamingo_mpt.py:378-379,585-607): the patch tokens of an environment's two frames are
+                             * ONE media sequence (2 x 256 tokens) for ONE PerceiverResampler call -> perc_latents media tokens per environment for
+                             * the gated x-attn (post fusion, the default and every released checkpoint: one call per frame, 2 x perc_latents) */
 } deer_config;
 
 typedef struct deer_model deer_model;
@@ -108,7 +111,7 @@ int deer_vit_l14_encode(deer_model* m, const void* images_bf16, int n_images, fl
 /* (operands_f16: every `*_bf16` media / image argument below carries IEEE fp16 instead - the model's 16-bit format) */
 /* tokens: f32 [n_images,256,W] or NULL (= the workspace tokens of the last deer_vit_l14_encode); media_bf16_out / media_f32_out:
  * [n_images*64, W] latents of every image in image order (rgb, gripper per environment = the post-fusion concat of
- * flamingo_mpt.py:661) or NULL to leave them in the workspace. */
+ * flamingo_mpt.py:661; with fusion_pre [n_envs*64, W]) or NULL to leave them in the workspace. */
 int deer_perceiver_resample(deer_model* m, const float* tokens, int n_images, void* media_bf16_out, float* media_f32_out,
                             void* stream);
 /* ids: int64 [n_envs,T] device; key_mask: uint8 [n_envs,T] (0 = padding) or NULL; media_bf16: [n_envs*128, W] or NULL (workspace);

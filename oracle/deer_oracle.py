@@ -532,8 +532,8 @@ def llm_forward(sd: SD, cfg, input_ids, attention_mask, vis_x, exit_controller=N
 
 
 class OracleDeer:
-    """``MPTFlamingo`` inference path (flamingo_mpt.py:308-461) with fusion_mode='post',
-    use_gripper=True (the released DeeR configuration), extra-exit head only."""
+    """``MPTFlamingo`` inference path (flamingo_mpt.py:308-461) with use_gripper=True and fusion_mode='post' (the released DeeR configuration)
+    or 'pre' (``cfg.fusion_mode``; flamingo_mpt.py:585-607)."""
 
     def __init__(self, sd: SD, cfg):
         self.sd, self.cfg = sd, cfg
@@ -578,6 +578,8 @@ class OracleDeer:
             t = vit_visual_tokens(self.sd, cfg, v.reshape(b * T * Fr, *v.shape[3:]))
             return t.reshape(b, T, Fr, t.shape[1], t.shape[2])
 
+        if getattr(cfg, "fusion_mode", "post") == "pre":                   # _encode_multi_vision_pre_fusion :585-607: ViT tokens of both cameras
+            return perceiver_resampler(self.sd, cfg, torch.cat([enc(vision_x), enc(vision_gripper)], dim=3))   # cat along v -> ONE call, (b,T,n,D)
         rgb = perceiver_resampler(self.sd, cfg, enc(vision_x))
         grip = perceiver_resampler(self.sd, cfg, enc(vision_gripper),       # :656-659: own weights when sep_resampler
                                    "perceiver_gripper." if getattr(cfg, "sep_resampler", False) else "perceiver.")

@@ -343,7 +343,7 @@ def gen_deer_forward_r6(name, cfg_kw=None, thr_types=("L2",), exit_id_list=None,
     venc_mod.visual = _OracleVisual(cfg, sd)
     model = MPTFlamingo(venc_mod, lm, cfg.eoc_token_id, cfg.media_token_id, vis_dim=cfg.vit_width,
                         cross_attn_every_n_layers=cfg.cross_attn_every_n_layers, window_size=cfg.window_size,
-                        use_gripper=True, fusion_mode="post", llm="mpt_dolly_3b", pooling=cfg.pooling,
+                        use_gripper=True, fusion_mode=cfg.fusion_mode, llm="mpt_dolly_3b", pooling=cfg.pooling,
                         early_exit_layer=cfg.early_exit_layer, multi_exit=False, exit_interval=cfg.exit_interval,
                         mlp_layernorm=cfg.mlp_layernorm, lstm_layernorm=cfg.lstm_layernorm,
                         mlp_num_hidden_layers=cfg.mlp_num_hidden_layers, lstm_num_layers=cfg.lstm_num_layers).eval()
@@ -428,6 +428,7 @@ def gen_deer_forward_r6(name, cfg_kw=None, thr_types=("L2",), exit_id_list=None,
         outs.update({f"{ttype}_thr": np.asarray(thr), f"{ttype}_exit": np.asarray(ex), f"{ttype}_pose": torch.stack(ps),
                      f"{ttype}_grip": torch.stack(gs), f"{ttype}_rec_layer": np.asarray([i for i, _ in vn.rec]),
                      f"{ttype}_rec_delta": np.asarray([v for _, v in vn.rec]), f"{ttype}_min_margin": marg})
+    outs["vis_x"] = lm._get_decoder_layers()[0].vis_x            # the media tokens of the last step (b, T, n_media, D)
     save(name, cfg, seed, ids=ids, mask=mask, rgb=rgb, grip=grip, bf16_round=1, exit_ids=np.asarray(exit_ids),
          thr_types=np.frombuffer(",".join(thr_types).encode(), dtype=np.uint8), **outs)
 
@@ -525,6 +526,48 @@ def gen_round6_variants():
     gen_deer_forward_r6("deer_forward_consec.npz", thr_types=("L2", "max"), exit_id_list=[1, 2, 3, 4])
     gen_exit_interval_1()
     gen_window_padded()
+    gen_fusion_modes_in_reference()
+    gen_deer_forward_r6("deer_forward_pre.npz", cfg_kw=dict(fusion_mode="pre"), thr_types=("L2", "max"))   # flamingo_mpt.py:585-607
+
+
+def gen_fusion_modes_in_reference():
+    """What the reference's OWN forward does for the vision paths this repo does not build (VERDICT r5 missing-5): recorded as data.
+    ``use_gripper=False`` and ``fusion_mode='two_way'`` both go through ``_encode_vision_x`` (flamingo_mpt.py:375-376), whose body reads an
+    undefined name (``if eval_flop:``, :541) - the reference raises NameError on the first step, there is nothing to be compatible with;
+    ``'pre'`` (both cameras' ViT tokens through ONE Perceiver call, :585-607) runs; ``'vit_concat'`` needs window-sized batches (:755)."""
+    _dist_init()
+    cfg = llm_cfg()
+    S = cfg.image_size
+    ids = torch.tensor([[cfg.media_token_id, 5, 17, 3, 42, 8, cfg.eoc_token_id, 0]])
+    mask = torch.ones(1, 8, dtype=torch.bool)
+    rgb, grip = seeded("deer.rgb", (1, 1, 1, 3, S, S)), seeded("deer.grip", (1, 1, 1, 3, S, S))
+    names, outcomes = [], []
+    for use_gripper, fusion in ((False, "post"), (True, "two_way"), (True, "pre"), (True, "vit_concat"), (True, "post")):
+        try:
+            sd = syn.make_synthetic_state(cfg, 7, bf16_round=True)
+            lm, mod = build_ref_lang_encoder(cfg, sd)
+            extend_instance(lm, FlamingoLMMixin)
+            lm.set_decoder_layers_attr_name("transformer.blocks")
+            venc_mod = nn.Module()
+            venc_mod.visual = _OracleVisual(cfg, sd)
+            model = MPTFlamingo(venc_mod, lm, cfg.eoc_token_id, cfg.media_token_id, vis_dim=cfg.vit_width,
+                                cross_attn_every_n_layers=cfg.cross_attn_every_n_layers, window_size=cfg.window_size,
+                                use_gripper=use_gripper, fusion_mode=fusion, llm="mpt_dolly_3b", pooling=cfg.pooling,
+                                early_exit_layer=cfg.early_exit_layer, multi_exit=False, exit_interval=cfg.exit_interval,
+                                mlp_layernorm=cfg.mlp_layernorm, lstm_layernorm=cfg.lstm_layernorm,
+                                mlp_num_hidden_layers=cfg.mlp_num_hidden_layers, lstm_num_layers=cfg.lstm_num_layers).eval()
+            model.set_all_exit_window_size(1)
+            with torch.no_grad():
+                o = model(vision_x=rgb, lang_x=ids, attention_mask=mask, vision_gripper=grip, state_tensor=torch.zeros(1, 1, 1, 15),
+                          return_feature=True, deterministic=True, exit_id=3, dynamic_early_exit=False, exit_controller=None)
+            out = "ok:" + "x".join(str(v) for v in lm._get_decoder_layers()[0].vis_x.shape)
+        except Exception as e:                              # noqa: BLE001 - the exception type IS the recorded result
+            out = type(e).__name__ + ":" + str(e)[:80]
+        names.append(f"use_gripper={use_gripper},fusion_mode={fusion}")
+        outcomes.append(out)
+        print("  reference forward,", names[-1], "->", out)
+    enc = lambda xs: np.frombuffer("|".join(xs).encode(), dtype=np.uint8)
+    save("fusion_modes_reference.npz", cfg, 7, modes=enc(names), outcomes=enc(outcomes))
 
 
 def gen_round5_variants():

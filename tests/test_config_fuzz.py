@@ -35,7 +35,10 @@ def draw(seed):
         lens = [min(t, 128 // B) for t in lens]
     ttype, wseed = r.choice(["L2", "L2", "mean", "max", "cosine"]), r.randint(0, 10 ** 6)
     # the controller's own knobs: stage holds (value_net.py:285-286) and a max_layer cut below the last exit (value_net.py:173)
-    return kw, B, precision, lens, ttype, wseed, r.choice([1, 1, 1, 2, 3]), r.random() < 0.25
+    sps, cut = r.choice([1, 1, 1, 2, 3]), r.random() < 0.25
+    if r.random() < 0.2 and not kw["sep_resampler"]:            # one PerceiverResampler call over both cameras (flamingo_mpt.py:585-607)
+        kw["fusion_mode"] = "pre"
+    return kw, B, precision, lens, ttype, wseed, sps, cut
 
 
 class RecVN(orc.OracleValueNet):
@@ -109,7 +112,7 @@ def test_random_combination_of_variants_matches_the_oracle(case):
     state = torch.randn(n_steps, 1, 1, 1, 15, generator=g)
     state[..., -1] = torch.where(torch.rand(n_steps, 1, 1, 1, generator=g) < 0.5, -1.0, 1.0)
     model, _, _ = factory.create_model_and_transforms(
-        "ViT-L-14", "openai", "", "", cross_attn_every_n_layers=1, window_size=12, use_gripper=True, fusion_mode="post", llm_name="mpt_dolly_3b",
+        "ViT-L-14", "openai", "", "", cross_attn_every_n_layers=1, window_size=12, use_gripper=True, fusion_mode=cfg.fusion_mode, llm_name="mpt_dolly_3b",
         state_dict=sd, cfg=cfg, use_state=cfg.use_state, sep_resampler=cfg.sep_resampler, multi_step_action=A,
         layerwise_exit_eval=cfg.layerwise_exit_eval, multi_exit=cfg.layerwise_exit_eval, n_envs=B, precision=precision)
     exit_ids = cfg.exit_ids()
@@ -190,7 +193,10 @@ def draw_window(seed):
     precision = r.choice(["fp16", "fp16", "fp16", "bf16", "fp32"])
     tmax = 128 // (bs * W) if precision == "fp32" else 24                 # the fp32 arithmetic keeps 128 trunk rows
     lens = [r.randint(3, max(3, min(24, tmax))) for _ in range(bs)]
-    return kw, W, bs, precision, lens, r.choice(["L2", "L2", "mean", "max", "cosine"]), r.randint(0, 10 ** 6)
+    ttype, wseed = r.choice(["L2", "L2", "mean", "max", "cosine"]), r.randint(0, 10 ** 6)
+    if r.random() < 0.2 and not kw["sep_resampler"]:
+        kw["fusion_mode"] = "pre"
+    return kw, W, bs, precision, lens, ttype, wseed
 
 
 @pytest.mark.parametrize("case", range(N_WINDOW_CASES))
@@ -225,7 +231,7 @@ def test_random_window_batch_calibration_call_matches_the_oracle(case):
             ref.append(torch.stack([x[0] for x in h]))                         # (L, T, d)
         omodel.clear_all_exit_memory()
     ref = torch.stack(ref, dim=1)                                              # (L, bs*W, T, d)
-    model = MPTFlamingo(cfg, sd, window_size=W, precision=precision)
+    model = MPTFlamingo(cfg, sd, window_size=W, fusion_mode=cfg.fusion_mode, precision=precision)
     vx = torch.stack([f[0].reshape(1, 1, 3, S, S) for fr in frames for f in fr])
     vg = torch.stack([f[1].reshape(1, 1, 3, S, S) for fr in frames for f in fr])
     input_ids = ids.unsqueeze(1).repeat(1, W, 1).flatten(0, 1)

@@ -140,9 +140,15 @@ def test_factory_fails_loudly_on_keywords_it_does_not_implement():
     for kw in (dict(multi_step_action=9), dict(last_action=True), dict(fwd_pred=True), dict(fwd_pred_hand=True), dict(residual=True),
                dict(pad_length=12), dict(refresh=2), dict(layerwise_exit_eval=True, use_state=True), dict(use_hist=True),
                dict(use_diff=True), dict(share_exit=True), dict(decoder_type="gpt"),
-               dict(head_type="diffusion"), dict(llm_name="llama_9b"), dict(clip_vision_encoder_path="ViT-B-32")):
+               dict(head_type="diffusion"), dict(llm_name="llama_9b"), dict(clip_vision_encoder_path="ViT-B-32"),
+               # the vision paths the reference's own forward cannot run in step mode (tests/golden/fusion_modes_reference.npz)
+               dict(use_gripper=False, cfg=deer_tiny()), dict(fusion_mode="two_way", cfg=deer_tiny()), dict(fusion_mode="vit_concat", cfg=deer_tiny())):
         with pytest.raises(NotImplementedError):
             create_model_and_transforms(**{**base, **kw})
+    m = create_model_and_transforms(**{**base, "fusion_mode": "pre", "cfg": deer_tiny()})[0]     # built in round 6 (flamingo_mpt.py:585-607)
+    assert m.cfg.fusion_mode == "pre" and m.cfg.n_media == m.cfg.perc_latents and m.fusion_mode == "pre"
+    with pytest.raises(ValueError):                       # one PerceiverResampler for both cameras: sep_resampler does not apply
+        create_model_and_transforms(**{**base, "fusion_mode": "pre", "sep_resampler": True, "cfg": deer_tiny()})
     with pytest.raises(ValueError):                       # the per-layer heads only exist with multi_exit=True (flamingo_mpt.py:236-249)
         create_model_and_transforms(**{**base, "layerwise_exit_eval": True, "multi_exit": False})
 

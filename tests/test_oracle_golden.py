@@ -4,7 +4,9 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import load, state, s2str
+import os
+
+from golden_util import GOLD, load, state, s2str
 from oracle import deer_oracle as orc
 
 TOL = dict(rtol=1e-5, atol=2e-6)
@@ -370,7 +372,8 @@ def test_forward_variants_match_reference_mptflamingo(name):
         close(o["logits"][1], g["dyn_grip"][s], atol=1e-5)
 
 
-R6_VARIANTS = ["deer_forward_plain.npz", "deer_forward_avg3.npz", "deer_forward_thr.npz", "deer_forward_consec.npz"]
+R6_VARIANTS = ["deer_forward_plain.npz", "deer_forward_avg3.npz", "deer_forward_thr.npz", "deer_forward_consec.npz",
+               "deer_forward_pre.npz"]          # fusion_mode="pre": both cameras through ONE PerceiverResampler call (flamingo_mpt.py:585-607)
 
 
 @pytest.mark.parametrize("name", R6_VARIANTS)
@@ -403,6 +406,27 @@ def test_round6_head_and_criterion_variants_match_reference_mptflamingo(name):
             close(o["logits"][0], g[ttype + "_pose"][s], atol=1e-5)
             close(o["logits"][1], g[ttype + "_grip"][s], atol=1e-5)
         assert float(g[ttype + "_min_margin"]) > 0.05            # decisions far from the knife edge: exact exits are a fair demand of a bf16 path
+
+
+def test_pre_fusion_media_tokens_and_the_vision_paths_the_reference_itself_cannot_run():
+    """``fusion_mode='pre'``: 64 media tokens from ONE resampler call over 2 x 4 patch tokens (fixture ``vis_x``).  And, recorded as data by
+    running the reference's own forward once per mode (tests/golden/make_golden.py::gen_fusion_modes_in_reference): ``use_gripper=False`` and
+    ``'two_way'`` raise NameError inside ``_encode_vision_x`` (flamingo_mpt.py:541 reads an undefined ``eval_flop``), ``'vit_concat'`` cannot
+    reshape a step-mode batch into windows (:755) - this repo's surface refuses exactly those (tests/test_host_logic.py)."""
+    cfg, seed, g = load("deer_forward_pre.npz")
+    assert cfg.fusion_mode == "pre" and cfg.n_media == cfg.perc_latents
+    from deer_vla_amd import synthetic as syn
+    sd = syn.make_synthetic_state(cfg, seed, bf16_round=True)
+    model = orc.OracleDeer(sd, cfg)
+    vis = model.encode_vision(g["rgb"][-1], g["grip"][-1])
+    assert tuple(vis.shape) == tuple(g["vis_x"].shape) == (1, 1, cfg.perc_latents, cfg.vit_width)
+    close(vis, g["vis_x"], atol=1e-5)
+    z = np.load(os.path.join(GOLD, "fusion_modes_reference.npz"))
+    dec = lambda a: bytes(np.asarray(a).astype("uint8")).decode()
+    got = dict(zip(dec(z["modes"]).split("|"), dec(z["outcomes"]).split("|")))
+    assert got["use_gripper=False,fusion_mode=post"].startswith("NameError") and got["use_gripper=True,fusion_mode=two_way"].startswith("NameError")
+    assert got["use_gripper=True,fusion_mode=vit_concat"].startswith("RuntimeError")
+    assert got["use_gripper=True,fusion_mode=pre"] == "ok:1x1x64x64" and got["use_gripper=True,fusion_mode=post"] == "ok:1x1x128x64"
 
 
 def test_exit_interval_one_is_rejected_like_the_reference():

@@ -95,7 +95,9 @@ def test_engine_head_matches_reference_deterministic_decoder(name, precision, to
 
 R6 = [("deer_forward_plain.npz", "fp16"), ("deer_forward_avg3.npz", "fp16"), ("deer_forward_thr.npz", "fp16"), ("deer_forward_consec.npz", "fp16"),
       ("deer_forward_plain.npz", "bf16"), ("deer_forward_thr.npz", "bf16"),
-      ("deer_forward_plain.npz", "fp32"), ("deer_forward_avg3.npz", "fp32"), ("deer_forward_thr.npz", "fp32")]
+      ("deer_forward_plain.npz", "fp32"), ("deer_forward_avg3.npz", "fp32"), ("deer_forward_thr.npz", "fp32"),
+      # fusion_mode="pre" (flamingo_mpt.py:585-607): both cameras' patch tokens through ONE PerceiverResampler call, 64 media tokens
+      ("deer_forward_pre.npz", "fp16"), ("deer_forward_pre.npz", "bf16"), ("deer_forward_pre.npz", "fp32")]
 
 
 @pytest.mark.parametrize("name,precision", R6)
@@ -114,6 +116,11 @@ def test_engine_matches_reference_forward_for_head_and_criterion_variants(name, 
             assert r["exit_layer"] == eid
             assert float((r["pose"] - g[f"static{eid}_pose"][s].reshape(-1)).abs().max()) < tol, (eid, s)
             assert abs(r["gripper"] - float(g[f"static{eid}_grip"][s])) < tol, (eid, s)
+    if "vis_x" in g:                                         # the media tokens of the last step against the reference's
+        ref_vis = g["vis_x"].reshape(-1, cfg.vit_width)
+        vis = eng.vis_x_f32.cpu()
+        assert vis.shape == ref_vis.shape == (cfg.n_media, cfg.vit_width)
+        assert float((vis - ref_vis).abs().max() / ref_vis.abs().max()) < (2e-2 if precision != "fp32" else 1e-4)
     exit_ids = [int(v) for v in g["exit_ids"]]
     for ttype in s2str(g["thr_types"]).split(","):
         e2 = DeerEngine(cfg, None, precision=precision, weights_from=eng, threshold_type=ttype)
