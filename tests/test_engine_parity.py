@@ -524,6 +524,32 @@ def test_full_size_mpt1b_vitl14_steps_vs_oracle():
         assert float((rr["pose"] - ref[s][1]).abs().max()) < ACTION_TOL
 
 
+@pytest.mark.parametrize("precision", ["fp16", "fp32"])
+def test_full_size_pre_fusion_vs_oracle(precision):
+    """``fusion_mode='pre'`` (flamingo_mpt.py:585-607) at FULL size: the 2 x 256 patch tokens of the two frames are one 512-token media
+    sequence for the 64 latents (the two-segment attention at kv1 = 512), 64 media tokens for the x-attn - same weights as the post-fusion
+    model (the variant shares every parameter): media tokens, hidden states and the action of static steps (graph replay included)."""
+    import dataclasses
+    cfg0 = deer_3b(max_layer=12)
+    cfg = dataclasses.replace(cfg0, fusion_mode="pre")
+    sd = full_size_state(cfg0, 0, std="0.02", bf16_round=True)
+    eng = DeerEngine(cfg, sd, precision=precision)
+    model = orc.OracleDeer(sd, cfg)
+    model.set_all_exit_window_size(1)
+    eng.reset()
+    rel, tol = (2e-2, ACTION_TOL) if precision != "fp32" else (2e-4, 1e-3)
+    for s, eid in enumerate((11, 5, 11)):
+        rgb, grip, ids, mask = syn.synthetic_step_inputs(cfg, s)
+        o = model.forward(rgb, ids, mask, grip, exit_id=eid)
+        r = eng.step(rgb, grip, ids, mask, exit_id=eid, use_graph=(s == 2))
+        vis, ref_vis = eng.vis_x_f32.cpu(), o["vis_x"].reshape(cfg.n_media, cfg.vit_width)
+        assert vis.shape == (cfg.perc_latents, cfg.vit_width) and float((vis - ref_vis).norm() / ref_vis.norm()) < rel, s
+        a, b = eng.hidden[eid, :14].cpu(), o["hidden_states"][eid][0]
+        assert float((a - b).norm() / b.norm()) < rel, s
+        assert float((r["pose"] - o["logits"][0].reshape(-1)).abs().max()) < tol, s
+        assert abs(r["gripper"] - float(o["logits"][1])) < tol, s
+
+
 def test_full_size_mpt7b_openflamingo9b_steps_vs_oracle():
     """BASELINE configs[4] at FULL size (MPT-7B trunk: d=4096, 32 heads x 128, FF 16384, gated x-attn in front of every 4th
     layer, no q/k LayerNorm; 13 layers for max_layer=12): hidden states, static exits and a dynamic episode (pipelined
