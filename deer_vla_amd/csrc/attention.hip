@@ -22,11 +22,12 @@
 #define AM_HD 64
 #define AM_KPITCH 72          // K rows: 64 + 8 bf16
 #define AM_MAXT 20            // max 16-key tiles (kv_len <= 320)
+#define AM_MAXT_LONG 36       // the long-sequence instantiation: kv_len <= 576 (pre fusion: 2 x 256 patch tokens + 64 latents)
 
 // Optional extras (gated x-attn inside the LLM, helpers.py:192-232): Q given as f32 split-K partial slabs
 // (q_slabs > 0: Q points to f32, reduced while loading), keys masked by media time (text_time[q] == key/n_per_media + 1,
 // rows with text_time == 0 zeroed), f32 output, early-exit control block.
-template <bool XATTN, int NWAVE, bool LOOP = false, bool F16 = false>   // F16: q / k / v / P / o in fp16 (the vision tower's fp16 arithmetic)
+template <bool XATTN, int NWAVE, bool LOOP = false, bool F16 = false, int MAXT = AM_MAXT>   // F16: q / k / v / P / o in fp16 (the vision tower's fp16 arithmetic); MAXT: key tiles of 16 held in registers
 __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __restrict__ Qv, const bf16_t* __restrict__ Kp,
                                                         const bf16_t* __restrict__ V, void* __restrict__ Ov,
                                                         int q_len, int kv_len, int ldq, int ldk, int ldv, int ldo,
@@ -118,9 +119,9 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
   if (LOOP && ti >= NWAVE) load_q();
 
   // ---- S^T tiles: s[t][r] = S[q = c][key = t*16 + g*4 + r] ----
-  f32x4 s[AM_MAXT];
+  f32x4 s[MAXT];
 #pragma unroll
-  for (int t = 0; t < AM_MAXT; ++t) {
+  for (int t = 0; t < MAXT; ++t) {
     s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t < nt) {
 #pragma unroll
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
   // ---- softmax over keys (fp32) ----
   float mx = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < AM_MAXT; ++t) {
+  for (int t = 0; t < MAXT; ++t) {
     if (t < nt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float sum = 0.f;
 #pragma unroll
-  for (int t = 0; t < AM_MAXT; ++t) {
+  for (int t = 0; t < MAXT; ++t) {
     if (t < nt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int ch = 0; ch < AM_MAXT / 2; ++ch) {
+  for (int ch = 0; ch < MAXT / 2; ++ch) {
     if (ch * 2 < nt) {
       uint4 pw;
       pw.x = pack2x<F16>(s[2 * ch][0], s[2 * ch][1]);
@@ -365,14 +366,34 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
                             float scale, int q_slabs, long q_slab_stride, const int* text_time, int n_per_media, int out_is_f32,
                             const int* ctl, void* stream, const void* K2 = nullptr, const void* V2 = nullptr, int kv1 = -1,
                             int ld2 = 0, long bstride2 = 0) {
-  if (q_len <= 0 || kv_len <= 0 || kv_len > AM_MAXT * 16 || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3))
+  // long key sequences (pre fusion, flamingo_mpt.py:585-607: the 64 latents attend 2 x 256 patch tokens + themselves = 576 keys): the same
+  // kernel with 36 key tiles in registers (144 score VGPRs; one workgroup per CU: 154 KB of LDS for K and V^T) - <= 64 queries, no extras
+  const bool long_kv = kv_len > AM_MAXT * 16;
+  if (q_len <= 0 || kv_len <= 0 || kv_len > AM_MAXT_LONG * 16 || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3))
     return DEER_ERR_SHAPE;
+  if (long_kv && (q_slabs > 0 || text_time != nullptr || out_is_f32 || ctl != nullptr)) return DEER_ERR_SHAPE;
   if (K2 == nullptr) kv1 = kv_len;                         // single segment
   else if (V2 == nullptr || kv1 < 0 || kv1 > kv_len || (ld2 & 7)) return DEER_ERR_SHAPE;
   const bf16_t* k2 = reinterpret_cast<const bf16_t*>(K2);
   const bf16_t* v2 = reinterpret_cast<const bf16_t*>(V2);
   const int kvpad = (kv_len + 31) & ~31;
   const int smem = (kvpad * AM_KPITCH + AM_HD * (kvpad + 8)) * (int)sizeof(bf16_t);
+  if (long_kv) {
+    static std::atomic<bool> long_attr{false};
+    constexpr int max_long = (AM_MAXT_LONG * 16 * AM_KPITCH + AM_HD * (AM_MAXT_LONG * 16 + 8)) * 2;
+    if (!long_attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, 4, false, F16, AM_MAXT_LONG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              max_long) != hipSuccess)
+        return DEER_ERR_LAUNCH;
+      long_attr = true;
+    }
+    const int tiles_q = (q_len + 15) / 16;
+    hipLaunchKernelGGL((attn_mfma_kernel<false, 4, false, F16, AM_MAXT_LONG>), dim3((tiles_q + 3) / 4, heads, batch), dim3(256), smem, reinterpret_cast<hipStream_t>(stream),
+                       Q, reinterpret_cast<const bf16_t*>(K), reinterpret_cast<const bf16_t*>(V), O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride,
+                       v_bstride, o_bstride, scale, 0, 0L, nullptr, 1, 0, nullptr, k2, v2, kv1, ld2, bstride2, 4);
+    DEER_LAUNCH_CHECK();
+    return DEER_OK;
+  }
   static std::atomic<bool> attr_set{false};
   constexpr int max_smem = (AM_MAXT * 16 * AM_KPITCH + AM_HD * (AM_MAXT * 16 + 8)) * 2;
   if (!attr_set) {

@@ -199,15 +199,120 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
   }
 }
 
+// The same for key sequences beyond PA_MAXKV (pre fusion at full size, flamingo_mpt.py:585-607: 2 x 256 patch tokens + 64 latents = 576
+// keys): K and V pass through LDS in chunks of PAL_CH keys, the raw scores of all keys wait in `ps`, the softmax runs once over the row.
+#define PAL_CH 256
+#define PAL_MAXKV 1024
+__global__ __launch_bounds__(256) void attn_f32_long_kernel(const float* __restrict__ Q, const float* __restrict__ K1, const float* __restrict__ V1,
+                                                            const float* __restrict__ K2, const float* __restrict__ V2, float* __restrict__ O,
+                                                            int q_len, int kv1, int kv2, int ldq, int ld1, int ld2, int ldo, long q_bstride,
+                                                            long bstride1, long bstride2, long o_bstride, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float pa_lds[];
+  const int kv = kv1 + kv2;
+  float* kvs = pa_lds;                                   // [PAL_CH][65] (a K chunk), then [PAL_CH][64] (a V chunk)
+  float* qs = kvs + PAL_CH * 65;                         // [PA_QB][64]
+  float* ps = qs + PA_QB * 64;                           // [PA_QB][kv]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * PA_QB;
+  const int nq = min(PA_QB, q_len - q0);
+  Q += b * q_bstride + (long)q0 * ldq + h * 64;
+  K1 += b * bstride1 + h * 64; V1 += b * bstride1 + h * 64;
+  if (kv2 > 0) { K2 += b * bstride2 + h * 64; V2 += b * bstride2 + h * 64; }
+  for (int idx = tid; idx < nq * 16; idx += 256) {
+    const int t = idx >> 4, d4 = (idx & 15) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(Q + (long)t * ldq + d4);
+    *reinterpret_cast<float4*>(qs + t * 64 + d4) = float4{v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+  }
+  for (int c0 = 0; c0 < kv; c0 += PAL_CH) {              // raw scores, chunk by chunk
+    const int cn = min(PAL_CH, kv - c0);
+    __syncthreads();
+    for (int idx = tid; idx < cn * 16; idx += 256) {
+      const int j = c0 + (idx >> 4), d4 = (idx & 15) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(j < kv1 ? K1 + (long)j * ld1 + d4 : K2 + (long)(j - kv1) * ld2 + d4);
+      float* dst = kvs + (j - c0) * 65 + d4;
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    __syncthreads();
+    for (int t = wave; t < nq; t += 4) {
+      const float* qr = qs + t * 64;
+      for (int jj = lane; jj < cn; jj += 64) {
+        const float* kr = kvs + jj * 65;
+        float a = 0.f;
+#pragma unroll 16
+        for (int d = 0; d < 64; ++d) a += qr[d] * kr[d];
+        ps[t * kv + c0 + jj] = a;
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = wave; t < nq; t += 4) {                   // softmax of a query row inside its wave
+    float* pr = ps + t * kv;
+    float mx = -INFINITY;
+    for (int j = lane; j < kv; j += 64) mx = fmaxf(mx, pr[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < kv; j += 64) {
+      const float e = expf(pr[j] - mx);
+      pr[j] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int j = lane; j < kv; j += 64) pr[j] *= inv;
+  }
+  float acc[PA_QB / 4];
+#pragma unroll
+  for (int i = 0; i < PA_QB / 4; ++i) acc[i] = 0.f;
+  for (int c0 = 0; c0 < kv; c0 += PAL_CH) {              // O = P V, chunk by chunk; lane = d
+    const int cn = min(PAL_CH, kv - c0);
+    __syncthreads();
+    for (int idx = tid; idx < cn * 16; idx += 256) {
+      const int j = c0 + (idx >> 4), d4 = (idx & 15) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(j < kv1 ? V1 + (long)j * ld1 + d4 : V2 + (long)(j - kv1) * ld2 + d4);
+      *reinterpret_cast<float4*>(kvs + (j - c0) * 64 + d4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PA_QB / 4; ++i) {
+      const int t = wave + 4 * i;
+      if (t < nq) {
+        const float* pr = ps + t * kv + c0;
+        float a = acc[i];
+        for (int j = 0; j < cn; ++j) a += pr[j] * kvs[j * 64 + lane];
+        acc[i] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PA_QB / 4; ++i) {
+    const int t = wave + 4 * i;
+    if (t < nq) O[b * o_bstride + (long)(q0 + t) * ldo + h * 64 + lane] = acc[i];
+  }
+}
+
 // q f32 [batch][q_len][ldq] (head h at column h*64), keys/values f32 in one or two segments (segment s: [batch][kv_s][ld_s], K and V
 // pointers already at their column offset), out f32 [batch][q_len][ldo].  open_clip MHA / PerceiverAttention (helpers.py:47-73).
 extern "C" int deer_attn_f32(const float* Q, const float* K1, const float* V1, const float* K2, const float* V2, float* O, int batch, int heads,
                              int q_len, int kv1, int kv2, int ldq, int ld1, int ld2, int ldo, long q_bstride, long bstride1, long bstride2,
                              long o_bstride, float scale, void* stream) {
   if (Q == nullptr || K1 == nullptr || V1 == nullptr || O == nullptr || batch <= 0 || heads <= 0 || q_len <= 0 || kv1 <= 0 || kv2 < 0 ||
-      kv1 + kv2 > PA_MAXKV || (kv2 > 0 && (K2 == nullptr || V2 == nullptr)) || (ldq & 3) || (ld1 & 3) || (ld2 & 3))
+      kv1 + kv2 > PAL_MAXKV || (kv2 > 0 && (K2 == nullptr || V2 == nullptr)) || (ldq & 3) || (ld1 & 3) || (ld2 & 3))
     return DEER_ERR_SHAPE;
   const int kv = kv1 + kv2;
+  if (kv > PA_MAXKV) {                                    // long key sequences: chunked K / V
+    const int smem_l = (PAL_CH * 65 + PA_QB * 64 + PA_QB * kv) * (int)sizeof(float);
+    static std::atomic<bool> attr_l{false};
+    if (!attr_l) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+        return DEER_ERR_LAUNCH;
+      attr_l = true;
+    }
+    if (smem_l > 156 * 1024) return DEER_ERR_SHAPE;
+    hipLaunchKernelGGL(attn_f32_long_kernel, dim3((q_len + PA_QB - 1) / PA_QB, heads, batch), dim3(256), smem_l, reinterpret_cast<hipStream_t>(stream), Q,
+                       K1, V1, K2, V2, O, q_len, kv1, kv2, ldq, ld1, ld2, ldo, q_bstride, bstride1, bstride2, o_bstride, scale);
+    DEER_LAUNCH_CHECK();
+    return DEER_OK;
+  }
   const int smem = (kv * 65 + PA_QB * 64 + PA_QB * kv) * (int)sizeof(float);
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {

@@ -170,7 +170,8 @@ int deer_slab_gelu_split(const float* slab, int s_in, long slab_stride, int gelu
 int deer_pack_weight_mfma16(const void* W, void* Wp, int N, int K, void* stream);  /* [N,K] -> [N/16][K/32][64][8] */
 
 /* ---- attention ----------------------------------------------------------------------------------------------
- * deer_attn_mfma_hd64: softmax(scale * Q K^T) V per (batch, head), head_dim 64, kv_len <= 320.  Replaces
+ * deer_attn_mfma_hd64: softmax(scale * Q K^T) V per (batch, head), head_dim 64, kv_len <= 320 (<= 576 for up to 64 queries per call: the two-segment
+ * form of pre fusion, 2 x 256 patch tokens + 64 latents, runs a 36-key-tile instantiation of the same kernel).  Replaces
  * nn.MultiheadAttention inside the open_clip ViT blocks and the einsum/softmax of PerceiverAttention
  * (helpers.py:53-63).  Q,K,V,O bf16 with row strides ld* and batch strides *_bstride (elements); head h lives at
  * column h*64. */
@@ -301,7 +302,7 @@ int deer_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const flo
                      int epi, void* stream);
 /* open_clip MHA core / PerceiverAttention core (helpers.py:47-73) in fp32: q [batch][q_len][ldq] (head h at column h*64), keys and
  * values in one or two segments ([batch][kv_s][ld_s], pointers at the K / V column offset), out f32 [batch][q_len][ldo].
- * head_dim 64, kv1 + kv2 <= 352. */
+ * head_dim 64, kv1 + kv2 <= 352 with the keys of a head resident in LDS; up to ~700 keys (pre fusion: 576) through a chunked form. */
 int deer_attn_f32(const float* Q, const float* K1, const float* V1, const float* K2, const float* V2, float* O, int batch, int heads,
                   int q_len, int kv1, int kv2, int ldq, int ld1, int ld2, int ldo, long q_bstride, long bstride1, long bstride2,
                   long o_bstride, float scale, void* stream);

@@ -371,17 +371,20 @@ def test_attn_mfma(lib, dt, B, H, q_len, kv_len):
     assert float((o.float() - ref).abs().max()) < (3e-2 if dt == "bf16" else 4e-3)
 
 
-@pytest.mark.parametrize("B,H,q_len,kv1,kv2", [(2, 8, 64, 256, 64), (1, 2, 16, 16, 16), (2, 2, 64, 17, 5), (1, 1, 5, 0, 33)])
-def test_attn_mfma_two_segments(lib, B, H, q_len, kv1, kv2):
+@pytest.mark.parametrize("B,H,q_len,kv1,kv2,dt", [(2, 8, 64, 256, 64, "bf16"), (1, 2, 16, 16, 16, "bf16"), (2, 2, 64, 17, 5, "bf16"), (1, 1, 5, 0, 33, "bf16"),
+                                                  # long key sequences (pre fusion: 2 x 256 patch tokens + 64 latents; the 36-tile instantiation)
+                                                  (2, 8, 64, 512, 64, "bf16"), (2, 8, 64, 512, 64, "f16"), (1, 2, 37, 300, 41, "f16"), (1, 1, 64, 321, 0 + 64, "bf16")])
+def test_attn_mfma_two_segments(lib, B, H, q_len, kv1, kv2, dt):
     """Perceiver attention over [media K/V ; latent K/V] without the concat; q|k|v of the latents share one buffer."""
     hd = 64
     inner = H * hd
-    qkv = dev(rnd(B, q_len, 3 * inner, seed=71), torch.bfloat16)           # kv2 == q_len in the Perceiver; general here
-    kv2buf = qkv if kv2 == q_len else dev(rnd(B, kv2, 3 * inner, seed=72), torch.bfloat16)
-    mkv = dev(rnd(B, max(kv1, 1), 2 * inner, seed=73), torch.bfloat16)
-    o = torch.zeros(B, q_len, inner, device="cuda", dtype=torch.bfloat16)
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    qkv = dev(rnd(B, q_len, 3 * inner, seed=71), tdt)           # kv2 == q_len in the Perceiver; general here
+    kv2buf = qkv if kv2 == q_len else dev(rnd(B, kv2, 3 * inner, seed=72), tdt)
+    mkv = dev(rnd(B, max(kv1, 1), 2 * inner, seed=73), tdt)
+    o = torch.zeros(B, q_len, inner, device="cuda", dtype=tdt)
     scale = hd ** -0.5
-    abi.check(lib.deer_attn_mfma_hd64_2seg(abi.ptr(qkv), abi.ptr(mkv), abi.ptr(mkv, inner * 2), abi.ptr(kv2buf, inner * 2),
+    abi.check((lib.deer_attn_f16_hd64_2seg if dt == "f16" else lib.deer_attn_mfma_hd64_2seg)(abi.ptr(qkv), abi.ptr(mkv), abi.ptr(mkv, inner * 2), abi.ptr(kv2buf, inner * 2),
                                            abi.ptr(kv2buf, 2 * inner * 2), abi.ptr(o), B, H, q_len, kv1, kv2, 3 * inner, 2 * inner,
                                            3 * inner, inner, q_len * 3 * inner, max(kv1, 1) * 2 * inner, kv2 * 3 * inner, q_len * inner,
                                            scale, st()), "attn 2seg")
@@ -392,8 +395,8 @@ def test_attn_mfma_two_segments(lib, B, H, q_len, kv1, kv2):
     kf = k.view(B, kv1 + kv2, H, hd).transpose(1, 2)
     vf = v.view(B, kv1 + kv2, H, hd).transpose(1, 2)
     ref = (torch.softmax(qf @ kf.transpose(-1, -2) * scale, -1) @ vf).transpose(1, 2).reshape(B, q_len, inner)
-    assert rel_err(o.float(), ref) < 8e-3
-    assert float((o.float() - ref).abs().max()) < 3e-2
+    assert rel_err(o.float(), ref) < (8e-3 if dt == "bf16" else 1e-3)
+    assert float((o.float() - ref).abs().max()) < (3e-2 if dt == "bf16" else 4e-3)
 
 
 def test_xattn_small(lib):
@@ -934,7 +937,8 @@ def test_gemm_f32_exact_products(lib, M, N, K, epi):
     assert rel_err(C, y) < 2e-6
 
 
-@pytest.mark.parametrize("q_len,kv1,kv2,heads,batch", [(257, 257, 0, 16, 2), (64, 256, 64, 8, 2), (5, 7, 0, 2, 1)])
+@pytest.mark.parametrize("q_len,kv1,kv2,heads,batch", [(257, 257, 0, 16, 2), (64, 256, 64, 8, 2), (5, 7, 0, 2, 1),
+                                                       (64, 512, 64, 8, 2), (33, 353, 0, 2, 1), (40, 300, 271, 1, 2)])   # > 352 keys: the chunked kernel
 def test_attn_f32_one_and_two_segments(lib, q_len, kv1, kv2, heads, batch):
     C = heads * 64
     q = dev(rnd(batch, q_len, C, seed=1))
