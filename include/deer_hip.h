@@ -170,8 +170,8 @@ int deer_slab_gelu_split(const float* slab, int s_in, long slab_stride, int gelu
 int deer_pack_weight_mfma16(const void* W, void* Wp, int N, int K, void* stream);  /* [N,K] -> [N/16][K/32][64][8] */
 
 /* ---- attention ----------------------------------------------------------------------------------------------
- * deer_attn_mfma_hd64: softmax(scale * Q K^T) V per (batch, head), head_dim 64, kv_len <= 320 (<= 576 for up to 64 queries per call: the two-segment
- * form of pre fusion, 2 x 256 patch tokens + 64 latents, runs a 36-key-tile instantiation of the same kernel).  Replaces
+ * deer_attn_mfma_hd64: softmax(scale * Q K^T) V per (batch, head), head_dim 64, kv_len <= 320 (<= 576 through a 36-key-tile instantiation of the same
+ * kernel, one workgroup per CU: pre fusion's two-segment call over 2 x 256 patch tokens + 64 latents).  Replaces
  * nn.MultiheadAttention inside the open_clip ViT blocks and the einsum/softmax of PerceiverAttention
  * (helpers.py:53-63).  Q,K,V,O bf16 with row strides ld* and batch strides *_bstride (elements); head h lives at
  * column h*64. */
