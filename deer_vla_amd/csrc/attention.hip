@@ -369,6 +369,7 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
   // long key sequences (pre fusion, flamingo_mpt.py:585-607: the 64 latents attend 2 x 256 patch tokens + themselves = 576 keys): the same
   // kernel with 36 key tiles in registers (144 score VGPRs; one workgroup per CU: 154 KB of LDS for K and V^T) - <= 64 queries, no extras
   const bool long_kv = kv_len > AM_MAXT * 16;
+  if (Q == nullptr || K == nullptr || V == nullptr || O == nullptr) return DEER_ERR_SHAPE;
   if (q_len <= 0 || kv_len <= 0 || kv_len > AM_MAXT_LONG * 16 || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3))
     return DEER_ERR_SHAPE;
   if (long_kv && (q_slabs > 0 || text_time != nullptr || out_is_f32 || ctl != nullptr)) return DEER_ERR_SHAPE;

@@ -129,7 +129,14 @@ def test_abi_rejects_bad_shapes(lib):
     torch.cuda.synchronize()
     assert lib.deer_gemm_skinny(None, 0, None, 0, 0, 0, None, None, 4, 60, 64, 1, None, st()) == 1       # N % 16
     assert lib.deer_gemm_bf16_nt(None, 8, 0, None, 8, None, None, 8, 0, 4, 16, 12, 1, 0, None, 0, None, st()) == 1   # K % 8
-    assert lib.deer_attn_mfma_hd64(None, None, None, None, 1, 1, 4, 400, 64, 64, 64, 64, 0, 0, 0, 0, 1.0, st()) == 1  # kv_len
+    q = torch.zeros(4, 64, device="cuda", dtype=torch.bfloat16)
+    kv = torch.zeros(640, 64, device="cuda", dtype=torch.bfloat16)
+    attn = lambda n, Q=q: lib.deer_attn_mfma_hd64(abi.ptr(Q) if Q is not None else None, abi.ptr(kv), abi.ptr(kv), abi.ptr(q), 1, 1, 4, n, 64, 64, 64, 64,
+                                                  0, 0, 0, 0, 1.0, st())
+    assert attn(576) == 0                                                                                 # 36 key tiles: the cap (pre fusion)
+    assert attn(577) == 1                                                                                 # kv_len
+    assert attn(400, None) == 1                                                                           # Q == NULL
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("M", [70, 96, 112, 128])
