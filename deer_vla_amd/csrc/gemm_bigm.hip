@@ -784,6 +784,266 @@ static int launch_frame8(const bf16_t* A, int lda, long strideA, const bf16_t* W
   return DEER_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// frame4 (round 6; prototyped as tools/frame4.hip): the frame tile on FOUR waves, 2 x 2, wave tile 128 rows x (TN x 16) columns
+// (BN = 32 TN: 256, 192 or 128) - 17 fragment reads per 8 TN + TN / 2 MFMAs and wave.  What the prototype measured about this shape:
+//  * with 256 threads per workgroup hipcc selects the AGPR form of the MFMA with dst != src C and copies every accumulator around every
+//    MFMA (2.5 v_accvgpr_* per MFMA in the loop): the MFMAs are asm statements with the accumulator TIED in the accumulator file
+//    ("+a"; TN = 8: all 256 of them).  Each accumulator is touched once per K-step (>= 34 MFMAs apart: no dependent-MFMA hazard);
+//    `s_nop 15` separates the last MFMA from the epilogue's reads.  The dealt-out tiles of the 17th row tile accumulate in VGPRs ("+v"),
+//    their W fragment chosen by v_cndmask (a branch on the wave row makes hipcc copy those accumulators with v_mov right behind the asm
+//    MFMAs, whose latency it does not know: stale values), s_nop 1 between the select and the MFMA;
+//  * one wave per SIMD: nothing else hides a wait.  The fragments of K-step kt+1 are read into a second register set while the MFMAs of
+//    K-step kt issue, in two batches (a wave has at most 15 LDS operations in flight), the batch the head of the next K-step needs LAST
+//    so that the compiler's lgkmcnt there is 0 and never lands behind new reads;
+//  * an LDS-DMA piece costs its wave ~60 issue cycles (MI355X_MICROARCH.md): as a burst behind the barrier they run while the matrix
+//    pipe is empty - dealt out one per MFMA group: c_fc at 16 frames 43.2 -> 40.4 us.
+// Same K order per output element as the 16-wave tile: bit-identical results (tests/test_hip_ops.py compares every element in both 16-bit
+// formats).  Measured (profiles/r06_g_*): the K loop is 19 % faster (26.1 against 32.2 us per 257 x 256 x 1024 tile); plain launches on
+// cold weights, 16 frames: c_fc 39.8 us against 44.4, in_proj 31.4 against 33.8, K = 4096 117 against 140; 32 frames (two rounds), graph
+// replay: c_fc 83.2 against 94.0, in_proj 61.4 against 66.8.  IN THE STEP it loses: with bias + QuickGELU on fp16 operands c_fc takes 53.0
+// us against 46.6, in_proj 38.7 against 35.8, the c_proj halves 48.8 against 47.0 (rocprofv3 kernel trace of the 8-environment step) and
+// `batched` goes from 1052-1061 to 1023-1024 env-steps/s: a lane holds 4 x the output tiles of the 16-wave kernel, so the epilogue is
+// straight-line code over 68 tiles on ONE wave per SIMD (the transcendentals of QuickGELU and the LDS staging are latency-, not
+// rate-bound there) and what the loop gains the epilogue gives back.  Shipped as tiles 76-79, selected only by DEER_GEMM_FRAME4=1 (or 2:
+// two-round launches only); the selector keeps the 16-wave tiles.
+template <bool F16>
+__device__ __forceinline__ void f4_mma_a(f32x4& acc, const bf16x8& w, const bf16x8& a) {
+  if constexpr (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
+}
+template <bool F16>
+__device__ __forceinline__ void f4_mma_v(f32x4& acc, const bf16x8& w, const bf16x8& a) {
+  if constexpr (F16) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+  else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+}
+
+template <int TN, int D, bool F16>
+__global__ __launch_bounds__(256) void gemm_frame4_kernel(const bf16_t* __restrict__ A, int lda, long strideA, const bf16_t* __restrict__ W,
+                                                           int ldw, long strideW, const float* __restrict__ bias, void* __restrict__ Cv, int ldc,
+                                                           long strideC, int M, int N, int K, int epi, const int* ctl) {
+  DEER_RETURN_IF_EXITED(ctl);
+  constexpr int NW = 4, BN = 32 * TN, CH = 17 + BN / 16, STAGE = CH * 1024, XT = TN / 2;
+  constexpr int CPW = (CH + NW - 1) / NW, N_HI = CH - (CPW - 1) * NW;
+  static_assert(TN == 8 || TN == 6 || TN == 4, "wave tile");
+  static_assert(D >= 3 && D * STAGE <= 160 * 1024 && (D - 2) * CPW <= 63 && CPW <= 9, "LDS / vmcnt field / DMA slots of a K-step");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c = lane & 15, g = lane >> 4;
+  const int tiles_n = N / BN, rows_n = gridDim.x / tiles_n;
+  int rt, ct;
+  {                                                          // XCD blocks, as in gemm_frame_kernel
+    int gr = 0, gc = 0;
+    long best = 1L << 60;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r_ = 1 << e, c_ = 8 >> e;
+      if (rows_n % r_ == 0 && tiles_n % c_ == 0) {
+        const long cost = (long)(rows_n / r_) * 257 + (long)(tiles_n / c_) * BN;
+        if (cost < best) { best = cost; gr = r_; gc = c_; }
+      }
+    }
+    const int bid = blockIdx.x, nb = gridDim.x;
+    if (gr != 0) {
+      const int xcd = bid & 7, idx = bid >> 3, bc = tiles_n / gc, br = rows_n / gr;
+      rt = (xcd / gc) * br + idx / bc;
+      ct = (xcd % gc) * bc + idx % bc;
+    } else {
+      const int xq = nb >> 3, xr = nb & 7, xcd = bid & 7;
+      const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+      rt = tile / tiles_n;
+      ct = tile % tiles_n;
+    }
+  }
+  const int m0 = rt * 257, n0 = ct * BN;
+  const int rows_valid = min(257, M - m0);
+  A += (long)blockIdx.z * strideA;
+  W += (long)blockIdx.z * strideW;
+
+  const int lr = lane >> 2;
+  const int ls = ((lane & 3) ^ ((0x1320 >> (((lr >> 2) & 3) * 4)) & 3)) * 8;
+  const bf16_t* base[CPW];
+  unsigned vo[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int q = min(wave + i * NW, CH - 1);
+    const bool is_a = q < 17;
+    base[i] = is_a ? A : W;
+    vo[i] = is_a ? (unsigned)(((long)min(m0 + q * 16 + lr, M - 1) * lda + ls) * 2) : (unsigned)(((long)min(n0 + (q - 17) * 16 + lr, N - 1) * ldw + ls) * 2);
+  }
+  const int nk = K >> 5;                                      // even (launcher)
+  f32x4 acc[TN][8], accx[XT];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int x = 0; x < XT; ++x) accx[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr_sw = (g ^ ((0x1320 >> (((c >> 2) & 3) * 4)) & 3)) << 4;
+  const int a_off = (wm * 128 + c) * 64 + fr_sw;
+  const int x_off = (256 + c) * 64 + fr_sw;
+  const int w_off = 17 * 1024 + (wn * TN * 16 + c) * 64 + fr_sw;
+
+  struct Frags { bf16x8 a[8], w[TN], x; };
+  auto load_frags_a = [&](Frags& F, int stage) {              // first batch: the extra row tile, A fragments 1..7
+    const unsigned char* st = smem + (stage % D) * STAGE;
+    F.x = *reinterpret_cast<const bf16x8*>(st + x_off);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) F.a[j] = *reinterpret_cast<const bf16x8*>(st + a_off + j * 1024);
+  };
+  auto load_frags_b = [&](Frags& F, int stage) {              // second batch: what the head of the next K-step needs
+    const unsigned char* st = smem + (stage % D) * STAGE;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) F.w[i] = *reinterpret_cast<const bf16x8*>(st + w_off + i * 1024);
+    F.a[0] = *reinterpret_cast<const bf16x8*>(st + a_off);
+  };
+  auto mma_j = [&](const Frags& F, int j) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) f4_mma_a<F16>(acc[i][j], F.w[i], F.a[j]);
+  };
+  auto mma_x = [&](const Frags& F) {
+#pragma unroll
+    for (int x = 0; x < XT; ++x) {
+      const bf16x8 wx = wm ? F.w[XT + x] : F.w[x];
+      f4_mma_v<F16>(accx[x], wx, F.x);
+    }
+  };
+  auto run = [&](auto cpw_tag) {
+    constexpr int CPWL = decltype(cpw_tag)::value;
+    auto issue_one = [&](int t, int i) {
+      if (i < CPWL) {
+        const int k0 = min(t, nk - 1) << 5;
+        f8_dma16(base[i], vo[i], k0 * 2, smem + (t % D) * STAGE + (wave + i * NW) * 1024);
+      }
+    };
+    auto half = [&](Frags& Fc, Frags& Fn, int kt) {
+      p8_wait_vmcnt<(D - 3) * CPWL>();                        // this wave's share of stage kt+1 has landed
+      __builtin_amdgcn_s_barrier();                           // ... everybody's; and every wave is done with the fragments of stage kt-1
+      const int t = kt + D - 1;                               // into the slot of stage kt-1
+      mma_j(Fc, 0);
+      asm volatile("" ::: "memory");                          // the reads below stay below the head
+      issue_one(t, 0); issue_one(t, 1);
+      load_frags_a(Fn, kt + 1);
+      mma_j(Fc, 1); issue_one(t, 2);
+      mma_j(Fc, 2); issue_one(t, 3);
+      mma_j(Fc, 3); issue_one(t, 4);
+      asm volatile("" ::: "memory");
+      load_frags_b(Fn, kt + 1);
+      mma_j(Fc, 4); issue_one(t, 5);
+      mma_j(Fc, 5); issue_one(t, 6);
+      mma_j(Fc, 6); issue_one(t, 7);
+      mma_j(Fc, 7); issue_one(t, 8);
+      mma_x(Fc);
+    };
+    Frags F0, F1;
+#pragma unroll
+    for (int t = 0; t < D - 1; ++t)
+#pragma unroll
+      for (int i = 0; i < CPWL; ++i) issue_one(t, i);
+    p8_wait_vmcnt<(D - 2) * CPWL>();
+    __builtin_amdgcn_s_barrier();
+    load_frags_a(F0, 0);
+    load_frags_b(F0, 0);
+    for (int kt = 0; kt < nk; kt += 2) {
+      half(F0, F1, kt);
+      half(F1, F0, kt + 1);
+    }
+    p8_wait_vmcnt<0>();
+    asm volatile("s_nop 15" ::: "memory");
+  };
+  if (wave < N_HI) run(std::integral_constant<int, CPW>{});
+  else run(std::integral_constant<int, CPW - 1>{});
+
+  // epilogue: 16-bit results (bias, QuickGELU / GELU) and f32 slabs (BN = 128) leave through LDS as whole lines, like the 16-wave kernel
+  constexpr int CPITCH = BN * 2 + 16, FPITCH = BN * 4 + 16;
+  constexpr bool F32_STAGE = 272 * FPITCH <= 160 * 1024;
+  static_assert(272 * CPITCH <= 160 * 1024, "C staging");
+  const bool f32_out = F32_STAGE && epi == P8_EPI_F32;        // the launcher refuses f32 results for the wider tiles
+  // one straight-line copy of the 8 TN + TN / 2 tile stores per activation (a lane holds 4 x as many tiles as in the 16-wave kernel: with
+  // the activation chosen per tile the epilogue alone is > 100 KB of code)
+  auto emit = [&](auto kind_tag) {
+    constexpr int KIND = decltype(kind_tag)::value;           // 0: 16-bit, 1: QuickGELU, 3: f32 (erf GELU is not a frame-shaped GEMM's epilogue: refused)
+    auto put = [&](int r, int n, const f32x4& a) {             // row r of the frame, columns n0 + n .. n0 + n + 3
+      float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3];
+      if (bias != nullptr) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + n);
+        v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+      }
+      if constexpr (KIND == 3) {
+        *reinterpret_cast<float4*>(smem + r * FPITCH + n * 4) = float4{v0, v1, v2, v3};
+      } else {
+        if constexpr (KIND == 1) {
+          v0 = quick_gelu_bf(v0); v1 = quick_gelu_bf(v1); v2 = quick_gelu_bf(v2); v3 = quick_gelu_bf(v3);
+        }
+        *reinterpret_cast<uint2*>(smem + r * CPITCH + n * 2) = uint2{pack2_epi<F16>(v0, v1, epi), pack2_epi<F16>(v2, v3, epi)};
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = (wn * TN + i) * 16 + g * 4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) put(wm * 128 + j * 16 + c, n, acc[i][j]);
+    }
+#pragma unroll
+    for (int x = 0; x < XT; ++x) put(256 + c, (wn * TN + wm * XT + x) * 16 + g * 4, accx[x]);
+  };
+  BIGM_SYNC();                                                 // every wave has read its last fragments: the ring becomes the C tile
+  if constexpr (F32_STAGE) {
+    if (f32_out) emit(std::integral_constant<int, 3>{});
+  }
+  if (!f32_out) {
+    if (epi == P8_EPI_QGELU_BF16) emit(std::integral_constant<int, 1>{});
+    else emit(std::integral_constant<int, 0>{});
+  }
+  BIGM_SYNC();
+  if (f32_out) {
+    constexpr int PPR = BN / 4;
+    const int pieces = rows_valid * PPR;
+    float* Cf = reinterpret_cast<float*>(Cv) + (long)blockIdx.z * strideC + (long)m0 * ldc + n0;
+    for (int p = tid; p < pieces; p += 256) {
+      const int r = p / PPR, cp = p - r * PPR;
+      *reinterpret_cast<uint4*>(Cf + (long)r * ldc + cp * 4) = *reinterpret_cast<const uint4*>(smem + r * FPITCH + cp * 16);
+    }
+  } else {
+    constexpr int PPR = BN / 8;
+    const int pieces = rows_valid * PPR;
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv) + (long)blockIdx.z * strideC + (long)m0 * ldc + n0;
+    for (int p = tid; p < pieces; p += 256) {
+      const int r = p / PPR, cp = p - r * PPR;
+      *reinterpret_cast<uint4*>(Cb + (long)r * ldc + cp * 8) = *reinterpret_cast<const uint4*>(smem + r * CPITCH + cp * 16);
+    }
+  }
+}
+
+template <bool F16, int TN, int D>
+static int launch_frame4(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C, int ldc,
+                         long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl, hipStream_t st) {
+  constexpr int BN = 32 * TN;
+  const bool to_bf16 = epi == P8_EPI_BF16 || epi == P8_EPI_QGELU_BF16 || epi == P8_EPI_BF16OUT;
+  const bool to_f32 = epi == P8_EPI_F32 && 272 * (BN * 4 + 16) <= 160 * 1024;
+  if ((N % BN) || (K & 63) || M <= 0 || (M % 257) || batch <= 0 || !(to_bf16 || to_f32)) return DEER_ERR_SHAPE;
+  // MUBUF byte offsets are 32 bits: every operand (one batch slice) has to end below 4 GiB
+  if ((long)M * lda * 2 >= (1L << 32) || (long)N * ldw * 2 >= (1L << 32)) return DEER_ERR_SHAPE;
+  constexpr int ring_bytes = D * (17 + BN / 16) * 1024, c_bytes = 272 * (BN * 2 + 16);
+  constexpr int f_bytes = 272 * (BN * 4 + 16) <= 160 * 1024 ? 272 * (BN * 4 + 16) : 0;
+  constexpr int rc_bytes = ring_bytes > c_bytes ? ring_bytes : c_bytes;
+  constexpr int smem_bytes = rc_bytes > f_bytes ? rc_bytes : f_bytes;
+  static std::atomic<bool> attr_set{false};
+  auto kern = &gemm_frame4_kernel<TN, D, F16>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes) != hipSuccess)
+      return DEER_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int tiles = (M / 257) * (N / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles, 1, batch), dim3(256), smem_bytes, st, A, lda, strideA, W, ldw, strideW, bias, C, ldc, strideC, M, N, K, epi,
+                     ctl);
+  DEER_LAUNCH_CHECK();
+  return DEER_OK;
+}
+
 template <bool F16, int BM, int BN, int D, bool STAG = false>
 static int launch_ring32(const bf16_t* A, int lda, long strideA, const bf16_t* W, int ldw, long strideW, const float* bias, void* C,
                          int ldc, long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl,
@@ -839,6 +1099,10 @@ int deer_launch_gemm_ring32(int variant, const bf16_t* A, int lda, long strideA,
     case 22: return launch_frame<F16, 2, 2, 4, 4>(P8_ARGS);      // 129 | 128 x 128, 8 waves (32 x 64 wave tiles), 68 KB
     case 23: return launch_frame8<F16, 8, 4>(P8_ARGS);           // frame8: 257 x 256, 8 waves (64 x 128 wave tiles), 132 KB
     case 24: return launch_frame8<F16, 6, 4>(P8_ARGS);           // frame8: 257 x 192, 8 waves (64 x 96 wave tiles), 116 KB
+    case 25: return launch_frame4<F16, 8, 4>(P8_ARGS);           // frame4: 257 x 256, 4 waves (128 x 128 wave tiles), 132 KB ring / 144 KB C tile
+    case 26: return launch_frame4<F16, 6, 4>(P8_ARGS);           // frame4: 257 x 192, 4 waves (128 x 96 wave tiles), 116 KB
+    case 27: return launch_frame4<F16, 4, 4>(P8_ARGS);           // frame4: 257 x 128, 4 waves (128 x 64 wave tiles), 100 KB ring / 144 KB f32 C tile
+    case 28: return launch_frame4<F16, 4, 6>(P8_ARGS);           // the same on a 150 KB ring
     default: return DEER_ERR_SHAPE;
   }
 #undef P8_ARGS

@@ -443,10 +443,14 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
       };
       // DEER_GEMM_FRAME8=1: the same tiles on eight waves (csrc/gemm_bigm.hip: gemm_frame8_kernel)
       static const bool frame8 = [] { const char* e = getenv("DEER_GEMM_FRAME8"); return e != nullptr && e[0] == '1'; }();
-      if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16 || epi == EPI_BF16OUT) && one_round(192)) tile = frame8 ? 75 : 64;
-      else if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16 || epi == EPI_BF16OUT) && one_round(256)) tile = frame8 ? 74 : 63;
+      // DEER_GEMM_FRAME4=1 (or 2: only where the launch is TWO rounds of workgroups): the same tiles on four waves (gemm_frame4_kernel,
+      // round 6: bit-identical results; 16-bit / QuickGELU epilogues and the f32 slabs of the 257 x 128 tile, K-steps in pairs)
+      static const int frame4 = [] { const char* e = getenv("DEER_GEMM_FRAME4"); return e != nullptr ? atoi(e) : 0; }();
+      auto f4 = [&](int bn) { return (K & 63) == 0 && epi != EPI_GELU_BF16 && (frame4 == 1 || (frame4 == 2 && frames * (N / bn) * batch == 512)); };
+      if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16 || epi == EPI_BF16OUT) && one_round(192)) tile = f4(192) ? 77 : frame8 ? 75 : 64;
+      else if (sel256 && big_sel && (K & 31) == 0 && (epi == EPI_BF16 || epi == EPI_QGELU_BF16 || epi == EPI_GELU_BF16 || epi == EPI_BF16OUT) && one_round(256)) tile = f4(256) ? 76 : frame8 ? 74 : 63;
       // ... and the K halves of c_proj (f32 slabs, N = 1024) as 257 x 128 tiles: 16 frames x 8 x 2 = 256 workgroups, 49.8 -> 43.1 us
-      else if (sel256 && big_sel && (K & 31) == 0 && epi == EPI_F32 && one_round(128)) tile = 67;
+      else if (sel256 && big_sel && (K & 31) == 0 && epi == EPI_F32 && one_round(128)) tile = f4(128) ? 78 : 67;
       else if (sel256 && big_sel && (N & 255) == 0 && (K & 31) == 0 && n256 >= 192 && n256 <= 256) tile = 61;
       else if (big_sel && N <= 1024 && batch == 1) tile = 17;   // out_proj at 16 frames: 264 128x128 tiles sit two per CU (17.5 us; 192-row tiles 19.9)
       else if (big_sel) {
@@ -513,6 +517,7 @@ static int gemm_dispatch(const void* A, int lda, long strideA, const void* W, in
     case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71:                                     // one camera frame per row tile, balanced (csrc/gemm_bigm.hip)
     case 72: case 73:                                                                                                    // half a frame per row tile
     case 74: case 75:                                                                                                    // frame8: one frame per row tile on eight waves (round 5)
+    case 76: case 77: case 78: case 79:                                                                                  // frame4: one frame per row tile on four waves (round 6)
       return deer_launch_gemm_ring32<F16>(tile - 51, DEER_ARGS);
     case 26: return launch_ring<F16, 64, 64, 2, 4, 4, 0, 1, 1>(DEER_ARGS);    // register-pipelined K loop (fragments of k+1 read under the MFMAs of k)
     case 24: return launch_ring<F16, 64, 64, 2, 4, 4, 1>(DEER_ARGS);   // ablations (tools/bench_gemm.py)

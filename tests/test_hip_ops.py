@@ -247,13 +247,14 @@ def test_skinny_hl_producers_and_exit_flag(lib):
 
 
 # ------------------------------------------------------------------------------------------- tiled GEMM
-BIG_TILES = [17, 39, 45, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74, 75]
+BIG_TILES = [17, 39, 45, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79]
 # every tile on the 16-frame batch (whole frames) and on a small ragged M; the selector (tile 0) and the tiles it picks on the 8 / 12-frame
 # batches and on a power-of-two M; the fp16 instantiation (round 6: the vision tower's fp16 arithmetic) on the selector and on one tile of
 # every kernel of csrc/gemm_bigm.hip + the 128x128 ring of csrc/gemm_tiled.hip
 BIG_CASES = ([("bf16", t, M) for t in BIG_TILES for M in (4112, 300)] + [("bf16", 0, M) for M in (2056, 3084, 4112, 4096, 300)] +
              [("bf16", t, M) for t in (17, 39, 45, 63, 64, 67) for M in (2056, 3084)] +
-             [("f16", t, M) for t in (0, 17, 39, 51, 57, 63, 64, 67, 72, 74, 75) for M in (4112, 300)] + [("f16", 0, M) for M in (2056, 3084)])
+             [("f16", t, M) for t in (0, 17, 39, 51, 57, 63, 64, 67, 72, 74, 75) for M in (4112, 300)] + [("f16", 0, M) for M in (2056, 3084)] +
+             [(dt, t, M) for dt in ("bf16", "f16") for t in (76, 77, 78) for M in (3084, 8224)] + [("f16", t, 4112) for t in (76, 77, 78, 79)])
 
 
 @pytest.mark.parametrize("dt,tile,M", BIG_CASES)
@@ -266,6 +267,8 @@ def test_gemm_tiled_big_m_tiles(lib, dt, tile, M, N, K, epi):
         pytest.skip("192-column frame tiles")
     if tile in (74, 75) and (epi == "f32" or M % 257):
         pytest.skip("frame8 tiles (eight waves, csrc/gemm_bigm.hip: gemm_frame8_kernel): whole camera frames, bf16 epilogues only")
+    if tile in (76, 77, 78, 79) and (M % 257 or (tile == 77 and N % 192) or (tile in (76, 77) and epi == "f32")):
+        pytest.skip("frame4 tiles (four waves, csrc/gemm_bigm.hip: gemm_frame4_kernel): whole camera frames; f32 slabs from the 128-column tile only")
     tdt, sfx = _fmt(dt)
     A = dev(rnd(M, K, seed=61), tdt)
     W = dev(rnd(N, K, seed=62, scale=K ** -0.5), tdt)
@@ -283,6 +286,51 @@ def test_gemm_tiled_big_m_tiles(lib, dt, tile, M, N, K, epi):
         assert rel_err(C[:M].float(), ref) < tol16
     else:
         assert rel_err(C[:M].float(), ref * torch.sigmoid(1.702 * ref)) < (tol16 if dt == "bf16" else 1e-3)   # quick_gelu_bf: v_exp + v_rcp
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("t4,t16,N,K,epi,batch", [(76, 63, 4096, 1024, "qgelu", 1), (77, 64, 3072, 1024, "bf16", 1), (78, 67, 1024, 2048, "f32", 2), (79, 67, 1024, 2048, "f32", 2),
+                                                  (76, 63, 1024, 1024, "bf16out", 1), (78, 67, 1024, 1024, "bf16", 1)])
+@pytest.mark.parametrize("M", [4112, 3084, 8224])
+def test_gemm_frame4_bit_identical_to_the_16_wave_frame_tile(lib, dt, t4, t16, N, K, epi, batch, M):
+    """The four-wave frame tile (round 6: asm MFMAs with the accumulators tied in AGPRs, fragments of the next K-step read under the MFMAs
+    of the current one) walks K in the same order per output element as the 16-wave tile it replaces in the selector: identical bits for
+    every epilogue it takes (16-bit, QuickGELU, bf16-out, f32 slabs of K halves through blockIdx.z), at 12 / 16 / 32 frames."""
+    tdt, sfx = _fmt(dt)
+    A = dev(rnd(M, K * batch, seed=71), tdt)
+    W = dev(rnd(N, K * batch, seed=72, scale=(K * batch) ** -0.5), tdt)
+    bias = None if epi == "f32" else dev(rnd(N, seed=73, scale=0.1))
+    e = {"bf16": abi.EPI_BF16, "qgelu": abi.EPI_QGELU_BF16, "f32": abi.EPI_F32, "bf16out": abi.EPI_BF16OUT}[epi]
+    odt = torch.float32 if epi == "f32" else (torch.bfloat16 if epi == "bf16out" else tdt)
+    out = []
+    for tile in (t4, t16):
+        C = torch.full((batch, M + 8, N), float("nan"), device="cuda", dtype=odt)
+        abi.check(getattr(lib, f"deer_gemm_{sfx}_nt_wbatch")(abi.ptr(A), K * batch, K, abi.ptr(W), K * batch, K, abi.ptr(bias), abi.ptr(C), N, (M + 8) * N, M, N, K,
+                                                             batch, e, tile, None, st()), "gemm")
+        torch.cuda.synchronize()
+        assert torch.isnan(C[:, M:].float()).all() and torch.isfinite(C[:, :M].float()).all()
+        out.append(C[:, :M].clone())
+    assert torch.equal(out[0], out[1])
+    ref = sum(A[:, z * K:(z + 1) * K].float() @ W[:, z * K:(z + 1) * K].float().t() for z in range(batch))
+    if epi == "f32":
+        assert rel_err(out[0].sum(0), ref) < 2e-5
+
+
+def test_gemm_frame4_respects_exit_flag_and_refuses_what_it_does_not_take(lib):
+    M, N, K = 4112, 1024, 1024
+    A = dev(rnd(M, K, seed=74), torch.bfloat16)
+    W = dev(rnd(N, K, seed=75, scale=K ** -0.5), torch.bfloat16)
+    C = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+    ctl = torch.zeros(abi.CTL_WORDS, dtype=torch.int32, device="cuda")
+    ctl[abi.CTL_ALL_EXITED] = 1
+    call = lambda m, k, e, t, c=None: lib.deer_gemm_bf16_nt(abi.ptr(A), K, 0, abi.ptr(W), K, None, abi.ptr(C), N, 0, m, N, k, 1, e, None, t, abi.ptr(c), st())
+    assert call(M, K, abi.EPI_BF16, 76, ctl) == 0
+    torch.cuda.synchronize()
+    assert float(C.float().min()) == 7.0 and float(C.float().max()) == 7.0          # every environment has exited: nothing runs
+    assert call(M, K, abi.EPI_GELU_BF16, 76) == 1                                       # erf GELU: not a frame-shaped GEMM's epilogue
+    assert call(M, K, abi.EPI_F32, 76) == 1                                             # f32 slabs: the 128-column tile only
+    assert call(M - 1, K, abi.EPI_BF16, 76) == 1                                        # whole frames only
+    assert call(M, 32 * 31, abi.EPI_BF16, 76) == 1                                      # K-steps in pairs
 
 
 @pytest.mark.parametrize("M", [2056, 4112])
