@@ -956,64 +956,68 @@ __global__ __launch_bounds__(256) void gemm_frame4_kernel(const bf16_t* __restri
   if (wave < N_HI) run(std::integral_constant<int, CPW>{});
   else run(std::integral_constant<int, CPW - 1>{});
 
-  // epilogue: 16-bit results (bias, QuickGELU / GELU) and f32 slabs (BN = 128) leave through LDS as whole lines, like the 16-wave kernel
-  constexpr int CPITCH = BN * 2 + 16, FPITCH = BN * 4 + 16;
-  constexpr bool F32_STAGE = 272 * FPITCH <= 160 * 1024;
-  static_assert(272 * CPITCH <= 160 * 1024, "C staging");
-  const bool f32_out = F32_STAGE && epi == P8_EPI_F32;        // the launcher refuses f32 results for the wider tiles
-  // one straight-line copy of the 8 TN + TN / 2 tile stores per activation (a lane holds 4 x as many tiles as in the 16-wave kernel: with
-  // the activation chosen per tile the epilogue alone is > 100 KB of code)
-  auto emit = [&](auto kind_tag) {
-    constexpr int KIND = decltype(kind_tag)::value;           // 0: 16-bit, 1: QuickGELU, 3: f32 (erf GELU is not a frame-shaped GEMM's epilogue: refused)
-    auto put = [&](int r, int n, const f32x4& a) {             // row r of the frame, columns n0 + n .. n0 + n + 3
-      float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3];
-      if (bias != nullptr) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + n);
-        v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
-      }
-      if constexpr (KIND == 3) {
-        *reinterpret_cast<float4*>(smem + r * FPITCH + n * 4) = float4{v0, v1, v2, v3};
-      } else {
-        if constexpr (KIND == 1) {
-          v0 = quick_gelu_bf(v0); v1 = quick_gelu_bf(v1); v2 = quick_gelu_bf(v2); v3 = quick_gelu_bf(v3);
-        }
-        *reinterpret_cast<uint2*>(smem + r * CPITCH + n * 2) = uint2{pack2_epi<F16>(v0, v1, epi), pack2_epi<F16>(v2, v3, epi)};
-      }
-    };
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int n = (wn * TN + i) * 16 + g * 4;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) put(wm * 128 + j * 16 + c, n, acc[i][j]);
-    }
-#pragma unroll
-    for (int x = 0; x < XT; ++x) put(256 + c, (wn * TN + wm * XT + x) * 16 + g * 4, accx[x]);
-  };
+  // epilogue.  A lane holds 8 TN + TN / 2 output tiles (4 x the 16-wave kernel's): bias / activation / pack / staging as straight-line code
+  // over them on ONE wave per SIMD is latency-bound and gave back more than the loop gains (first form of this kernel, c_fc in the step
+  // 53.0 us against 46.6).  Here the RAW f32 accumulators of one wave row (128 frame rows; with the second row also the frame's 257th
+  // row) go to LDS, and all four waves run a rolled loop over the f32 half tile: bias, activation, 16-bit pack (or f32), whole-line
+  // stores.  Same arithmetic per element as the other frame tiles: bit-identical results.
+  constexpr int FP = BN * 4 + 16;                             // f32 row pitch: ds_write_b128 of a 16 x 16 tile conflict-free (as FPITCH of gemm_frame_kernel)
+  static_assert(129 * FP <= 160 * 1024, "f32 half tile");
+  const bool f32_out = epi == P8_EPI_F32;
   BIGM_SYNC();                                                 // every wave has read its last fragments: the ring becomes the C tile
-  if constexpr (F32_STAGE) {
-    if (f32_out) emit(std::integral_constant<int, 3>{});
-  }
-  if (!f32_out) {
-    if (epi == P8_EPI_QGELU_BF16) emit(std::integral_constant<int, 1>{});
-    else emit(std::integral_constant<int, 0>{});
-  }
-  BIGM_SYNC();
-  if (f32_out) {
-    constexpr int PPR = BN / 4;
-    const int pieces = rows_valid * PPR;
-    float* Cf = reinterpret_cast<float*>(Cv) + (long)blockIdx.z * strideC + (long)m0 * ldc + n0;
-    for (int p = tid; p < pieces; p += 256) {
-      const int r = p / PPR, cp = p - r * PPR;
-      *reinterpret_cast<uint4*>(Cf + (long)r * ldc + cp * 4) = *reinterpret_cast<const uint4*>(smem + r * FPITCH + cp * 16);
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if (wm == h) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          *reinterpret_cast<f32x4*>(smem + (j * 16 + c) * FP + ((wn * TN + i) * 16 + g * 4) * 4) = acc[i][j];
     }
-  } else {
-    constexpr int PPR = BN / 8;
-    const int pieces = rows_valid * PPR;
-    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv) + (long)blockIdx.z * strideC + (long)m0 * ldc + n0;
-    for (int p = tid; p < pieces; p += 256) {
-      const int r = p / PPR, cp = p - r * PPR;
-      *reinterpret_cast<uint4*>(Cb + (long)r * ldc + cp * 8) = *reinterpret_cast<const uint4*>(smem + r * CPITCH + cp * 16);
+    if (h == 1) {                                             // row 256 of the frame = row 128 of the second half tile (lanes c = 0)
+#pragma unroll
+      for (int x = 0; x < XT; ++x)
+        if (c == 0) *reinterpret_cast<f32x4*>(smem + 128 * FP + ((wn * TN + wm * XT + x) * 16 + g * 4) * 4) = accx[x];
     }
+    BIGM_SYNC();
+    const int rows = min(h == 0 ? 128 : 129, rows_valid - h * 128);
+    const long crow = (long)blockIdx.z * strideC + (long)(m0 + h * 128) * ldc + n0;
+    if (f32_out) {
+      constexpr int PPR = BN / 4;
+      float* Cf = reinterpret_cast<float*>(Cv) + crow;
+      for (int p = tid; p < rows * PPR; p += 256) {
+        const int r = p / PPR, cp = p - r * PPR;
+        float4 v = *reinterpret_cast<const float4*>(smem + r * FP + cp * 16);
+        if (bias != nullptr) {
+          const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + cp * 4);
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        }
+        *reinterpret_cast<float4*>(Cf + (long)r * ldc + cp * 4) = v;
+      }
+    } else {
+      constexpr int PPR = BN / 8;                             // 16-byte output pieces (8 columns) per row
+      bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv) + crow;
+      const bool qg = epi == P8_EPI_QGELU_BF16;
+#pragma unroll 2
+      for (int p = tid; p < rows * PPR; p += 256) {
+        const int r = p / PPR, cp = p - r * PPR;
+        float4 a = *reinterpret_cast<const float4*>(smem + r * FP + cp * 32);
+        float4 b = *reinterpret_cast<const float4*>(smem + r * FP + cp * 32 + 16);
+        if (bias != nullptr) {
+          const float4 ba = *reinterpret_cast<const float4*>(bias + n0 + cp * 8);
+          const float4 bb = *reinterpret_cast<const float4*>(bias + n0 + cp * 8 + 4);
+          a.x += ba.x; a.y += ba.y; a.z += ba.z; a.w += ba.w;
+          b.x += bb.x; b.y += bb.y; b.z += bb.z; b.w += bb.w;
+        }
+        if (qg) {
+          a.x = quick_gelu_bf(a.x); a.y = quick_gelu_bf(a.y); a.z = quick_gelu_bf(a.z); a.w = quick_gelu_bf(a.w);
+          b.x = quick_gelu_bf(b.x); b.y = quick_gelu_bf(b.y); b.z = quick_gelu_bf(b.z); b.w = quick_gelu_bf(b.w);
+        }
+        *reinterpret_cast<uint4*>(Cb + (long)r * ldc + cp * 8) =
+            uint4{pack2_epi<F16>(a.x, a.y, epi), pack2_epi<F16>(a.z, a.w, epi), pack2_epi<F16>(b.x, b.y, epi), pack2_epi<F16>(b.z, b.w, epi)};
+      }
+    }
+    if (h == 0) BIGM_SYNC();                                  // the first half tile has been read: the second one may overwrite it
   }
 }
 
@@ -1022,14 +1026,12 @@ static int launch_frame4(const bf16_t* A, int lda, long strideA, const bf16_t* W
                          long strideC, int M, int N, int K, int batch, int epi, const float* gate, const int* ctl, hipStream_t st) {
   constexpr int BN = 32 * TN;
   const bool to_bf16 = epi == P8_EPI_BF16 || epi == P8_EPI_QGELU_BF16 || epi == P8_EPI_BF16OUT;
-  const bool to_f32 = epi == P8_EPI_F32 && 272 * (BN * 4 + 16) <= 160 * 1024;
+  const bool to_f32 = epi == P8_EPI_F32;
   if ((N % BN) || (K & 63) || M <= 0 || (M % 257) || batch <= 0 || !(to_bf16 || to_f32)) return DEER_ERR_SHAPE;
   // MUBUF byte offsets are 32 bits: every operand (one batch slice) has to end below 4 GiB
   if ((long)M * lda * 2 >= (1L << 32) || (long)N * ldw * 2 >= (1L << 32)) return DEER_ERR_SHAPE;
-  constexpr int ring_bytes = D * (17 + BN / 16) * 1024, c_bytes = 272 * (BN * 2 + 16);
-  constexpr int f_bytes = 272 * (BN * 4 + 16) <= 160 * 1024 ? 272 * (BN * 4 + 16) : 0;
-  constexpr int rc_bytes = ring_bytes > c_bytes ? ring_bytes : c_bytes;
-  constexpr int smem_bytes = rc_bytes > f_bytes ? rc_bytes : f_bytes;
+  constexpr int ring_bytes = D * (17 + BN / 16) * 1024, c_bytes = 129 * (BN * 4 + 16);     // the ring, then an f32 half tile
+  constexpr int smem_bytes = ring_bytes > c_bytes ? ring_bytes : c_bytes;
   static std::atomic<bool> attr_set{false};
   auto kern = &gemm_frame4_kernel<TN, D, F16>;
   if (!attr_set) {

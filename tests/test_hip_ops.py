@@ -267,8 +267,8 @@ def test_gemm_tiled_big_m_tiles(lib, dt, tile, M, N, K, epi):
         pytest.skip("192-column frame tiles")
     if tile in (74, 75) and (epi == "f32" or M % 257):
         pytest.skip("frame8 tiles (eight waves, csrc/gemm_bigm.hip: gemm_frame8_kernel): whole camera frames, bf16 epilogues only")
-    if tile in (76, 77, 78, 79) and (M % 257 or (tile == 77 and N % 192) or (tile in (76, 77) and epi == "f32")):
-        pytest.skip("frame4 tiles (four waves, csrc/gemm_bigm.hip: gemm_frame4_kernel): whole camera frames; f32 slabs from the 128-column tile only")
+    if tile in (76, 77, 78, 79) and (M % 257 or (tile == 77 and N % 192)):
+        pytest.skip("frame4 tiles (four waves, csrc/gemm_bigm.hip: gemm_frame4_kernel): whole camera frames")
     tdt, sfx = _fmt(dt)
     A = dev(rnd(M, K, seed=61), tdt)
     W = dev(rnd(N, K, seed=62, scale=K ** -0.5), tdt)
@@ -290,12 +290,13 @@ def test_gemm_tiled_big_m_tiles(lib, dt, tile, M, N, K, epi):
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("t4,t16,N,K,epi,batch", [(76, 63, 4096, 1024, "qgelu", 1), (77, 64, 3072, 1024, "bf16", 1), (78, 67, 1024, 2048, "f32", 2), (79, 67, 1024, 2048, "f32", 2),
-                                                  (76, 63, 1024, 1024, "bf16out", 1), (78, 67, 1024, 1024, "bf16", 1)])
+                                                  (76, 63, 1024, 1024, "bf16out", 1), (78, 67, 1024, 1024, "bf16", 1), (76, 63, 1024, 1024, "f32", 1), (77, 64, 3072, 1024, "f32", 1)])
 @pytest.mark.parametrize("M", [4112, 3084, 8224])
 def test_gemm_frame4_bit_identical_to_the_16_wave_frame_tile(lib, dt, t4, t16, N, K, epi, batch, M):
     """The four-wave frame tile (round 6: asm MFMAs with the accumulators tied in AGPRs, fragments of the next K-step read under the MFMAs
     of the current one) walks K in the same order per output element as the 16-wave tile it replaces in the selector: identical bits for
-    every epilogue it takes (16-bit, QuickGELU, bf16-out, f32 slabs of K halves through blockIdx.z), at 12 / 16 / 32 frames."""
+    every epilogue it takes (16-bit, QuickGELU, bf16-out, f32 / f32 slabs of K halves through blockIdx.z; bias where the 16-bit forms have
+    one), at 12 / 16 / 32 frames."""
     tdt, sfx = _fmt(dt)
     A = dev(rnd(M, K * batch, seed=71), tdt)
     W = dev(rnd(N, K * batch, seed=72, scale=(K * batch) ** -0.5), tdt)
@@ -328,7 +329,6 @@ def test_gemm_frame4_respects_exit_flag_and_refuses_what_it_does_not_take(lib):
     torch.cuda.synchronize()
     assert float(C.float().min()) == 7.0 and float(C.float().max()) == 7.0          # every environment has exited: nothing runs
     assert call(M, K, abi.EPI_GELU_BF16, 76) == 1                                       # erf GELU: not a frame-shaped GEMM's epilogue
-    assert call(M, K, abi.EPI_F32, 76) == 1                                             # f32 slabs: the 128-column tile only
     assert call(M - 1, K, abi.EPI_BF16, 76) == 1                                        # whole frames only
     assert call(M, 32 * 31, abi.EPI_BF16, 76) == 1                                      # K-steps in pairs
 
