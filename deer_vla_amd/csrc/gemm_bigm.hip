@@ -803,10 +803,11 @@ static int launch_frame8(const bf16_t* A, int lda, long strideA, const bf16_t* W
 // cold weights, 16 frames: c_fc 39.8 us against 44.4, in_proj 31.4 against 33.8, K = 4096 117 against 140; 32 frames (two rounds), graph
 // replay: c_fc 83.2 against 94.0, in_proj 61.4 against 66.8.  IN THE STEP it loses: with bias + QuickGELU on fp16 operands c_fc takes 53.0
 // us against 46.6, in_proj 38.7 against 35.8, the c_proj halves 48.8 against 47.0 (rocprofv3 kernel trace of the 8-environment step) and
-// `batched` goes from 1052-1061 to 1023-1024 env-steps/s: a lane holds 4 x the output tiles of the 16-wave kernel, so the epilogue is
+// `batched` goes from 1052-1061 to 1023-1024 env-steps/s: a lane holds 4 x the output tiles of the 16-wave kernel, so the epilogue was
 // straight-line code over 68 tiles on ONE wave per SIMD (the transcendentals of QuickGELU and the LDS staging are latency-, not
-// rate-bound there) and what the loop gains the epilogue gives back.  Shipped as tiles 76-79, selected only by DEER_GEMM_FRAME4=1 (or 2:
-// two-round launches only); the selector keeps the 16-wave tiles.
+// rate-bound there) and what the loop gains the epilogue gave back.  With the rolled epilogue below (f32 half tiles through LDS) the
+// deficit halves: c_fc 52.3 against 49.2, in_proj 39.7 against 37.5, c_proj halves 49.1 against 48.8 (another box).  Shipped as tiles
+// 76-79, selected only by DEER_GEMM_FRAME4=1 (or 2: two-round launches only); the selector keeps the 16-wave tiles.
 template <bool F16>
 __device__ __forceinline__ void f4_mma_a(f32x4& acc, const bf16x8& w, const bf16x8& a) {
   if constexpr (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
