@@ -222,11 +222,16 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_mfma_kernel(const void* __res
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
-template <int NWAVE, bool LOOP, int NT, bool F16>     // NT = key tiles of 16 (kv_len <= 16 NT); PV runs (NT + 1) / 2 chunks of 32 keys
-__global__ __launch_bounds__(64 * NWAVE, 4) void attn_vit_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
+// SEG2 (round 6): keys [0, kv1) from (Kp, V), keys [kv1, kv_len) from (K2, V2) with their own row pitch / batch stride - the Perceiver's
+// [media K/V ; latent K/V] (helpers.py:51 without the concat) at 64 latents x (256 + 64) keys: NT = 20, four waves, MINW = 2 (20 K / V pieces
+// + 20 score tiles per lane need more than 128 VGPRs); was attn_mfma_kernel (transposing V stores): 12.3 us per launch
+template <int NWAVE, bool LOOP, int NT, bool F16, bool SEG2 = false, int MINW = 4>     // NT = key tiles of 16 (kv_len <= 16 NT); PV runs (NT + 1) / 2 chunks of 32 keys
+__global__ __launch_bounds__(64 * NWAVE, MINW) void attn_vit_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
                                                               const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int q_len, int kv_len,
                                                               int ldq, int ldk, int ldv, int ldo, long q_bstride, long k_bstride,
-                                                              long v_bstride, long o_bstride, float scale_log2e, int tpw) {
+                                                              long v_bstride, long o_bstride, float scale_log2e, int tpw,
+                                                              const bf16_t* __restrict__ K2, const bf16_t* __restrict__ V2, int kv1, int ld2,
+                                                              long bstride2) {
   constexpr int KROWS = NT * 16, NCH = (NT + 1) / 2, VROWS = NCH * 32;
   constexpr int NPIECE = (KROWS + VROWS) * 8, PER = (NPIECE + 64 * NWAVE - 1) / (64 * NWAVE);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -247,10 +252,14 @@ __global__ __launch_bounds__(64 * NWAVE, 4) void attn_vit_kernel(const bf16_t* _
     piece[i] = uint4{0, 0, 0, 0};
     if (p < KROWS * 8) {
       const int row = p >> 3, seg = p & 7;
-      if (row < kv_len) piece[i] = *reinterpret_cast<const uint4*>(Kb + (long)row * ldk + seg * 8);
+      if (SEG2 && row >= kv1) {
+        if (row < kv_len) piece[i] = *reinterpret_cast<const uint4*>(K2 + b * bstride2 + h * AM_HD + (long)(row - kv1) * ld2 + seg * 8);
+      } else if (row < kv_len) piece[i] = *reinterpret_cast<const uint4*>(Kb + (long)row * ldk + seg * 8);
     } else if (p < NPIECE) {
       const int row = (p - KROWS * 8) >> 3, seg = p & 7;
-      if (row < kv_len) piece[i] = *reinterpret_cast<const uint4*>(Vb + (long)row * ldv + seg * 8);
+      if (SEG2 && row >= kv1) {
+        if (row < kv_len) piece[i] = *reinterpret_cast<const uint4*>(V2 + b * bstride2 + h * AM_HD + (long)(row - kv1) * ld2 + seg * 8);
+      } else if (row < kv_len) piece[i] = *reinterpret_cast<const uint4*>(Vb + (long)row * ldv + seg * 8);
     }
   }
   bf16x8 qf[2];
@@ -344,18 +353,19 @@ __global__ __launch_bounds__(64 * NWAVE, 4) void attn_vit_kernel(const bf16_t* _
   }
 }
 
-template <int NWAVE, bool LOOP, int NT, bool F16>
+template <int NWAVE, bool LOOP, int NT, bool F16, bool SEG2 = false, int MINW = 4>
 static int launch_attn_vit_nt(dim3 grid, hipStream_t st, const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, int q_len, int kv_len, int ldq,
-                              int ldk, int ldv, int ldo, long q_bstride, long k_bstride, long v_bstride, long o_bstride, float scale, int tpw) {
+                              int ldk, int ldv, int ldo, long q_bstride, long k_bstride, long v_bstride, long o_bstride, float scale, int tpw,
+                              const bf16_t* K2 = nullptr, const bf16_t* V2 = nullptr, int kv1 = 0, int ld2 = 0, long bstride2 = 0) {
   constexpr int smem = (NT * 16 + ((NT + 1) / 2) * 32) * AM_KPITCH * 2;
   static std::atomic<bool> attr_set{false};
-  auto kern = &attn_vit_kernel<NWAVE, LOOP, NT, F16>;
+  auto kern = &attn_vit_kernel<NWAVE, LOOP, NT, F16, SEG2, MINW>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return DEER_ERR_LAUNCH;
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, grid, dim3(64 * NWAVE), smem, st, Q, K, V, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride,
-                     scale * 1.4426950408889634f, tpw);
+                     scale * 1.4426950408889634f, tpw, K2, V2, kv1, ld2, bstride2);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }
@@ -443,6 +453,11 @@ static int launch_attn_mfma(const void* Q, const void* K, const void* V, void* O
     return tpw != nwave ? launch_attn_vit_nt<8, true, 17, F16>(DEER_VIT_ARGS) : launch_attn_vit_nt<8, false, 17, F16>(DEER_VIT_ARGS);
 #undef DEER_VIT_ARGS
   }
+  // Perceiver attention (64 latents over [256 media tokens ; 64 latents] = 20 key tiles, two segments): the same restructured kernel
+  if (vit_ok && !wide && K2 != nullptr && q_slabs == 0 && text_time == nullptr && !out_is_f32 && ctl == nullptr && (kv_len + 15) / 16 == 20 &&
+      kv_len > 16 * 19 && tpw == nwave)
+    return launch_attn_vit_nt<4, false, 20, F16, true, 2>(grid, st, reinterpret_cast<const bf16_t*>(Q), kp, vp, reinterpret_cast<bf16_t*>(O), q_len, kv_len, ldq,
+                                                          ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride, scale, tpw, k2, v2, kv1, ld2, bstride2);
 #define DEER_ATTN_ARGS Q, kp, vp, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride, scale, q_slabs, \
                        q_slab_stride, text_time, n_per_media, out_is_f32, ctl, k2, v2, kv1, ld2, bstride2, tpw
   if (q_slabs > 0) {

@@ -426,11 +426,12 @@ def test_attn_mfma(lib, dt, B, H, q_len, kv_len):
     assert float((o.float() - ref).abs().max()) < (3e-2 if dt == "bf16" else 4e-3)
 
 
-@pytest.mark.parametrize("B,H,q_len,kv1,kv2,dt", [(2, 8, 64, 256, 64, "bf16"), (1, 2, 16, 16, 16, "bf16"), (2, 2, 64, 17, 5, "bf16"), (1, 1, 5, 0, 33, "bf16"),
+@pytest.mark.parametrize("B,H,q_len,kv1,kv2,dt", [(2, 8, 64, 256, 64, "bf16"), (2, 8, 64, 256, 64, "f16"), (16, 8, 64, 256, 64, "f16"), (3, 8, 50, 256, 60, "bf16"), (1, 2, 16, 16, 16, "bf16"), (2, 2, 64, 17, 5, "bf16"), (1, 1, 5, 0, 33, "bf16"),
                                                   # long key sequences (pre fusion: 2 x 256 patch tokens + 64 latents; the 36-tile instantiation)
                                                   (2, 8, 64, 512, 64, "bf16"), (2, 8, 64, 512, 64, "f16"), (1, 2, 37, 300, 41, "f16"), (1, 1, 64, 321, 0 + 64, "bf16")])
 def test_attn_mfma_two_segments(lib, B, H, q_len, kv1, kv2, dt):
-    """Perceiver attention over [media K/V ; latent K/V] without the concat; q|k|v of the latents share one buffer."""
+    """Perceiver attention over [media K/V ; latent K/V] without the concat; q|k|v of the latents share one buffer.  64 latents over
+    256 + 64 keys (20 key tiles) runs the two-segment instantiation of attn_vit_kernel (round 6), ragged forms of it included."""
     hd = 64
     inner = H * hd
     tdt = torch.float16 if dt == "f16" else torch.bfloat16
