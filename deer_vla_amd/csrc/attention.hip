@@ -305,6 +305,15 @@ __global__ __launch_bounds__(64 * NWAVE, MINW) void attn_vit_kernel(const bf16_t
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if ((NT - 1) * 16 + g * 4 + r >= kv_len) s[NT - 1][r] = -INFINITY;
+    // SEG2 (Perceiver): the arithmetic of attn_mfma_kernel, which this instantiation replaces - scores scaled first, __expf of the
+    // difference (`scale_log2e` carries the plain scale there) - so that its results are the old kernel's bit for bit (the bf16
+    // arithmetic sits 5 % under its hard-input gate: tests/test_hard_inputs.py); the ViT form keeps its fused exp2
+    if constexpr (SEG2) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[t][r] *= scale_log2e;   // -inf stays -inf
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NT; ++t) mx = fmaxf(fmaxf(fmaxf(mx, s[t][0]), fmaxf(s[t][1], s[t][2])), s[t][3]);
@@ -316,7 +325,9 @@ __global__ __launch_bounds__(64 * NWAVE, MINW) void attn_vit_kernel(const bf16_t
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], scale_log2e, mneg));
+        float p;
+        if constexpr (SEG2) p = __expf(s[t][r] - mx);
+        else p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], scale_log2e, mneg));
         s[t][r] = p;
         sum += p;
       }
@@ -365,7 +376,7 @@ static int launch_attn_vit_nt(dim3 grid, hipStream_t st, const bf16_t* Q, const 
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, grid, dim3(64 * NWAVE), smem, st, Q, K, V, O, q_len, kv_len, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride,
-                     scale * 1.4426950408889634f, tpw, K2, V2, kv1, ld2, bstride2);
+                     SEG2 ? scale : scale * 1.4426950408889634f, tpw, K2, V2, kv1, ld2, bstride2);
   DEER_LAUNCH_CHECK();
   return DEER_OK;
 }

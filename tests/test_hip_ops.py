@@ -455,6 +455,28 @@ def test_attn_mfma_two_segments(lib, B, H, q_len, kv1, kv2, dt):
     assert float((o.float() - ref).abs().max()) < (3e-2 if dt == "bf16" else 4e-3)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_attn_two_segments_perceiver_kernel_is_bit_identical_to_the_general_kernel(lib, dt):
+    """64 queries over 256 + 64 keys run the two-segment instantiation of attn_vit_kernel (round 6); 80 queries run the general kernel
+    (attn_mfma_kernel, eight waves).  Queries are independent, so the first 64 rows of the two launches must agree bit for bit: the new
+    instantiation keeps the old arithmetic (scores scaled first, __expf of the difference)."""
+    B, H, hd, kv1, kv2 = 2, 8, 64, 256, 64
+    inner = H * hd
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    fn = lib.deer_attn_f16_hd64_2seg if dt == "f16" else lib.deer_attn_mfma_hd64_2seg
+    q = dev(rnd(B, 80, inner, seed=91), tdt)
+    lkv = dev(rnd(B, kv2, 3 * inner, seed=92), tdt)
+    mkv = dev(rnd(B, kv1, 2 * inner, seed=93), tdt)
+    outs = []
+    for q_len in (64, 80):
+        o = torch.zeros(B, 80, inner, device="cuda", dtype=tdt)
+        abi.check(fn(abi.ptr(q), abi.ptr(mkv), abi.ptr(mkv, inner * 2), abi.ptr(lkv, inner * 2), abi.ptr(lkv, 2 * inner * 2), abi.ptr(o), B, H, q_len, kv1, kv2,
+                     inner, 2 * inner, 3 * inner, inner, 80 * inner, kv1 * 2 * inner, kv2 * 3 * inner, 80 * inner, hd ** -0.5, st()), "attn 2seg")
+        torch.cuda.synchronize()
+        outs.append(o[:, :64].clone())
+    assert float(outs[0].float().abs().max()) > 0 and torch.equal(outs[0], outs[1])
+
+
 def test_xattn_small(lib):
     T, n_kv, heads, inner, ldkv = 14, 128, 8, 512, 3 * 1024
     s_in = 3
