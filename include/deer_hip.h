@@ -88,7 +88,10 @@ extern "C" {
  * robot_flamingo/models/flamingo_mpt.py:580), PerceiverAttention/FeedForward (open_flamingo/src/helpers.py:47-52,
  * 15-22) and MaskedCrossAttention.to_kv (helpers.py:190).  A, W bf16; bias f32 or NULL; C bf16 or f32 per `epi`;
  * DEER_EPI_RESADD_F32: C(f32) += tanh(*gate or 1) * (A W^T + bias).  batch: A += z*strideA, C += z*strideC.
- * tile: 0 auto, 1 64x64, 2 64x128, 3 128x128.  Needs K%8==0, N%16==0. */
+ * tile: 0 auto (the selector of csrc/gemm_tiled.hip: by M, N, K and the epilogue), 1 64x64, 2 64x128, 3 128x128; 4..79 name one kernel
+ * instantiation each for tests and microbenchmarks (LDS-ring tiles 4-46, 16-wave 32-column rings 51-62, frame tiles = one 257-row camera
+ * frame per row tile: 63-73 on 16 waves, 74 / 75 on 8, 76-79 on 4 waves (whole frames only, K % 64 == 0, no erf-GELU epilogue); a tile
+ * that does not take the shape / epilogue returns DEER_ERR_SHAPE).  Needs K%8==0, N%16==0. */
 int deer_gemm_bf16_nt(const void* A, int lda, long strideA, const void* W, int ldw, const float* bias, void* C, int ldc,
                       long strideC, int M, int N, int K, int batch, int epi, const float* gate, int tile, const int* ctl,
                       void* stream);
