@@ -211,3 +211,44 @@ def test_full_size_compaction_is_bit_identical_to_the_uncompacted_batch(setup):
         torch.cuda.synchronize()
         assert torch.equal(eng.h_state, off.h_state) and torch.equal(eng.c_state, off.c_state)
     assert len(layers) > 2, layers
+
+
+_FRAME4_PROBE = r'''
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from deer_vla_amd import synthetic as syn
+from deer_vla_amd.config import deer_3b
+from deer_vla_amd.engine import DeerEngine
+from golden_util import full_size_state
+cfg = deer_3b(max_layer=12)
+base = DeerEngine(cfg, full_size_state(cfg, 0, std="0.02", bf16_round=True), n_envs=8)
+out = []
+for B in (8, 16):          # 16 frames: one round of frame tiles per GEMM launch; 32 frames: two rounds
+    eng = base if B == 8 else DeerEngine(cfg, None, n_envs=B, weights_from=base)
+    for s in range(2):
+        pe = [syn.synthetic_step_inputs(cfg, s, rank=e % 8, text_seed=7 + e % 8) for e in range(B)]
+        rgb = torch.stack([p[0] for p in pe]).to(eng.dev, eng.img_dtype); grip = torch.stack([p[1] for p in pe]).to(eng.dev, eng.img_dtype)
+        r = eng.step(rgb, grip, torch.cat([p[2] for p in pe]).to(eng.dev), None, exit_id=3)
+        out.append(np.stack([np.concatenate([np.asarray(x["pose"], np.float32).reshape(-1), [np.float32(x["gripper"])]]) for x in r]))
+        out.append(eng.vis_x_f32.float().cpu().numpy().copy())
+np.savez(sys.argv[2], *out)
+'''
+
+
+def test_four_wave_frame_tiles_selected_by_env_knob_leave_every_engine_output_unchanged(tmp_path):
+    """DEER_GEMM_FRAME4=1 swaps the 16-wave frame tiles of the env-batch vision tower for the four-wave ones (csrc/gemm_bigm.hip:
+    gemm_frame4_kernel).  The knob is read once per process: two fresh processes run the same full-size static steps at 8 and 16
+    environments; actions and media tokens must agree bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    res = []
+    for v in ("0", "1"):
+        path = str(tmp_path / f"frame4_{v}.npz")
+        env = dict(os.environ, DEER_GEMM_FRAME4=v)
+        subprocess.run([sys.executable, "-c", _FRAME4_PROBE, root, path], check=True, env=env, timeout=600)
+        z = np.load(path)
+        res.append([z[k] for k in z.files])
+    for a, b in zip(*res):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
